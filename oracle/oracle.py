@@ -1,0 +1,198 @@
+"""ctypes loader for the CPU checkers under oracle/ -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product package (scannet_amd/) never does.  See oracle/tsdf_oracle.c for what is and is not pinned
+by the reference ("parity unpinned" for the TSDF part).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def build(verbose=False):
+    """Compile oracle/liboracle.so and (when /root/reference is present) oracle/_ref/*."""
+    out = subprocess.run(["make", "-C", _HERE, "all"], capture_output=True, text=True)
+    if out.returncode != 0:
+        raise RuntimeError("oracle build failed:\n" + out.stdout + out.stderr)
+    if verbose:
+        print(out.stdout)
+
+
+class OrParams(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32),
+        ("fx", C.c_float), ("fy", C.c_float), ("mx", C.c_float), ("my", C.c_float),
+        ("depth_shift", C.c_float), ("depth_min", C.c_float), ("depth_max", C.c_float),
+        ("voxel_size", C.c_float), ("trunc_base", C.c_float), ("trunc_scale", C.c_float),
+        ("max_integration_dist", C.c_float),
+        ("weight_sample", C.c_int32), ("weight_max", C.c_int32),
+        ("mc_thresh_factor", C.c_float),
+    ]
+
+
+def default_params(width=640, height=480, voxel=0.004):
+    """SURVEY.md section 8d camera + Server/tools/recons/zParametersScanNet.txt:34-35,47-53 values."""
+    return OrParams(width, height, 577.87, 577.87, (width - 1) / 2.0, (height - 1) / 2.0, 1000.0, 0.1, 6.0,
+                    voxel, 0.06, 0.02, 4.0, 1, 255, 10.0)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.or_create.restype = C.c_void_p
+        L.or_create.argtypes = [C.POINTER(OrParams), C.c_int]
+        L.or_destroy.argtypes = [C.c_void_p]
+        for f in (L.or_integrate, L.or_deintegrate):
+            f.restype = C.c_int64
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.or_garbage_collect.restype = C.c_int64
+        L.or_garbage_collect.argtypes = [C.c_void_p]
+        L.or_num_blocks.restype = C.c_int64
+        L.or_num_blocks.argtypes = [C.c_void_p]
+        L.or_export.restype = C.c_int64
+        L.or_export.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.or_depth_to_float.argtypes = [C.POINTER(OrParams), C.c_void_p, C.c_void_p]
+        L.or_mc_extract.restype = C.c_void_p
+        L.or_mc_extract.argtypes = [C.c_void_p]
+        L.or_mc_num_verts.restype = C.c_int64
+        L.or_mc_num_verts.argtypes = [C.c_void_p]
+        L.or_mc_num_tris.restype = C.c_int64
+        L.or_mc_num_tris.argtypes = [C.c_void_p]
+        L.or_mc_copy.argtypes = [C.c_void_p] * 5
+        L.or_mc_free.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+VOXEL_DTYPE = np.dtype([("sdf", "<f4"), ("r", "u1"), ("g", "u1"), ("b", "u1"), ("w", "u1")])
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Volume:
+    """CPU voxel-hash TSDF volume (the executable form of DESIGN.md section 3)."""
+
+    def __init__(self, params, threads=1):
+        self.params = params
+        self._h = lib().or_create(C.byref(params), int(threads))
+
+    def close(self):
+        if self._h:
+            lib().or_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def _frame(self, fn, depth, rgb, pose):
+        depth = np.ascontiguousarray(depth, dtype=np.uint16)
+        pose = np.ascontiguousarray(pose, dtype=np.float32).reshape(16)
+        if rgb is not None:
+            rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        assert depth.size == self.params.width * self.params.height
+        return int(fn(self._h, _ptr(depth), _ptr(rgb), _ptr(pose)))
+
+    def integrate(self, depth, pose, rgb=None):
+        return self._frame(lib().or_integrate, depth, rgb, pose)
+
+    def deintegrate(self, depth, pose, rgb=None):
+        return self._frame(lib().or_deintegrate, depth, rgb, pose)
+
+    def garbage_collect(self):
+        return int(lib().or_garbage_collect(self._h))
+
+    @property
+    def num_blocks(self):
+        return int(lib().or_num_blocks(self._h))
+
+    def export(self):
+        """-> (coords int32 [n,3], voxels VOXEL_DTYPE [n,512]) sorted lexicographically by (x,y,z)."""
+        n = self.num_blocks
+        coords = np.zeros((n, 3), np.int32)
+        vox = np.zeros((n, 512), VOXEL_DTYPE)
+        lib().or_export(self._h, _ptr(coords), _ptr(vox))
+        return sort_blocks(coords, vox)
+
+    def extract_mesh(self):
+        """-> dict(pos f32[nv,3], col u8[nv,3], idx i32[nt,3], keys u64[nv]) in canonical order."""
+        L = lib()
+        m = L.or_mc_extract(self._h)
+        nv, nt = int(L.or_mc_num_verts(m)), int(L.or_mc_num_tris(m))
+        pos = np.zeros((nv, 3), np.float32)
+        col = np.zeros((nv, 3), np.uint8)
+        idx = np.zeros((nt, 3), np.int32)
+        keys = np.zeros(nv, np.uint64)
+        L.or_mc_copy(m, _ptr(pos), _ptr(col), _ptr(idx), _ptr(keys))
+        L.or_mc_free(m)
+        return dict(pos=pos, col=col, idx=idx, keys=keys)
+
+
+def sort_blocks(coords, vox):
+    order = np.lexsort((coords[:, 2], coords[:, 1], coords[:, 0]))
+    return coords[order], vox[order]
+
+
+def depth_to_float(params, depth):
+    depth = np.ascontiguousarray(depth, dtype=np.uint16)
+    out = np.zeros(depth.shape, np.float32)
+    lib().or_depth_to_float(C.byref(params), _ptr(depth), _ptr(out))
+    return out
+
+
+# ---------------------------------------------------------------- compiled REFERENCE (oracle/_ref)
+class RefSensInfo(C.Structure):
+    _fields_ = [
+        ("version", C.c_uint32),
+        ("color_width", C.c_uint32), ("color_height", C.c_uint32), ("depth_width", C.c_uint32), ("depth_height", C.c_uint32),
+        ("color_compression", C.c_int32), ("depth_compression", C.c_int32),
+        ("depth_shift", C.c_float),
+        ("num_frames", C.c_uint64), ("num_imu", C.c_uint64),
+        ("color_intrinsic", C.c_float * 16), ("color_extrinsic", C.c_float * 16),
+        ("depth_intrinsic", C.c_float * 16), ("depth_extrinsic", C.c_float * 16),
+        ("sensor_name", C.c_char * 256),
+    ]
+
+
+_ref = None
+
+
+def ref_sens_available():
+    return os.path.exists(os.path.join(_HERE, "_ref", "libref_sens.so"))
+
+
+def ref_segmentator_path(o0=False):
+    p = os.path.join(_HERE, "_ref", "segmentator_ref_O0" if o0 else "segmentator_ref")
+    return p if os.path.exists(p) else None
+
+
+def ref_sens():
+    global _ref
+    if _ref is None:
+        L = C.CDLL(os.path.join(_HERE, "_ref", "libref_sens.so"))
+        L.ref_sens_open.restype = C.c_void_p
+        L.ref_sens_open.argtypes = [C.c_char_p]
+        L.ref_sens_close.argtypes = [C.c_void_p]
+        L.ref_sens_get_info.argtypes = [C.c_void_p, C.POINTER(RefSensInfo)]
+        L.ref_sens_decode_depth.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+        L.ref_sens_decode_color.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+        L.ref_sens_pose.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+        L.ref_sens_frame_meta.argtypes = [C.c_void_p, C.c_uint64] + [C.POINTER(C.c_uint64)] * 4
+        L.ref_sens_create.restype = C.c_void_p
+        L.ref_sens_create.argtypes = [C.c_uint32] * 4 + [C.c_void_p, C.c_void_p, C.c_float, C.c_char_p]
+        L.ref_sens_add_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
+        L.ref_sens_save.argtypes = [C.c_void_p, C.c_char_p]
+        _ref = L
+    return _ref

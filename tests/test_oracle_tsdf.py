@@ -1,0 +1,171 @@
+"""Pins for the CPU TSDF oracle (oracle/tsdf_oracle.c).
+
+The reference holds no TSDF code, tests or golden vectors (SURVEY.md sections 0, 4, 8c: "parity
+unpinned"), so the oracle is pinned by analytic known answers on the reference's own conventions:
+depth/depthShift (sensorData.h:968-977), K^-1 unprojection without y flip (sensorData.h:1568-1579),
+-inf poses skipped (sensorData.h:382) and the zParametersScanNet.txt:34-35,47-53 constants.
+"""
+import numpy as np
+import pytest
+
+from scannet_amd import synth
+
+
+def f32(x):
+    return np.float32(x)
+
+
+def test_depth_prepass(oracle):
+    p = oracle.default_params(8, 2)
+    d = np.array([[0, 50, 99, 100, 101, 2000, 6000, 6001], [7000, 65535, 1, 1234, 4000, 4001, 3999, 100]], np.uint16)
+    out = oracle.depth_to_float(p, d)
+    exp = d.astype(np.float32) / np.float32(1000.0)
+    bad = (d == 0) | (exp < np.float32(0.1)) | (exp > np.float32(6.0))
+    assert np.array_equal(np.isneginf(out), bad)
+    assert np.array_equal(out[~bad], exp[~bad])
+    assert out[0, 5] == np.float32(2.0)
+
+
+@pytest.fixture(scope="module")
+def plane_volume(oracle):
+    p = oracle.default_params()
+    vol = oracle.Volume(p, threads=8)
+    n = vol.integrate(synth.plane_frame(), np.eye(4, dtype=np.float32))
+    return p, vol, n
+
+
+def test_plane_known_answer(oracle, plane_volume):
+    p, vol, n = plane_volume
+    coords, vox = vol.export()
+    # SURVEY 8d worked example: ~26k blocks for the 2 m plane at 4 mm
+    assert 20000 < vol.num_blocks < 34000
+    assert n == vol.num_blocks  # everything allocated by this frame is in its frustum
+    voxel = f32(0.004)
+    t = np.float32(np.float32(0.02) * np.float32(2.0) + np.float32(0.06))
+    # z range of allocated blocks covers [2 - t, 2 + t]
+    zmin = (coords[:, 2].min() * 8) * 0.004
+    zmax = (coords[:, 2].max() * 8 + 7) * 0.004
+    assert zmin <= 2.0 - float(t) + 0.004 and zmax >= 2.0 + float(t) - 0.004
+    assert zmin > 2.0 - float(t) - 0.04 and zmax < 2.0 + float(t) + 0.04
+    # analytic voxel values: identity pose => pc = voxel centre exactly, d = 2.0 exactly
+    l = np.arange(8)
+    gz = (coords[:, 2, None] * 8 + l[None, :]).astype(np.float32) * voxel  # [n,8]
+    gy = (coords[:, 1, None] * 8 + l[None, :]).astype(np.float32) * voxel
+    gx = (coords[:, 0, None] * 8 + l[None, :]).astype(np.float32) * voxel
+    Z = np.broadcast_to(gz[:, :, None, None], (len(coords), 8, 8, 8)).reshape(len(coords), 512)
+    Y = np.broadcast_to(gy[:, None, :, None], (len(coords), 8, 8, 8)).reshape(len(coords), 512)
+    X = np.broadcast_to(gx[:, None, None, :], (len(coords), 8, 8, 8)).reshape(len(coords), 512)
+    fx, fy, mx, my = (f32(v) for v in synth.intrinsics())
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rz = f32(1.0) / Z
+        # fmaf(pc.x*fx, rz, mx): emulate the fused op in float64 (exact product of two f32 fits in f64)
+        u = ((X * fx).astype(np.float64) * rz.astype(np.float64) + np.float64(mx)).astype(np.float32) + f32(0.5)
+        v = ((Y * fy).astype(np.float64) * rz.astype(np.float64) + np.float64(my)).astype(np.float32) + f32(0.5)
+    inside = (Z > 0) & (u >= 0) & (u < 640) & (v >= 0) & (v < 480)
+    sdf = f32(2.0) - Z
+    upd = inside & (sdf > -t)
+    exp = np.where(upd, np.minimum(sdf, t), f32(0)).astype(np.float32)
+    assert np.array_equal(vox["w"], upd.astype(np.uint8))
+    assert np.array_equal(vox["sdf"], exp)
+    assert upd.sum() > 5_000_000
+
+
+def test_running_mean_and_deintegrate(oracle):
+    p = oracle.default_params()
+    vol = oracle.Volume(p, threads=8)
+    I = np.eye(4, dtype=np.float32)
+    a, b = synth.plane_frame(depth_mm=2000), synth.plane_frame(depth_mm=2010)
+    vol.integrate(a, I)
+    c1, v1 = vol.export()
+    vol.integrate(b, I)
+    c2, v2 = vol.export()
+    assert v2["w"].max() == 2
+    # blocks of frame a keep their identity; weights add up where both frames touch
+    both = (v2["w"] == 2)
+    assert both.sum() > 1_000_000
+    vol.deintegrate(b, I)
+    c3, v3 = vol.export()
+    assert np.array_equal(c2, c3)
+    # after removing b the voxels touched by a are back to a's values (weights exact, sdf <= 1e-5)
+    idx = {tuple(c): i for i, c in enumerate(c3)}
+    sel = np.array([idx[tuple(c)] for c in c1])
+    assert np.array_equal(v3["w"][sel], v1["w"])
+    assert np.abs(v3["sdf"][sel] - v1["sdf"]).max() <= 1e-5
+    # voxels only b touched are reset to zero
+    rest = np.ones(len(c3), bool)
+    rest[sel] = False
+    assert (v3["w"][rest] == 0).all() and (v3["sdf"][rest] == 0).all()
+    vol.deintegrate(a, I)
+    _, v4 = vol.export()
+    assert (v4["w"] == 0).all() and (v4["sdf"] == 0).all()
+    # everything is now empty => GC frees every block
+    assert vol.garbage_collect() == len(c3)
+    assert vol.num_blocks == 0
+
+
+def test_weight_saturates_and_invalid_pose(oracle):
+    p = oracle.default_params(160, 120)
+    p.fx = p.fy = 577.87 / 4
+    p.weight_max = 3
+    vol = oracle.Volume(p)
+    I = np.eye(4, dtype=np.float32)
+    d = synth.plane_frame(160, 120, 1500)
+    for _ in range(5):
+        vol.integrate(d, I)
+    _, v = vol.export()
+    assert v["w"].max() == 3
+    n = vol.num_blocks
+    bad = np.full((4, 4), -np.inf, np.float32)
+    assert vol.integrate(d, bad) == -1
+    assert vol.num_blocks == n
+
+
+def test_colour_average(oracle):
+    p = oracle.default_params(160, 120)
+    p.fx = p.fy = 577.87 / 4
+    vol = oracle.Volume(p)
+    I = np.eye(4, dtype=np.float32)
+    d = synth.plane_frame(160, 120, 1500)
+    c0 = np.full((120, 160, 3), (10, 200, 31), np.uint8)
+    c1 = np.full((120, 160, 3), (21, 100, 30), np.uint8)
+    vol.integrate(d, I, rgb=c0)
+    vol.integrate(d, I, rgb=c1)
+    _, v = vol.export()
+    m = v["w"] == 2
+    assert m.any()
+    assert (v["r"][m] == 16).all() and (v["g"][m] == 150).all() and (v["b"][m] == 31).all()
+
+
+def test_room_mesh_on_walls(oracle):
+    """Marching cubes on a few frames of the config-2 room: vertices lie on the room's planes."""
+    W, H = 160, 120
+    p = oracle.default_params(W, H, voxel=0.02)
+    p.fx = p.fy = 577.87 / 4
+    vol = oracle.Volume(p, threads=8)
+    for depth, pose in synth.room_stream(6, total_frames=60, width=W, height=H):
+        assert vol.integrate(depth, pose) > 0
+    m = vol.extract_mesh()
+    pos, idx = m["pos"], m["idx"]
+    assert len(pos) > 1000 and len(idx) > 1000
+    assert np.all(np.diff(m["keys"].astype(np.int64)) > 0)  # canonical order, welded
+    rx, ry, rz = synth.ROOM
+    dist = np.min(np.abs(np.stack([pos[:, 0], pos[:, 0] - rx, pos[:, 1], pos[:, 1] - ry, pos[:, 2], pos[:, 2] - rz])), 0)
+    # depth is quantised to mm and sampled at the nearest pixel: a few mm of error at grazing angles
+    assert np.percentile(dist, 99) < 0.02
+    assert idx.min() >= 0 and idx.max() < len(pos)
+    # every edge is shared by at most two triangles (manifold) and interior edges appear in opposite directions
+    e = np.concatenate([idx[:, [0, 1]], idx[:, [1, 2]], idx[:, [2, 0]]])
+    fw = set(map(tuple, e))
+    assert len(fw) == len(e)  # no directed edge twice => consistent orientation
+
+
+def test_plane_mesh_known_answer(oracle, plane_volume):
+    p, vol, _ = plane_volume
+    m = vol.extract_mesh()
+    pos, idx = m["pos"], m["idx"]
+    assert len(pos) > 100000
+    assert np.abs(pos[:, 2] - 2.0).max() < 1e-6
+    # normals point from inside (behind the surface) to outside (towards the camera): -z
+    a, b, c = pos[idx[:, 0]], pos[idx[:, 1]], pos[idx[:, 2]]
+    n = np.cross(b - a, c - a)
+    assert (n[:, 2] <= 0).all() and (n[:, 2] < 0).sum() > 0.9 * len(idx)
