@@ -1,0 +1,130 @@
+/*
+ * scanfuse.h -- C ABI of the MI355X-native RGB-D integration hot path (libscanfuse.so).
+ *
+ * This is the drop-in boundary for the `improve` and `segment` stages of the reference pipeline
+ * (Server/scan_processor.py:137-138,155-156).  Plain pointers and sizes only; no exception crosses the
+ * ABI.  Every function returns SF_OK (0) or a negative sf_status; the message of the last failure on the
+ * calling thread is available from sf_last_error().
+ *
+ * Each group below cites the reference interface it replaces (paths relative to the reference root).
+ */
+#ifndef SCANFUSE_H
+#define SCANFUSE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum sf_status {
+  SF_OK = 0,
+  SF_ERR_INVALID_ARG = -1,
+  SF_ERR_IO = -2,
+  SF_ERR_FORMAT = -3,      /* bad .sens / PLY / zlib / parameter file */
+  SF_ERR_UNSUPPORTED = -4, /* e.g. TYPE_OCCI_USHORT depth (needs uplinksimple, sensorData.h:711-722) */
+  SF_ERR_DEVICE = -5,      /* HIP error, no GPU */
+  SF_ERR_CAPACITY = -6,    /* SDF block heap or hash table exhausted */
+  SF_ERR_BOUNDS = -7,
+  SF_ERR_SKIPPED = -8      /* frame skipped: camToWorld is all -inf (tracking lost, sensorData.h:382) */
+} sf_status;
+
+const char* sf_last_error(void);
+const char* sf_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Reconstruction parameters.  Field names follow Server/tools/recons/zParametersScanNet.txt (the
+ * mLib ParameterFile the reference passes to FriedLiver.exe / DepthSensing.exe as argv[1]).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct sf_params {
+  int32_t depth_width, depth_height;   /* size of the depth frames handed to integrate()          */
+  float fx, fy, mx, my;                /* depth intrinsics (sensorData.h:305-312 layout)          */
+  float depth_shift;                   /* m_depthShift, sensorData.h:895 (1000)                   */
+  float depth_min, depth_max;          /* s_sensorDepthMin / Max            (:34-35)              */
+  float voxel_size;                    /* s_SDFVoxelSize                    (:47)                 */
+  float trunc_base, trunc_scale;       /* s_SDFTruncation / Scale           (:49-50)              */
+  float max_integration_dist;          /* s_SDFMaxIntegrationDistance       (:51)                 */
+  int32_t weight_sample;               /* s_SDFIntegrationWeightSample      (:52)                 */
+  int32_t weight_max;                  /* s_SDFIntegrationWeightMax (:53), saturated at 255       */
+  float mc_thresh_factor;              /* s_SDFMarchingCubeThreshFactor     (:48)                 */
+  uint32_t hash_num_buckets;           /* s_hashNumBuckets                  (:56)                 */
+  uint32_t hash_bucket_size;           /* HASH_BUCKET_SIZE (pound-defined upstream, :55) = 10     */
+  uint32_t num_sdf_blocks;             /* s_hashNumSDFBlocks                (:57)                 */
+  uint32_t mc_max_triangles;           /* s_marchingCubesMaxNumTriangles (:106); 0 = unlimited    */
+  int32_t gc_enabled;                  /* s_garbageCollectionEnabled        (:83)                 */
+} sf_params;
+
+/* SURVEY 8d camera + zParametersScanNet.txt values with BASELINE.json's 4 mm / 2^19-bucket overrides */
+void sf_params_default(sf_params* p);
+/* Parse an mLib ParameterFile ("name = v1 v2 ...; // comment").  Unknown keys are ignored; keys that are
+ * present override *p (call sf_params_default first).  Replaces GlobalAppState::readMembers upstream;
+ * in-tree format examples: Alignment/src/globalAppState.h:8-41. */
+int sf_params_load_file(const char* path, sf_params* p);
+
+/* ------------------------------------------------------------------------------------------------
+ * Voxel-hash TSDF fuser.  Replaces the scene-representation calls of the external DepthSensing.exe /
+ * FriedLiver.exe (call sites Server/scan_processor.py:126,138).  One fuser per HIP
+ * device + stream; a handle is not thread-safe, distinct handles are independent.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct sf_fuser sf_fuser;
+
+typedef struct sf_stats {
+  uint64_t frames_integrated, frames_skipped;
+  uint32_t blocks_allocated;     /* live SDF blocks                                              */
+  uint32_t heap_free;            /* free SDF blocks ("heapFreeCount" of processed.txt)           */
+  uint32_t last_frame_blocks;    /* N_blk of the last integrate: allocated AND in the frustum    */
+  uint32_t alloc_failures;       /* blocks that could not be allocated (heap / table exhausted)  */
+  uint64_t total_frame_blocks;   /* sum of N_blk over all frames since create / reset_counters   */
+  uint32_t hash_slots_used;
+  uint32_t high_water;           /* 1 + highest heap block index ever handed out                 */
+} sf_stats;
+
+int sf_device_count(int* count);
+int sf_fuser_create(const sf_params* p, int device, sf_fuser** out);
+void sf_fuser_destroy(sf_fuser* f);
+
+/* Host-buffer entry points: depth = W*H u16 (row-major, as decompressDepthAlloc returns it,
+ * sensorData.h:943-946), rgb = W*H*3 u8 at depth resolution or NULL, pose = row-major camToWorld
+ * (RGBDFrame::getCameraToWorld, sensorData.h:432).  Asynchronous; returns SF_ERR_SKIPPED for -inf poses. */
+int sf_fuser_integrate(sf_fuser* f, const uint16_t* depth, const uint8_t* rgb, const float pose[16]);
+int sf_fuser_deintegrate(sf_fuser* f, const uint16_t* depth, const uint8_t* rgb, const float pose[16]);
+
+/* Device-buffer entry points (inputs already resident in HBM; used by bench.py and by sf_fuse_run). */
+int sf_fuser_integrate_device(sf_fuser* f, const void* d_depth, const void* d_rgb, const float pose[16]);
+int sf_fuser_deintegrate_device(sf_fuser* f, const void* d_depth, const void* d_rgb, const float pose[16]);
+/* n frames laid out `frame_stride_bytes` apart starting at d_depth; poses = n*16 floats on the host. */
+int sf_fuser_integrate_batch_device(sf_fuser* f, const void* d_depth, uint64_t frame_stride_bytes,
+                                    const float* poses, uint64_t n);
+
+int sf_fuser_garbage_collect(sf_fuser* f, uint32_t* freed);
+int sf_fuser_sync(sf_fuser* f);
+int sf_fuser_stats(sf_fuser* f, sf_stats* out); /* synchronises */
+void* sf_fuser_stream(sf_fuser* f);            /* the hipStream_t all work of this handle is queued on */
+
+/* Kernel timing with HIP events on the fuser's stream: when enabled, every integrate launch is bracketed
+ * by an event pair; sf_fuser_profile_read sums and clears them (synchronises). */
+int sf_fuser_profile_enable(sf_fuser* f, int on);
+int sf_fuser_profile_read(sf_fuser* f, double* integrate_ms, uint64_t* launches, uint64_t* blocks);
+
+/* Copy out the live blocks (for parity checks): coords = n*3 int32 block coordinates, voxels = n*4096
+ * bytes ({float sdf; uchar r,g,b,weight} x 512, index z*64+y*8+x).  Pass NULLs to query n only. */
+int sf_fuser_export_blocks(sf_fuser* f, int32_t* coords, void* voxels, uint64_t capacity, uint64_t* n);
+
+/* Host <-> device helpers so that callers without a HIP binding can stage inputs in HBM. */
+int sf_device_malloc(int device, uint64_t bytes, void** out);
+int sf_device_free(void* p);
+int sf_device_upload(void* dst, const void* src, uint64_t bytes);
+int sf_device_download(void* dst, const void* src, uint64_t bytes);
+
+/* ------------------------------------------------------------------------------------------------
+ * Synthetic stream source (benchmark input): renders frames
+ * [first_frame, first_frame+n) of the `total_frames`-frame box-room walk as u16 millimetre depth directly
+ * into device memory and returns the n camToWorld poses (n*16 floats, host).
+ * ---------------------------------------------------------------------------------------------- */
+int sf_synth_room_device(void* d_depth, uint64_t frame_stride_bytes, uint64_t first_frame, uint64_t n, uint64_t total_frames,
+                         int width, int height, int noise, float* poses_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCANFUSE_H */

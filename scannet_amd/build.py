@@ -1,0 +1,78 @@
+"""Builds libscanfuse.so in-tree with hipcc for gfx950 (no JIT cache: the .so travels with the snapshot)."""
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(HERE, "libscanfuse.so")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# -ffp-contract=off: the TSDF / Segmentator arithmetic is specified operation by operation;
+# only explicit fmaf() may fuse.  HIP's default correctly-rounded fp32 divide / sqrt is relied upon.
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden", "-Wall", "-Wno-unused-result",
+          "-I" + os.path.join(ROOT, "include")]
+
+
+def sources():
+    src = sorted(glob.glob(os.path.join(HERE, "csrc", "*.hip")) + glob.glob(os.path.join(HERE, "csrc", "*.cpp")))
+    return [s for s in src if not os.path.basename(s).startswith("tool_")]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    src = sources()
+    hdr = glob.glob(os.path.join(HERE, "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+    objdir = os.path.join(HERE, "_build")
+    os.makedirs(objdir, exist_ok=True)
+    objs = []
+    procs = []
+    for s in src:
+        o = os.path.join(objdir, os.path.basename(s) + ".o")
+        objs.append(o)
+        if force or _stale(o, [s] + hdr):
+            cmd = [HIPCC, "--offload-arch=gfx950", "-c", s, "-o", o] + COMMON
+            if s.endswith(".cpp"):
+                cmd = [HIPCC, "-x", "hip", "--offload-arch=gfx950", "-c", s, "-o", o] + COMMON
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (s, out))
+        if verbose and out.strip():
+            print(out)
+    if force or procs or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs + ["-lpthread"]
+        out = subprocess.run(cmd, capture_output=True, text=True)
+        if out.returncode != 0:
+            raise RuntimeError("link failed:\n" + out.stdout + out.stderr)
+    build_tools(force, verbose)
+    return LIB
+
+
+def build_tools(force=False, verbose=False):
+    """Drop-in command-line tools (tool_*.cpp): plain C++ hosts linked against libscanfuse.so."""
+    bindir = os.path.join(ROOT, "bin")
+    for s in sorted(glob.glob(os.path.join(HERE, "csrc", "tool_*.cpp"))):
+        name = os.path.basename(s)[len("tool_"):-len(".cpp")]
+        exe = os.path.join(bindir, name)
+        if force or _stale(exe, [s, LIB]):
+            os.makedirs(bindir, exist_ok=True)
+            cmd = ["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), s, "-o", exe, "-L" + HERE, "-lscanfuse",
+                   "-Wl,-rpath," + HERE, "-Wl,-rpath,/opt/rocm/lib", "-lpthread"]
+            out = subprocess.run(cmd, capture_output=True, text=True)
+            if out.returncode != 0:
+                raise RuntimeError("tool build failed (%s):\n%s" % (name, out.stdout + out.stderr))
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

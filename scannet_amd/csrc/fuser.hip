@@ -1,0 +1,837 @@
+// fuser.hip -- voxel-hash TSDF fusion for gfx950 (MI355X): depth pre-pass, sparse block allocation,
+// frustum compaction, integrate / deintegrate, garbage collection, block export.
+//
+// Replaces the scene-representation part of the external DepthSensing.exe / FriedLiver.exe that the
+// reference pipeline shells out to (Server/scan_processor.py:126,138); the arithmetic is the specification
+// in DESIGN.md section 3, reproduced operation for operation so that the voxels are
+// bit-identical to the CPU checker's.  Built with -ffp-contract=off: every fmaf() below is a deliberate
+// fused multiply-add of the spec, nothing else is contracted.
+//
+// Data layout in HBM:
+//   table      HashEntry[num_buckets * bucket_size]   16 B: {u64 key (3 x 21-bit block coords), i32 heap block, pad}
+//   block_keys u64[num_sdf_blocks]                    directory: key of the block living in heap slot i, or EMPTY
+//   heap       i32[num_sdf_blocks] + free counter     free list of heap slots (wave-aggregated pops)
+//   voxels     8 B x 512 x num_sdf_blocks             {f32 sdf; u8 r,g,b,weight}, one 4 KiB tile per block, index z*64+y*8+x
+//   depthf     f32[W*H], color u32[W*H]               per-frame pre-pass outputs (L2 resident)
+//   compact    i32[num_sdf_blocks]                    heap slots of the blocks in the current frustum
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+constexpr uint64_t KEY_EMPTY = ~0ull;
+constexpr uint64_t KEY_TOMB = ~0ull - 1ull;
+constexpr int MAX_DDA_ITERS = 1024;
+constexpr int MAX_PROBES = 4096;
+
+struct HashEntry {
+  uint64_t key;
+  int32_t ptr;
+  uint32_t pad;
+};
+static_assert(sizeof(HashEntry) == 16, "hash entry is 16 bytes");
+
+struct ParamsK {
+  int W, H;
+  float fx, fy, mx, my;
+  float depth_shift, dmin, dmax;
+  float voxel, tbase, tscale, maxd;
+  int wsample, wmax;
+  uint32_t num_buckets, bucket_size, total_slots, num_blocks;
+};
+
+struct FrameK {
+  float T[12];
+  float Ti[12];
+  float xa[2], xc[2], xr[2];
+  float ya[2], yc[2], yr[2];
+  float radius, zfar;
+};
+
+enum Counter {
+  C_HEAP_FREE = 0,
+  C_COMPACT = 1,
+  C_HIGH_WATER = 2,
+  C_ALLOC_FAIL = 3,
+  C_SLOTS_USED = 4,
+  C_LAST_BLOCKS = 5,
+  C_EXPORT = 6,
+  C_GC_FREED = 7,
+  C_TOTAL_LO = 8,  // 64-bit sum of N_blk lives in counters[8..9]
+  C_COUNT = 16
+};
+
+__host__ __device__ inline uint64_t pack_key(int x, int y, int z) {
+  return (((uint64_t)x & 0x1FFFFFull) << 42) | (((uint64_t)y & 0x1FFFFFull) << 21) | ((uint64_t)z & 0x1FFFFFull);
+}
+__host__ __device__ inline void unpack_key(uint64_t k, int& x, int& y, int& z) {
+  x = ((int)((k >> 42) & 0x1FFFFF) << 11) >> 11;
+  y = ((int)((k >> 21) & 0x1FFFFF) << 11) >> 11;
+  z = ((int)(k & 0x1FFFFF) << 11) >> 11;
+}
+
+__device__ inline uint32_t hash_bucket(int x, int y, int z, uint32_t num_buckets) {
+  const uint32_t h = ((uint32_t)x * 73856093u) ^ ((uint32_t)y * 19349669u) ^ ((uint32_t)z * 83492791u);
+  return h % num_buckets;
+}
+
+// bounding sphere of the block against the four side planes and the z range of the frustum
+__device__ inline bool block_in_frustum(const ParamsK& P, const FrameK& F, int bx, int by, int bz) {
+  const float cx = ((float)(8 * bx) + 3.5f) * P.voxel;
+  const float cy = ((float)(8 * by) + 3.5f) * P.voxel;
+  const float cz = ((float)(8 * bz) + 3.5f) * P.voxel;
+  const float px = fmaf(F.Ti[0], cx, fmaf(F.Ti[1], cy, fmaf(F.Ti[2], cz, F.Ti[3])));
+  const float py = fmaf(F.Ti[4], cx, fmaf(F.Ti[5], cy, fmaf(F.Ti[6], cz, F.Ti[7])));
+  const float pz = fmaf(F.Ti[8], cx, fmaf(F.Ti[9], cy, fmaf(F.Ti[10], cz, F.Ti[11])));
+  bool in = pz > -F.radius;
+  in = in && (pz < F.zfar + F.radius);
+  in = in && (fmaf(F.xa[0], px, F.xc[0] * pz) >= -F.xr[0]);
+  in = in && (fmaf(F.xa[1], px, F.xc[1] * pz) >= -F.xr[1]);
+  in = in && (fmaf(F.ya[0], py, F.yc[0] * pz) >= -F.yr[0]);
+  in = in && (fmaf(F.ya[1], py, F.yc[1] * pz) >= -F.yr[1]);
+  return in;
+}
+
+__device__ inline int world_to_block(float w, float voxel) {
+  const float q = w / voxel;
+  const int vi = (int)(q >= 0.0f ? q + 0.5f : q - 0.5f);
+  return vi >> 3;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K1: depth pre-pass.  u16 -> metres (sensorData.h:968-977: d = depth / depthShift, 0 invalid), range
+// gate (zParametersScanNet.txt:34-35) -> -inf; optional rgb -> packed u32.  8 pixels per lane.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_prepass(const uint16_t* __restrict__ depth, const uint8_t* __restrict__ rgb,
+                                                 float* __restrict__ depthf, uint32_t* __restrict__ color, int n,
+                                                 float shift, float dmin, float dmax, int32_t* counters) {
+  const int i0 = (blockIdx.x * 256 + threadIdx.x) * 8;
+  if (blockIdx.x == 0 && threadIdx.x == 0) counters[C_COMPACT] = 0;
+  if (i0 >= n) return;
+  uint16_t u[8];
+  if (i0 + 8 <= n) {
+    const uint4 raw = *reinterpret_cast<const uint4*>(depth + i0);
+    u[0] = raw.x & 0xFFFF; u[1] = raw.x >> 16; u[2] = raw.y & 0xFFFF; u[3] = raw.y >> 16;
+    u[4] = raw.z & 0xFFFF; u[5] = raw.z >> 16; u[6] = raw.w & 0xFFFF; u[7] = raw.w >> 16;
+  } else {
+    for (int k = 0; k < 8; k++) u[k] = (i0 + k < n) ? depth[i0 + k] : (uint16_t)0;
+  }
+  float d[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    float v = (float)u[k] / shift;
+    if (u[k] == 0 || v < dmin || v > dmax) v = -INFINITY;
+    d[k] = v;
+  }
+  if (i0 + 8 <= n) {
+    *reinterpret_cast<float4*>(depthf + i0) = make_float4(d[0], d[1], d[2], d[3]);
+    *reinterpret_cast<float4*>(depthf + i0 + 4) = make_float4(d[4], d[5], d[6], d[7]);
+  } else {
+    for (int k = 0; k < 8 && i0 + k < n; k++) depthf[i0 + k] = d[k];
+  }
+  if (rgb) {
+    for (int k = 0; k < 8 && i0 + k < n; k++) {
+      const uint8_t* c = rgb + 3 * (size_t)(i0 + k);
+      color[i0 + k] = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K2: allocation.  One lane per depth pixel, one wave per 8x8 pixel tile (neighbouring rays hit the same
+// blocks).  Every lane walks its own 3-D DDA over the blocks of [d - t, d + t]; at every step the wave
+// removes duplicate candidates with ballots, the surviving owner lanes probe the hash in parallel
+// (lock-free CAS claim of an EMPTY slot), and newly claimed slots get heap blocks through one
+// wave-aggregated pop (ballot + mbcnt prefix).  The allocated SET is deterministic; which heap slot a
+// block lands in is not (neither is it upstream).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf, HashEntry* table, int32_t* heap,
+                                               uint64_t* block_keys, int32_t* counters, ParamsK P, FrameK F) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+  const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+
+  bool active = false;
+  int cx = 0, cy = 0, cz = 0, sx = 0, sy = 0, sz = 0, ex = 0, ey = 0, ez = 0;
+  float tmx = INFINITY, tmy = INFINITY, tmz = INFINITY, tdx = INFINITY, tdy = INFINITY, tdz = INFINITY;
+  if (x < P.W && y < P.H) {
+    const float d = depthf[y * P.W + x];
+    if (d != -INFINITY && d < P.maxd) {
+      const float t = fmaf(P.tscale, d, P.tbase);
+      const float lo = fminf(P.maxd, d - t);
+      const float hi = fminf(P.maxd, d + t);
+      if (lo < hi) {
+        active = true;
+        const float kx = ((float)x - P.mx) / P.fx;
+        const float ky = ((float)y - P.my) / P.fy;
+        float p0[3], p1[3];
+        {
+          const float ax = kx * lo, ay = ky * lo, az = lo;
+#pragma unroll
+          for (int r = 0; r < 3; r++) p0[r] = fmaf(F.T[4 * r], ax, fmaf(F.T[4 * r + 1], ay, fmaf(F.T[4 * r + 2], az, F.T[4 * r + 3])));
+        }
+        {
+          const float ax = kx * hi, ay = ky * hi, az = hi;
+#pragma unroll
+          for (int r = 0; r < 3; r++) p1[r] = fmaf(F.T[4 * r], ax, fmaf(F.T[4 * r + 1], ay, fmaf(F.T[4 * r + 2], az, F.T[4 * r + 3])));
+        }
+        const float bsize = 8.0f * P.voxel;
+        int cur[3], stp[3], bnd[3];
+        float tm[3], td[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          const float dir = p1[c] - p0[c];
+          cur[c] = world_to_block(p0[c], P.voxel);
+          const int e = world_to_block(p1[c], P.voxel);
+          stp[c] = dir > 0.0f ? 1 : (dir < 0.0f ? -1 : 0);
+          bnd[c] = e + stp[c];
+          if (stp[c] == 0) { tm[c] = INFINITY; td[c] = INFINITY; }
+          else {
+            const int nb = cur[c] + (stp[c] > 0 ? 1 : 0);
+            const float plane = ((float)(8 * nb) - 0.5f) * P.voxel;
+            tm[c] = (plane - p0[c]) / dir;
+            td[c] = ((float)stp[c] * bsize) / dir;
+          }
+        }
+        cx = cur[0]; cy = cur[1]; cz = cur[2]; sx = stp[0]; sy = stp[1]; sz = stp[2];
+        ex = bnd[0]; ey = bnd[1]; ez = bnd[2];
+        tmx = tm[0]; tmy = tm[1]; tmz = tm[2]; tdx = td[0]; tdy = td[1]; tdz = td[2];
+      }
+    }
+  }
+
+  uint64_t last_key = KEY_EMPTY;
+  int iters = 0;
+  int hw_local = 0;
+  while (__ballot(active) != 0ull) {
+    uint64_t key = KEY_EMPTY;
+    bool want = false;
+    if (active && block_in_frustum(P, F, cx, cy, cz)) {
+      key = pack_key(cx, cy, cz);
+      want = key != last_key;
+      last_key = key;
+    }
+    // wave-level duplicate removal: the lowest lane holding a key becomes its owner
+    bool owner = false;
+    uint64_t todo = __ballot(want);
+    while (todo != 0ull) {
+      const int leader = __ffsll((unsigned long long)todo) - 1;
+      const uint64_t k = __shfl(key, leader);
+      const uint64_t same = __ballot(want && key == k);
+      if (lane == leader) owner = true;
+      todo &= ~same;
+    }
+    // owners probe in parallel
+    HashEntry* claimed = nullptr;
+    if (owner) {
+      uint32_t slot = hash_bucket(cx, cy, cz, P.num_buckets) * P.bucket_size;
+      int probe = 0;
+      for (; probe < MAX_PROBES; ++probe) {
+        HashEntry* e = table + slot;
+        const uint64_t k = __hip_atomic_load(&e->key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (k == key) break;
+        if (k == KEY_EMPTY) {
+          const uint64_t old = atomicCAS((unsigned long long*)&e->key, (unsigned long long)KEY_EMPTY, (unsigned long long)key);
+          if (old == KEY_EMPTY) { claimed = e; break; }
+          if (old == key) break;
+        }
+        slot++;
+        if (slot == P.total_slots) slot = 0;
+      }
+      if (probe == MAX_PROBES) atomicAdd(&counters[C_ALLOC_FAIL], 1);
+    }
+    // wave-aggregated heap pop for the freshly claimed slots
+    const uint64_t cm = __ballot(claimed != nullptr);
+    if (cm != 0ull) {
+      const int n = __popcll((unsigned long long)cm);
+      const int first = __ffsll((unsigned long long)cm) - 1;
+      int base = 0;
+      if (lane == first) {
+        base = atomicSub(&counters[C_HEAP_FREE], n);
+        atomicAdd(&counters[C_SLOTS_USED], n);
+      }
+      base = __shfl(base, first);
+      if (claimed != nullptr) {
+        const int rank = __popcll((unsigned long long)(cm & ((1ull << lane) - 1ull)));
+        const int at = base - 1 - rank;
+        if (at >= 0) {
+          const int idx = heap[at];
+          claimed->ptr = idx;
+          block_keys[idx] = key;
+          hw_local = max(hw_local, idx + 1);
+        } else {
+          // heap exhausted: the entry stays claimed without a block; give the slot count back
+          atomicAdd(&counters[C_HEAP_FREE], 1);
+          atomicAdd(&counters[C_ALLOC_FAIL], 1);
+        }
+      }
+    }
+    // advance the DDA
+    if (active) {
+      bool done;
+      if (tmx < tmy && tmx < tmz) { cx += sx; done = (cx == ex); tmx += tdx; }
+      else if (tmz < tmy) { cz += sz; done = (cz == ez); tmz += tdz; }
+      else { cy += sy; done = (cy == ey); tmy += tdy; }
+      ++iters;
+      if (done || iters >= MAX_DDA_ITERS) active = false;
+    }
+  }
+  if (hw_local > 0) atomicMax(&counters[C_HIGH_WATER], hw_local);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K3: compactify.  Scans the block directory (8 B per heap slot up to the high-water mark -- not the
+// 16 B x buckets x 10 hash table upstream scans) and appends the slots whose block is in the frustum,
+// one atomic per wave.  all_live != 0 skips the frustum test (used by export / GC).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_compactify(const uint64_t* __restrict__ block_keys, int32_t* __restrict__ compact,
+                                                    int32_t* counters, int counter_id, int all_live, ParamsK P, FrameK F) {
+  const int hw = counters[C_HIGH_WATER];
+  const int lane = threadIdx.x & 63;
+  for (int base = blockIdx.x * 256; base < hw; base += gridDim.x * 256) {
+    const int i = base + threadIdx.x;
+    bool in = false;
+    if (i < hw) {
+      const uint64_t k = block_keys[i];
+      if (k != KEY_EMPTY) {
+        if (all_live) in = true;
+        else {
+          int bx, by, bz;
+          unpack_key(k, bx, by, bz);
+          in = block_in_frustum(P, F, bx, by, bz);
+        }
+      }
+    }
+    const uint64_t m = __ballot(in);
+    if (m != 0ull) {
+      const int first = __ffsll((unsigned long long)m) - 1;
+      int off = 0;
+      if (lane == first) off = atomicAdd(&counters[counter_id], __popcll((unsigned long long)m));
+      off = __shfl(off, first);
+      if (in) compact[off + __popcll((unsigned long long)(m & ((1ull << lane) - 1ull)))] = i;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K4: integrate / deintegrate.  One wave per 8^3 block: the 4 KiB tile is read with four fully
+// coalesced 16 B-per-lane loads (1 KiB per instruction, two x-adjacent voxels per load), updated in
+// registers and written back with the same pattern.  There is no reuse inside a tile, so it is not
+// staged through LDS; the depth image (1.2 MB f32) is gathered through L1/L2.
+// lane l, load j: uint4 q = 64 j + l -> voxels 2q, 2q+1 -> x = (2l)&7 (+1), y = (l>>2)&7, z = 2j + (l>>5).
+// ---------------------------------------------------------------------------------------------------
+template <int SIGN, bool COLOR>
+__device__ inline bool fuse_voxel(const ParamsK& P, const float* __restrict__ depthf, const uint32_t* __restrict__ color,
+                                  float pcx, float pcy, float pcz, uint32_t& sdf_bits, uint32_t& cw) {
+  if (!(pcz > 0.0f)) return false;
+  const float rz = 1.0f / pcz;
+  const float uf = fmaf(pcx * P.fx, rz, P.mx) + 0.5f;
+  const float vf = fmaf(pcy * P.fy, rz, P.my) + 0.5f;
+  if (!(uf >= 0.0f && uf < (float)P.W && vf >= 0.0f && vf < (float)P.H)) return false;
+  const int pix = (int)vf * P.W + (int)uf;
+  const float d = depthf[pix];
+  if (d == -INFINITY) return false;
+  if (!(d < P.maxd)) return false;
+  float sdf = d - pcz;
+  const float t = fmaf(P.tscale, d, P.tbase);
+  if (sdf <= -t) return false;
+  if (sdf > t) sdf = t;
+  const uint32_t w = cw >> 24;
+  const float wo = (float)w;
+  const float wn = (float)P.wsample;
+  const float old = __uint_as_float(sdf_bits);
+  if (SIGN > 0) {
+    sdf_bits = __float_as_uint(fmaf(old, wo, sdf * wn) / (wo + wn));
+    uint32_t rgb = cw & 0xFFFFFFu;
+    if (COLOR) {
+      const uint32_t c = color[pix];
+      if (w == 0) rgb = c;
+      else {
+        const uint32_t r = ((rgb & 0xFF) + (c & 0xFF) + 1) >> 1;
+        const uint32_t g = (((rgb >> 8) & 0xFF) + ((c >> 8) & 0xFF) + 1) >> 1;
+        const uint32_t b = (((rgb >> 16) & 0xFF) + ((c >> 16) & 0xFF) + 1) >> 1;
+        rgb = r | (g << 8) | (b << 16);
+      }
+    }
+    uint32_t nw = w + (uint32_t)P.wsample;
+    if (nw > (uint32_t)P.wmax) nw = (uint32_t)P.wmax;
+    cw = rgb | (nw << 24);
+  } else {
+    const int nw = (int)w - P.wsample;
+    if (nw <= 0) { sdf_bits = 0u; cw = 0u; }
+    else {
+      sdf_bits = __float_as_uint(fmaf(old, wo, -(sdf * wn)) / (wo - wn));
+      cw = (cw & 0xFFFFFFu) | ((uint32_t)nw << 24);
+    }
+  }
+  return true;
+}
+
+template <int SIGN, bool COLOR>
+__global__ __launch_bounds__(256) void k_integrate(uint4* __restrict__ voxels, const uint64_t* __restrict__ block_keys,
+                                                   const int32_t* __restrict__ compact, const float* __restrict__ depthf,
+                                                   const uint32_t* __restrict__ color, int32_t* counters,
+                                                   int32_t* host_mirror, ParamsK P, FrameK F) {
+  const int n = counters[C_COMPACT];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    counters[C_LAST_BLOCKS] = n;
+    atomicAdd(reinterpret_cast<unsigned long long*>(&counters[C_TOTAL_LO]), (unsigned long long)n);
+    if (host_mirror) *host_mirror = n;
+  }
+  const int lx = (2 * lane) & 7;
+  const int ly = (lane >> 2) & 7;
+  const int lzb = lane >> 5;
+  for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {
+    const int slot = compact[i];
+    int bx, by, bz;
+    unpack_key(block_keys[slot], bx, by, bz);
+    uint4* vb = voxels + (size_t)slot * 256;
+    uint4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = vb[j * 64 + lane];
+    const float wx0 = (float)(8 * bx + lx) * P.voxel;
+    const float wx1 = (float)(8 * bx + lx + 1) * P.voxel;
+    const float wy = (float)(8 * by + ly) * P.voxel;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float wz = (float)(8 * bz + 2 * j + lzb) * P.voxel;
+      const float ax = fmaf(F.Ti[1], wy, fmaf(F.Ti[2], wz, F.Ti[3]));
+      const float ay = fmaf(F.Ti[5], wy, fmaf(F.Ti[6], wz, F.Ti[7]));
+      const float az = fmaf(F.Ti[9], wy, fmaf(F.Ti[10], wz, F.Ti[11]));
+      const bool u0 = fuse_voxel<SIGN, COLOR>(P, depthf, color, fmaf(F.Ti[0], wx0, ax), fmaf(F.Ti[4], wx0, ay), fmaf(F.Ti[8], wx0, az), v[j].x, v[j].y);
+      const bool u1 = fuse_voxel<SIGN, COLOR>(P, depthf, color, fmaf(F.Ti[0], wx1, ax), fmaf(F.Ti[4], wx1, ay), fmaf(F.Ti[8], wx1, az), v[j].z, v[j].w);
+      if (u0 || u1) vb[j * 64 + lane] = v[j];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Garbage collection: one 256-thread workgroup per live block; min |sdf| over observed
+// voxels and max weight reduced through wave shuffles + LDS; freed blocks are zeroed, unlinked
+// (tombstone) and pushed back on the heap.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gc(uint4* voxels, uint64_t* block_keys, const int32_t* __restrict__ live,
+                                            HashEntry* table, int32_t* heap, int32_t* counters, float thr, ParamsK P) {
+  __shared__ float s_min[4];
+  __shared__ uint32_t s_max[4];
+  const int n = counters[C_EXPORT];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    const int slot = live[i];
+    uint4* vb = voxels + (size_t)slot * 256;
+    const uint4 v = vb[threadIdx.x];
+    float mn = INFINITY;
+    uint32_t mw = 0;
+    const uint32_t w0 = v.y >> 24, w1 = v.w >> 24;
+    if (w0 > 0) mn = fminf(mn, fabsf(__uint_as_float(v.x)));
+    if (w1 > 0) mn = fminf(mn, fabsf(__uint_as_float(v.z)));
+    mw = max(w0, w1);
+    for (int o = 32; o > 0; o >>= 1) {
+      mn = fminf(mn, __shfl_xor(mn, o));
+      mw = max(mw, (uint32_t)__shfl_xor((int)mw, o));
+    }
+    if (lane == 0) { s_min[wave] = mn; s_max[wave] = mw; }
+    __syncthreads();
+    mn = fminf(fminf(s_min[0], s_min[1]), fminf(s_min[2], s_min[3]));
+    mw = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+    __syncthreads();
+    if (mw == 0 || mn >= thr) {
+      vb[threadIdx.x] = make_uint4(0, 0, 0, 0);
+      if (threadIdx.x == 0) {
+        const uint64_t key = block_keys[slot];
+        int bx, by, bz;
+        unpack_key(key, bx, by, bz);
+        uint32_t s = hash_bucket(bx, by, bz, P.num_buckets) * P.bucket_size;
+        for (int probe = 0; probe < MAX_PROBES; ++probe) {
+          if (table[s].key == key) { table[s].key = KEY_TOMB; table[s].ptr = -1; break; }
+          if (table[s].key == KEY_EMPTY) break;
+          s++;
+          if (s == P.total_slots) s = 0;
+        }
+        block_keys[slot] = KEY_EMPTY;
+        const int at = atomicAdd(&counters[C_HEAP_FREE], 1);
+        heap[at] = slot;
+        atomicAdd(&counters[C_GC_FREED], 1);
+      }
+    }
+  }
+}
+
+__global__ void k_init_heap(int32_t* heap, uint64_t* block_keys, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { heap[i] = n - 1 - i; block_keys[i] = KEY_EMPTY; }
+}
+
+__global__ __launch_bounds__(256) void k_gather(const uint4* __restrict__ voxels, const uint64_t* __restrict__ block_keys,
+                                                const int32_t* __restrict__ live, int n, int32_t* coords, uint4* out) {
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    const int slot = live[i];
+    out[(size_t)i * 256 + threadIdx.x] = voxels[(size_t)slot * 256 + threadIdx.x];
+    if (threadIdx.x == 0) {
+      int bx, by, bz;
+      unpack_key(block_keys[slot], bx, by, bz);
+      coords[3 * i] = bx; coords[3 * i + 1] = by; coords[3 * i + 2] = bz;
+    }
+  }
+}
+
+}  // namespace
+
+// ======================================================================================================
+// host side
+// ======================================================================================================
+struct sf_fuser {
+  sf_params p;
+  ParamsK pk;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  HashEntry* table = nullptr;
+  int32_t* heap = nullptr;
+  uint64_t* block_keys = nullptr;
+  uint4* voxels = nullptr;
+  float* depthf = nullptr;
+  uint32_t* color = nullptr;
+  int32_t* compact = nullptr;
+  int32_t* counters = nullptr;
+  void* staging_depth = nullptr;  // device copies of host-supplied frames
+  void* staging_rgb = nullptr;
+  int32_t* host_mirror = nullptr;  // pinned, device-visible: N_blk of the most recent integrate
+  int num_cus = 256;
+  uint64_t frames_integrated = 0, frames_skipped = 0;
+  bool profile = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  size_t events_used = 0;
+};
+
+namespace {
+
+// per-frame constants in double, rounded once to float.
+bool frame_setup(const sf_params& p, const float* pose, FrameK& f) {
+  if (pose[0] == -INFINITY) return false;
+  for (int i = 0; i < 12; i++) f.T[i] = pose[i];
+  const double a00 = pose[0], a01 = pose[1], a02 = pose[2], t0 = pose[3];
+  const double a10 = pose[4], a11 = pose[5], a12 = pose[6], t1 = pose[7];
+  const double a20 = pose[8], a21 = pose[9], a22 = pose[10], t2 = pose[11];
+  const double c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
+  const double det = a00 * c00 + a01 * c01 + a02 * c02;
+  const double inv[9] = {c00 / det, (a02 * a21 - a01 * a22) / det, (a01 * a12 - a02 * a11) / det,
+                         c01 / det, (a00 * a22 - a02 * a20) / det, (a02 * a10 - a00 * a12) / det,
+                         c02 / det, (a01 * a20 - a00 * a21) / det, (a00 * a11 - a01 * a10) / det};
+  for (int r = 0; r < 3; r++) {
+    const double ti = -(inv[3 * r] * t0 + inv[3 * r + 1] * t1 + inv[3 * r + 2] * t2);
+    f.Ti[4 * r] = (float)inv[3 * r];
+    f.Ti[4 * r + 1] = (float)inv[3 * r + 1];
+    f.Ti[4 * r + 2] = (float)inv[3 * r + 2];
+    f.Ti[4 * r + 3] = (float)ti;
+  }
+  const double rad = 4.0 * std::sqrt(3.0) * (double)p.voxel_size;
+  f.radius = (float)rad;
+  const double fx = p.fx, fy = p.fy, mx = p.mx, my = p.my;
+  const double xl = mx + 0.5, xh = ((double)p.depth_width - 0.5) - mx;
+  const double yl = my + 0.5, yh = ((double)p.depth_height - 0.5) - my;
+  f.xa[0] = (float)fx;  f.xc[0] = (float)xl; f.xr[0] = (float)(rad * std::sqrt(fx * fx + xl * xl));
+  f.xa[1] = (float)-fx; f.xc[1] = (float)xh; f.xr[1] = (float)(rad * std::sqrt(fx * fx + xh * xh));
+  f.ya[0] = (float)fy;  f.yc[0] = (float)yl; f.yr[0] = (float)(rad * std::sqrt(fy * fy + yl * yl));
+  f.ya[1] = (float)-fy; f.yc[1] = (float)yh; f.yr[1] = (float)(rad * std::sqrt(fy * fy + yh * yh));
+  f.zfar = p.max_integration_dist + std::fmaf(p.trunc_scale, p.max_integration_dist, p.trunc_base);
+  return true;
+}
+
+int run_frame(sf_fuser* f, const void* d_depth, const void* d_rgb, const float* pose, int sign) {
+  FrameK fk;
+  if (!frame_setup(f->p, pose, fk)) {
+    f->frames_skipped++;
+    return sf::fail(SF_ERR_SKIPPED, "frame skipped: camToWorld is -inf (tracking lost)");
+  }
+  const int n = f->p.depth_width * f->p.depth_height;
+  hipStream_t s = f->stream;
+  hipLaunchKernelGGL(k_prepass, dim3((n / 8 + 255) / 256 + 1), dim3(256), 0, s, (const uint16_t*)d_depth, (const uint8_t*)d_rgb,
+                     f->depthf, f->color, n, f->p.depth_shift, f->p.depth_min, f->p.depth_max, f->counters);
+  if (sign > 0) {
+    hipLaunchKernelGGL(k_alloc, dim3((f->p.depth_width + 15) / 16, (f->p.depth_height + 15) / 16), dim3(256), 0, s, f->depthf,
+                       f->table, f->heap, f->block_keys, f->counters, f->pk, fk);
+  }
+  hipLaunchKernelGGL(k_compactify, dim3(f->num_cus * 2), dim3(256), 0, s, f->block_keys, f->compact, f->counters, (int)C_COMPACT, 0,
+                     f->pk, fk);
+  // grid: enough workgroups (4 blocks each) for the last N_blk the device reported, +25 %; the kernel's
+  // grid-stride loop covers any excess, surplus workgroups exit at once.
+  const int last = *f->host_mirror;
+  int est = last + last / 4 + 4096;
+  int grid = (est + 3) / 4;
+  const int grid_max = f->num_cus * 64;
+  if (grid > grid_max) grid = grid_max;
+  const bool col = d_rgb != nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (f->profile) {
+    if (f->events_used == f->events.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return sf::fail(SF_ERR_DEVICE, "hipEventCreate failed");
+      f->events.emplace_back(a, b);
+    }
+    e0 = f->events[f->events_used].first;
+    e1 = f->events[f->events_used].second;
+    f->events_used++;
+    (void)hipEventRecord(e0, s);
+  }
+#define LAUNCH_INT(SG, CL)                                                                                               \
+  hipLaunchKernelGGL((k_integrate<SG, CL>), dim3(grid), dim3(256), 0, s, f->voxels, f->block_keys, f->compact, f->depthf, \
+                     f->color, f->counters, f->host_mirror, f->pk, fk)
+  if (sign > 0) { if (col) LAUNCH_INT(1, true); else LAUNCH_INT(1, false); }
+  else          { if (col) LAUNCH_INT(-1, true); else LAUNCH_INT(-1, false); }
+#undef LAUNCH_INT
+  if (f->profile) (void)hipEventRecord(e1, s);
+  const hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return sf::fail(SF_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(err));
+  f->frames_integrated++;
+  return SF_OK;
+}
+
+}  // namespace
+
+SF_API int sf_device_count(int* count) {
+  if (!count) return sf::fail(SF_ERR_INVALID_ARG, "count is NULL");
+  int n = 0;
+  const hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { *count = 0; return sf::fail(SF_ERR_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+  *count = n;
+  return SF_OK;
+}
+
+SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
+  if (!p || !out) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  if (p->depth_width <= 0 || p->depth_height <= 0 || !(p->voxel_size > 0) || p->hash_num_buckets == 0 || p->hash_bucket_size == 0 ||
+      p->num_sdf_blocks == 0 || !(p->fx > 0) || !(p->fy > 0) || !(p->depth_shift > 0))
+    return sf::fail(SF_ERR_INVALID_ARG, "invalid reconstruction parameters");
+  if ((uint64_t)p->hash_num_buckets * p->hash_bucket_size > 0x7FFFFFFFull || p->num_sdf_blocks > 0x3FFFFFFFu)
+    return sf::fail(SF_ERR_INVALID_ARG, "hash table / heap too large for 32-bit slot indices");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return sf::fail(SF_ERR_DEVICE, "no HIP device: libscanfuse has no CPU fallback, the fuser needs an MI355X");
+  if (device < 0 || device >= ndev) return sf::fail(SF_ERR_INVALID_ARG, "device %d out of range (%d devices)", device, ndev);
+  SF_HIP_CHECK(hipSetDevice(device));
+  sf_fuser* f = new sf_fuser();
+  f->p = *p;
+  if (f->p.weight_max > 255) f->p.weight_max = 255;  // uchar weight saturates (SURVEY App. C decision)
+  if (f->p.weight_max < 1) f->p.weight_max = 1;
+  f->device = device;
+  ParamsK& k = f->pk;
+  k.W = p->depth_width; k.H = p->depth_height; k.fx = p->fx; k.fy = p->fy; k.mx = p->mx; k.my = p->my;
+  k.depth_shift = p->depth_shift; k.dmin = p->depth_min; k.dmax = p->depth_max; k.voxel = p->voxel_size;
+  k.tbase = p->trunc_base; k.tscale = p->trunc_scale; k.maxd = p->max_integration_dist;
+  k.wsample = p->weight_sample; k.wmax = f->p.weight_max;
+  k.num_buckets = p->hash_num_buckets; k.bucket_size = p->hash_bucket_size;
+  k.total_slots = p->hash_num_buckets * p->hash_bucket_size; k.num_blocks = p->num_sdf_blocks;
+  hipDeviceProp_t prop;
+  SF_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+  f->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  const size_t npx = (size_t)k.W * k.H;
+#define SF_ALLOC(ptr, bytes)                                                                      \
+  do {                                                                                            \
+    hipError_t e_ = hipMalloc((void**)&(ptr), (bytes));                                           \
+    if (e_ != hipSuccess) {                                                                       \
+      sf_fuser_destroy(f);                                                                        \
+      return sf::fail(SF_ERR_DEVICE, "hipMalloc(%zu bytes) failed: %s", (size_t)(bytes), hipGetErrorString(e_)); \
+    }                                                                                             \
+  } while (0)
+  SF_HIP_CHECK(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
+  SF_ALLOC(f->table, (size_t)k.total_slots * sizeof(HashEntry));
+  SF_ALLOC(f->heap, (size_t)k.num_blocks * 4);
+  SF_ALLOC(f->block_keys, (size_t)k.num_blocks * 8);
+  SF_ALLOC(f->voxels, (size_t)k.num_blocks * 4096);
+  SF_ALLOC(f->depthf, npx * 4);
+  SF_ALLOC(f->color, npx * 4);
+  SF_ALLOC(f->compact, (size_t)k.num_blocks * 4);
+  SF_ALLOC(f->counters, C_COUNT * 4);
+  SF_ALLOC(f->staging_depth, npx * 2);
+  SF_ALLOC(f->staging_rgb, npx * 3);
+#undef SF_ALLOC
+  SF_HIP_CHECK(hipHostMalloc((void**)&f->host_mirror, 64, hipHostMallocMapped));
+  *f->host_mirror = 0;
+  SF_HIP_CHECK(hipMemsetAsync(f->table, 0xFF, (size_t)k.total_slots * sizeof(HashEntry), f->stream));
+  SF_HIP_CHECK(hipMemsetAsync(f->voxels, 0, (size_t)k.num_blocks * 4096, f->stream));
+  SF_HIP_CHECK(hipMemsetAsync(f->counters, 0, C_COUNT * 4, f->stream));
+  hipLaunchKernelGGL(k_init_heap, dim3((k.num_blocks + 255) / 256), dim3(256), 0, f->stream, f->heap, f->block_keys, (int)k.num_blocks);
+  const int32_t free0 = (int32_t)k.num_blocks;
+  SF_HIP_CHECK(hipMemcpyAsync(&f->counters[C_HEAP_FREE], &free0, 4, hipMemcpyHostToDevice, f->stream));
+  SF_HIP_CHECK(hipStreamSynchronize(f->stream));
+  *out = f;
+  return SF_OK;
+}
+
+SF_API void sf_fuser_destroy(sf_fuser* f) {
+  if (!f) return;
+  (void)hipSetDevice(f->device);
+  if (f->stream) (void)hipStreamSynchronize(f->stream);
+  for (auto& e : f->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  (void)hipFree(f->table); (void)hipFree(f->heap); (void)hipFree(f->block_keys); (void)hipFree(f->voxels);
+  (void)hipFree(f->depthf); (void)hipFree(f->color); (void)hipFree(f->compact); (void)hipFree(f->counters);
+  (void)hipFree(f->staging_depth); (void)hipFree(f->staging_rgb);
+  if (f->host_mirror) (void)hipHostFree(f->host_mirror);
+  if (f->stream) (void)hipStreamDestroy(f->stream);
+  delete f;
+}
+
+static int fuse_host(sf_fuser* f, const uint16_t* depth, const uint8_t* rgb, const float* pose, int sign) {
+  if (!f || !depth || !pose) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  if (pose[0] == -INFINITY) { f->frames_skipped++; return sf::fail(SF_ERR_SKIPPED, "frame skipped: camToWorld is -inf (tracking lost)"); }
+  SF_HIP_CHECK(hipSetDevice(f->device));
+  const size_t npx = (size_t)f->p.depth_width * f->p.depth_height;
+  // the staging buffer is reused: wait for the previous frame's kernels before overwriting it
+  SF_HIP_CHECK(hipStreamSynchronize(f->stream));
+  SF_HIP_CHECK(hipMemcpyAsync(f->staging_depth, depth, npx * 2, hipMemcpyHostToDevice, f->stream));
+  if (rgb) SF_HIP_CHECK(hipMemcpyAsync(f->staging_rgb, rgb, npx * 3, hipMemcpyHostToDevice, f->stream));
+  return run_frame(f, f->staging_depth, rgb ? f->staging_rgb : nullptr, pose, sign);
+}
+
+SF_API int sf_fuser_integrate(sf_fuser* f, const uint16_t* depth, const uint8_t* rgb, const float pose[16]) {
+  return fuse_host(f, depth, rgb, pose, +1);
+}
+SF_API int sf_fuser_deintegrate(sf_fuser* f, const uint16_t* depth, const uint8_t* rgb, const float pose[16]) {
+  return fuse_host(f, depth, rgb, pose, -1);
+}
+SF_API int sf_fuser_integrate_device(sf_fuser* f, const void* d_depth, const void* d_rgb, const float pose[16]) {
+  if (!f || !d_depth || !pose) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  SF_HIP_CHECK(hipSetDevice(f->device));
+  return run_frame(f, d_depth, d_rgb, pose, +1);
+}
+SF_API int sf_fuser_deintegrate_device(sf_fuser* f, const void* d_depth, const void* d_rgb, const float pose[16]) {
+  if (!f || !d_depth || !pose) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  SF_HIP_CHECK(hipSetDevice(f->device));
+  return run_frame(f, d_depth, d_rgb, pose, -1);
+}
+SF_API int sf_fuser_integrate_batch_device(sf_fuser* f, const void* d_depth, uint64_t frame_stride_bytes, const float* poses, uint64_t n) {
+  if (!f || !d_depth || !poses) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  SF_HIP_CHECK(hipSetDevice(f->device));
+  for (uint64_t i = 0; i < n; i++) {
+    const int rc = run_frame(f, (const uint8_t*)d_depth + i * frame_stride_bytes, nullptr, poses + 16 * i, +1);
+    if (rc != SF_OK && rc != SF_ERR_SKIPPED) return rc;
+  }
+  return SF_OK;
+}
+
+SF_API int sf_fuser_sync(sf_fuser* f) {
+  if (!f) return sf::fail(SF_ERR_INVALID_ARG, "NULL fuser");
+  SF_HIP_CHECK(hipSetDevice(f->device));
+  SF_HIP_CHECK(hipStreamSynchronize(f->stream));
+  return SF_OK;
+}
+SF_API void* sf_fuser_stream(sf_fuser* f) { return f ? (void*)f->stream : nullptr; }
+
+SF_API int sf_fuser_stats(sf_fuser* f, sf_stats* out) {
+  if (!f || !out) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  SF_HIP_CHECK(hipSetDevice(f->device));
+  int32_t c[C_COUNT];
+  SF_HIP_CHECK(hipMemcpyAsync(c, f->counters, sizeof(c), hipMemcpyDeviceToHost, f->stream));
+  SF_HIP_CHECK(hipStreamSynchronize(f->stream));
+  std::memset(out, 0, sizeof(*out));
+  out->frames_integrated = f->frames_integrated;
+  out->frames_skipped = f->frames_skipped;
+  out->heap_free = (uint32_t)c[C_HEAP_FREE];
+  out->blocks_allocated = f->pk.num_blocks - (uint32_t)c[C_HEAP_FREE];
+  out->last_frame_blocks = (uint32_t)c[C_LAST_BLOCKS];
+  out->alloc_failures = (uint32_t)c[C_ALLOC_FAIL];
+  uint64_t tot;
+  std::memcpy(&tot, &c[C_TOTAL_LO], 8);
+  out->total_frame_blocks = tot;
+  out->hash_slots_used = (uint32_t)c[C_SLOTS_USED];
+  out->high_water = (uint32_t)c[C_HIGH_WATER];
+  return SF_OK;
+}
+
+SF_API int sf_fuser_profile_enable(sf_fuser* f, int on) {
+  if (!f) return sf::fail(SF_ERR_INVALID_ARG, "NULL fuser");
+  f->profile = on != 0;
+  return SF_OK;
+}
+SF_API int sf_fuser_profile_read(sf_fuser* f, double* integrate_ms, uint64_t* launches, uint64_t* blocks) {
+  if (!f) return sf::fail(SF_ERR_INVALID_ARG, "NULL fuser");
+  SF_HIP_CHECK(hipSetDevice(f->device));
+  SF_HIP_CHECK(hipStreamSynchronize(f->stream));
+  double ms = 0;
+  for (size_t i = 0; i < f->events_used; i++) {
+    float t = 0;
+    SF_HIP_CHECK(hipEventElapsedTime(&t, f->events[i].first, f->events[i].second));
+    ms += t;
+  }
+  if (integrate_ms) *integrate_ms = ms;
+  if (launches) *launches = f->events_used;
+  if (blocks) {
+    int32_t c[2];
+    SF_HIP_CHECK(hipMemcpy(c, &f->counters[C_TOTAL_LO], 8, hipMemcpyDeviceToHost));
+    std::memcpy(blocks, c, 8);
+  }
+  f->events_used = 0;
+  return SF_OK;
+}
+
+static int compact_live(sf_fuser* f, int32_t* n_out) {
+  FrameK dummy;
+  std::memset(&dummy, 0, sizeof(dummy));
+  SF_HIP_CHECK(hipMemsetAsync(&f->counters[C_EXPORT], 0, 4, f->stream));
+  hipLaunchKernelGGL(k_compactify, dim3(f->num_cus * 2), dim3(256), 0, f->stream, f->block_keys, f->compact, f->counters, (int)C_EXPORT, 1,
+                     f->pk, dummy);
+  SF_HIP_CHECK(hipMemcpyAsync(n_out, &f->counters[C_EXPORT], 4, hipMemcpyDeviceToHost, f->stream));
+  SF_HIP_CHECK(hipStreamSynchronize(f->stream));
+  return SF_OK;
+}
+
+SF_API int sf_fuser_garbage_collect(sf_fuser* f, uint32_t* freed) {
+  if (!f) return sf::fail(SF_ERR_INVALID_ARG, "NULL fuser");
+  SF_HIP_CHECK(hipSetDevice(f->device));
+  int32_t n = 0;
+  const int rc = compact_live(f, &n);
+  if (rc != SF_OK) return rc;
+  SF_HIP_CHECK(hipMemsetAsync(&f->counters[C_GC_FREED], 0, 4, f->stream));
+  const float thr = std::fmaf(f->p.trunc_scale, f->p.depth_max, f->p.trunc_base);
+  if (n > 0)
+    hipLaunchKernelGGL(k_gc, dim3(n < f->num_cus * 8 ? n : f->num_cus * 8), dim3(256), 0, f->stream, f->voxels, f->block_keys, f->compact,
+                       f->table, f->heap, f->counters, thr, f->pk);
+  int32_t fr = 0;
+  SF_HIP_CHECK(hipMemcpyAsync(&fr, &f->counters[C_GC_FREED], 4, hipMemcpyDeviceToHost, f->stream));
+  SF_HIP_CHECK(hipStreamSynchronize(f->stream));
+  if (freed) *freed = (uint32_t)fr;
+  return SF_OK;
+}
+
+SF_API int sf_fuser_export_blocks(sf_fuser* f, int32_t* coords, void* voxels, uint64_t capacity, uint64_t* n_out) {
+  if (!f || !n_out) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  SF_HIP_CHECK(hipSetDevice(f->device));
+  int32_t n = 0;
+  const int rc = compact_live(f, &n);
+  if (rc != SF_OK) return rc;
+  *n_out = (uint64_t)n;
+  if (!coords && !voxels) return SF_OK;
+  if (!coords || !voxels) return sf::fail(SF_ERR_INVALID_ARG, "coords and voxels must both be given");
+  if (capacity < (uint64_t)n) return sf::fail(SF_ERR_BOUNDS, "capacity %llu < %d live blocks", (unsigned long long)capacity, n);
+  if (n == 0) return SF_OK;
+  int32_t* d_coords = nullptr;
+  uint4* d_vox = nullptr;
+  SF_HIP_CHECK(hipMalloc((void**)&d_coords, (size_t)n * 12));
+  if (hipMalloc((void**)&d_vox, (size_t)n * 4096) != hipSuccess) { (void)hipFree(d_coords); return sf::fail(SF_ERR_DEVICE, "hipMalloc export buffer failed"); }
+  hipLaunchKernelGGL(k_gather, dim3(n < 65535 ? n : 65535), dim3(256), 0, f->stream, f->voxels, f->block_keys, f->compact, n, d_coords, d_vox);
+  hipError_t e1 = hipMemcpyAsync(coords, d_coords, (size_t)n * 12, hipMemcpyDeviceToHost, f->stream);
+  hipError_t e2 = hipMemcpyAsync(voxels, d_vox, (size_t)n * 4096, hipMemcpyDeviceToHost, f->stream);
+  hipError_t e3 = hipStreamSynchronize(f->stream);
+  (void)hipFree(d_coords);
+  (void)hipFree(d_vox);
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return sf::fail(SF_ERR_DEVICE, "export copy failed");
+  return SF_OK;
+}
+
+SF_API int sf_device_malloc(int device, uint64_t bytes, void** out) {
+  if (!out) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  SF_HIP_CHECK(hipSetDevice(device));
+  SF_HIP_CHECK(hipMalloc(out, bytes));
+  return SF_OK;
+}
+SF_API int sf_device_free(void* p) { SF_HIP_CHECK(hipFree(p)); return SF_OK; }
+SF_API int sf_device_upload(void* dst, const void* src, uint64_t bytes) { SF_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return SF_OK; }
+SF_API int sf_device_download(void* dst, const void* src, uint64_t bytes) { SF_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return SF_OK; }

@@ -1,0 +1,150 @@
+// params.cpp -- error state, version string and the reconstruction-parameter surface.
+//
+// sf_params_load_file reads the mLib "ParameterFile" text format the reference passes to its native
+// tools as argv[1] (Server/scan_processor.py:34-35,138; the shipped instance is
+// Server/tools/recons/zParametersScanNet.txt): one `name = value [value ...];` statement per line,
+// `//` comments, `f` suffix on floats, quoted strings, true/false.  mLib itself is not in the reference
+// tree (.gitmodules:1-3), the grammar is taken from the shipped files and from the in-tree X-macro
+// readers (Alignment/src/globalAppState.h:8-41).
+#include <cctype>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace sf {
+std::string& last_error_ref() {
+  static thread_local std::string err;
+  return err;
+}
+}  // namespace sf
+
+SF_API const char* sf_last_error(void) { return sf::last_error_ref().c_str(); }
+SF_API const char* sf_version(void) { return "scanfuse 0.1 (gfx950)"; }
+
+SF_API void sf_params_default(sf_params* p) {
+  if (!p) return;
+  std::memset(p, 0, sizeof(*p));
+  p->depth_width = 640;
+  p->depth_height = 480;
+  p->fx = 577.87f; p->fy = 577.87f; p->mx = 319.5f; p->my = 239.5f;  // SURVEY.md 8d camera
+  p->depth_shift = 1000.0f;                                            // sensorData.h:895
+  p->depth_min = 0.1f; p->depth_max = 6.0f;                            // zParametersScanNet.txt:34-35
+  p->voxel_size = 0.004f;                                              // BASELINE.json configs[1] (file value: 0.010, :47)
+  p->trunc_base = 0.06f; p->trunc_scale = 0.02f;                       // :49-50
+  p->max_integration_dist = 4.0f;                                      // :51
+  p->weight_sample = 1;                                                // :52
+  p->weight_max = 255;                                                 // :53 says 99999999; a uchar weight saturates
+  p->mc_thresh_factor = 10.0f;                                         // :48
+  p->hash_num_buckets = 1u << 19;                                      // BASELINE.json configs[1] (file value: 800000, :56)
+  p->hash_bucket_size = 10;                                            // HASH_BUCKET_SIZE, :55
+  p->num_sdf_blocks = 1u << 20;                                        // 4 GiB of 4 KiB tiles; file value 600000 (:57)
+  p->mc_max_triangles = 0;
+  p->gc_enabled = 0;
+}
+
+namespace {
+
+std::string strip(const std::string& s) {
+  size_t a = 0, b = s.size();
+  while (a < b && std::isspace((unsigned char)s[a])) a++;
+  while (b > a && std::isspace((unsigned char)s[b - 1])) b--;
+  return s.substr(a, b - a);
+}
+
+bool parse_float(const std::string& tok, float* out) {
+  std::string t = tok;
+  if (!t.empty() && (t.back() == 'f' || t.back() == 'F')) t.pop_back();
+  if (t.empty()) return false;
+  char* end = nullptr;
+  const double v = std::strtod(t.c_str(), &end);
+  if (end == t.c_str() || *end != 0) return false;
+  *out = (float)v;
+  return true;
+}
+
+}  // namespace
+
+SF_API int sf_params_load_file(const char* path, sf_params* p) {
+  if (!path || !p) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  std::ifstream in(path);
+  if (!in) return sf::fail(SF_ERR_IO, "could not open parameter file %s", path);
+  std::map<std::string, std::vector<std::string>> kv;
+  std::string line;
+  int lineno = 0;
+  while (std::getline(in, line)) {
+    lineno++;
+    // strip // comments (not inside quotes)
+    bool inq = false;
+    size_t cut = std::string::npos;
+    for (size_t i = 0; i + 1 < line.size(); i++) {
+      if (line[i] == '"') inq = !inq;
+      if (!inq && line[i] == '/' && line[i + 1] == '/') { cut = i; break; }
+    }
+    if (cut != std::string::npos) line = line.substr(0, cut);
+    line = strip(line);
+    if (line.empty()) continue;
+    const size_t eq = line.find('=');
+    if (eq == std::string::npos) continue;  // mLib ignores lines without an assignment
+    std::string name = strip(line.substr(0, eq));
+    std::string val = strip(line.substr(eq + 1));
+    const size_t semi = val.find(';');
+    if (semi != std::string::npos) val = strip(val.substr(0, semi));
+    std::vector<std::string> toks;
+    if (!val.empty() && val[0] == '"') {
+      const size_t q = val.find('"', 1);
+      toks.push_back(q == std::string::npos ? val.substr(1) : val.substr(1, q - 1));
+    } else {
+      std::istringstream ss(val);
+      std::string t;
+      while (ss >> t) toks.push_back(t);
+    }
+    if (name.empty()) return sf::fail(SF_ERR_FORMAT, "%s:%d: empty parameter name", path, lineno);
+    kv[name] = toks;
+  }
+  auto getf = [&](const char* k, float* dst) -> int {
+    auto it = kv.find(k);
+    if (it == kv.end()) return SF_OK;
+    if (it->second.empty() || !parse_float(it->second[0], dst)) return sf::fail(SF_ERR_FORMAT, "%s: bad value for %s", path, k);
+    return SF_OK;
+  };
+  auto geti = [&](const char* k, int64_t* dst) -> int {
+    auto it = kv.find(k);
+    if (it == kv.end()) return SF_OK;
+    if (it->second.empty()) return sf::fail(SF_ERR_FORMAT, "%s: bad value for %s", path, k);
+    const std::string& t = it->second[0];
+    if (t == "true") { *dst = 1; return SF_OK; }
+    if (t == "false") { *dst = 0; return SF_OK; }
+    float fv;
+    if (!parse_float(t, &fv)) return sf::fail(SF_ERR_FORMAT, "%s: bad value for %s", path, k);
+    *dst = (int64_t)std::strtoll(t.c_str(), nullptr, 10);
+    return SF_OK;
+  };
+  int rc;
+#define GETF(key, field) if ((rc = getf(key, &p->field)) != SF_OK) return rc
+  GETF("s_sensorDepthMax", depth_max);
+  GETF("s_sensorDepthMin", depth_min);
+  GETF("s_SDFVoxelSize", voxel_size);
+  GETF("s_SDFMarchingCubeThreshFactor", mc_thresh_factor);
+  GETF("s_SDFTruncation", trunc_base);
+  GETF("s_SDFTruncationScale", trunc_scale);
+  GETF("s_SDFMaxIntegrationDistance", max_integration_dist);
+#undef GETF
+  int64_t v;
+  v = p->weight_sample; if ((rc = geti("s_SDFIntegrationWeightSample", &v)) != SF_OK) return rc; p->weight_sample = (int32_t)v;
+  v = p->weight_max;    if ((rc = geti("s_SDFIntegrationWeightMax", &v)) != SF_OK) return rc;    p->weight_max = (int32_t)(v > 255 ? 255 : v);
+  v = p->hash_num_buckets; if ((rc = geti("s_hashNumBuckets", &v)) != SF_OK) return rc; p->hash_num_buckets = (uint32_t)v;
+  v = p->num_sdf_blocks;   if ((rc = geti("s_hashNumSDFBlocks", &v)) != SF_OK) return rc; p->num_sdf_blocks = (uint32_t)v;
+  v = p->mc_max_triangles; if ((rc = geti("s_marchingCubesMaxNumTriangles", &v)) != SF_OK) return rc; p->mc_max_triangles = (uint32_t)v;
+  v = p->gc_enabled;       if ((rc = geti("s_garbageCollectionEnabled", &v)) != SF_OK) return rc; p->gc_enabled = (int32_t)v;
+  v = p->depth_width;      if ((rc = geti("s_integrationWidth", &v)) != SF_OK) return rc; p->depth_width = (int32_t)v;
+  v = p->depth_height;     if ((rc = geti("s_integrationHeight", &v)) != SF_OK) return rc; p->depth_height = (int32_t)v;
+  if (!(p->voxel_size > 0) || p->hash_num_buckets == 0 || p->num_sdf_blocks == 0)
+    return sf::fail(SF_ERR_FORMAT, "%s: non-positive voxel size / hash size", path);
+  return SF_OK;
+}

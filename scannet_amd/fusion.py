@@ -1,0 +1,145 @@
+"""Voxel-hash TSDF fuser -- host-side mirror of the scene-representation interface of the reference's
+`improve` stage (external DepthSensing.exe, call site Server/scan_processor.py:137-138).
+
+Thin ctypes layer over the C ABI (include/scanfuse.h); all arithmetic runs in the HIP kernels of
+scannet_amd/csrc/fuser.hip.  There is no CPU fallback: creating a Fuser without an MI355X raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._abi import SfParams, SfStats, check
+
+VOXEL_DTYPE = np.dtype([("sdf", "<f4"), ("r", "u1"), ("g", "u1"), ("b", "u1"), ("w", "u1")])
+
+
+def default_params(**over):
+    """zParametersScanNet.txt values with BASELINE.json's 4 mm / 2^19-bucket overrides; keyword overrides."""
+    p = SfParams()
+    _abi.lib().sf_params_default(C.byref(p))
+    for k, v in over.items():
+        if not hasattr(p, k):
+            raise AttributeError("sf_params has no field %r" % k)
+        setattr(p, k, v)
+    return p
+
+
+def load_params(path, base=None):
+    """Parse an mLib ParameterFile (e.g. Server/tools/recons/zParametersScanNet.txt)."""
+    p = base if base is not None else default_params()
+    check(_abi.lib().sf_params_load_file(str(path).encode(), C.byref(p)))
+    return p
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = _abi.lib().sf_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    if hasattr(a, "data_ptr"):  # torch tensor
+        return C.c_void_p(a.data_ptr())
+    return C.c_void_p(int(a))
+
+
+class Fuser:
+    def __init__(self, params=None, device=0):
+        self.params = params if params is not None else default_params()
+        self.device = device
+        h = C.c_void_p()
+        check(_abi.lib().sf_fuser_create(C.byref(self.params), int(device), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _abi.lib().sf_fuser_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- host buffers -------------------------------------------------------------------------------
+    def _host_frame(self, fn, depth, pose, rgb):
+        depth = np.ascontiguousarray(depth, dtype=np.uint16)
+        if depth.size != self.params.depth_width * self.params.depth_height:
+            raise ValueError("depth frame has %d pixels, fuser expects %dx%d" % (depth.size, self.params.depth_width, self.params.depth_height))
+        pose = np.ascontiguousarray(pose, dtype=np.float32).reshape(16)
+        if rgb is not None:
+            rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+            if rgb.size != depth.size * 3:
+                raise ValueError("rgb must be depth-resolution HxWx3")
+        rc = check(fn(self._h, _ptr(depth), _ptr(rgb), _ptr(pose)), allow=(_abi.SF_ERR_SKIPPED,))
+        return rc == 0
+
+    def integrate(self, depth, pose, rgb=None):
+        """Fuse one frame; returns False when the frame was skipped (pose all -inf)."""
+        return self._host_frame(_abi.lib().sf_fuser_integrate, depth, pose, rgb)
+
+    def deintegrate(self, depth, pose, rgb=None):
+        return self._host_frame(_abi.lib().sf_fuser_deintegrate, depth, pose, rgb)
+
+    # -- device buffers (torch tensors or raw device pointers) --------------------------------------
+    def integrate_device(self, d_depth, pose, d_rgb=None):
+        pose = np.ascontiguousarray(pose, dtype=np.float32).reshape(16)
+        rc = check(_abi.lib().sf_fuser_integrate_device(self._h, _ptr(d_depth), _ptr(d_rgb), _ptr(pose)), allow=(_abi.SF_ERR_SKIPPED,))
+        return rc == 0
+
+    def deintegrate_device(self, d_depth, pose, d_rgb=None):
+        pose = np.ascontiguousarray(pose, dtype=np.float32).reshape(16)
+        rc = check(_abi.lib().sf_fuser_deintegrate_device(self._h, _ptr(d_depth), _ptr(d_rgb), _ptr(pose)), allow=(_abi.SF_ERR_SKIPPED,))
+        return rc == 0
+
+    def integrate_batch_device(self, d_depth, frame_stride_bytes, poses):
+        poses = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 16)
+        check(_abi.lib().sf_fuser_integrate_batch_device(self._h, _ptr(d_depth), int(frame_stride_bytes), _ptr(poses), len(poses)))
+
+    def garbage_collect(self):
+        n = C.c_uint32(0)
+        check(_abi.lib().sf_fuser_garbage_collect(self._h, C.byref(n)))
+        return n.value
+
+    def sync(self):
+        check(_abi.lib().sf_fuser_sync(self._h))
+
+    @property
+    def stream(self):
+        return _abi.lib().sf_fuser_stream(self._h)
+
+    def stats(self):
+        s = SfStats()
+        check(_abi.lib().sf_fuser_stats(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in SfStats._fields_}
+
+    def profile(self, on=True):
+        check(_abi.lib().sf_fuser_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self):
+        ms, n, b = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
+        check(_abi.lib().sf_fuser_profile_read(self._h, C.byref(ms), C.byref(n), C.byref(b)))
+        return ms.value, n.value, b.value
+
+    def export_blocks(self):
+        """-> (coords int32 [n,3], voxels VOXEL_DTYPE [n,512]) sorted lexicographically by (x,y,z)."""
+        n = C.c_uint64(0)
+        check(_abi.lib().sf_fuser_export_blocks(self._h, None, None, 0, C.byref(n)))
+        coords = np.zeros((n.value, 3), np.int32)
+        vox = np.zeros((n.value, 512), VOXEL_DTYPE)
+        if n.value:
+            check(_abi.lib().sf_fuser_export_blocks(self._h, _ptr(coords), _ptr(vox), n.value, C.byref(n)))
+        order = np.lexsort((coords[:, 2], coords[:, 1], coords[:, 0]))
+        return coords[order], vox[order]

@@ -1,0 +1,165 @@
+"""Parity of the HIP fusion path (through the C ABI) against the CPU oracle: bit-exact block sets and voxels.
+
+All tests here need an MI355X (`-m gpu`).  Inputs are seeded / closed-form (scannet_amd/synth.py); the
+oracle is oracle/tsdf_oracle.c ("parity unpinned" vs upstream -- see its header -- but pinned analytically in
+tests/test_oracle_tsdf.py).
+"""
+import numpy as np
+import pytest
+
+from scannet_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(oracle, W=640, H=480, voxel=0.004, **over):
+    from scannet_amd import fusion
+    op = oracle.default_params(W, H, voxel)
+    fx, fy, mx, my = synth.intrinsics(W, H)
+    op.fx, op.fy, op.mx, op.my = fx, fy, mx, my
+    gp = fusion.default_params(depth_width=W, depth_height=H, voxel_size=voxel, fx=fx, fy=fy, mx=mx, my=my,
+                               num_sdf_blocks=over.pop("num_sdf_blocks", 1 << 18))
+    for k, v in over.items():
+        setattr(gp, k, v)
+        if hasattr(op, k):
+            setattr(op, k, v)
+    return op, gp
+
+
+def _assert_same(ovol, fuser):
+    oc, ov = ovol.export()
+    gc, gv = fuser.export_blocks()
+    assert len(oc) == len(gc), "block count differs: oracle %d gpu %d" % (len(oc), len(gc))
+    assert np.array_equal(oc, gc), "allocated block sets differ"
+    same = ov.view(np.uint8).reshape(len(oc), -1) == gv.view(np.uint8).reshape(len(gc), -1)
+    if not same.all():
+        bad = np.argwhere(~same.reshape(len(oc), 512, 8).all(-1))
+        b, v = bad[0]
+        raise AssertionError("%d voxels differ; first: block %s voxel %d oracle %s gpu %s" %
+                             (len(bad), oc[b], v, ov[b, v], gv[b, v]))
+
+
+def test_plane_bit_exact(oracle):
+    from scannet_amd import fusion
+    op, gp = _mk(oracle)
+    ovol = oracle.Volume(op, threads=8)
+    I = np.eye(4, dtype=np.float32)
+    d = synth.plane_frame()
+    n = ovol.integrate(d, I)
+    with fusion.Fuser(gp) as f:
+        assert f.integrate(d, I)
+        st = f.stats()
+        assert st["last_frame_blocks"] == n
+        assert st["blocks_allocated"] == ovol.num_blocks
+        assert st["alloc_failures"] == 0
+        _assert_same(ovol, f)
+
+
+def test_room_stream_bit_exact(oracle):
+    """Config-2 style walk (noise on): 6 frames spread over the loop, compared after every frame count."""
+    from scannet_amd import fusion
+    op, gp = _mk(oracle, num_sdf_blocks=1 << 19)
+    ovol = oracle.Volume(op, threads=8)
+    with fusion.Fuser(gp) as f:
+        for i in (0, 1, 2, 700, 1400, 1401):
+            pose = synth.trajectory_pose(i, 5578)
+            d = synth.render_room_depth(pose, noise_frame=i)
+            n = ovol.integrate(d, pose)
+            assert f.integrate(d, pose)
+            assert f.stats()["last_frame_blocks"] == n
+        _assert_same(ovol, f)
+
+
+def test_colour_deintegrate_gc_ragged(oracle):
+    """Ragged image size (not a multiple of 8 or 16), colour fusion, deintegration and garbage collection."""
+    from scannet_amd import fusion
+    W, H = 161, 123
+    op, gp = _mk(oracle, W, H, voxel=0.01, num_sdf_blocks=1 << 16)
+    ovol = oracle.Volume(op, threads=4)
+    rng = np.random.default_rng(7)
+    with fusion.Fuser(gp) as f:
+        frames = []
+        for i in (0, 30, 60):
+            pose = synth.trajectory_pose(i, 400)
+            d = synth.render_room_depth(pose, W, H, noise_frame=i)
+            d[rng.random(d.shape) < 0.05] = 0  # holes
+            rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+            frames.append((d, pose, rgb))
+            ovol.integrate(d, pose, rgb=rgb)
+            assert f.integrate(d, pose, rgb=rgb)
+        _assert_same(ovol, f)
+        d, pose, rgb = frames[1]
+        ovol.deintegrate(d, pose, rgb=rgb)
+        assert f.deintegrate(d, pose, rgb=rgb)
+        _assert_same(ovol, f)
+        freed_o = ovol.garbage_collect()
+        freed_g = f.garbage_collect()
+        assert freed_o == freed_g and freed_o > 0
+        _assert_same(ovol, f)
+        # the freed heap slots are reusable: fuse another frame
+        pose = synth.trajectory_pose(90, 400)
+        d = synth.render_room_depth(pose, W, H)
+        ovol.integrate(d, pose)
+        assert f.integrate(d, pose)
+        _assert_same(ovol, f)
+        assert f.stats()["alloc_failures"] == 0
+
+
+def test_invalid_pose_and_empty_depth(oracle):
+    from scannet_amd import fusion
+    op, gp = _mk(oracle, 160, 120, voxel=0.02, num_sdf_blocks=1 << 14)
+    with fusion.Fuser(gp) as f:
+        bad = np.full((4, 4), -np.inf, np.float32)
+        assert f.integrate(synth.plane_frame(160, 120), bad) is False
+        assert f.integrate(np.zeros((120, 160), np.uint16), np.eye(4, dtype=np.float32))
+        st = f.stats()
+        assert st["blocks_allocated"] == 0 and st["frames_skipped"] == 1 and st["last_frame_blocks"] == 0
+        with pytest.raises(ValueError):
+            f.integrate(np.zeros((10, 10), np.uint16), np.eye(4, dtype=np.float32))
+
+
+def test_one_mm_voxels(oracle):
+    """Config 3 flavour: 1 mm voxels / 2^22 buckets on a window of the plane (HBM-capacity stress is bench territory)."""
+    from scannet_amd import fusion
+    op, gp = _mk(oracle, 200, 150, voxel=0.001, hash_num_buckets=1 << 22, num_sdf_blocks=1 << 18)
+    ovol = oracle.Volume(op, threads=8)
+    d = synth.plane_frame(200, 150, 600)
+    I = np.eye(4, dtype=np.float32)
+    n = ovol.integrate(d, I)
+    with fusion.Fuser(gp) as f:
+        assert f.integrate(d, I)
+        assert f.stats()["last_frame_blocks"] == n
+        _assert_same(ovol, f)
+
+
+def test_heap_exhaustion_is_reported(oracle):
+    from scannet_amd import fusion
+    _, gp = _mk(oracle, 160, 120, voxel=0.004, num_sdf_blocks=256)
+    with fusion.Fuser(gp) as f:
+        assert f.integrate(synth.plane_frame(160, 120, 1000), np.eye(4, dtype=np.float32))
+        st = f.stats()
+        assert st["heap_free"] == 0 and st["blocks_allocated"] == 256 and st["alloc_failures"] > 0
+
+
+def test_full_size_roundtrip_property(oracle):
+    """BASELINE size (640x480, 4 mm): integrate 8 noisy frames then deintegrate them in reverse => empty volume,
+    and integrating the same stream through the device-resident batch entry point gives the same voxels."""
+    import torch
+    from scannet_amd import fusion
+    _, gp = _mk(oracle, num_sdf_blocks=1 << 19)
+    frames = [(synth.render_room_depth(synth.trajectory_pose(i, 5578), noise_frame=i), synth.trajectory_pose(i, 5578)) for i in range(0, 64, 8)]
+    with fusion.Fuser(gp) as f, fusion.Fuser(gp) as g:
+        for d, p in frames:
+            assert f.integrate(d, p)
+        dev = torch.from_numpy(np.stack([d for d, _ in frames]).astype(np.int16)).cuda()
+        g.integrate_batch_device(dev, 640 * 480 * 2, np.stack([p for _, p in frames]))
+        c1, v1 = f.export_blocks()
+        c2, v2 = g.export_blocks()
+        assert np.array_equal(c1, c2) and np.array_equal(v1.view(np.uint8), v2.view(np.uint8))
+        assert f.stats()["total_frame_blocks"] == g.stats()["total_frame_blocks"]
+        for d, p in reversed(frames):
+            assert f.deintegrate(d, p)
+        _, v = f.export_blocks()
+        assert (v["w"] == 0).all() and (v["sdf"] == 0).all()
+        assert f.garbage_collect() == len(c1)
+        assert f.stats()["blocks_allocated"] == 0
