@@ -96,6 +96,7 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     fuser.integrate_batch_device(frames[Wm:].data_ptr() if K else frames.data_ptr(), stride, poses[Wm:])
+    t_enq = time.perf_counter() - t0  # host time to enqueue the K frames (launch-bound if ~= elapsed)
     fuser.sync()
     torch.cuda.synchronize()
     if world > 1:
@@ -127,6 +128,7 @@ def main():
             "value": round(world * K / elapsed, 2), "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": round(elapsed * 1e3 / max(K, 1), 5),
+            "host_enqueue_ms_per_step": round(t_enq * 1e3 / max(K, 1), 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: scene0000_00-scale synthetic stream (5578-frame box-room walk, 640x480 u16 depth, "

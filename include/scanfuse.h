@@ -124,6 +124,9 @@ int sf_device_download(void* dst, const void* src, uint64_t bytes);
 int sf_synth_room_device(void* d_depth, uint64_t frame_stride_bytes, uint64_t first_frame, uint64_t n, uint64_t total_frames,
                          int width, int height, int noise, float* poses_out);
 
+/* PMC calibration stream (tools/pmc_calibrate.py): known-byte-count 16 B/lane RMW + read-only launches. */
+int sf_calib_stream(int device, uint64_t bytes, int iters);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -63,6 +64,7 @@ enum Counter {
   C_EXPORT = 6,
   C_GC_FREED = 7,
   C_TOTAL_LO = 8,  // 64-bit sum of N_blk lives in counters[8..9]
+  C_COMPACT_B = 10,  // second frame slot (frames alternate between two sets of per-frame buffers)
   C_COUNT = 16
 };
 
@@ -109,9 +111,9 @@ __device__ inline int world_to_block(float w, float voxel) {
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_prepass(const uint16_t* __restrict__ depth, const uint8_t* __restrict__ rgb,
                                                  float* __restrict__ depthf, uint32_t* __restrict__ color, int n,
-                                                 float shift, float dmin, float dmax, int32_t* counters) {
+                                                 float shift, float dmin, float dmax, int32_t* counters, int compact_counter) {
   const int i0 = (blockIdx.x * 256 + threadIdx.x) * 8;
-  if (blockIdx.x == 0 && threadIdx.x == 0) counters[C_COMPACT] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicExch(&counters[compact_counter], 0);
   if (i0 >= n) return;
   uint16_t u[8];
   if (i0 + 8 <= n) {
@@ -143,23 +145,85 @@ __global__ __launch_bounds__(256) void k_prepass(const uint16_t* __restrict__ de
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K2: allocation.  One lane per depth pixel, one wave per 8x8 pixel tile (neighbouring rays hit the same
-// blocks).  Every lane walks its own 3-D DDA over the blocks of [d - t, d + t]; at every step the wave
-// removes duplicate candidates with ballots, the surviving owner lanes probe the hash in parallel
-// (lock-free CAS claim of an EMPTY slot), and newly claimed slots get heap blocks through one
-// wave-aggregated pop (ballot + mbcnt prefix).  The allocated SET is deterministic; which heap slot a
-// block lands in is not (neither is it upstream).
+// K2: allocation.  One lane per depth pixel, one 256-thread workgroup per 16x16 pixel tile.
+//   phase 1 (no global memory): every lane walks its 3-D DDA over the blocks of [d - t, d + t] and drops
+//            the block keys into a workgroup-wide LDS hash set (ds_cmpst CAS) -- neighbouring rays and
+//            consecutive steps hit the same blocks, the set keeps ~50-150 unique keys per tile;
+//   phase 2: the unique keys are frustum-tested and probed in the global hash table by all lanes in
+//            parallel (one memory round trip instead of one per DDA step); an EMPTY slot is claimed with
+//            a lock-free 64-bit CAS, and the freshly claimed slots of a wave receive their heap blocks
+//            through ONE wave-aggregated pop (ballot + prefix popcount).
+// The allocated SET is deterministic (no insertion ever gives up, so no fix-point iteration as upstream);
+// which heap slot a block lands in is not (neither is it upstream).
 // ---------------------------------------------------------------------------------------------------
+constexpr int ALLOC_SET = 2048;       // LDS hash-set slots per workgroup (16 KiB)
+constexpr int ALLOC_LIST = 1024;      // dense list of the set's keys (8 KiB)
+constexpr int ALLOC_SET_PROBES = 32;
+
+struct HashRefs {
+  HashEntry* table;
+  int32_t* heap;
+  uint64_t* block_keys;
+  int32_t* counters;
+};
+
+// find-or-claim `key`; returns the claimed entry (needs a heap block) or nullptr (already present / table full)
+__device__ inline HashEntry* hash_find_or_claim(const HashRefs& h, const ParamsK& P, uint64_t key, int bx, int by, int bz) {
+  uint32_t slot = hash_bucket(bx, by, bz, P.num_buckets) * P.bucket_size;
+  for (int probe = 0; probe < MAX_PROBES; ++probe) {
+    HashEntry* e = h.table + slot;
+    const uint64_t k = __hip_atomic_load(&e->key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == key) return nullptr;
+    if (k == KEY_EMPTY) {
+      const uint64_t old = atomicCAS((unsigned long long*)&e->key, (unsigned long long)KEY_EMPTY, (unsigned long long)key);
+      if (old == KEY_EMPTY) return e;
+      if (old == key) return nullptr;
+    }
+    slot++;
+    if (slot == P.total_slots) slot = 0;
+  }
+  atomicAdd(&h.counters[C_ALLOC_FAIL], 1);
+  return nullptr;
+}
+
+__device__ inline void give_block(const HashRefs& h, HashEntry* e, uint64_t key, int at) {
+  if (at >= 0) {
+    const int idx = h.heap[at];
+    e->ptr = idx;
+    h.block_keys[idx] = key;
+    atomicMax(&h.counters[C_HIGH_WATER], idx + 1);
+  } else {
+    // heap exhausted: the entry stays claimed without a block; undo the pop
+    atomicAdd(&h.counters[C_HEAP_FREE], 1);
+    atomicAdd(&h.counters[C_ALLOC_FAIL], 1);
+  }
+}
+
+template <int WIN_LOG2>
 __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf, HashEntry* table, int32_t* heap,
-                                               uint64_t* block_keys, int32_t* counters, ParamsK P, FrameK F) {
+                                               uint64_t* block_keys, int32_t* counters, ParamsK P, FrameK F, int dbg) {
+  constexpr int WIN = 1 << WIN_LOG2;                // window edge in blocks
+  constexpr int WIN_WORDS = (WIN * WIN * WIN) / 32; // occupancy bitmap words
+  __shared__ uint32_t s_bits[WIN_WORDS];            // 4 KiB (WIN 32) / 32 KiB (WIN 64)
+  __shared__ unsigned long long s_keys[ALLOC_SET];  // overflow set for blocks outside the window
+  __shared__ unsigned long long s_list[ALLOC_LIST]; // unique keys, densely packed for phase 2
+  __shared__ int s_count;
+  __shared__ int s_chooser;
+  __shared__ int s_anchor[3];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) { s_count = 0; s_chooser = 256; }
   const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
   const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+  const HashRefs h{table, heap, block_keys, counters};
+  for (int i = threadIdx.x; i < ALLOC_SET; i += 256) s_keys[i] = KEY_EMPTY;
+  for (int i = threadIdx.x; i < WIN_WORDS; i += 256) s_bits[i] = 0u;
+  __syncthreads();
 
+  // ---- phase 1: DDA into the LDS set
   bool active = false;
-  int cx = 0, cy = 0, cz = 0, sx = 0, sy = 0, sz = 0, ex = 0, ey = 0, ez = 0;
-  float tmx = INFINITY, tmy = INFINITY, tmz = INFINITY, tdx = INFINITY, tdy = INFINITY, tdz = INFINITY;
+  int a_cx = 0, a_cy = 0, a_cz = 0, a_sx = 0, a_sy = 0, a_sz = 0, a_ex = 0, a_ey = 0, a_ez = 0;
+  float a_tmx = INFINITY, a_tmy = INFINITY, a_tmz = INFINITY, a_tdx = INFINITY, a_tdy = INFINITY, a_tdz = INFINITY;
   if (x < P.W && y < P.H) {
     const float d = depthf[y * P.W + x];
     if (d != -INFINITY && d < P.maxd) {
@@ -167,7 +231,6 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf,
       const float lo = fminf(P.maxd, d - t);
       const float hi = fminf(P.maxd, d + t);
       if (lo < hi) {
-        active = true;
         const float kx = ((float)x - P.mx) / P.fx;
         const float ky = ((float)y - P.my) / P.fy;
         float p0[3], p1[3];
@@ -199,52 +262,99 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf,
             td[c] = ((float)stp[c] * bsize) / dir;
           }
         }
-        cx = cur[0]; cy = cur[1]; cz = cur[2]; sx = stp[0]; sy = stp[1]; sz = stp[2];
-        ex = bnd[0]; ey = bnd[1]; ez = bnd[2];
-        tmx = tm[0]; tmy = tm[1]; tmz = tm[2]; tdx = td[0]; tdy = td[1]; tdz = td[2];
+        a_cx = cur[0]; a_cy = cur[1]; a_cz = cur[2];
+        a_sx = stp[0]; a_sy = stp[1]; a_sz = stp[2]; a_ex = bnd[0]; a_ey = bnd[1]; a_ez = bnd[2];
+        a_tmx = tm[0]; a_tmy = tm[1]; a_tmz = tm[2]; a_tdx = td[0]; a_tdy = td[1]; a_tdz = td[2];
+        active = true;
       }
     }
   }
-
-  uint64_t last_key = KEY_EMPTY;
-  int iters = 0;
-  int hw_local = 0;
-  while (__ballot(active) != 0ull) {
-    uint64_t key = KEY_EMPTY;
-    bool want = false;
-    if (active && block_in_frustum(P, F, cx, cy, cz)) {
-      key = pack_key(cx, cy, cz);
-      want = key != last_key;
-      last_key = key;
-    }
-    // wave-level duplicate removal: the lowest lane holding a key becomes its owner
-    bool owner = false;
-    uint64_t todo = __ballot(want);
-    while (todo != 0ull) {
-      const int leader = __ffsll((unsigned long long)todo) - 1;
-      const uint64_t k = __shfl(key, leader);
-      const uint64_t same = __ballot(want && key == k);
-      if (lane == leader) owner = true;
-      todo &= ~same;
-    }
-    // owners probe in parallel
-    HashEntry* claimed = nullptr;
-    if (owner) {
-      uint32_t slot = hash_bucket(cx, cy, cz, P.num_buckets) * P.bucket_size;
-      int probe = 0;
-      for (; probe < MAX_PROBES; ++probe) {
-        HashEntry* e = table + slot;
-        const uint64_t k = __hip_atomic_load(&e->key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (k == key) break;
-        if (k == KEY_EMPTY) {
-          const uint64_t old = atomicCAS((unsigned long long*)&e->key, (unsigned long long)KEY_EMPTY, (unsigned long long)key);
-          if (old == KEY_EMPTY) { claimed = e; break; }
-          if (old == key) break;
+  // The tile's rays stay inside a small region of block space: the first active lane anchors a WIN^3
+  // window there and every DDA step just sets one bit of an LDS occupancy bitmap with a non-returning
+  // ds_or (no latency on the lane, duplicates across lanes and steps collapse for free).  Blocks that
+  // fall outside the window (tiles straddling a depth discontinuity) go to a small LDS hash set.
+  if (active) atomicMin(&s_chooser, (int)threadIdx.x);
+  __syncthreads();
+  if ((int)threadIdx.x == s_chooser) {
+    s_anchor[0] = a_cx - (a_sx >= 0 ? WIN / 4 : 3 * WIN / 4);
+    s_anchor[1] = a_cy - (a_sy >= 0 ? WIN / 4 : 3 * WIN / 4);
+    s_anchor[2] = a_cz - (a_sz >= 0 ? WIN / 4 : 3 * WIN / 4);
+  }
+  __syncthreads();
+  const int anx = s_anchor[0], any_ = s_anchor[1], anz = s_anchor[2];
+  if (active && (dbg & 2) == 0) {
+    uint64_t last_key = KEY_EMPTY;
+    for (int it = 0; it < MAX_DDA_ITERS; ++it) {
+      const uint32_t ux = (uint32_t)(a_cx - anx), uy = (uint32_t)(a_cy - any_), uz = (uint32_t)(a_cz - anz);
+      if ((ux | uy | uz) < (uint32_t)WIN) {
+        const uint32_t bit = (uz << (2 * WIN_LOG2)) | (uy << WIN_LOG2) | ux;
+        atomicOr(&s_bits[bit >> 5], 1u << (bit & 31));
+      } else {
+        const uint64_t key = pack_key(a_cx, a_cy, a_cz);
+        if (key != last_key) {
+          last_key = key;
+          uint32_t sl = ((uint32_t)(key ^ (key >> 21) ^ (key >> 42)) * 2654435761u) >> 21;  // 11 bits
+          bool placed = false;
+          for (int pr = 0; pr < ALLOC_SET_PROBES; ++pr) {
+            const unsigned long long old = atomicCAS(&s_keys[sl], (unsigned long long)KEY_EMPTY, (unsigned long long)key);
+            if (old == key) { placed = true; break; }
+            if (old == KEY_EMPTY) {
+              const int pos = atomicAdd(&s_count, 1);
+              if (pos < ALLOC_LIST) { s_list[pos] = key; placed = true; }
+              break;  // list full: direct path below
+            }
+            sl = (sl + 1) & (ALLOC_SET - 1);
+          }
+          if (!placed && block_in_frustum(P, F, a_cx, a_cy, a_cz)) {
+            // overflow of the overflow set (pathological tile): straight to the global table
+            HashEntry* e = hash_find_or_claim(h, P, key, a_cx, a_cy, a_cz);
+            if (e) {
+              atomicAdd(&counters[C_SLOTS_USED], 1);
+              give_block(h, e, key, atomicSub(&counters[C_HEAP_FREE], 1) - 1);
+            }
+          }
         }
-        slot++;
-        if (slot == P.total_slots) slot = 0;
       }
-      if (probe == MAX_PROBES) atomicAdd(&counters[C_ALLOC_FAIL], 1);
+      bool done;
+      if (a_tmx < a_tmy && a_tmx < a_tmz) { a_cx += a_sx; done = (a_cx == a_ex); a_tmx += a_tdx; }
+      else if (a_tmz < a_tmy) { a_cz += a_sz; done = (a_cz == a_ez); a_tmz += a_tdz; }
+      else { a_cy += a_sy; done = (a_cy == a_ey); a_tmy += a_tdy; }
+      if (done) break;
+    }
+  }
+  __syncthreads();
+  // bitmap -> dense key list
+  for (int w = threadIdx.x; w < WIN_WORDS; w += 256) {
+    uint32_t bits = s_bits[w];
+    while (bits) {
+      const int b = __ffs((int)bits) - 1;
+      bits &= bits - 1u;
+      const uint32_t bit = ((uint32_t)w << 5) | (uint32_t)b;
+      const int bx = anx + (int)(bit & (WIN - 1)), by = any_ + (int)((bit >> WIN_LOG2) & (WIN - 1)), bz = anz + (int)(bit >> (2 * WIN_LOG2));
+      const int pos = atomicAdd(&s_count, 1);
+      if (pos < ALLOC_LIST) s_list[pos] = pack_key(bx, by, bz);
+      else if (block_in_frustum(P, F, bx, by, bz)) {
+        const uint64_t key = pack_key(bx, by, bz);
+        HashEntry* e = hash_find_or_claim(h, P, key, bx, by, bz);
+        if (e) {
+          atomicAdd(&counters[C_SLOTS_USED], 1);
+          give_block(h, e, key, atomicSub(&counters[C_HEAP_FREE], 1) - 1);
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: unique keys -> frustum test -> global hash, all lanes in parallel
+  const int n_unique = (dbg & 1) ? 0 : min(s_count, ALLOC_LIST);
+  for (int i0 = 0; i0 < n_unique; i0 += 256) {
+    const int i = i0 + threadIdx.x;
+    const uint64_t key = i < n_unique ? s_list[i] : KEY_EMPTY;
+    HashEntry* claimed = nullptr;
+    if (key != KEY_EMPTY) {
+      int bx, by, bz;
+      unpack_key(key, bx, by, bz);
+      if (block_in_frustum(P, F, bx, by, bz)) claimed = hash_find_or_claim(h, P, key, bx, by, bz);
     }
     // wave-aggregated heap pop for the freshly claimed slots
     const uint64_t cm = __ballot(claimed != nullptr);
@@ -259,63 +369,61 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf,
       base = __shfl(base, first);
       if (claimed != nullptr) {
         const int rank = __popcll((unsigned long long)(cm & ((1ull << lane) - 1ull)));
-        const int at = base - 1 - rank;
-        if (at >= 0) {
-          const int idx = heap[at];
-          claimed->ptr = idx;
-          block_keys[idx] = key;
-          hw_local = max(hw_local, idx + 1);
-        } else {
-          // heap exhausted: the entry stays claimed without a block; give the slot count back
-          atomicAdd(&counters[C_HEAP_FREE], 1);
-          atomicAdd(&counters[C_ALLOC_FAIL], 1);
-        }
+        give_block(h, claimed, key, base - 1 - rank);
       }
     }
-    // advance the DDA
-    if (active) {
-      bool done;
-      if (tmx < tmy && tmx < tmz) { cx += sx; done = (cx == ex); tmx += tdx; }
-      else if (tmz < tmy) { cz += sz; done = (cz == ez); tmz += tdz; }
-      else { cy += sy; done = (cy == ey); tmy += tdy; }
-      ++iters;
-      if (done || iters >= MAX_DDA_ITERS) active = false;
-    }
   }
-  if (hw_local > 0) atomicMax(&counters[C_HIGH_WATER], hw_local);
 }
 
 // ---------------------------------------------------------------------------------------------------
 // K3: compactify.  Scans the block directory (8 B per heap slot up to the high-water mark -- not the
-// 16 B x buckets x 10 hash table upstream scans) and appends the slots whose block is in the frustum,
-// one atomic per wave.  all_live != 0 skips the frustum test (used by export / GC).
+// 16 B x buckets x 10 hash table upstream scans) and appends the slots whose block is in the frustum.
+// 1024 directory entries per workgroup, ballot prefix sums inside the waves, one LDS exchange and ONE
+// global atomic per workgroup (a single counter word saturates at ~88 atomics/us on this chip).
+// all_live != 0 skips the frustum test (used by export / GC).
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_compactify(const uint64_t* __restrict__ block_keys, int32_t* __restrict__ compact,
                                                     int32_t* counters, int counter_id, int all_live, ParamsK P, FrameK F) {
+  __shared__ int s_wtot[4];
+  __shared__ int s_base;
   const int hw = counters[C_HIGH_WATER];
-  const int lane = threadIdx.x & 63;
-  for (int base = blockIdx.x * 256; base < hw; base += gridDim.x * 256) {
-    const int i = base + threadIdx.x;
-    bool in = false;
-    if (i < hw) {
-      const uint64_t k = block_keys[i];
-      if (k != KEY_EMPTY) {
-        if (all_live) in = true;
-        else {
-          int bx, by, bz;
-          unpack_key(k, bx, by, bz);
-          in = block_in_frustum(P, F, bx, by, bz);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int base = blockIdx.x * 1024; base < hw; base += gridDim.x * 1024) {
+    bool in[4];
+    int rank[4];
+    int wtotal = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int i = base + j * 256 + threadIdx.x;
+      in[j] = false;
+      if (i < hw) {
+        const uint64_t k = block_keys[i];
+        if (k != KEY_EMPTY) {
+          if (all_live) in[j] = true;
+          else {
+            int bx, by, bz;
+            unpack_key(k, bx, by, bz);
+            in[j] = block_in_frustum(P, F, bx, by, bz);
+          }
         }
       }
+      const uint64_t m = __ballot(in[j]);
+      rank[j] = wtotal + __popcll((unsigned long long)(m & ((1ull << lane) - 1ull)));
+      wtotal += __popcll((unsigned long long)m);
     }
-    const uint64_t m = __ballot(in);
-    if (m != 0ull) {
-      const int first = __ffsll((unsigned long long)m) - 1;
-      int off = 0;
-      if (lane == first) off = atomicAdd(&counters[counter_id], __popcll((unsigned long long)m));
-      off = __shfl(off, first);
-      if (in) compact[off + __popcll((unsigned long long)(m & ((1ull << lane) - 1ull)))] = i;
+    if (lane == 0) s_wtot[wave] = wtotal;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int total = s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
+      s_base = total ? atomicAdd(&counters[counter_id], total) : 0;
     }
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wave; w++) off += s_wtot[w];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (in[j]) compact[off + rank[j]] = base + j * 256 + threadIdx.x;
+    __syncthreads();
   }
 }
 
@@ -377,12 +485,12 @@ template <int SIGN, bool COLOR>
 __global__ __launch_bounds__(256) void k_integrate(uint4* __restrict__ voxels, const uint64_t* __restrict__ block_keys,
                                                    const int32_t* __restrict__ compact, const float* __restrict__ depthf,
                                                    const uint32_t* __restrict__ color, int32_t* counters,
-                                                   int32_t* host_mirror, ParamsK P, FrameK F) {
-  const int n = counters[C_COMPACT];
+                                                   int32_t* host_mirror, int compact_counter, ParamsK P, FrameK F) {
+  const int n = counters[compact_counter];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    counters[C_LAST_BLOCKS] = n;
+    atomicExch(&counters[C_LAST_BLOCKS], n);  // counters share a cache line with words the front stream updates atomically
     atomicAdd(reinterpret_cast<unsigned long long*>(&counters[C_TOTAL_LO]), (unsigned long long)n);
     if (host_mirror) *host_mirror = n;
   }
@@ -488,28 +596,46 @@ __global__ __launch_bounds__(256) void k_gather(const uint4* __restrict__ voxels
 // ======================================================================================================
 // host side
 // ======================================================================================================
+struct sf_fuser;
+static hipError_t sf_quiesce(sf_fuser* f);
 struct sf_fuser {
   sf_params p;
   ParamsK pk;
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;  // integrate / deintegrate and everything synchronous
+  hipStream_t front = nullptr;   // pre-pass, allocation, compaction of the NEXT frame (overlaps integrate)
+  hipEvent_t ev_compact[2] = {nullptr, nullptr};   // front: frame slot ready for integrate
+  hipEvent_t ev_fused[2] = {nullptr, nullptr};     // stream: frame slot consumed
+  int slot = 0;
+  bool overlap = true;  // SF_NO_OVERLAP=1 runs everything on one stream
+  float* depthf2[2] = {nullptr, nullptr};
+  uint32_t* color2[2] = {nullptr, nullptr};
+  int32_t* compact2[2] = {nullptr, nullptr};
   HashEntry* table = nullptr;
   int32_t* heap = nullptr;
   uint64_t* block_keys = nullptr;
   uint4* voxels = nullptr;
-  float* depthf = nullptr;
-  uint32_t* color = nullptr;
-  int32_t* compact = nullptr;
+  int32_t* compact = nullptr;  // alias of compact2[0], used by the synchronous paths (export, GC)
   int32_t* counters = nullptr;
   void* staging_depth = nullptr;  // device copies of host-supplied frames
   void* staging_rgb = nullptr;
   int32_t* host_mirror = nullptr;  // pinned, device-visible: N_blk of the most recent integrate
   int num_cus = 256;
+  bool alloc_win64 = false;  // 64^3-block LDS window when a ray segment spans more than ~20 blocks
+  int alloc_dbg = 0;  // SF_ALLOC_DEBUG: timing experiments only (1 = skip phase 2, 2 = skip LDS inserts)
+  int compact_grid = 1024;  // 1024 directory entries per workgroup, grid-stride beyond
   uint64_t frames_integrated = 0, frames_skipped = 0;
   bool profile = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   size_t events_used = 0;
 };
+
+static hipError_t sf_quiesce(sf_fuser* f) {
+  hipError_t e = hipSuccess;
+  if (f->front) e = hipStreamSynchronize(f->front);
+  const hipError_t e2 = hipStreamSynchronize(f->stream);
+  return e != hipSuccess ? e : e2;
+}
 
 namespace {
 
@@ -552,15 +678,30 @@ int run_frame(sf_fuser* f, const void* d_depth, const void* d_rgb, const float* 
     return sf::fail(SF_ERR_SKIPPED, "frame skipped: camToWorld is -inf (tracking lost)");
   }
   const int n = f->p.depth_width * f->p.depth_height;
+  // Two-stream software pipeline: the front stream prepares frame slot `sl` (pre-pass, allocation,
+  // compaction) while the back stream is still integrating the previous frame out of the other slot.
+  // Allocation only touches new hash entries / heap slots, integrate only the blocks of its own compact
+  // list, so the two never write the same data; slot reuse is ordered by ev_fused[sl].
+  const int sl = f->slot;
+  f->slot ^= 1;
+  const int cc = sl ? (int)C_COMPACT_B : (int)C_COMPACT;
+  hipStream_t sa = f->overlap ? f->front : f->stream;
   hipStream_t s = f->stream;
-  hipLaunchKernelGGL(k_prepass, dim3((n / 8 + 255) / 256 + 1), dim3(256), 0, s, (const uint16_t*)d_depth, (const uint8_t*)d_rgb,
-                     f->depthf, f->color, n, f->p.depth_shift, f->p.depth_min, f->p.depth_max, f->counters);
+  if (f->overlap) (void)hipStreamWaitEvent(sa, f->ev_fused[sl], 0);
+  hipLaunchKernelGGL(k_prepass, dim3((n / 8 + 255) / 256 + 1), dim3(256), 0, sa, (const uint16_t*)d_depth, (const uint8_t*)d_rgb,
+                     f->depthf2[sl], f->color2[sl], n, f->p.depth_shift, f->p.depth_min, f->p.depth_max, f->counters, cc);
   if (sign > 0) {
-    hipLaunchKernelGGL(k_alloc, dim3((f->p.depth_width + 15) / 16, (f->p.depth_height + 15) / 16), dim3(256), 0, s, f->depthf,
-                       f->table, f->heap, f->block_keys, f->counters, f->pk, fk);
+    const dim3 ag((f->p.depth_width + 15) / 16, (f->p.depth_height + 15) / 16);
+    if (f->alloc_win64)
+      hipLaunchKernelGGL(k_alloc<6>, ag, dim3(256), 0, sa, f->depthf2[sl], f->table, f->heap, f->block_keys, f->counters, f->pk, fk, f->alloc_dbg);
+    else
+      hipLaunchKernelGGL(k_alloc<5>, ag, dim3(256), 0, sa, f->depthf2[sl], f->table, f->heap, f->block_keys, f->counters, f->pk, fk, f->alloc_dbg);
   }
-  hipLaunchKernelGGL(k_compactify, dim3(f->num_cus * 2), dim3(256), 0, s, f->block_keys, f->compact, f->counters, (int)C_COMPACT, 0,
-                     f->pk, fk);
+  hipLaunchKernelGGL(k_compactify, dim3(f->compact_grid), dim3(256), 0, sa, f->block_keys, f->compact2[sl], f->counters, cc, 0, f->pk, fk);
+  if (f->overlap) {
+    (void)hipEventRecord(f->ev_compact[sl], sa);
+    (void)hipStreamWaitEvent(s, f->ev_compact[sl], 0);
+  }
   // grid: enough workgroups (4 blocks each) for the last N_blk the device reported, +25 %; the kernel's
   // grid-stride loop covers any excess, surplus workgroups exit at once.
   const int last = *f->host_mirror;
@@ -581,13 +722,14 @@ int run_frame(sf_fuser* f, const void* d_depth, const void* d_rgb, const float* 
     f->events_used++;
     (void)hipEventRecord(e0, s);
   }
-#define LAUNCH_INT(SG, CL)                                                                                               \
-  hipLaunchKernelGGL((k_integrate<SG, CL>), dim3(grid), dim3(256), 0, s, f->voxels, f->block_keys, f->compact, f->depthf, \
-                     f->color, f->counters, f->host_mirror, f->pk, fk)
+#define LAUNCH_INT(SG, CL)                                                                                                         \
+  hipLaunchKernelGGL((k_integrate<SG, CL>), dim3(grid), dim3(256), 0, s, f->voxels, f->block_keys, f->compact2[sl], f->depthf2[sl], \
+                     f->color2[sl], f->counters, f->host_mirror, cc, f->pk, fk)
   if (sign > 0) { if (col) LAUNCH_INT(1, true); else LAUNCH_INT(1, false); }
   else          { if (col) LAUNCH_INT(-1, true); else LAUNCH_INT(-1, false); }
 #undef LAUNCH_INT
   if (f->profile) (void)hipEventRecord(e1, s);
+  if (f->overlap) (void)hipEventRecord(f->ev_fused[sl], s);
   const hipError_t err = hipGetLastError();
   if (err != hipSuccess) return sf::fail(SF_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(err));
   f->frames_integrated++;
@@ -622,6 +764,12 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
   if (f->p.weight_max > 255) f->p.weight_max = 255;  // uchar weight saturates (SURVEY App. C decision)
   if (f->p.weight_max < 1) f->p.weight_max = 1;
   f->device = device;
+  if (const char* e = getenv("SF_ALLOC_DEBUG")) f->alloc_dbg = atoi(e);
+  {
+    // longest ray segment 2 * trunc(max distance) in blocks decides the LDS window size of k_alloc
+    const float seg = 2.0f * (p->trunc_base + p->trunc_scale * p->max_integration_dist) / (8.0f * p->voxel_size);
+    f->alloc_win64 = seg > 20.0f;
+  }
   ParamsK& k = f->pk;
   k.W = p->depth_width; k.H = p->depth_height; k.fx = p->fx; k.fy = p->fy; k.mx = p->mx; k.my = p->my;
   k.depth_shift = p->depth_shift; k.dmin = p->depth_min; k.dmax = p->depth_max; k.voxel = p->voxel_size;
@@ -632,6 +780,8 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
   hipDeviceProp_t prop;
   SF_HIP_CHECK(hipGetDeviceProperties(&prop, device));
   f->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  f->compact_grid = (int)((k.num_blocks + 1023) / 1024);
+  if (f->compact_grid > f->num_cus * 8) f->compact_grid = f->num_cus * 8;
   const size_t npx = (size_t)k.W * k.H;
 #define SF_ALLOC(ptr, bytes)                                                                      \
   do {                                                                                            \
@@ -642,13 +792,29 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
     }                                                                                             \
   } while (0)
   SF_HIP_CHECK(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
+  {
+    // the front stream runs short latency-bound kernels that must slip in between the workgroups of the
+    // bandwidth-bound integrate kernel: give it the highest priority the device offers
+    int prio_lo = 0, prio_hi = 0;
+    SF_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    if (getenv("SF_NO_PRIORITY")) prio_hi = prio_lo;
+    SF_HIP_CHECK(hipStreamCreateWithPriority(&f->front, hipStreamNonBlocking, prio_hi));
+  }
+  for (int q = 0; q < 2; q++) {
+    SF_HIP_CHECK(hipEventCreateWithFlags(&f->ev_compact[q], hipEventDisableTiming));
+    SF_HIP_CHECK(hipEventCreateWithFlags(&f->ev_fused[q], hipEventDisableTiming));
+  }
+  if (const char* e = getenv("SF_NO_OVERLAP")) f->overlap = atoi(e) == 0;
   SF_ALLOC(f->table, (size_t)k.total_slots * sizeof(HashEntry));
   SF_ALLOC(f->heap, (size_t)k.num_blocks * 4);
   SF_ALLOC(f->block_keys, (size_t)k.num_blocks * 8);
   SF_ALLOC(f->voxels, (size_t)k.num_blocks * 4096);
-  SF_ALLOC(f->depthf, npx * 4);
-  SF_ALLOC(f->color, npx * 4);
-  SF_ALLOC(f->compact, (size_t)k.num_blocks * 4);
+  for (int q = 0; q < 2; q++) {
+    SF_ALLOC(f->depthf2[q], npx * 4);
+    SF_ALLOC(f->color2[q], npx * 4);
+    SF_ALLOC(f->compact2[q], (size_t)k.num_blocks * 4);
+  }
+  f->compact = f->compact2[0];
   SF_ALLOC(f->counters, C_COUNT * 4);
   SF_ALLOC(f->staging_depth, npx * 2);
   SF_ALLOC(f->staging_rgb, npx * 3);
@@ -661,7 +827,7 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
   hipLaunchKernelGGL(k_init_heap, dim3((k.num_blocks + 255) / 256), dim3(256), 0, f->stream, f->heap, f->block_keys, (int)k.num_blocks);
   const int32_t free0 = (int32_t)k.num_blocks;
   SF_HIP_CHECK(hipMemcpyAsync(&f->counters[C_HEAP_FREE], &free0, 4, hipMemcpyHostToDevice, f->stream));
-  SF_HIP_CHECK(hipStreamSynchronize(f->stream));
+  SF_HIP_CHECK(sf_quiesce(f));
   *out = f;
   return SF_OK;
 }
@@ -672,7 +838,10 @@ SF_API void sf_fuser_destroy(sf_fuser* f) {
   if (f->stream) (void)hipStreamSynchronize(f->stream);
   for (auto& e : f->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   (void)hipFree(f->table); (void)hipFree(f->heap); (void)hipFree(f->block_keys); (void)hipFree(f->voxels);
-  (void)hipFree(f->depthf); (void)hipFree(f->color); (void)hipFree(f->compact); (void)hipFree(f->counters);
+  for (int q = 0; q < 2; q++) { (void)hipFree(f->depthf2[q]); (void)hipFree(f->color2[q]); (void)hipFree(f->compact2[q]); }
+  (void)hipFree(f->counters);
+  for (int q = 0; q < 2; q++) { if (f->ev_compact[q]) (void)hipEventDestroy(f->ev_compact[q]); if (f->ev_fused[q]) (void)hipEventDestroy(f->ev_fused[q]); }
+  if (f->front) { (void)hipStreamSynchronize(f->front); (void)hipStreamDestroy(f->front); }
   (void)hipFree(f->staging_depth); (void)hipFree(f->staging_rgb);
   if (f->host_mirror) (void)hipHostFree(f->host_mirror);
   if (f->stream) (void)hipStreamDestroy(f->stream);
@@ -685,9 +854,10 @@ static int fuse_host(sf_fuser* f, const uint16_t* depth, const uint8_t* rgb, con
   SF_HIP_CHECK(hipSetDevice(f->device));
   const size_t npx = (size_t)f->p.depth_width * f->p.depth_height;
   // the staging buffer is reused: wait for the previous frame's kernels before overwriting it
-  SF_HIP_CHECK(hipStreamSynchronize(f->stream));
-  SF_HIP_CHECK(hipMemcpyAsync(f->staging_depth, depth, npx * 2, hipMemcpyHostToDevice, f->stream));
-  if (rgb) SF_HIP_CHECK(hipMemcpyAsync(f->staging_rgb, rgb, npx * 3, hipMemcpyHostToDevice, f->stream));
+  SF_HIP_CHECK(sf_quiesce(f));
+  hipStream_t in_stream = f->overlap ? f->front : f->stream;  // the stream the pre-pass reads the frame on
+  SF_HIP_CHECK(hipMemcpyAsync(f->staging_depth, depth, npx * 2, hipMemcpyHostToDevice, in_stream));
+  if (rgb) SF_HIP_CHECK(hipMemcpyAsync(f->staging_rgb, rgb, npx * 3, hipMemcpyHostToDevice, in_stream));
   return run_frame(f, f->staging_depth, rgb ? f->staging_rgb : nullptr, pose, sign);
 }
 
@@ -720,7 +890,7 @@ SF_API int sf_fuser_integrate_batch_device(sf_fuser* f, const void* d_depth, uin
 SF_API int sf_fuser_sync(sf_fuser* f) {
   if (!f) return sf::fail(SF_ERR_INVALID_ARG, "NULL fuser");
   SF_HIP_CHECK(hipSetDevice(f->device));
-  SF_HIP_CHECK(hipStreamSynchronize(f->stream));
+  SF_HIP_CHECK(sf_quiesce(f));
   return SF_OK;
 }
 SF_API void* sf_fuser_stream(sf_fuser* f) { return f ? (void*)f->stream : nullptr; }
@@ -730,7 +900,7 @@ SF_API int sf_fuser_stats(sf_fuser* f, sf_stats* out) {
   SF_HIP_CHECK(hipSetDevice(f->device));
   int32_t c[C_COUNT];
   SF_HIP_CHECK(hipMemcpyAsync(c, f->counters, sizeof(c), hipMemcpyDeviceToHost, f->stream));
-  SF_HIP_CHECK(hipStreamSynchronize(f->stream));
+  SF_HIP_CHECK(sf_quiesce(f));
   std::memset(out, 0, sizeof(*out));
   out->frames_integrated = f->frames_integrated;
   out->frames_skipped = f->frames_skipped;
@@ -754,7 +924,7 @@ SF_API int sf_fuser_profile_enable(sf_fuser* f, int on) {
 SF_API int sf_fuser_profile_read(sf_fuser* f, double* integrate_ms, uint64_t* launches, uint64_t* blocks) {
   if (!f) return sf::fail(SF_ERR_INVALID_ARG, "NULL fuser");
   SF_HIP_CHECK(hipSetDevice(f->device));
-  SF_HIP_CHECK(hipStreamSynchronize(f->stream));
+  SF_HIP_CHECK(sf_quiesce(f));
   double ms = 0;
   for (size_t i = 0; i < f->events_used; i++) {
     float t = 0;
@@ -773,13 +943,14 @@ SF_API int sf_fuser_profile_read(sf_fuser* f, double* integrate_ms, uint64_t* la
 }
 
 static int compact_live(sf_fuser* f, int32_t* n_out) {
+  SF_HIP_CHECK(sf_quiesce(f));
   FrameK dummy;
   std::memset(&dummy, 0, sizeof(dummy));
   SF_HIP_CHECK(hipMemsetAsync(&f->counters[C_EXPORT], 0, 4, f->stream));
-  hipLaunchKernelGGL(k_compactify, dim3(f->num_cus * 2), dim3(256), 0, f->stream, f->block_keys, f->compact, f->counters, (int)C_EXPORT, 1,
+  hipLaunchKernelGGL(k_compactify, dim3(f->compact_grid), dim3(256), 0, f->stream, f->block_keys, f->compact, f->counters, (int)C_EXPORT, 1,
                      f->pk, dummy);
   SF_HIP_CHECK(hipMemcpyAsync(n_out, &f->counters[C_EXPORT], 4, hipMemcpyDeviceToHost, f->stream));
-  SF_HIP_CHECK(hipStreamSynchronize(f->stream));
+  SF_HIP_CHECK(sf_quiesce(f));
   return SF_OK;
 }
 
@@ -796,7 +967,7 @@ SF_API int sf_fuser_garbage_collect(sf_fuser* f, uint32_t* freed) {
                        f->table, f->heap, f->counters, thr, f->pk);
   int32_t fr = 0;
   SF_HIP_CHECK(hipMemcpyAsync(&fr, &f->counters[C_GC_FREED], 4, hipMemcpyDeviceToHost, f->stream));
-  SF_HIP_CHECK(hipStreamSynchronize(f->stream));
+  SF_HIP_CHECK(sf_quiesce(f));
   if (freed) *freed = (uint32_t)fr;
   return SF_OK;
 }
@@ -819,7 +990,7 @@ SF_API int sf_fuser_export_blocks(sf_fuser* f, int32_t* coords, void* voxels, ui
   hipLaunchKernelGGL(k_gather, dim3(n < 65535 ? n : 65535), dim3(256), 0, f->stream, f->voxels, f->block_keys, f->compact, n, d_coords, d_vox);
   hipError_t e1 = hipMemcpyAsync(coords, d_coords, (size_t)n * 12, hipMemcpyDeviceToHost, f->stream);
   hipError_t e2 = hipMemcpyAsync(voxels, d_vox, (size_t)n * 4096, hipMemcpyDeviceToHost, f->stream);
-  hipError_t e3 = hipStreamSynchronize(f->stream);
+  hipError_t e3 = sf_quiesce(f);
   (void)hipFree(d_coords);
   (void)hipFree(d_vox);
   if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return sf::fail(SF_ERR_DEVICE, "export copy failed");
