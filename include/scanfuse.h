@@ -117,6 +117,63 @@ int sf_device_upload(void* dst, const void* src, uint64_t bytes);
 int sf_device_download(void* dst, const void* src, uint64_t bytes);
 
 /* ------------------------------------------------------------------------------------------------
+ * zlib codec used for .sens depth blobs.  Replaces stb::stbi_zlib_decode_malloc / stbi_zlib_compress as
+ * called from SensReader/c++/src/sensorData.h:703-709 and :659-670.  Like the reference reader the
+ * decoder validates the 2-byte zlib header and does NOT verify the trailing Adler-32.
+ * ---------------------------------------------------------------------------------------------- */
+int sf_zlib_inflate(const void* src, uint64_t src_bytes, void* dst, uint64_t dst_capacity, uint64_t* out_bytes);
+int sf_zlib_deflate(const void* src, uint64_t src_bytes, void* dst, uint64_t dst_capacity, uint64_t* out_bytes);
+uint64_t sf_zlib_deflate_bound(uint64_t src_bytes);
+
+/* ------------------------------------------------------------------------------------------------
+ * .sens v4 container.  Replaces ml::SensorData (SensReader/c++/src/sensorData.h:285-1936):
+ *   sf_sens_open          SensorData(filename) / loadFromFile          :855-859, :1250-1290
+ *   sf_sens_get_info      header members                               :1257-1273
+ *   sf_sens_decode_depth  decompressDepthAlloc(frameIdx)               :943-946 (strict bounds check; the
+ *                         reference's `>` off-by-one at :944 is not reproduced); caller owns dst (W*H u16)
+ *   sf_sens_decode_color  decompressColorAlloc(frameIdx)               :933-936 (RAW and baseline JPEG)
+ *   sf_sens_pose          m_frames[i].getCameraToWorld()               :432; *valid = 0 for the all -inf
+ *                         "tracking lost" pose (:382, SensReader/c++/README.txt:55-57)
+ *   sf_sens_create/add_frame/save   initDefault / addFrame / saveToFile  :891-921, :1101-1109
+ *   sf_sens_set_pose      RGBDFrame::setCameraToWorld                  :436 (trajectory rewrite by `recons`)
+ * The reference throws MLibException on open / version errors (:883-886, :1253-1255); here every failure is
+ * a negative sf_status.  The file is memory-mapped; compressed blobs are never copied.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct sf_sens sf_sens;
+
+typedef struct sf_sens_info {
+  uint32_t version;                    /* 4 */
+  uint32_t color_width, color_height, depth_width, depth_height;
+  int32_t color_compression;           /* -1 unknown, 0 raw, 1 png, 2 jpeg   (sensorData.h:346-351) */
+  int32_t depth_compression;           /* -1 unknown, 0 raw u16, 1 zlib u16, 2 occi u16 (:352-357)  */
+  float depth_shift;
+  uint64_t num_frames, num_imu;
+  float color_intrinsic[16], color_extrinsic[16], depth_intrinsic[16], depth_extrinsic[16]; /* row-major */
+  char sensor_name[256];
+} sf_sens_info;
+
+typedef struct sf_sens_frame_meta_t {
+  uint64_t timestamp_color, timestamp_depth;  /* microseconds (sensorData.h:440-457) */
+  uint64_t color_bytes, depth_bytes;          /* compressed sizes */
+} sf_sens_frame_meta_t;
+
+int sf_sens_open(const char* path, sf_sens** out);
+void sf_sens_close(sf_sens* s);
+int sf_sens_get_info(const sf_sens* s, sf_sens_info* out);
+int sf_sens_decode_depth(const sf_sens* s, uint64_t frame, uint16_t* dst);
+int sf_sens_decode_color(const sf_sens* s, uint64_t frame, uint8_t* dst_rgb);
+int sf_sens_pose(const sf_sens* s, uint64_t frame, float out16[16], int* valid);
+int sf_sens_frame_meta(const sf_sens* s, uint64_t frame, sf_sens_frame_meta_t* out);
+/* Writer.  `header` supplies everything but num_frames / num_imu.  color = W*H*3 RGB bytes for TYPE_RAW, an
+ * already encoded blob for TYPE_JPEG / TYPE_PNG, or NULL / 0 for no colour; depth = W*H u16, compressed as
+ * header->depth_compression says (0 raw, 1 zlib). */
+int sf_sens_create(const sf_sens_info* header, sf_sens** out);
+int sf_sens_add_frame(sf_sens* s, const uint8_t* color, uint64_t color_bytes, const uint16_t* depth, const float pose[16],
+                      uint64_t timestamp_color, uint64_t timestamp_depth);
+int sf_sens_set_pose(sf_sens* s, uint64_t frame, const float pose[16]);
+int sf_sens_save(const sf_sens* s, const char* path);
+
+/* ------------------------------------------------------------------------------------------------
  * Synthetic stream source (benchmark input): renders frames
  * [first_frame, first_frame+n) of the `total_frames`-frame box-room walk as u16 millimetre depth directly
  * into device memory and returns the n camToWorld poses (n*16 floats, host).

@@ -1,0 +1,331 @@
+// jpeg.cpp -- baseline (SOF0 / SOF1 Huffman, 8-bit) JPEG decoder for .sens colour frames.
+//
+// Replaces stb::stbi_load_from_memory as called by RGBDFrame::decompressColorAlloc_stb
+// (SensReader/c++/src/sensorData.h:609-616 -> sensorData/stb_image.h:1067,3411).  ScanNet colour frames are
+// baseline YCbCr 4:2:0 / 4:2:2 JPEGs written by the capture app; progressive streams are rejected with
+// SF_ERR_UNSUPPORTED.  Written from ITU-T T.81: exact separable float IDCT, triangle-filter ("fancy") 2x
+// chroma upsampling, BT.601 full-range YCbCr -> RGB.  T.81 does not define bit-exact decoding, so parity
+// with the reference's integer IDCT is a tolerance (tests/test_sens.py: max |diff| <= 4 levels, mean < 0.5).
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+struct HuffDC_AC {
+  // canonical decode tables (T.81 annex F.2.2.3) + 9-bit lookahead
+  uint8_t bits[17];
+  uint8_t vals[256];
+  int32_t mincode[17], maxcode[18], valptr[17];
+  uint16_t look[512];  // (len << 8) | symbol, 0 = slow path
+  bool present = false;
+  void build() {
+    int code = 0, k = 0;
+    for (int l = 1; l <= 16; l++) {
+      valptr[l] = k;
+      mincode[l] = code;
+      code += bits[l];
+      k += bits[l];
+      maxcode[l] = bits[l] ? code - 1 : -1;
+      code <<= 1;
+    }
+    maxcode[17] = 0x7FFFFFFF;
+    std::memset(look, 0, sizeof(look));
+    code = 0; k = 0;
+    for (int l = 1; l <= 9; l++) {
+      for (int i = 0; i < bits[l]; i++, k++) {
+        const int first = code << (9 - l);
+        for (int f = 0; f < (1 << (9 - l)); f++) look[first + f] = (uint16_t)((l << 8) | vals[k]);
+        code++;
+      }
+      code <<= 1;
+    }
+    present = true;
+  }
+};
+
+struct Component {
+  int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0;
+  int pred = 0;
+  int bw = 0, bh = 0;  // plane size in samples (padded to whole MCUs)
+  std::vector<uint8_t> plane;
+};
+
+struct BitSrc {
+  const uint8_t* p;
+  const uint8_t* end;
+  uint32_t buf = 0;
+  int cnt = 0;
+  bool hit_marker = false;
+  inline void fill() {
+    while (cnt <= 24) {
+      uint32_t b = 0;
+      if (!hit_marker && p < end) {
+        b = *p;
+        if (b == 0xFF) {
+          const uint8_t n = (p + 1 < end) ? p[1] : 0xD9;
+          if (n == 0) p += 2;
+          else { hit_marker = true; b = 0; }
+        } else p++;
+      }
+      buf |= b << (24 - cnt);
+      cnt += 8;
+    }
+  }
+  inline int peek(int n) { return (int)(buf >> (32 - n)); }
+  inline void drop(int n) { buf <<= n; cnt -= n; }
+  inline int get(int n) {
+    if (n == 0) return 0;
+    if (cnt < n) fill();
+    const int v = peek(n);
+    drop(n);
+    return v;
+  }
+  void reset() { buf = 0; cnt = 0; hit_marker = false; }
+};
+
+inline int extend(int v, int t) { return v < (1 << (t - 1)) ? v - (1 << t) + 1 : v; }
+
+inline int decode_huff(BitSrc& bs, const HuffDC_AC& h) {
+  if (bs.cnt < 16) bs.fill();
+  const uint16_t e = h.look[bs.peek(9)];
+  if (e) { bs.drop(e >> 8); return e & 0xFF; }
+  int code = bs.peek(9);
+  int l = 9;
+  const uint32_t all = bs.buf;
+  while (l < 17 && code > h.maxcode[l]) {
+    l++;
+    code = (int)(all >> (32 - l));
+  }
+  if (l > 16) return -1;
+  bs.drop(l);
+  return h.vals[h.valptr[l] + code - h.mincode[l]];
+}
+
+const uint8_t ZIGZAG[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                            35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+struct IdctTable {
+  float c[8][8];  // c[x][u] = 0.5 * C(u) * cos((2x+1) u pi / 16)
+  IdctTable() {
+    for (int x = 0; x < 8; x++)
+      for (int u = 0; u < 8; u++) c[x][u] = (float)(0.5 * (u == 0 ? std::sqrt(0.5) : 1.0) * std::cos((2 * x + 1) * u * 3.14159265358979323846 / 16.0));
+  }
+};
+const IdctTable& idct_table() { static const IdctTable t; return t; }
+
+void idct_block(const float* in, uint8_t* out, int stride) {
+  const IdctTable& T = idct_table();
+  float tmp[64];
+  for (int v = 0; v < 8; v++)      // rows: over u
+    for (int x = 0; x < 8; x++) {
+      float s = 0;
+      for (int u = 0; u < 8; u++) s += T.c[x][u] * in[v * 8 + u];
+      tmp[v * 8 + x] = s;
+    }
+  for (int x = 0; x < 8; x++)
+    for (int y = 0; y < 8; y++) {
+      float s = 0;
+      for (int v = 0; v < 8; v++) s += T.c[y][v] * tmp[v * 8 + x];
+      const int q = (int)std::lrintf(s + 128.0f);
+      out[y * stride + x] = (uint8_t)(q < 0 ? 0 : (q > 255 ? 255 : q));
+    }
+}
+
+inline uint8_t clamp8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+}  // namespace
+
+int jpeg_decode_rgb(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t expect_w, uint32_t expect_h) {
+  if (n < 4 || data[0] != 0xFF || data[1] != 0xD8) return sf::fail(SF_ERR_FORMAT, "jpeg: missing SOI");
+  uint16_t qt[4][64];
+  bool qt_ok[4] = {false, false, false, false};
+  HuffDC_AC hdc[4], hac[4];
+  Component comp[3];
+  int ncomp = 0, width = 0, height = 0, restart = 0, hmax = 1, vmax = 1;
+  uint64_t pos = 2;
+  bool have_sof = false;
+  auto u16 = [&](uint64_t at) { return (int)((data[at] << 8) | data[at + 1]); };
+  while (true) {
+    if (pos + 4 > n) return sf::fail(SF_ERR_FORMAT, "jpeg: truncated before SOS");
+    if (data[pos] != 0xFF) return sf::fail(SF_ERR_FORMAT, "jpeg: expected a marker");
+    while (pos < n && data[pos] == 0xFF) pos++;
+    const int m = data[pos++];
+    if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
+    if (pos + 2 > n) return sf::fail(SF_ERR_FORMAT, "jpeg: truncated segment");
+    const int len = u16(pos);
+    if (len < 2 || pos + len > n) return sf::fail(SF_ERR_FORMAT, "jpeg: bad segment length");
+    const uint64_t seg = pos + 2, seg_end = pos + len;
+    if (m == 0xDB) {
+      uint64_t q = seg;
+      while (q < seg_end) {
+        const int pq = data[q] >> 4, tq = data[q] & 15;
+        q++;
+        if (tq > 3 || q + (pq ? 128 : 64) > seg_end) return sf::fail(SF_ERR_FORMAT, "jpeg: bad DQT");
+        for (int i = 0; i < 64; i++) { qt[tq][ZIGZAG[i]] = pq ? (uint16_t)u16(q + 2 * i) : data[q + i]; }
+        q += pq ? 128 : 64;
+        qt_ok[tq] = true;
+      }
+    } else if (m == 0xC4) {
+      uint64_t q = seg;
+      while (q < seg_end) {
+        const int tc = data[q] >> 4, th = data[q] & 15;
+        q++;
+        if (tc > 1 || th > 3 || q + 16 > seg_end) return sf::fail(SF_ERR_FORMAT, "jpeg: bad DHT");
+        HuffDC_AC& h = tc ? hac[th] : hdc[th];
+        int total = 0;
+        h.bits[0] = 0;
+        for (int i = 1; i <= 16; i++) { h.bits[i] = data[q + i - 1]; total += h.bits[i]; }
+        q += 16;
+        if (total > 256 || q + total > seg_end) return sf::fail(SF_ERR_FORMAT, "jpeg: bad DHT counts");
+        std::memcpy(h.vals, data + q, (size_t)total);
+        q += total;
+        h.build();
+      }
+    } else if (m == 0xC0 || m == 0xC1) {
+      if (len < 8 || data[seg] != 8) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: only 8-bit precision is supported");
+      height = u16(seg + 1); width = u16(seg + 3); ncomp = data[seg + 5];
+      if (ncomp != 1 && ncomp != 3) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: %d components not supported", ncomp);
+      if (len < 8 + 3 * ncomp || width == 0 || height == 0) return sf::fail(SF_ERR_FORMAT, "jpeg: bad SOF");
+      for (int i = 0; i < ncomp; i++) {
+        comp[i].id = data[seg + 6 + 3 * i];
+        comp[i].h = data[seg + 7 + 3 * i] >> 4; comp[i].v = data[seg + 7 + 3 * i] & 15;
+        comp[i].tq = data[seg + 8 + 3 * i];
+        if (comp[i].h < 1 || comp[i].h > 4 || comp[i].v < 1 || comp[i].v > 4 || comp[i].tq > 3) return sf::fail(SF_ERR_FORMAT, "jpeg: bad sampling factors");
+        hmax = comp[i].h > hmax ? comp[i].h : hmax; vmax = comp[i].v > vmax ? comp[i].v : vmax;
+      }
+      have_sof = true;
+    } else if (m == 0xC2 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC)) {
+      return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: progressive / lossless / arithmetic JPEG (SOF%d) is not supported", m - 0xC0);
+    } else if (m == 0xDD) {
+      restart = u16(seg);
+    } else if (m == 0xDA) {
+      if (!have_sof) return sf::fail(SF_ERR_FORMAT, "jpeg: SOS before SOF");
+      const int ns = data[seg];
+      if (ns != ncomp || len < 6 + 2 * ns) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: non-interleaved scans are not supported");
+      for (int i = 0; i < ns; i++) {
+        const int cid = data[seg + 1 + 2 * i];
+        int ci = -1;
+        for (int k = 0; k < ncomp; k++) if (comp[k].id == cid) ci = k;
+        if (ci < 0) return sf::fail(SF_ERR_FORMAT, "jpeg: scan refers to an unknown component");
+        comp[ci].td = data[seg + 2 + 2 * i] >> 4; comp[ci].ta = data[seg + 2 + 2 * i] & 15;
+        if (comp[ci].td > 3 || comp[ci].ta > 3) return sf::fail(SF_ERR_FORMAT, "jpeg: bad table selector");
+      }
+      pos = seg_end;
+      break;
+    } else if (m == 0xD9) {
+      return sf::fail(SF_ERR_FORMAT, "jpeg: EOI before any scan");
+    }
+    pos = seg_end;
+  }
+  if ((uint32_t)width != expect_w || (uint32_t)height != expect_h)
+    return sf::fail(SF_ERR_FORMAT, "jpeg: image is %dx%d, header says %ux%u", width, height, expect_w, expect_h);
+  for (int i = 0; i < ncomp; i++)
+    if (!qt_ok[comp[i].tq] || !hdc[comp[i].td].present || !hac[comp[i].ta].present) return sf::fail(SF_ERR_FORMAT, "jpeg: missing quantisation / Huffman table");
+  const int mcu_w = 8 * hmax, mcu_h = 8 * vmax;
+  const int mcux = (width + mcu_w - 1) / mcu_w, mcuy = (height + mcu_h - 1) / mcu_h;
+  for (int i = 0; i < ncomp; i++) {
+    comp[i].bw = mcux * comp[i].h * 8; comp[i].bh = mcuy * comp[i].v * 8;
+    comp[i].plane.assign((size_t)comp[i].bw * comp[i].bh, 0);
+    comp[i].pred = 0;
+  }
+  BitSrc bs{data + pos, data + n};
+  int todo = restart ? restart : 0x7FFFFFFF;
+  float blk[64];
+  for (int my = 0; my < mcuy; my++)
+    for (int mx = 0; mx < mcux; mx++) {
+      for (int ci = 0; ci < ncomp; ci++) {
+        Component& c = comp[ci];
+        const uint16_t* q = qt[c.tq];
+        for (int by = 0; by < c.v; by++)
+          for (int bx = 0; bx < c.h; bx++) {
+            std::memset(blk, 0, sizeof(blk));
+            const int t = decode_huff(bs, hdc[c.td]);
+            if (t < 0 || t > 11) return sf::fail(SF_ERR_FORMAT, "jpeg: bad DC code");
+            const int diff = t ? extend(bs.get(t), t) : 0;
+            c.pred += diff;
+            blk[0] = (float)(c.pred * (int)q[0]);
+            for (int k = 1; k < 64;) {
+              const int rs = decode_huff(bs, hac[c.ta]);
+              if (rs < 0) return sf::fail(SF_ERR_FORMAT, "jpeg: bad AC code");
+              const int r = rs >> 4, s = rs & 15;
+              if (s == 0) {
+                if (r == 15) { k += 16; continue; }
+                break;
+              }
+              k += r;
+              if (k > 63) return sf::fail(SF_ERR_FORMAT, "jpeg: AC run past the end of the block");
+              const int z = ZIGZAG[k];
+              blk[z] = (float)(extend(bs.get(s), s) * (int)q[z]);
+              k++;
+            }
+            idct_block(blk, c.plane.data() + (size_t)((my * c.v + by) * 8) * c.bw + (mx * c.h + bx) * 8, c.bw);
+          }
+      }
+      if (--todo <= 0) {
+        // restart interval: skip to the RSTn marker, reset predictors
+        bs.reset();
+        while (bs.p + 1 < bs.end && !(bs.p[0] == 0xFF && bs.p[1] >= 0xD0 && bs.p[1] <= 0xD7)) bs.p++;
+        if (bs.p + 1 < bs.end) bs.p += 2;
+        for (int i = 0; i < ncomp; i++) comp[i].pred = 0;
+        todo = restart;
+      }
+    }
+  // upsample + colour convert
+  if (ncomp == 1) {
+    for (int y = 0; y < height; y++)
+      for (int x = 0; x < width; x++) {
+        const uint8_t g = comp[0].plane[(size_t)y * comp[0].bw + x];
+        uint8_t* o = dst + 3 * ((size_t)y * width + x);
+        o[0] = o[1] = o[2] = g;
+      }
+    return SF_OK;
+  }
+  std::vector<uint8_t> up[3];
+  const uint8_t* full[3];
+  int fstride[3];
+  for (int ci = 0; ci < 3; ci++) {
+    Component& c = comp[ci];
+    const int sx = hmax / c.h, sy = vmax / c.v;
+    if (sx == 1 && sy == 1) { full[ci] = c.plane.data(); fstride[ci] = c.bw; continue; }
+    if ((hmax % c.h) || (vmax % c.v)) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: fractional sampling ratios are not supported");
+    const int cw = (width * c.h + hmax - 1) / hmax, ch = (height * c.v + vmax - 1) / vmax;  // valid chroma samples
+    up[ci].assign((size_t)width * height, 0);
+    for (int y = 0; y < height; y++) {
+      // vertical: triangle filter for 2x, nearest otherwise
+      int y0, y1, wy0, wy1;
+      if (sy == 2) { const int cy = y >> 1; y0 = cy; y1 = (y & 1) ? (cy + 1 < ch ? cy + 1 : cy) : (cy > 0 ? cy - 1 : cy); wy0 = 3; wy1 = 1; }
+      else { y0 = y1 = (y / sy < ch ? y / sy : ch - 1); wy0 = 4; wy1 = 0; }
+      const uint8_t* r0 = c.plane.data() + (size_t)y0 * c.bw;
+      const uint8_t* r1 = c.plane.data() + (size_t)y1 * c.bw;
+      uint8_t* o = up[ci].data() + (size_t)y * width;
+      for (int x = 0; x < width; x++) {
+        if (sx == 2) {
+          const int cx = x >> 1;
+          const int cn = (x & 1) ? (cx + 1 < cw ? cx + 1 : cx) : (cx > 0 ? cx - 1 : cx);
+          const int a = wy0 * r0[cx] + wy1 * r1[cx], b = wy0 * r0[cn] + wy1 * r1[cn];  // each scaled by 4
+          o[x] = (uint8_t)((3 * a + b + 8) >> 4);
+        } else {
+          const int cx = x / sx < cw ? x / sx : cw - 1;
+          o[x] = (uint8_t)((wy0 * r0[cx] + wy1 * r1[cx] + 2) >> 2);
+        }
+      }
+    }
+    full[ci] = up[ci].data();
+    fstride[ci] = width;
+  }
+  for (int y = 0; y < height; y++)
+    for (int x = 0; x < width; x++) {
+      const int Y = full[0][(size_t)y * fstride[0] + x];
+      const int cb = full[1][(size_t)y * fstride[1] + x] - 128, cr = full[2][(size_t)y * fstride[2] + x] - 128;
+      uint8_t* o = dst + 3 * ((size_t)y * width + x);
+      // BT.601 full range, 16.16 fixed point
+      o[0] = clamp8((Y * 65536 + 91881 * cr + 32768) >> 16);
+      o[1] = clamp8((Y * 65536 - 22554 * cb - 46802 * cr + 32768) >> 16);
+      o[2] = clamp8((Y * 65536 + 116130 * cb + 32768) >> 16);
+    }
+  return SF_OK;
+}

@@ -1,0 +1,282 @@
+// sens.cpp -- from-scratch reader / writer of the .sens v4 container (little-endian, packed).
+//
+// Layout restated from the reference codec, SensReader/c++/src/sensorData.h:
+//   header  :1257-1273  u32 version(=4) . u64 strlen . name . 4 x mat4f (colour K, colour E, depth K, depth E)
+//                       . i32 colourCompr . i32 depthCompr . u32 cw,ch,dw,dh . f32 depthShift
+//   frames  :1275-1280, :743-754   u64 numFrames ; per frame mat4f camToWorld . u64 tsColor . u64 tsDepth
+//                       . u64 colourBytes . u64 depthBytes . colour blob . depth blob
+//   IMU     :1282-1289, :796-803   u64 numIMU ; per IMU frame 5 x vec3d + u64 = 128 bytes
+// The Python reader's struct formats (SensReader/python/SensorData.py:14-20,54-74) say the same.
+// Unlike the reference (whole file malloc'ed frame by frame, 7 istream::read calls per frame) the file is
+// memory-mapped once and frames are views into the mapping.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+
+#include "sens.h"
+
+int jpeg_decode_rgb(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t expect_w, uint32_t expect_h);  // jpeg.cpp
+
+namespace {
+
+struct Cursor {
+  const uint8_t* p;
+  const uint8_t* end;
+  bool ok = true;
+  template <typename T>
+  T get() {
+    T v{};
+    if ((uint64_t)(end - p) < sizeof(T)) { ok = false; return v; }
+    std::memcpy(&v, p, sizeof(T));
+    p += sizeof(T);
+    return v;
+  }
+  const uint8_t* take(uint64_t n) {
+    if ((uint64_t)(end - p) < n) { ok = false; return nullptr; }
+    const uint8_t* q = p;
+    p += n;
+    return q;
+  }
+};
+
+}  // namespace
+
+SF_API int sf_sens_open(const char* path, sf_sens** out) {
+  if (!path || !out) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  const int fd = ::open(path, O_RDONLY);
+  if (fd < 0) return sf::fail(SF_ERR_IO, "could not open file %s", path);
+  struct stat st;
+  if (fstat(fd, &st) != 0 || st.st_size < 4) { ::close(fd); return sf::fail(SF_ERR_FORMAT, "%s: too short to be a .sens file", path); }
+  void* map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+  if (map == MAP_FAILED) { ::close(fd); return sf::fail(SF_ERR_IO, "mmap of %s failed", path); }
+  sf_sens* s = new sf_sens();
+  s->map = map; s->map_bytes = (uint64_t)st.st_size; s->fd = fd;
+  auto bail = [&](int code, const char* what) { sf_sens_close(s); return sf::fail(code, "%s: %s", path, what); };
+  Cursor c{(const uint8_t*)map, (const uint8_t*)map + st.st_size};
+  sf_sens_info& h = s->info;
+  std::memset(&h, 0, sizeof(h));
+  h.version = c.get<uint32_t>();
+  if (!c.ok) return bail(SF_ERR_FORMAT, "truncated header");
+  if (h.version != 4) {  // assertVersionNumber, sensorData.h:883-886
+    const uint32_t v = h.version;
+    sf_sens_close(s);
+    return sf::fail(SF_ERR_FORMAT, "%s: invalid file version -- found %u but expected 4", path, v);
+  }
+  const uint64_t slen = c.get<uint64_t>();
+  const uint8_t* name = c.take(slen);
+  if (!c.ok) return bail(SF_ERR_FORMAT, "truncated header (sensor name)");
+  std::memcpy(h.sensor_name, name, slen < sizeof(h.sensor_name) - 1 ? slen : sizeof(h.sensor_name) - 1);
+  float* mats[4] = {h.color_intrinsic, h.color_extrinsic, h.depth_intrinsic, h.depth_extrinsic};
+  for (float* m : mats) {
+    const uint8_t* q = c.take(64);
+    if (!c.ok) return bail(SF_ERR_FORMAT, "truncated header (calibration)");
+    std::memcpy(m, q, 64);
+  }
+  h.color_compression = c.get<int32_t>();
+  h.depth_compression = c.get<int32_t>();
+  h.color_width = c.get<uint32_t>(); h.color_height = c.get<uint32_t>();
+  h.depth_width = c.get<uint32_t>(); h.depth_height = c.get<uint32_t>();
+  h.depth_shift = c.get<float>();
+  h.num_frames = c.get<uint64_t>();
+  if (!c.ok) return bail(SF_ERR_FORMAT, "truncated header");
+  if (h.num_frames > (uint64_t)st.st_size / 96) return bail(SF_ERR_FORMAT, "frame count larger than the file allows");
+  s->frames.resize(h.num_frames);
+  for (uint64_t i = 0; i < h.num_frames; i++) {
+    SensFrame& f = s->frames[i];
+    const uint8_t* q = c.take(64);
+    if (!c.ok) return bail(SF_ERR_FORMAT, "truncated frame record");
+    std::memcpy(f.pose, q, 64);
+    f.ts_color = c.get<uint64_t>(); f.ts_depth = c.get<uint64_t>();
+    f.color_bytes = c.get<uint64_t>(); f.depth_bytes = c.get<uint64_t>();
+    if (!c.ok) return bail(SF_ERR_FORMAT, "truncated frame record");
+    f.color = c.take(f.color_bytes);
+    f.depth = c.ok ? c.take(f.depth_bytes) : nullptr;
+    if (!c.ok) return bail(SF_ERR_FORMAT, "truncated frame data");
+  }
+  // files written by LiveSensorDataWriter before close() may end right after the frames (sensorData.h:1146-1156)
+  h.num_imu = 0;
+  if (c.p < c.end) {
+    h.num_imu = c.get<uint64_t>();
+    if (!c.ok) return bail(SF_ERR_FORMAT, "truncated IMU count");
+    if (h.num_imu > (uint64_t)(c.end - c.p) / 128) return bail(SF_ERR_FORMAT, "truncated IMU frames");
+    const uint8_t* q = c.take(h.num_imu * 128);
+    s->imu.assign(q, q + h.num_imu * 128);
+  }
+  *out = s;
+  return SF_OK;
+}
+
+SF_API void sf_sens_close(sf_sens* s) {
+  if (!s) return;
+  if (s->map) munmap(s->map, (size_t)s->map_bytes);
+  if (s->fd >= 0) ::close(s->fd);
+  delete s;
+}
+
+SF_API int sf_sens_get_info(const sf_sens* s, sf_sens_info* out) {
+  if (!s || !out) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  *out = s->info;
+  out->num_frames = s->frames.size();
+  out->num_imu = s->imu.size() / 128;
+  return SF_OK;
+}
+
+int sens_decode_depth(const sf_sens* s, uint64_t i, uint16_t* dst) {
+  if (i >= s->frames.size()) return sf::fail(SF_ERR_BOUNDS, "frame %llu out of bounds (%zu frames)", (unsigned long long)i, s->frames.size());
+  const SensFrame& f = s->frames[i];
+  const uint64_t want = (uint64_t)s->info.depth_width * s->info.depth_height * 2;
+  switch (s->info.depth_compression) {
+    case 0:  // TYPE_RAW_USHORT, sensorData.h:724-730
+      if (f.depth_bytes != want) return sf::fail(SF_ERR_FORMAT, "raw depth frame %llu has %llu bytes, expected %llu", (unsigned long long)i, (unsigned long long)f.depth_bytes, (unsigned long long)want);
+      std::memcpy(dst, f.depth, want);
+      return SF_OK;
+    case 1: {  // TYPE_ZLIB_USHORT, sensorData.h:703-709
+      if (!f.depth || f.depth_bytes == 0) return sf::fail(SF_ERR_FORMAT, "frame %llu has no depth data", (unsigned long long)i);
+      uint64_t got = 0;
+      const int rc = sf_zlib_inflate(f.depth, f.depth_bytes, dst, want, &got);
+      if (rc != SF_OK) return rc;
+      if (got != want) return sf::fail(SF_ERR_FORMAT, "depth frame %llu inflates to %llu bytes, expected %llu", (unsigned long long)i, (unsigned long long)got, (unsigned long long)want);
+      return SF_OK;
+    }
+    case 2:
+      return sf::fail(SF_ERR_UNSUPPORTED, "TYPE_OCCI_USHORT depth needs the Windows-only uplinksimple codec (sensorData.h:711-722)");
+    default:
+      return sf::fail(SF_ERR_FORMAT, "unknown depth compression type %d", s->info.depth_compression);
+  }
+}
+
+SF_API int sf_sens_decode_depth(const sf_sens* s, uint64_t frame, uint16_t* dst) {
+  if (!s || !dst) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  return sens_decode_depth(s, frame, dst);
+}
+
+SF_API int sf_sens_decode_color(const sf_sens* s, uint64_t frame, uint8_t* dst) {
+  if (!s || !dst) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  if (frame >= s->frames.size()) return sf::fail(SF_ERR_BOUNDS, "frame %llu out of bounds (%zu frames)", (unsigned long long)frame, s->frames.size());
+  const SensFrame& f = s->frames[frame];
+  const uint64_t want = (uint64_t)s->info.color_width * s->info.color_height * 3;
+  if (!f.color || f.color_bytes == 0) return sf::fail(SF_ERR_FORMAT, "frame %llu has no colour data", (unsigned long long)frame);  // sensorData.h:607,646
+  switch (s->info.color_compression) {
+    case 0:  // TYPE_RAW, sensorData.h:644-650
+      if (f.color_bytes != want) return sf::fail(SF_ERR_FORMAT, "raw colour frame has %llu bytes, expected %llu", (unsigned long long)f.color_bytes, (unsigned long long)want);
+      std::memcpy(dst, f.color, want);
+      return SF_OK;
+    case 2:  // TYPE_JPEG, sensorData.h:609-616
+      return jpeg_decode_rgb(f.color, f.color_bytes, dst, s->info.color_width, s->info.color_height);
+    case 1:
+      return sf::fail(SF_ERR_UNSUPPORTED, "TYPE_PNG colour is not produced by any ScanNet tool (Converter/main.cpp:37) and is not implemented");
+    default:
+      return sf::fail(SF_ERR_FORMAT, "unknown colour compression type %d", s->info.color_compression);
+  }
+}
+
+SF_API int sf_sens_pose(const sf_sens* s, uint64_t frame, float out16[16], int* valid) {
+  if (!s || !out16) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  if (frame >= s->frames.size()) return sf::fail(SF_ERR_BOUNDS, "frame %llu out of bounds (%zu frames)", (unsigned long long)frame, s->frames.size());
+  std::memcpy(out16, s->frames[frame].pose, 64);
+  if (valid) *valid = out16[0] != -std::numeric_limits<float>::infinity();
+  return SF_OK;
+}
+
+SF_API int sf_sens_frame_meta(const sf_sens* s, uint64_t frame, sf_sens_frame_meta_t* out) {
+  if (!s || !out) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  if (frame >= s->frames.size()) return sf::fail(SF_ERR_BOUNDS, "frame %llu out of bounds (%zu frames)", (unsigned long long)frame, s->frames.size());
+  const SensFrame& f = s->frames[frame];
+  out->timestamp_color = f.ts_color; out->timestamp_depth = f.ts_depth;
+  out->color_bytes = f.color_bytes; out->depth_bytes = f.depth_bytes;
+  return SF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ writer
+SF_API int sf_sens_create(const sf_sens_info* header, sf_sens** out) {
+  if (!header || !out) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  if (header->depth_compression != 0 && header->depth_compression != 1)
+    return sf::fail(SF_ERR_UNSUPPORTED, "writer supports depth compression 0 (raw) and 1 (zlib) only");
+  sf_sens* s = new sf_sens();
+  s->info = *header;
+  s->info.version = 4;
+  s->info.num_frames = 0;
+  s->info.num_imu = 0;
+  s->info.sensor_name[sizeof(s->info.sensor_name) - 1] = 0;
+  *out = s;
+  return SF_OK;
+}
+
+SF_API int sf_sens_add_frame(sf_sens* s, const uint8_t* color, uint64_t color_bytes, const uint16_t* depth, const float pose[16],
+                             uint64_t ts_color, uint64_t ts_depth) {
+  if (!s || !pose) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  if (!color) color_bytes = 0;
+  if (color_bytes && s->info.color_compression == 0 && color_bytes != (uint64_t)s->info.color_width * s->info.color_height * 3)
+    return sf::fail(SF_ERR_INVALID_ARG, "raw colour frame must be colorWidth*colorHeight*3 bytes");
+  SensFrame f;
+  std::memcpy(f.pose, pose, 64);
+  f.ts_color = ts_color; f.ts_depth = ts_depth;
+  const uint64_t raw = (uint64_t)s->info.depth_width * s->info.depth_height * 2;
+  uint64_t dbytes = 0;
+  if (depth) {
+    if (s->info.depth_compression == 0) {
+      f.owned.resize(color_bytes + raw);
+      std::memcpy(f.owned.data() + color_bytes, depth, raw);
+      dbytes = raw;
+    } else {
+      const uint64_t bound = sf_zlib_deflate_bound(raw);
+      f.owned.resize(color_bytes + bound);
+      const int rc = sf_zlib_deflate(depth, raw, f.owned.data() + color_bytes, bound, &dbytes);
+      if (rc != SF_OK) return rc;
+      f.owned.resize(color_bytes + dbytes);
+    }
+  } else {
+    f.owned.resize(color_bytes);
+  }
+  if (color_bytes) std::memcpy(f.owned.data(), color, color_bytes);
+  f.color_bytes = color_bytes;
+  f.depth_bytes = dbytes;
+  s->frames.push_back(std::move(f));
+  SensFrame& g = s->frames.back();
+  g.color = g.owned.data();
+  g.depth = g.owned.data() + color_bytes;
+  // earlier frames' vectors may have moved with the push_back: re-point all writer-owned frames
+  for (SensFrame& q : s->frames)
+    if (!q.owned.empty()) { q.color = q.owned.data(); q.depth = q.owned.data() + q.color_bytes; }
+  return SF_OK;
+}
+
+SF_API int sf_sens_set_pose(sf_sens* s, uint64_t frame, const float pose[16]) {
+  if (!s || !pose) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  if (frame >= s->frames.size()) return sf::fail(SF_ERR_BOUNDS, "frame %llu out of bounds (%zu frames)", (unsigned long long)frame, s->frames.size());
+  std::memcpy(s->frames[frame].pose, pose, 64);
+  return SF_OK;
+}
+
+SF_API int sf_sens_save(const sf_sens* s, const char* path) {
+  if (!s || !path) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  FILE* fp = std::fopen(path, "wb");
+  if (!fp) return sf::fail(SF_ERR_IO, "unable to open file for writing: %s", path);
+  bool ok = true;
+  auto put = [&](const void* p, size_t n) { if (n && std::fwrite(p, 1, n, fp) != n) ok = false; };
+  const sf_sens_info& h = s->info;
+  const uint32_t version = 4;
+  const uint64_t slen = std::strlen(h.sensor_name);
+  put(&version, 4); put(&slen, 8); put(h.sensor_name, slen);
+  put(h.color_intrinsic, 64); put(h.color_extrinsic, 64); put(h.depth_intrinsic, 64); put(h.depth_extrinsic, 64);
+  put(&h.color_compression, 4); put(&h.depth_compression, 4);
+  put(&h.color_width, 4); put(&h.color_height, 4); put(&h.depth_width, 4); put(&h.depth_height, 4);
+  put(&h.depth_shift, 4);
+  const uint64_t nf = s->frames.size();
+  put(&nf, 8);
+  for (const SensFrame& f : s->frames) {
+    put(f.pose, 64); put(&f.ts_color, 8); put(&f.ts_depth, 8); put(&f.color_bytes, 8); put(&f.depth_bytes, 8);
+    put(f.color, f.color_bytes); put(f.depth, f.depth_bytes);
+  }
+  const uint64_t ni = s->imu.size() / 128;
+  put(&ni, 8); put(s->imu.data(), s->imu.size());
+  if (std::fclose(fp) != 0) ok = false;
+  if (!ok) return sf::fail(SF_ERR_IO, "write to %s failed", path);
+  return SF_OK;
+}

@@ -1,0 +1,200 @@
+"""`.sens` container -- host-side mirror of the reference readers over the C ABI.
+
+Attribute and method names follow SensReader/python/SensorData.py (classes SensorData / RGBDFrame: `sensor_name`,
+`intrinsic_depth`, `frames[i].camera_to_world`, `decompress_depth`, `export_poses`, ...), semantics follow the
+C++ codec SensReader/c++/src/sensorData.h.  Parsing, inflate and JPEG decode run in libscanfuse.so
+(scannet_amd/csrc/sens.cpp, zlib_codec.cpp, jpeg.cpp); frames are lazy views into the memory-mapped file.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi
+from ._abi import check
+
+COMPRESSION_TYPE_COLOR = {-1: 'unknown', 0: 'raw', 1: 'png', 2: 'jpeg'}
+COMPRESSION_TYPE_DEPTH = {-1: 'unknown', 0: 'raw_ushort', 1: 'zlib_ushort', 2: 'occi_ushort'}
+
+
+class SfSensInfo(C.Structure):
+    _fields_ = [
+        ("version", C.c_uint32),
+        ("color_width", C.c_uint32), ("color_height", C.c_uint32), ("depth_width", C.c_uint32), ("depth_height", C.c_uint32),
+        ("color_compression", C.c_int32), ("depth_compression", C.c_int32),
+        ("depth_shift", C.c_float),
+        ("num_frames", C.c_uint64), ("num_imu", C.c_uint64),
+        ("color_intrinsic", C.c_float * 16), ("color_extrinsic", C.c_float * 16),
+        ("depth_intrinsic", C.c_float * 16), ("depth_extrinsic", C.c_float * 16),
+        ("sensor_name", C.c_char * 256),
+    ]
+
+
+class SfSensFrameMeta(C.Structure):
+    _fields_ = [("timestamp_color", C.c_uint64), ("timestamp_depth", C.c_uint64), ("color_bytes", C.c_uint64), ("depth_bytes", C.c_uint64)]
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def zlib_inflate(data, out_bytes):
+    """Inflate a zlib stream into a bytes object of at most out_bytes (no Adler-32 check, like the reference)."""
+    src = np.frombuffer(data, np.uint8)
+    dst = np.empty(out_bytes, np.uint8)
+    n = C.c_uint64(0)
+    check(_abi.lib().sf_zlib_inflate(_ptr(src), len(src), _ptr(dst), out_bytes, C.byref(n)))
+    return dst[:n.value].tobytes()
+
+
+def zlib_deflate(data):
+    src = np.frombuffer(data, np.uint8)
+    L = _abi.lib()
+    cap = int(L.sf_zlib_deflate_bound(len(src)))
+    dst = np.empty(cap, np.uint8)
+    n = C.c_uint64(0)
+    check(L.sf_zlib_deflate(_ptr(src), len(src), _ptr(dst), cap, C.byref(n)))
+    return dst[:n.value].tobytes()
+
+
+class RGBDFrame:
+    """One frame of a SensorData (lazy: blobs stay in the mapped file until decompress_* is called)."""
+
+    def __init__(self, owner, index):
+        self._o, self._i = owner, index
+        pose = np.zeros(16, np.float32)
+        valid = C.c_int(0)
+        check(_abi.lib().sf_sens_pose(owner._h, index, _ptr(pose), C.byref(valid)))
+        self.camera_to_world = pose.reshape(4, 4)
+        self.valid_pose = bool(valid.value)  # False for the all -inf "tracking lost" pose
+        m = SfSensFrameMeta()
+        check(_abi.lib().sf_sens_frame_meta(owner._h, index, C.byref(m)))
+        self.timestamp_color, self.timestamp_depth = m.timestamp_color, m.timestamp_depth
+        self.color_size_bytes, self.depth_size_bytes = m.color_bytes, m.depth_bytes
+
+    def decompress_depth(self, compression_type=None):
+        """-> uint16 array [depth_height, depth_width] (the reference returns the raw bytes of the same data)."""
+        o = self._o
+        out = np.empty((o.depth_height, o.depth_width), np.uint16)
+        check(_abi.lib().sf_sens_decode_depth(o._h, self._i, _ptr(out)))
+        return out
+
+    def decompress_color(self, compression_type=None):
+        o = self._o
+        out = np.empty((o.color_height, o.color_width, 3), np.uint8)
+        check(_abi.lib().sf_sens_decode_color(o._h, self._i, _ptr(out)))
+        return out
+
+
+class SensorData:
+    def __init__(self, filename=None, _handle=None):
+        self.version = 4
+        self._h = None
+        if filename is not None:
+            self.load(filename)
+        elif _handle is not None:
+            self._h = _handle
+            self._refresh()
+
+    # -- reading ---------------------------------------------------------------------------------------
+    def load(self, filename):
+        h = C.c_void_p()
+        check(_abi.lib().sf_sens_open(os.fsencode(filename), C.byref(h)))
+        self._h = h
+        self._refresh()
+
+    def _refresh(self):
+        info = SfSensInfo()
+        check(_abi.lib().sf_sens_get_info(self._h, C.byref(info)))
+        self.sensor_name = info.sensor_name.decode("latin-1")
+        self.intrinsic_color = np.array(info.color_intrinsic, np.float32).reshape(4, 4)
+        self.extrinsic_color = np.array(info.color_extrinsic, np.float32).reshape(4, 4)
+        self.intrinsic_depth = np.array(info.depth_intrinsic, np.float32).reshape(4, 4)
+        self.extrinsic_depth = np.array(info.depth_extrinsic, np.float32).reshape(4, 4)
+        self.color_compression_type = COMPRESSION_TYPE_COLOR.get(info.color_compression, 'unknown')
+        self.depth_compression_type = COMPRESSION_TYPE_DEPTH.get(info.depth_compression, 'unknown')
+        self.color_width, self.color_height = info.color_width, info.color_height
+        self.depth_width, self.depth_height = info.depth_width, info.depth_height
+        self.depth_shift = info.depth_shift
+        self.num_frames, self.num_imu_frames = info.num_frames, info.num_imu
+        self._frames = None
+
+    @property
+    def frames(self):
+        if self._frames is None:
+            self._frames = [RGBDFrame(self, i) for i in range(self.num_frames)]
+        return self._frames
+
+    def close(self):
+        if self._h:
+            _abi.lib().sf_sens_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- writing (initDefault / addFrame / saveToFile, sensorData.h:891-921,1101-1109) ------------------
+    @classmethod
+    def create(cls, color_width, color_height, depth_width, depth_height, intrinsic_color, intrinsic_depth,
+               color_compression=0, depth_compression=1, depth_shift=1000.0, sensor_name="Unknown",
+               extrinsic_color=None, extrinsic_depth=None):
+        info = SfSensInfo()
+        info.version = 4
+        info.color_width, info.color_height, info.depth_width, info.depth_height = color_width, color_height, depth_width, depth_height
+        info.color_compression, info.depth_compression, info.depth_shift = color_compression, depth_compression, depth_shift
+        eye = np.eye(4, dtype=np.float32)
+        for name, m in (("color_intrinsic", intrinsic_color), ("color_extrinsic", eye if extrinsic_color is None else extrinsic_color),
+                        ("depth_intrinsic", intrinsic_depth), ("depth_extrinsic", eye if extrinsic_depth is None else extrinsic_depth)):
+            setattr(info, name, (C.c_float * 16)(*np.asarray(m, np.float32).reshape(16)))
+        info.sensor_name = sensor_name.encode("latin-1")[:255]
+        h = C.c_void_p()
+        check(_abi.lib().sf_sens_create(C.byref(info), C.byref(h)))
+        return cls(_handle=h)
+
+    def add_frame(self, depth, camera_to_world=None, color=None, timestamp_color=0, timestamp_depth=0):
+        pose = np.ascontiguousarray(np.eye(4) if camera_to_world is None else camera_to_world, np.float32).reshape(16)
+        d = None if depth is None else np.ascontiguousarray(depth, np.uint16)
+        if d is not None and d.size != self.depth_width * self.depth_height:
+            raise ValueError("depth frame size mismatch")
+        c = None if color is None else np.ascontiguousarray(np.frombuffer(color, np.uint8) if isinstance(color, (bytes, bytearray)) else color, np.uint8)
+        check(_abi.lib().sf_sens_add_frame(self._h, _ptr(c), 0 if c is None else c.size, _ptr(d), _ptr(pose), timestamp_color, timestamp_depth))
+        self._refresh()
+
+    def set_pose(self, frame, camera_to_world):
+        pose = np.ascontiguousarray(camera_to_world, np.float32).reshape(16)
+        check(_abi.lib().sf_sens_set_pose(self._h, frame, _ptr(pose)))
+        self._frames = None
+
+    def save(self, filename):
+        check(_abi.lib().sf_sens_save(self._h, os.fsencode(filename)))
+
+    # -- exports (SensorData.py:76-124) -----------------------------------------------------------------
+    @staticmethod
+    def save_mat_to_file(matrix, filename):
+        with open(filename, 'w') as f:
+            for line in matrix:
+                np.savetxt(f, line[np.newaxis], fmt='%f')
+
+    def export_poses(self, output_path, frame_skip=1):
+        os.makedirs(output_path, exist_ok=True)
+        for f in range(0, len(self.frames), frame_skip):
+            self.save_mat_to_file(self.frames[f].camera_to_world, os.path.join(output_path, str(f) + '.txt'))
+
+    def export_intrinsics(self, output_path):
+        os.makedirs(output_path, exist_ok=True)
+        self.save_mat_to_file(self.intrinsic_color, os.path.join(output_path, 'intrinsic_color.txt'))
+        self.save_mat_to_file(self.extrinsic_color, os.path.join(output_path, 'extrinsic_color.txt'))
+        self.save_mat_to_file(self.intrinsic_depth, os.path.join(output_path, 'intrinsic_depth.txt'))
+        self.save_mat_to_file(self.extrinsic_depth, os.path.join(output_path, 'extrinsic_depth.txt'))
+
+    def export_depth_images(self, output_path, frame_skip=1):
+        """16-bit PGM dumps (the reference writes 16-bit PNG through pypng, which is not available here)."""
+        os.makedirs(output_path, exist_ok=True)
+        for f in range(0, len(self.frames), frame_skip):
+            d = self.frames[f].decompress_depth()
+            with open(os.path.join(output_path, str(f) + '.pgm'), 'wb') as fh:
+                fh.write(b"P5\n%d %d\n65535\n" % (d.shape[1], d.shape[0]))
+                fh.write(d.astype('>u2').tobytes())
