@@ -174,6 +174,37 @@ int sf_sens_set_pose(sf_sens* s, uint64_t frame, const float pose[16]);
 int sf_sens_save(const sf_sens* s, const char* path);
 
 /* ------------------------------------------------------------------------------------------------
+ * Triangle meshes and the PLY surface (README.md:45-46: binary little-endian PLY, vertex float x,y,z +
+ * uchar red,green,blue,alpha, face list uchar int vertex_indices).  sf_ply_read replaces tinyply as the
+ * Segmentator uses it (Segmentator/segmentator.cpp:131-141, tinyply.cpp:54-108,306-360): ascii / binary
+ * little / big endian, x y z as 4-byte floats, triangle lists named vertex_indices or vertex_index with a
+ * 4-byte index type; anything else is SF_ERR_FORMAT (tinyply throws or misreads).  .obj files are read like
+ * tiny_obj_loader's first shape (segmentator.cpp:142-174).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct sf_mesh sf_mesh;
+int sf_ply_read(const char* path, sf_mesh** out);                 /* .ply or .obj by extension */
+int sf_mesh_create(const float* xyz, const uint8_t* rgba /*nullable*/, uint64_t num_vertices, const uint32_t* tris,
+                   uint64_t num_faces, sf_mesh** out);
+int sf_mesh_counts(const sf_mesh* m, uint64_t* num_vertices, uint64_t* num_faces);
+/* any destination may be NULL: xyz 3 floats, rgba 4 bytes, tris 3 u32, keys 1 u64 (marching-cubes meshes only) */
+int sf_mesh_copy(const sf_mesh* m, float* xyz, uint8_t* rgba, uint32_t* tris, uint64_t* keys);
+int sf_mesh_write_ply(const sf_mesh* m, const char* path);        /* the PLY surface above */
+void sf_mesh_free(sf_mesh* m);
+
+/* ------------------------------------------------------------------------------------------------
+ * Segmentator: Felzenszwalb-Huttenlocher graph segmentation on vertex normals.  Replaces
+ * Segmentator/segmentator.cpp: segment() :123-251 (normals :185-208, edge weights :211-229,
+ * segment_graph :71-92, small-segment merge :237-243), writeToJSON :253-266, main :268-289.
+ * segIndices are bit-exact with the reference binary (same union-find roots): the edge sort is libstdc++
+ * std::sort with the reference's weight-only comparator, all float arithmetic is un-contracted IEEE fp32.
+ * ---------------------------------------------------------------------------------------------- */
+int sf_segment_mesh(const float* xyz, uint64_t num_vertices, const uint32_t* tris, uint64_t num_faces, float kThresh,
+                    int segMinVerts, int32_t* segIndices_out);
+/* Reads mesh_path (.ply/.obj), segments, writes the JSON.  out_json NULL => reference naming:
+ * <mesh minus extension>.<std::to_string(kThresh)>.segs.json (segmentator.cpp:282-286).  Prints nothing. */
+int sf_segment_file(const char* mesh_path, float kThresh, int segMinVerts, const char* out_json, uint64_t* num_segments);
+
+/* ------------------------------------------------------------------------------------------------
  * Synthetic stream source (benchmark input): renders frames
  * [first_frame, first_frame+n) of the `total_frames`-frame box-room walk as u16 millimetre depth directly
  * into device memory and returns the n camToWorld poses (n*16 floats, host).

@@ -1,0 +1,395 @@
+// ply.cpp -- PLY / OBJ ingest and the PLY writer (see include/scanfuse.h for the reference interfaces replaced).
+//
+// The reader maps the file and walks it once with fixed strides (tinyply dispatches a std::function per
+// property per element: 63 % of the reference Segmentator's run time).
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "mesh.h"
+
+namespace {
+
+struct Prop {
+  std::string name;
+  int type = -1;       // index into TYPES
+  bool is_list = false;
+  int count_type = -1;
+};
+struct Elem {
+  std::string name;
+  uint64_t size = 0;
+  std::vector<Prop> props;
+};
+
+const char* const TYPE_NAMES[][2] = {{"char", "int8"}, {"uchar", "uint8"}, {"short", "int16"}, {"ushort", "uint16"},
+                                     {"int", "int32"}, {"uint", "uint32"}, {"float", "float32"}, {"double", "float64"}};
+const int TYPE_SIZE[] = {1, 1, 2, 2, 4, 4, 4, 8};
+
+int type_from(const std::string& s) {
+  for (int i = 0; i < 8; i++)
+    if (s == TYPE_NAMES[i][0] || s == TYPE_NAMES[i][1]) return i;
+  return -1;
+}
+
+struct MapFile {
+  const uint8_t* p = nullptr;
+  uint64_t n = 0;
+  int fd = -1;
+  ~MapFile() {
+    if (p) munmap((void*)p, (size_t)n);
+    if (fd >= 0) ::close(fd);
+  }
+  int open_file(const char* path) {
+    fd = ::open(path, O_RDONLY);
+    if (fd < 0) return sf::fail(SF_ERR_IO, "could not open file %s", path);
+    struct stat st;
+    if (fstat(fd, &st) != 0) return sf::fail(SF_ERR_IO, "could not stat %s", path);
+    n = (uint64_t)st.st_size;
+    if (n == 0) { p = nullptr; return SF_OK; }
+    void* m = mmap(nullptr, (size_t)n, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (m == MAP_FAILED) return sf::fail(SF_ERR_IO, "mmap of %s failed", path);
+    p = (const uint8_t*)m;
+    return SF_OK;
+  }
+};
+
+template <typename T>
+inline T load(const uint8_t* p, bool swap) {
+  uint8_t b[sizeof(T)];
+  if (swap) for (size_t i = 0; i < sizeof(T); i++) b[i] = p[sizeof(T) - 1 - i];
+  else std::memcpy(b, p, sizeof(T));
+  T v;
+  std::memcpy(&v, b, sizeof(T));
+  return v;
+}
+
+inline uint64_t load_uint(const uint8_t* p, int type, bool swap) {
+  switch (type) {
+    case 0: return (uint64_t)(int64_t)load<int8_t>(p, swap);
+    case 1: return load<uint8_t>(p, swap);
+    case 2: return (uint64_t)(int64_t)load<int16_t>(p, swap);
+    case 3: return load<uint16_t>(p, swap);
+    case 4: return (uint64_t)(int64_t)load<int32_t>(p, swap);
+    case 5: return load<uint32_t>(p, swap);
+    default: return 0;
+  }
+}
+
+int read_ply(const char* path, sf_mesh* m) {
+  MapFile f;
+  int rc = f.open_file(path);
+  if (rc != SF_OK) return rc;
+  // ---- header
+  std::vector<Elem> elems;
+  bool binary = false, big = false, got_end = false;
+  uint64_t pos = 0;
+  while (pos < f.n) {
+    uint64_t e = pos;
+    while (e < f.n && f.p[e] != '\n') e++;
+    std::string line((const char*)f.p + pos, (size_t)(e - pos));
+    pos = e < f.n ? e + 1 : e;
+    if (!line.empty() && line.back() == '\r') line.pop_back();
+    std::istringstream ls(line);
+    std::string tok;
+    ls >> tok;
+    if (tok == "ply" || tok == "PLY" || tok.empty()) continue;
+    if (tok == "comment" || tok == "obj_info") continue;
+    if (tok == "format") {
+      std::string s;
+      ls >> s;
+      if (s == "binary_little_endian") binary = true;
+      else if (s == "binary_big_endian") binary = big = true;
+    } else if (tok == "element") {
+      Elem el;
+      ls >> el.name >> el.size;
+      elems.push_back(el);
+    } else if (tok == "property") {
+      if (elems.empty()) return sf::fail(SF_ERR_FORMAT, "%s: property before any element", path);
+      Prop pr;
+      std::string t;
+      ls >> t;
+      if (t == "list") {
+        std::string ct;
+        ls >> ct >> t;
+        pr.is_list = true;
+        pr.count_type = type_from(ct);
+        if (pr.count_type < 0 || pr.count_type > 5) return sf::fail(SF_ERR_FORMAT, "%s: bad list count type '%s'", path, ct.c_str());
+      }
+      pr.type = type_from(t);
+      if (pr.type < 0) return sf::fail(SF_ERR_FORMAT, "%s: unknown property type '%s'", path, t.c_str());
+      ls >> pr.name;
+      elems.back().props.push_back(pr);
+    } else if (tok == "end_header") {
+      got_end = true;
+      break;
+    } else {
+      return sf::fail(SF_ERR_FORMAT, "%s: file is not ply or encountered junk in header", path);  // tinyply.cpp:56-59
+    }
+  }
+  if (!got_end) return sf::fail(SF_ERR_FORMAT, "%s: file is not ply or encountered junk in header", path);
+
+  // ---- body
+  const uint8_t* p = f.p + pos;
+  const uint8_t* end = f.p + f.n;
+  auto need = [&](uint64_t k) { return (uint64_t)(end - p) >= k; };
+  // ascii tokenizer
+  auto next_token = [&](const char*& a, const char*& b) -> bool {
+    while (p < end && (*p == ' ' || *p == '\n' || *p == '\r' || *p == '\t')) p++;
+    if (p >= end) return false;
+    a = (const char*)p;
+    while (p < end && !(*p == ' ' || *p == '\n' || *p == '\r' || *p == '\t')) p++;
+    b = (const char*)p;
+    return true;
+  };
+  for (const Elem& el : elems) {
+    const bool is_vertex = el.name == "vertex", is_face = el.name == "face";
+    int ix = -1, iy = -1, iz = -1, ir = -1, ig = -1, ib = -1, ia = -1, il = -1;
+    for (size_t k = 0; k < el.props.size(); k++) {
+      const Prop& pr = el.props[k];
+      if (is_vertex && !pr.is_list) {
+        if (pr.name == "x") ix = (int)k; else if (pr.name == "y") iy = (int)k; else if (pr.name == "z") iz = (int)k;
+        else if (pr.name == "red") ir = (int)k; else if (pr.name == "green") ig = (int)k; else if (pr.name == "blue") ib = (int)k;
+        else if (pr.name == "alpha") ia = (int)k;
+      }
+      if (is_face && pr.is_list && il < 0 && pr.name == "vertex_indices") il = (int)k;
+    }
+    if (is_face && il < 0)
+      for (size_t k = 0; k < el.props.size(); k++)
+        if (el.props[k].is_list && el.props[k].name == "vertex_index") { il = (int)k; break; }  // segmentator.cpp:136-139
+    if (is_vertex && ix >= 0 && iy >= 0 && iz >= 0) {
+      for (int q : {ix, iy, iz})
+        if (TYPE_SIZE[el.props[q].type] != 4) return sf::fail(SF_ERR_FORMAT, "%s: destination vector is wrongly typed to hold this property (x/y/z must be 4-byte floats)", path);
+      m->pos.resize(el.size * 3);
+      const bool has_col = ir >= 0 && ig >= 0 && ib >= 0 && TYPE_SIZE[el.props[ir].type] == 1 && TYPE_SIZE[el.props[ig].type] == 1 && TYPE_SIZE[el.props[ib].type] == 1;
+      if (has_col) m->col.assign(el.size * 4, 255);
+    }
+    if (is_face && il >= 0 && TYPE_SIZE[el.props[il].type] != 4)
+      return sf::fail(SF_ERR_FORMAT, "%s: destination vector is wrongly typed to hold this property (face indices must be 4-byte integers)", path);
+    if (is_face && il >= 0) m->tri.resize(el.size * 3);
+    const bool want_v = is_vertex && !m->pos.empty();
+    const bool want_f = is_face && il >= 0;
+    const bool has_col = want_v && !m->col.empty();
+    if (binary) {
+      // fixed-stride fast path when the element has no list property
+      bool fixed = true;
+      uint64_t stride = 0;
+      std::vector<uint64_t> off(el.props.size());
+      for (size_t k = 0; k < el.props.size(); k++) {
+        if (el.props[k].is_list) fixed = false;
+        off[k] = stride;
+        stride += TYPE_SIZE[el.props[k].type];
+      }
+      if (fixed) {
+        if (stride && el.size > (uint64_t)(end - p) / stride) return sf::fail(SF_ERR_FORMAT, "%s: truncated '%s' element", path, el.name.c_str());
+        if (want_v) {
+          for (uint64_t i = 0; i < el.size; i++) {
+            const uint8_t* r = p + i * stride;
+            m->pos[3 * i] = load<float>(r + off[ix], big);
+            m->pos[3 * i + 1] = load<float>(r + off[iy], big);
+            m->pos[3 * i + 2] = load<float>(r + off[iz], big);
+            if (has_col) {
+              m->col[4 * i] = r[off[ir]]; m->col[4 * i + 1] = r[off[ig]]; m->col[4 * i + 2] = r[off[ib]];
+              if (ia >= 0 && TYPE_SIZE[el.props[ia].type] == 1) m->col[4 * i + 3] = r[off[ia]];
+            }
+          }
+        }
+        p += el.size * stride;
+      } else {
+        for (uint64_t i = 0; i < el.size; i++) {
+          for (size_t k = 0; k < el.props.size(); k++) {
+            const Prop& pr = el.props[k];
+            const int ts = TYPE_SIZE[pr.type];
+            if (!pr.is_list) {
+              if (!need((uint64_t)ts)) return sf::fail(SF_ERR_FORMAT, "%s: truncated '%s' element", path, el.name.c_str());
+              if (want_v) {
+                if ((int)k == ix) m->pos[3 * i] = load<float>(p, big);
+                else if ((int)k == iy) m->pos[3 * i + 1] = load<float>(p, big);
+                else if ((int)k == iz) m->pos[3 * i + 2] = load<float>(p, big);
+              }
+              p += ts;
+            } else {
+              const int cs = TYPE_SIZE[pr.count_type];
+              if (!need((uint64_t)cs)) return sf::fail(SF_ERR_FORMAT, "%s: truncated '%s' element", path, el.name.c_str());
+              const uint64_t cnt = load_uint(p, pr.count_type, big);
+              p += cs;
+              if (cnt > (uint64_t)(end - p) / (uint64_t)ts) return sf::fail(SF_ERR_FORMAT, "%s: truncated '%s' element", path, el.name.c_str());
+              if (want_f && (int)k == il) {
+                if (cnt != 3) return sf::fail(SF_ERR_FORMAT, "%s: face %llu has %llu vertices; only triangle meshes are supported", path, (unsigned long long)i, (unsigned long long)cnt);
+                for (int q = 0; q < 3; q++) m->tri[3 * i + q] = load<uint32_t>(p + 4 * q, big);
+              }
+              p += cnt * (uint64_t)ts;
+            }
+          }
+        }
+      }
+    } else {
+      const char *a, *b;
+      for (uint64_t i = 0; i < el.size; i++) {
+        for (size_t k = 0; k < el.props.size(); k++) {
+          const Prop& pr = el.props[k];
+          if (!pr.is_list) {
+            if (!next_token(a, b)) return sf::fail(SF_ERR_FORMAT, "%s: truncated '%s' element", path, el.name.c_str());
+            if (want_v && ((int)k == ix || (int)k == iy || (int)k == iz)) {
+              const float v = std::strtof(std::string(a, b).c_str(), nullptr);
+              m->pos[3 * i + ((int)k == ix ? 0 : ((int)k == iy ? 1 : 2))] = v;
+            } else if (has_col && ((int)k == ir || (int)k == ig || (int)k == ib || (int)k == ia)) {
+              const int v = std::atoi(std::string(a, b).c_str());
+              m->col[4 * i + ((int)k == ir ? 0 : ((int)k == ig ? 1 : ((int)k == ib ? 2 : 3)))] = (uint8_t)v;
+            }
+          } else {
+            if (!next_token(a, b)) return sf::fail(SF_ERR_FORMAT, "%s: truncated '%s' element", path, el.name.c_str());
+            const long cnt = std::atol(std::string(a, b).c_str());
+            if (cnt < 0) return sf::fail(SF_ERR_FORMAT, "%s: negative list size", path);
+            if (want_f && (int)k == il && cnt != 3) return sf::fail(SF_ERR_FORMAT, "%s: face %llu has %ld vertices; only triangle meshes are supported", path, (unsigned long long)i, cnt);
+            for (long q = 0; q < cnt; q++) {
+              if (!next_token(a, b)) return sf::fail(SF_ERR_FORMAT, "%s: truncated '%s' element", path, el.name.c_str());
+              if (want_f && (int)k == il) m->tri[3 * i + q] = (uint32_t)std::strtoll(std::string(a, b).c_str(), nullptr, 10);
+            }
+          }
+        }
+      }
+    }
+  }
+  const uint64_t nv = m->pos.size() / 3;
+  for (uint32_t t : m->tri)
+    if (t >= nv) return sf::fail(SF_ERR_FORMAT, "%s: face index %u out of range (%llu vertices)", path, t, (unsigned long long)nv);
+  return SF_OK;
+}
+
+// Minimal Wavefront OBJ reader with tiny_obj_loader's shape rules as the Segmentator relies on them
+// (segmentator.cpp:142-174): all `v` records, faces of the FIRST shape only.
+int read_obj(const char* path, sf_mesh* m, bool* multi) {
+  FILE* fp = std::fopen(path, "r");
+  if (!fp) return sf::fail(SF_ERR_IO, "could not open file %s", path);
+  char buf[4096];
+  int shape = 0;
+  bool shape_has_faces = false;
+  *multi = false;
+  auto fix = [&](long idx) -> long { const long nv = (long)(m->pos.size() / 3); return idx > 0 ? idx - 1 : (idx < 0 ? nv + idx : -1); };
+  while (std::fgets(buf, sizeof(buf), fp)) {
+    char* s = buf;
+    while (*s == ' ' || *s == '\t') s++;
+    if (s[0] == 'v' && (s[1] == ' ' || s[1] == '\t')) {
+      float x = 0, y = 0, z = 0;
+      std::sscanf(s + 2, "%f %f %f", &x, &y, &z);
+      m->pos.push_back(x); m->pos.push_back(y); m->pos.push_back(z);
+    } else if (s[0] == 'f' && (s[1] == ' ' || s[1] == '\t')) {
+      std::vector<long> ids;
+      char* q = s + 2;
+      while (*q) {
+        while (*q == ' ' || *q == '\t') q++;
+        if (*q == 0 || *q == '\n' || *q == '\r') break;
+        ids.push_back(fix(std::strtol(q, &q, 10)));
+        while (*q && *q != ' ' && *q != '\t' && *q != '\n' && *q != '\r') q++;  // skip /vt/vn
+      }
+      if (shape == 0) {
+        if (ids.size() != 3) { std::fclose(fp); return sf::fail(SF_ERR_FORMAT, "%s: only triangle faces are supported", path); }
+        for (long id : ids) m->tri.push_back((uint32_t)id);
+      } else *multi = true;
+      shape_has_faces = true;
+    } else if ((s[0] == 'o' || s[0] == 'g') && (s[1] == ' ' || s[1] == '\t' || s[1] == '\n')) {
+      if (shape_has_faces) { shape++; shape_has_faces = false; }
+    }
+  }
+  std::fclose(fp);
+  const uint64_t nv = m->pos.size() / 3;
+  for (uint32_t t : m->tri)
+    if (t >= nv) return sf::fail(SF_ERR_FORMAT, "%s: face index out of range", path);
+  return SF_OK;
+}
+
+bool ends_with(const std::string& v, const std::string& e) { return e.size() <= v.size() && std::equal(e.rbegin(), e.rend(), v.rbegin()); }
+
+}  // namespace
+
+int mesh_read_any(const char* path, sf_mesh* m, bool* obj_multi) {
+  const std::string s(path);
+  if (obj_multi) *obj_multi = false;
+  if (ends_with(s, ".ply") || ends_with(s, ".PLY")) return read_ply(path, m);
+  if (ends_with(s, ".obj") || ends_with(s, ".OBJ")) { bool mm = false; const int rc = read_obj(path, m, &mm); if (obj_multi) *obj_multi = mm; return rc; }
+  // the reference silently segments an empty mesh for other extensions (segmentator.cpp:130-175)
+  return SF_OK;
+}
+
+SF_API int sf_ply_read(const char* path, sf_mesh** out) {
+  if (!path || !out) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  sf_mesh* m = new sf_mesh();
+  const int rc = mesh_read_any(path, m, nullptr);
+  if (rc != SF_OK) { delete m; return rc; }
+  *out = m;
+  return SF_OK;
+}
+
+SF_API int sf_mesh_create(const float* xyz, const uint8_t* rgba, uint64_t nv, const uint32_t* tris, uint64_t nf, sf_mesh** out) {
+  if ((!xyz && nv) || (!tris && nf) || !out) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  for (uint64_t i = 0; i < nf * 3; i++)
+    if (tris[i] >= nv) return sf::fail(SF_ERR_BOUNDS, "face index %u out of range (%llu vertices)", tris[i], (unsigned long long)nv);
+  sf_mesh* m = new sf_mesh();
+  m->pos.assign(xyz, xyz + nv * 3);
+  if (rgba) m->col.assign(rgba, rgba + nv * 4);
+  m->tri.assign(tris, tris + nf * 3);
+  *out = m;
+  return SF_OK;
+}
+
+SF_API int sf_mesh_counts(const sf_mesh* m, uint64_t* nv, uint64_t* nf) {
+  if (!m) return sf::fail(SF_ERR_INVALID_ARG, "NULL mesh");
+  if (nv) *nv = m->pos.size() / 3;
+  if (nf) *nf = m->tri.size() / 3;
+  return SF_OK;
+}
+
+SF_API int sf_mesh_copy(const sf_mesh* m, float* xyz, uint8_t* rgba, uint32_t* tris, uint64_t* keys) {
+  if (!m) return sf::fail(SF_ERR_INVALID_ARG, "NULL mesh");
+  if (xyz) std::memcpy(xyz, m->pos.data(), m->pos.size() * 4);
+  if (rgba) {
+    if (m->col.empty()) std::memset(rgba, 255, m->pos.size() / 3 * 4);
+    else std::memcpy(rgba, m->col.data(), m->col.size());
+  }
+  if (tris) std::memcpy(tris, m->tri.data(), m->tri.size() * 4);
+  if (keys) {
+    if (m->keys.empty()) return sf::fail(SF_ERR_INVALID_ARG, "mesh has no vertex keys");
+    std::memcpy(keys, m->keys.data(), m->keys.size() * 8);
+  }
+  return SF_OK;
+}
+
+SF_API int sf_mesh_write_ply(const sf_mesh* m, const char* path) {
+  if (!m || !path) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  FILE* fp = std::fopen(path, "wb");
+  if (!fp) return sf::fail(SF_ERR_IO, "unable to open file for writing: %s", path);
+  const uint64_t nv = m->pos.size() / 3, nf = m->tri.size() / 3;
+  std::fprintf(fp,
+               "ply\nformat binary_little_endian 1.0\ncomment scanfuse-mi355x\nelement vertex %llu\nproperty float x\nproperty float y\nproperty float z\n"
+               "property uchar red\nproperty uchar green\nproperty uchar blue\nproperty uchar alpha\nelement face %llu\n"
+               "property list uchar int vertex_indices\nend_header\n",
+               (unsigned long long)nv, (unsigned long long)nf);
+  std::vector<uint8_t> buf;
+  buf.resize(nv * 16);
+  for (uint64_t i = 0; i < nv; i++) {
+    std::memcpy(&buf[i * 16], &m->pos[3 * i], 12);
+    if (m->col.empty()) { buf[i * 16 + 12] = buf[i * 16 + 13] = buf[i * 16 + 14] = 255; buf[i * 16 + 15] = 255; }
+    else std::memcpy(&buf[i * 16 + 12], &m->col[4 * i], 4);
+  }
+  bool ok = nv == 0 || std::fwrite(buf.data(), 1, buf.size(), fp) == buf.size();
+  buf.resize(nf * 13);
+  for (uint64_t i = 0; i < nf; i++) {
+    buf[i * 13] = 3;
+    std::memcpy(&buf[i * 13 + 1], &m->tri[3 * i], 12);
+  }
+  ok = ok && (nf == 0 || std::fwrite(buf.data(), 1, buf.size(), fp) == buf.size());
+  if (std::fclose(fp) != 0) ok = false;
+  if (!ok) return sf::fail(SF_ERR_IO, "write to %s failed", path);
+  return SF_OK;
+}
+
+SF_API void sf_mesh_free(sf_mesh* m) { delete m; }

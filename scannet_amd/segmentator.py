@@ -1,0 +1,92 @@
+"""Segmentator -- host-side mirror of Segmentator/segmentator.cpp over the C ABI.
+
+`segment(mesh_file, kthr, seg_min_verts)` mirrors `segment()` (segmentator.cpp:123-251) and returns the
+segIndices; `segment_to_json` mirrors `main` + `writeToJSON` (:253-289) including the output file naming.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi
+from ._abi import check
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Mesh:
+    """Triangle mesh handle (PLY/OBJ in, marching cubes out, PLY out)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def read(cls, path):
+        h = C.c_void_p()
+        check(_abi.lib().sf_ply_read(os.fsencode(path), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_arrays(cls, xyz, tris, rgba=None):
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        tris = np.ascontiguousarray(tris, np.uint32).reshape(-1, 3)
+        if rgba is not None:
+            rgba = np.ascontiguousarray(rgba, np.uint8).reshape(-1, 4)
+        L = _abi.lib()
+        L.sf_mesh_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
+        h = C.c_void_p()
+        check(L.sf_mesh_create(_ptr(xyz), _ptr(rgba), len(xyz), _ptr(tris), len(tris), C.byref(h)))
+        return cls(h)
+
+    def counts(self):
+        nv, nf = C.c_uint64(0), C.c_uint64(0)
+        check(_abi.lib().sf_mesh_counts(self._h, C.byref(nv), C.byref(nf)))
+        return nv.value, nf.value
+
+    def arrays(self, keys=False):
+        nv, nf = self.counts()
+        xyz = np.zeros((nv, 3), np.float32)
+        rgba = np.zeros((nv, 4), np.uint8)
+        tris = np.zeros((nf, 3), np.uint32)
+        k = np.zeros(nv, np.uint64) if keys else None
+        check(_abi.lib().sf_mesh_copy(self._h, _ptr(xyz), _ptr(rgba), _ptr(tris), _ptr(k)))
+        return (xyz, rgba, tris, k) if keys else (xyz, rgba, tris)
+
+    def write_ply(self, path):
+        check(_abi.lib().sf_mesh_write_ply(self._h, os.fsencode(path)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _abi.lib().sf_mesh_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def segment_arrays(xyz, tris, kthr=0.01, seg_min_verts=20):
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    tris = np.ascontiguousarray(tris, np.uint32).reshape(-1, 3)
+    out = np.zeros(len(xyz), np.int32)
+    check(_abi.lib().sf_segment_mesh(_ptr(xyz), len(xyz), _ptr(tris), len(tris), float(kthr), int(seg_min_verts), _ptr(out)))
+    return out
+
+
+def segment(mesh_file, kthr=0.01, seg_min_verts=20):
+    m = Mesh.read(mesh_file)
+    xyz, _, tris = m.arrays()
+    m.close()
+    return segment_arrays(xyz, tris, kthr, seg_min_verts)
+
+
+def segment_to_json(mesh_file, kthr=0.01, seg_min_verts=20, out_json=None):
+    """Writes <mesh minus ext>.<kThresh %f>.segs.json (or out_json); returns the number of segments."""
+    n = C.c_uint64(0)
+    check(_abi.lib().sf_segment_file(os.fsencode(mesh_file), float(kthr), int(seg_min_verts),
+                                     None if out_json is None else os.fsencode(out_json), C.byref(n)))
+    return n.value
