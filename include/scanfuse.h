@@ -110,6 +110,12 @@ int sf_fuser_profile_read(sf_fuser* f, double* integrate_ms, uint64_t* launches,
  * bytes ({float sdf; uchar r,g,b,weight} x 512, index z*64+y*8+x).  Pass NULLs to query n only. */
 int sf_fuser_export_blocks(sf_fuser* f, int32_t* coords, void* voxels, uint64_t capacity, uint64_t* n);
 
+/* Iso-surface extraction (marching cubes over all live blocks, exact weld): the `<id>_vh.ply` product of the
+ * improve stage (Server/scan_processor.py:141, scan_stages.json:33-42).  Vertices are ordered by grid-edge key,
+ * triangles by cube; the result is deterministic.  Free with sf_mesh_free; write with sf_mesh_write_ply. */
+struct sf_mesh;
+int sf_fuser_extract_mesh(sf_fuser* f, struct sf_mesh** out);
+
 /* Host <-> device helpers so that callers without a HIP binding can stage inputs in HBM. */
 int sf_device_malloc(int device, uint64_t bytes, void** out);
 int sf_device_free(void* p);

@@ -21,66 +21,9 @@
 #include <cstring>
 #include <vector>
 
-#include "common.h"
+#include "fuser_internal.h"
 
 namespace {
-
-constexpr uint64_t KEY_EMPTY = ~0ull;
-constexpr uint64_t KEY_TOMB = ~0ull - 1ull;
-constexpr int MAX_DDA_ITERS = 1024;
-constexpr int MAX_PROBES = 4096;
-
-struct HashEntry {
-  uint64_t key;
-  int32_t ptr;
-  uint32_t pad;
-};
-static_assert(sizeof(HashEntry) == 16, "hash entry is 16 bytes");
-
-struct ParamsK {
-  int W, H;
-  float fx, fy, mx, my;
-  float depth_shift, dmin, dmax;
-  float voxel, tbase, tscale, maxd;
-  int wsample, wmax;
-  uint32_t num_buckets, bucket_size, total_slots, num_blocks;
-};
-
-struct FrameK {
-  float T[12];
-  float Ti[12];
-  float xa[2], xc[2], xr[2];
-  float ya[2], yc[2], yr[2];
-  float radius, zfar;
-};
-
-enum Counter {
-  C_HEAP_FREE = 0,
-  C_COMPACT = 1,
-  C_HIGH_WATER = 2,
-  C_ALLOC_FAIL = 3,
-  C_SLOTS_USED = 4,
-  C_LAST_BLOCKS = 5,
-  C_EXPORT = 6,
-  C_GC_FREED = 7,
-  C_TOTAL_LO = 8,  // 64-bit sum of N_blk lives in counters[8..9]
-  C_COMPACT_B = 10,  // second frame slot (frames alternate between two sets of per-frame buffers)
-  C_COUNT = 16
-};
-
-__host__ __device__ inline uint64_t pack_key(int x, int y, int z) {
-  return (((uint64_t)x & 0x1FFFFFull) << 42) | (((uint64_t)y & 0x1FFFFFull) << 21) | ((uint64_t)z & 0x1FFFFFull);
-}
-__host__ __device__ inline void unpack_key(uint64_t k, int& x, int& y, int& z) {
-  x = ((int)((k >> 42) & 0x1FFFFF) << 11) >> 11;
-  y = ((int)((k >> 21) & 0x1FFFFF) << 11) >> 11;
-  z = ((int)(k & 0x1FFFFF) << 11) >> 11;
-}
-
-__device__ inline uint32_t hash_bucket(int x, int y, int z, uint32_t num_buckets) {
-  const uint32_t h = ((uint32_t)x * 73856093u) ^ ((uint32_t)y * 19349669u) ^ ((uint32_t)z * 83492791u);
-  return h % num_buckets;
-}
 
 // bounding sphere of the block against the four side planes and the z range of the frustum
 __device__ inline bool block_in_frustum(const ParamsK& P, const FrameK& F, int bx, int by, int bz) {
@@ -596,41 +539,7 @@ __global__ __launch_bounds__(256) void k_gather(const uint4* __restrict__ voxels
 // ======================================================================================================
 // host side
 // ======================================================================================================
-struct sf_fuser;
-static hipError_t sf_quiesce(sf_fuser* f);
-struct sf_fuser {
-  sf_params p;
-  ParamsK pk;
-  int device = 0;
-  hipStream_t stream = nullptr;  // integrate / deintegrate and everything synchronous
-  hipStream_t front = nullptr;   // pre-pass, allocation, compaction of the NEXT frame (overlaps integrate)
-  hipEvent_t ev_compact[2] = {nullptr, nullptr};   // front: frame slot ready for integrate
-  hipEvent_t ev_fused[2] = {nullptr, nullptr};     // stream: frame slot consumed
-  int slot = 0;
-  bool overlap = true;  // SF_NO_OVERLAP=1 runs everything on one stream
-  float* depthf2[2] = {nullptr, nullptr};
-  uint32_t* color2[2] = {nullptr, nullptr};
-  int32_t* compact2[2] = {nullptr, nullptr};
-  HashEntry* table = nullptr;
-  int32_t* heap = nullptr;
-  uint64_t* block_keys = nullptr;
-  uint4* voxels = nullptr;
-  int32_t* compact = nullptr;  // alias of compact2[0], used by the synchronous paths (export, GC)
-  int32_t* counters = nullptr;
-  void* staging_depth = nullptr;  // device copies of host-supplied frames
-  void* staging_rgb = nullptr;
-  int32_t* host_mirror = nullptr;  // pinned, device-visible: N_blk of the most recent integrate
-  int num_cus = 256;
-  bool alloc_win64 = false;  // 64^3-block LDS window when a ray segment spans more than ~20 blocks
-  int alloc_dbg = 0;  // SF_ALLOC_DEBUG: timing experiments only (1 = skip phase 2, 2 = skip LDS inserts)
-  int compact_grid = 1024;  // 1024 directory entries per workgroup, grid-stride beyond
-  uint64_t frames_integrated = 0, frames_skipped = 0;
-  bool profile = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
-  size_t events_used = 0;
-};
-
-static hipError_t sf_quiesce(sf_fuser* f) {
+hipError_t sf_quiesce(sf_fuser* f) {
   hipError_t e = hipSuccess;
   if (f->front) e = hipStreamSynchronize(f->front);
   const hipError_t e2 = hipStreamSynchronize(f->stream);
@@ -942,7 +851,7 @@ SF_API int sf_fuser_profile_read(sf_fuser* f, double* integrate_ms, uint64_t* la
   return SF_OK;
 }
 
-static int compact_live(sf_fuser* f, int32_t* n_out) {
+int sf_compact_live(sf_fuser* f, int32_t* n_out) {
   SF_HIP_CHECK(sf_quiesce(f));
   FrameK dummy;
   std::memset(&dummy, 0, sizeof(dummy));
@@ -958,7 +867,7 @@ SF_API int sf_fuser_garbage_collect(sf_fuser* f, uint32_t* freed) {
   if (!f) return sf::fail(SF_ERR_INVALID_ARG, "NULL fuser");
   SF_HIP_CHECK(hipSetDevice(f->device));
   int32_t n = 0;
-  const int rc = compact_live(f, &n);
+  const int rc = sf_compact_live(f, &n);
   if (rc != SF_OK) return rc;
   SF_HIP_CHECK(hipMemsetAsync(&f->counters[C_GC_FREED], 0, 4, f->stream));
   const float thr = std::fmaf(f->p.trunc_scale, f->p.depth_max, f->p.trunc_base);
@@ -976,7 +885,7 @@ SF_API int sf_fuser_export_blocks(sf_fuser* f, int32_t* coords, void* voxels, ui
   if (!f || !n_out) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
   SF_HIP_CHECK(hipSetDevice(f->device));
   int32_t n = 0;
-  const int rc = compact_live(f, &n);
+  const int rc = sf_compact_live(f, &n);
   if (rc != SF_OK) return rc;
   *n_out = (uint64_t)n;
   if (!coords && !voxels) return SF_OK;

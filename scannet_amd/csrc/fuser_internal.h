@@ -1,0 +1,116 @@
+// fuser_internal.h -- device-side layout and the sf_fuser handle, shared by fuser.hip and mc.hip
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <utility>
+#include <vector>
+
+#include "common.h"
+
+constexpr uint64_t KEY_EMPTY = ~0ull;
+constexpr uint64_t KEY_TOMB = ~0ull - 1ull;
+constexpr int MAX_DDA_ITERS = 1024;
+constexpr int MAX_PROBES = 4096;
+
+struct HashEntry {
+  uint64_t key;
+  int32_t ptr;
+  uint32_t pad;
+};
+static_assert(sizeof(HashEntry) == 16, "hash entry is 16 bytes");
+
+struct ParamsK {
+  int W, H;
+  float fx, fy, mx, my;
+  float depth_shift, dmin, dmax;
+  float voxel, tbase, tscale, maxd;
+  int wsample, wmax;
+  uint32_t num_buckets, bucket_size, total_slots, num_blocks;
+};
+
+struct FrameK {
+  float T[12];
+  float Ti[12];
+  float xa[2], xc[2], xr[2];
+  float ya[2], yc[2], yr[2];
+  float radius, zfar;
+};
+
+enum Counter {
+  C_HEAP_FREE = 0,
+  C_COMPACT = 1,
+  C_HIGH_WATER = 2,
+  C_ALLOC_FAIL = 3,
+  C_SLOTS_USED = 4,
+  C_LAST_BLOCKS = 5,
+  C_EXPORT = 6,
+  C_GC_FREED = 7,
+  C_TOTAL_LO = 8,  // 64-bit sum of N_blk lives in counters[8..9]
+  C_COMPACT_B = 10,  // second frame slot (frames alternate between two sets of per-frame buffers)
+  C_COUNT = 16
+};
+
+__host__ __device__ inline uint64_t pack_key(int x, int y, int z) {
+  return (((uint64_t)x & 0x1FFFFFull) << 42) | (((uint64_t)y & 0x1FFFFFull) << 21) | ((uint64_t)z & 0x1FFFFFull);
+}
+__host__ __device__ inline void unpack_key(uint64_t k, int& x, int& y, int& z) {
+  x = ((int)((k >> 42) & 0x1FFFFF) << 11) >> 11;
+  y = ((int)((k >> 21) & 0x1FFFFF) << 11) >> 11;
+  z = ((int)(k & 0x1FFFFF) << 11) >> 11;
+}
+
+__device__ inline uint32_t hash_bucket(int x, int y, int z, uint32_t num_buckets) {
+  const uint32_t h = ((uint32_t)x * 73856093u) ^ ((uint32_t)y * 19349669u) ^ ((uint32_t)z * 83492791u);
+  return h % num_buckets;
+}
+
+
+// lookup only: heap slot of block (x,y,z) or -1
+__device__ inline int hash_lookup(const HashEntry* __restrict__ table, const ParamsK& P, int x, int y, int z) {
+  const uint64_t key = pack_key(x, y, z);
+  uint32_t slot = hash_bucket(x, y, z, P.num_buckets) * P.bucket_size;
+  for (int probe = 0; probe < MAX_PROBES; ++probe) {
+    const uint64_t k = table[slot].key;
+    if (k == key) return table[slot].ptr;
+    if (k == KEY_EMPTY) return -1;
+    slot++;
+    if (slot == P.total_slots) slot = 0;
+  }
+  return -1;
+}
+
+struct sf_fuser {
+  sf_params p;
+  ParamsK pk;
+  int device = 0;
+  hipStream_t stream = nullptr;  // integrate / deintegrate and everything synchronous
+  hipStream_t front = nullptr;   // pre-pass, allocation, compaction of the NEXT frame (overlaps integrate)
+  hipEvent_t ev_compact[2] = {nullptr, nullptr};   // front: frame slot ready for integrate
+  hipEvent_t ev_fused[2] = {nullptr, nullptr};     // stream: frame slot consumed
+  int slot = 0;
+  bool overlap = true;  // SF_NO_OVERLAP=1 runs everything on one stream
+  float* depthf2[2] = {nullptr, nullptr};
+  uint32_t* color2[2] = {nullptr, nullptr};
+  int32_t* compact2[2] = {nullptr, nullptr};
+  HashEntry* table = nullptr;
+  int32_t* heap = nullptr;
+  uint64_t* block_keys = nullptr;
+  uint4* voxels = nullptr;
+  int32_t* compact = nullptr;  // alias of compact2[0], used by the synchronous paths (export, GC)
+  int32_t* counters = nullptr;
+  void* staging_depth = nullptr;  // device copies of host-supplied frames
+  void* staging_rgb = nullptr;
+  int32_t* host_mirror = nullptr;  // pinned, device-visible: N_blk of the most recent integrate
+  int num_cus = 256;
+  bool alloc_win64 = false;  // 64^3-block LDS window when a ray segment spans more than ~20 blocks
+  int alloc_dbg = 0;  // SF_ALLOC_DEBUG: timing experiments only (1 = skip phase 2, 2 = skip LDS inserts)
+  int compact_grid = 1024;  // 1024 directory entries per workgroup, grid-stride beyond
+  uint64_t frames_integrated = 0, frames_skipped = 0;
+  bool profile = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  size_t events_used = 0;
+};
+
+
+hipError_t sf_quiesce(sf_fuser* f);                 // drain both streams
+int sf_compact_live(sf_fuser* f, int32_t* n_out);   // live heap slots -> f->compact, synchronous

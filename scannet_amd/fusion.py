@@ -133,6 +133,13 @@ class Fuser:
         check(_abi.lib().sf_fuser_profile_read(self._h, C.byref(ms), C.byref(n), C.byref(b)))
         return ms.value, n.value, b.value
 
+    def extract_mesh(self):
+        """Marching cubes over all live blocks -> segmentator.Mesh (vertices in edge-key order, deterministic)."""
+        from .segmentator import Mesh
+        h = C.c_void_p()
+        check(_abi.lib().sf_fuser_extract_mesh(self._h, C.byref(h)))
+        return Mesh(h)
+
     def export_blocks(self):
         """-> (coords int32 [n,3], voxels VOXEL_DTYPE [n,512]) sorted lexicographically by (x,y,z)."""
         n = C.c_uint64(0)
