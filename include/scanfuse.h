@@ -110,6 +110,19 @@ int sf_fuser_profile_read(sf_fuser* f, double* integrate_ms, uint64_t* launches,
  * bytes ({float sdf; uchar r,g,b,weight} x 512, index z*64+y*8+x).  Pass NULLs to query n only. */
 int sf_fuser_export_blocks(sf_fuser* f, int32_t* coords, void* voxels, uint64_t capacity, uint64_t* n);
 
+/* Fuse frames [first, last) of an opened .sens file (last = 0: to the end): a pool of `decode_threads` (0 = one
+ * per core) inflates depth frames into pinned buffers in frame order, copies and kernels are queued as frames
+ * become ready.  Replaces the frame loop around RGBDFrameCacheRead (sensorData.h:1717-1831).  The fuser must have
+ * been created for the file's depth resolution.  Colour is fused when it is stored at depth resolution. */
+typedef struct sf_run_stats {
+  uint64_t frames_total, frames_integrated, frames_skipped;
+  uint32_t decode_threads, color_fused;
+  double seconds_total;       /* wall time of the call: first byte decoded -> last kernel complete */
+  double seconds_decode_cpu;  /* decode time summed over the pool */
+} sf_run_stats;
+struct sf_sens;
+int sf_fuse_run(sf_fuser* f, const struct sf_sens* s, uint64_t first, uint64_t last, int decode_threads, sf_run_stats* stats);
+
 /* Iso-surface extraction (marching cubes over all live blocks, exact weld): the `<id>_vh.ply` product of the
  * improve stage (Server/scan_processor.py:141, scan_stages.json:33-42).  Vertices are ordered by grid-edge key,
  * triangles by cube; the result is deterministic.  Free with sf_mesh_free; write with sf_mesh_write_ply. */

@@ -11,6 +11,12 @@ import numpy as np
 from . import _abi
 from ._abi import SfParams, SfStats, check
 
+class SfRunStats(C.Structure):
+    _fields_ = [("frames_total", C.c_uint64), ("frames_integrated", C.c_uint64), ("frames_skipped", C.c_uint64),
+                ("decode_threads", C.c_uint32), ("color_fused", C.c_uint32),
+                ("seconds_total", C.c_double), ("seconds_decode_cpu", C.c_double)]
+
+
 VOXEL_DTYPE = np.dtype([("sdf", "<f4"), ("r", "u1"), ("g", "u1"), ("b", "u1"), ("w", "u1")])
 
 
@@ -132,6 +138,12 @@ class Fuser:
         ms, n, b = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
         check(_abi.lib().sf_fuser_profile_read(self._h, C.byref(ms), C.byref(n), C.byref(b)))
         return ms.value, n.value, b.value
+
+    def run(self, sensor_data, first=0, last=0, decode_threads=0):
+        """Fuse frames [first, last) of a scannet_amd.sens.SensorData (threaded decode overlapped with the GPU)."""
+        st = SfRunStats()
+        check(_abi.lib().sf_fuse_run(self._h, sensor_data._h, int(first), int(last), int(decode_threads), C.byref(st)))
+        return {k: getattr(st, k) for k, _ in SfRunStats._fields_}
 
     def extract_mesh(self):
         """Marching cubes over all live blocks -> segmentator.Mesh (vertices in edge-key order, deterministic)."""
