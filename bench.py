@@ -11,9 +11,14 @@ every rank fuses its own scan (independent scans shard scan-per-GPU, no data-pat
 """
 import argparse
 import ctypes as C
+import glob
 import json
 import os
+import shutil
+import sqlite3
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -43,6 +48,53 @@ def cpu_baseline(depth_host, poses, budget_s=12.0, max_frames=96):
             "sample": "first %d frames of the same stream, oracle/tsdf_oracle.c -O2 -fopenmp (%d threads), %.1f s" % (n, threads, dt)}
 
 
+def pmc_traffic(steps, warmup, timeout_s=300):
+    """HBM traffic of k_integrate from the PMC counters, per launch: two SEPARATE rocprofv3 passes (--pmc FETCH_SIZE,
+    --pmc WRITE_SIZE; no trace domains) over the first `steps` timed frames of this same script.  Corrections as
+    MI355X_MICROARCH.md (HBM) prescribes and tools/pmc_calibrate.py confirmed for this kernel's 16 B/lane pattern
+    (profiles/r01_b_alloc_bitmap_rocprofv3.txt): both counters are KiB per dispatch, FETCH_SIZE reports exactly half of
+    the bytes read, WRITE_SIZE the bytes written.  Returns None when rocprofv3 is missing or a pass fails."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    per_launch = {}
+    child_line = None
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="sf_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            cmd = [exe, "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--steps", str(steps),
+                   "--warmup", str(warmup), "--no-cpu-baseline", "--no-profile", "--no-pmc"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None
+            for ln in r.stdout.splitlines():
+                if ln.startswith("{") and '"metric"' in ln:
+                    child_line = json.loads(ln)
+            db = sqlite3.connect(dbs[0])
+            # the integrate launches of the timed region are the LAST `steps` dispatches of the kernel (warm-up comes first)
+            rows = [v for (v,) in db.execute("select value from counters_collection where counter_name = ? and kernel_name like "
+                                             "'%k_integrate<1, false>%' order by dispatch_id", (counter,))]
+            db.close()
+            launches = child_line["config"]["integrate_launches"] if child_line else 0
+            if launches <= 0 or len(rows) < launches:
+                return None
+            per_launch[counter] = sum(rows[-launches:]) / launches * 1024.0
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    read_b = 2.0 * per_launch["FETCH_SIZE"]
+    write_b = per_launch["WRITE_SIZE"]
+    alg = child_line["config"].get("alg_bytes_per_launch") if child_line else None
+    return {"bytes": round(read_b + write_b), "read_bytes": round(read_b), "write_bytes": round(write_b),
+            "sample": "k_integrate launches of frames %d..%d, rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; "
+                      "FETCH_SIZE x2 (gfx950 128-B requests tallied at 64 B), WRITE_SIZE x1, KiB -> bytes" % (warmup, warmup + steps - 1),
+            "alg_bytes_same_launches": alg,
+            "traffic_over_alg": round((read_b + write_b) / alg, 4) if alg else None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -50,6 +102,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket the integrate kernel with HIP events")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes that measure roofline.traffic")
+    ap.add_argument("--pmc-steps", type=int, default=400)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -113,6 +167,8 @@ def main():
 
     if rank == 0:
         blocks = st1["total_frame_blocks"] - st0["total_frame_blocks"]
+        batch = fuser.batch_frames
+        n_launch = (K + batch - 1) // batch
         # B_frame = N_blk*(512*8 read + 512*8 write + 16) + W*H*2 + 64
         alg_bytes = blocks * (4096 + 4096 + 16) + K * (W * H * 2 + 64)
         roof = None
@@ -121,8 +177,11 @@ def main():
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                     "kernel": "k_integrate<1,false>", "avg_kernel_us": round(kernel_ms * 1e3 / launches, 2),
-                    "avg_blocks_per_launch": round(blocks / max(launches, 1), 1),
-                    "alg_bytes_per_launch": round(alg_bytes / max(launches, 1))}
+                    "launches": launches, "frames_per_launch": round(K / launches, 2),
+                    "avg_frame_blocks_per_launch": round(blocks / max(launches, 1), 1),
+                    "alg_bytes_per_launch": round(alg_bytes / max(launches, 1)),
+                    "note": "one launch fuses frames_per_launch frames into each tile while it sits in registers (temporal blocking): "
+                            "algorithmic bytes = sum of the per-frame SURVEY 8d figures, HBM traffic is ~1/frames_per_launch of it"}
         out = {
             "metric": "RGB-D frames/sec integrated (640x480, 4 mm voxel)",
             "value": round(world * K / elapsed, 2), "unit": "frames/s",
@@ -134,9 +193,16 @@ def main():
             "config": {"workload": "configs[1]: scene0000_00-scale synthetic stream (5578-frame box-room walk, 640x480 u16 depth, "
                                    "4 mm voxels, 2^19 hash buckets x 10, 2^20 SDF blocks), frames %d..%d per rank, depth resident in HBM" % (Wm, n_frames - 1),
                        "sharding": "one independent scan per GPU, no collective on the data path",
-                       "blocks_live_end": st1["blocks_allocated"], "alloc_failures": st1["alloc_failures"]},
+                       "blocks_live_end": st1["blocks_allocated"], "alloc_failures": st1["alloc_failures"],
+                       "frames_per_pass": batch, "integrate_launches": n_launch,
+                       "alg_bytes_per_launch": round(alg_bytes / max(n_launch, 1))},
             "roofline": roof,
         }
+        if roof is not None and world == 1 and not args.no_pmc:
+            t = pmc_traffic(min(args.pmc_steps, K), Wm)
+            if t is not None:
+                roof["traffic"] = t["bytes"]
+                roof["traffic_detail"] = t
         if not args.no_cpu_baseline:
             ns = min(96, n_frames)
             out["cpu_baseline"] = cpu_baseline(frames[:ns].cpu().numpy().view(np.uint16), poses[:ns].reshape(-1, 4, 4))

@@ -92,9 +92,12 @@ int sf_fuser_deintegrate(sf_fuser* f, const uint16_t* depth, const uint8_t* rgb,
 /* Device-buffer entry points (inputs already resident in HBM; used by bench.py and by sf_fuse_run). */
 int sf_fuser_integrate_device(sf_fuser* f, const void* d_depth, const void* d_rgb, const float pose[16]);
 int sf_fuser_deintegrate_device(sf_fuser* f, const void* d_depth, const void* d_rgb, const float pose[16]);
-/* n frames laid out `frame_stride_bytes` apart starting at d_depth; poses = n*16 floats on the host. */
+/* n frames laid out `frame_stride_bytes` apart starting at d_depth; poses = n*16 floats on the host; -inf poses are
+ * skipped.  Frames are fused sf_fuser_batch_frames() at a time: one pass over the voxel tiles applies every frame of
+ * the batch in frame order (temporal blocking) -- the result is bit-identical to frame-by-frame integration. */
 int sf_fuser_integrate_batch_device(sf_fuser* f, const void* d_depth, uint64_t frame_stride_bytes,
                                     const float* poses, uint64_t n);
+int sf_fuser_batch_frames(const sf_fuser* f);   /* 16 unless SF_BATCH=1..16 was set when the fuser was created */
 
 int sf_fuser_garbage_collect(sf_fuser* f, uint32_t* freed);
 int sf_fuser_sync(sf_fuser* f);

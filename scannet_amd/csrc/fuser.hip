@@ -8,12 +8,12 @@
 // fused multiply-add of the spec, nothing else is contracted.
 //
 // Data layout in HBM:
-//   table      HashEntry[num_buckets * bucket_size]   16 B: {u64 key (3 x 21-bit block coords), i32 heap block, pad}
+//   table      HashEntry[num_buckets * bucket_size]   16 B: {u64 key (3 x 21-bit block coords), i32 heap block, u32 birth frame}
 //   block_keys u64[num_sdf_blocks]                    directory: key of the block living in heap slot i, or EMPTY
 //   heap       i32[num_sdf_blocks] + free counter     free list of heap slots (wave-aggregated pops)
 //   voxels     8 B x 512 x num_sdf_blocks             {f32 sdf; u8 r,g,b,weight}, one 4 KiB tile per block, index z*64+y*8+x
-//   depthf     f32[W*H], color u32[W*H]               per-frame pre-pass outputs (L2 resident)
-//   compact    i32[num_sdf_blocks]                    heap slots of the blocks in the current frustum
+//   depthf     f32[B][W*H], color u32[B][W*H]         pre-pass outputs of the B <= 16 frames of a batch (L2 / Infinity-Cache resident)
+//   compact    i32[num_sdf_blocks] + u32 mask         heap slots of the blocks some frame of the batch sees; bit j = frame j updates it
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -50,13 +50,20 @@ __device__ inline int world_to_block(float w, float voxel) {
 
 // ---------------------------------------------------------------------------------------------------
 // K1: depth pre-pass.  u16 -> metres (sensorData.h:968-977: d = depth / depthShift, 0 invalid), range
-// gate (zParametersScanNet.txt:34-35) -> -inf; optional rgb -> packed u32.  8 pixels per lane.
+// gate (zParametersScanNet.txt:34-35) -> -inf; optional rgb -> packed u32.  8 pixels per lane; blockIdx.y = frame
+// of the batch (every frame of a batch is converted by ONE launch).
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_prepass(const uint16_t* __restrict__ depth, const uint8_t* __restrict__ rgb,
-                                                 float* __restrict__ depthf, uint32_t* __restrict__ color, int n,
+__global__ __launch_bounds__(256) void k_prepass(BatchIn in, float* __restrict__ depthf_all, uint32_t* __restrict__ color_all, int n,
                                                  float shift, float dmin, float dmax, int32_t* counters, int compact_counter) {
+  const int j = blockIdx.y;  // frame of the batch
+  const uint16_t* __restrict__ depth = in.depth[j];
+  const uint8_t* __restrict__ rgb = in.rgb[j];
+  float* __restrict__ depthf = depthf_all + (size_t)j * n;
+  uint32_t* __restrict__ color = color_all + (size_t)j * n;
   const int i0 = (blockIdx.x * 256 + threadIdx.x) * 8;
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicExch(&counters[compact_counter], 0);
+  if (blockIdx.x == 0 && j == 0 && threadIdx.x == 0) {
+    atomicExch(reinterpret_cast<unsigned long long*>(&counters[compact_counter]), 0ull);
+  }
   if (i0 >= n) return;
   uint16_t u[8];
   if (i0 + 8 <= n) {
@@ -88,7 +95,8 @@ __global__ __launch_bounds__(256) void k_prepass(const uint16_t* __restrict__ de
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K2: allocation.  One lane per depth pixel, one 256-thread workgroup per 16x16 pixel tile.
+// K2: allocation.  One lane per depth pixel, one 256-thread workgroup per 16x16 pixel tile, blockIdx.z = frame of
+// the batch (ONE launch allocates for up to 16 frames: 16 x 1200 workgroups fill the chip, one frame's 1200 do not).
 //   phase 1 (no global memory): every lane walks its 3-D DDA over the blocks of [d - t, d + t] and drops
 //            the block keys into a workgroup-wide LDS hash set (ds_cmpst CAS) -- neighbouring rays and
 //            consecutive steps hit the same blocks, the set keeps ~50-150 unique keys per tile;
@@ -107,20 +115,28 @@ struct HashRefs {
   HashEntry* table;
   int32_t* heap;
   uint64_t* block_keys;
+  int32_t* block_entry;
   int32_t* counters;
 };
 
+// A block is "born" in the first frame that asks for it: frames of one batch are allocated by ONE launch, so the
+// entry keeps the minimum sequence number over everybody who found or claimed it (the frames before its birth
+// must not update the block -- sequentially it did not exist yet).
+__device__ inline void note_birth(HashEntry* e, uint32_t seq) {
+  if (__hip_atomic_load(&e->birth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > seq) atomicMin(&e->birth, seq);
+}
+
 // find-or-claim `key`; returns the claimed entry (needs a heap block) or nullptr (already present / table full)
-__device__ inline HashEntry* hash_find_or_claim(const HashRefs& h, const ParamsK& P, uint64_t key, int bx, int by, int bz) {
+__device__ inline HashEntry* hash_find_or_claim(const HashRefs& h, const ParamsK& P, uint64_t key, int bx, int by, int bz, uint32_t seq) {
   uint32_t slot = hash_bucket(bx, by, bz, P.num_buckets) * P.bucket_size;
   for (int probe = 0; probe < MAX_PROBES; ++probe) {
     HashEntry* e = h.table + slot;
     const uint64_t k = __hip_atomic_load(&e->key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (k == key) return nullptr;
+    if (k == key) { note_birth(e, seq); return nullptr; }
     if (k == KEY_EMPTY) {
       const uint64_t old = atomicCAS((unsigned long long*)&e->key, (unsigned long long)KEY_EMPTY, (unsigned long long)key);
-      if (old == KEY_EMPTY) return e;
-      if (old == key) return nullptr;
+      if (old == KEY_EMPTY) { note_birth(e, seq); return e; }
+      if (old == key) { note_birth(e, seq); return nullptr; }
     }
     slot++;
     if (slot == P.total_slots) slot = 0;
@@ -134,6 +150,7 @@ __device__ inline void give_block(const HashRefs& h, HashEntry* e, uint64_t key,
     const int idx = h.heap[at];
     e->ptr = idx;
     h.block_keys[idx] = key;
+    h.block_entry[idx] = (int32_t)(e - h.table);
     atomicMax(&h.counters[C_HIGH_WATER], idx + 1);
   } else {
     // heap exhausted: the entry stays claimed without a block; undo the pop
@@ -143,8 +160,11 @@ __device__ inline void give_block(const HashRefs& h, HashEntry* e, uint64_t key,
 }
 
 template <int WIN_LOG2>
-__global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf, HashEntry* table, int32_t* heap,
-                                               uint64_t* block_keys, int32_t* counters, ParamsK P, FrameK F, int dbg) {
+__global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_all, HashEntry* table, int32_t* heap,
+                                               uint64_t* block_keys, int32_t* block_entry, int32_t* counters, ParamsK P, BatchFrames B, int dbg) {
+  const FrameK& F = B.f[blockIdx.z];  // blockIdx.z = frame of the batch (uniform: scalar loads from the kernarg segment)
+  const uint32_t seq = B.seq0 + blockIdx.z;
+  const float* __restrict__ depthf = depthf_all + (size_t)blockIdx.z * ((size_t)P.W * P.H);
   constexpr int WIN = 1 << WIN_LOG2;                // window edge in blocks
   constexpr int WIN_WORDS = (WIN * WIN * WIN) / 32; // occupancy bitmap words
   __shared__ uint32_t s_bits[WIN_WORDS];            // 4 KiB (WIN 32) / 32 KiB (WIN 64)
@@ -158,7 +178,7 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf,
   if (threadIdx.x == 0) { s_count = 0; s_chooser = 256; }
   const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
   const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
-  const HashRefs h{table, heap, block_keys, counters};
+  const HashRefs h{table, heap, block_keys, block_entry, counters};
   for (int i = threadIdx.x; i < ALLOC_SET; i += 256) s_keys[i] = KEY_EMPTY;
   for (int i = threadIdx.x; i < WIN_WORDS; i += 256) s_bits[i] = 0u;
   __syncthreads();
@@ -250,7 +270,7 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf,
           }
           if (!placed && block_in_frustum(P, F, a_cx, a_cy, a_cz)) {
             // overflow of the overflow set (pathological tile): straight to the global table
-            HashEntry* e = hash_find_or_claim(h, P, key, a_cx, a_cy, a_cz);
+            HashEntry* e = hash_find_or_claim(h, P, key, a_cx, a_cy, a_cz, seq);
             if (e) {
               atomicAdd(&counters[C_SLOTS_USED], 1);
               give_block(h, e, key, atomicSub(&counters[C_HEAP_FREE], 1) - 1);
@@ -278,7 +298,7 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf,
       if (pos < ALLOC_LIST) s_list[pos] = pack_key(bx, by, bz);
       else if (block_in_frustum(P, F, bx, by, bz)) {
         const uint64_t key = pack_key(bx, by, bz);
-        HashEntry* e = hash_find_or_claim(h, P, key, bx, by, bz);
+        HashEntry* e = hash_find_or_claim(h, P, key, bx, by, bz, seq);
         if (e) {
           atomicAdd(&counters[C_SLOTS_USED], 1);
           give_block(h, e, key, atomicSub(&counters[C_HEAP_FREE], 1) - 1);
@@ -297,7 +317,7 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf,
     if (key != KEY_EMPTY) {
       int bx, by, bz;
       unpack_key(key, bx, by, bz);
-      if (block_in_frustum(P, F, bx, by, bz)) claimed = hash_find_or_claim(h, P, key, bx, by, bz);
+      if (block_in_frustum(P, F, bx, by, bz)) claimed = hash_find_or_claim(h, P, key, bx, by, bz, seq);
     }
     // wave-aggregated heap pop for the freshly claimed slots
     const uint64_t cm = __ballot(claimed != nullptr);
@@ -320,52 +340,78 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf,
 
 // ---------------------------------------------------------------------------------------------------
 // K3: compactify.  Scans the block directory (8 B per heap slot up to the high-water mark -- not the
-// 16 B x buckets x 10 hash table upstream scans) and appends the slots whose block is in the frustum.
-// 1024 directory entries per workgroup, ballot prefix sums inside the waves, one LDS exchange and ONE
-// global atomic per workgroup (a single counter word saturates at ~88 atomics/us on this chip).
-// all_live != 0 skips the frustum test (used by export / GC).
+// 16 B x buckets x 10 hash table upstream scans) and appends the slots of the blocks that at least one
+// frame of the batch updates, together with the bit mask of those frames: bit j is set iff the block is in
+// frame j's frustum AND was born no later than frame j.  1024 directory entries per workgroup, ballot
+// prefix sums inside the waves, one LDS exchange and TWO global atomics per workgroup (list position +
+// last-frame count in one 64-bit word, the N_blk total in another cache line; a single counter word
+// saturates at ~88 atomics/us on this chip).  all_live != 0 lists every live block (export / GC / meshing).
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_compactify(const uint64_t* __restrict__ block_keys, int32_t* __restrict__ compact,
-                                                    int32_t* counters, int counter_id, int all_live, ParamsK P, FrameK F) {
-  __shared__ int s_wtot[4];
+__global__ __launch_bounds__(256) void k_compactify(const uint64_t* __restrict__ block_keys, const int32_t* __restrict__ block_entry,
+                                                    const HashEntry* __restrict__ table, int32_t* __restrict__ compact,
+                                                    uint32_t* __restrict__ cmask, int32_t* counters, int counter_id, int all_live, ParamsK P,
+                                                    BatchFrames B) {
+  __shared__ int s_wtot[4], s_wlast[4], s_wpop[4];
   __shared__ int s_base;
   const int hw = counters[C_HIGH_WATER];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t last_bit = 1u << (B.n - 1);
   for (int base = blockIdx.x * 1024; base < hw; base += gridDim.x * 1024) {
-    bool in[4];
+    uint32_t m[4];
     int rank[4];
-    int wtotal = 0;
+    int wtotal = 0, wlast = 0, pop = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const int i = base + j * 256 + threadIdx.x;
-      in[j] = false;
+      m[j] = 0u;
       if (i < hw) {
         const uint64_t k = block_keys[i];
         if (k != KEY_EMPTY) {
-          if (all_live) in[j] = true;
+          if (all_live) m[j] = 1u;
           else {
             int bx, by, bz;
             unpack_key(k, bx, by, bz);
-            in[j] = block_in_frustum(P, F, bx, by, bz);
+            for (int q = 0; q < B.n; q++)
+              if (block_in_frustum(P, B.f[q], bx, by, bz)) m[j] |= 1u << q;
+            if (m[j] != 0u && B.n > 1) {
+              const uint32_t birth = table[block_entry[i]].birth;
+              if (birth > B.seq0) {
+                const uint32_t d = birth - B.seq0;
+                m[j] = d >= 32u ? 0u : (m[j] & ~((1u << d) - 1u));
+              }
+            }
           }
         }
       }
-      const uint64_t m = __ballot(in[j]);
-      rank[j] = wtotal + __popcll((unsigned long long)(m & ((1ull << lane) - 1ull)));
-      wtotal += __popcll((unsigned long long)m);
+      const uint64_t bal = __ballot(m[j] != 0u);
+      rank[j] = wtotal + __popcll((unsigned long long)(bal & ((1ull << lane) - 1ull)));
+      wtotal += __popcll((unsigned long long)bal);
+      wlast += __popcll((unsigned long long)__ballot((m[j] & last_bit) != 0u));
+      pop += __popc(m[j]);
     }
-    if (lane == 0) s_wtot[wave] = wtotal;
+    for (int o = 32; o > 0; o >>= 1) pop += __shfl_xor(pop, o);
+    if (lane == 0) { s_wtot[wave] = wtotal; s_wlast[wave] = wlast; s_wpop[wave] = pop; }
     __syncthreads();
     if (threadIdx.x == 0) {
       const int total = s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
-      s_base = total ? atomicAdd(&counters[counter_id], total) : 0;
+      const int tlast = s_wlast[0] + s_wlast[1] + s_wlast[2] + s_wlast[3];
+      const int tpop = s_wpop[0] + s_wpop[1] + s_wpop[2] + s_wpop[3];
+      s_base = 0;
+      if (total) {
+        const unsigned long long add = (unsigned long long)(uint32_t)total | ((unsigned long long)(uint32_t)tlast << 32);
+        s_base = (int)(uint32_t)atomicAdd(reinterpret_cast<unsigned long long*>(&counters[counter_id]), add);
+        if (!all_live) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[C_TOTAL_LO]), (unsigned long long)tpop);
+      }
     }
     __syncthreads();
     int off = s_base;
     for (int w = 0; w < wave; w++) off += s_wtot[w];
 #pragma unroll
     for (int j = 0; j < 4; j++)
-      if (in[j]) compact[off + rank[j]] = base + j * 256 + threadIdx.x;
+      if (m[j] != 0u) {
+        compact[off + rank[j]] = base + j * 256 + threadIdx.x;
+        cmask[off + rank[j]] = m[j];
+      }
     __syncthreads();
   }
 }
@@ -373,7 +419,9 @@ __global__ __launch_bounds__(256) void k_compactify(const uint64_t* __restrict__
 // ---------------------------------------------------------------------------------------------------
 // K4: integrate / deintegrate.  One wave per 8^3 block: the 4 KiB tile is read with four fully
 // coalesced 16 B-per-lane loads (1 KiB per instruction, two x-adjacent voxels per load), updated in
-// registers and written back with the same pattern.  There is no reuse inside a tile, so it is not
+// registers by EVERY frame of the batch that sees the block (temporal blocking: HBM traffic per frame
+// falls by the batch size, the kernel turns from HBM-bound at B = 1 to VALU/L2-gather-bound) and written
+// back with the same pattern.  There is no reuse inside a tile, so it is not
 // staged through LDS; the depth image (1.2 MB f32) is gathered through L1/L2.
 // lane l, load j: uint4 q = 64 j + l -> voxels 2q, 2q+1 -> x = (2l)&7 (+1), y = (l>>2)&7, z = 2j + (l>>5).
 // ---------------------------------------------------------------------------------------------------
@@ -426,22 +474,23 @@ __device__ inline bool fuse_voxel(const ParamsK& P, const float* __restrict__ de
 
 template <int SIGN, bool COLOR>
 __global__ __launch_bounds__(256) void k_integrate(uint4* __restrict__ voxels, const uint64_t* __restrict__ block_keys,
-                                                   const int32_t* __restrict__ compact, const float* __restrict__ depthf,
-                                                   const uint32_t* __restrict__ color, int32_t* counters,
-                                                   int32_t* host_mirror, int compact_counter, ParamsK P, FrameK F) {
+                                                   const int32_t* __restrict__ compact, const uint32_t* __restrict__ cmask,
+                                                   const float* __restrict__ depthf_all, const uint32_t* __restrict__ color_all,
+                                                   int32_t* counters, int32_t* host_mirror, int compact_counter, ParamsK P, BatchTi B) {
   const int n = counters[compact_counter];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    atomicExch(&counters[C_LAST_BLOCKS], n);  // counters share a cache line with words the front stream updates atomically
-    atomicAdd(reinterpret_cast<unsigned long long*>(&counters[C_TOTAL_LO]), (unsigned long long)n);
+    atomicExch(&counters[C_LAST_BLOCKS], counters[compact_counter + 1]);  // counters share cache lines with words the front stream updates atomically
     if (host_mirror) *host_mirror = n;
   }
   const int lx = (2 * lane) & 7;
   const int ly = (lane >> 2) & 7;
   const int lzb = lane >> 5;
+  const size_t npx = (size_t)P.W * P.H;
   for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {
     const int slot = compact[i];
+    uint32_t frames = (uint32_t)__builtin_amdgcn_readfirstlane((int)cmask[i]);  // wave-uniform: the frame loop runs on the scalar unit
     int bx, by, bz;
     unpack_key(block_keys[slot], bx, by, bz);
     uint4* vb = voxels + (size_t)slot * 256;
@@ -451,16 +500,31 @@ __global__ __launch_bounds__(256) void k_integrate(uint4* __restrict__ voxels, c
     const float wx0 = (float)(8 * bx + lx) * P.voxel;
     const float wx1 = (float)(8 * bx + lx + 1) * P.voxel;
     const float wy = (float)(8 * by + ly) * P.voxel;
+    float wz[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const float wz = (float)(8 * bz + 2 * j + lzb) * P.voxel;
-      const float ax = fmaf(F.Ti[1], wy, fmaf(F.Ti[2], wz, F.Ti[3]));
-      const float ay = fmaf(F.Ti[5], wy, fmaf(F.Ti[6], wz, F.Ti[7]));
-      const float az = fmaf(F.Ti[9], wy, fmaf(F.Ti[10], wz, F.Ti[11]));
-      const bool u0 = fuse_voxel<SIGN, COLOR>(P, depthf, color, fmaf(F.Ti[0], wx0, ax), fmaf(F.Ti[4], wx0, ay), fmaf(F.Ti[8], wx0, az), v[j].x, v[j].y);
-      const bool u1 = fuse_voxel<SIGN, COLOR>(P, depthf, color, fmaf(F.Ti[0], wx1, ax), fmaf(F.Ti[4], wx1, ay), fmaf(F.Ti[8], wx1, az), v[j].z, v[j].w);
-      if (u0 || u1) vb[j * 64 + lane] = v[j];
+    for (int j = 0; j < 4; j++) wz[j] = (float)(8 * bz + 2 * j + lzb) * P.voxel;
+    bool dirty[4] = {false, false, false, false};
+    // temporal blocking: the tile stays in registers while every frame of the batch that sees the block is fused
+    // into it, in frame order (the same sequence of updates per voxel as frame-by-frame integration)
+    while (frames != 0u) {
+      const int q = __builtin_ctz(frames);
+      frames &= frames - 1u;
+      const float* Ti = B.Ti[q];
+      const float* __restrict__ depthf = depthf_all + (size_t)q * npx;
+      const uint32_t* __restrict__ color = color_all + (size_t)q * npx;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float ax = fmaf(Ti[1], wy, fmaf(Ti[2], wz[j], Ti[3]));
+        const float ay = fmaf(Ti[5], wy, fmaf(Ti[6], wz[j], Ti[7]));
+        const float az = fmaf(Ti[9], wy, fmaf(Ti[10], wz[j], Ti[11]));
+        const bool u0 = fuse_voxel<SIGN, COLOR>(P, depthf, color, fmaf(Ti[0], wx0, ax), fmaf(Ti[4], wx0, ay), fmaf(Ti[8], wx0, az), v[j].x, v[j].y);
+        const bool u1 = fuse_voxel<SIGN, COLOR>(P, depthf, color, fmaf(Ti[0], wx1, ax), fmaf(Ti[4], wx1, ay), fmaf(Ti[8], wx1, az), v[j].z, v[j].w);
+        dirty[j] = dirty[j] || u0 || u1;
+      }
     }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (dirty[j]) vb[j * 64 + lane] = v[j];
   }
 }
 
@@ -580,45 +644,57 @@ bool frame_setup(const sf_params& p, const float* pose, FrameK& f) {
   return true;
 }
 
-int run_frame(sf_fuser* f, const void* d_depth, const void* d_rgb, const float* pose, int sign) {
-  FrameK fk;
-  if (!frame_setup(f->p, pose, fk)) {
-    f->frames_skipped++;
-    return sf::fail(SF_ERR_SKIPPED, "frame skipped: camToWorld is -inf (tracking lost)");
+// One batch: n <= f->batch frames with valid poses, all with or all without colour.  The front stream prepares
+// batch slot `sl` (pre-pass, allocation, compaction for all n frames, three launches) while the back stream is
+// still fusing the previous batch out of the other slot.  Allocation only touches new hash entries / heap slots,
+// integrate only the tiles of its own compact list, so the two never write the same data; slot reuse is ordered
+// by ev_fused[sl].
+int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb, const float* const* poses, int n, int sign) {
+  BatchIn in;
+  BatchFrames bf;
+  BatchTi bt;
+  std::memset(&in, 0, sizeof(in));
+  std::memset(&bf, 0, sizeof(bf));
+  std::memset(&bt, 0, sizeof(bt));
+  bf.n = n;
+  bf.seq0 = f->frame_seq;
+  const bool col = d_rgb != nullptr && d_rgb[0] != nullptr;
+  for (int j = 0; j < n; j++) {
+    if (!frame_setup(f->p, poses[j], bf.f[j])) return sf::fail(SF_ERR_INVALID_ARG, "run_batch: invalid pose in batch");
+    std::memcpy(bt.Ti[j], bf.f[j].Ti, sizeof(bt.Ti[j]));
+    in.depth[j] = (const uint16_t*)d_depth[j];
+    in.rgb[j] = col ? (const uint8_t*)d_rgb[j] : nullptr;
   }
-  const int n = f->p.depth_width * f->p.depth_height;
-  // Two-stream software pipeline: the front stream prepares frame slot `sl` (pre-pass, allocation,
-  // compaction) while the back stream is still integrating the previous frame out of the other slot.
-  // Allocation only touches new hash entries / heap slots, integrate only the blocks of its own compact
-  // list, so the two never write the same data; slot reuse is ordered by ev_fused[sl].
+  f->frame_seq += (uint32_t)n;
+  const int npx = f->p.depth_width * f->p.depth_height;
   const int sl = f->slot;
   f->slot ^= 1;
   const int cc = sl ? (int)C_COMPACT_B : (int)C_COMPACT;
   hipStream_t sa = f->overlap ? f->front : f->stream;
   hipStream_t s = f->stream;
   if (f->overlap) (void)hipStreamWaitEvent(sa, f->ev_fused[sl], 0);
-  hipLaunchKernelGGL(k_prepass, dim3((n / 8 + 255) / 256 + 1), dim3(256), 0, sa, (const uint16_t*)d_depth, (const uint8_t*)d_rgb,
-                     f->depthf2[sl], f->color2[sl], n, f->p.depth_shift, f->p.depth_min, f->p.depth_max, f->counters, cc);
+  hipLaunchKernelGGL(k_prepass, dim3((npx / 8 + 255) / 256 + 1, n), dim3(256), 0, sa, in, f->depthf2[sl], f->color2[sl], npx, f->p.depth_shift,
+                     f->p.depth_min, f->p.depth_max, f->counters, cc);
   if (sign > 0) {
-    const dim3 ag((f->p.depth_width + 15) / 16, (f->p.depth_height + 15) / 16);
+    const dim3 ag((f->p.depth_width + 15) / 16, (f->p.depth_height + 15) / 16, n);
     if (f->alloc_win64)
-      hipLaunchKernelGGL(k_alloc<6>, ag, dim3(256), 0, sa, f->depthf2[sl], f->table, f->heap, f->block_keys, f->counters, f->pk, fk, f->alloc_dbg);
+      hipLaunchKernelGGL(k_alloc<6>, ag, dim3(256), 0, sa, f->depthf2[sl], f->table, f->heap, f->block_keys, f->block_entry, f->counters, f->pk, bf, f->alloc_dbg);
     else
-      hipLaunchKernelGGL(k_alloc<5>, ag, dim3(256), 0, sa, f->depthf2[sl], f->table, f->heap, f->block_keys, f->counters, f->pk, fk, f->alloc_dbg);
+      hipLaunchKernelGGL(k_alloc<5>, ag, dim3(256), 0, sa, f->depthf2[sl], f->table, f->heap, f->block_keys, f->block_entry, f->counters, f->pk, bf, f->alloc_dbg);
   }
-  hipLaunchKernelGGL(k_compactify, dim3(f->compact_grid), dim3(256), 0, sa, f->block_keys, f->compact2[sl], f->counters, cc, 0, f->pk, fk);
+  hipLaunchKernelGGL(k_compactify, dim3(f->compact_grid), dim3(256), 0, sa, f->block_keys, f->block_entry, f->table, f->compact2[sl], f->cmask2[sl],
+                     f->counters, cc, 0, f->pk, bf);
   if (f->overlap) {
     (void)hipEventRecord(f->ev_compact[sl], sa);
     (void)hipStreamWaitEvent(s, f->ev_compact[sl], 0);
   }
-  // grid: enough workgroups (4 blocks each) for the last N_blk the device reported, +25 %; the kernel's
+  // grid: enough workgroups (4 blocks each) for the last list length the device reported, +25 %; the kernel's
   // grid-stride loop covers any excess, surplus workgroups exit at once.
   const int last = *f->host_mirror;
   int est = last + last / 4 + 4096;
   int grid = (est + 3) / 4;
   const int grid_max = f->num_cus * 64;
   if (grid > grid_max) grid = grid_max;
-  const bool col = d_rgb != nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (f->profile) {
     if (f->events_used == f->events.size()) {
@@ -631,9 +707,9 @@ int run_frame(sf_fuser* f, const void* d_depth, const void* d_rgb, const float* 
     f->events_used++;
     (void)hipEventRecord(e0, s);
   }
-#define LAUNCH_INT(SG, CL)                                                                                                         \
-  hipLaunchKernelGGL((k_integrate<SG, CL>), dim3(grid), dim3(256), 0, s, f->voxels, f->block_keys, f->compact2[sl], f->depthf2[sl], \
-                     f->color2[sl], f->counters, f->host_mirror, cc, f->pk, fk)
+#define LAUNCH_INT(SG, CL)                                                                                                          \
+  hipLaunchKernelGGL((k_integrate<SG, CL>), dim3(grid), dim3(256), 0, s, f->voxels, f->block_keys, f->compact2[sl], f->cmask2[sl], \
+                     f->depthf2[sl], f->color2[sl], f->counters, f->host_mirror, cc, f->pk, bt)
   if (sign > 0) { if (col) LAUNCH_INT(1, true); else LAUNCH_INT(1, false); }
   else          { if (col) LAUNCH_INT(-1, true); else LAUNCH_INT(-1, false); }
 #undef LAUNCH_INT
@@ -641,8 +717,19 @@ int run_frame(sf_fuser* f, const void* d_depth, const void* d_rgb, const float* 
   if (f->overlap) (void)hipEventRecord(f->ev_fused[sl], s);
   const hipError_t err = hipGetLastError();
   if (err != hipSuccess) return sf::fail(SF_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(err));
-  f->frames_integrated++;
+  f->frames_integrated += (uint64_t)n;
   return SF_OK;
+}
+
+int run_frame(sf_fuser* f, const void* d_depth, const void* d_rgb, const float* pose, int sign) {
+  if (pose[0] == -INFINITY) {
+    f->frames_skipped++;
+    return sf::fail(SF_ERR_SKIPPED, "frame skipped: camToWorld is -inf (tracking lost)");
+  }
+  const void* dd[1] = {d_depth};
+  const void* dr[1] = {d_rgb};
+  const float* pp[1] = {pose};
+  return run_batch(f, dd, dr, pp, 1, sign);
 }
 
 }  // namespace
@@ -714,14 +801,17 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
     SF_HIP_CHECK(hipEventCreateWithFlags(&f->ev_fused[q], hipEventDisableTiming));
   }
   if (const char* e = getenv("SF_NO_OVERLAP")) f->overlap = atoi(e) == 0;
+  if (const char* e = getenv("SF_BATCH")) { f->batch = atoi(e); if (f->batch < 1) f->batch = 1; if (f->batch > MAX_BATCH) f->batch = MAX_BATCH; }
   SF_ALLOC(f->table, (size_t)k.total_slots * sizeof(HashEntry));
   SF_ALLOC(f->heap, (size_t)k.num_blocks * 4);
   SF_ALLOC(f->block_keys, (size_t)k.num_blocks * 8);
+  SF_ALLOC(f->block_entry, (size_t)k.num_blocks * 4);
   SF_ALLOC(f->voxels, (size_t)k.num_blocks * 4096);
   for (int q = 0; q < 2; q++) {
-    SF_ALLOC(f->depthf2[q], npx * 4);
-    SF_ALLOC(f->color2[q], npx * 4);
+    SF_ALLOC(f->depthf2[q], npx * 4 * MAX_BATCH);
+    SF_ALLOC(f->color2[q], npx * 4 * MAX_BATCH);
     SF_ALLOC(f->compact2[q], (size_t)k.num_blocks * 4);
+    SF_ALLOC(f->cmask2[q], (size_t)k.num_blocks * 4);
   }
   f->compact = f->compact2[0];
   SF_ALLOC(f->counters, C_COUNT * 4);
@@ -746,8 +836,8 @@ SF_API void sf_fuser_destroy(sf_fuser* f) {
   (void)hipSetDevice(f->device);
   if (f->stream) (void)hipStreamSynchronize(f->stream);
   for (auto& e : f->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-  (void)hipFree(f->table); (void)hipFree(f->heap); (void)hipFree(f->block_keys); (void)hipFree(f->voxels);
-  for (int q = 0; q < 2; q++) { (void)hipFree(f->depthf2[q]); (void)hipFree(f->color2[q]); (void)hipFree(f->compact2[q]); }
+  (void)hipFree(f->table); (void)hipFree(f->heap); (void)hipFree(f->block_keys); (void)hipFree(f->block_entry); (void)hipFree(f->voxels);
+  for (int q = 0; q < 2; q++) { (void)hipFree(f->depthf2[q]); (void)hipFree(f->color2[q]); (void)hipFree(f->compact2[q]); (void)hipFree(f->cmask2[q]); }
   (void)hipFree(f->counters);
   for (int q = 0; q < 2; q++) { if (f->ev_compact[q]) (void)hipEventDestroy(f->ev_compact[q]); if (f->ev_fused[q]) (void)hipEventDestroy(f->ev_fused[q]); }
   if (f->front) { (void)hipStreamSynchronize(f->front); (void)hipStreamDestroy(f->front); }
@@ -789,11 +879,31 @@ SF_API int sf_fuser_deintegrate_device(sf_fuser* f, const void* d_depth, const v
 SF_API int sf_fuser_integrate_batch_device(sf_fuser* f, const void* d_depth, uint64_t frame_stride_bytes, const float* poses, uint64_t n) {
   if (!f || !d_depth || !poses) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
   SF_HIP_CHECK(hipSetDevice(f->device));
-  for (uint64_t i = 0; i < n; i++) {
-    const int rc = run_frame(f, (const uint8_t*)d_depth + i * frame_stride_bytes, nullptr, poses + 16 * i, +1);
-    if (rc != SF_OK && rc != SF_ERR_SKIPPED) return rc;
+  const void* dd[MAX_BATCH];
+  const float* pp[MAX_BATCH];
+  int m = 0;
+  for (uint64_t i = 0; i <= n; i++) {
+    if (i < n) {
+      if (poses[16 * i] == -INFINITY) { f->frames_skipped++; continue; }  // tracking lost: skip (sensorData.h:382)
+      dd[m] = (const uint8_t*)d_depth + i * frame_stride_bytes;
+      pp[m] = poses + 16 * i;
+      m++;
+    }
+    if (m == f->batch || (i == n && m > 0)) {
+      const int rc = run_batch(f, dd, nullptr, pp, m, +1);
+      if (rc != SF_OK) return rc;
+      m = 0;
+    }
   }
   return SF_OK;
+}
+
+SF_API int sf_fuser_batch_frames(const sf_fuser* f) { return f ? f->batch : 0; }
+
+// Internal (pipeline.hip): fuse n <= MAX_BATCH device-resident frames with valid poses in one pass.
+int sf_fuser_run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb, const float* const* poses, int n) {
+  if (n < 1 || n > f->batch) return sf::fail(SF_ERR_INVALID_ARG, "batch of %d frames (limit %d)", n, f->batch);
+  return run_batch(f, d_depth, d_rgb, poses, n, +1);
 }
 
 SF_API int sf_fuser_sync(sf_fuser* f) {
@@ -853,11 +963,12 @@ SF_API int sf_fuser_profile_read(sf_fuser* f, double* integrate_ms, uint64_t* la
 
 int sf_compact_live(sf_fuser* f, int32_t* n_out) {
   SF_HIP_CHECK(sf_quiesce(f));
-  FrameK dummy;
+  BatchFrames dummy;
   std::memset(&dummy, 0, sizeof(dummy));
-  SF_HIP_CHECK(hipMemsetAsync(&f->counters[C_EXPORT], 0, 4, f->stream));
-  hipLaunchKernelGGL(k_compactify, dim3(f->compact_grid), dim3(256), 0, f->stream, f->block_keys, f->compact, f->counters, (int)C_EXPORT, 1,
-                     f->pk, dummy);
+  dummy.n = 1;
+  SF_HIP_CHECK(hipMemsetAsync(&f->counters[C_EXPORT], 0, 8, f->stream));
+  hipLaunchKernelGGL(k_compactify, dim3(f->compact_grid), dim3(256), 0, f->stream, f->block_keys, f->block_entry, f->table, f->compact, f->cmask2[0],
+                     f->counters, (int)C_EXPORT, 1, f->pk, dummy);
   SF_HIP_CHECK(hipMemcpyAsync(n_out, &f->counters[C_EXPORT], 4, hipMemcpyDeviceToHost, f->stream));
   SF_HIP_CHECK(sf_quiesce(f));
   return SF_OK;

@@ -11,11 +11,12 @@ constexpr uint64_t KEY_EMPTY = ~0ull;
 constexpr uint64_t KEY_TOMB = ~0ull - 1ull;
 constexpr int MAX_DDA_ITERS = 1024;
 constexpr int MAX_PROBES = 4096;
+constexpr int MAX_BATCH = 16;  // frames fused per pass over the voxel tiles (temporal blocking)
 
 struct HashEntry {
   uint64_t key;
   int32_t ptr;
-  uint32_t pad;
+  uint32_t birth;  // sequence number of the first frame that asked for this block (0xFFFFFFFF until then)
 };
 static_assert(sizeof(HashEntry) == 16, "hash entry is 16 bytes");
 
@@ -36,18 +37,34 @@ struct FrameK {
   float radius, zfar;
 };
 
+// Per-batch kernel arguments (passed by value: kernarg segment, read with scalar loads).
+struct BatchIn {  // k_prepass
+  const uint16_t* depth[MAX_BATCH];
+  const uint8_t* rgb[MAX_BATCH];
+};
+struct BatchFrames {  // k_alloc, k_compactify
+  int n;
+  uint32_t seq0;  // sequence number of frame 0 of the batch; frame j has seq0 + j
+  FrameK f[MAX_BATCH];
+};
+struct BatchTi {  // k_integrate: world -> camera rows 0..2 of every frame of the batch
+  float Ti[MAX_BATCH][12];
+};
+
 enum Counter {
   C_HEAP_FREE = 0,
-  C_COMPACT = 1,
   C_HIGH_WATER = 2,
   C_ALLOC_FAIL = 3,
   C_SLOTS_USED = 4,
   C_LAST_BLOCKS = 5,
-  C_EXPORT = 6,
   C_GC_FREED = 7,
-  C_TOTAL_LO = 8,  // 64-bit sum of N_blk lives in counters[8..9]
-  C_COMPACT_B = 10,  // second frame slot (frames alternate between two sets of per-frame buffers)
-  C_COUNT = 16
+  // 64-bit compaction counters (8-byte aligned, own cache line): low word = entries in the compact list,
+  // high word = blocks the LAST frame of the batch updates
+  C_COMPACT = 16,
+  C_COMPACT_B = 18,  // second batch slot (batches alternate between two sets of per-batch buffers)
+  C_EXPORT = 20,
+  C_TOTAL_LO = 32,   // 64-bit sum of N_blk over all frames lives in counters[32..33] (own cache line)
+  C_COUNT = 48
 };
 
 __host__ __device__ inline uint64_t pack_key(int x, int y, int z) {
@@ -89,9 +106,13 @@ struct sf_fuser {
   hipEvent_t ev_fused[2] = {nullptr, nullptr};     // stream: frame slot consumed
   int slot = 0;
   bool overlap = true;  // SF_NO_OVERLAP=1 runs everything on one stream
-  float* depthf2[2] = {nullptr, nullptr};
-  uint32_t* color2[2] = {nullptr, nullptr};
-  int32_t* compact2[2] = {nullptr, nullptr};
+  float* depthf2[2] = {nullptr, nullptr};      // MAX_BATCH x W*H per batch slot
+  uint32_t* color2[2] = {nullptr, nullptr};    // MAX_BATCH x W*H per batch slot
+  int32_t* compact2[2] = {nullptr, nullptr};   // heap slots of the blocks some frame of the batch sees
+  uint32_t* cmask2[2] = {nullptr, nullptr};    // per compact entry: bit j = frame j of the batch updates this block
+  int32_t* block_entry = nullptr;              // directory: table index of the entry of the block in heap slot i
+  uint32_t frame_seq = 1;                      // sequence number of the next frame
+  int batch = MAX_BATCH;                       // frames per pass (SF_BATCH overrides, 1..MAX_BATCH)
   HashEntry* table = nullptr;
   int32_t* heap = nullptr;
   uint64_t* block_keys = nullptr;

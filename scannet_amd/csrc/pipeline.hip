@@ -19,6 +19,8 @@
 #include "fuser_internal.h"
 #include "sens.h"
 
+int sf_fuser_run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb, const float* const* poses, int n);  // fuser.hip
+
 namespace {
 
 struct Slot {
@@ -53,7 +55,8 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   if (nthreads < 1) nthreads = 1;
   if (nthreads > 64) nthreads = 64;
   const uint64_t total = last - first;
-  const int R = (int)std::min<uint64_t>(std::max<uint64_t>(4 * (uint64_t)nthreads, 16), std::max<uint64_t>(total, 1));
+  const int B = f->batch;  // frames fused per pass over the voxel tiles
+  const int R = (int)std::min<uint64_t>(std::max<uint64_t>(std::max<uint64_t>(4 * (uint64_t)nthreads, 16), 3 * (uint64_t)B), std::max<uint64_t>(total, 1));
   std::vector<Slot> ring((size_t)R);
   hipStream_t copy_stream = nullptr;
   auto cleanup = [&]() {
@@ -128,6 +131,32 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   std::string err;
   uint64_t n_int = 0, n_skip = 0;
   hipStream_t in_stream = f->overlap ? f->front : f->stream;
+  // frames whose copies are queued but whose kernels are not: fused B at a time (one pass over the tiles per batch)
+  int pend_slot[MAX_BATCH];
+  const float* pend_pose[MAX_BATCH];
+  int pend = 0;
+  bool pend_rgb = false;
+  auto flush = [&]() -> int {
+    if (pend == 0) return SF_OK;
+    const void* dd[MAX_BATCH];
+    const void* dr[MAX_BATCH];
+    for (int q = 0; q < pend; q++) {
+      Slot& ps = ring[(size_t)pend_slot[q]];
+      dd[q] = ps.d_depth;
+      dr[q] = pend_rgb ? ps.d_rgb : nullptr;
+      if (hipStreamWaitEvent(in_stream, ps.copied, 0) != hipSuccess) return sf::fail(SF_ERR_DEVICE, "hipStreamWaitEvent failed");
+    }
+    const int rc = sf_fuser_run_batch(f, dd, pend_rgb ? dr : nullptr, pend_pose, pend);
+    if (rc != SF_OK) return rc;
+    for (int q = 0; q < pend; q++) {
+      Slot& ps = ring[(size_t)pend_slot[q]];
+      (void)hipEventRecord(ps.consumed, in_stream);  // device buffers of the batch are free once its pre-pass has run
+      ps.used = true;
+    }
+    n_int += (uint64_t)pend;
+    pend = 0;
+    return SF_OK;
+  };
   for (uint64_t k = 0; k < total && result == SF_OK; k++) {
     const int si = (int)(k % (uint64_t)R);
     Slot& sl = ring[(size_t)si];
@@ -142,23 +171,29 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
     else if (pose[0] == -INFINITY) { n_skip++; f->frames_skipped++; }
     else {
       const bool rgb = use_rgb && s->frames[frame].color_bytes;
-      hipError_t e = hipSuccess;
-      if (sl.used) e = hipStreamWaitEvent(copy_stream, sl.consumed, 0);  // device buffer still read by an earlier pre-pass?
-      if (e == hipSuccess) e = hipMemcpyAsync(sl.d_depth, sl.h_depth, npx * 2, hipMemcpyHostToDevice, copy_stream);
-      if (e == hipSuccess && rgb) e = hipMemcpyAsync(sl.d_rgb, sl.h_rgb, npx * 3, hipMemcpyHostToDevice, copy_stream);
-      if (e == hipSuccess) e = hipEventRecord(sl.copied, copy_stream);
-      if (e == hipSuccess) e = hipStreamWaitEvent(in_stream, sl.copied, 0);
-      if (e != hipSuccess) { result = SF_ERR_DEVICE; err = std::string("copy pipeline: ") + hipGetErrorString(e); }
-      else {
-        const int rc = sf_fuser_integrate_device(f, sl.d_depth, rgb ? sl.d_rgb : nullptr, pose);
+      if (pend > 0 && rgb != pend_rgb) {  // a batch is all-colour or all-geometry
+        const int rc = flush();
         if (rc != SF_OK) { result = rc; err = sf_last_error(); }
-        else {
-          (void)hipEventRecord(sl.consumed, in_stream);
-          sl.used = true;
-          n_int++;
-          // the pinned host buffer goes back to the decoders once its copy has landed
-          (void)hipEventSynchronize(sl.copied);
+      }
+      hipError_t e = hipSuccess;
+      if (result == SF_OK) {
+        if (sl.used) e = hipStreamWaitEvent(copy_stream, sl.consumed, 0);  // device buffer still read by an earlier pre-pass?
+        if (e == hipSuccess) e = hipMemcpyAsync(sl.d_depth, sl.h_depth, npx * 2, hipMemcpyHostToDevice, copy_stream);
+        if (e == hipSuccess && rgb) e = hipMemcpyAsync(sl.d_rgb, sl.h_rgb, npx * 3, hipMemcpyHostToDevice, copy_stream);
+        if (e == hipSuccess) e = hipEventRecord(sl.copied, copy_stream);
+        if (e != hipSuccess) { result = SF_ERR_DEVICE; err = std::string("copy pipeline: ") + hipGetErrorString(e); }
+      }
+      if (result == SF_OK) {
+        pend_slot[pend] = si;
+        pend_pose[pend] = pose;
+        pend_rgb = rgb;
+        pend++;
+        if (pend == B) {
+          const int rc = flush();
+          if (rc != SF_OK) { result = rc; err = sf_last_error(); }
         }
+        // the pinned host buffer goes back to the decoders once its copy has landed
+        if (result == SF_OK) (void)hipEventSynchronize(sl.copied);
       }
     }
     {
@@ -166,6 +201,10 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
       issued = k + 1;
     }
     cv_free.notify_all();
+  }
+  if (result == SF_OK) {
+    const int rc = flush();
+    if (rc != SF_OK) { result = rc; err = sf_last_error(); }
   }
   if (result != SF_OK) {
     abort.store(true);

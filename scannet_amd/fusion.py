@@ -114,6 +114,11 @@ class Fuser:
         poses = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 16)
         check(_abi.lib().sf_fuser_integrate_batch_device(self._h, _ptr(d_depth), int(frame_stride_bytes), _ptr(poses), len(poses)))
 
+    @property
+    def batch_frames(self):
+        """Frames fused per pass over the voxel tiles by integrate_batch_device / run (SF_BATCH, default 16)."""
+        return int(_abi.lib().sf_fuser_batch_frames(self._h))
+
     def garbage_collect(self):
         n = C.c_uint32(0)
         check(_abi.lib().sf_fuser_garbage_collect(self._h, C.byref(n)))

@@ -70,6 +70,44 @@ def test_room_stream_bit_exact(oracle):
         _assert_same(ovol, f)
 
 
+def test_batched_pass_equals_frame_by_frame(oracle):
+    """Temporal blocking: sf_fuser_integrate_batch_device fuses up to 16 frames per pass over the tiles.  The result must
+    be the frame-by-frame result bit for bit: blocks born in the middle of a batch (large pose jumps) only receive the
+    frames from their birth on, skipped poses leave gaps, the final batch is partial."""
+    from scannet_amd import fusion
+    W, H = 320, 240
+    op, gp = _mk(oracle, W, H, voxel=0.008, num_sdf_blocks=1 << 17)
+    ovol = oracle.Volume(op, threads=8)
+    idx = [0, 1, 2, 300, 301, 3, 600, 601, 900, 4, 5, 1100, 302, 303, 6, 7, 8, 602, 9, 901, 902, 10, 11]  # 23 frames: 16 + 7
+    depth = np.zeros((len(idx), H, W), np.uint16)
+    poses = np.zeros((len(idx), 16), np.float32)
+    last = None
+    for k, i in enumerate(idx):
+        pose = synth.trajectory_pose(i, 1200)
+        depth[k] = synth.render_room_depth(pose, W, H, noise_frame=i)
+        if k in (5, 17):
+            pose = np.full((4, 4), -np.inf, np.float32)  # tracking lost
+        else:
+            last = ovol.integrate(depth[k], pose)
+        poses[k] = pose.reshape(16)
+    import ctypes as C
+    from scannet_amd import _abi
+    L = _abi.lib()
+    dptr = C.c_void_p()
+    _abi.check(L.sf_device_malloc(0, depth.nbytes, C.byref(dptr)))
+    try:
+        _abi.check(L.sf_device_upload(dptr, depth.ctypes.data_as(C.c_void_p), depth.nbytes))
+        with fusion.Fuser(gp) as f:
+            assert f.batch_frames == 16
+            f.integrate_batch_device(dptr.value, W * H * 2, poses)
+            st = f.stats()
+            assert st["frames_integrated"] == 21 and st["frames_skipped"] == 2
+            assert st["last_frame_blocks"] == last
+            _assert_same(ovol, f)
+    finally:
+        L.sf_device_free(dptr)
+
+
 def test_colour_deintegrate_gc_ragged(oracle):
     """Ragged image size (not a multiple of 8 or 16), colour fusion, deintegration and garbage collection."""
     from scannet_amd import fusion
