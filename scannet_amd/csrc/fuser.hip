@@ -16,6 +16,7 @@
 //   compact    i32[num_sdf_blocks] + u32 mask         heap slots of the blocks some frame of the batch sees; bit j = frame j updates it
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -95,20 +96,26 @@ __global__ __launch_bounds__(256) void k_prepass(BatchIn in, float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K2: allocation.  One lane per depth pixel, one 256-thread workgroup per 16x16 pixel tile, blockIdx.z = frame of
-// the batch (ONE launch allocates for up to 16 frames: 16 x 1200 workgroups fill the chip, one frame's 1200 do not).
-//   phase 1 (no global memory): every lane walks its 3-D DDA over the blocks of [d - t, d + t] and drops
-//            the block keys into a workgroup-wide LDS hash set (ds_cmpst CAS) -- neighbouring rays and
-//            consecutive steps hit the same blocks, the set keeps ~50-150 unique keys per tile;
-//   phase 2: the unique keys are frustum-tested and probed in the global hash table by all lanes in
-//            parallel (one memory round trip instead of one per DDA step); an EMPTY slot is claimed with
-//            a lock-free 64-bit CAS, and the freshly claimed slots of a wave receive their heap blocks
-//            through ONE wave-aggregated pop (ballot + prefix popcount).
-// The allocated SET is deterministic (no insertion ever gives up, so no fix-point iteration as upstream);
-// which heap slot a block lands in is not (neither is it upstream).
+// K2: allocation.  One lane per depth pixel, one 256-thread workgroup per 16x16 pixel tile and per GROUP of
+// consecutive frames of the batch (blockIdx.z): the same pixel tile of neighbouring frames looks at almost the
+// same blocks, so the workgroup walks its frames in order and only the blocks a frame adds go any further.
+//   phase 1, per frame (no global memory traffic except the 1 KiB of depth):
+//            every lane walks its 3-D DDA over the blocks of [d - t, d + t] and sets ONE BIT per visited block in
+//            an LDS occupancy bitmap of a WIN^3-block window anchored at the tile's first ray (non-returning
+//            ds_or: no latency on the lane, duplicates across the 256 rays and across steps collapse for free);
+//            then the bitmap words are scanned: bits not yet queued by an earlier frame of the group are
+//            frustum-tested for THIS frame and queued as (key, frame).  Rays that leave the window (tiles
+//            straddling a depth discontinuity) go through a small LDS hash set instead.
+//   phase 2, once per workgroup: the queued keys are probed in the global hash table by all lanes in parallel
+//            (one memory round trip instead of one per DDA step); an EMPTY slot is claimed with a lock-free
+//            64-bit CAS, the entry's birth frame becomes the minimum over everybody who asked for the block, and
+//            the freshly claimed slots of a wave receive their heap blocks through ONE wave-aggregated pop
+//            (ballot + prefix popcount).
+// The allocated SET and every block's birth frame are deterministic (no insertion ever gives up, so no fix-point
+// iteration as upstream); which heap slot a block lands in is not (neither is it upstream).
 // ---------------------------------------------------------------------------------------------------
-constexpr int ALLOC_SET = 2048;       // LDS hash-set slots per workgroup (16 KiB)
-constexpr int ALLOC_LIST = 1024;      // dense list of the set's keys (8 KiB)
+constexpr int ALLOC_SET = 1024;       // LDS hash-set slots per workgroup (8 KiB): blocks outside the window
+constexpr int ALLOC_LIST = 1024;      // queue of (key, frame) for phase 2 (8 KiB + 1 KiB)
 constexpr int ALLOC_SET_PROBES = 32;
 
 struct HashRefs {
@@ -159,157 +166,177 @@ __device__ inline void give_block(const HashRefs& h, HashEntry* e, uint64_t key,
   }
 }
 
-template <int WIN_LOG2>
+template <int WIN_LOG2, bool MULTI>
 __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_all, HashEntry* table, int32_t* heap,
-                                               uint64_t* block_keys, int32_t* block_entry, int32_t* counters, ParamsK P, BatchFrames B, int dbg) {
-  const FrameK& F = B.f[blockIdx.z];  // blockIdx.z = frame of the batch (uniform: scalar loads from the kernarg segment)
-  const uint32_t seq = B.seq0 + blockIdx.z;
-  const float* __restrict__ depthf = depthf_all + (size_t)blockIdx.z * ((size_t)P.W * P.H);
+                                               uint64_t* block_keys, int32_t* block_entry, int32_t* counters, ParamsK P, BatchFrames B,
+                                               int group_frames) {
   constexpr int WIN = 1 << WIN_LOG2;                // window edge in blocks
-  constexpr int WIN_WORDS = (WIN * WIN * WIN) / 32; // occupancy bitmap words
-  __shared__ uint32_t s_bits[WIN_WORDS];            // 4 KiB (WIN 32) / 32 KiB (WIN 64)
-  __shared__ unsigned long long s_keys[ALLOC_SET];  // overflow set for blocks outside the window
-  __shared__ unsigned long long s_list[ALLOC_LIST]; // unique keys, densely packed for phase 2
+  constexpr int WIN_WORDS = (WIN * WIN * WIN) / 32; // occupancy bitmap words: 4 KiB (WIN 32) / 32 KiB (WIN 64)
+  __shared__ uint32_t s_frame[WIN_WORDS];           // blocks the current frame's rays visit
+  __shared__ uint32_t s_done[MULTI ? WIN_WORDS : 1];// blocks an earlier frame of the group has already queued
+  __shared__ unsigned long long s_keys[ALLOC_SET];  // the same for blocks outside the window
+  __shared__ unsigned long long s_list[ALLOC_LIST]; // queue for phase 2
+  __shared__ uint8_t s_birth[ALLOC_LIST];           // ... and the frame (index in the batch) that queued the key
   __shared__ int s_count;
   __shared__ int s_chooser;
+  __shared__ int s_anchored;
   __shared__ int s_anchor[3];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) { s_count = 0; s_chooser = 256; }
+  if (threadIdx.x == 0) { s_count = 0; s_chooser = 256; s_anchored = 0; }
   const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
   const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
   const HashRefs h{table, heap, block_keys, block_entry, counters};
   for (int i = threadIdx.x; i < ALLOC_SET; i += 256) s_keys[i] = KEY_EMPTY;
-  for (int i = threadIdx.x; i < WIN_WORDS; i += 256) s_bits[i] = 0u;
-  __syncthreads();
+  if (MULTI)
+    for (int i = threadIdx.x; i < WIN_WORDS; i += 256) s_done[i] = 0u;
+  const size_t npx = (size_t)P.W * P.H;
+  const int j_begin = blockIdx.z * group_frames;
+  const int j_end = min(B.n, j_begin + group_frames);
 
-  // ---- phase 1: DDA into the LDS set
-  bool active = false;
-  int a_cx = 0, a_cy = 0, a_cz = 0, a_sx = 0, a_sy = 0, a_sz = 0, a_ex = 0, a_ey = 0, a_ez = 0;
-  float a_tmx = INFINITY, a_tmy = INFINITY, a_tmz = INFINITY, a_tdx = INFINITY, a_tdy = INFINITY, a_tdz = INFINITY;
-  if (x < P.W && y < P.H) {
-    const float d = depthf[y * P.W + x];
-    if (d != -INFINITY && d < P.maxd) {
-      const float t = fmaf(P.tscale, d, P.tbase);
-      const float lo = fminf(P.maxd, d - t);
-      const float hi = fminf(P.maxd, d + t);
-      if (lo < hi) {
-        const float kx = ((float)x - P.mx) / P.fx;
-        const float ky = ((float)y - P.my) / P.fy;
-        float p0[3], p1[3];
-        {
-          const float ax = kx * lo, ay = ky * lo, az = lo;
-#pragma unroll
-          for (int r = 0; r < 3; r++) p0[r] = fmaf(F.T[4 * r], ax, fmaf(F.T[4 * r + 1], ay, fmaf(F.T[4 * r + 2], az, F.T[4 * r + 3])));
-        }
-        {
-          const float ax = kx * hi, ay = ky * hi, az = hi;
-#pragma unroll
-          for (int r = 0; r < 3; r++) p1[r] = fmaf(F.T[4 * r], ax, fmaf(F.T[4 * r + 1], ay, fmaf(F.T[4 * r + 2], az, F.T[4 * r + 3])));
-        }
-        const float bsize = 8.0f * P.voxel;
-        int cur[3], stp[3], bnd[3];
-        float tm[3], td[3];
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-          const float dir = p1[c] - p0[c];
-          cur[c] = world_to_block(p0[c], P.voxel);
-          const int e = world_to_block(p1[c], P.voxel);
-          stp[c] = dir > 0.0f ? 1 : (dir < 0.0f ? -1 : 0);
-          bnd[c] = e + stp[c];
-          if (stp[c] == 0) { tm[c] = INFINITY; td[c] = INFINITY; }
-          else {
-            const int nb = cur[c] + (stp[c] > 0 ? 1 : 0);
-            const float plane = ((float)(8 * nb) - 0.5f) * P.voxel;
-            tm[c] = (plane - p0[c]) / dir;
-            td[c] = ((float)stp[c] * bsize) / dir;
-          }
-        }
-        a_cx = cur[0]; a_cy = cur[1]; a_cz = cur[2];
-        a_sx = stp[0]; a_sy = stp[1]; a_sz = stp[2]; a_ex = bnd[0]; a_ey = bnd[1]; a_ez = bnd[2];
-        a_tmx = tm[0]; a_tmy = tm[1]; a_tmz = tm[2]; a_tdx = td[0]; a_tdy = td[1]; a_tdz = td[2];
-        active = true;
-      }
+  // a block the workgroup cannot queue (queue full: pathological tile) goes straight to the global table
+  auto direct = [&](uint64_t key, int bx, int by, int bz, uint32_t seq) {
+    HashEntry* e = hash_find_or_claim(h, P, key, bx, by, bz, seq);
+    if (e) {
+      atomicAdd(&counters[C_SLOTS_USED], 1);
+      give_block(h, e, key, atomicSub(&counters[C_HEAP_FREE], 1) - 1);
     }
-  }
-  // The tile's rays stay inside a small region of block space: the first active lane anchors a WIN^3
-  // window there and every DDA step just sets one bit of an LDS occupancy bitmap with a non-returning
-  // ds_or (no latency on the lane, duplicates across lanes and steps collapse for free).  Blocks that
-  // fall outside the window (tiles straddling a depth discontinuity) go to a small LDS hash set.
-  if (active) atomicMin(&s_chooser, (int)threadIdx.x);
-  __syncthreads();
-  if ((int)threadIdx.x == s_chooser) {
-    s_anchor[0] = a_cx - (a_sx >= 0 ? WIN / 4 : 3 * WIN / 4);
-    s_anchor[1] = a_cy - (a_sy >= 0 ? WIN / 4 : 3 * WIN / 4);
-    s_anchor[2] = a_cz - (a_sz >= 0 ? WIN / 4 : 3 * WIN / 4);
-  }
-  __syncthreads();
-  const int anx = s_anchor[0], any_ = s_anchor[1], anz = s_anchor[2];
-  if (active && (dbg & 2) == 0) {
-    uint64_t last_key = KEY_EMPTY;
-    for (int it = 0; it < MAX_DDA_ITERS; ++it) {
-      const uint32_t ux = (uint32_t)(a_cx - anx), uy = (uint32_t)(a_cy - any_), uz = (uint32_t)(a_cz - anz);
-      if ((ux | uy | uz) < (uint32_t)WIN) {
-        const uint32_t bit = (uz << (2 * WIN_LOG2)) | (uy << WIN_LOG2) | ux;
-        atomicOr(&s_bits[bit >> 5], 1u << (bit & 31));
-      } else {
-        const uint64_t key = pack_key(a_cx, a_cy, a_cz);
-        if (key != last_key) {
-          last_key = key;
-          uint32_t sl = ((uint32_t)(key ^ (key >> 21) ^ (key >> 42)) * 2654435761u) >> 21;  // 11 bits
-          bool placed = false;
-          for (int pr = 0; pr < ALLOC_SET_PROBES; ++pr) {
-            const unsigned long long old = atomicCAS(&s_keys[sl], (unsigned long long)KEY_EMPTY, (unsigned long long)key);
-            if (old == key) { placed = true; break; }
-            if (old == KEY_EMPTY) {
-              const int pos = atomicAdd(&s_count, 1);
-              if (pos < ALLOC_LIST) { s_list[pos] = key; placed = true; }
-              break;  // list full: direct path below
-            }
-            sl = (sl + 1) & (ALLOC_SET - 1);
+  };
+
+  for (int j = j_begin; j < j_end; ++j) {
+    const FrameK& F = B.f[j];  // uniform index: scalar loads from the kernarg segment
+    const float* __restrict__ depthf = depthf_all + (size_t)j * npx;
+    for (int i = threadIdx.x; i < WIN_WORDS; i += 256) s_frame[i] = 0u;
+
+    // ---- ray set-up
+    bool active = false;
+    int a_cx = 0, a_cy = 0, a_cz = 0, a_sx = 0, a_sy = 0, a_sz = 0, a_ex = 0, a_ey = 0, a_ez = 0;
+    float a_tmx = INFINITY, a_tmy = INFINITY, a_tmz = INFINITY, a_tdx = INFINITY, a_tdy = INFINITY, a_tdz = INFINITY;
+    if (x < P.W && y < P.H) {
+      const float d = depthf[y * P.W + x];
+      if (d != -INFINITY && d < P.maxd) {
+        const float t = fmaf(P.tscale, d, P.tbase);
+        const float lo = fminf(P.maxd, d - t);
+        const float hi = fminf(P.maxd, d + t);
+        if (lo < hi) {
+          const float kx = ((float)x - P.mx) / P.fx;
+          const float ky = ((float)y - P.my) / P.fy;
+          float p0[3], p1[3];
+          {
+            const float ax = kx * lo, ay = ky * lo, az = lo;
+#pragma unroll
+            for (int r = 0; r < 3; r++) p0[r] = fmaf(F.T[4 * r], ax, fmaf(F.T[4 * r + 1], ay, fmaf(F.T[4 * r + 2], az, F.T[4 * r + 3])));
           }
-          if (!placed && block_in_frustum(P, F, a_cx, a_cy, a_cz)) {
-            // overflow of the overflow set (pathological tile): straight to the global table
-            HashEntry* e = hash_find_or_claim(h, P, key, a_cx, a_cy, a_cz, seq);
-            if (e) {
-              atomicAdd(&counters[C_SLOTS_USED], 1);
-              give_block(h, e, key, atomicSub(&counters[C_HEAP_FREE], 1) - 1);
+          {
+            const float ax = kx * hi, ay = ky * hi, az = hi;
+#pragma unroll
+            for (int r = 0; r < 3; r++) p1[r] = fmaf(F.T[4 * r], ax, fmaf(F.T[4 * r + 1], ay, fmaf(F.T[4 * r + 2], az, F.T[4 * r + 3])));
+          }
+          const float bsize = 8.0f * P.voxel;
+          int cur[3], stp[3], bnd[3];
+          float tm[3], td[3];
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            const float dir = p1[c] - p0[c];
+            cur[c] = world_to_block(p0[c], P.voxel);
+            const int e = world_to_block(p1[c], P.voxel);
+            stp[c] = dir > 0.0f ? 1 : (dir < 0.0f ? -1 : 0);
+            bnd[c] = e + stp[c];
+            if (stp[c] == 0) { tm[c] = INFINITY; td[c] = INFINITY; }
+            else {
+              const int nb = cur[c] + (stp[c] > 0 ? 1 : 0);
+              const float plane = ((float)(8 * nb) - 0.5f) * P.voxel;
+              tm[c] = (plane - p0[c]) / dir;
+              td[c] = ((float)stp[c] * bsize) / dir;
             }
           }
+          a_cx = cur[0]; a_cy = cur[1]; a_cz = cur[2];
+          a_sx = stp[0]; a_sy = stp[1]; a_sz = stp[2]; a_ex = bnd[0]; a_ey = bnd[1]; a_ez = bnd[2];
+          a_tmx = tm[0]; a_tmy = tm[1]; a_tmz = tm[2]; a_tdx = td[0]; a_tdy = td[1]; a_tdz = td[2];
+          active = true;
         }
       }
-      bool done;
-      if (a_tmx < a_tmy && a_tmx < a_tmz) { a_cx += a_sx; done = (a_cx == a_ex); a_tmx += a_tdx; }
-      else if (a_tmz < a_tmy) { a_cz += a_sz; done = (a_cz == a_ez); a_tmz += a_tdz; }
-      else { a_cy += a_sy; done = (a_cy == a_ey); a_tmy += a_tdy; }
-      if (done) break;
     }
-  }
-  __syncthreads();
-  // bitmap -> dense key list
-  for (int w = threadIdx.x; w < WIN_WORDS; w += 256) {
-    uint32_t bits = s_bits[w];
-    while (bits) {
-      const int b = __ffs((int)bits) - 1;
-      bits &= bits - 1u;
-      const uint32_t bit = ((uint32_t)w << 5) | (uint32_t)b;
-      const int bx = anx + (int)(bit & (WIN - 1)), by = any_ + (int)((bit >> WIN_LOG2) & (WIN - 1)), bz = anz + (int)(bit >> (2 * WIN_LOG2));
-      const int pos = atomicAdd(&s_count, 1);
-      if (pos < ALLOC_LIST) s_list[pos] = pack_key(bx, by, bz);
-      else if (block_in_frustum(P, F, bx, by, bz)) {
-        const uint64_t key = pack_key(bx, by, bz);
-        HashEntry* e = hash_find_or_claim(h, P, key, bx, by, bz, seq);
-        if (e) {
-          atomicAdd(&counters[C_SLOTS_USED], 1);
-          give_block(h, e, key, atomicSub(&counters[C_HEAP_FREE], 1) - 1);
-        }
+    __syncthreads();  // s_frame zeroed, previous frame's scan finished
+    // The tile's rays stay inside a small region of block space: the first active lane of the first frame that has
+    // one anchors the WIN^3 window there for the whole group.
+    if (s_anchored == 0) {
+      if (active) atomicMin(&s_chooser, (int)threadIdx.x);
+      __syncthreads();
+      if ((int)threadIdx.x == s_chooser) {
+        s_anchor[0] = a_cx - (a_sx >= 0 ? WIN / 4 : 3 * WIN / 4);
+        s_anchor[1] = a_cy - (a_sy >= 0 ? WIN / 4 : 3 * WIN / 4);
+        s_anchor[2] = a_cz - (a_sz >= 0 ? WIN / 4 : 3 * WIN / 4);
+        s_anchored = 1;
       }
+      __syncthreads();
+    }
+    const int anx = s_anchor[0], any_ = s_anchor[1], anz = s_anchor[2];
+
+    // ---- DDA: one LDS bit per visited block
+    if (active) {
+      uint64_t last_key = KEY_EMPTY;
+      for (int it = 0; it < MAX_DDA_ITERS; ++it) {
+        const uint32_t ux = (uint32_t)(a_cx - anx), uy = (uint32_t)(a_cy - any_), uz = (uint32_t)(a_cz - anz);
+        const bool inwin = (ux | uy | uz) < (uint32_t)WIN;
+        const uint32_t bit = inwin ? ((uz << (2 * WIN_LOG2)) | (uy << WIN_LOG2) | ux) : 0xFFFFFFFFu;
+        // The 8x8 pixel patch of a wave mostly sits in ONE block: 64 ds_or to the same LDS word serialise.  Drop
+        // the lane when its left neighbour (DPP row_shr:1, free) sets the same bit; a disabled or out-of-row
+        // neighbour reads as "different" (old value, bound_ctrl off), so run heads always write.
+        const uint32_t left = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFEu, (int)bit, 0x111, 0xF, 0xF, false);
+        if (inwin) {
+          if (left != bit) atomicOr(&s_frame[bit >> 5], 1u << (bit & 31));
+        } else {
+          const uint64_t key = pack_key(a_cx, a_cy, a_cz);
+          if (key != last_key) {
+            last_key = key;
+            if (block_in_frustum(P, F, a_cx, a_cy, a_cz)) {
+              uint32_t sl = ((uint32_t)(key ^ (key >> 21) ^ (key >> 42)) * 2654435761u) >> 22;  // 10 bits
+              bool placed = false;
+              for (int pr = 0; pr < ALLOC_SET_PROBES; ++pr) {
+                const unsigned long long old = atomicCAS(&s_keys[sl], (unsigned long long)KEY_EMPTY, (unsigned long long)key);
+                if (old == key) { placed = true; break; }  // queued by an earlier step / ray / frame
+                if (old == KEY_EMPTY) {
+                  const int pos = atomicAdd(&s_count, 1);
+                  if (pos < ALLOC_LIST) { s_list[pos] = key; s_birth[pos] = (uint8_t)j; placed = true; }
+                  break;  // queue full: direct path below
+                }
+                sl = (sl + 1) & (ALLOC_SET - 1);
+              }
+              if (!placed) direct(key, a_cx, a_cy, a_cz, B.seq0 + (uint32_t)j);
+            }
+          }
+        }
+        bool done;
+        if (a_tmx < a_tmy && a_tmx < a_tmz) { a_cx += a_sx; done = (a_cx == a_ex); a_tmx += a_tdx; }
+        else if (a_tmz < a_tmy) { a_cz += a_sz; done = (a_cz == a_ez); a_tmz += a_tdz; }
+        else { a_cy += a_sy; done = (a_cy == a_ey); a_tmy += a_tdy; }
+        if (done) break;
+      }
+    }
+    __syncthreads();
+    // ---- scan: blocks this frame visits that no earlier frame of the group queued -> frustum test -> queue
+    for (int w = threadIdx.x; w < WIN_WORDS; w += 256) {
+      uint32_t bits = MULTI ? (s_frame[w] & ~s_done[w]) : s_frame[w];
+      uint32_t queued = 0u;
+      while (bits) {
+        const int b = __ffs((int)bits) - 1;
+        bits &= bits - 1u;
+        const uint32_t bit = ((uint32_t)w << 5) | (uint32_t)b;
+        const int bx = anx + (int)(bit & (WIN - 1)), by = any_ + (int)((bit >> WIN_LOG2) & (WIN - 1)), bz = anz + (int)(bit >> (2 * WIN_LOG2));
+        if (!block_in_frustum(P, F, bx, by, bz)) continue;  // a later frame may still want it
+        queued |= 1u << b;
+        const int pos = atomicAdd(&s_count, 1);
+        if (pos < ALLOC_LIST) { s_list[pos] = pack_key(bx, by, bz); s_birth[pos] = (uint8_t)j; }
+        else direct(pack_key(bx, by, bz), bx, by, bz, B.seq0 + (uint32_t)j);
+      }
+      if (MULTI && queued) s_done[w] |= queued;  // word w is only ever touched by this thread
     }
   }
   __syncthreads();
 
-  // ---- phase 2: unique keys -> frustum test -> global hash, all lanes in parallel
-  const int n_unique = (dbg & 1) ? 0 : min(s_count, ALLOC_LIST);
+  // ---- phase 2: queued keys -> global hash, all lanes in parallel
+  const int n_unique = min(s_count, ALLOC_LIST);
   for (int i0 = 0; i0 < n_unique; i0 += 256) {
     const int i = i0 + threadIdx.x;
     const uint64_t key = i < n_unique ? s_list[i] : KEY_EMPTY;
@@ -317,7 +344,7 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_
     if (key != KEY_EMPTY) {
       int bx, by, bz;
       unpack_key(key, bx, by, bz);
-      if (block_in_frustum(P, F, bx, by, bz)) claimed = hash_find_or_claim(h, P, key, bx, by, bz, seq);
+      claimed = hash_find_or_claim(h, P, key, bx, by, bz, B.seq0 + (uint32_t)s_birth[i]);
     }
     // wave-aggregated heap pop for the freshly claimed slots
     const uint64_t cm = __ballot(claimed != nullptr);
@@ -425,51 +452,141 @@ __global__ __launch_bounds__(256) void k_compactify(const uint64_t* __restrict__
 // staged through LDS; the depth image (1.2 MB f32) is gathered through L1/L2.
 // lane l, load j: uint4 q = 64 j + l -> voxels 2q, 2q+1 -> x = (2l)&7 (+1), y = (l>>2)&7, z = 2j + (l>>5).
 // ---------------------------------------------------------------------------------------------------
+// One frame into one tile held in registers (8 voxels per lane).  The kernel is VALU-issue bound once a batch
+// amortises the HBM traffic (SQ_ACTIVE_INST_VALU ~ 100 %, profiles/), so the update is written for instruction count:
+//   * two straight-line phases: phase A projects all eight voxels and issues the eight depth gathers together at
+//     clamped addresses, phase B applies the update under a select (a per-voxel early-out chain serialises eight
+//     L2 round trips and costs a scalar branch pair per test);
+//   * the two x-adjacent voxels of a lane go through packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32:
+//     two IEEE operations per issue slot);
+//   * the two IEEE divisions of DESIGN.md 3.5 are expanded by hand.  1/pcz: v_rcp_f32 seed + two Newton steps --
+//     the arithmetic core of the compiler's own correctly rounded expansion without the div_scale / div_fixup
+//     range handling (pcz is a camera-space depth in metres; exhaustive check over all mantissas and seed errors up
+//     to 2 ulp: tools/check_division.c).  (old*w + sdf*wn) / (w + wn): the divisor is a small integer, its
+//     correctly rounded reciprocal comes from an LDS table and ONE Markstein correction q1 = fma(fma(-m, q0, n), r, q0)
+//     yields the correctly rounded quotient (same tool: 1.4e9 cases incl. near-halfway); numerators below 2^-100
+//     take the plain division so that underflow cannot bite.
+// Every value stored is bit-identical to oracle/tsdf_oracle.c fuse_block.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ inline v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ inline v2f splat(float x) { return (v2f){x, x}; }
+__device__ inline v2f recip_rn(v2f b) {
+  v2f r = {__builtin_amdgcn_rcpf(b.x), __builtin_amdgcn_rcpf(b.y)};
+  const v2f one = splat(1.0f);
+  r = pk_fma(pk_fma(-b, r, one), r, r);
+  return pk_fma(pk_fma(-b, r, one), r, r);
+}
+
+constexpr int RTAB = 512;  // LDS table of correctly rounded 1/m, m = weight + weight_sample < 512
+
 template <int SIGN, bool COLOR>
-__device__ inline bool fuse_voxel(const ParamsK& P, const float* __restrict__ depthf, const uint32_t* __restrict__ color,
-                                  float pcx, float pcy, float pcz, uint32_t& sdf_bits, uint32_t& cw) {
-  if (!(pcz > 0.0f)) return false;
-  const float rz = 1.0f / pcz;
-  const float uf = fmaf(pcx * P.fx, rz, P.mx) + 0.5f;
-  const float vf = fmaf(pcy * P.fy, rz, P.my) + 0.5f;
-  if (!(uf >= 0.0f && uf < (float)P.W && vf >= 0.0f && vf < (float)P.H)) return false;
-  const int pix = (int)vf * P.W + (int)uf;
-  const float d = depthf[pix];
-  if (d == -INFINITY) return false;
-  if (!(d < P.maxd)) return false;
-  float sdf = d - pcz;
-  const float t = fmaf(P.tscale, d, P.tbase);
-  if (sdf <= -t) return false;
-  if (sdf > t) sdf = t;
-  const uint32_t w = cw >> 24;
-  const float wo = (float)w;
-  const float wn = (float)P.wsample;
-  const float old = __uint_as_float(sdf_bits);
-  if (SIGN > 0) {
-    sdf_bits = __float_as_uint(fmaf(old, wo, sdf * wn) / (wo + wn));
-    uint32_t rgb = cw & 0xFFFFFFu;
-    if (COLOR) {
-      const uint32_t c = color[pix];
-      if (w == 0) rgb = c;
-      else {
-        const uint32_t r = ((rgb & 0xFF) + (c & 0xFF) + 1) >> 1;
-        const uint32_t g = (((rgb >> 8) & 0xFF) + ((c >> 8) & 0xFF) + 1) >> 1;
-        const uint32_t b = (((rgb >> 16) & 0xFF) + ((c >> 16) & 0xFF) + 1) >> 1;
-        rgb = r | (g << 8) | (b << 16);
-      }
-    }
-    uint32_t nw = w + (uint32_t)P.wsample;
-    if (nw > (uint32_t)P.wmax) nw = (uint32_t)P.wmax;
-    cw = rgb | (nw << 24);
-  } else {
-    const int nw = (int)w - P.wsample;
-    if (nw <= 0) { sdf_bits = 0u; cw = 0u; }
-    else {
-      sdf_bits = __float_as_uint(fmaf(old, wo, -(sdf * wn)) / (wo - wn));
-      cw = (cw & 0xFFFFFFu) | ((uint32_t)nw << 24);
+__device__ inline void fuse_tile(const ParamsK& P, const float* __restrict__ Ti, const float* __restrict__ depthf,
+                                 const uint32_t* __restrict__ color, const float* rtab, bool use_tab, v2f wx, float wy,
+                                 const float (&wz)[4], uint4 (&v)[4], bool (&dirty)[4]) {
+  v2f pz[4];
+  float d[8];
+  uint32_t c[8];
+  bool ok[8];
+  int pix[8];
+  const uint32_t wbits = __float_as_uint((float)P.W), hbits = __float_as_uint((float)P.H);
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const float ax = fmaf(Ti[1], wy, fmaf(Ti[2], wz[j], Ti[3]));
+    const float ay = fmaf(Ti[5], wy, fmaf(Ti[6], wz[j], Ti[7]));
+    const float az = fmaf(Ti[9], wy, fmaf(Ti[10], wz[j], Ti[11]));
+    const v2f pcx = pk_fma(splat(Ti[0]), wx, splat(ax));
+    const v2f pcy = pk_fma(splat(Ti[4]), wx, splat(ay));
+    const v2f pcz = pk_fma(splat(Ti[8]), wx, splat(az));
+    const v2f rz = recip_rn(pcz);
+    const v2f uf = pk_fma(pcx * splat(P.fx), rz, splat(P.mx)) + splat(0.5f);
+    const v2f vf = pk_fma(pcy * splat(P.fy), rz, splat(P.my)) + splat(0.5f);
+    pz[j] = pcz;
+#pragma unroll
+    for (int hx = 0; hx < 2; hx++) {
+      // 0 <= u < W as ONE unsigned compare of the float bits (negative, NaN and inf all compare high; u is never -0)
+      const bool in = (pcz[hx] > 0.0f) && (__float_as_uint(uf[hx]) < wbits) && (__float_as_uint(vf[hx]) < hbits);
+      ok[2 * j + hx] = in;
+      pix[2 * j + hx] = in ? (int)vf[hx] * P.W + (int)uf[hx] : 0;
     }
   }
-  return true;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    d[k] = depthf[pix[k]];
+    if (COLOR) c[k] = color[pix[k]];
+  }
+  const float wn = (float)P.wsample;
+  const uint32_t maxd_bits = __float_as_uint(P.maxd);
+  bool slow = false;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const v2f dk = {d[2 * j], d[2 * j + 1]};
+    v2f sdf = dk - pz[j];
+    const v2f t = pk_fma(splat(P.tscale), dk, splat(P.tbase));
+    const uint32_t cw0 = v[j].y, cw1 = v[j].w;
+    const uint32_t w0 = cw0 >> 24, w1 = cw1 >> 24;
+    const v2f wo = {(float)w0, (float)w1};
+    const v2f old = {__uint_as_float(v[j].x), __uint_as_float(v[j].z)};
+    bool upd[2];
+#pragma unroll
+    for (int hx = 0; hx < 2; hx++) {
+      // valid depth (-inf has the sign bit set, valid depths are positive) below the integration distance, not behind the band
+      upd[hx] = ok[2 * j + hx] && (__float_as_uint(dk[hx]) < maxd_bits) && (sdf[hx] > -t[hx]);
+      sdf[hx] = fminf(sdf[hx], t[hx]);
+    }
+    v2f q;
+    uint32_t ncw[2];
+    if (SIGN > 0) {
+      const v2f n = pk_fma(old, wo, sdf * splat(wn));
+      const v2f m = wo + splat(wn);
+      if (use_tab) {
+        const v2f r = {rtab[w0 + (uint32_t)P.wsample], rtab[w1 + (uint32_t)P.wsample]};
+        const v2f q0 = n * r;
+        q = pk_fma(pk_fma(-m, q0, n), r, q0);
+        slow = slow || (fabsf(n.x) < 0x1p-100f) || (fabsf(n.y) < 0x1p-100f);
+      } else {
+        q = (v2f){n.x / m.x, n.y / m.y};
+      }
+#pragma unroll
+      for (int hx = 0; hx < 2; hx++) {
+        const uint32_t cw = hx ? cw1 : cw0;
+        const uint32_t w = hx ? w1 : w0;
+        uint32_t rgb = cw & 0xFFFFFFu;
+        if (COLOR) {
+          const uint32_t ck = c[2 * j + hx];
+          const uint32_t r8 = ((rgb & 0xFF) + (ck & 0xFF) + 1) >> 1;
+          const uint32_t g8 = (((rgb >> 8) & 0xFF) + ((ck >> 8) & 0xFF) + 1) >> 1;
+          const uint32_t b8 = (((rgb >> 16) & 0xFF) + ((ck >> 16) & 0xFF) + 1) >> 1;
+          rgb = w == 0 ? ck : (r8 | (g8 << 8) | (b8 << 16));
+        }
+        uint32_t nw = w + (uint32_t)P.wsample;
+        if (nw > (uint32_t)P.wmax) nw = (uint32_t)P.wmax;
+        ncw[hx] = rgb | (nw << 24);
+      }
+    } else {
+      const v2f n = pk_fma(old, wo, -(sdf * splat(wn)));
+      const v2f m = wo - splat(wn);
+      q = (v2f){n.x / m.x, n.y / m.y};  // discarded when the weight drops to <= 0 (then m <= 0)
+#pragma unroll
+      for (int hx = 0; hx < 2; hx++) {
+        const uint32_t cw = hx ? cw1 : cw0;
+        const int nw = (int)(hx ? w1 : w0) - P.wsample;
+        if (nw <= 0) { q[hx] = __uint_as_float(0u); ncw[hx] = 0u; }
+        else ncw[hx] = (cw & 0xFFFFFFu) | ((uint32_t)nw << 24);
+      }
+    }
+    if (SIGN > 0 && use_tab && __builtin_expect(__any((int)slow), 0)) {
+      // some lane of the wave has a numerator in the underflow range: plain IEEE division for this row pair
+      const v2f n = pk_fma(old, wo, sdf * splat(wn));
+      const v2f m = wo + splat(wn);
+      q = (v2f){n.x / m.x, n.y / m.y};
+      slow = false;
+    }
+    v[j].x = upd[0] ? __float_as_uint(q.x) : v[j].x;
+    v[j].y = upd[0] ? ncw[0] : cw0;
+    v[j].z = upd[1] ? __float_as_uint(q.y) : v[j].z;
+    v[j].w = upd[1] ? ncw[1] : cw1;
+    dirty[j] = dirty[j] || upd[0] || upd[1];
+  }
 }
 
 template <int SIGN, bool COLOR>
@@ -477,6 +594,10 @@ __global__ __launch_bounds__(256) void k_integrate(uint4* __restrict__ voxels, c
                                                    const int32_t* __restrict__ compact, const uint32_t* __restrict__ cmask,
                                                    const float* __restrict__ depthf_all, const uint32_t* __restrict__ color_all,
                                                    int32_t* counters, int32_t* host_mirror, int compact_counter, ParamsK P, BatchTi B) {
+  __shared__ float s_rtab[RTAB];  // correctly rounded 1/m for the weighted-mean division (fuse_tile)
+  for (int i = threadIdx.x; i < RTAB; i += 256) s_rtab[i] = 1.0f / (float)(i > 0 ? i : 1);
+  const bool use_tab = P.wsample >= 1 && P.wsample <= RTAB - 256;
+  __syncthreads();
   const int n = counters[compact_counter];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -497,8 +618,7 @@ __global__ __launch_bounds__(256) void k_integrate(uint4* __restrict__ voxels, c
     uint4 v[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) v[j] = vb[j * 64 + lane];
-    const float wx0 = (float)(8 * bx + lx) * P.voxel;
-    const float wx1 = (float)(8 * bx + lx + 1) * P.voxel;
+    const v2f wx = {(float)(8 * bx + lx) * P.voxel, (float)(8 * bx + lx + 1) * P.voxel};
     const float wy = (float)(8 * by + ly) * P.voxel;
     float wz[4];
 #pragma unroll
@@ -512,15 +632,7 @@ __global__ __launch_bounds__(256) void k_integrate(uint4* __restrict__ voxels, c
       const float* Ti = B.Ti[q];
       const float* __restrict__ depthf = depthf_all + (size_t)q * npx;
       const uint32_t* __restrict__ color = color_all + (size_t)q * npx;
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const float ax = fmaf(Ti[1], wy, fmaf(Ti[2], wz[j], Ti[3]));
-        const float ay = fmaf(Ti[5], wy, fmaf(Ti[6], wz[j], Ti[7]));
-        const float az = fmaf(Ti[9], wy, fmaf(Ti[10], wz[j], Ti[11]));
-        const bool u0 = fuse_voxel<SIGN, COLOR>(P, depthf, color, fmaf(Ti[0], wx0, ax), fmaf(Ti[4], wx0, ay), fmaf(Ti[8], wx0, az), v[j].x, v[j].y);
-        const bool u1 = fuse_voxel<SIGN, COLOR>(P, depthf, color, fmaf(Ti[0], wx1, ax), fmaf(Ti[4], wx1, ay), fmaf(Ti[8], wx1, az), v[j].z, v[j].w);
-        dirty[j] = dirty[j] || u0 || u1;
-      }
+      fuse_tile<SIGN, COLOR>(P, Ti, depthf, color, s_rtab, use_tab, wx, wy, wz, v, dirty);
     }
 #pragma unroll
     for (int j = 0; j < 4; j++)
@@ -676,11 +788,15 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
   hipLaunchKernelGGL(k_prepass, dim3((npx / 8 + 255) / 256 + 1, n), dim3(256), 0, sa, in, f->depthf2[sl], f->color2[sl], npx, f->p.depth_shift,
                      f->p.depth_min, f->p.depth_max, f->counters, cc);
   if (sign > 0) {
-    const dim3 ag((f->p.depth_width + 15) / 16, (f->p.depth_height + 15) / 16, n);
-    if (f->alloc_win64)
-      hipLaunchKernelGGL(k_alloc<6>, ag, dim3(256), 0, sa, f->depthf2[sl], f->table, f->heap, f->block_keys, f->block_entry, f->counters, f->pk, bf, f->alloc_dbg);
-    else
-      hipLaunchKernelGGL(k_alloc<5>, ag, dim3(256), 0, sa, f->depthf2[sl], f->table, f->heap, f->block_keys, f->block_entry, f->counters, f->pk, bf, f->alloc_dbg);
+    // WIN 64 (32 KiB bitmap) has no room for the second bitmap: one frame per workgroup there
+    const int gf = f->alloc_win64 ? 1 : std::min(f->alloc_group, n);
+    const dim3 ag((f->p.depth_width + 15) / 16, (f->p.depth_height + 15) / 16, (n + gf - 1) / gf);
+#define LAUNCH_ALLOC(WL, MU) \
+  hipLaunchKernelGGL((k_alloc<WL, MU>), ag, dim3(256), 0, sa, f->depthf2[sl], f->table, f->heap, f->block_keys, f->block_entry, f->counters, f->pk, bf, gf)
+    if (f->alloc_win64) LAUNCH_ALLOC(6, false);
+    else if (gf == 1) LAUNCH_ALLOC(5, false);
+    else LAUNCH_ALLOC(5, true);
+#undef LAUNCH_ALLOC
   }
   hipLaunchKernelGGL(k_compactify, dim3(f->compact_grid), dim3(256), 0, sa, f->block_keys, f->block_entry, f->table, f->compact2[sl], f->cmask2[sl],
                      f->counters, cc, 0, f->pk, bf);
@@ -760,7 +876,7 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
   if (f->p.weight_max > 255) f->p.weight_max = 255;  // uchar weight saturates (SURVEY App. C decision)
   if (f->p.weight_max < 1) f->p.weight_max = 1;
   f->device = device;
-  if (const char* e = getenv("SF_ALLOC_DEBUG")) f->alloc_dbg = atoi(e);
+  if (const char* e = getenv("SF_ALLOC_GROUP")) { f->alloc_group = atoi(e); if (f->alloc_group < 1) f->alloc_group = 1; }
   {
     // longest ray segment 2 * trunc(max distance) in blocks decides the LDS window size of k_alloc
     const float seg = 2.0f * (p->trunc_base + p->trunc_scale * p->max_integration_dist) / (8.0f * p->voxel_size);

@@ -124,7 +124,7 @@ struct sf_fuser {
   int32_t* host_mirror = nullptr;  // pinned, device-visible: N_blk of the most recent integrate
   int num_cus = 256;
   bool alloc_win64 = false;  // 64^3-block LDS window when a ray segment spans more than ~20 blocks
-  int alloc_dbg = 0;  // SF_ALLOC_DEBUG: timing experiments only (1 = skip phase 2, 2 = skip LDS inserts)
+  int alloc_group = 4;  // consecutive frames of a batch one k_alloc workgroup walks (SF_ALLOC_GROUP)
   int compact_grid = 1024;  // 1024 directory entries per workgroup, grid-stride beyond
   uint64_t frames_integrated = 0, frames_skipped = 0;
   bool profile = false;
