@@ -479,24 +479,42 @@ __device__ inline v2f recip_rn(v2f b) {
 
 constexpr int RTAB = 512;  // LDS table of correctly rounded 1/m, m = weight + weight_sample < 512
 
-template <int SIGN, bool COLOR>
+__device__ inline int cvt_i32(float x) {  // v_cvt_i32_f32: truncates, saturates, NaN -> 0 (a C cast of NaN / inf would be undefined)
+  int r;
+  asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
+// TAB: the weighted-mean division goes through the LDS reciprocal table (integrate with 1 <= weight_sample <= 256).
+template <int SIGN, bool COLOR, bool TAB, bool WS1>
 __device__ inline void fuse_tile(const ParamsK& P, const float* __restrict__ Ti, const float* __restrict__ depthf,
-                                 const uint32_t* __restrict__ color, const float* rtab, bool use_tab, v2f wx, float wy,
-                                 const float (&wz)[4], uint4 (&v)[4], bool (&dirty)[4]) {
-  v2f pz[4];
+                                 const uint32_t* __restrict__ color, const float* rtab, v2f wx, float wy, const float (&wz)[4],
+                                 uint4 (&v)[4], bool (&dirty)[4]) {
+  v2f pz[4], rcp_m[4];
   float d[8];
   uint32_t c[8];
   bool ok[8];
-  int pix[8];
+  uint32_t pix[8];  // unsigned 32-bit offsets: SGPR base + VGPR offset addressing, no 64-bit pointer arithmetic per gather
+  // the weights are known before anything else: start the eight table reads now, they are consumed in phase B
+  if (TAB) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) rcp_m[j] = (v2f){rtab[(v[j].y >> 24) + (uint32_t)P.wsample], rtab[(v[j].w >> 24) + (uint32_t)P.wsample]};
+  }
   const uint32_t wbits = __float_as_uint((float)P.W), hbits = __float_as_uint((float)P.H);
+  // ---- phase A: project, gather.  Row constants first, two rows or two components per packed instruction:
+  //      a{x,y}_j = fma(Ti[1|5], wy, fma(Ti[2|6], wz_j, Ti[3|7])),  az_j = fma(Ti[9], wy, fma(Ti[10], wz_j, Ti[11]))
+  v2f axy[4], azz[2];
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+    axy[j] = pk_fma((v2f){Ti[1], Ti[5]}, splat(wy), pk_fma((v2f){Ti[2], Ti[6]}, splat(wz[j]), (v2f){Ti[3], Ti[7]}));
+#pragma unroll
+  for (int jj = 0; jj < 2; jj++)
+    azz[jj] = pk_fma(splat(Ti[9]), splat(wy), pk_fma(splat(Ti[10]), (v2f){wz[2 * jj], wz[2 * jj + 1]}, splat(Ti[11])));
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    const float ax = fmaf(Ti[1], wy, fmaf(Ti[2], wz[j], Ti[3]));
-    const float ay = fmaf(Ti[5], wy, fmaf(Ti[6], wz[j], Ti[7]));
-    const float az = fmaf(Ti[9], wy, fmaf(Ti[10], wz[j], Ti[11]));
-    const v2f pcx = pk_fma(splat(Ti[0]), wx, splat(ax));
-    const v2f pcy = pk_fma(splat(Ti[4]), wx, splat(ay));
-    const v2f pcz = pk_fma(splat(Ti[8]), wx, splat(az));
+    const v2f pcx = pk_fma(splat(Ti[0]), wx, splat(axy[j].x));
+    const v2f pcy = pk_fma(splat(Ti[4]), wx, splat(axy[j].y));
+    const v2f pcz = pk_fma(splat(Ti[8]), wx, splat(azz[j >> 1][j & 1]));
     const v2f rz = recip_rn(pcz);
     const v2f uf = pk_fma(pcx * splat(P.fx), rz, splat(P.mx)) + splat(0.5f);
     const v2f vf = pk_fma(pcy * splat(P.fy), rz, splat(P.my)) + splat(0.5f);
@@ -505,8 +523,9 @@ __device__ inline void fuse_tile(const ParamsK& P, const float* __restrict__ Ti,
     for (int hx = 0; hx < 2; hx++) {
       // 0 <= u < W as ONE unsigned compare of the float bits (negative, NaN and inf all compare high; u is never -0)
       const bool in = (pcz[hx] > 0.0f) && (__float_as_uint(uf[hx]) < wbits) && (__float_as_uint(vf[hx]) < hbits);
+      const uint32_t p = (uint32_t)cvt_i32(vf[hx]) * (uint32_t)P.W + (uint32_t)cvt_i32(uf[hx]);
       ok[2 * j + hx] = in;
-      pix[2 * j + hx] = in ? (int)vf[hx] * P.W + (int)uf[hx] : 0;
+      pix[2 * j + hx] = in ? p : 0u;
     }
   }
 #pragma unroll
@@ -514,42 +533,42 @@ __device__ inline void fuse_tile(const ParamsK& P, const float* __restrict__ Ti,
     d[k] = depthf[pix[k]];
     if (COLOR) c[k] = color[pix[k]];
   }
+  // ---- phase B: new values into temporaries (the tile itself stays untouched until the end)
   const float wn = (float)P.wsample;
   const uint32_t maxd_bits = __float_as_uint(P.maxd);
+  v2f q[4], sdfc[4];
+  uint32_t ncw[8];
+  bool upd[8];
   bool slow = false;
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const v2f dk = {d[2 * j], d[2 * j + 1]};
     v2f sdf = dk - pz[j];
     const v2f t = pk_fma(splat(P.tscale), dk, splat(P.tbase));
-    const uint32_t cw0 = v[j].y, cw1 = v[j].w;
-    const uint32_t w0 = cw0 >> 24, w1 = cw1 >> 24;
-    const v2f wo = {(float)w0, (float)w1};
+    const uint32_t cwj[2] = {v[j].y, v[j].w};
+    const v2f wo = {(float)(cwj[0] >> 24), (float)(cwj[1] >> 24)};
     const v2f old = {__uint_as_float(v[j].x), __uint_as_float(v[j].z)};
-    bool upd[2];
 #pragma unroll
     for (int hx = 0; hx < 2; hx++) {
       // valid depth (-inf has the sign bit set, valid depths are positive) below the integration distance, not behind the band
-      upd[hx] = ok[2 * j + hx] && (__float_as_uint(dk[hx]) < maxd_bits) && (sdf[hx] > -t[hx]);
+      upd[2 * j + hx] = ok[2 * j + hx] && (__float_as_uint(dk[hx]) < maxd_bits) && (sdf[hx] > -t[hx]);
       sdf[hx] = fminf(sdf[hx], t[hx]);
     }
-    v2f q;
-    uint32_t ncw[2];
+    sdfc[j] = sdf;
     if (SIGN > 0) {
-      const v2f n = pk_fma(old, wo, sdf * splat(wn));
+      const v2f n = pk_fma(old, wo, WS1 ? sdf : sdf * splat(wn));  // x * 1.0f == x bit for bit
       const v2f m = wo + splat(wn);
-      if (use_tab) {
-        const v2f r = {rtab[w0 + (uint32_t)P.wsample], rtab[w1 + (uint32_t)P.wsample]};
-        const v2f q0 = n * r;
-        q = pk_fma(pk_fma(-m, q0, n), r, q0);
+      if (TAB) {
+        const v2f q0 = n * rcp_m[j];
+        q[j] = pk_fma(pk_fma(-m, q0, n), rcp_m[j], q0);
         slow = slow || (fabsf(n.x) < 0x1p-100f) || (fabsf(n.y) < 0x1p-100f);
       } else {
-        q = (v2f){n.x / m.x, n.y / m.y};
+        q[j] = (v2f){n.x / m.x, n.y / m.y};
       }
 #pragma unroll
       for (int hx = 0; hx < 2; hx++) {
-        const uint32_t cw = hx ? cw1 : cw0;
-        const uint32_t w = hx ? w1 : w0;
+        const uint32_t cw = cwj[hx];
+        const uint32_t w = cw >> 24;
         uint32_t rgb = cw & 0xFFFFFFu;
         if (COLOR) {
           const uint32_t ck = c[2 * j + hx];
@@ -560,44 +579,51 @@ __device__ inline void fuse_tile(const ParamsK& P, const float* __restrict__ Ti,
         }
         uint32_t nw = w + (uint32_t)P.wsample;
         if (nw > (uint32_t)P.wmax) nw = (uint32_t)P.wmax;
-        ncw[hx] = rgb | (nw << 24);
+        ncw[2 * j + hx] = rgb | (nw << 24);
       }
     } else {
       const v2f n = pk_fma(old, wo, -(sdf * splat(wn)));
       const v2f m = wo - splat(wn);
-      q = (v2f){n.x / m.x, n.y / m.y};  // discarded when the weight drops to <= 0 (then m <= 0)
+      q[j] = (v2f){n.x / m.x, n.y / m.y};  // discarded when the weight drops to <= 0 (then m <= 0)
 #pragma unroll
       for (int hx = 0; hx < 2; hx++) {
-        const uint32_t cw = hx ? cw1 : cw0;
-        const int nw = (int)(hx ? w1 : w0) - P.wsample;
-        if (nw <= 0) { q[hx] = __uint_as_float(0u); ncw[hx] = 0u; }
-        else ncw[hx] = (cw & 0xFFFFFFu) | ((uint32_t)nw << 24);
+        const int nw = (int)(cwj[hx] >> 24) - P.wsample;
+        if (nw <= 0) { q[j][hx] = __uint_as_float(0u); ncw[2 * j + hx] = 0u; }
+        else ncw[2 * j + hx] = (cwj[hx] & 0xFFFFFFu) | ((uint32_t)nw << 24);
       }
     }
-    if (SIGN > 0 && use_tab && __builtin_expect(__any((int)slow), 0)) {
-      // some lane of the wave has a numerator in the underflow range: plain IEEE division for this row pair
-      const v2f n = pk_fma(old, wo, sdf * splat(wn));
+  }
+  if (SIGN > 0 && TAB && __builtin_expect(__any((int)slow), 0)) {
+    // some numerator of the wave is in the underflow range (practically: never): plain IEEE division for this tile
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const v2f wo = {(float)(v[j].y >> 24), (float)(v[j].w >> 24)};
+      const v2f old = {__uint_as_float(v[j].x), __uint_as_float(v[j].z)};
+      const v2f n = pk_fma(old, wo, sdfc[j] * splat(wn));
       const v2f m = wo + splat(wn);
-      q = (v2f){n.x / m.x, n.y / m.y};
-      slow = false;
+      q[j] = (v2f){n.x / m.x, n.y / m.y};
     }
-    v[j].x = upd[0] ? __float_as_uint(q.x) : v[j].x;
-    v[j].y = upd[0] ? ncw[0] : cw0;
-    v[j].z = upd[1] ? __float_as_uint(q.y) : v[j].z;
-    v[j].w = upd[1] ? ncw[1] : cw1;
-    dirty[j] = dirty[j] || upd[0] || upd[1];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    v[j].x = upd[2 * j] ? __float_as_uint(q[j].x) : v[j].x;
+    v[j].y = upd[2 * j] ? ncw[2 * j] : v[j].y;
+    v[j].z = upd[2 * j + 1] ? __float_as_uint(q[j].y) : v[j].z;
+    v[j].w = upd[2 * j + 1] ? ncw[2 * j + 1] : v[j].w;
+    dirty[j] = dirty[j] || upd[2 * j] || upd[2 * j + 1];
   }
 }
 
-template <int SIGN, bool COLOR>
-__global__ __launch_bounds__(256) void k_integrate(uint4* __restrict__ voxels, const uint64_t* __restrict__ block_keys,
+template <int SIGN, bool COLOR, bool TAB, bool WS1>
+__global__ __launch_bounds__(256, 4) void k_integrate(uint4* __restrict__ voxels, const uint64_t* __restrict__ block_keys,
                                                    const int32_t* __restrict__ compact, const uint32_t* __restrict__ cmask,
                                                    const float* __restrict__ depthf_all, const uint32_t* __restrict__ color_all,
                                                    int32_t* counters, int32_t* host_mirror, int compact_counter, ParamsK P, BatchTi B) {
   __shared__ float s_rtab[RTAB];  // correctly rounded 1/m for the weighted-mean division (fuse_tile)
-  for (int i = threadIdx.x; i < RTAB; i += 256) s_rtab[i] = 1.0f / (float)(i > 0 ? i : 1);
-  const bool use_tab = P.wsample >= 1 && P.wsample <= RTAB - 256;
-  __syncthreads();
+  if (TAB) {
+    for (int i = threadIdx.x; i < RTAB; i += 256) s_rtab[i] = 1.0f / (float)(i > 0 ? i : 1);
+    __syncthreads();
+  }
   const int n = counters[compact_counter];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -632,7 +658,7 @@ __global__ __launch_bounds__(256) void k_integrate(uint4* __restrict__ voxels, c
       const float* Ti = B.Ti[q];
       const float* __restrict__ depthf = depthf_all + (size_t)q * npx;
       const uint32_t* __restrict__ color = color_all + (size_t)q * npx;
-      fuse_tile<SIGN, COLOR>(P, Ti, depthf, color, s_rtab, use_tab, wx, wy, wz, v, dirty);
+      fuse_tile<SIGN, COLOR, TAB, WS1>(P, Ti, depthf, color, s_rtab, wx, wy, wz, v, dirty);
     }
 #pragma unroll
     for (int j = 0; j < 4; j++)
@@ -823,11 +849,15 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
     f->events_used++;
     (void)hipEventRecord(e0, s);
   }
-#define LAUNCH_INT(SG, CL)                                                                                                          \
-  hipLaunchKernelGGL((k_integrate<SG, CL>), dim3(grid), dim3(256), 0, s, f->voxels, f->block_keys, f->compact2[sl], f->cmask2[sl], \
+#define LAUNCH_INT(SG, CL, TB, W1)                                                                                                        \
+  hipLaunchKernelGGL((k_integrate<SG, CL, TB, W1>), dim3(grid), dim3(256), 0, s, f->voxels, f->block_keys, f->compact2[sl], f->cmask2[sl], \
                      f->depthf2[sl], f->color2[sl], f->counters, f->host_mirror, cc, f->pk, bt)
-  if (sign > 0) { if (col) LAUNCH_INT(1, true); else LAUNCH_INT(1, false); }
-  else          { if (col) LAUNCH_INT(-1, true); else LAUNCH_INT(-1, false); }
+  const bool tab = f->p.weight_sample >= 1 && f->p.weight_sample <= RTAB - 256;  // the LDS reciprocal table covers weight + sample < 512
+  if (sign > 0) {
+    if (f->p.weight_sample == 1) { if (col) LAUNCH_INT(1, true, true, true); else LAUNCH_INT(1, false, true, true); }  // the shipped setting
+    else if (tab)                { if (col) LAUNCH_INT(1, true, true, false); else LAUNCH_INT(1, false, true, false); }
+    else                         { if (col) LAUNCH_INT(1, true, false, false); else LAUNCH_INT(1, false, false, false); }
+  } else                         { if (col) LAUNCH_INT(-1, true, false, false); else LAUNCH_INT(-1, false, false, false); }
 #undef LAUNCH_INT
   if (f->profile) (void)hipEventRecord(e1, s);
   if (f->overlap) (void)hipEventRecord(f->ev_fused[sl], s);
