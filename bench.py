@@ -48,7 +48,7 @@ def cpu_baseline(depth_host, poses, budget_s=12.0, max_frames=96):
             "sample": "first %d frames of the same stream, oracle/tsdf_oracle.c -O2 -fopenmp (%d threads), %.1f s" % (n, threads, dt)}
 
 
-def pmc_traffic(steps, warmup, timeout_s=300):
+def pmc_traffic(steps, warmup, timeout_s=300, single_frame=False):
     """HBM traffic of k_integrate from the PMC counters, per launch: two SEPARATE rocprofv3 passes (--pmc FETCH_SIZE,
     --pmc WRITE_SIZE; no trace domains) over the first `steps` timed frames of this same script.  Corrections as
     MI355X_MICROARCH.md (HBM) prescribes and tools/pmc_calibrate.py confirmed for this kernel's 16 B/lane pattern
@@ -64,7 +64,7 @@ def pmc_traffic(steps, warmup, timeout_s=300):
         try:
             env = dict(os.environ, TMPDIR="/tmp")
             cmd = [exe, "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--steps", str(steps),
-                   "--warmup", str(warmup), "--no-cpu-baseline", "--no-profile", "--no-pmc"]
+                   "--warmup", str(warmup), "--no-cpu-baseline", "--no-profile", "--no-pmc"] + (["--single-frame"] if single_frame else [])
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
             dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
             if r.returncode != 0 or not dbs:
@@ -75,7 +75,7 @@ def pmc_traffic(steps, warmup, timeout_s=300):
             db = sqlite3.connect(dbs[0])
             # the integrate launches of the timed region are the LAST `steps` dispatches of the kernel (warm-up comes first)
             rows = [v for (v,) in db.execute("select value from counters_collection where counter_name = ? and kernel_name like "
-                                             "'%k_integrate<1, false>%' order by dispatch_id", (counter,))]
+                                             "'%k_integrate<1, false%' order by dispatch_id", (counter,))]
             db.close()
             launches = child_line["config"]["integrate_launches"] if child_line else 0
             if launches <= 0 or len(rows) < launches:
@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not bracket the integrate kernel with HIP events")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes that measure roofline.traffic")
     ap.add_argument("--pmc-steps", type=int, default=400)
+    ap.add_argument("--single-frame", action="store_true", help="one frame per launch (SF_BATCH=1) for the main measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -133,69 +134,79 @@ def main():
                                       poses.ctypes.data_as(C.c_void_p)))
 
     params = fusion.default_params()  # 640x480, 4 mm, 2^19 buckets x 10, 2^20 SDF blocks
-    fuser = fusion.Fuser(params, device=local_rank)
 
-    def sync_all():
-        fuser.sync()
-        torch.cuda.synchronize()
+    def run(n_warm, n_timed, profile, single_frame=False):
+        """Fuse frames [0, n_warm) untimed, then frames [n_warm, n_warm + n_timed) between two barrier+synchronize pairs."""
+        if single_frame:
+            os.environ["SF_BATCH"] = "1"   # read once, at sf_fuser_create
+        fuser = fusion.Fuser(params, device=local_rank)
+        os.environ.pop("SF_BATCH", None)
+
+        def sync_all():
+            fuser.sync()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+
+        fuser.integrate_batch_device(frames[:n_warm].data_ptr(), stride, poses[:n_warm])
+        sync_all()
+        st0 = fuser.stats()
+        if profile:
+            fuser.profile(True)
+        sync_all()
+        t0 = time.perf_counter()
+        fuser.integrate_batch_device(frames[n_warm:].data_ptr(), stride, poses[n_warm:n_warm + n_timed])
+        t_enq = time.perf_counter() - t0  # host time to enqueue (launch-bound if ~= elapsed)
+        sync_all()
+        elapsed = time.perf_counter() - t0
         if world > 1:
-            dist.barrier()
-
-    # warmup (untimed): first frames of the walk, where allocation is heaviest
-    fuser.integrate_batch_device(frames[:Wm].data_ptr(), stride, poses[:Wm])
-    sync_all()
-    st0 = fuser.stats()
-    if not args.no_profile:
-        fuser.profile(True)
-    sync_all()
-    t0 = time.perf_counter()
-    fuser.integrate_batch_device(frames[Wm:].data_ptr() if K else frames.data_ptr(), stride, poses[Wm:])
-    t_enq = time.perf_counter() - t0  # host time to enqueue the K frames (launch-bound if ~= elapsed)
-    fuser.sync()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    st1 = fuser.stats()
-    kernel_ms, launches, _ = (0.0, 0, 0) if args.no_profile else fuser.profile_read()
-    fuser.profile(False)
-
-    if rank == 0:
-        blocks = st1["total_frame_blocks"] - st0["total_frame_blocks"]
+            tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        st1 = fuser.stats()
+        kernel_ms, launches, _ = fuser.profile_read() if profile else (0.0, 0, 0)
+        fuser.profile(False)
         batch = fuser.batch_frames
-        n_launch = (K + batch - 1) // batch
-        # B_frame = N_blk*(512*8 read + 512*8 write + 16) + W*H*2 + 64
-        alg_bytes = blocks * (4096 + 4096 + 16) + K * (W * H * 2 + 64)
-        roof = None
-        if launches:
-            achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                    "kernel": "k_integrate<1,false>", "avg_kernel_us": round(kernel_ms * 1e3 / launches, 2),
-                    "launches": launches, "frames_per_launch": round(K / launches, 2),
-                    "avg_frame_blocks_per_launch": round(blocks / max(launches, 1), 1),
-                    "alg_bytes_per_launch": round(alg_bytes / max(launches, 1)),
-                    "note": "one launch fuses frames_per_launch frames into each tile while it sits in registers (temporal blocking): "
-                            "algorithmic bytes = sum of the per-frame SURVEY 8d figures, HBM traffic is ~1/frames_per_launch of it"}
+        fuser.close()
+        blocks = st1["total_frame_blocks"] - st0["total_frame_blocks"]
+        # SURVEY.md 8d: B_frame = N_blk*(512*8 read + 512*8 write + 16) + W*H*2 + 64, summed over the frames
+        alg_bytes = blocks * (4096 + 4096 + 16) + n_timed * (W * H * 2 + 64)
+        return {"elapsed": elapsed, "t_enq": t_enq, "kernel_ms": kernel_ms, "launches": launches, "blocks": blocks,
+                "alg_bytes": alg_bytes, "batch": batch, "n_launch": (n_timed + batch - 1) // batch, "st1": st1}
+
+    def roofline(m, n_timed, kernel):
+        if not m["launches"]:
+            return None
+        achieved = m["alg_bytes"] / (m["kernel_ms"] * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kernel,
+                "avg_kernel_us": round(m["kernel_ms"] * 1e3 / m["launches"], 2), "launches": m["launches"],
+                "frames_per_launch": round(n_timed / m["launches"], 2),
+                "avg_frame_blocks_per_launch": round(m["blocks"] / m["launches"], 1),
+                "alg_bytes_per_launch": round(m["alg_bytes"] / m["launches"])}
+
+    m = run(Wm, K, not args.no_profile, single_frame=args.single_frame)
+    if rank == 0:
+        roof = roofline(m, K, "k_integrate<1,false,true,true>")
+        if roof is not None and m["batch"] > 1:
+            roof["note"] = ("one launch fuses frames_per_launch frames into each 4 KiB tile while it sits in registers (temporal blocking): "
+                            "algorithmic bytes = sum of the per-frame SURVEY 8d figures, so achieved can exceed the HBM peak; the HBM "
+                            "traffic really moved is `traffic` (~1/frames_per_launch of it) and the kernel is VALU-issue bound "
+                            "(SQ_ACTIVE_INST_VALU ~ 90 %, profiles/); roofline_single_frame is the same kernel at one frame per launch")
         out = {
             "metric": "RGB-D frames/sec integrated (640x480, 4 mm voxel)",
-            "value": round(world * K / elapsed, 2), "unit": "frames/s",
+            "value": round(world * K / m["elapsed"], 2), "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": Wm,
-            "ms_per_step": round(elapsed * 1e3 / max(K, 1), 5),
-            "host_enqueue_ms_per_step": round(t_enq * 1e3 / max(K, 1), 5),
+            "ms_per_step": round(m["elapsed"] * 1e3 / max(K, 1), 5),
+            "host_enqueue_ms_per_step": round(m["t_enq"] * 1e3 / max(K, 1), 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: scene0000_00-scale synthetic stream (5578-frame box-room walk, 640x480 u16 depth, "
                                    "4 mm voxels, 2^19 hash buckets x 10, 2^20 SDF blocks), frames %d..%d per rank, depth resident in HBM" % (Wm, n_frames - 1),
                        "sharding": "one independent scan per GPU, no collective on the data path",
-                       "blocks_live_end": st1["blocks_allocated"], "alloc_failures": st1["alloc_failures"],
-                       "frames_per_pass": batch, "integrate_launches": n_launch,
-                       "alg_bytes_per_launch": round(alg_bytes / max(n_launch, 1))},
+                       "blocks_live_end": m["st1"]["blocks_allocated"], "alloc_failures": m["st1"]["alloc_failures"],
+                       "frames_per_pass": m["batch"], "integrate_launches": m["n_launch"],
+                       "alg_bytes_per_launch": round(m["alg_bytes"] / max(m["n_launch"], 1))},
             "roofline": roof,
         }
         if roof is not None and world == 1 and not args.no_pmc:
@@ -203,11 +214,25 @@ def main():
             if t is not None:
                 roof["traffic"] = t["bytes"]
                 roof["traffic_detail"] = t
+        if world == 1 and not args.no_profile and not args.single_frame and K > 1:
+            # the same kernel HBM-bound: one frame per launch (what sf_fuser_integrate does for a live stream)
+            ks = min(K, 1200)
+            m1 = run(Wm, ks, True, single_frame=True)
+            r1 = roofline(m1, ks, "k_integrate<1,false,true,true>, one frame per launch (SF_BATCH=1)")
+            if r1 is not None:
+                r1["frames_per_s"] = round(ks / m1["elapsed"], 1)
+                if not args.no_pmc:
+                    t = pmc_traffic(min(args.pmc_steps, ks), Wm, single_frame=True)
+                    if t is not None:
+                        r1["traffic"] = t["bytes"]
+                        r1["traffic_detail"] = t
+                out["roofline_single_frame"] = r1
         if not args.no_cpu_baseline:
             ns = min(96, n_frames)
             out["cpu_baseline"] = cpu_baseline(frames[:ns].cpu().numpy().view(np.uint16), poses[:ns].reshape(-1, 4, 4))
         print(json.dumps(out))
-    fuser.close()
+    else:
+        pass
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

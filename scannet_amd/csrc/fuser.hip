@@ -486,32 +486,34 @@ __device__ inline int cvt_i32(float x) {  // v_cvt_i32_f32: truncates, saturates
 }
 
 // TAB: the weighted-mean division goes through the LDS reciprocal table (integrate with 1 <= weight_sample <= 256).
-template <int SIGN, bool COLOR, bool TAB, bool WS1>
-__device__ inline void fuse_tile(const ParamsK& P, const float* __restrict__ Ti, const float* __restrict__ depthf,
+// Rows [J0, J0 + NJ) of the tile (a row = the 64 x 2 voxels one 16 B load per lane covers).  NJ = 4 gives the most
+// independent work per issue slot, NJ = 2 called twice halves the live registers (single-frame, occupancy-bound variant).
+template <int SIGN, bool COLOR, bool TAB, bool WS1, int J0, int NJ>
+__device__ inline void fuse_rows(const ParamsK& P, const float* __restrict__ Ti, const float* __restrict__ depthf,
                                  const uint32_t* __restrict__ color, const float* rtab, v2f wx, float wy, const float (&wz)[4],
                                  uint4 (&v)[4], bool (&dirty)[4]) {
-  v2f pz[4], rcp_m[4];
-  float d[8];
-  uint32_t c[8];
-  bool ok[8];
-  uint32_t pix[8];  // unsigned 32-bit offsets: SGPR base + VGPR offset addressing, no 64-bit pointer arithmetic per gather
+  v2f pz[NJ], rcp_m[NJ];
+  float d[2 * NJ];
+  uint32_t c[2 * NJ];
+  bool ok[2 * NJ];
+  uint32_t pix[2 * NJ];  // unsigned 32-bit offsets: SGPR base + VGPR offset addressing, no 64-bit pointer arithmetic per gather
   // the weights are known before anything else: start the eight table reads now, they are consumed in phase B
   if (TAB) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) rcp_m[j] = (v2f){rtab[(v[j].y >> 24) + (uint32_t)P.wsample], rtab[(v[j].w >> 24) + (uint32_t)P.wsample]};
+    for (int j = 0; j < NJ; j++) rcp_m[j] = (v2f){rtab[(v[J0 + j].y >> 24) + (uint32_t)P.wsample], rtab[(v[J0 + j].w >> 24) + (uint32_t)P.wsample]};
   }
   const uint32_t wbits = __float_as_uint((float)P.W), hbits = __float_as_uint((float)P.H);
   // ---- phase A: project, gather.  Row constants first, two rows or two components per packed instruction:
   //      a{x,y}_j = fma(Ti[1|5], wy, fma(Ti[2|6], wz_j, Ti[3|7])),  az_j = fma(Ti[9], wy, fma(Ti[10], wz_j, Ti[11]))
-  v2f axy[4], azz[2];
+  v2f axy[NJ], azz[NJ / 2];
 #pragma unroll
-  for (int j = 0; j < 4; j++)
-    axy[j] = pk_fma((v2f){Ti[1], Ti[5]}, splat(wy), pk_fma((v2f){Ti[2], Ti[6]}, splat(wz[j]), (v2f){Ti[3], Ti[7]}));
+  for (int j = 0; j < NJ; j++)
+    axy[j] = pk_fma((v2f){Ti[1], Ti[5]}, splat(wy), pk_fma((v2f){Ti[2], Ti[6]}, splat(wz[J0 + j]), (v2f){Ti[3], Ti[7]}));
 #pragma unroll
-  for (int jj = 0; jj < 2; jj++)
-    azz[jj] = pk_fma(splat(Ti[9]), splat(wy), pk_fma(splat(Ti[10]), (v2f){wz[2 * jj], wz[2 * jj + 1]}, splat(Ti[11])));
+  for (int jj = 0; jj < NJ / 2; jj++)
+    azz[jj] = pk_fma(splat(Ti[9]), splat(wy), pk_fma(splat(Ti[10]), (v2f){wz[J0 + 2 * jj], wz[J0 + 2 * jj + 1]}, splat(Ti[11])));
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
+  for (int j = 0; j < NJ; j++) {
     const v2f pcx = pk_fma(splat(Ti[0]), wx, splat(axy[j].x));
     const v2f pcy = pk_fma(splat(Ti[4]), wx, splat(axy[j].y));
     const v2f pcz = pk_fma(splat(Ti[8]), wx, splat(azz[j >> 1][j & 1]));
@@ -529,25 +531,25 @@ __device__ inline void fuse_tile(const ParamsK& P, const float* __restrict__ Ti,
     }
   }
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
+  for (int k = 0; k < 2 * NJ; k++) {
     d[k] = depthf[pix[k]];
     if (COLOR) c[k] = color[pix[k]];
   }
   // ---- phase B: new values into temporaries (the tile itself stays untouched until the end)
   const float wn = (float)P.wsample;
   const uint32_t maxd_bits = __float_as_uint(P.maxd);
-  v2f q[4], sdfc[4];
-  uint32_t ncw[8];
-  bool upd[8];
+  v2f q[NJ], sdfc[NJ];
+  uint32_t ncw[2 * NJ];
+  bool upd[2 * NJ];
   bool slow = false;
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
+  for (int j = 0; j < NJ; j++) {
     const v2f dk = {d[2 * j], d[2 * j + 1]};
     v2f sdf = dk - pz[j];
     const v2f t = pk_fma(splat(P.tscale), dk, splat(P.tbase));
-    const uint32_t cwj[2] = {v[j].y, v[j].w};
+    const uint32_t cwj[2] = {v[J0 + j].y, v[J0 + j].w};
     const v2f wo = {(float)(cwj[0] >> 24), (float)(cwj[1] >> 24)};
-    const v2f old = {__uint_as_float(v[j].x), __uint_as_float(v[j].z)};
+    const v2f old = {__uint_as_float(v[J0 + j].x), __uint_as_float(v[J0 + j].z)};
 #pragma unroll
     for (int hx = 0; hx < 2; hx++) {
       // valid depth (-inf has the sign bit set, valid depths are positive) below the integration distance, not behind the band
@@ -596,24 +598,26 @@ __device__ inline void fuse_tile(const ParamsK& P, const float* __restrict__ Ti,
   if (SIGN > 0 && TAB && __builtin_expect(__any((int)slow), 0)) {
     // some numerator of the wave is in the underflow range (practically: never): plain IEEE division for this tile
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const v2f wo = {(float)(v[j].y >> 24), (float)(v[j].w >> 24)};
-      const v2f old = {__uint_as_float(v[j].x), __uint_as_float(v[j].z)};
+    for (int j = 0; j < NJ; j++) {
+      const v2f wo = {(float)(v[J0 + j].y >> 24), (float)(v[J0 + j].w >> 24)};
+      const v2f old = {__uint_as_float(v[J0 + j].x), __uint_as_float(v[J0 + j].z)};
       const v2f n = pk_fma(old, wo, sdfc[j] * splat(wn));
       const v2f m = wo + splat(wn);
       q[j] = (v2f){n.x / m.x, n.y / m.y};
     }
   }
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    v[j].x = upd[2 * j] ? __float_as_uint(q[j].x) : v[j].x;
-    v[j].y = upd[2 * j] ? ncw[2 * j] : v[j].y;
-    v[j].z = upd[2 * j + 1] ? __float_as_uint(q[j].y) : v[j].z;
-    v[j].w = upd[2 * j + 1] ? ncw[2 * j + 1] : v[j].w;
-    dirty[j] = dirty[j] || upd[2 * j] || upd[2 * j + 1];
+  for (int j = 0; j < NJ; j++) {
+    v[J0 + j].x = upd[2 * j] ? __float_as_uint(q[j].x) : v[J0 + j].x;
+    v[J0 + j].y = upd[2 * j] ? ncw[2 * j] : v[J0 + j].y;
+    v[J0 + j].z = upd[2 * j + 1] ? __float_as_uint(q[j].y) : v[J0 + j].z;
+    v[J0 + j].w = upd[2 * j + 1] ? ncw[2 * j + 1] : v[J0 + j].w;
+    dirty[J0 + j] = dirty[J0 + j] || upd[2 * j] || upd[2 * j + 1];
   }
 }
 
+// 4 waves per SIMD (<= 128 VGPRs).  Tried for the one-frame-per-launch case: 5 waves / 96 VGPRs with the tile in two
+// half passes -- the spills cost more than the occupancy buys (183 us vs 112 us per launch).
 template <int SIGN, bool COLOR, bool TAB, bool WS1>
 __global__ __launch_bounds__(256, 4) void k_integrate(uint4* __restrict__ voxels, const uint64_t* __restrict__ block_keys,
                                                    const int32_t* __restrict__ compact, const uint32_t* __restrict__ cmask,
@@ -658,7 +662,7 @@ __global__ __launch_bounds__(256, 4) void k_integrate(uint4* __restrict__ voxels
       const float* Ti = B.Ti[q];
       const float* __restrict__ depthf = depthf_all + (size_t)q * npx;
       const uint32_t* __restrict__ color = color_all + (size_t)q * npx;
-      fuse_tile<SIGN, COLOR, TAB, WS1>(P, Ti, depthf, color, s_rtab, wx, wy, wz, v, dirty);
+      fuse_rows<SIGN, COLOR, TAB, WS1, 0, 4>(P, Ti, depthf, color, s_rtab, wx, wy, wz, v, dirty);
     }
 #pragma unroll
     for (int j = 0; j < 4; j++)
