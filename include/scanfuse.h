@@ -214,6 +214,34 @@ int sf_mesh_write_ply(const sf_mesh* m, const char* path);        /* the PLY sur
 void sf_mesh_free(sf_mesh* m);
 
 /* ------------------------------------------------------------------------------------------------
+ * Mesh cleaning: `<id>_vh.ply` -> `<id>_vh_clean.ply`.  Replaces `meshlabserver -i in.ply -o out.ply -m vc -s clean.mlx`
+ * (Server/scan_processor.py:134,143) for the filter scripts the pipeline ships -- Server/tools/meshclean/clean.mlx:3-10
+ * and cleanLoRes.mlx:3-10: "Merge Close Vertices" (absolute Threshold 0.0010689), "Remove Duplicate Faces", "Remove
+ * Isolated pieces (wrt Face Num.)" (MinComponentSize 7500 / 1000), "Remove Unreferenced Vertex".  Semantics: the VCG
+ * algorithms behind those filters, restated in scannet_amd/csrc/clean.cpp.  simplify.mlx (quadric edge collapse,
+ * scan_processor.py:144-145) is not implemented: sf_mlx_load returns SF_ERR_UNSUPPORTED for it.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct sf_clean_stats {
+  uint64_t vertices_in, faces_in;
+  uint64_t vertices_merged;        /* vertices collapsed into a lower-index vertex                  */
+  uint64_t faces_degenerate;       /* faces with a repeated vertex after merging                    */
+  uint64_t faces_duplicate;
+  uint64_t components_in, components_removed, faces_small_component;
+  uint64_t vertices_unreferenced;
+  uint64_t vertices_out, faces_out;
+} sf_clean_stats;
+
+typedef struct sf_clean_script {   /* what a .mlx FilterScript asks for */
+  int32_t merge_close_vertices, remove_duplicate_faces, remove_small_components, remove_unreferenced;
+  float merge_distance;            /* clean.mlx:4  Threshold value (absolute)   */
+  uint32_t min_component_faces;    /* clean.mlx:8  MinComponentSize             */
+} sf_clean_script;
+
+int sf_mesh_clean(const sf_mesh* in, float merge_distance, uint32_t min_component_faces, sf_mesh** out, sf_clean_stats* stats /*nullable*/);
+int sf_mlx_load(const char* mlx_path, sf_clean_script* out);
+int sf_mesh_clean_script(const sf_mesh* in, const sf_clean_script* script, sf_mesh** out, sf_clean_stats* stats /*nullable*/);
+
+/* ------------------------------------------------------------------------------------------------
  * Segmentator: Felzenszwalb-Huttenlocher graph segmentation on vertex normals.  Replaces
  * Segmentator/segmentator.cpp: segment() :123-251 (normals :185-208, edge weights :211-229,
  * segment_graph :71-92, small-segment merge :237-243), writeToJSON :253-266, main :268-289.
@@ -225,6 +253,10 @@ int sf_segment_mesh(const float* xyz, uint64_t num_vertices, const uint32_t* tri
 /* Reads mesh_path (.ply/.obj), segments, writes the JSON.  out_json NULL => reference naming:
  * <mesh minus extension>.<std::to_string(kThresh)>.segs.json (segmentator.cpp:282-286).  Prints nothing. */
 int sf_segment_file(const char* mesh_path, float kThresh, int segMinVerts, const char* out_json, uint64_t* num_segments);
+/* The same with what the drop-in CLI prints (segmentator.cpp:176-180, :285): counts4 = {vertexCount, verts.size(), faceCount,
+ * faces.size()}, the path written, and whether an .obj held more than one shape (only the first is used, :166-169). */
+int sf_segment_file_ex(const char* mesh_path, float kThresh, int segMinVerts, const char* out_json, uint64_t* num_segments,
+                       uint64_t* counts4, char* out_path, uint64_t out_path_cap, int* obj_multi);
 
 /* ------------------------------------------------------------------------------------------------
  * Synthetic stream source (benchmark input): renders frames

@@ -8,7 +8,7 @@
 
 #include "scanfuse.h"
 
-extern "C" int sf_segment_file_ex(const char*, float, int, const char*, uint64_t*, uint64_t*, char*, uint64_t, int*);
+
 
 int main(int argc, const char** argv) {
   if (argc < 2) {

@@ -1,0 +1,58 @@
+"""Mesh cleaning -- host-side mirror of the meshlabserver clean step (Server/scan_processor.py:134,143 with
+Server/tools/meshclean/clean.mlx / cleanLoRes.mlx) over the C ABI."""
+import ctypes as C
+import os
+
+from . import _abi
+from ._abi import check
+from .segmentator import Mesh
+
+CLEAN_MLX_MERGE_DISTANCE = 0.0010689   # clean.mlx:4 (absolute)
+CLEAN_MLX_MIN_COMPONENT = 7500         # clean.mlx:8
+CLEAN_LORES_MIN_COMPONENT = 1000       # cleanLoRes.mlx:8
+
+
+class SfCleanStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("vertices_in", "faces_in", "vertices_merged", "faces_degenerate", "faces_duplicate",
+                                          "components_in", "components_removed", "faces_small_component", "vertices_unreferenced",
+                                          "vertices_out", "faces_out")]
+
+
+class SfCleanScript(C.Structure):
+    _fields_ = [("merge_close_vertices", C.c_int32), ("remove_duplicate_faces", C.c_int32), ("remove_small_components", C.c_int32),
+                ("remove_unreferenced", C.c_int32), ("merge_distance", C.c_float), ("min_component_faces", C.c_uint32)]
+
+
+def _lib():
+    L = _abi.lib()
+    vp = C.c_void_p
+    L.sf_mesh_clean.argtypes = [vp, C.c_float, C.c_uint32, C.POINTER(vp), C.POINTER(SfCleanStats)]
+    L.sf_mlx_load.argtypes = [C.c_char_p, C.POINTER(SfCleanScript)]
+    L.sf_mesh_clean_script.argtypes = [vp, C.POINTER(SfCleanScript), C.POINTER(vp), C.POINTER(SfCleanStats)]
+    return L
+
+
+def clean(mesh, merge_distance=CLEAN_MLX_MERGE_DISTANCE, min_component_faces=CLEAN_MLX_MIN_COMPONENT):
+    """The four clean.mlx filters on a Mesh; returns (Mesh, stats dict)."""
+    h, st = C.c_void_p(), SfCleanStats()
+    check(_lib().sf_mesh_clean(mesh._h, float(merge_distance), int(min_component_faces), C.byref(h), C.byref(st)))
+    return Mesh(h), {n: getattr(st, n) for n, _ in SfCleanStats._fields_}
+
+
+def load_script(path):
+    s = SfCleanScript()
+    check(_lib().sf_mlx_load(os.fsencode(path), C.byref(s)))
+    return s
+
+
+def clean_file(in_ply, out_ply, script_mlx):
+    """meshlabserver -i in_ply -o out_ply -m vc -s script_mlx"""
+    s = load_script(script_mlx)
+    m = Mesh.read(in_ply)
+    h, st = C.c_void_p(), SfCleanStats()
+    check(_lib().sf_mesh_clean_script(m._h, C.byref(s), C.byref(h), C.byref(st)))
+    out = Mesh(h)
+    out.write_ply(out_ply)
+    out.close()
+    m.close()
+    return {n: getattr(st, n) for n, _ in SfCleanStats._fields_}

@@ -1,0 +1,93 @@
+"""The drop-in boundary without a GPU: libscanfuse.so loads, exports every entry point include/scanfuse.h declares (and
+nothing else), keeps its struct layouts in step with the ctypes mirror, and refuses to fuse without an MI355X -- there is
+no CPU fallback in the product path."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from scannet_amd import _abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "scanfuse.h")
+
+
+def _declared():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sf_[a-z0-9_]+)\s*\(", text)))
+
+
+def _exported():
+    out = subprocess.run(["nm", "-D", "--defined-only", _abi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    return sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("sf_") and " T " in ln})
+
+
+def test_every_declared_symbol_is_exported_and_nothing_else():
+    decl, exp = _declared(), _exported()
+    assert len(decl) >= 50
+    assert [s for s in decl if s not in exp] == [], "declared in scanfuse.h but not exported"
+    assert [s for s in exp if s not in decl] == [], "exported but not declared in scanfuse.h"
+    L = _abi.lib()
+    for s in decl:
+        assert hasattr(L, s)
+
+
+def test_every_declaration_cites_the_reference():
+    """Each group of entry points names the reference interface it replaces (file:line)."""
+    text = open(HEADER).read()
+    for anchor in ("sensorData.h:", "segmentator.cpp:", "scan_processor.py:", "zParametersScanNet.txt", "tinyply.cpp:", "clean.mlx:"):
+        assert anchor in text, anchor
+
+
+def test_struct_layouts_match_the_header():
+    # compile a tiny C program against the header and compare sizeof / offsetof with the ctypes mirror
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "scanfuse.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu\n", sizeof(sf_params), offsetof(sf_params, hash_num_buckets), sizeof(sf_stats),
+         offsetof(sf_stats, total_frame_blocks), sizeof(sf_sens_info), sizeof(sf_run_stats));
+  return 0;
+}'''
+    exe = "/tmp/sf_layout_check"
+    subprocess.run(["gcc", "-x", "c", "-std=c11", "-I" + os.path.join(ROOT, "include"), "-o", exe, "-"], input=src, text=True, check=True)
+    got = [int(x) for x in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
+    from scannet_amd import fusion, sens
+    assert got[0] == C.sizeof(_abi.SfParams) and got[1] == _abi.SfParams.hash_num_buckets.offset
+    assert got[2] == C.sizeof(_abi.SfStats) and got[3] == _abi.SfStats.total_frame_blocks.offset
+    assert got[4] == C.sizeof(sens.SfSensInfo)
+    assert got[5] == C.sizeof(fusion.SfRunStats)
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = _abi.lib()
+    n = C.c_int(-1)
+    L.sf_device_count(C.byref(n))
+    assert n.value == 0
+    p = _abi.SfParams()
+    L.sf_params_default(C.byref(p))
+    h = C.c_void_p()
+    rc = L.sf_fuser_create(C.byref(p), 0, C.byref(h))
+    assert rc == -5 and not h.value  # SF_ERR_DEVICE
+    assert b"no CPU fallback" in L.sf_last_error()
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under scannet_amd/ (python or C++) may reference it."""
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "scannet_amd")):
+        if "_build" in dirpath or "__pycache__" in dirpath:
+            continue
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hip", ".h")):
+                t = open(os.path.join(dirpath, fn), errors="replace").read()
+                if re.search(r"(from|import)\s+oracle|liboracle|oracle/_ref|#include\s+\"[^\"]*oracle", t):
+                    bad.append(fn)
+    assert bad == []

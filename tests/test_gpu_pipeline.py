@@ -73,13 +73,23 @@ def test_drop_in_executables(tmp_path):
     ply = str(tmp_path / "scene0000_00_vh.ply")
     assert os.path.getsize(ply) > 100000
     assert "Integrated 30 frames" in out.stdout and "written to" in out.stdout
-    seg = subprocess.run([os.path.join(ROOT, "bin", "segmentator"), ply], capture_output=True, text=True)
-    assert seg.returncode == 0 and seg.stderr == ""
-    js = json.load(open(str(tmp_path / "scene0000_00_vh.0.010000.segs.json")))
-    assert js["params"] == {"kThresh": 0.01, "segMinVerts": 20} and js["sceneId"] == "/scene0000_00_vh"
+    # meshlabserver -i X_vh.ply -o X_vh_clean.ply -m vc -s clean.mlx (scan_processor.py:143)
+    mlx = tmp_path / "clean.mlx"
+    mlx.write_text('<!DOCTYPE FilterScript>\n<FilterScript>\n <filter name="Merge Close Vertices">\n  <Param name="Threshold" value="0.0010689" type="RichAbsPerc"/>\n </filter>\n'
+                   ' <filter name="Remove Duplicate Faces"/>\n <filter name="Remove Isolated pieces (wrt Face Num.)">\n  <Param name="MinComponentSize" value="7500" type="RichInt"/>\n </filter>\n'
+                   ' <filter name="Remove Unreferenced Vertex"/>\n</FilterScript>\n')
+    clean_ply = str(tmp_path / "scene0000_00_vh_clean.ply")
+    cl = subprocess.run([os.path.join(ROOT, "bin", "meshclean"), "-i", ply, "-o", clean_ply, "-m", "vc", "-s", str(mlx)], capture_output=True, text=True)
+    assert cl.returncode == 0 and cl.stderr == "", cl.stderr
     from scannet_amd import segmentator
-    nv, nf = segmentator.Mesh.read(ply).counts()
-    assert len(js["segIndices"]) == nv and nf > 10000
+    nv0, nf0 = segmentator.Mesh.read(ply).counts()
+    nv, nf = segmentator.Mesh.read(clean_ply).counts()
+    assert 10000 < nf <= nf0 and nv <= nv0
+    seg = subprocess.run([os.path.join(ROOT, "bin", "segmentator"), clean_ply], capture_output=True, text=True)
+    assert seg.returncode == 0 and seg.stderr == ""
+    js = json.load(open(str(tmp_path / "scene0000_00_vh_clean.0.010000.segs.json")))
+    assert js["params"] == {"kThresh": 0.01, "segMinVerts": 20} and js["sceneId"] == "/scene0000_00_vh_clean"
+    assert len(js["segIndices"]) == nv
     # failure protocol: non-zero exit and a message on stderr
     bad = subprocess.run([os.path.join(ROOT, "bin", "depthsensing"), str(params), str(params), str(tmp_path / "missing.sens")], capture_output=True, text=True)
     assert bad.returncode != 0 and "could not open" in bad.stderr
