@@ -113,6 +113,18 @@ int sf_fuser_profile_read(sf_fuser* f, double* integrate_ms, uint64_t* launches,
  * bytes ({float sdf; uchar r,g,b,weight} x 512, index z*64+y*8+x).  Pass NULLs to query n only. */
 int sf_fuser_export_blocks(sf_fuser* f, int32_t* coords, void* voxels, uint64_t capacity, uint64_t* n);
 
+/* One large scan over several GPUs (BASELINE configs[4]): the block space is cut into slabs along `axis`; a fuser with a
+ * slab set still sees every frame but only allocates (hence fuses) the blocks whose coordinate on `axis` lies in
+ * [lo_block, hi_block).  axis < 0 removes the partition.  Before meshing, each fuser imports -- as GHOST blocks, which are
+ * read as neighbours but never fused, meshed or garbage-collected -- the lowest block layer of the slab above it (marching
+ * cubes needs the +1 voxel neighbours): sf_fuser_export_blocks_where(axis, lo, lo + 1) on the owner, an all-gather (RCCL
+ * over xGMI when the buffers are device tensors: dst_on_device / src_on_device = 1), sf_fuser_import_blocks(ghost = 1) on
+ * the neighbour.  Slabs along x concatenate into the canonical mesh (scannet_amd/partition.py). */
+int sf_fuser_set_slab(sf_fuser* f, int axis, int32_t lo_block, int32_t hi_block);
+int sf_fuser_export_blocks_where(sf_fuser* f, int axis, int32_t lo, int32_t hi, int include_ghosts, int32_t* coords, void* voxels,
+                                 uint64_t capacity, uint64_t* n, int dst_on_device);   /* coords = voxels = NULL: count only */
+int sf_fuser_import_blocks(sf_fuser* f, const int32_t* coords, const void* voxels, uint64_t n, int ghost, int src_on_device);
+
 /* Fuse frames [first, last) of an opened .sens file (last = 0: to the end): a pool of `decode_threads` (0 = one
  * per core) inflates depth frames into pinned buffers in frame order, copies and kernels are queued as frames
  * become ready.  Replaces the frame loop around RGBDFrameCacheRead (sensorData.h:1717-1831).  The fuser must have

@@ -109,6 +109,9 @@ def _declare_optional(L):
         "sf_sens_save": ([vp, C.c_char_p], C.c_int),
         "sf_fuse_run": ([vp, vp, u64, u64, C.c_int, vp], C.c_int),
         "sf_fuser_batch_frames": ([vp], C.c_int),
+        "sf_fuser_set_slab": ([vp, C.c_int, i32, i32], C.c_int),
+        "sf_fuser_export_blocks_where": ([vp, C.c_int, i32, i32, C.c_int, vp, vp, u64, C.POINTER(u64), C.c_int], C.c_int),
+        "sf_fuser_import_blocks": ([vp, vp, vp, u64, C.c_int, C.c_int], C.c_int),
         "sf_calib_stream": ([C.c_int, u64, C.c_int], C.c_int),
         "sf_fuser_extract_mesh": ([vp, C.POINTER(vp)], C.c_int),
         "sf_mesh_counts": ([vp, C.POINTER(u64), C.POINTER(u64)], C.c_int),

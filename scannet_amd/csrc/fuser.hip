@@ -123,6 +123,7 @@ struct HashRefs {
   int32_t* heap;
   uint64_t* block_keys;
   int32_t* block_entry;
+  uint8_t* block_flags;
   int32_t* counters;
 };
 
@@ -158,6 +159,7 @@ __device__ inline void give_block(const HashRefs& h, HashEntry* e, uint64_t key,
     e->ptr = idx;
     h.block_keys[idx] = key;
     h.block_entry[idx] = (int32_t)(e - h.table);
+    h.block_flags[idx] = 0;
     atomicMax(&h.counters[C_HIGH_WATER], idx + 1);
   } else {
     // heap exhausted: the entry stays claimed without a block; undo the pop
@@ -168,8 +170,8 @@ __device__ inline void give_block(const HashRefs& h, HashEntry* e, uint64_t key,
 
 template <int WIN_LOG2, bool MULTI>
 __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_all, HashEntry* table, int32_t* heap,
-                                               uint64_t* block_keys, int32_t* block_entry, int32_t* counters, ParamsK P, BatchFrames B,
-                                               int group_frames) {
+                                               uint64_t* block_keys, int32_t* block_entry, uint8_t* block_flags, int32_t* counters, ParamsK P,
+                                               BatchFrames B, int group_frames) {
   constexpr int WIN = 1 << WIN_LOG2;                // window edge in blocks
   constexpr int WIN_WORDS = (WIN * WIN * WIN) / 32; // occupancy bitmap words: 4 KiB (WIN 32) / 32 KiB (WIN 64)
   __shared__ uint32_t s_frame[WIN_WORDS];           // blocks the current frame's rays visit
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_
   if (threadIdx.x == 0) { s_count = 0; s_chooser = 256; s_anchored = 0; }
   const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
   const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
-  const HashRefs h{table, heap, block_keys, block_entry, counters};
+  const HashRefs h{table, heap, block_keys, block_entry, block_flags, counters};
   for (int i = threadIdx.x; i < ALLOC_SET; i += 256) s_keys[i] = KEY_EMPTY;
   if (MULTI)
     for (int i = threadIdx.x; i < WIN_WORDS; i += 256) s_done[i] = 0u;
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_
           const uint64_t key = pack_key(a_cx, a_cy, a_cz);
           if (key != last_key) {
             last_key = key;
-            if (block_in_frustum(P, F, a_cx, a_cy, a_cz)) {
+            if (slab_owns(P, a_cx, a_cy, a_cz) && block_in_frustum(P, F, a_cx, a_cy, a_cz)) {
               uint32_t sl = ((uint32_t)(key ^ (key >> 21) ^ (key >> 42)) * 2654435761u) >> 22;  // 10 bits
               bool placed = false;
               for (int pr = 0; pr < ALLOC_SET_PROBES; ++pr) {
@@ -324,6 +326,7 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_
         bits &= bits - 1u;
         const uint32_t bit = ((uint32_t)w << 5) | (uint32_t)b;
         const int bx = anx + (int)(bit & (WIN - 1)), by = any_ + (int)((bit >> WIN_LOG2) & (WIN - 1)), bz = anz + (int)(bit >> (2 * WIN_LOG2));
+        if (!slab_owns(P, bx, by, bz)) { queued |= 1u << b; continue; }  // another GPU's block: never ours, stop looking at it
         if (!block_in_frustum(P, F, bx, by, bz)) continue;  // a later frame may still want it
         queued |= 1u << b;
         const int pos = atomicAdd(&s_count, 1);
@@ -372,10 +375,12 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_
 // frame j's frustum AND was born no later than frame j.  1024 directory entries per workgroup, ballot
 // prefix sums inside the waves, one LDS exchange and TWO global atomics per workgroup (list position +
 // last-frame count in one 64-bit word, the N_blk total in another cache line; a single counter word
-// saturates at ~88 atomics/us on this chip).  all_live != 0 lists every live block (export / GC / meshing).
+// saturates at ~88 atomics/us on this chip).  all_live = 1 lists every live block (export), 2 every live block this
+// fuser owns (GC, meshing); ghost copies of a neighbour slab's blocks are never fused.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_compactify(const uint64_t* __restrict__ block_keys, const int32_t* __restrict__ block_entry,
-                                                    const HashEntry* __restrict__ table, int32_t* __restrict__ compact,
+                                                    const uint8_t* __restrict__ block_flags, const HashEntry* __restrict__ table,
+                                                    int32_t* __restrict__ compact,
                                                     uint32_t* __restrict__ cmask, int32_t* counters, int counter_id, int all_live, ParamsK P,
                                                     BatchFrames B) {
   __shared__ int s_wtot[4], s_wlast[4], s_wpop[4];
@@ -393,7 +398,7 @@ __global__ __launch_bounds__(256) void k_compactify(const uint64_t* __restrict__
       m[j] = 0u;
       if (i < hw) {
         const uint64_t k = block_keys[i];
-        if (k != KEY_EMPTY) {
+        if (k != KEY_EMPTY && !(all_live != 1 && (block_flags[i] & 1))) {  // ghosts are listed by all_live == 1 only
           if (all_live) m[j] = 1u;
           else {
             int bx, by, bz;
@@ -740,6 +745,58 @@ __global__ __launch_bounds__(256) void k_gather(const uint4* __restrict__ voxels
   }
 }
 
+// Filtered export: the live blocks whose coordinate on `axis` lies in [lo, hi) (axis < 0: all), appended in no
+// particular order.  One workgroup per candidate block.
+__global__ __launch_bounds__(256) void k_gather_where(const uint4* __restrict__ voxels, const uint64_t* __restrict__ block_keys,
+                                                      const int32_t* __restrict__ live, int n, int axis, int lo, int hi, int capacity,
+                                                      int32_t* counter, int32_t* coords, uint4* out) {
+  __shared__ int s_pos;
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    const int slot = live[i];
+    int bx, by, bz;
+    unpack_key(block_keys[slot], bx, by, bz);
+    const int c = axis == 0 ? bx : (axis == 1 ? by : bz);
+    if (axis >= 0 && (c < lo || c >= hi)) continue;  // uniform per workgroup
+    if (threadIdx.x == 0) s_pos = atomicAdd(counter, 1);
+    __syncthreads();
+    const int pos = s_pos;
+    if (pos < capacity && out != nullptr) {
+      out[(size_t)pos * 256 + threadIdx.x] = voxels[(size_t)slot * 256 + threadIdx.x];
+      if (threadIdx.x == 0) { coords[3 * pos] = bx; coords[3 * pos + 1] = by; coords[3 * pos + 2] = bz; }
+    }
+    __syncthreads();
+  }
+}
+
+// Import: one workgroup per block; lane 0 finds or creates the entry (+ heap pop), all lanes copy the 4 KiB tile.
+__global__ __launch_bounds__(256) void k_import(const int32_t* __restrict__ coords, const uint4* __restrict__ src, int n, int ghost,
+                                                uint4* voxels, HashEntry* table, int32_t* heap, uint64_t* block_keys, int32_t* block_entry,
+                                                uint8_t* block_flags, int32_t* counters, ParamsK P) {
+  __shared__ int s_slot;
+  const HashRefs h{table, heap, block_keys, block_entry, block_flags, counters};
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    if (threadIdx.x == 0) {
+      const int bx = coords[3 * i], by = coords[3 * i + 1], bz = coords[3 * i + 2];
+      const uint64_t key = pack_key(bx, by, bz);
+      HashEntry* e = hash_find_or_claim(h, P, key, bx, by, bz, 0u);
+      int slot = -1;
+      if (e) {
+        atomicAdd(&counters[C_SLOTS_USED], 1);
+        give_block(h, e, key, atomicSub(&counters[C_HEAP_FREE], 1) - 1);
+        slot = e->ptr >= 0 && block_keys[e->ptr] == key ? e->ptr : -1;  // -1: heap exhausted
+      } else {
+        slot = hash_lookup(table, P, bx, by, bz);  // already present (re-import): overwrite
+      }
+      if (slot >= 0) block_flags[slot] = ghost ? 1 : 0;
+      s_slot = slot;
+    }
+    __syncthreads();
+    const int slot = s_slot;
+    if (slot >= 0) voxels[(size_t)slot * 256 + threadIdx.x] = src[(size_t)i * 256 + threadIdx.x];
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 // ======================================================================================================
@@ -822,14 +879,14 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
     const int gf = f->alloc_win64 ? 1 : std::min(f->alloc_group, n);
     const dim3 ag((f->p.depth_width + 15) / 16, (f->p.depth_height + 15) / 16, (n + gf - 1) / gf);
 #define LAUNCH_ALLOC(WL, MU) \
-  hipLaunchKernelGGL((k_alloc<WL, MU>), ag, dim3(256), 0, sa, f->depthf2[sl], f->table, f->heap, f->block_keys, f->block_entry, f->counters, f->pk, bf, gf)
+  hipLaunchKernelGGL((k_alloc<WL, MU>), ag, dim3(256), 0, sa, f->depthf2[sl], f->table, f->heap, f->block_keys, f->block_entry, f->block_flags, f->counters, f->pk, bf, gf)
     if (f->alloc_win64) LAUNCH_ALLOC(6, false);
     else if (gf == 1) LAUNCH_ALLOC(5, false);
     else LAUNCH_ALLOC(5, true);
 #undef LAUNCH_ALLOC
   }
-  hipLaunchKernelGGL(k_compactify, dim3(f->compact_grid), dim3(256), 0, sa, f->block_keys, f->block_entry, f->table, f->compact2[sl], f->cmask2[sl],
-                     f->counters, cc, 0, f->pk, bf);
+  hipLaunchKernelGGL(k_compactify, dim3(f->compact_grid), dim3(256), 0, sa, f->block_keys, f->block_entry, f->block_flags, f->table, f->compact2[sl],
+                     f->cmask2[sl], f->counters, cc, 0, f->pk, bf);
   if (f->overlap) {
     (void)hipEventRecord(f->ev_compact[sl], sa);
     (void)hipStreamWaitEvent(s, f->ev_compact[sl], 0);
@@ -923,6 +980,7 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
   k.wsample = p->weight_sample; k.wmax = f->p.weight_max;
   k.num_buckets = p->hash_num_buckets; k.bucket_size = p->hash_bucket_size;
   k.total_slots = p->hash_num_buckets * p->hash_bucket_size; k.num_blocks = p->num_sdf_blocks;
+  k.slab_axis = -1; k.slab_lo = 0; k.slab_hi = 0;
   hipDeviceProp_t prop;
   SF_HIP_CHECK(hipGetDeviceProperties(&prop, device));
   f->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -956,6 +1014,7 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
   SF_ALLOC(f->heap, (size_t)k.num_blocks * 4);
   SF_ALLOC(f->block_keys, (size_t)k.num_blocks * 8);
   SF_ALLOC(f->block_entry, (size_t)k.num_blocks * 4);
+  SF_ALLOC(f->block_flags, (size_t)k.num_blocks);
   SF_ALLOC(f->voxels, (size_t)k.num_blocks * 4096);
   for (int q = 0; q < 2; q++) {
     SF_ALLOC(f->depthf2[q], npx * 4 * MAX_BATCH);
@@ -972,6 +1031,7 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
   *f->host_mirror = 0;
   SF_HIP_CHECK(hipMemsetAsync(f->table, 0xFF, (size_t)k.total_slots * sizeof(HashEntry), f->stream));
   SF_HIP_CHECK(hipMemsetAsync(f->voxels, 0, (size_t)k.num_blocks * 4096, f->stream));
+  SF_HIP_CHECK(hipMemsetAsync(f->block_flags, 0, (size_t)k.num_blocks, f->stream));
   SF_HIP_CHECK(hipMemsetAsync(f->counters, 0, C_COUNT * 4, f->stream));
   hipLaunchKernelGGL(k_init_heap, dim3((k.num_blocks + 255) / 256), dim3(256), 0, f->stream, f->heap, f->block_keys, (int)k.num_blocks);
   const int32_t free0 = (int32_t)k.num_blocks;
@@ -986,7 +1046,7 @@ SF_API void sf_fuser_destroy(sf_fuser* f) {
   (void)hipSetDevice(f->device);
   if (f->stream) (void)hipStreamSynchronize(f->stream);
   for (auto& e : f->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-  (void)hipFree(f->table); (void)hipFree(f->heap); (void)hipFree(f->block_keys); (void)hipFree(f->block_entry); (void)hipFree(f->voxels);
+  (void)hipFree(f->table); (void)hipFree(f->heap); (void)hipFree(f->block_keys); (void)hipFree(f->block_entry); (void)hipFree(f->block_flags); (void)hipFree(f->voxels);
   for (int q = 0; q < 2; q++) { (void)hipFree(f->depthf2[q]); (void)hipFree(f->color2[q]); (void)hipFree(f->compact2[q]); (void)hipFree(f->cmask2[q]); }
   (void)hipFree(f->counters);
   for (int q = 0; q < 2; q++) { if (f->ev_compact[q]) (void)hipEventDestroy(f->ev_compact[q]); if (f->ev_fused[q]) (void)hipEventDestroy(f->ev_fused[q]); }
@@ -1111,14 +1171,14 @@ SF_API int sf_fuser_profile_read(sf_fuser* f, double* integrate_ms, uint64_t* la
   return SF_OK;
 }
 
-int sf_compact_live(sf_fuser* f, int32_t* n_out) {
+int sf_compact_live(sf_fuser* f, int32_t* n_out, int include_ghosts) {
   SF_HIP_CHECK(sf_quiesce(f));
   BatchFrames dummy;
   std::memset(&dummy, 0, sizeof(dummy));
   dummy.n = 1;
   SF_HIP_CHECK(hipMemsetAsync(&f->counters[C_EXPORT], 0, 8, f->stream));
-  hipLaunchKernelGGL(k_compactify, dim3(f->compact_grid), dim3(256), 0, f->stream, f->block_keys, f->block_entry, f->table, f->compact, f->cmask2[0],
-                     f->counters, (int)C_EXPORT, 1, f->pk, dummy);
+  hipLaunchKernelGGL(k_compactify, dim3(f->compact_grid), dim3(256), 0, f->stream, f->block_keys, f->block_entry, f->block_flags, f->table, f->compact,
+                     f->cmask2[0], f->counters, (int)C_EXPORT, include_ghosts ? 1 : 2, f->pk, dummy);
   SF_HIP_CHECK(hipMemcpyAsync(n_out, &f->counters[C_EXPORT], 4, hipMemcpyDeviceToHost, f->stream));
   SF_HIP_CHECK(sf_quiesce(f));
   return SF_OK;
@@ -1128,7 +1188,7 @@ SF_API int sf_fuser_garbage_collect(sf_fuser* f, uint32_t* freed) {
   if (!f) return sf::fail(SF_ERR_INVALID_ARG, "NULL fuser");
   SF_HIP_CHECK(hipSetDevice(f->device));
   int32_t n = 0;
-  const int rc = sf_compact_live(f, &n);
+  const int rc = sf_compact_live(f, &n, 0);
   if (rc != SF_OK) return rc;
   SF_HIP_CHECK(hipMemsetAsync(&f->counters[C_GC_FREED], 0, 4, f->stream));
   const float thr = std::fmaf(f->p.trunc_scale, f->p.depth_max, f->p.trunc_base);
@@ -1176,3 +1236,88 @@ SF_API int sf_device_malloc(int device, uint64_t bytes, void** out) {
 SF_API int sf_device_free(void* p) { SF_HIP_CHECK(hipFree(p)); return SF_OK; }
 SF_API int sf_device_upload(void* dst, const void* src, uint64_t bytes) { SF_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return SF_OK; }
 SF_API int sf_device_download(void* dst, const void* src, uint64_t bytes) { SF_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return SF_OK; }
+
+// ------------------------------------------------------------------------------------------------------
+// One large scan over several GPUs (BASELINE configs[4]): slab ownership, boundary layer export / import
+// ------------------------------------------------------------------------------------------------------
+SF_API int sf_fuser_set_slab(sf_fuser* f, int axis, int32_t lo_block, int32_t hi_block) {
+  if (!f) return sf::fail(SF_ERR_INVALID_ARG, "NULL fuser");
+  if (axis > 2) return sf::fail(SF_ERR_INVALID_ARG, "axis must be 0, 1, 2 or negative (no partition)");
+  if (axis >= 0 && !(lo_block < hi_block)) return sf::fail(SF_ERR_INVALID_ARG, "empty slab [%d, %d)", lo_block, hi_block);
+  SF_HIP_CHECK(hipSetDevice(f->device));
+  SF_HIP_CHECK(sf_quiesce(f));
+  f->pk.slab_axis = axis < 0 ? -1 : axis;
+  f->pk.slab_lo = lo_block;
+  f->pk.slab_hi = hi_block;
+  return SF_OK;
+}
+
+SF_API int sf_fuser_export_blocks_where(sf_fuser* f, int axis, int32_t lo, int32_t hi, int include_ghosts, int32_t* coords, void* voxels,
+                                        uint64_t capacity, uint64_t* n_out, int dst_on_device) {
+  if (!f || !n_out) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  if ((coords == nullptr) != (voxels == nullptr)) return sf::fail(SF_ERR_INVALID_ARG, "coords and voxels must both be given (or both NULL to count)");
+  SF_HIP_CHECK(hipSetDevice(f->device));
+  int32_t n_live = 0;
+  const int rc = sf_compact_live(f, &n_live, include_ghosts);
+  if (rc != SF_OK) return rc;
+  *n_out = 0;
+  if (n_live == 0) return SF_OK;
+  SF_HIP_CHECK(hipMemsetAsync(&f->counters[C_GC_FREED], 0, 4, f->stream));  // scratch counter (GC is synchronous, never concurrent)
+  int32_t* d_coords = nullptr;
+  uint4* d_vox = nullptr;
+  const bool want = coords != nullptr;
+  const int cap = (int)std::min<uint64_t>(capacity, 0x7FFFFFFFull);
+  if (want && !dst_on_device && cap > 0) {
+    SF_HIP_CHECK(hipMalloc((void**)&d_coords, (size_t)cap * 12));
+    if (hipMalloc((void**)&d_vox, (size_t)cap * 4096) != hipSuccess) { (void)hipFree(d_coords); return sf::fail(SF_ERR_DEVICE, "hipMalloc export buffer failed"); }
+  } else if (want) {
+    d_coords = coords;
+    d_vox = (uint4*)voxels;
+  }
+  hipLaunchKernelGGL(k_gather_where, dim3(n_live < 65535 ? n_live : 65535), dim3(256), 0, f->stream, f->voxels, f->block_keys, f->compact, n_live, axis, lo, hi,
+                     want ? cap : 0, &f->counters[C_GC_FREED], d_coords, want && cap > 0 ? d_vox : nullptr);
+  int32_t n = 0;
+  hipError_t e = hipMemcpyAsync(&n, &f->counters[C_GC_FREED], 4, hipMemcpyDeviceToHost, f->stream);
+  if (e == hipSuccess) e = sf_quiesce(f);
+  if (e == hipSuccess && want && !dst_on_device && cap > 0) {
+    const size_t m = (size_t)std::min(n, cap);
+    e = hipMemcpy(coords, d_coords, m * 12, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(voxels, d_vox, m * 4096, hipMemcpyDeviceToHost);
+  }
+  if (want && !dst_on_device && cap > 0) { (void)hipFree(d_coords); (void)hipFree(d_vox); }
+  if (e != hipSuccess) return sf::fail(SF_ERR_DEVICE, "export failed: %s", hipGetErrorString(e));
+  *n_out = (uint64_t)n;
+  if (want && (uint64_t)n > capacity) return sf::fail(SF_ERR_BOUNDS, "capacity %llu < %d matching blocks", (unsigned long long)capacity, n);
+  return SF_OK;
+}
+
+SF_API int sf_fuser_import_blocks(sf_fuser* f, const int32_t* coords, const void* voxels, uint64_t n, int ghost, int src_on_device) {
+  if (!f || (n && (!coords || !voxels))) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  if (n == 0) return SF_OK;
+  if (n > 0x7FFFFFFFull) return sf::fail(SF_ERR_INVALID_ARG, "too many blocks");
+  SF_HIP_CHECK(hipSetDevice(f->device));
+  SF_HIP_CHECK(sf_quiesce(f));
+  const int32_t* d_coords = coords;
+  const uint4* d_vox = (const uint4*)voxels;
+  int32_t* tmp_c = nullptr;
+  uint4* tmp_v = nullptr;
+  if (!src_on_device) {
+    SF_HIP_CHECK(hipMalloc((void**)&tmp_c, n * 12));
+    if (hipMalloc((void**)&tmp_v, n * 4096) != hipSuccess) { (void)hipFree(tmp_c); return sf::fail(SF_ERR_DEVICE, "hipMalloc import buffer failed"); }
+    hipError_t e = hipMemcpy(tmp_c, coords, n * 12, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(tmp_v, voxels, n * 4096, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(tmp_c); (void)hipFree(tmp_v); return sf::fail(SF_ERR_DEVICE, "import copy failed: %s", hipGetErrorString(e)); }
+    d_coords = tmp_c;
+    d_vox = tmp_v;
+  }
+  int32_t fail0 = 0, fail1 = 0;
+  (void)hipMemcpy(&fail0, &f->counters[C_ALLOC_FAIL], 4, hipMemcpyDeviceToHost);
+  hipLaunchKernelGGL(k_import, dim3(n < 65535 ? (unsigned)n : 65535u), dim3(256), 0, f->stream, d_coords, d_vox, (int)n, ghost, f->voxels, f->table, f->heap,
+                     f->block_keys, f->block_entry, f->block_flags, f->counters, f->pk);
+  hipError_t e = hipMemcpyAsync(&fail1, &f->counters[C_ALLOC_FAIL], 4, hipMemcpyDeviceToHost, f->stream);
+  if (e == hipSuccess) e = sf_quiesce(f);
+  if (tmp_c) { (void)hipFree(tmp_c); (void)hipFree(tmp_v); }
+  if (e != hipSuccess) return sf::fail(SF_ERR_DEVICE, "import failed: %s", hipGetErrorString(e));
+  if (fail1 != fail0) return sf::fail(SF_ERR_CAPACITY, "%d imported blocks did not fit (heap or hash table exhausted)", fail1 - fail0);
+  return SF_OK;
+}

@@ -27,7 +27,16 @@ struct ParamsK {
   float voxel, tbase, tscale, maxd;
   int wsample, wmax;
   uint32_t num_buckets, bucket_size, total_slots, num_blocks;
+  // slab partition of one large scan over several GPUs: this fuser only allocates blocks whose
+  // coordinate on slab_axis lies in [slab_lo, slab_hi); slab_axis < 0 = no partition
+  int slab_axis, slab_lo, slab_hi;
 };
+
+__host__ __device__ inline bool slab_owns(const ParamsK& P, int bx, int by, int bz) {
+  if (P.slab_axis < 0) return true;
+  const int c = P.slab_axis == 0 ? bx : (P.slab_axis == 1 ? by : bz);
+  return c >= P.slab_lo && c < P.slab_hi;
+}
 
 struct FrameK {
   float T[12];
@@ -111,6 +120,7 @@ struct sf_fuser {
   int32_t* compact2[2] = {nullptr, nullptr};   // heap slots of the blocks some frame of the batch sees
   uint32_t* cmask2[2] = {nullptr, nullptr};    // per compact entry: bit j = frame j of the batch updates this block
   int32_t* block_entry = nullptr;              // directory: table index of the entry of the block in heap slot i
+  uint8_t* block_flags = nullptr;              // directory: bit 0 = ghost (imported copy of a neighbour slab's block: read by meshing, never fused or meshed)
   uint32_t frame_seq = 1;                      // sequence number of the next frame
   int batch = MAX_BATCH;                       // frames per pass (SF_BATCH overrides, 1..MAX_BATCH)
   HashEntry* table = nullptr;
@@ -134,4 +144,4 @@ struct sf_fuser {
 
 
 hipError_t sf_quiesce(sf_fuser* f);                 // drain both streams
-int sf_compact_live(sf_fuser* f, int32_t* n_out);   // live heap slots -> f->compact, synchronous
+int sf_compact_live(sf_fuser* f, int32_t* n_out, int include_ghosts = 1);   // live heap slots -> f->compact, synchronous

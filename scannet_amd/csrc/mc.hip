@@ -217,7 +217,7 @@ SF_API int sf_fuser_extract_mesh(sf_fuser* f, sf_mesh** out) {
   if (!f || !out) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
   MC_CHECK(hipSetDevice(f->device));
   int32_t n_live = 0;
-  int rc = sf_compact_live(f, &n_live);
+  int rc = sf_compact_live(f, &n_live, 0);  // ghost copies of a neighbour slab's blocks are read as neighbours, never meshed
   if (rc != SF_OK) return rc;
   std::unique_ptr<sf_mesh> m(new sf_mesh());
   if (n_live == 0) { *out = m.release(); return SF_OK; }

@@ -150,6 +150,30 @@ class Fuser:
         check(_abi.lib().sf_fuse_run(self._h, sensor_data._h, int(first), int(last), int(decode_threads), C.byref(st)))
         return {k: getattr(st, k) for k, _ in SfRunStats._fields_}
 
+    # -- one large scan over several GPUs (scannet_amd/partition.py) -------------------------------------
+    def set_slab(self, axis, lo_block, hi_block):
+        """Only allocate blocks with lo_block <= coord[axis] < hi_block (axis < 0: no partition)."""
+        check(_abi.lib().sf_fuser_set_slab(self._h, int(axis), int(lo_block), int(hi_block)))
+
+    def export_blocks_where(self, axis, lo, hi, include_ghosts=False):
+        """Live blocks with lo <= coord[axis] < hi -> (coords int32 [n,3], voxels VOXEL_DTYPE [n,512]), sorted by (x,y,z)."""
+        L = _abi.lib()
+        n = C.c_uint64(0)
+        check(L.sf_fuser_export_blocks_where(self._h, int(axis), int(lo), int(hi), int(bool(include_ghosts)), None, None, 0, C.byref(n), 0))
+        coords = np.zeros((n.value, 3), np.int32)
+        vox = np.zeros((n.value, 512), VOXEL_DTYPE)
+        if n.value:
+            check(L.sf_fuser_export_blocks_where(self._h, int(axis), int(lo), int(hi), int(bool(include_ghosts)), _ptr(coords), _ptr(vox), n.value, C.byref(n), 0))
+        order = np.lexsort((coords[:, 2], coords[:, 1], coords[:, 0]))
+        return coords[order], vox[order]
+
+    def import_blocks(self, coords, voxels, ghost=True):
+        coords = np.ascontiguousarray(coords, np.int32).reshape(-1, 3)
+        voxels = np.ascontiguousarray(voxels)
+        if voxels.nbytes != len(coords) * 4096:
+            raise ValueError("voxels must hold 4096 bytes per block")
+        check(_abi.lib().sf_fuser_import_blocks(self._h, _ptr(coords), _ptr(voxels), len(coords), int(bool(ghost)), 0))
+
     def extract_mesh(self):
         """Marching cubes over all live blocks -> segmentator.Mesh (vertices in edge-key order, deterministic)."""
         from .segmentator import Mesh

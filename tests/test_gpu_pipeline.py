@@ -93,3 +93,65 @@ def test_drop_in_executables(tmp_path):
     # failure protocol: non-zero exit and a message on stderr
     bad = subprocess.run([os.path.join(ROOT, "bin", "depthsensing"), str(params), str(params), str(tmp_path / "missing.sens")], capture_output=True, text=True)
     assert bad.returncode != 0 and "could not open" in bad.stderr
+
+
+def _room_frames(n, W, H, total, stride=9):
+    out = []
+    for i in range(n):
+        pose = synth.trajectory_pose(i * stride, total)
+        out.append((synth.render_room_depth(pose, W, H, noise_frame=i), pose))
+    return out
+
+
+def test_slab_partition_matches_one_gpu():
+    """configs[4] in miniature: the block space cut into 3 slabs along x, three fusers see every frame and fuse only their
+    slab, boundary layers are exchanged as ghost blocks, the slab meshes concatenate into the one-fuser mesh byte for byte."""
+    from scannet_amd import fusion, partition
+    W, H = 320, 240
+    fx, fy, mx, my = synth.intrinsics(W, H)
+    gp = fusion.default_params(depth_width=W, depth_height=H, fx=fx, fy=fy, mx=mx, my=my, voxel_size=0.01, num_sdf_blocks=1 << 17)
+    frames = _room_frames(24, W, H, 1200, stride=40)
+    with fusion.Fuser(gp) as whole:
+        for d, pose in frames:
+            whole.integrate(d, pose)
+        ref = whole.extract_mesh().arrays(keys=True)
+        wc, wv = whole.export_blocks()
+    world = 3
+    planes = partition.planes_from_poses([p for _, p in frames], gp.voxel_size, gp.max_integration_dist, world)
+    # the room spans x in [0, 6] m: put the inner planes inside it so that every slab owns surface
+    planes[1], planes[2] = int(2.0 / 0.08), int(4.0 / 0.08)
+    fusers = [fusion.Fuser(gp) for _ in range(world)]
+    try:
+        for r, f in enumerate(fusers):
+            f.set_slab(0, planes[r], planes[r + 1])
+            for d, pose in frames:
+                f.integrate(d, pose)
+        # the slabs partition the one-GPU block set, voxels bit-identical
+        owned = [f.export_blocks() for f in fusers]
+        assert sum(len(c) for c, _ in owned) == len(wc)
+        allc = np.concatenate([c for c, _ in owned]); allv = np.concatenate([v for _, v in owned])
+        order = np.lexsort((allc[:, 2], allc[:, 1], allc[:, 0]))
+        assert np.array_equal(allc[order], wc) and np.array_equal(allv[order].view(np.uint8), wv.view(np.uint8))
+        for r, (c, _) in enumerate(owned):
+            assert len(c) > 100 and c[:, 0].min() >= planes[r] and c[:, 0].max() < planes[r + 1]
+        # boundary exchange (in-process stand-in for the all-gather), then mesh per slab
+        layers = [f.export_blocks_where(0, planes[r], planes[r] + 1) if r > 0 else (np.zeros((0, 3), np.int32), np.zeros((0, 512), fusion.VOXEL_DTYPE))
+                  for r, f in enumerate(fusers)]
+        gather = lambda c, v: ([l[0] for l in layers], [l[1] for l in layers])
+        sent_got = [partition.exchange_boundary_layers(f, planes, r, gather=gather) for r, f in enumerate(fusers)]
+        assert sent_got[0][1] > 0 and sent_got[1][1] > 0 and sent_got[2][1] == 0 and sent_got[1][0] == sent_got[0][1]
+        for f, (c, _) in zip(fusers, owned):   # ghosts are not exported as owned blocks, not fused, not garbage-collected
+            assert len(f.export_blocks_where(-1, 0, 0)[0]) == len(c)
+        parts = [f.extract_mesh().arrays(keys=True) for f in fusers]
+        xyz, rgba, tris, keys = partition.merge_slab_meshes(parts)
+        assert np.array_equal(keys, ref[3]) and np.array_equal(xyz.view(np.uint32), ref[0].view(np.uint32))
+        assert np.array_equal(rgba, ref[1]) and np.array_equal(tris, ref[2])
+        # another frame after the exchange: ghosts stay untouched, owned blocks keep matching
+        d, pose = frames[3]
+        for f in fusers:
+            f.integrate(d, pose)
+        g0 = fusers[0].export_blocks_where(0, planes[1], planes[1] + 1, include_ghosts=True)
+        assert np.array_equal(g0[1].view(np.uint8), layers[1][1].view(np.uint8))
+    finally:
+        for f in fusers:
+            f.close()

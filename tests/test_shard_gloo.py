@@ -1,0 +1,132 @@
+"""Multi-process paths on CPU (gloo, world size 2): the scan-per-GPU work queue of scannet_amd/shard.py and the host
+logic of the slab partition (scannet_amd/partition.py).  No GPU: the per-scan / per-slab work is injected."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker_queue(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from scannet_amd import shard
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    costs = [5, 90, 17, 17, 300, 1, 42, 8, 8, 64, 3]
+    items = ["scan%02d" % i for i in range(len(costs))]
+    seen = []
+
+    def work(item):
+        seen.append(item)
+        return costs[items.index(item)]
+
+    done = shard.run_sharded(items, costs, work)
+    # a second pass over the same list needs its own counter key
+    done2 = shard.run_sharded(items, costs, work, key="scanfuse/queue/pass2")
+    np.save(os.path.join(out_dir, "r%d.npy" % rank), np.array([i for i, _ in done] + [-1] + [i for i, _ in done2]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_work_queue_two_ranks(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker_queue, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    per_rank = [np.load(str(tmp_path / ("r%d.npy" % r))).tolist() for r in range(2)]
+    for which in (0, 1):
+        got = []
+        for lst in per_rank:
+            cut = lst.index(-1)
+            got.append(lst[:cut] if which == 0 else lst[cut + 1:])
+        allidx = sorted(got[0] + got[1])
+        assert allidx == list(range(11)), "every scan exactly once"
+        # within a rank the popped positions follow the longest-first order
+        from scannet_amd import shard
+        order = shard.order_longest_first([5, 90, 17, 17, 300, 1, 42, 8, 8, 64, 3])
+        for lst in got:
+            pos = [order.index(i) for i in lst]
+            assert pos == sorted(pos)
+
+
+def test_queue_without_process_group_and_static_lpt():
+    from scannet_amd import shard
+    costs = [5, 90, 17, 17, 300, 1, 42]
+    assert shard.order_longest_first(costs) == [4, 1, 6, 2, 3, 0, 5]
+    done = shard.run_sharded(list("abcdefg"), costs, lambda s: s.upper())
+    assert [i for i, _ in done] == [4, 1, 6, 2, 3, 0, 5] and done[0][1] == "E"
+    parts = shard.static_lpt(costs, 3)
+    assert sorted(sum(parts, [])) == list(range(7))
+    loads = [sum(costs[i] for i in p) for p in parts]
+    assert max(loads) == 300 and parts[0] == [4]
+
+
+def _worker_gather(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from scannet_amd import partition
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    rng = np.random.default_rng(100 + rank)
+    n = [0, 37][rank]                      # rank 0 (lowest slab) sends nothing
+    coords = rng.integers(-50, 50, (n, 3)).astype(np.int32)
+    vox = rng.integers(0, 256, (n, 4096), dtype=np.uint8)
+    all_c = partition._all_gather_ragged(coords)
+    all_v = partition._all_gather_ragged(vox)
+    assert [len(c) for c in all_c] == [0, 37] and all_v[1].shape == (37, 4096)
+    np.save(os.path.join(out_dir, "g%d.npy" % rank), np.concatenate([all_c[1].ravel(), all_v[1].ravel().astype(np.int32)]))
+
+    class FakeFuser:                        # the host logic of the exchange without a GPU
+        def __init__(self):
+            self.imported = None
+
+        def export_blocks_where(self, axis, lo, hi):
+            assert axis == 0 and hi == lo + 1
+            c = coords.copy()
+            c[:, 0] = lo
+            return c, vox
+
+        def import_blocks(self, c, v, ghost=True):
+            self.imported = (c.copy(), v.copy(), ghost)
+
+    f = FakeFuser()
+    planes = [-1000, 7, 1000]
+    sent, got = partition.exchange_boundary_layers(f, planes, rank)
+    if rank == 0:
+        assert sent == 0 and got == 37 and f.imported[2] is True and (f.imported[0][:, 0] == 7).all()
+    else:
+        assert sent == 37 and got == 0 and f.imported is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_boundary_all_gather_two_ranks(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker_gather, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(str(tmp_path / "g0.npy")), np.load(str(tmp_path / "g1.npy"))
+    assert np.array_equal(a, b) and len(a) == 37 * 3 + 37 * 4096
+
+
+def test_slab_planes_and_mesh_merge():
+    from scannet_amd import partition
+    p = partition.slab_planes(-40, 40, 4)
+    assert p[1:-1] == [-20, 0, 20] and p[0] < -(1 << 19) and p[-1] > (1 << 19)
+    poses = np.tile(np.eye(4, dtype=np.float32), (5, 1, 1))
+    poses[:, 0, 3] = [0.0, 1.0, 2.0, 3.0, -np.inf]
+    q = partition.planes_from_poses(poses, 0.004, 4.0, 2)
+    assert q[1] == int(round((np.floor(-4.0 / 0.032) + np.ceil(7.0 / 0.032)) / 2))
+    # two slab meshes sharing two boundary vertices (keys 20, 30)
+    a = (np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0]], np.float32), np.full((3, 4), 1, np.uint8), np.array([[0, 1, 2]], np.uint32), np.array([10, 20, 30], np.uint64))
+    b = (np.array([[1, 0, 0], [1, 1, 0], [2, 0, 0]], np.float32), np.full((3, 4), 2, np.uint8), np.array([[0, 2, 1]], np.uint32), np.array([20, 30, 40], np.uint64))
+    xyz, rgba, tris, keys = partition.merge_slab_meshes([a, b])
+    assert keys.tolist() == [10, 20, 30, 40] and tris.tolist() == [[0, 1, 2], [1, 3, 2]]
+    assert xyz.tolist() == [[0, 0, 0], [1, 0, 0], [1, 1, 0], [2, 0, 0]] and rgba[:, 0].tolist() == [1, 1, 1, 2]
