@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""End-to-end timing of the drop-in stage chain on one MI355X (numbers for DESIGN.md section 5; not bench.py's metric):
+.sens on disk -> threaded inflate -> pinned ring -> H2D -> fusion (PCIe-inclusive frames/s) -> marching cubes -> PLY ->
+clean -> Segmentator.  The stream is the config-2 walk rendered on the GPU, written with this repo's .sens writer.
+
+  python tools/e2e_bench.py [--frames 1500] [--voxel 0.004] [--threads 0] [--out gpurun_out/e2e.json]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from scannet_amd import _abi, fusion, meshclean, segmentator, sens, synth  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=1500)
+    ap.add_argument("--total", type=int, default=5578)
+    ap.add_argument("--voxel", type=float, default=0.004)
+    ap.add_argument("--blocks", type=int, default=1 << 20)
+    ap.add_argument("--buckets", type=int, default=1 << 19)
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--dir", default="/tmp/sf_e2e")
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    W, H = 640, 480
+    os.makedirs(a.dir, exist_ok=True)
+    path = os.path.join(a.dir, "scene_e2e.sens")
+    L = _abi.lib()
+    # render on the GPU, pull to the host, write a real .sens (zlib depth)
+    t0 = time.perf_counter()
+    nbytes = a.frames * W * H * 2
+    dptr = C.c_void_p()
+    _abi.check(L.sf_device_malloc(0, nbytes, C.byref(dptr)))
+    poses = np.zeros((a.frames, 16), np.float32)
+    _abi.check(L.sf_synth_room_device(dptr, W * H * 2, 0, a.frames, a.total, W, H, 1, poses.ctypes.data_as(C.c_void_p)))
+    depth = np.zeros((a.frames, H, W), np.uint16)
+    _abi.check(L.sf_device_download(depth.ctypes.data_as(C.c_void_p), dptr, nbytes))
+    L.sf_device_free(dptr)
+    K = synth.intrinsic_matrix(W, H)
+    sd = sens.SensorData.create(0, 0, W, H, K, K, color_compression=0, depth_compression=1, sensor_name="StructureSensor")
+    for i in range(a.frames):
+        sd.add_frame(depth[i], poses[i].reshape(4, 4), timestamp_depth=33333 * i)
+    sd.save(path)
+    sd.close()
+    t_write = time.perf_counter() - t0
+    res = {"frames": a.frames, "sens_bytes": os.path.getsize(path), "write_s": round(t_write, 2), "voxel": a.voxel, "host_cores": os.cpu_count()}
+
+    fx, fy, mx, my = synth.intrinsics(W, H)
+    gp = fusion.default_params(depth_width=W, depth_height=H, fx=fx, fy=fy, mx=mx, my=my, voxel_size=a.voxel, num_sdf_blocks=a.blocks,
+                               hash_num_buckets=a.buckets)
+    sd = sens.SensorData(path)
+    with fusion.Fuser(gp) as f:
+        rs = f.run(sd, decode_threads=a.threads)
+        st = f.stats()
+        res["fuse"] = {"frames_per_s_end_to_end": round(rs["frames_total"] / rs["seconds_total"], 1), "seconds": round(rs["seconds_total"], 3),
+                       "decode_threads": rs["decode_threads"], "decode_cpu_s": round(rs["seconds_decode_cpu"], 2),
+                       "decode_ms_per_frame_per_thread": round(1e3 * rs["seconds_decode_cpu"] / max(rs["frames_total"], 1), 3),
+                       "blocks": st["blocks_allocated"], "alloc_failures": st["alloc_failures"],
+                       "voxel_tiles_GB": round(st["blocks_allocated"] * 4096 / 1e9, 2)}
+        t0 = time.perf_counter()
+        mesh = f.extract_mesh()
+        res["marching_cubes_s"] = round(time.perf_counter() - t0, 3)
+    nv, nf = mesh.counts()
+    res["mesh"] = {"vertices": nv, "faces": nf}
+    ply = os.path.join(a.dir, "scene_e2e_vh.ply")
+    t0 = time.perf_counter()
+    mesh.write_ply(ply)
+    res["ply_write_s"] = round(time.perf_counter() - t0, 3)
+    t0 = time.perf_counter()
+    cleaned, cst = meshclean.clean(mesh)
+    res["clean_s"] = round(time.perf_counter() - t0, 3)
+    res["clean"] = {k: cst[k] for k in ("vertices_out", "faces_out", "components_in", "components_removed")}
+    cply = os.path.join(a.dir, "scene_e2e_vh_clean.ply")
+    cleaned.write_ply(cply)
+    t0 = time.perf_counter()
+    nseg = segmentator.segment_to_json(cply)
+    res["segment_s"] = round(time.perf_counter() - t0, 3)
+    res["segments"] = nseg
+    ref = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "segmentator_ref")
+    if os.path.exists(ref):
+        import subprocess
+        t0 = time.perf_counter()
+        subprocess.run([ref, cply], capture_output=True)
+        res["segment_reference_binary_s"] = round(time.perf_counter() - t0, 3)
+    print(json.dumps(res))
+    if a.out:
+        open(a.out, "w").write(json.dumps(res, indent=1) + "\n")
+
+
+if __name__ == "__main__":
+    main()
