@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes that measure roofline.traffic")
     ap.add_argument("--pmc-steps", type=int, default=400)
     ap.add_argument("--single-frame", action="store_true", help="one frame per launch (SF_BATCH=1) for the main measurement")
+    ap.add_argument("--no-single-frame", action="store_true", help="skip the secondary one-frame-per-launch roofline pass")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -214,7 +215,7 @@ def main():
             if t is not None:
                 roof["traffic"] = t["bytes"]
                 roof["traffic_detail"] = t
-        if world == 1 and not args.no_profile and not args.single_frame and K > 1:
+        if world == 1 and not args.no_profile and not args.single_frame and not args.no_single_frame and K > 1:
             # the same kernel HBM-bound: one frame per launch (what sf_fuser_integrate does for a live stream)
             ks = min(K, 1200)
             m1 = run(Wm, ks, True, single_frame=True)

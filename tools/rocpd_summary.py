@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 rocpd (.db) result: per-kernel time statistics and, when present, PMC counter sums.
 
-  python tools/rocpd_summary.py gpurun_out/prof/kt/kt_results.db [more.db ...] > profiles/rNN_summary.txt
+  python tools/rocpd_summary.py [--tail KERNEL N] gpurun_out/prof/kt/kt_results.db [more.db ...] > profiles/rNN_summary.txt
 """
 import sqlite3
 import sys
@@ -39,9 +39,41 @@ def pmc_stats(db):
             print("%-72s %-14s %8d %16.1f %14.2f" % (k[:72], c, n, s, a))
 
 
-for path in sys.argv[1:]:
+def tail_stats(db, kernel, n):
+    """Average duration of the LAST n dispatches of a kernel (the timed region of bench.py: warm-up launches come first)."""
+    rows = [d for (d,) in db.execute("select end-start from kernels where name like ? order by start", ("%" + kernel + "%",))]
+    if len(rows) >= n > 0:
+        t = rows[-n:]
+        print("last %d dispatches of %s: avg %.2f us, total %.1f us (all %d dispatches: avg %.2f us)" %
+              (n, kernel, sum(t) / n / 1e3, sum(t) / 1e3, len(rows), sum(rows) / len(rows) / 1e3))
+
+
+def slice_stats(db, kernel, start, count):
+    """Average duration of dispatches [start, start + count) of a kernel, in launch order."""
+    rows = [d for (d,) in db.execute("select end-start from kernels where name like ? order by start", ("%" + kernel + "%",))]
+    t = rows[start:start + count]
+    if t:
+        print("dispatches %d..%d of %s: avg %.2f us, total %.1f us" % (start, start + len(t) - 1, kernel, sum(t) / len(t) / 1e3, sum(t) / 1e3))
+
+
+args = sys.argv[1:]
+slices = []
+while "--slice" in args:
+    i = args.index("--slice")
+    slices.append((args[i + 1], int(args[i + 2]), int(args[i + 3])))
+    del args[i:i + 4]
+tails = []
+while "--tail" in args:
+    i = args.index("--tail")
+    tails.append((args[i + 1], int(args[i + 2])))
+    del args[i:i + 3]
+for path in args:
     print("== %s" % path)
     db = sqlite3.connect(path)
     kernel_stats(db)
+    for k, n in tails:
+        tail_stats(db, k, n)
+    for k, a, c in slices:
+        slice_stats(db, k, a, c)
     pmc_stats(db)
     print()
