@@ -228,7 +228,7 @@ def main():
                         r1["traffic"] = t["bytes"]
                         r1["traffic_detail"] = t
                 out["roofline_single_frame"] = r1
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
             ns = min(96, n_frames)
             out["cpu_baseline"] = cpu_baseline(frames[:ns].cpu().numpy().view(np.uint16), poses[:ns].reshape(-1, 4, 4))
         print(json.dumps(out))

@@ -278,6 +278,11 @@ int sf_segment_file_ex(const char* mesh_path, float kThresh, int segMinVerts, co
 int sf_synth_room_device(void* d_depth, uint64_t frame_stride_bytes, uint64_t first_frame, uint64_t n, uint64_t total_frames,
                          int width, int height, int noise, float* poses_out);
 
+/* Device self-test: the hand-expanded correctly rounded divisions of the integrate kernel against the hardware's IEEE
+ * division -- all 2^23 mantissas x 9 exponents for 1/x, 511 integer divisors x 2^21 numerators for n/m.  Both counts
+ * must be 0 (tests/test_gpu_tsdf.py). */
+int sf_selftest_division(int device, uint64_t* recip_mismatches, uint64_t* quot_mismatches);
+
 /* PMC calibration stream (tools/pmc_calibrate.py): known-byte-count 16 B/lane RMW + read-only launches. */
 int sf_calib_stream(int device, uint64_t bytes, int iters);
 

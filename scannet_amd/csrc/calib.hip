@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include "common.h"
+#include "fuser_internal.h"
 
 namespace {
 __global__ __launch_bounds__(256) void k_calib_rmw(uint4* __restrict__ buf, size_t n16) {
@@ -37,5 +38,61 @@ SF_API int sf_calib_stream(int device, uint64_t bytes, int iters) {
   SF_HIP_CHECK(hipDeviceSynchronize());
   (void)hipFree(buf);
   (void)hipFree(sink);
+  return SF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Device self-test of the hand-expanded divisions (fuser_internal.h) against the hardware's IEEE division:
+//   recip: every one of the 2^23 mantissas at 9 exponents spanning 2^-20 .. 2^20 (camera-space depths in metres),
+//   quot : every integer divisor 1..511 against 2^20 numerators each (counter-based bit patterns with exponents in the
+//          TSDF range, plus exact multiples and their neighbours: the near-halfway quotients).
+// Returns the number of lanes whose result differs in any bit (expected: 0 and 0).
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void k_selftest_recip(unsigned long long* bad) {
+  const uint32_t mant = blockIdx.x * 256 + threadIdx.x;  // 2^23 threads
+  const uint32_t expo[9] = {107, 117, 122, 126, 127, 128, 132, 137, 147};
+  unsigned int n = 0;
+  for (int e = 0; e < 9; e += 2) {
+    const float b0 = __uint_as_float((expo[e] << 23) | mant), b1 = __uint_as_float((expo[(e + 1) % 9] << 23) | mant);
+    const v2f r = recip_rn((v2f){b0, b1});
+    n += __float_as_uint(r.x) != __float_as_uint(1.0f / b0);
+    n += __float_as_uint(r.y) != __float_as_uint(1.0f / b1);
+  }
+  if (n) atomicAdd(bad, (unsigned long long)n);
+}
+__global__ __launch_bounds__(256) void k_selftest_quot(unsigned long long* bad) {
+  const uint32_t m_int = blockIdx.y + 1;  // 1..511
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;  // 2^20 numerators per divisor
+  const float m = (float)m_int, r = 1.0f / m;
+  uint64_t x = ((uint64_t)m_int << 32 | i) * 0x9E3779B97F4A7C15ull;
+  x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+  float n0, n1;
+  {
+    const uint32_t e = 100u + (uint32_t)(x >> 58);  // 2^-27 .. 2^36
+    n0 = __uint_as_float(((uint32_t)x & 0x807FFFFFu) | (e << 23));
+    const float qf = __uint_as_float(0x3F800000u | ((uint32_t)(x >> 24) & 0x7FFFFFu));  // quotient near 1..2
+    n1 = __uint_as_float(__float_as_uint(qf * m) + ((uint32_t)(x >> 50) & 7u) - 3u);    // a multiple of m, +-3 ulp
+  }
+  const v2f q = quot_rn((v2f){n0, n1}, splat(m), splat(r));
+  unsigned int n = (__float_as_uint(q.x) != __float_as_uint(n0 / m)) + (__float_as_uint(q.y) != __float_as_uint(n1 / m));
+  if (n) atomicAdd(bad, (unsigned long long)n);
+}
+}  // namespace
+
+SF_API int sf_selftest_division(int device, uint64_t* recip_mismatches, uint64_t* quot_mismatches) {
+  if (!recip_mismatches || !quot_mismatches) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  SF_HIP_CHECK(hipSetDevice(device));
+  unsigned long long* d = nullptr;
+  SF_HIP_CHECK(hipMalloc((void**)&d, 16));
+  SF_HIP_CHECK(hipMemset(d, 0, 16));
+  hipLaunchKernelGGL(k_selftest_recip, dim3((1u << 23) / 256), dim3(256), 0, nullptr, d);
+  hipLaunchKernelGGL(k_selftest_quot, dim3((1u << 20) / 256, 511), dim3(256), 0, nullptr, d + 1);
+  unsigned long long h[2] = {0, 0};
+  const hipError_t e = hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return sf::fail(SF_ERR_DEVICE, "self-test failed: %s", hipGetErrorString(e));
+  *recip_mismatches = h[0];
+  *quot_mismatches = h[1];
   return SF_OK;
 }

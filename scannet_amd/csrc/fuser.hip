@@ -472,15 +472,7 @@ __global__ __launch_bounds__(256) void k_compactify(const uint64_t* __restrict__
 //     yields the correctly rounded quotient (same tool: 1.4e9 cases incl. near-halfway); numerators below 2^-100
 //     take the plain division so that underflow cannot bite.
 // Every value stored is bit-identical to oracle/tsdf_oracle.c fuse_block.
-typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ inline v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ inline v2f splat(float x) { return (v2f){x, x}; }
-__device__ inline v2f recip_rn(v2f b) {
-  v2f r = {__builtin_amdgcn_rcpf(b.x), __builtin_amdgcn_rcpf(b.y)};
-  const v2f one = splat(1.0f);
-  r = pk_fma(pk_fma(-b, r, one), r, r);
-  return pk_fma(pk_fma(-b, r, one), r, r);
-}
+// (v2f, pk_fma, splat, recip_rn, quot_rn live in fuser_internal.h: the device self-test in calib.hip runs the same code)
 
 constexpr int RTAB = 512;  // LDS table of correctly rounded 1/m, m = weight + weight_sample < 512
 
@@ -566,8 +558,7 @@ __device__ inline void fuse_rows(const ParamsK& P, const float* __restrict__ Ti,
       const v2f n = pk_fma(old, wo, WS1 ? sdf : sdf * splat(wn));  // x * 1.0f == x bit for bit
       const v2f m = wo + splat(wn);
       if (TAB) {
-        const v2f q0 = n * rcp_m[j];
-        q[j] = pk_fma(pk_fma(-m, q0, n), rcp_m[j], q0);
+        q[j] = quot_rn(n, m, rcp_m[j]);
         slow = slow || (fabsf(n.x) < 0x1p-100f) || (fabsf(n.y) < 0x1p-100f);
       } else {
         q[j] = (v2f){n.x / m.x, n.y / m.y};
@@ -627,7 +618,8 @@ template <int SIGN, bool COLOR, bool TAB, bool WS1>
 __global__ __launch_bounds__(256, 4) void k_integrate(uint4* __restrict__ voxels, const uint64_t* __restrict__ block_keys,
                                                    const int32_t* __restrict__ compact, const uint32_t* __restrict__ cmask,
                                                    const float* __restrict__ depthf_all, const uint32_t* __restrict__ color_all,
-                                                   int32_t* counters, int32_t* host_mirror, int compact_counter, ParamsK P, BatchTi B) {
+                                                   int32_t* counters, int32_t* host_mirror, int compact_counter, int xcd_walk, ParamsK P,
+                                                   BatchTi B) {
   __shared__ float s_rtab[RTAB];  // correctly rounded 1/m for the weighted-mean division (fuse_tile)
   if (TAB) {
     for (int i = threadIdx.x; i < RTAB; i += 256) s_rtab[i] = 1.0f / (float)(i > 0 ? i : 1);
@@ -644,7 +636,18 @@ __global__ __launch_bounds__(256, 4) void k_integrate(uint4* __restrict__ voxels
   const int ly = (lane >> 2) & 7;
   const int lzb = lane >> 5;
   const size_t npx = (size_t)P.W * P.H;
-  for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {
+  // XCD-aware walk of the list: workgroup b runs on XCD b % 8 (observed placement; a speed hint only, any placement is
+  // correct).  Each XCD takes ONE contiguous eighth of the list -- neighbouring list entries are neighbouring blocks
+  // that gather neighbouring depth pixels, so an XCD's 4 MiB L2 holds its own part of the batch's depth images instead
+  // of all eight L2s each cycling through all 16 x 1.2 MB.  xcd_walk == 0: plain grid-stride order.
+  const int wg_total = (n + 3) >> 2;                         // workgroups' worth of list entries
+  const int chunk = xcd_walk ? (wg_total + 7) >> 3 : wg_total;
+  const int lanes = xcd_walk ? 8 : 1;                        // interleaved sub-grids
+  const int sub = xcd_walk ? (int)(blockIdx.x & 7) : 0;
+  const int per_sub = max(1, (int)gridDim.x / lanes);
+  for (int loc = xcd_walk ? (int)(blockIdx.x >> 3) : (int)blockIdx.x; loc < chunk; loc += per_sub) {
+    const int i = ((sub * chunk + loc) << 2) + wave;
+    if (i >= n) continue;
     const int slot = compact[i];
     uint32_t frames = (uint32_t)__builtin_amdgcn_readfirstlane((int)cmask[i]);  // wave-uniform: the frame loop runs on the scalar unit
     int bx, by, bz;
@@ -898,6 +901,7 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
   int grid = (est + 3) / 4;
   const int grid_max = f->num_cus * 64;
   if (grid > grid_max) grid = grid_max;
+  grid = (grid + 7) & ~7;  // whole sub-grids for the XCD-aware walk
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (f->profile) {
     if (f->events_used == f->events.size()) {
@@ -912,7 +916,7 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
   }
 #define LAUNCH_INT(SG, CL, TB, W1)                                                                                                        \
   hipLaunchKernelGGL((k_integrate<SG, CL, TB, W1>), dim3(grid), dim3(256), 0, s, f->voxels, f->block_keys, f->compact2[sl], f->cmask2[sl], \
-                     f->depthf2[sl], f->color2[sl], f->counters, f->host_mirror, cc, f->pk, bt)
+                     f->depthf2[sl], f->color2[sl], f->counters, f->host_mirror, cc, f->xcd_walk ? 1 : 0, f->pk, bt)
   const bool tab = f->p.weight_sample >= 1 && f->p.weight_sample <= RTAB - 256;  // the LDS reciprocal table covers weight + sample < 512
   if (sign > 0) {
     if (f->p.weight_sample == 1) { if (col) LAUNCH_INT(1, true, true, true); else LAUNCH_INT(1, false, true, true); }  // the shipped setting
@@ -967,6 +971,7 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
   if (f->p.weight_max > 255) f->p.weight_max = 255;  // uchar weight saturates (SURVEY App. C decision)
   if (f->p.weight_max < 1) f->p.weight_max = 1;
   f->device = device;
+  if (const char* e = getenv("SF_NO_XCD")) f->xcd_walk = atoi(e) == 0;
   if (const char* e = getenv("SF_ALLOC_GROUP")) { f->alloc_group = atoi(e); if (f->alloc_group < 1) f->alloc_group = 1; }
   {
     // longest ray segment 2 * trunc(max distance) in blocks decides the LDS window size of k_alloc

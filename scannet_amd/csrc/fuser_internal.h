@@ -105,6 +105,25 @@ __device__ inline int hash_lookup(const HashEntry* __restrict__ table, const Par
   return -1;
 }
 
+#ifdef __HIPCC__
+// Packed fp32 helpers and the two hand-expanded, correctly rounded divisions of k_integrate.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ inline v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ inline v2f splat(float x) { return (v2f){x, x}; }
+// RN(1 / b) for normal-range b: v_rcp_f32 seed (1 ulp) + two Newton steps
+__device__ inline v2f recip_rn(v2f b) {
+  v2f r = {__builtin_amdgcn_rcpf(b.x), __builtin_amdgcn_rcpf(b.y)};
+  const v2f one = splat(1.0f);
+  r = pk_fma(pk_fma(-b, r, one), r, r);
+  return pk_fma(pk_fma(-b, r, one), r, r);
+}
+// RN(n / m) given r = RN(1 / m): one Markstein correction (|n| >= 2^-100, m a small integer)
+__device__ inline v2f quot_rn(v2f n, v2f m, v2f r) {
+  const v2f q0 = n * r;
+  return pk_fma(pk_fma(-m, q0, n), r, q0);
+}
+#endif
+
 struct sf_fuser {
   sf_params p;
   ParamsK pk;
@@ -134,6 +153,7 @@ struct sf_fuser {
   int32_t* host_mirror = nullptr;  // pinned, device-visible: N_blk of the most recent integrate
   int num_cus = 256;
   bool alloc_win64 = false;  // 64^3-block LDS window when a ray segment spans more than ~20 blocks
+  bool xcd_walk = true;  // k_integrate: each XCD walks one contiguous eighth of the list (SF_NO_XCD=1: plain grid-stride)
   int alloc_group = 4;  // consecutive frames of a batch one k_alloc workgroup walks (SF_ALLOC_GROUP)
   int compact_grid = 1024;  // 1024 directory entries per workgroup, grid-stride beyond
   uint64_t frames_integrated = 0, frames_skipped = 0;

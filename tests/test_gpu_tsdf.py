@@ -256,3 +256,16 @@ def test_marching_cubes_plane_full_size(oracle):
         gm = _assert_same_mesh(ovol, f)
         xyz, _, _ = gm.arrays()
         assert np.abs(xyz[:, 2] - 2.0).max() < 1e-6
+
+
+def test_hand_expanded_divisions_on_device():
+    """k_integrate expands its two IEEE divisions by hand (rcp + Newton; table reciprocal + Markstein correction).  On the
+    device itself: identical bits to the hardware division for every mantissa / every divisor (tools/check_division.c is
+    the CPU-side proof sketch; this closes the loop on the real v_rcp_f32)."""
+    import ctypes as C
+    from scannet_amd import _abi
+    L = _abi.lib()
+    a, b = C.c_uint64(1), C.c_uint64(1)
+    L.sf_selftest_division.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    _abi.check(L.sf_selftest_division(0, C.byref(a), C.byref(b)))
+    assert (a.value, b.value) == (0, 0)
