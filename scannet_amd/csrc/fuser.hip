@@ -114,8 +114,8 @@ __global__ __launch_bounds__(256) void k_prepass(BatchIn in, float* __restrict__
 // The allocated SET and every block's birth frame are deterministic (no insertion ever gives up, so no fix-point
 // iteration as upstream); which heap slot a block lands in is not (neither is it upstream).
 // ---------------------------------------------------------------------------------------------------
-constexpr int ALLOC_SET = 1024;       // LDS hash-set slots per workgroup (8 KiB): blocks outside the window
-constexpr int ALLOC_LIST = 1024;      // queue of (key, frame) for phase 2 (8 KiB + 1 KiB)
+constexpr int ALLOC_SET = 256;        // LDS hash-set slots per workgroup (2 KiB): blocks outside the window
+constexpr int ALLOC_LIST = 512;       // queue of (key, frame) for phase 2 (4 KiB + 0.5 KiB); 14.5 KiB LDS per workgroup in all => 8 workgroups per CU
 constexpr int ALLOC_SET_PROBES = 32;
 
 struct HashRefs {
@@ -205,24 +205,27 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_
     }
   };
 
+  const bool in_image = x < P.W && y < P.H;
+  const float kx = ((float)x - P.mx) / P.fx, ky = ((float)y - P.my) / P.fy;  // the pixel's ray direction is the same for every frame
+  float d_next = in_image && j_begin < j_end ? depthf_all[(size_t)j_begin * npx + (size_t)(y * P.W + x)] : -INFINITY;
   for (int j = j_begin; j < j_end; ++j) {
     const FrameK& F = B.f[j];  // uniform index: scalar loads from the kernarg segment
-    const float* __restrict__ depthf = depthf_all + (size_t)j * npx;
+    const float d_cur = d_next;
+    // the next frame's depth is requested now and lands while this frame's rays are walked
+    d_next = in_image && j + 1 < j_end ? depthf_all[(size_t)(j + 1) * npx + (size_t)(y * P.W + x)] : -INFINITY;
     for (int i = threadIdx.x; i < WIN_WORDS; i += 256) s_frame[i] = 0u;
 
     // ---- ray set-up
     bool active = false;
     int a_cx = 0, a_cy = 0, a_cz = 0, a_sx = 0, a_sy = 0, a_sz = 0, a_ex = 0, a_ey = 0, a_ez = 0;
     float a_tmx = INFINITY, a_tmy = INFINITY, a_tmz = INFINITY, a_tdx = INFINITY, a_tdy = INFINITY, a_tdz = INFINITY;
-    if (x < P.W && y < P.H) {
-      const float d = depthf[y * P.W + x];
+    if (in_image) {
+      const float d = d_cur;
       if (d != -INFINITY && d < P.maxd) {
         const float t = fmaf(P.tscale, d, P.tbase);
         const float lo = fminf(P.maxd, d - t);
         const float hi = fminf(P.maxd, d + t);
         if (lo < hi) {
-          const float kx = ((float)x - P.mx) / P.fx;
-          const float ky = ((float)y - P.my) / P.fy;
           float p0[3], p1[3];
           {
             const float ax = kx * lo, ay = ky * lo, az = lo;
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_
           if (key != last_key) {
             last_key = key;
             if (slab_owns(P, a_cx, a_cy, a_cz) && block_in_frustum(P, F, a_cx, a_cy, a_cz)) {
-              uint32_t sl = ((uint32_t)(key ^ (key >> 21) ^ (key >> 42)) * 2654435761u) >> 22;  // 10 bits
+              uint32_t sl = ((uint32_t)(key ^ (key >> 21) ^ (key >> 42)) * 2654435761u) >> 24;  // 8 bits
               bool placed = false;
               for (int pr = 0; pr < ALLOC_SET_PROBES; ++pr) {
                 const unsigned long long old = atomicCAS(&s_keys[sl], (unsigned long long)KEY_EMPTY, (unsigned long long)key);
