@@ -52,6 +52,12 @@ typedef struct sf_params {
   uint32_t num_sdf_blocks;             /* s_hashNumSDFBlocks                (:57)                 */
   uint32_t mc_max_triangles;           /* s_marchingCubesMaxNumTriangles (:106); 0 = unlimited    */
   int32_t gc_enabled;                  /* s_garbageCollectionEnabled        (:83)                 */
+  /* Colour frames at their own resolution (real ScanNet scans: 1296x968 colour, 640x480 depth, sensorData.h:1269-1272).
+   * color_width == 0: rgb buffers are depth_width x depth_height.  Otherwise rgb buffers are color_width x color_height
+   * and every depth pixel (x, y) takes the colour pixel under the same ray: u = (x - mx) / fx * cfx + cmx (nearest),
+   * black outside the colour image -- depth and colour share the extrinsics in ScanNet's .sens files. */
+  int32_t color_width, color_height;
+  float cfx, cfy, cmx, cmy;            /* colour intrinsics (m_calibrationColor, sensorData.h:1264) */
 } sf_params;
 
 /* SURVEY 8d camera + zParametersScanNet.txt values with BASELINE.json's 4 mm / 2^19-bucket overrides */

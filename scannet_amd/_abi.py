@@ -18,6 +18,8 @@ class SfParams(C.Structure):
         ("mc_thresh_factor", C.c_float),
         ("hash_num_buckets", C.c_uint32), ("hash_bucket_size", C.c_uint32), ("num_sdf_blocks", C.c_uint32),
         ("mc_max_triangles", C.c_uint32), ("gc_enabled", C.c_int32),
+        ("color_width", C.c_int32), ("color_height", C.c_int32),
+        ("cfx", C.c_float), ("cfy", C.c_float), ("cmx", C.c_float), ("cmy", C.c_float),
     ]
 
 

@@ -55,7 +55,7 @@ __device__ inline int world_to_block(float w, float voxel) {
 // of the batch (every frame of a batch is converted by ONE launch).
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_prepass(BatchIn in, float* __restrict__ depthf_all, uint32_t* __restrict__ color_all, int n,
-                                                 float shift, float dmin, float dmax, int32_t* counters, int compact_counter) {
+                                                 float shift, float dmin, float dmax, int32_t* counters, int compact_counter, ParamsK P) {
   const int j = blockIdx.y;  // frame of the batch
   const uint16_t* __restrict__ depth = in.depth[j];
   const uint8_t* __restrict__ rgb = in.rgb[j];
@@ -90,6 +90,14 @@ __global__ __launch_bounds__(256) void k_prepass(BatchIn in, float* __restrict__
   if (rgb) {
     for (int k = 0; k < 8 && i0 + k < n; k++) {
       const uint8_t* c = rgb + 3 * (size_t)(i0 + k);
+      if (P.cW > 0) {
+        // colour image at its own resolution: the colour pixel under the depth pixel's ray (nearest), black outside
+        const int x = (i0 + k) % P.W, y = (i0 + k) / P.W;
+        const float u = fmaf(((float)x - P.mx) / P.fx, P.cfx, P.cmx) + 0.5f;
+        const float v = fmaf(((float)y - P.my) / P.fy, P.cfy, P.cmy) + 0.5f;
+        if (!(u >= 0.0f && u < (float)P.cW && v >= 0.0f && v < (float)P.cH)) { color[i0 + k] = 0u; continue; }
+        c = rgb + 3 * ((size_t)(int)v * (size_t)P.cW + (size_t)(int)u);
+      }
       color[i0 + k] = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
     }
   }
@@ -879,7 +887,7 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
   hipStream_t s = f->stream;
   if (f->overlap) (void)hipStreamWaitEvent(sa, f->ev_fused[sl], 0);
   hipLaunchKernelGGL(k_prepass, dim3((npx / 8 + 255) / 256 + 1, n), dim3(256), 0, sa, in, f->depthf2[sl], f->color2[sl], npx, f->p.depth_shift,
-                     f->p.depth_min, f->p.depth_max, f->counters, cc);
+                     f->p.depth_min, f->p.depth_max, f->counters, cc, f->pk);
   if (sign > 0) {
     // WIN 64 (32 KiB bitmap) has no room for the second bitmap: one frame per workgroup there
     const int gf = f->alloc_win64 ? 1 : std::min(f->alloc_group, n);
@@ -962,6 +970,8 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
   if (p->depth_width <= 0 || p->depth_height <= 0 || !(p->voxel_size > 0) || p->hash_num_buckets == 0 || p->hash_bucket_size == 0 ||
       p->num_sdf_blocks == 0 || !(p->fx > 0) || !(p->fy > 0) || !(p->depth_shift > 0))
     return sf::fail(SF_ERR_INVALID_ARG, "invalid reconstruction parameters");
+  if (p->color_width > 0 && p->color_height > 0 && !(p->cfx > 0 && p->cfy > 0))
+    return sf::fail(SF_ERR_INVALID_ARG, "colour resolution given without colour intrinsics");
   if ((uint64_t)p->hash_num_buckets * p->hash_bucket_size > 0x7FFFFFFFull || p->num_sdf_blocks > 0x3FFFFFFFu)
     return sf::fail(SF_ERR_INVALID_ARG, "hash table / heap too large for 32-bit slot indices");
   int ndev = 0;
@@ -989,6 +999,9 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
   k.num_buckets = p->hash_num_buckets; k.bucket_size = p->hash_bucket_size;
   k.total_slots = p->hash_num_buckets * p->hash_bucket_size; k.num_blocks = p->num_sdf_blocks;
   k.slab_axis = -1; k.slab_lo = 0; k.slab_hi = 0;
+  k.cW = p->color_width > 0 && p->color_height > 0 ? p->color_width : 0;
+  k.cH = k.cW ? p->color_height : 0;
+  k.cfx = p->cfx; k.cfy = p->cfy; k.cmx = p->cmx; k.cmy = p->cmy;
   hipDeviceProp_t prop;
   SF_HIP_CHECK(hipGetDeviceProperties(&prop, device));
   f->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -1033,7 +1046,7 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
   f->compact = f->compact2[0];
   SF_ALLOC(f->counters, C_COUNT * 4);
   SF_ALLOC(f->staging_depth, npx * 2);
-  SF_ALLOC(f->staging_rgb, npx * 3);
+  SF_ALLOC(f->staging_rgb, (k.cW ? (size_t)k.cW * k.cH : npx) * 3);
 #undef SF_ALLOC
   SF_HIP_CHECK(hipHostMalloc((void**)&f->host_mirror, 64, hipHostMallocMapped));
   *f->host_mirror = 0;
@@ -1074,7 +1087,7 @@ static int fuse_host(sf_fuser* f, const uint16_t* depth, const uint8_t* rgb, con
   SF_HIP_CHECK(sf_quiesce(f));
   hipStream_t in_stream = f->overlap ? f->front : f->stream;  // the stream the pre-pass reads the frame on
   SF_HIP_CHECK(hipMemcpyAsync(f->staging_depth, depth, npx * 2, hipMemcpyHostToDevice, in_stream));
-  if (rgb) SF_HIP_CHECK(hipMemcpyAsync(f->staging_rgb, rgb, npx * 3, hipMemcpyHostToDevice, in_stream));
+  if (rgb) SF_HIP_CHECK(hipMemcpyAsync(f->staging_rgb, rgb, (f->pk.cW ? (size_t)f->pk.cW * f->pk.cH : npx) * 3, hipMemcpyHostToDevice, in_stream));
   return run_frame(f, f->staging_depth, rgb ? f->staging_rgb : nullptr, pose, sign);
 }
 

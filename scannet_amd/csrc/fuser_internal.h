@@ -30,6 +30,9 @@ struct ParamsK {
   // slab partition of one large scan over several GPUs: this fuser only allocates blocks whose
   // coordinate on slab_axis lies in [slab_lo, slab_hi); slab_axis < 0 = no partition
   int slab_axis, slab_lo, slab_hi;
+  // colour frames at their own resolution (cW == 0: same as depth)
+  int cW, cH;
+  float cfx, cfy, cmx, cmy;
 };
 
 __host__ __device__ inline bool slab_owns(const ParamsK& P, int bx, int by, int bz) {

@@ -46,6 +46,8 @@ SF_API void sf_params_default(sf_params* p) {
   p->num_sdf_blocks = 1u << 20;                                        // 4 GiB of 4 KiB tiles; file value 600000 (:57)
   p->mc_max_triangles = 0;
   p->gc_enabled = 0;
+  p->color_width = 0; p->color_height = 0;
+  p->cfx = p->cfy = p->cmx = p->cmy = 0.0f;
 }
 
 namespace {

@@ -49,8 +49,12 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   const auto t_start = std::chrono::steady_clock::now();
   const size_t npx = (size_t)f->p.depth_width * f->p.depth_height;
   // colour is fused when it is stored at depth resolution (raw or JPEG); other resolutions: geometry only
-  const bool use_rgb = s->info.color_width == s->info.depth_width && s->info.color_height == s->info.depth_height &&
-                       (s->info.color_compression == 0 || s->info.color_compression == 2);
+  // colour is fused when its frames match what the fuser was created for: depth resolution, or the colour resolution
+  // given in sf_params (raw or JPEG); anything else: geometry only
+  const bool same_res = s->info.color_width == s->info.depth_width && s->info.color_height == s->info.depth_height;
+  const bool own_res = f->pk.cW > 0 && (int)s->info.color_width == f->pk.cW && (int)s->info.color_height == f->pk.cH;
+  const bool use_rgb = ((same_res && f->pk.cW == 0) || own_res) && (s->info.color_compression == 0 || s->info.color_compression == 2);
+  const size_t cpx = f->pk.cW > 0 ? (size_t)f->pk.cW * f->pk.cH : npx;
   int nthreads = decode_threads > 0 ? decode_threads : (int)std::thread::hardware_concurrency();
   if (nthreads < 1) nthreads = 1;
   if (nthreads > 64) nthreads = 64;
@@ -80,8 +84,8 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
     RUN_CHECK(hipHostMalloc((void**)&sl.h_depth, npx * 2, hipHostMallocDefault));
     RUN_CHECK(hipMalloc(&sl.d_depth, npx * 2));
     if (use_rgb) {
-      RUN_CHECK(hipHostMalloc((void**)&sl.h_rgb, npx * 3, hipHostMallocDefault));
-      RUN_CHECK(hipMalloc(&sl.d_rgb, npx * 3));
+      RUN_CHECK(hipHostMalloc((void**)&sl.h_rgb, cpx * 3, hipHostMallocDefault));
+      RUN_CHECK(hipMalloc(&sl.d_rgb, cpx * 3));
     }
     RUN_CHECK(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
     RUN_CHECK(hipEventCreateWithFlags(&sl.consumed, hipEventDisableTiming));
@@ -179,7 +183,7 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
       if (result == SF_OK) {
         if (sl.used) e = hipStreamWaitEvent(copy_stream, sl.consumed, 0);  // device buffer still read by an earlier pre-pass?
         if (e == hipSuccess) e = hipMemcpyAsync(sl.d_depth, sl.h_depth, npx * 2, hipMemcpyHostToDevice, copy_stream);
-        if (e == hipSuccess && rgb) e = hipMemcpyAsync(sl.d_rgb, sl.h_rgb, npx * 3, hipMemcpyHostToDevice, copy_stream);
+        if (e == hipSuccess && rgb) e = hipMemcpyAsync(sl.d_rgb, sl.h_rgb, cpx * 3, hipMemcpyHostToDevice, copy_stream);
         if (e == hipSuccess) e = hipEventRecord(sl.copied, copy_stream);
         if (e != hipSuccess) { result = SF_ERR_DEVICE; err = std::string("copy pipeline: ") + hipGetErrorString(e); }
       }

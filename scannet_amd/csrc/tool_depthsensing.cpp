@@ -40,6 +40,12 @@ int main(int argc, const char** argv) {
   p.depth_height = (int32_t)info.depth_height;
   p.fx = info.depth_intrinsic[0]; p.fy = info.depth_intrinsic[5]; p.mx = info.depth_intrinsic[2]; p.my = info.depth_intrinsic[6];
   p.depth_shift = info.depth_shift;
+  if ((info.color_width != info.depth_width || info.color_height != info.depth_height) && info.color_width > 0 && info.color_height > 0 &&
+      (info.color_compression == 0 || info.color_compression == 2) && info.color_intrinsic[0] > 0) {
+    // real ScanNet scans: 1296x968 colour over 640x480 depth -- sample the colour under each depth pixel's ray
+    p.color_width = (int32_t)info.color_width; p.color_height = (int32_t)info.color_height;
+    p.cfx = info.color_intrinsic[0]; p.cfy = info.color_intrinsic[5]; p.cmx = info.color_intrinsic[2]; p.cmy = info.color_intrinsic[6];
+  }
   const int device = std::getenv("SF_DEVICE") ? std::atoi(std::getenv("SF_DEVICE")) : 0;
   sf_fuser* fuser = nullptr;
   if (sf_fuser_create(&p, device, &fuser) != SF_OK) return die("fuser");

@@ -87,8 +87,9 @@ class Fuser:
         pose = np.ascontiguousarray(pose, dtype=np.float32).reshape(16)
         if rgb is not None:
             rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
-            if rgb.size != depth.size * 3:
-                raise ValueError("rgb must be depth-resolution HxWx3")
+            want = (self.params.color_width * self.params.color_height if self.params.color_width > 0 else depth.size) * 3
+            if rgb.size != want:
+                raise ValueError("rgb must be HxWx3 at depth resolution (or at the colour resolution given in sf_params)")
         rc = check(fn(self._h, _ptr(depth), _ptr(rgb), _ptr(pose)), allow=(_abi.SF_ERR_SKIPPED,))
         return rc == 0
 

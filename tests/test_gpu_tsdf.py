@@ -269,3 +269,66 @@ def test_hand_expanded_divisions_on_device():
     L.sf_selftest_division.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     _abi.check(L.sf_selftest_division(0, C.byref(a), C.byref(b)))
     assert (a.value, b.value) == (0, 0)
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_gpu_matches_committed_digests(case):
+    """The HIP path against tests/golden/tsdf_golden.json (digests of the oracle's voxels and canonical mesh, generated by
+    tests/golden/make_tsdf_golden.py) -- no oracle call on the GPU box for this one."""
+    from scannet_amd import fusion
+    from tests.test_oracle_tsdf import _golden
+    mod, gold = _golden()
+    name, size, voxel, idx, colour, deint = mod.SCENARIOS[case]
+
+    class Adapter:
+        def __init__(self, W, H, vx):
+            fx, fy, mx, my = synth.intrinsics(W, H)
+            self.f = fusion.Fuser(fusion.default_params(depth_width=W, depth_height=H, voxel_size=vx, fx=fx, fy=fy, mx=mx, my=my, num_sdf_blocks=1 << 16))
+
+        def integrate(self, d, pose, rgb=None):
+            self.f.integrate(d, pose, rgb=rgb)
+
+        def deintegrate(self, d, pose, rgb=None):
+            self.f.deintegrate(d, pose, rgb=rgb)
+
+        def export(self):
+            return self.f.export_blocks()
+
+        def extract_mesh(self):
+            xyz, rgba, tris, keys = self.f.extract_mesh().arrays(keys=True)
+            return xyz, np.ascontiguousarray(rgba[:, :3]), tris.astype(np.int32), keys
+
+    got = mod.run(Adapter, name, size, voxel, idx, colour, deint)
+    assert got == gold[name]
+
+
+def test_colour_at_its_own_resolution(oracle):
+    """Real ScanNet scans store 1296x968 colour over 640x480 depth: sf_params.color_width/height + colour intrinsics make the
+    pre-pass sample the colour pixel under each depth pixel's ray (nearest, black outside).  Checked against the oracle fed
+    with the same resampling done in numpy."""
+    from scannet_amd import fusion
+    W, H, CW, CH = 160, 120, 324, 242
+    op, gp = _mk(oracle, W, H, voxel=0.02, num_sdf_blocks=1 << 15)
+    cfx, cfy, cmx, cmy = np.float32(340.3), np.float32(338.1), np.float32(160.2), np.float32(119.7)   # narrower than the depth camera: black rim
+    gp.color_width, gp.color_height, gp.cfx, gp.cfy, gp.cmx, gp.cmy = CW, CH, cfx, cfy, cmx, cmy
+    ovol = oracle.Volume(op, threads=4)
+    rng = np.random.default_rng(3)
+    xs, ys = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32))
+    u = (((xs - np.float32(gp.mx)) / np.float32(gp.fx)) * cfx + cmx).astype(np.float32)   # fmaf == mul + add here?  use float64 fma emulation below
+    # exact fmaf: products of two floats fit in float64, one rounding to float32 at the end
+    u = (((xs - np.float32(gp.mx)) / np.float32(gp.fx)).astype(np.float64) * np.float64(cfx) + np.float64(cmx)).astype(np.float32) + np.float32(0.5)
+    v = (((ys - np.float32(gp.my)) / np.float32(gp.fy)).astype(np.float64) * np.float64(cfy) + np.float64(cmy)).astype(np.float32) + np.float32(0.5)
+    ok = (u >= 0) & (u < CW) & (v >= 0) & (v < CH)
+    iu, iv = np.where(ok, u, 0).astype(np.int64), np.where(ok, v, 0).astype(np.int64)
+    assert ok.mean() < 1.0 and ok.mean() > 0.5
+    with fusion.Fuser(gp) as f:
+        for i in (0, 25, 50):
+            pose = synth.trajectory_pose(i, 400)
+            d = synth.render_room_depth(pose, W, H, noise_frame=i)
+            big = rng.integers(1, 256, (CH, CW, 3), dtype=np.uint8)
+            small = np.where(ok[..., None], big[iv, iu], 0).astype(np.uint8)
+            ovol.integrate(d, pose, rgb=small)
+            assert f.integrate(d, pose, rgb=big)
+        _assert_same(ovol, f)
+        with pytest.raises(ValueError):
+            f.integrate(d, pose, rgb=small)   # wrong size: the fuser expects colour-resolution frames

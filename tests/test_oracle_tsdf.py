@@ -169,3 +169,35 @@ def test_plane_mesh_known_answer(oracle, plane_volume):
     a, b, c = pos[idx[:, 0]], pos[idx[:, 1]], pos[idx[:, 2]]
     n = np.cross(b - a, c - a)
     assert (n[:, 2] <= 0).all() and (n[:, 2] < 0).sum() > 0.9 * len(idx)
+
+
+def _golden():
+    import importlib.util
+    import json
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_tsdf_golden", os.path.join(here, "make_tsdf_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod, json.load(open(os.path.join(here, "tsdf_golden.json")))
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_oracle_matches_committed_digests(oracle, case):
+    """tests/golden/tsdf_golden.json freezes the oracle's output (voxels + canonical mesh) on small seeded scenarios."""
+    mod, gold = _golden()
+    name, size, voxel, idx, colour, deint = mod.SCENARIOS[case]
+
+    def factory(W, H, vx):
+        p = oracle.default_params(W, H, vx)
+        p.fx, p.fy, p.mx, p.my = synth.intrinsics(W, H)
+        vol = oracle.Volume(p, threads=4)
+        raw = vol.extract_mesh
+
+        def extract():
+            m = raw()
+            return m["pos"], m["col"], m["idx"].astype(np.int32), m["keys"]
+        vol.extract_mesh = extract
+        return vol
+
+    assert mod.run(factory, name, size, voxel, idx, colour, deint) == gold[name]
