@@ -167,13 +167,21 @@ def main():
         st1 = fuser.stats()
         kernel_ms, launches, _ = fuser.profile_read() if profile else (0.0, 0, 0)
         fuser.profile(False)
+        ceiling = None
+        if single_frame and profile:
+            # the last frame's tile traffic without the arithmetic: what this access pattern (scattered 4 KiB RMW) can reach
+            rmw_us, tiles = fuser.calib_tile_rmw(read_only=False, iters=50)
+            ro_us, _ = fuser.calib_tile_rmw(read_only=True, iters=50)
+            if tiles > 0:
+                ceiling = {"tiles": tiles, "rmw_copy_us": round(rmw_us, 2), "rmw_copy_GBs": round(tiles * 8192 / rmw_us / 1e3, 1),
+                           "read_only_us": round(ro_us, 2), "read_only_GBs": round(tiles * 4096 / ro_us / 1e3, 1)}
         batch = fuser.batch_frames
         fuser.close()
         blocks = st1["total_frame_blocks"] - st0["total_frame_blocks"]
         # B_frame = N_blk*(512*8 read + 512*8 write + 16) + W*H*2 + 64, summed over the frames
         alg_bytes = blocks * (4096 + 4096 + 16) + n_timed * (W * H * 2 + 64)
         return {"elapsed": elapsed, "t_enq": t_enq, "kernel_ms": kernel_ms, "launches": launches, "blocks": blocks,
-                "alg_bytes": alg_bytes, "batch": batch, "n_launch": (n_timed + batch - 1) // batch, "st1": st1}
+                "alg_bytes": alg_bytes, "batch": batch, "n_launch": (n_timed + batch - 1) // batch, "st1": st1, "ceiling": ceiling}
 
     def roofline(m, n_timed, kernel):
         if not m["launches"]:
@@ -189,6 +197,8 @@ def main():
     m = run(Wm, K, not args.no_profile, single_frame=args.single_frame)
     if rank == 0:
         roof = roofline(m, K, "k_integrate<1,false,true,true>")
+        if roof is not None and m["ceiling"]:
+            roof["pattern_ceiling"] = dict(m["ceiling"], frac_of_ceiling=round(roof["achieved"] / m["ceiling"]["rmw_copy_GBs"], 4))
         if roof is not None and m["batch"] > 1:
             roof["note"] = ("one launch fuses frames_per_launch frames into each 4 KiB tile while it sits in registers (temporal blocking): "
                             "algorithmic bytes = sum of the per-frame SURVEY 8d figures, so achieved can exceed the HBM peak; the HBM "
@@ -222,6 +232,10 @@ def main():
             r1 = roofline(m1, ks, "k_integrate<1,false,true,true>, one frame per launch (SF_BATCH=1)")
             if r1 is not None:
                 r1["frames_per_s"] = round(ks / m1["elapsed"], 1)
+                if m1["ceiling"]:
+                    r1["pattern_ceiling"] = dict(m1["ceiling"], frac_of_ceiling=round(r1["achieved"] / m1["ceiling"]["rmw_copy_GBs"], 4),
+                                                 note="k_tile_rmw: the same tiles of the last timed frame read and written back unchanged, no "
+                                                      "arithmetic, same launch geometry -- what scattered 4 KiB read-modify-write reaches on this HBM")
                 if not args.no_pmc:
                     t = pmc_traffic(min(args.pmc_steps, ks), Wm, single_frame=True)
                     if t is not None:

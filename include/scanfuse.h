@@ -289,6 +289,11 @@ int sf_synth_room_device(void* d_depth, uint64_t frame_stride_bytes, uint64_t fi
  * must be 0 (tests/test_gpu_tsdf.py). */
 int sf_selftest_division(int device, uint64_t* recip_mismatches, uint64_t* quot_mismatches);
 
+/* Measurement aid (bench.py roofline_single_frame.pattern_ceiling): the memory traffic of the most recent integrate pass
+ * without its arithmetic -- every tile of that pass's list is read and (read_only == 0) written back unchanged, with the
+ * integrate kernel's launch geometry; iters timed launches, average duration in microseconds.  The volume is unchanged. */
+int sf_fuser_calib_tile_rmw(sf_fuser* f, int read_only, int iters, double* avg_us, uint32_t* tiles);
+
 /* PMC calibration stream (tools/pmc_calibrate.py): known-byte-count 16 B/lane RMW + read-only launches. */
 int sf_calib_stream(int device, uint64_t bytes, int iters);
 

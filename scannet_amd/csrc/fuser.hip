@@ -690,6 +690,45 @@ __global__ __launch_bounds__(256, 4) void k_integrate(uint4* __restrict__ voxels
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Measurement aid: the memory traffic of k_integrate WITHOUT its arithmetic -- every tile of the compact list is read
+// with the same four 1 KiB loads per wave and (mode 0) written back unchanged, same grid, same list walk.  Its duration
+// is the ceiling the access pattern itself (scattered 4 KiB read-modify-write) allows on this HBM; bench.py reports
+// the one-frame-per-launch kernel against it (sf_fuser_calib_tile_rmw).  The volume is left bit-identical.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 4) void k_tile_rmw(uint4* __restrict__ voxels, const int32_t* __restrict__ compact,
+                                                  const int32_t* __restrict__ counters, int compact_counter, int xcd_walk, int read_only,
+                                                  uint32_t* sink) {
+  const int n = counters[compact_counter];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int wg_total = (n + 3) >> 2;
+  const int chunk = xcd_walk ? (wg_total + 7) >> 3 : wg_total;
+  const int lanes = xcd_walk ? 8 : 1;
+  const int sub = xcd_walk ? (int)(blockIdx.x & 7) : 0;
+  const int per_sub = max(1, (int)gridDim.x / lanes);
+  uint32_t acc = 0;
+  for (int loc = xcd_walk ? (int)(blockIdx.x >> 3) : (int)blockIdx.x; loc < chunk; loc += per_sub) {
+    const int i = ((sub * chunk + loc) << 2) + wave;
+    if (i >= n) continue;
+    uint4* vb = voxels + (size_t)compact[i] * 256;
+    uint4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = vb[j * 64 + lane];
+    if (read_only) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc ^= v[j].x ^ v[j].y ^ v[j].z ^ v[j].w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        asm volatile("" : "+v"(v[j].x));  // opaque to the optimiser: the store below stays
+        vb[j * 64 + lane] = v[j];
+      }
+    }
+  }
+  if (read_only && acc == 0x9E3779B9u) *sink = acc;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Garbage collection: one 256-thread workgroup per live block; min |sdf| over observed
 // voxels and max weight reduced through wave shuffles + LDS; freed blocks are zeroed, unlinked
 // (tombstone) and pushed back on the heap.
@@ -1189,6 +1228,41 @@ SF_API int sf_fuser_profile_read(sf_fuser* f, double* integrate_ms, uint64_t* la
     std::memcpy(blocks, c, 8);
   }
   f->events_used = 0;
+  return SF_OK;
+}
+
+SF_API int sf_fuser_calib_tile_rmw(sf_fuser* f, int read_only, int iters, double* avg_us, uint32_t* tiles) {
+  if (!f || iters < 1) return sf::fail(SF_ERR_INVALID_ARG, "sf_fuser_calib_tile_rmw: bad argument");
+  SF_HIP_CHECK(hipSetDevice(f->device));
+  SF_HIP_CHECK(sf_quiesce(f));
+  const int sl = f->slot ^ 1;  // the list of the most recent pass
+  const int cc = sl ? (int)C_COMPACT_B : (int)C_COMPACT;
+  int32_t n = 0;
+  SF_HIP_CHECK(hipMemcpy(&n, &f->counters[cc], 4, hipMemcpyDeviceToHost));
+  int grid = (n + n / 4 + 4096 + 3) / 4;  // the sizing rule of run_batch
+  if (grid > f->num_cus * 64) grid = f->num_cus * 64;
+  grid = (grid + 7) & ~7;
+  uint32_t* sink = nullptr;
+  SF_HIP_CHECK(hipMalloc((void**)&sink, 4));
+  hipEvent_t e0, e1;
+  SF_HIP_CHECK(hipEventCreate(&e0));
+  SF_HIP_CHECK(hipEventCreate(&e1));
+  double total_ms = 0;
+  for (int it = 0; it < iters + 1; it++) {  // first launch untimed
+    SF_HIP_CHECK(hipEventRecord(e0, f->stream));
+    hipLaunchKernelGGL(k_tile_rmw, dim3(grid), dim3(256), 0, f->stream, f->voxels, f->compact2[sl], f->counters, cc, f->xcd_walk ? 1 : 0,
+                       read_only ? 1 : 0, sink);
+    SF_HIP_CHECK(hipEventRecord(e1, f->stream));
+    SF_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    SF_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (it > 0) total_ms += ms;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(sink);
+  if (avg_us) *avg_us = total_ms * 1e3 / iters;
+  if (tiles) *tiles = (uint32_t)n;
   return SF_OK;
 }
 

@@ -145,6 +145,12 @@ class Fuser:
         check(_abi.lib().sf_fuser_profile_read(self._h, C.byref(ms), C.byref(n), C.byref(b)))
         return ms.value, n.value, b.value
 
+    def calib_tile_rmw(self, read_only=False, iters=20):
+        """(average microseconds, tiles): the most recent pass's tile traffic without its arithmetic (pattern ceiling)."""
+        us, n = C.c_double(0), C.c_uint32(0)
+        check(_abi.lib().sf_fuser_calib_tile_rmw(self._h, 1 if read_only else 0, int(iters), C.byref(us), C.byref(n)))
+        return us.value, n.value
+
     def run(self, sensor_data, first=0, last=0, decode_threads=0):
         """Fuse frames [first, last) of a scannet_amd.sens.SensorData (threaded decode overlapped with the GPU)."""
         st = SfRunStats()
