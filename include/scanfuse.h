@@ -236,8 +236,8 @@ void sf_mesh_free(sf_mesh* m);
  * (Server/scan_processor.py:134,143) for the filter scripts the pipeline ships -- Server/tools/meshclean/clean.mlx:3-10
  * and cleanLoRes.mlx:3-10: "Merge Close Vertices" (absolute Threshold 0.0010689), "Remove Duplicate Faces", "Remove
  * Isolated pieces (wrt Face Num.)" (MinComponentSize 7500 / 1000), "Remove Unreferenced Vertex".  Semantics: the VCG
- * algorithms behind those filters, restated in scannet_amd/csrc/clean.cpp.  simplify.mlx (quadric edge collapse,
- * scan_processor.py:144-145) is not implemented: sf_mlx_load returns SF_ERR_UNSUPPORTED for it.
+ * algorithms behind those filters, restated in scannet_amd/csrc/clean.cpp.  simplify.mlx (scan_processor.py:144-145) =
+ * quadric edge collapse (below) followed by the same four filters with MinComponentSize 1000.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct sf_clean_stats {
   uint64_t vertices_in, faces_in;
@@ -249,15 +249,44 @@ typedef struct sf_clean_stats {
   uint64_t vertices_out, faces_out;
 } sf_clean_stats;
 
+/* "Quadric Edge Collapse Decimation" (Server/tools/meshclean/simplify.mlx:3-16), the first filter of the two
+ * `meshlabserver ... -s simplify.mlx` calls of the decimate stage (Server/scan_processor.py:144-145).  Semantics: VCG's
+ * TriEdgeCollapseQuadric restated in scannet_amd/csrc/simplify.cpp (parity unpinned: MeshLab is not in the tree). */
+typedef struct sf_simplify_params {
+  uint64_t target_faces;           /* simplify.mlx:4  TargetFaceNum (used when target_perc == 0)            */
+  float target_perc;               /* :5  TargetPerc 0.2: keep this fraction of the faces                     */
+  float quality_thr;               /* :6  QualityThr 0.3                                                      */
+  int32_t preserve_boundary;       /* :7  false (true: SF_ERR_UNSUPPORTED)                                    */
+  float boundary_weight;           /* :8  BoundaryWeight 1                                                    */
+  int32_t preserve_normal;         /* :9  false (true: unsupported)                                           */
+  int32_t preserve_topology;       /* :10 false (true: unsupported)                                           */
+  int32_t optimal_placement;       /* :11 true                                                                */
+  int32_t planar_quadric;          /* :12 false                                                               */
+  int32_t quality_weight;          /* :13 false (true: unsupported)                                           */
+  int32_t auto_clean;              /* :14 true                                                                */
+} sf_simplify_params;
+typedef struct sf_simplify_stats {
+  uint64_t vertices_in, faces_in, target_faces;
+  uint64_t collapses, stale_popped;
+  uint64_t faces_zero_area, vertices_duplicate;   /* AutoClean */
+  uint64_t vertices_out, faces_out;
+  float max_priority;              /* largest scaled quadric error / quality of an executed collapse */
+} sf_simplify_stats;
+void sf_simplify_default_params(sf_simplify_params* p);   /* the values simplify.mlx ships */
+int sf_mesh_simplify(const sf_mesh* in, const sf_simplify_params* p, sf_mesh** out, sf_simplify_stats* stats /*nullable*/);
+
 typedef struct sf_clean_script {   /* what a .mlx FilterScript asks for */
   int32_t merge_close_vertices, remove_duplicate_faces, remove_small_components, remove_unreferenced;
   float merge_distance;            /* clean.mlx:4  Threshold value (absolute)   */
   uint32_t min_component_faces;    /* clean.mlx:8  MinComponentSize             */
+  int32_t simplify;                /* simplify.mlx: "Quadric Edge Collapse Decimation" comes first */
+  sf_simplify_params simplify_params;
+  sf_simplify_stats simplify_stats;  /* filled by sf_mesh_clean_script when simplify != 0 */
 } sf_clean_script;
 
 int sf_mesh_clean(const sf_mesh* in, float merge_distance, uint32_t min_component_faces, sf_mesh** out, sf_clean_stats* stats /*nullable*/);
 int sf_mlx_load(const char* mlx_path, sf_clean_script* out);
-int sf_mesh_clean_script(const sf_mesh* in, const sf_clean_script* script, sf_mesh** out, sf_clean_stats* stats /*nullable*/);
+int sf_mesh_clean_script(const sf_mesh* in, sf_clean_script* script, sf_mesh** out, sf_clean_stats* stats /*nullable*/);
 
 /* ------------------------------------------------------------------------------------------------
  * Segmentator: Felzenszwalb-Huttenlocher graph segmentation on vertex normals.  Replaces

@@ -339,6 +339,13 @@ SF_API int sf_mlx_load(const char* path, sf_clean_script* out) {
     if (tag.compare(0, 7, "filter ") == 0) {
       current = attr(tag, "name");
       int want;
+      if (current == "Quadric Edge Collapse Decimation") {
+        if (stage != 0) return sf::fail(SF_ERR_UNSUPPORTED, "\"Quadric Edge Collapse Decimation\" must be the first filter (simplify.mlx order)");
+        if (out->simplify) return sf::fail(SF_ERR_UNSUPPORTED, "more than one \"Quadric Edge Collapse Decimation\"");
+        out->simplify = 1;
+        sf_simplify_default_params(&out->simplify_params);
+        continue;
+      }
       if (current == "Merge Close Vertices") { want = 1; out->merge_close_vertices = 1; }
       else if (current == "Remove Duplicate Faces") { want = 2; out->remove_duplicate_faces = 1; }
       else if (current == "Remove Isolated pieces (wrt Face Num.)") { want = 3; out->remove_small_components = 1; }
@@ -348,20 +355,54 @@ SF_API int sf_mlx_load(const char* path, sf_clean_script* out) {
       stage = want;
     } else if (tag.compare(0, 6, "Param ") == 0) {
       const std::string name = attr(tag, "name"), value = attr(tag, "value");
+      if (current == "Quadric Edge Collapse Decimation") {
+        sf_simplify_params& sp = out->simplify_params;
+        const bool on = value == "true";
+        if (name == "TargetFaceNum") sp.target_faces = (uint64_t)std::atoll(value.c_str());
+        else if (name == "TargetPerc") sp.target_perc = (float)std::atof(value.c_str());
+        else if (name == "QualityThr") sp.quality_thr = (float)std::atof(value.c_str());
+        else if (name == "PreserveBoundary") sp.preserve_boundary = on;
+        else if (name == "BoundaryWeight") sp.boundary_weight = (float)std::atof(value.c_str());
+        else if (name == "PreserveNormal") sp.preserve_normal = on;
+        else if (name == "PreserveTopology") sp.preserve_topology = on;
+        else if (name == "OptimalPlacement") sp.optimal_placement = on;
+        else if (name == "PlanarQuadric") sp.planar_quadric = on;
+        else if (name == "QualityWeight") sp.quality_weight = on;
+        else if (name == "AutoClean") sp.auto_clean = on;
+        else if (name == "Selected" && on) return sf::fail(SF_ERR_UNSUPPORTED, "Selected = true: there is no face selection in a batch run");
+      }
       if (current == "Merge Close Vertices" && name == "Threshold") out->merge_distance = (float)std::atof(value.c_str());
       if (current == "Remove Isolated pieces (wrt Face Num.)" && name == "MinComponentSize") out->min_component_faces = (uint32_t)std::atol(value.c_str());
     }
   }
-  if (stage == 0) return sf::fail(SF_ERR_FORMAT, "%s holds no filter", path);
+  if (stage == 0 && !out->simplify) return sf::fail(SF_ERR_FORMAT, "%s holds no filter", path);
   return SF_OK;
 }
 
-SF_API int sf_mesh_clean_script(const sf_mesh* in, const sf_clean_script* s, sf_mesh** out, sf_clean_stats* stats) {
+SF_API int sf_mesh_clean_script(const sf_mesh* in, sf_clean_script* s, sf_mesh** out, sf_clean_stats* stats) {
   if (!s) return sf::fail(SF_ERR_INVALID_ARG, "NULL script");
+  sf_mesh* simplified = nullptr;
+  if (s->simplify) {
+    const int rc = sf_mesh_simplify(in, &s->simplify_params, &simplified, &s->simplify_stats);
+    if (rc != SF_OK) return rc;
+    in = simplified;
+    if (!s->merge_close_vertices && !s->remove_duplicate_faces && !s->remove_small_components && !s->remove_unreferenced) {
+      if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->vertices_in = stats->vertices_out = simplified->pos.size() / 3;
+        stats->faces_in = stats->faces_out = simplified->tri.size() / 3;
+      }
+      *out = simplified;
+      return SF_OK;
+    }
+  }
   // a filter that is absent from the script degenerates to a no-op parameter
   const float dist = s->merge_close_vertices ? s->merge_distance : -1.0f;
+  int rc = SF_OK;
   if (!s->remove_duplicate_faces || !s->remove_unreferenced)
-    return sf::fail(SF_ERR_UNSUPPORTED, "scripts without \"Remove Duplicate Faces\" / \"Remove Unreferenced Vertex\" are not supported");
-  if (dist < 0.0f) return sf::fail(SF_ERR_UNSUPPORTED, "scripts without \"Merge Close Vertices\" are not supported");
-  return sf_mesh_clean(in, dist, s->remove_small_components ? s->min_component_faces : 0u, out, stats);
+    rc = sf::fail(SF_ERR_UNSUPPORTED, "scripts without \"Remove Duplicate Faces\" / \"Remove Unreferenced Vertex\" are not supported");
+  else if (dist < 0.0f) rc = sf::fail(SF_ERR_UNSUPPORTED, "scripts without \"Merge Close Vertices\" are not supported");
+  else rc = sf_mesh_clean(in, dist, s->remove_small_components ? s->min_component_faces : 0u, out, stats);
+  if (simplified) sf_mesh_free(simplified);
+  return rc;
 }

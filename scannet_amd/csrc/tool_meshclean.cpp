@@ -3,7 +3,8 @@
 //     meshlabserver -i <in.ply> -o <in.ply>  -m vc -s <dir>/cleanLoRes.mlx     (Server/scan_processor.py:134)
 // Point cfg.MESHLAB_BIN (Server/config.py:19) at this executable.  Same flags: -i input, -o output, -m save-mask
 // tokens (vc = vertex colours: always written), -s filter script.  Progress on stdout, nothing on stderr on success,
-// non-zero exit + stderr message on failure (Server/util.py:38-50).  simplify.mlx is reported as unsupported.
+// non-zero exit + stderr message on failure (Server/util.py:38-50).  The same executable serves the decimate stage:
+//     meshlabserver -i X_vh_clean.ply -o X_vh_clean_1.ply -m vc -s <dir>/simplify.mlx   (Server/scan_processor.py:144-145)
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -26,7 +27,7 @@ int main(int argc, const char** argv) {
     else { std::fprintf(stderr, "unknown option %s\n", argv[i]); return 255; }
   }
   if (!in || !out || !script) {
-    std::printf("Usage: meshclean -i input.ply -o output.ply [-m vc] -s clean.mlx\n");
+    std::printf("Usage: meshclean -i input.ply -o output.ply [-m vc] -s clean.mlx|simplify.mlx\n");
     return 255;
   }
   sf_clean_script sc;
@@ -39,6 +40,12 @@ int main(int argc, const char** argv) {
   sf_mesh* c = nullptr;
   sf_clean_stats st;
   if (sf_mesh_clean_script(m, &sc, &c, &st) != SF_OK) return die("clean");
+  if (sc.simplify) {
+    const sf_simplify_stats& ss = sc.simplify_stats;
+    std::printf("Quadric Edge Collapse Decimation: %llu -> %llu faces (target %llu), %llu collapses, %llu vertices left\n",
+                (unsigned long long)ss.faces_in, (unsigned long long)ss.faces_out, (unsigned long long)ss.target_faces,
+                (unsigned long long)ss.collapses, (unsigned long long)ss.vertices_out);
+  }
   std::printf("Merge Close Vertices (%g): merged %llu vertices, removed %llu degenerate faces\n", (double)sc.merge_distance,
               (unsigned long long)st.vertices_merged, (unsigned long long)st.faces_degenerate);
   std::printf("Remove Duplicate Faces: removed %llu faces\n", (unsigned long long)st.faces_duplicate);

@@ -18,9 +18,22 @@ class SfCleanStats(C.Structure):
                                           "vertices_out", "faces_out")]
 
 
+class SfSimplifyParams(C.Structure):
+    """simplify.mlx:3-16 ("Quadric Edge Collapse Decimation")."""
+    _fields_ = [("target_faces", C.c_uint64), ("target_perc", C.c_float), ("quality_thr", C.c_float), ("preserve_boundary", C.c_int32),
+                ("boundary_weight", C.c_float), ("preserve_normal", C.c_int32), ("preserve_topology", C.c_int32),
+                ("optimal_placement", C.c_int32), ("planar_quadric", C.c_int32), ("quality_weight", C.c_int32), ("auto_clean", C.c_int32)]
+
+
+class SfSimplifyStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("vertices_in", "faces_in", "target_faces", "collapses", "stale_popped", "faces_zero_area",
+                                          "vertices_duplicate", "vertices_out", "faces_out")] + [("max_priority", C.c_float)]
+
+
 class SfCleanScript(C.Structure):
     _fields_ = [("merge_close_vertices", C.c_int32), ("remove_duplicate_faces", C.c_int32), ("remove_small_components", C.c_int32),
-                ("remove_unreferenced", C.c_int32), ("merge_distance", C.c_float), ("min_component_faces", C.c_uint32)]
+                ("remove_unreferenced", C.c_int32), ("merge_distance", C.c_float), ("min_component_faces", C.c_uint32),
+                ("simplify", C.c_int32), ("simplify_params", SfSimplifyParams), ("simplify_stats", SfSimplifyStats)]
 
 
 def _lib():
@@ -29,7 +42,24 @@ def _lib():
     L.sf_mesh_clean.argtypes = [vp, C.c_float, C.c_uint32, C.POINTER(vp), C.POINTER(SfCleanStats)]
     L.sf_mlx_load.argtypes = [C.c_char_p, C.POINTER(SfCleanScript)]
     L.sf_mesh_clean_script.argtypes = [vp, C.POINTER(SfCleanScript), C.POINTER(vp), C.POINTER(SfCleanStats)]
+    L.sf_simplify_default_params.argtypes = [C.POINTER(SfSimplifyParams)]
+    L.sf_simplify_default_params.restype = None
+    L.sf_mesh_simplify.argtypes = [vp, C.POINTER(SfSimplifyParams), C.POINTER(vp), C.POINTER(SfSimplifyStats)]
     return L
+
+
+def simplify(mesh, **overrides):
+    """"Quadric Edge Collapse Decimation" with simplify.mlx's parameters (keep 20 % of the faces) unless overridden;
+    returns (Mesh, stats dict)."""
+    p = SfSimplifyParams()
+    _lib().sf_simplify_default_params(C.byref(p))
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise TypeError("unknown simplify parameter %r" % k)
+        setattr(p, k, v)
+    h, st = C.c_void_p(), SfSimplifyStats()
+    check(_lib().sf_mesh_simplify(mesh._h, C.byref(p), C.byref(h), C.byref(st)))
+    return Mesh(h), {n: getattr(st, n) for n, _ in SfSimplifyStats._fields_}
 
 
 def clean(mesh, merge_distance=CLEAN_MLX_MERGE_DISTANCE, min_component_faces=CLEAN_MLX_MIN_COMPONENT):
@@ -55,4 +85,7 @@ def clean_file(in_ply, out_ply, script_mlx):
     out.write_ply(out_ply)
     out.close()
     m.close()
-    return {n: getattr(st, n) for n, _ in SfCleanStats._fields_}
+    res = {n: getattr(st, n) for n, _ in SfCleanStats._fields_}
+    if s.simplify:
+        res["simplify"] = {n: getattr(s.simplify_stats, n) for n, _ in SfSimplifyStats._fields_}
+    return res

@@ -117,10 +117,10 @@ def test_shipped_scripts_and_cli(tmp_path):
         s = meshclean.load_script(path)
         assert (s.merge_close_vertices, s.remove_duplicate_faces, s.remove_small_components, s.remove_unreferenced) == (1, 1, 1, 1)
         assert abs(s.merge_distance - 0.0010689) < 1e-9 and s.min_component_faces == want
-    simplify = tmp_path / "simplify.mlx"
-    simplify.write_text('<!DOCTYPE FilterScript>\n<FilterScript>\n <filter name="Quadric Edge Collapse Decimation">\n </filter>\n</FilterScript>\n')
+    unknown = tmp_path / "unknown.mlx"
+    unknown.write_text('<!DOCTYPE FilterScript>\n<FilterScript>\n <filter name="Laplacian Smooth">\n </filter>\n</FilterScript>\n')
     with pytest.raises(Exception, match="not implemented"):
-        meshclean.load_script(str(simplify))
+        meshclean.load_script(str(unknown))
     # CLI with meshlabserver's flags, in place (-i == -o, scan_processor.py:134)
     xyz, rgba, tris = _soup(np.random.default_rng(5))
     ply = str(tmp_path / "scene_vh.ply")
