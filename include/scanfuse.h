@@ -213,6 +213,48 @@ int sf_sens_add_frame(sf_sens* s, const uint8_t* color, uint64_t color_bytes, co
 int sf_sens_set_pose(sf_sens* s, uint64_t frame, const float pose[16]);
 int sf_sens_save(const sf_sens* s, const char* path);
 
+/* IMU frames of a .sens under construction: 128 bytes each = rotationRate, acceleration, magneticField, attitude, gravity
+ * (5 x 3 doubles) + u64 time stamp in microseconds (sensorData.h:796-803); addIMUFrame :1111-1113. */
+int sf_sens_add_imu(sf_sens* s, const void* frame128);
+
+/* ------------------------------------------------------------------------------------------------
+ * ScannerApp captures and the `convert` stage (scannet_amd/csrc/occipital.cpp).  Replaces
+ *   uplinksimple::decode / encode    ScannerApp/depth2pgm/uplinksimple_image-codecs.h:180-249 / :253-396
+ *   uplinksimple::shift2depth        ScannerApp/depth2pgm/uplinksimple_shift2depth.h:9-90
+ *   Converter convertToSens          Converter/main.cpp:16-179, MetaData Converter/src/metaData.h:11-72
+ * sf_occ_decode is bounds-checked (SF_ERR_FORMAT on a truncated stream; the reference only asserts).  sf_occ_encode rejects
+ * values above 2047 (the code has 11 bits; the reference would corrupt its own stream).
+ * ---------------------------------------------------------------------------------------------- */
+int sf_occ_decode(const uint8_t* stream, uint64_t stream_bytes, uint64_t num_elements, uint16_t* out_shift);
+uint64_t sf_occ_encode_bound(uint64_t num_elements);
+int sf_occ_encode(const uint16_t* shift_in, uint64_t num_elements, uint8_t* out, uint64_t out_capacity, uint64_t* out_bytes);
+uint16_t sf_occ_shift2depth(uint16_t shift);
+int sf_occ_shift2depth_buffer(uint16_t* buf, uint64_t n, int zero_invalid /* values >= shift2depth(0xffff) -> 0, Converter/main.cpp:89-93 */);
+
+typedef struct sf_capture_meta {     /* <base>.txt (Converter/src/metaData.h:17-60) */
+  uint32_t num_color_frames, num_depth_frames, num_imu;
+  uint32_t color_width, color_height, depth_width, depth_height;
+  float fx_color, fy_color, mx_color, my_color, fx_depth, fy_depth, mx_depth, my_depth;
+  float color_to_depth_extrinsics[16];   /* row-major; identity when absent */
+  int32_t has_extrinsics;
+} sf_capture_meta;
+typedef struct sf_convert_stats {
+  uint64_t frames, depth_frames_in_capture, imu_frames, imu_skipped, depth_stream_bytes;
+  uint32_t threads;
+} sf_convert_stats;
+typedef struct sf_capture sf_capture;
+/* colour source of sf_capture_convert: *blob / *bytes for frame `frame` (valid until the next call); SF_OK or an sf_status */
+typedef int (*sf_capture_color_fn)(void* user, uint64_t frame, const uint8_t** blob, uint64_t* bytes);
+int sf_capture_open(const char* any_capture_file /* <base>.txt|.depth|.imu|.h264 */, sf_capture** out);
+void sf_capture_close(sf_capture* c);
+int sf_capture_get_meta(const sf_capture* c, sf_capture_meta* out);
+int sf_capture_decode_depth(const sf_capture* c, uint64_t frame, uint16_t* dst_mm, uint64_t* timestamp_us /*nullable*/);
+/* capture -> .sens: zlib depth, depthShift 1000, "StructureSensor", identity poses, depth time stamp on both streams,
+ * IMU records with a zero time stamp skipped.  color_fn NULL: frames without colour; else color_compression 0 (raw RGB) or
+ * 2 (JPEG blobs passed through). */
+int sf_capture_convert(const sf_capture* c, const char* out_sens, sf_capture_color_fn color_fn, void* color_user, int color_compression,
+                       int threads, sf_convert_stats* stats /*nullable*/);
+
 /* ------------------------------------------------------------------------------------------------
  * Triangle meshes and the PLY surface (README.md:45-46: binary little-endian PLY, vertex float x,y,z +
  * uchar red,green,blue,alpha, face list uchar int vertex_indices).  sf_ply_read replaces tinyply as the

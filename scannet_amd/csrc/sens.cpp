@@ -254,6 +254,13 @@ SF_API int sf_sens_set_pose(sf_sens* s, uint64_t frame, const float pose[16]) {
   return SF_OK;
 }
 
+SF_API int sf_sens_add_imu(sf_sens* s, const void* frame128) {
+  if (!s || !frame128) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  const uint8_t* b = (const uint8_t*)frame128;
+  s->imu.insert(s->imu.end(), b, b + 128);
+  return SF_OK;
+}
+
 SF_API int sf_sens_save(const sf_sens* s, const char* path) {
   if (!s || !path) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
   FILE* fp = std::fopen(path, "wb");

@@ -1,0 +1,215 @@
+"""Convert stage: the Occipital depth codec, the shift table and the capture -> .sens converter
+(scannet_amd/csrc/occipital.cpp) against the REFERENCE's own headers compiled where they lie (oracle/_ref/libref_occ.so from
+ScannerApp/depth2pgm/uplinksimple_*.h), plus golden digests for boxes without the reference build."""
+import ctypes as C
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from scannet_amd import capture, sens
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref", "libref_occ.so")
+W, H = 640, 480
+# produced by the REFERENCE codec: tests/golden/make_occipital_golden.py
+GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "occipital_golden.json")))
+
+
+def _ref():
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/libref_occ.so not built (needs /root/reference at build time)")
+    L = C.CDLL(REF)
+    L.ref_occ_decode.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
+    L.ref_occ_encode.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32]
+    L.ref_occ_encode.restype = C.c_uint32
+    L.ref_occ_shift2depth.argtypes = [C.c_uint16]
+    L.ref_occ_shift2depth.restype = C.c_uint16
+    L.ref_occ_frame.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
+    return L
+
+
+def _ref_encode(L, a):
+    out = np.zeros(2 * a.size + 64, np.uint8)
+    n = L.ref_occ_encode(a.ctypes.data, a.size, out.ctypes.data, out.size)
+    return out[:n].tobytes()
+
+
+def _ref_decode(L, stream, n):
+    buf = np.frombuffer(stream + b"\0" * 8, np.uint8)  # the reference reads past the last code
+    out = np.zeros(n + 64, np.uint16)  # ... and a final run may overshoot the frame by up to 35 values
+    L.ref_occ_decode(buf.ctypes.data, len(stream), n, out.ctypes.data)
+    return out[:n]
+
+
+def _shift_frames():
+    """Shift images the way a structured-light sensor produces them: smooth ramps, plateaus, holes (0), noise, steps."""
+    rng = np.random.default_rng(11)
+    y, x = np.mgrid[0:H, 0:W]
+    f0 = (600 + 0.4 * x + 0.1 * y).astype(np.uint16)                       # ramp: +-1 codes
+    f1 = np.full((H, W), 777, np.uint16)                                   # constant: long zero runs (31+5 chunks)
+    f1[100:200, 50:300] = 0                                                # a hole
+    f2 = (500 + 200 * np.sin(x / 37.0) * np.cos(y / 23.0) + rng.integers(-2, 3, (H, W))).astype(np.uint16)  # noise: +-2 and resets
+    f3 = rng.integers(0, 2048, (H, W)).astype(np.uint16)                   # worst case: a reset per pixel
+    f4 = np.zeros((H, W), np.uint16)                                       # all zero: only runs
+    f5 = np.where((x // 5 + y // 3) % 2 == 0, 1000, 1001).astype(np.uint16)
+    return [f0, f1, f2, f3, f4, f5]
+
+
+def test_shift_table_equals_the_reference_for_every_input():
+    L = _ref()
+    lib = capture._lib()
+    mine = np.array([lib.sf_occ_shift2depth(s) for s in range(65536)], np.uint16)
+    ref = np.array([L.ref_occ_shift2depth(s) for s in range(65536)], np.uint16)
+    assert np.array_equal(mine, ref)
+
+
+def test_shift_table_golden():
+    # without the reference build: digest of the REFERENCE's 65536-entry mapping (tests/golden/occipital_golden.json)
+    lib = capture._lib()
+    mine = np.array([lib.sf_occ_shift2depth(s) for s in range(65536)], np.uint16)
+    assert mine[0] == 0 and mine[1] == 264 and mine[1104] == 9729 and mine[65535] == 9729 and mine[640] == 606
+    assert hashlib.sha256(mine.tobytes()).hexdigest() == GOLDEN["table"]
+
+
+def test_codec_matches_the_reference_both_ways():
+    L = _ref()
+    for i, f in enumerate(_shift_frames()):
+        a = np.ascontiguousarray(f.ravel())
+        s_ref = _ref_encode(L, a)
+        s_mine = capture.encode(a)
+        assert s_mine == s_ref, "frame %d: encoder output differs" % i
+        assert np.array_equal(capture.decode(s_ref, a.size), a)
+        assert np.array_equal(_ref_decode(L, s_mine, a.size), a)
+        # the whole frame step: decode + table + invalid -> 0
+        out = np.zeros(a.size + 64, np.uint16)
+        buf = np.frombuffer(s_ref + b"\0" * 8, np.uint8)
+        L.ref_occ_frame(buf.ctypes.data, len(s_ref), a.size, out.ctypes.data)
+        assert np.array_equal(capture.shift2depth(capture.decode(s_ref, a.size), zero_invalid=True), out[:a.size])
+
+
+def test_decoder_on_arbitrary_bit_streams_matches_the_reference():
+    # any bit string is a valid code sequence (values wrap at 16 bits, -1 at 0 gives 0xFFFF): random bytes exercise every
+    # branch in orders an encoder never produces
+    L = _ref()
+    rng = np.random.default_rng(3)
+    for trial in range(40):
+        stream = rng.integers(0, 256, 4096, dtype=np.uint8).tobytes()
+        n = 1500  # 4096 bytes always hold more than 1500 codes (a code is at most 15 bits)
+        assert np.array_equal(capture.decode(stream, n), _ref_decode(L, stream, n)), trial
+
+
+def test_codec_golden_and_edge_cases():
+    frames = _shift_frames()
+    digest = hashlib.sha256()
+    for f in frames:
+        s = capture.encode(f)
+        digest.update(s)
+        assert np.array_equal(capture.decode(s, f.size), f.ravel())
+    assert digest.hexdigest() == GOLDEN["streams"]
+    # compression ratio of the smooth frame (the header's "typical 0.17" is for real sensor data)
+    assert len(capture.encode(frames[0])) < 0.2 * frames[0].size * 2
+    # empty input, truncated stream, values that do not fit the code
+    assert capture.encode(np.zeros(0, np.uint16)) == b"" and len(capture.decode(b"", 0)) == 0
+    s = capture.encode(frames[2])
+    with pytest.raises(Exception, match="ends after"):
+        capture.decode(s[: len(s) // 2], frames[2].size)
+    with pytest.raises(Exception, match="11 bits"):
+        capture.encode(np.array([5, 2048], np.uint16))
+    # a run that would overshoot the frame is clipped
+    run = capture.encode(np.full(36, 9, np.uint16))
+    assert np.array_equal(capture.decode(run, 30), np.full(30, 9, np.uint16))
+
+
+def _write_capture(tmp_path, n_frames=6, name="cap01"):
+    folder = tmp_path / name
+    folder.mkdir()
+    base = str(folder / name)
+    frames = _shift_frames()[:n_frames]
+    ts = [100.0 + i / 30.0 for i in range(n_frames)]
+    meta = [("colorWidth", 1296), ("colorHeight", 968), ("depthWidth", W), ("depthHeight", H),
+            ("fx_color", "1170.187988"), ("fy_color", "1170.187988"), ("mx_color", "647.750000"), ("my_color", "483.750000"),
+            ("fx_depth", "571.623718"), ("fy_depth", "571.623718"), ("mx_depth", "319.500000"), ("my_depth", "239.500000"),
+            ("colorToDepthExtrinsics", "0.999980 0.006000 -0.002000 -0.037000 -0.006000 0.999970 0.004000 0.003000 0.002000 -0.004000 "
+                                       "0.999990 -0.021000 0.000000 0.000000 0.000000 1.000000 "),
+            ("deviceId", "test"), ("deviceName", "unit test"), ("sceneLabel", "x"), ("numDepthFrames", n_frames), ("numColorFrames", n_frames),
+            ("numIMUmeasurements", 4)]
+    imu = [[100.0 + 0.01 * k] + [float(k * 15 + j) for j in range(15)] for k in range(4)]
+    imu[2][0] = 0.0  # an invalid record (time stamp 0): skipped by the converter
+    capture.write_capture(base, frames, ts, meta, imu)
+    return str(folder), base, frames, ts, imu
+
+
+def test_capture_to_sens(tmp_path):
+    folder, base, frames, ts, imu = _write_capture(tmp_path)
+    with capture.Capture(base + ".depth") as cap:
+        m = cap.meta
+        assert (m.num_depth_frames, m.depth_width, m.depth_height, m.color_width, m.num_imu) == (6, W, H, 1296, 4)
+        assert abs(m.fx_depth - 571.623718) < 1e-4 and m.has_extrinsics == 1
+        d, t = cap.depth(2)
+        assert np.array_equal(d, capture.shift2depth(frames[2], zero_invalid=True)) and t == int(ts[2] * 1000.0 * 1000.0)
+        out = str(tmp_path / "out.sens")
+        st = cap.convert(out, threads=3)
+        assert st["frames"] == 6 and st["imu_frames"] == 3 and st["imu_skipped"] == 1
+    sd = sens.SensorData(out)
+    assert (sd.depth_width, sd.depth_height, sd.color_width, sd.color_height) == (W, H, 1296, 968)
+    assert sd.depth_compression_type == "zlib_ushort" and sd.color_compression_type == "jpeg" and sd.depth_shift == 1000.0
+    assert sd.sensor_name == "StructureSensor" and sd.num_frames == 6 and sd.num_imu_frames == 3
+    K = sd.intrinsic_depth
+    assert abs(K[0, 0] - 571.623718) < 1e-4 and abs(K[0, 2] - 319.5) < 1e-6 and K[2, 2] == 1.0 and K[3, 3] == 1.0
+    # depth extrinsic = inverse of colorToDepthExtrinsics (metaData.h:47-48)
+    c2d = np.array([0.99998, 0.006, -0.002, -0.037, -0.006, 0.99997, 0.004, 0.003, 0.002, -0.004, 0.99999, -0.021, 0, 0, 0, 1], np.float64).reshape(4, 4)
+    assert np.allclose(sd.extrinsic_depth.astype(np.float64), np.linalg.inv(c2d), atol=1e-6)
+    assert np.array_equal(sd.extrinsic_color, np.eye(4, dtype=np.float32))
+    for i, fr in enumerate(sd.frames):
+        assert np.array_equal(fr.decompress_depth(), capture.shift2depth(frames[i], zero_invalid=True))
+        assert fr.valid_pose and np.array_equal(fr.camera_to_world, np.eye(4, dtype=np.float32))
+        assert fr.timestamp_depth == fr.timestamp_color == int(ts[i] * 1000.0 * 1000.0) and fr.color_size_bytes == 0
+    sd.close()
+    # the reference's own .sens reader accepts the file (when its build is here)
+    from oracle import oracle as orc
+    if orc.ref_sens_available():
+        R = orc.ref_sens()
+        h = R.ref_sens_open(out.encode())
+        assert h
+        ri = orc.RefSensInfo()
+        R.ref_sens_get_info(h, C.byref(ri))
+        assert ri.num_frames == 6 and ri.num_imu == 3 and ri.depth_width == W
+        d = np.zeros((H, W), np.uint16)
+        assert R.ref_sens_decode_depth(h, 3, d.ctypes.data) == 0
+        assert np.array_equal(d, capture.shift2depth(frames[3], zero_invalid=True))
+        R.ref_sens_close(h)
+
+
+def test_converter_cli(tmp_path):
+    folder, base, frames, ts, imu = _write_capture(tmp_path, n_frames=3, name="scan_a")
+    exe = os.path.join(ROOT, "bin", "converter")
+    out = str(tmp_path / "scan_a.sens")
+    r = subprocess.run([exe, folder, out], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stderr == "", r.stderr
+    assert "converting: " + base in r.stdout and "3 frames" in r.stdout
+    sd = sens.SensorData(out)
+    assert sd.num_frames == 3 and np.array_equal(sd.frames[1].decompress_depth(), capture.shift2depth(frames[1], zero_invalid=True))
+    sd.close()
+    again = subprocess.run([exe, folder, out], capture_output=True, text=True)  # Converter/main.cpp:198-201
+    assert again.returncode == 0 and "already available" in again.stdout
+    # pre-extracted colour frames are passed through untouched
+    os.remove(out)
+    os.mkdir(os.path.join(folder, "color"))
+    blobs = [b"\xff\xd8fakejpeg%d\xff\xd9" % i for i in range(3)]
+    for i, b in enumerate(blobs):
+        open(os.path.join(folder, "color", "frame-%06d.color.jpg" % (i + 1)), "wb").write(b)
+    r = subprocess.run([exe, folder, out], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stderr == ""
+    sd = sens.SensorData(out)
+    assert [fr.color_size_bytes for fr in sd.frames] == [len(b) for b in blobs]
+    sd.close()
+    missing = subprocess.run([exe, str(tmp_path / "nope"), str(tmp_path / "nope.sens")], capture_output=True, text=True)
+    assert missing.returncode != 0 and "file not found" in missing.stderr
+    usage = subprocess.run([exe], capture_output=True, text=True)
+    assert usage.returncode != 0 and usage.stderr != ""
+
+
