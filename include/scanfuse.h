@@ -256,6 +256,40 @@ int sf_capture_convert(const sf_capture* c, const char* out_sens, sf_capture_col
                        int threads, sf_convert_stats* stats /*nullable*/);
 
 /* ------------------------------------------------------------------------------------------------
+ * `calibrate` stage, per-frame image operations on the GPU (scannet_amd/csrc/calibrate.hip).  Replaces the frame body of
+ * Calibration::calibrateScan, Calibrate/src/calibration.h:253-307: colour undistortion (:185-223), distance-dependent
+ * depth correction through the 3-D look-up table (:226-250, Grid3D::GetValue src/grid3d.cpp:119-151), depth undistortion,
+ * the depth-to-colour warp that the reference draws with Direct3D 11 (src/aligner.h:21-87, shaders/aligner.hlsl), "invalidate
+ * depth where we have no color" and the conversion back to u16 (:286-301).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct sf_calib_params {     /* class Calib, calibration.h:10-72; parameter-file keys :22-48 */
+  uint32_t color_width, color_height, depth_width, depth_height;
+  float color_intrinsic[16], depth_intrinsic[16];   /* row-major 4x4, fx [0], fy [5], mx [2], my [6] */
+  float depth_extrinsic[16];                        /* depthToColorExtrinsics */
+  float color_dist[5], depth_dist[5];               /* k1..k5: k1 k2 k5 radial, k3 k4 tangential (:204-209) */
+} sf_calib_params;
+typedef struct sf_lut {              /* Grid3D, src/grid3d.h: xres*yres*zres floats, index (z*yres + y)*xres + x */
+  int32_t xres, yres, zres;
+  float max_dist;
+  float* data;                       /* owned: sf_lut_free */
+} sf_lut;
+int sf_calib_params_load(const char* path, sf_calib_params* out);   /* "name = value" parameter file */
+int sf_lut_load(const char* path, sf_lut* out);                     /* Grid3D::ReadFile, grid3d.cpp:362-406 */
+void sf_lut_free(sf_lut* t);
+typedef struct sf_calibrator sf_calibrator;
+/* lut may be NULL (no distance correction).  depth_shift = the .sens header's (1000).  No CPU fallback. */
+int sf_calibrator_create(const sf_calib_params* p, const sf_lut* lut, float depth_shift, int device, sf_calibrator** out);
+void sf_calibrator_destroy(sf_calibrator* c);
+int sf_calibrator_max_batch(void);   /* frames per call: 16 */
+/* n frames per call, host buffers: rgb = colour_width*colour_height*3 bytes (or rgb_in == NULL: depth only), depth = W*H u16.
+ * rgb_out receives the undistorted colour image, depth_out the corrected, undistorted depth aligned to the colour camera. */
+int sf_calibrator_run(sf_calibrator* c, int n, const uint8_t* const* rgb_in, uint8_t* const* rgb_out, const uint16_t* const* depth_in,
+                      uint16_t* const* depth_out);
+/* the same on device buffers; kernel_us != NULL: synchronous, returns the duration of the batch's kernels in microseconds */
+int sf_calibrator_run_device(sf_calibrator* c, int n, const void* const* d_rgb_in, void* const* d_rgb_out, const void* const* d_depth_in,
+                             void* const* d_depth_out, float* kernel_us);
+
+/* ------------------------------------------------------------------------------------------------
  * Triangle meshes and the PLY surface (README.md:45-46: binary little-endian PLY, vertex float x,y,z +
  * uchar red,green,blue,alpha, face list uchar int vertex_indices).  sf_ply_read replaces tinyply as the
  * Segmentator uses it (Segmentator/segmentator.cpp:131-141, tinyply.cpp:54-108,306-360): ascii / binary

@@ -196,3 +196,57 @@ def ref_sens():
         L.ref_sens_save.argtypes = [C.c_void_p, C.c_char_p]
         _ref = L
     return _ref
+
+
+# ---------------------------------------------------------------- calibrate stage (oracle/calib_oracle.c)
+class OrCalib(C.Structure):
+    _fields_ = [("color_width", C.c_uint32), ("color_height", C.c_uint32), ("depth_width", C.c_uint32), ("depth_height", C.c_uint32),
+                ("color_intrinsic", C.c_float * 16), ("depth_intrinsic", C.c_float * 16), ("depth_extrinsic", C.c_float * 16),
+                ("color_dist", C.c_float * 5), ("depth_dist", C.c_float * 5)]
+
+
+class OrLut(C.Structure):
+    _fields_ = [("xres", C.c_int32), ("yres", C.c_int32), ("zres", C.c_int32), ("max_dist", C.c_float), ("data", C.c_void_p)]
+
+
+def calib_lib():
+    L = lib()
+    vp = C.c_void_p
+    L.or_calib_undistort_rgb.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
+    L.or_calib_undistort_f32.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.c_float]
+    L.or_calib_undistort_distance.argtypes = [vp, C.c_int, C.c_int, C.POINTER(OrLut), C.c_float]
+    L.or_calib_depth_to_color.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(OrCalib), C.c_float]
+    L.or_calib_depth_to_color_splat.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(OrCalib), C.c_float]
+    L.or_calib_frame.argtypes = [C.POINTER(OrCalib), C.POINTER(OrLut), C.c_float, vp, vp, vp, vp]
+    return L
+
+
+def calib_from(params):
+    """OrCalib from a scannet_amd.calibrate.SfCalibParams-like object (same field names)."""
+    o = OrCalib()
+    for name, _ in OrCalib._fields_:
+        v = getattr(params, name)
+        if hasattr(v, "__len__"):
+            for i in range(len(v)):
+                getattr(o, name)[i] = v[i]
+        else:
+            setattr(o, name, v)
+    return o
+
+
+def calib_frame(cb, depth, rgb=None, lut_grid=None, lut_max_dist=0.0, shift=1000.0):
+    """One frame through calibrateScan's body -> (depth_out uint16 [H, W], rgb_out or None)."""
+    L = calib_lib()
+    d = np.ascontiguousarray(depth, np.uint16)
+    dout = np.empty_like(d)
+    lut = None
+    if lut_grid is not None:
+        g = np.ascontiguousarray(lut_grid, np.float32)
+        lut = OrLut(g.shape[2], g.shape[1], g.shape[0], float(lut_max_dist), g.ctypes.data)
+    rin = rout = None
+    if rgb is not None:
+        rin = np.ascontiguousarray(rgb, np.uint8)
+        rout = np.empty_like(rin)
+    L.or_calib_frame(C.byref(cb), C.byref(lut) if lut is not None else None, float(shift), rin.ctypes.data if rin is not None else None,
+                     rout.ctypes.data if rout is not None else None, d.ctypes.data, dout.ctypes.data)
+    return dout, rout
