@@ -7,6 +7,7 @@
 //   k_depth_prepare     undistortDistance (3-D look-up table, trilinear)      calibration.h:226-250, grid3d.cpp:119-151
 //                       + u16 -> metres + Calibration::undistort on depth     calibration.h:275-281, fused: the table correction
 //                       is pointwise on the SOURCE pixel, so the undistorted image gathers corrected source pixels directly
+//                       + the mesh vertex of the pixel (aligner.hlsl:66-103), once per pixel instead of once per quad corner
 //   k_raster_quads      Aligner::depthToColor: the depth image as a quad mesh projected into the colour camera and drawn
 //                       with a depth test                                     aligner.hlsl:52-166, aligner.h:24-81
 //   k_finalize          depth buffer -> metres, "invalidate depth where we have no color", -> u16   calibration.h:286-301
@@ -124,10 +125,13 @@ __device__ inline float lut_value(const float* __restrict__ t, int xr, int yr, i
   return v;
 }
 
+struct Vert { float px, py, z; bool ok; };
+__device__ inline Vert quad_vertex(float d, const CalibK& P, int x, int y);
+
 // per OUTPUT depth pixel: where it samples the distorted image, that source pixel's table-corrected depth in metres;
 // also clears the depth buffer of the draw
 __global__ __launch_bounds__(256) void k_depth_prepare(CalibBatch B, CalibK P, const float* __restrict__ lut, float* __restrict__ und_all,
-                                                       uint32_t* __restrict__ zbuf_all) {
+                                                       uint32_t* __restrict__ zbuf_all, float4* __restrict__ vert_all) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int n = P.w * P.h;
   if (i >= n) return;
@@ -153,13 +157,13 @@ __global__ __launch_bounds__(256) void k_depth_prepare(CalibBatch B, CalibK P, c
   }
   und[i] = v;
   zbuf[i] = __float_as_uint(1.0f);
+  // the mesh vertex of this pixel (aligner.hlsl:66-103), computed once here instead of by each of the four quads that share it
+  const Vert q = quad_vertex(v, P, (int)x, (int)y);
+  vert_all[(size_t)blockIdx.z * n + i] = make_float4(q.px, q.py, q.z, q.ok ? 1.0f : 0.0f);
 }
 
-struct Vert { float px, py, z; bool ok; };
-
 // aligner.hlsl:52-103 + viewport transform
-__device__ inline Vert quad_vertex(const float* __restrict__ depth, const CalibK& P, int x, int y) {
-  const float d = depth[(size_t)y * P.w + x];
+__device__ inline Vert quad_vertex(float d, const CalibK& P, int x, int y) {
   const float ax = (float)x * d, ay = (float)y * d;
   const float* Ki = P.Kinv;
   const float* E = P.E;
@@ -230,7 +234,8 @@ __device__ inline void raster_tri(uint32_t* __restrict__ zbuf, int w, int h, con
 }
 
 // one lane per quad (x, y), x < w-1, y < h-1 (aligner.hlsl:131-173)
-__global__ __launch_bounds__(256) void k_raster_quads(CalibK P, const float* __restrict__ und_all, uint32_t* __restrict__ zbuf_all) {
+__global__ __launch_bounds__(256) void k_raster_quads(CalibK P, const float* __restrict__ und_all, const float4* __restrict__ vert_all,
+                                                      uint32_t* __restrict__ zbuf_all) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int n = P.w * P.h;
   if (i >= n) return;
@@ -244,10 +249,12 @@ __global__ __launch_bounds__(256) void k_raster_quads(CalibK P, const float* __r
   const float dmax = fmaxf(fmaxf(d0, d1), fmaxf(d2, d3)), dmin = fminf(fminf(d0, d1), fminf(d2, d3));
   const float dm = 0.5f * (dmax + dmin);
   if (dmax - dmin > 0.01f + 0.05f * dm) return;  // aligner.h:31-32, aligner.hlsl:154
-  const Vert v0 = quad_vertex(depth, P, x, y + 1);
-  const Vert v1 = quad_vertex(depth, P, x, y);
-  const Vert v2 = quad_vertex(depth, P, x + 1, y + 1);
-  const Vert v3 = quad_vertex(depth, P, x + 1, y);
+  const float4* __restrict__ vert = vert_all + (size_t)blockIdx.z * n;
+  auto load = [&](int xx, int yy) {
+    const float4 q = vert[(size_t)yy * P.w + xx];
+    return Vert{q.x, q.y, q.z, q.w != 0.0f};
+  };
+  const Vert v0 = load(x, y + 1), v1 = load(x, y), v2 = load(x + 1, y + 1), v3 = load(x + 1, y);
   if (!(v0.ok && v1.ok && v2.ok && v3.ok)) return;
   raster_tri(zbuf, P.w, P.h, v0, v1, v2);
   raster_tri(zbuf, P.w, P.h, v1, v2, v3);
@@ -284,6 +291,7 @@ struct sf_calibrator {
   float* lut = nullptr;
   float* und = nullptr;      // CALIB_MAX_BATCH x W*H undistorted depth in metres
   uint32_t* zbuf = nullptr;  // CALIB_MAX_BATCH x W*H depth buffer
+  float4* vert = nullptr;    // CALIB_MAX_BATCH x W*H mesh vertices {target x, target y, projected z, valid}
   // staging for the host-pointer entry point
   uint8_t *d_rgb_in = nullptr, *d_rgb_out = nullptr;
   uint16_t *d_depth_in = nullptr, *d_depth_out = nullptr;
@@ -367,7 +375,7 @@ SF_API void sf_calibrator_destroy(sf_calibrator* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (void* p : {(void*)c->lut, (void*)c->und, (void*)c->zbuf, (void*)c->d_rgb_in, (void*)c->d_rgb_out, (void*)c->d_depth_in, (void*)c->d_depth_out})
+  for (void* p : {(void*)c->lut, (void*)c->und, (void*)c->zbuf, (void*)c->vert, (void*)c->d_rgb_in, (void*)c->d_rgb_out, (void*)c->d_depth_in, (void*)c->d_depth_out})
     if (p) (void)hipFree(p);
   if (c->e0) (void)hipEventDestroy(c->e0);
   if (c->e1) (void)hipEventDestroy(c->e1);
@@ -423,6 +431,7 @@ SF_API int sf_calibrator_create(const sf_calib_params* p, const sf_lut* lut, flo
   }
   CAL_ALLOC(c->und, n * 4 * CALIB_MAX_BATCH);
   CAL_ALLOC(c->zbuf, n * 4 * CALIB_MAX_BATCH);
+  CAL_ALLOC(c->vert, n * 16 * CALIB_MAX_BATCH);
   CAL_ALLOC(c->d_rgb_in, cn * 3 * CALIB_MAX_BATCH);
   CAL_ALLOC(c->d_rgb_out, cn * 3 * CALIB_MAX_BATCH);
   CAL_ALLOC(c->d_depth_in, n * 2 * CALIB_MAX_BATCH);
@@ -459,8 +468,8 @@ SF_API int sf_calibrator_run_device(sf_calibrator* c, int n, const void* const* 
   const size_t cn = (size_t)k.cw * k.ch;
   if (kernel_us) SF_HIP_CHECK(hipEventRecord(c->e0, c->stream));
   if (rgb) hipLaunchKernelGGL(k_undistort_rgb, dim3((unsigned)((cn / 4 + 1 + 255) / 256), 1, n), dim3(256), 0, c->stream, b, k);
-  hipLaunchKernelGGL(k_depth_prepare, dim3((np + 255) / 256, 1, n), dim3(256), 0, c->stream, b, k, c->lut, c->und, c->zbuf);
-  hipLaunchKernelGGL(k_raster_quads, dim3((np + 255) / 256, 1, n), dim3(256), 0, c->stream, k, c->und, c->zbuf);
+  hipLaunchKernelGGL(k_depth_prepare, dim3((np + 255) / 256, 1, n), dim3(256), 0, c->stream, b, k, c->lut, c->und, c->zbuf, c->vert);
+  hipLaunchKernelGGL(k_raster_quads, dim3((np + 255) / 256, 1, n), dim3(256), 0, c->stream, k, c->und, c->vert, c->zbuf);
   hipLaunchKernelGGL(k_finalize, dim3((np + 255) / 256, 1, n), dim3(256), 0, c->stream, b, k, c->zbuf);
   SF_HIP_CHECK(hipGetLastError());
   if (kernel_us) {
