@@ -31,7 +31,43 @@ def _lib():
     L.sf_calibrator_destroy.restype = None
     L.sf_calibrator_run.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     L.sf_calibrator_run_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.POINTER(C.c_float)]
+    L.sf_calibrate_sens.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(SfCalibrateStats)]
+    L.sf_jpeg_encode.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, vp, C.c_uint64, C.POINTER(C.c_uint64)]
     return L
+
+
+class SfCalibrateStats(C.Structure):
+    _fields_ = [("frames", C.c_uint64), ("frames_with_colour", C.c_uint64), ("skipped_existing", C.c_int32), ("already_aligned", C.c_int32),
+                ("seconds_total", C.c_double), ("threads", C.c_uint32)]
+
+
+def calibrate_sens(in_sens, out_sens, params_txt, lut_path=None, device=0, threads=0):
+    """Calibration::calibrateScan(inSens, outSens, params, table): the whole stage on one file."""
+    st = SfCalibrateStats()
+    check(_lib().sf_calibrate_sens(os.fsencode(in_sens), os.fsencode(out_sens), os.fsencode(params_txt),
+                                   os.fsencode(lut_path) if lut_path else None, int(device), int(threads), C.byref(st)))
+    return {n: getattr(st, n) for n, _ in SfCalibrateStats._fields_}
+
+
+def jpeg_encode(rgb, quality=90, subsample=True):
+    """Baseline JPEG blob of an [H, W, 3] uint8 image (what the stage writes for TYPE_JPEG colour)."""
+    a = np.ascontiguousarray(rgb, np.uint8)
+    h, w = a.shape[:2]
+    out = np.empty(a.size + 65536, np.uint8)
+    n = C.c_uint64(0)
+    check(_lib().sf_jpeg_encode(a.ctypes.data, w, h, int(quality), 1 if subsample else 0, out.ctypes.data, out.size, C.byref(n)))
+    return out[:n.value].tobytes()
+
+
+def write_params(path, p):
+    """A parameter file with the keys Calib::readFromFile reads (calibration.h:22-48)."""
+    with open(path, "w") as f:
+        f.write("colorWidth = %d\ncolorHeight = %d\ndepthWidth = %d\ndepthHeight = %d\n" % (p.color_width, p.color_height, p.depth_width, p.depth_height))
+        for tag, K, dist in (("color", p.color_intrinsic, p.color_dist), ("depth", p.depth_intrinsic, p.depth_dist)):
+            f.write("fx_%s = %r\nfy_%s = %r\nmx_%s = %r\nmy_%s = %r\n" % (tag, float(K[0]), tag, float(K[5]), tag, float(K[2]), tag, float(K[6])))
+            for i in range(5):
+                f.write("k%d_%s = %r\n" % (i + 1, tag, float(dist[i])))
+        f.write("depthToColorExtrinsics = %s\n" % " ".join(repr(float(v)) for v in p.depth_extrinsic))
 
 
 def make_params(color_wh, depth_wh, color_K, depth_K, depth_to_color=None, color_dist=(0,) * 5, depth_dist=(0,) * 5):

@@ -146,6 +146,48 @@ def test_frame_golden():
     assert (band == 0).all() and (do2[:, 450:455] > 0).any()
 
 
+def test_parameter_and_table_files(tmp_path):
+    p = _full_params()
+    calibrate.write_params(str(tmp_path / "dev.txt"), p)
+    q = calibrate.load_params(str(tmp_path / "dev.txt"))
+    for name, _ in calibrate.SfCalibParams._fields_:
+        a, b = getattr(p, name), getattr(q, name)
+        assert (list(a) == list(b)) if hasattr(a, "__len__") else (a == b), name
+    grid, maxd = _lut()
+    calibrate.write_lut(str(tmp_path / "dev.lut"), grid, maxd)
+    t = calibrate.SfLut()
+    L = calibrate._lib()
+    assert L.sf_lut_load(str(tmp_path / "dev.lut").encode(), C.byref(t)) == 0
+    assert (t.xres, t.yres, t.zres, t.max_dist) == (64, 48, 10, 10.0)
+    assert np.array_equal(np.ctypeslib.as_array(t.data, (10, 48, 64)), grid)
+    L.sf_lut_free(C.byref(t))
+    open(tmp_path / "bad.lut", "wb").write(b"\x01\x00\x00\x00")
+    assert L.sf_lut_load(str(tmp_path / "bad.lut").encode(), C.byref(t)) != 0
+
+
+def test_jpeg_encoder_round_trip():
+    """The colour re-encode of the stage (sensorData.h:565-596 TYPE_JPEG): a baseline JPEG every reader decodes."""
+    import io
+    from PIL import Image
+    from scannet_amd import sens
+    y, x = np.mgrid[0:97, 0:131]                        # odd sizes: partial MCUs
+    img = np.stack([x * 255 // 131, y * 255 // 97, (128 + 100 * np.sin(x / 9.0) * np.cos(y / 7.0))], -1).astype(np.uint8)
+    img[20:40, 50:80] = (255, 0, 0)
+    for sub, floor_db in ((True, 33.0), (False, 40.0)):
+        blob = calibrate.jpeg_encode(img, 90, sub)
+        assert blob[:2] == b"\xff\xd8" and blob[-2:] == b"\xff\xd9"
+        pil = np.array(Image.open(io.BytesIO(blob)).convert("RGB")).astype(float)
+        psnr = 10 * np.log10(255.0 ** 2 / ((pil - img) ** 2).mean())
+        assert psnr > floor_db, psnr
+        # ... including this repository's own decoder, through a .sens
+        K = np.eye(4, dtype=np.float32)
+        sd = sens.SensorData.create(131, 97, 8, 8, K, K, color_compression=2, depth_compression=1)
+        sd.add_frame(np.zeros((8, 8), np.uint16), np.eye(4, dtype=np.float32), color=blob)
+        mine = sd.frames[0].decompress_color().astype(float)
+        assert np.abs(mine - pil).max() <= 6 and np.abs(mine - pil).mean() < 1.0
+        sd.close()
+
+
 # ---------------------------------------------------------------------------------------------------- GPU: parity
 @pytest.mark.gpu
 def test_gpu_matches_the_checker_bit_for_bit():
@@ -193,3 +235,74 @@ def test_gpu_edge_cases():
         dout, rout = cal.run(d[None], rgb[None])
         do, ro = orc.calib_frame(cb, d, rgb)
         assert np.array_equal(rout[0], ro) and np.array_equal(dout[0], do)
+
+
+@pytest.mark.gpu
+def test_stage_and_cli(tmp_path):
+    """calibrate.exe in.sens out.sens devices.csv devices_dir (Server/scan_processor.py:118): header rewrite, frames, file handling."""
+    import subprocess
+    from scannet_amd import sens
+    p = _full_params()
+    cb = orc.calib_from(p)
+    grid, maxd = _lut()
+    scan = tmp_path / "scan7"
+    scan.mkdir()
+    devdir = tmp_path / "devices"
+    devdir.mkdir()
+    calibrate.write_params(str(devdir / "structure_A.txt"), p)
+    calibrate.write_lut(str(devdir / "structure_A.lut"), grid, maxd)
+    (tmp_path / "devices.csv").write_text("name,id,calibration_name\nfoo,dev-123,structure_A\nbar,dev-999,other\n")
+    (scan / "scan7.txt").write_text("colorWidth = 1296\r\ndeviceId = dev-123\r\nnumDepthFrames = 3\r\n")
+    Kc = np.array(p.color_intrinsic, np.float32).reshape(4, 4)
+    Kd = np.array(p.depth_intrinsic, np.float32).reshape(4, 4)
+    n = 3
+    frames = []
+    yy, xx = np.mgrid[0:CH, 0:CW]
+    for i in range(n):                                           # a compressible colour image (per-pixel noise is not JPEG's domain)
+        d, _ = _scene(frame=40 + i, seed=i + 1)
+        rgb = np.stack([60 + xx * 150 // CW + 10 * i, 40 + yy * 180 // CH, 128 + 90 * np.sin(xx / 40.0) * np.cos(yy / 55.0)], -1).astype(np.uint8)
+        rgb[:, 900:930] = 0
+        frames.append((d, rgb))
+    sd = sens.SensorData.create(CW, CH, W, H, Kc, Kd, color_compression=2, depth_compression=1, sensor_name="StructureSensor",
+                                extrinsic_depth=np.array(p.depth_extrinsic, np.float32).reshape(4, 4))
+    poses = [np.eye(4, dtype=np.float32) for _ in range(n)]
+    poses[1][0, 3] = 0.25
+    for i, (d, rgb) in enumerate(frames):
+        sd.add_frame(d, poses[i], color=calibrate.jpeg_encode(rgb, 95, False), timestamp_color=1000 + i, timestamp_depth=2000 + i)
+    src = str(scan / "scan7.uncalibrated.sens")
+    sd.save(src)
+    decoded = [fr.decompress_color() for fr in sd.frames]     # what the stage sees after JPEG decode
+    sd.close()
+    dst = str(scan / "scan7.sens")
+    exe = os.path.join(ROOT, "bin", "calibrate")
+    r = subprocess.run([exe, src, dst, str(tmp_path / "devices.csv"), str(devdir)], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stderr == "", r.stderr
+    assert "calibration name: structure_A" in r.stdout and "3 frames" in r.stdout
+    assert os.path.exists(dst) and not os.path.exists(src)                  # calibration.h:135: the input is consumed
+    out = sens.SensorData(dst)
+    assert out.sensor_name == "StructureSensor (calibrated)" and out.num_frames == n
+    assert np.array_equal(out.extrinsic_depth, np.eye(4, dtype=np.float32)) and np.array_equal(out.extrinsic_color, np.eye(4, dtype=np.float32))
+    assert np.array_equal(out.intrinsic_color, Kc)
+    want = Kc.copy()                                                         # calibration.h:123-128
+    want[0, 0] *= np.float32(W) / np.float32(CW)
+    want[1, 1] *= np.float32(H) / np.float32(CH)
+    want[0, 2] *= np.float32(W - 1) / np.float32(CW - 1)
+    want[1, 2] *= np.float32(H - 1) / np.float32(CH - 1)
+    assert np.array_equal(out.intrinsic_depth, want)
+    for i, fr in enumerate(out.frames):
+        do, ro = orc.calib_frame(cb, frames[i][0], decoded[i], grid, maxd)
+        assert np.array_equal(fr.decompress_depth(), do), i
+        got = fr.decompress_color().astype(float)                            # re-encoded at quality 90, 4:2:0: close to the undistorted image
+        assert 10 * np.log10(255.0 ** 2 / ((got - ro) ** 2).mean()) > 30.0
+        assert np.array_equal(fr.camera_to_world, poses[i]) and (fr.timestamp_color, fr.timestamp_depth) == (1000 + i, 2000 + i)
+    out.close()
+    # an aligned file is moved untouched; a missing input with the output present is skipped; unknown device: nothing to do
+    st = calibrate.calibrate_sens(dst, str(scan / "moved.sens"), str(devdir / "structure_A.txt"), str(devdir / "structure_A.lut"))
+    assert st["already_aligned"] == 1 and os.path.exists(scan / "moved.sens") and not os.path.exists(dst)
+    st = calibrate.calibrate_sens(dst, str(scan / "moved.sens"), str(devdir / "structure_A.txt"), None)
+    assert st["skipped_existing"] == 1
+    with pytest.raises(Exception, match="no sens file"):
+        calibrate.calibrate_sens(dst, str(scan / "nothing.sens"), str(devdir / "structure_A.txt"), None)
+    (scan / "scan7.txt").write_text("deviceId = unknown-device\r\n")
+    r = subprocess.run([exe, str(scan / "moved.sens"), dst, str(tmp_path / "devices.csv"), str(devdir)], capture_output=True, text=True)
+    assert r.returncode == 0 and "no calibration name found" in r.stdout and os.path.exists(scan / "moved.sens")
