@@ -74,8 +74,10 @@ def pmc_traffic(steps, warmup, timeout_s=300, single_frame=False):
                     child_line = json.loads(ln)
             db = sqlite3.connect(dbs[0])
             # the integrate launches of the timed region are the LAST `steps` dispatches of the kernel (warm-up comes first)
-            rows = [v for (v,) in db.execute("select value from counters_collection where counter_name = ? and kernel_name like "
-                                             "'%k_integrate<1, false%' order by dispatch_id", (counter,))]
+            # one frame per launch (SF_BATCH=1) runs the software-pipelined k_integrate_pipe, batches run k_integrate
+            pat = "%k_integrate_pipe%" if single_frame else "%k_integrate<1, false%"
+            rows = [v for (v,) in db.execute("select value from counters_collection where counter_name = ? and kernel_name like ? "
+                                             "order by dispatch_id", (counter, pat))]
             db.close()
             launches = child_line["config"]["integrate_launches"] if child_line else 0
             if launches <= 0 or len(rows) < launches:
@@ -196,7 +198,7 @@ def main():
 
     m = run(Wm, K, not args.no_profile, single_frame=args.single_frame)
     if rank == 0:
-        roof = roofline(m, K, "k_integrate<1,false,true,true>")
+        roof = roofline(m, K, "k_integrate_pipe<true,true>" if m["batch"] == 1 else "k_integrate<1,false,true,true>")
         if roof is not None and m["ceiling"]:
             roof["pattern_ceiling"] = dict(m["ceiling"], frac_of_ceiling=round(roof["achieved"] / m["ceiling"]["rmw_copy_GBs"], 4))
         if roof is not None and m["batch"] > 1:
@@ -229,7 +231,8 @@ def main():
             # the same kernel HBM-bound: one frame per launch (what sf_fuser_integrate does for a live stream)
             ks = min(K, 1200)
             m1 = run(Wm, ks, True, single_frame=True)
-            r1 = roofline(m1, ks, "k_integrate<1,false,true,true>, one frame per launch (SF_BATCH=1)")
+            r1 = roofline(m1, ks, "k_integrate_pipe<true,true>: one frame per launch (SF_BATCH=1), persistent, software-pipelined "
+                                  "(tiles and depth gathers of later tiles in flight into LDS), everything on one stream")
             if r1 is not None:
                 r1["frames_per_s"] = round(ks / m1["elapsed"], 1)
                 if m1["ceiling"]:

@@ -496,22 +496,13 @@ __device__ inline int cvt_i32(float x) {  // v_cvt_i32_f32: truncates, saturates
 // TAB: the weighted-mean division goes through the LDS reciprocal table (integrate with 1 <= weight_sample <= 256).
 // Rows [J0, J0 + NJ) of the tile (a row = the 64 x 2 voxels one 16 B load per lane covers).  NJ = 4 gives the most
 // independent work per issue slot, NJ = 2 called twice halves the live registers (single-frame, occupancy-bound variant).
-template <int SIGN, bool COLOR, bool TAB, bool WS1, int J0, int NJ>
-__device__ inline void fuse_rows(const ParamsK& P, const float* __restrict__ Ti, const float* __restrict__ depthf,
-                                 const uint32_t* __restrict__ color, const float* rtab, v2f wx, float wy, const float (&wz)[4],
-                                 uint4 (&v)[4], bool (&dirty)[4]) {
-  v2f pz[NJ], rcp_m[NJ];
-  float d[2 * NJ];
-  uint32_t c[2 * NJ];
-  bool ok[2 * NJ];
-  uint32_t pix[2 * NJ];  // unsigned 32-bit offsets: SGPR base + VGPR offset addressing, no 64-bit pointer arithmetic per gather
-  // the weights are known before anything else: start the eight table reads now, they are consumed in phase B
-  if (TAB) {
-#pragma unroll
-    for (int j = 0; j < NJ; j++) rcp_m[j] = (v2f){rtab[(v[J0 + j].y >> 24) + (uint32_t)P.wsample], rtab[(v[J0 + j].w >> 24) + (uint32_t)P.wsample]};
-  }
+// Phase A of one frame on rows [J0, J0 + NJ): camera-space z of the lane's voxel pairs, the pixel each voxel projects to
+// (0 when it projects outside) and whether it projects inside.
+template <int J0, int NJ>
+__device__ inline void fuse_project(const ParamsK& P, const float* __restrict__ Ti, v2f wx, float wy, const float (&wz)[4], v2f (&pz)[NJ],
+                                    uint32_t (&pix)[2 * NJ], bool (&ok)[2 * NJ]) {
   const uint32_t wbits = __float_as_uint((float)P.W), hbits = __float_as_uint((float)P.H);
-  // ---- phase A: project, gather.  Row constants first, two rows or two components per packed instruction:
+  // Row constants first, two rows or two components per packed instruction:
   //      a{x,y}_j = fma(Ti[1|5], wy, fma(Ti[2|6], wz_j, Ti[3|7])),  az_j = fma(Ti[9], wy, fma(Ti[10], wz_j, Ti[11]))
   v2f axy[NJ], azz[NJ / 2];
 #pragma unroll
@@ -538,11 +529,12 @@ __device__ inline void fuse_rows(const ParamsK& P, const float* __restrict__ Ti,
       pix[2 * j + hx] = in ? p : 0u;
     }
   }
-#pragma unroll
-  for (int k = 0; k < 2 * NJ; k++) {
-    d[k] = depthf[pix[k]];
-    if (COLOR) c[k] = color[pix[k]];
-  }
+}
+
+// Phase B: the update of DESIGN.md 3.5 from the gathered depths (colours) into the tile registers.
+template <int SIGN, bool COLOR, bool TAB, bool WS1, int J0, int NJ>
+__device__ inline void fuse_update(const ParamsK& P, const v2f (&rcp_m)[NJ], const float (&d)[2 * NJ], const uint32_t (&c)[2 * NJ], const v2f (&pz)[NJ],
+                                   const bool (&ok)[2 * NJ], uint4 (&v)[4], bool (&dirty)[4]) {
   // ---- phase B: new values into temporaries (the tile itself stays untouched until the end)
   const float wn = (float)P.wsample;
   const uint32_t maxd_bits = __float_as_uint(P.maxd);
@@ -623,6 +615,31 @@ __device__ inline void fuse_rows(const ParamsK& P, const float* __restrict__ Ti,
   }
 }
 
+
+template <int SIGN, bool COLOR, bool TAB, bool WS1, int J0, int NJ>
+__device__ inline void fuse_rows(const ParamsK& P, const float* __restrict__ Ti, const float* __restrict__ depthf,
+                                 const uint32_t* __restrict__ color, const float* rtab, v2f wx, float wy, const float (&wz)[4],
+                                 uint4 (&v)[4], bool (&dirty)[4]) {
+  v2f pz[NJ], rcp_m[NJ];
+  float d[2 * NJ];
+  uint32_t c[2 * NJ];
+  bool ok[2 * NJ];
+  uint32_t pix[2 * NJ];  // unsigned 32-bit offsets: SGPR base + VGPR offset addressing, no 64-bit pointer arithmetic per gather
+  // the weights are known before anything else: start the eight table reads now, they are consumed in phase B
+  if (TAB) {
+#pragma unroll
+    for (int j = 0; j < NJ; j++) rcp_m[j] = (v2f){rtab[(v[J0 + j].y >> 24) + (uint32_t)P.wsample], rtab[(v[J0 + j].w >> 24) + (uint32_t)P.wsample]};
+  }
+  // ---- phase A: project; then the gathers, all issued together
+  fuse_project<J0, NJ>(P, Ti, wx, wy, wz, pz, pix, ok);
+#pragma unroll
+  for (int k = 0; k < 2 * NJ; k++) {
+    d[k] = depthf[pix[k]];
+    if (COLOR) c[k] = color[pix[k]];
+  }
+  fuse_update<SIGN, COLOR, TAB, WS1, J0, NJ>(P, rcp_m, d, c, pz, ok, v, dirty);
+}
+
 // 4 waves per SIMD (<= 128 VGPRs).  Tried for the one-frame-per-launch case: 5 waves / 96 VGPRs with the tile in two
 // half passes -- the spills cost more than the occupancy buys (183 us vs 112 us per launch).
 template <int SIGN, bool COLOR, bool TAB, bool WS1>
@@ -686,6 +703,189 @@ __global__ __launch_bounds__(256, 4) void k_integrate(uint4* __restrict__ voxels
 #pragma unroll
     for (int j = 0; j < 4; j++)
       if (dirty[j]) vb[j * 64 + lane] = v[j];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K4p: the same update for the HBM-bound regime (ONE frame per launch: a live stream, SF_BATCH=1), software-pipelined.
+// In k_integrate every wave is a serial chain  tile load -> project -> 8 depth gathers -> update -> store  and a SIMD holds
+// four chains; measured the chains, not HBM, bound it.  Here a persistent wave walks its share of the list
+// and keeps three things in flight for LATER tiles while it updates tile k in registers:
+//   * tile k+2 and k+3 travel HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, four 1 KiB requests per tile, no VGPRs) into
+//     a two-slot ring per wave;
+//   * the eight depth gathers of tile k+1 (projected one turn early) land in LDS as well (global_load_lds_dword: per-lane
+//     source address, lane-linear destination), two 2 KiB slots per wave;
+// so nothing asynchronous ever targets a VGPR and every wait is a hand-counted s_waitcnt vmcnt(N) (vector-memory operations
+// return in order: "at most N outstanding" = everything but the N youngest has landed).  Per turn k the issue order is
+//   [tile k+1's stores of the previous turn: S(k-1)]  G(k+1) x8  D(k+3) x4   and the two waits are
+//   top : tile k+1 (requested two turns ago) has landed      -- younger: S(k-2)? G(k) 8, D(k+2) 4, S(k-1)  => vmcnt(12)
+//   mid : the gathers of tile k (issued last turn) have landed -- younger: D(k+2) 4, S(k-1), G(k+1) 8, D(k+3) 4 => vmcnt(16)
+// (stores only make the true count larger, i.e. the waits conservative).  hipcc never sees these loads (it would wait
+// vmcnt(0) at every use while an LDS-DMA is in flight); it only sees ordinary ds_reads after the waits.
+// LDS per wave: 2 x 4 KiB tiles + 2 x 2 KiB gathers = 12 KiB => 3 workgroups (12 waves) per CU.  Geometry only, no colour:
+// the colour variant stays on k_integrate.  Arithmetic = fuse_project / fuse_update, bit-identical to k_integrate.
+// ---------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <bool TAB, bool WS1>
+__global__ __launch_bounds__(256, 3) void k_integrate_pipe(uint4* __restrict__ voxels, const uint64_t* __restrict__ block_keys,
+                                                        const int32_t* __restrict__ compact, const float* __restrict__ depthf, int32_t* counters,
+                                                        int32_t* host_mirror, int compact_counter, ParamsK P, BatchTi B) {
+  __shared__ float s_rtab[RTAB];
+  __shared__ uint4 s_tile[4][2][256];   // per wave: two 4 KiB tile slots
+  __shared__ float s_gath[4][2][512];   // per wave: two slots of 8 gathers x 64 lanes
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int stride = (int)gridDim.x * 4;
+  const int i0 = (int)blockIdx.x * 4 + wave;
+  const int n = counters[compact_counter];
+  uint4* const ring = &s_tile[wave][0][0];
+  float* const gath = &s_gath[wave][0][0];
+  const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_ptr_t)ring);
+  const uint32_t gath_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_ptr_t)gath);
+  auto slot_of = [&](int i) { return i < n ? __builtin_amdgcn_readfirstlane(compact[i]) : 0; };
+  // LDS-DMA of one tile (4 x 1 KiB) into ring slot `ts`; the immediate offset applies to the global AND the LDS address
+  auto dma_tile = [&](int slot, int ts) {
+    const uint4* src = voxels + (size_t)slot * 256 + lane;
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %[src], off\n\tglobal_load_lds_dwordx4 %[src], off offset:1024\n\t"
+        "global_load_lds_dwordx4 %[src], off offset:2048\n\tglobal_load_lds_dwordx4 %[src], off offset:3072\n\t"
+        "s_mov_b32 m0, %[keep]"
+        : [keep] "=&s"(keep)
+        : [src] "v"(src), [lds] "s"(ring_lds + (uint32_t)ts * 4096u)
+        : "memory");
+  };
+  // the 8 gathers of one tile into gather slot `gs` (request j -> bytes [256 j, 256 j + 256) of the slot)
+  auto gather8 = [&](const uint32_t (&pix)[8], int gs) {
+    uint32_t o[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) o[k] = pix[k] << 2;
+    uint32_t keep;
+    const uint32_t base = gath_lds + (uint32_t)gs * 2048u;
+    asm volatile(
+        "s_mov_b32 %[keep], m0\n\t"
+        "s_mov_b32 m0, %[b]\n\ts_nop 0\n\tglobal_load_lds_dword %[o0], %[d]\n\t"
+        "s_add_u32 m0, %[b], 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %[o1], %[d]\n\t"
+        "s_add_u32 m0, %[b], 0x200\n\ts_nop 0\n\tglobal_load_lds_dword %[o2], %[d]\n\t"
+        "s_add_u32 m0, %[b], 0x300\n\ts_nop 0\n\tglobal_load_lds_dword %[o3], %[d]\n\t"
+        "s_add_u32 m0, %[b], 0x400\n\ts_nop 0\n\tglobal_load_lds_dword %[o4], %[d]\n\t"
+        "s_add_u32 m0, %[b], 0x500\n\ts_nop 0\n\tglobal_load_lds_dword %[o5], %[d]\n\t"
+        "s_add_u32 m0, %[b], 0x600\n\ts_nop 0\n\tglobal_load_lds_dword %[o6], %[d]\n\t"
+        "s_add_u32 m0, %[b], 0x700\n\ts_nop 0\n\tglobal_load_lds_dword %[o7], %[d]\n\t"
+        "s_mov_b32 m0, %[keep]"
+        : [keep] "=&s"(keep)
+        : [o0] "v"(o[0]), [o1] "v"(o[1]), [o2] "v"(o[2]), [o3] "v"(o[3]), [o4] "v"(o[4]), [o5] "v"(o[5]), [o6] "v"(o[6]), [o7] "v"(o[7]),
+          [d] "s"(depthf), [b] "s"(base)
+        : "memory", "scc");
+  };
+  if (TAB) {
+    for (int t = threadIdx.x; t < RTAB; t += 256) s_rtab[t] = 1.0f / (float)(t > 0 ? t : 1);
+    __syncthreads();
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    atomicExch(&counters[C_LAST_BLOCKS], counters[compact_counter + 1]);
+    if (host_mirror) *host_mirror = n;
+  }
+  if (i0 >= n) return;
+  const int lx = (2 * lane) & 7;
+  const int ly = (lane >> 2) & 7;
+  const int lzb = lane >> 5;
+  const float* Ti = B.Ti[0];
+  auto project = [&](uint64_t key, v2f (&pz)[4], uint32_t (&pix)[8], uint32_t& okmask) {
+    int bx, by, bz;
+    unpack_key(key, bx, by, bz);
+    const v2f wx = {(float)(8 * bx + lx) * P.voxel, (float)(8 * bx + lx + 1) * P.voxel};
+    const float wy = (float)(8 * by + ly) * P.voxel;
+    float wz[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) wz[j] = (float)(8 * bz + 2 * j + lzb) * P.voxel;
+    bool ok[8];
+    fuse_project<0, 4>(P, Ti, wx, wy, wz, pz, pix, ok);
+    okmask = 0u;
+#pragma unroll
+    for (int k = 0; k < 8; k++) okmask |= ok[k] ? (1u << k) : 0u;
+  };
+  // ---- prologue: tiles 0 and 1 requested, tile 0 read and projected, its gathers and tile 2 requested.
+  // List entries and block keys are wave-uniform scalar loads fetched ahead of their use (slot of tile k+4 and key of tile
+  // k+2 during turn k), so that no dependent scalar round trip ever opens a turn.
+  int i = i0;
+  int slot = slot_of(i), slot1 = slot_of(i + stride), slot2 = slot_of(i + 2 * stride), slot3 = slot_of(i + 3 * stride);
+  dma_tile(slot, 0);
+  if (i + stride < n) dma_tile(slot1, 1);
+  const uint64_t key0 = block_keys[slot];
+  uint64_t key1 = i + stride < n ? block_keys[slot1] : 0ull;
+  if (i + stride < n) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  uint4 v[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) v[j] = ring[0 * 256 + j * 64 + lane];
+  v2f pz[4];
+  uint32_t okmask;
+  {
+    uint32_t pix[8];
+    project(key0, pz, pix, okmask);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // tile 0 is in registers: its ring slot may be overwritten
+    gather8(pix, 0);
+    if (i + 2 * stride < n) dma_tile(slot2, 0);
+  }
+  int par = 0;  // parity of the current turn: tile k sits in gather slot par, tile k+1 in ring slot par ^ 1
+  for (;;) {
+    const int i1 = i + stride, i4 = i + 4 * stride;
+    const bool has1 = i1 < n, has2 = i + 2 * stride < n, has3 = i + 3 * stride < n;  // wave-uniform
+    uint4 vn[4];
+    v2f pzn[4];
+    uint32_t okn = 0u;
+    int slot4 = 0;
+    uint64_t key2 = 0ull;
+    if (has1) {
+      // top: tile k+1 has landed (younger than it: at least G(k) 8 + D(k+2) 4 when tile k+2 exists, else only G(k) 8)
+      if (has2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < 4; j++) vn[j] = ring[(par ^ 1) * 256 + j * 64 + lane];
+      uint32_t pixn[8];
+      project(key1, pzn, pixn, okn);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // tile k+1 is in registers before its slot is handed to tile k+3
+      gather8(pixn, par ^ 1);
+      if (has3) dma_tile(slot3, par ^ 1);
+      // scalar prefetch for later turns (after the lgkmcnt wait above, so that it is not waited for here)
+      if (i4 < n) slot4 = __builtin_amdgcn_readfirstlane(compact[i4]);
+      if (has2) key2 = block_keys[slot2];
+      // mid: the gathers of tile k have landed (younger: D(k+2) 4 if any, G(k+1) 8, D(k+3) 4 if any)
+      if (has3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (has2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    float d[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) d[k] = gath[par * 512 + k * 64 + lane];
+    v2f rcp_m[4];
+    if (TAB) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) rcp_m[j] = (v2f){s_rtab[(v[j].y >> 24) + (uint32_t)P.wsample], s_rtab[(v[j].w >> 24) + (uint32_t)P.wsample]};
+    }
+    bool ok[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) ok[k] = (okmask >> k) & 1u;
+    uint32_t cdummy[8];
+    bool dirty[4] = {false, false, false, false};
+    fuse_update<1, false, TAB, WS1, 0, 4>(P, rcp_m, d, cdummy, pz, ok, v, dirty);  // consumes d: the gather slot is free again
+    uint4* vb = voxels + (size_t)slot * 256;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (dirty[j]) vb[j * 64 + lane] = v[j];
+    if (!has1) break;
+    i = i1;
+    slot = slot1; slot1 = slot2; slot2 = slot3; slot3 = slot4;
+    key1 = key2;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { v[j] = vn[j]; pz[j] = pzn[j]; }
+    okmask = okn;
+    par ^= 1;
   }
 }
 
@@ -922,9 +1122,19 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
   const int sl = f->slot;
   f->slot ^= 1;
   const int cc = sl ? (int)C_COMPACT_B : (int)C_COMPACT;
-  hipStream_t sa = f->overlap ? f->front : f->stream;
   hipStream_t s = f->stream;
-  if (f->overlap) (void)hipStreamWaitEvent(sa, f->ev_fused[sl], 0);
+  // One frame per launch without colour runs the persistent k_integrate_pipe, which fills every CU: kernels of the next frame
+  // on the front stream would only get CUs by starving some of its waves (measured: 113 us overlapped vs 90 us alone, and
+  // no more frames/s), so for such a frame everything goes down ONE stream.
+  const bool tab_ok = f->p.weight_sample >= 1 && f->p.weight_sample <= RTAB - 256;
+  const bool pipe = sign > 0 && n == 1 && !col && tab_ok && f->pipe_mode != 0;
+  hipStream_t sa = (f->overlap && !pipe) ? f->front : f->stream;
+  if (f->overlap && sa != s) (void)hipStreamWaitEvent(sa, f->ev_fused[sl], 0);
+  if (f->overlap && sa == s) {
+    // callers stage their frames on the front stream (fuse_host, sf_fuse_run): whatever they queued there comes first
+    (void)hipEventRecord(f->ev_input, f->front);
+    (void)hipStreamWaitEvent(s, f->ev_input, 0);
+  }
   hipLaunchKernelGGL(k_prepass, dim3((npx / 8 + 255) / 256 + 1, n), dim3(256), 0, sa, in, f->depthf2[sl], f->color2[sl], npx, f->p.depth_shift,
                      f->p.depth_min, f->p.depth_max, f->counters, cc, f->pk);
   if (sign > 0) {
@@ -942,7 +1152,8 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
                      f->cmask2[sl], f->counters, cc, 0, f->pk, bf);
   if (f->overlap) {
     (void)hipEventRecord(f->ev_compact[sl], sa);
-    (void)hipStreamWaitEvent(s, f->ev_compact[sl], 0);
+    // (sa == s: the front stream must not start the NEXT batch's allocation before this batch's list is built)
+    (void)hipStreamWaitEvent(sa != s ? s : f->front, f->ev_compact[sl], 0);
   }
   // grid: enough workgroups (4 blocks each) for the last list length the device reported, +25 %; the kernel's
   // grid-stride loop covers any excess, surplus workgroups exit at once.
@@ -967,8 +1178,17 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
 #define LAUNCH_INT(SG, CL, TB, W1)                                                                                                        \
   hipLaunchKernelGGL((k_integrate<SG, CL, TB, W1>), dim3(grid), dim3(256), 0, s, f->voxels, f->block_keys, f->compact2[sl], f->cmask2[sl], \
                      f->depthf2[sl], f->color2[sl], f->counters, f->host_mirror, cc, f->xcd_walk ? 1 : 0, f->pk, bt)
-  const bool tab = f->p.weight_sample >= 1 && f->p.weight_sample <= RTAB - 256;  // the LDS reciprocal table covers weight + sample < 512
-  if (sign > 0) {
+  const bool tab = tab_ok;  // the LDS reciprocal table covers weight + sample < 512
+  // one frame per launch without colour: the software-pipelined kernel (SF_PIPE=0: always k_integrate)
+  if (pipe) {
+    const dim3 pg((unsigned)(f->num_cus * f->pipe_wgs));
+    if (f->p.weight_sample == 1)
+      hipLaunchKernelGGL((k_integrate_pipe<true, true>), pg, dim3(256), 0, s, f->voxels, f->block_keys, f->compact2[sl], f->depthf2[sl], f->counters,
+                         f->host_mirror, cc, f->pk, bt);
+    else
+      hipLaunchKernelGGL((k_integrate_pipe<true, false>), pg, dim3(256), 0, s, f->voxels, f->block_keys, f->compact2[sl], f->depthf2[sl], f->counters,
+                         f->host_mirror, cc, f->pk, bt);
+  } else if (sign > 0) {
     if (f->p.weight_sample == 1) { if (col) LAUNCH_INT(1, true, true, true); else LAUNCH_INT(1, false, true, true); }  // the shipped setting
     else if (tab)                { if (col) LAUNCH_INT(1, true, true, false); else LAUNCH_INT(1, false, true, false); }
     else                         { if (col) LAUNCH_INT(1, true, false, false); else LAUNCH_INT(1, false, false, false); }
@@ -1024,6 +1244,8 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
   if (f->p.weight_max < 1) f->p.weight_max = 1;
   f->device = device;
   if (const char* e = getenv("SF_NO_XCD")) f->xcd_walk = atoi(e) == 0;
+  if (const char* e = getenv("SF_PIPE")) f->pipe_mode = atoi(e);
+  if (const char* e = getenv("SF_PIPE_WGS")) f->pipe_wgs = std::max(1, std::min(3, atoi(e)));
   if (const char* e = getenv("SF_ALLOC_GROUP")) { f->alloc_group = atoi(e); if (f->alloc_group < 1) f->alloc_group = 1; }
   {
     // longest ray segment 2 * trunc(max distance) in blocks decides the LDS window size of k_alloc
@@ -1068,6 +1290,7 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
     SF_HIP_CHECK(hipEventCreateWithFlags(&f->ev_compact[q], hipEventDisableTiming));
     SF_HIP_CHECK(hipEventCreateWithFlags(&f->ev_fused[q], hipEventDisableTiming));
   }
+  SF_HIP_CHECK(hipEventCreateWithFlags(&f->ev_input, hipEventDisableTiming));
   if (const char* e = getenv("SF_NO_OVERLAP")) f->overlap = atoi(e) == 0;
   if (const char* e = getenv("SF_BATCH")) { f->batch = atoi(e); if (f->batch < 1) f->batch = 1; if (f->batch > MAX_BATCH) f->batch = MAX_BATCH; }
   SF_ALLOC(f->table, (size_t)k.total_slots * sizeof(HashEntry));
@@ -1110,6 +1333,7 @@ SF_API void sf_fuser_destroy(sf_fuser* f) {
   for (int q = 0; q < 2; q++) { (void)hipFree(f->depthf2[q]); (void)hipFree(f->color2[q]); (void)hipFree(f->compact2[q]); (void)hipFree(f->cmask2[q]); }
   (void)hipFree(f->counters);
   for (int q = 0; q < 2; q++) { if (f->ev_compact[q]) (void)hipEventDestroy(f->ev_compact[q]); if (f->ev_fused[q]) (void)hipEventDestroy(f->ev_fused[q]); }
+  if (f->ev_input) (void)hipEventDestroy(f->ev_input);
   if (f->front) { (void)hipStreamSynchronize(f->front); (void)hipStreamDestroy(f->front); }
   (void)hipFree(f->staging_depth); (void)hipFree(f->staging_rgb);
   if (f->host_mirror) (void)hipHostFree(f->host_mirror);

@@ -135,6 +135,7 @@ struct sf_fuser {
   hipStream_t front = nullptr;   // pre-pass, allocation, compaction of the NEXT frame (overlaps integrate)
   hipEvent_t ev_compact[2] = {nullptr, nullptr};   // front: frame slot ready for integrate
   hipEvent_t ev_fused[2] = {nullptr, nullptr};     // stream: frame slot consumed
+  hipEvent_t ev_input = nullptr;                   // front: the caller's staging work queued so far (single-stream batches wait for it)
   int slot = 0;
   bool overlap = true;  // SF_NO_OVERLAP=1 runs everything on one stream
   float* depthf2[2] = {nullptr, nullptr};      // MAX_BATCH x W*H per batch slot
@@ -157,6 +158,8 @@ struct sf_fuser {
   int num_cus = 256;
   bool alloc_win64 = false;  // 64^3-block LDS window when a ray segment spans more than ~20 blocks
   bool xcd_walk = true;  // k_integrate: each XCD walks one contiguous eighth of the list (SF_NO_XCD=1: plain grid-stride)
+  int pipe_mode = 1;    // 1: colourless one-frame launches run k_integrate_pipe (SF_PIPE=0: k_integrate)
+  int pipe_wgs = 3;     // persistent workgroups per CU of k_integrate_pipe (50 KiB of LDS each)
   int alloc_group = 4;  // consecutive frames of a batch one k_alloc workgroup walks (SF_ALLOC_GROUP)
   int compact_grid = 1024;  // 1024 directory entries per workgroup, grid-stride beyond
   uint64_t frames_integrated = 0, frames_skipped = 0;
