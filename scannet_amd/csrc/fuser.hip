@@ -1101,6 +1101,22 @@ bool frame_setup(const sf_params& p, const float* pose, FrameK& f) {
 // still fusing the previous batch out of the other slot.  Allocation only touches new hash entries / heap slots,
 // integrate only the tiles of its own compact list, so the two never write the same data; slot reuse is ordered
 // by ev_fused[sl].
+}  // namespace
+
+// One frame per launch without colour runs the persistent k_integrate_pipe, which fills every CU: kernels of the next frame
+// on the front stream would only get CUs by starving some of its waves (measured: 113 us overlapped vs 90 us alone, and no
+// more frames/s), so such a batch goes down ONE stream, pre-pass to integrate.
+bool sf_single_stream_batch(const sf_fuser* f, int n, bool color, int sign) {
+  const bool tab_ok = f->p.weight_sample >= 1 && f->p.weight_sample <= RTAB - 256;
+  return sign > 0 && n == 1 && !color && tab_ok && f->pipe_mode != 0;
+}
+// the stream the pre-pass of such a batch reads its frames on: where callers must have staged them
+hipStream_t sf_input_stream(const sf_fuser* f, int n, bool color, int sign) {
+  return (f->overlap && !sf_single_stream_batch(f, n, color, sign)) ? f->front : f->stream;
+}
+
+namespace {
+
 int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb, const float* const* poses, int n, int sign) {
   BatchIn in;
   BatchFrames bf;
@@ -1127,13 +1143,15 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
   // on the front stream would only get CUs by starving some of its waves (measured: 113 us overlapped vs 90 us alone, and
   // no more frames/s), so for such a frame everything goes down ONE stream.
   const bool tab_ok = f->p.weight_sample >= 1 && f->p.weight_sample <= RTAB - 256;
-  const bool pipe = sign > 0 && n == 1 && !col && tab_ok && f->pipe_mode != 0;
-  hipStream_t sa = (f->overlap && !pipe) ? f->front : f->stream;
-  if (f->overlap && sa != s) (void)hipStreamWaitEvent(sa, f->ev_fused[sl], 0);
-  if (f->overlap && sa == s) {
-    // callers stage their frames on the front stream (fuse_host, sf_fuse_run): whatever they queued there comes first
-    (void)hipEventRecord(f->ev_input, f->front);
-    (void)hipStreamWaitEvent(s, f->ev_input, 0);
+  const bool pipe = sf_single_stream_batch(f, n, col, sign);
+  hipStream_t sa = sf_input_stream(f, n, col, sign);  // callers stage the batch's frames on this stream too
+  if (f->overlap && sa != s) {
+    if (f->serial_tail) {  // single-stream batches came before: the front stream starts behind everything they queued
+      (void)hipEventRecord(f->ev_input, s);
+      (void)hipStreamWaitEvent(sa, f->ev_input, 0);
+      f->serial_tail = false;
+    }
+    (void)hipStreamWaitEvent(sa, f->ev_fused[sl], 0);
   }
   hipLaunchKernelGGL(k_prepass, dim3((npx / 8 + 255) / 256 + 1, n), dim3(256), 0, sa, in, f->depthf2[sl], f->color2[sl], npx, f->p.depth_shift,
                      f->p.depth_min, f->p.depth_max, f->counters, cc, f->pk);
@@ -1150,10 +1168,9 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
   }
   hipLaunchKernelGGL(k_compactify, dim3(f->compact_grid), dim3(256), 0, sa, f->block_keys, f->block_entry, f->block_flags, f->table, f->compact2[sl],
                      f->cmask2[sl], f->counters, cc, 0, f->pk, bf);
-  if (f->overlap) {
+  if (f->overlap && sa != s) {
     (void)hipEventRecord(f->ev_compact[sl], sa);
-    // (sa == s: the front stream must not start the NEXT batch's allocation before this batch's list is built)
-    (void)hipStreamWaitEvent(sa != s ? s : f->front, f->ev_compact[sl], 0);
+    (void)hipStreamWaitEvent(s, f->ev_compact[sl], 0);
   }
   // grid: enough workgroups (4 blocks each) for the last list length the device reported, +25 %; the kernel's
   // grid-stride loop covers any excess, surplus workgroups exit at once.
@@ -1195,7 +1212,8 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
   } else                         { if (col) LAUNCH_INT(-1, true, false, false); else LAUNCH_INT(-1, false, false, false); }
 #undef LAUNCH_INT
   if (f->profile) (void)hipEventRecord(e1, s);
-  if (f->overlap) (void)hipEventRecord(f->ev_fused[sl], s);
+  if (f->overlap && sa != s) (void)hipEventRecord(f->ev_fused[sl], s);
+  if (f->overlap && sa == s) f->serial_tail = true;  // no cross-stream traffic at all while single-stream batches follow each other
   const hipError_t err = hipGetLastError();
   if (err != hipSuccess) return sf::fail(SF_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(err));
   f->frames_integrated += (uint64_t)n;
@@ -1348,7 +1366,7 @@ static int fuse_host(sf_fuser* f, const uint16_t* depth, const uint8_t* rgb, con
   const size_t npx = (size_t)f->p.depth_width * f->p.depth_height;
   // the staging buffer is reused: wait for the previous frame's kernels before overwriting it
   SF_HIP_CHECK(sf_quiesce(f));
-  hipStream_t in_stream = f->overlap ? f->front : f->stream;  // the stream the pre-pass reads the frame on
+  hipStream_t in_stream = sf_input_stream(f, 1, rgb != nullptr, sign);  // the stream the pre-pass reads the frame on
   SF_HIP_CHECK(hipMemcpyAsync(f->staging_depth, depth, npx * 2, hipMemcpyHostToDevice, in_stream));
   if (rgb) SF_HIP_CHECK(hipMemcpyAsync(f->staging_rgb, rgb, (f->pk.cW ? (size_t)f->pk.cW * f->pk.cH : npx) * 3, hipMemcpyHostToDevice, in_stream));
   return run_frame(f, f->staging_depth, rgb ? f->staging_rgb : nullptr, pose, sign);

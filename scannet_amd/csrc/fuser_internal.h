@@ -137,6 +137,7 @@ struct sf_fuser {
   hipEvent_t ev_fused[2] = {nullptr, nullptr};     // stream: frame slot consumed
   hipEvent_t ev_input = nullptr;                   // front: the caller's staging work queued so far (single-stream batches wait for it)
   int slot = 0;
+  bool serial_tail = false;  // the most recent batches ran on `stream` alone (front has not been ordered behind them yet)
   bool overlap = true;  // SF_NO_OVERLAP=1 runs everything on one stream
   float* depthf2[2] = {nullptr, nullptr};      // MAX_BATCH x W*H per batch slot
   uint32_t* color2[2] = {nullptr, nullptr};    // MAX_BATCH x W*H per batch slot
@@ -170,4 +171,6 @@ struct sf_fuser {
 
 
 hipError_t sf_quiesce(sf_fuser* f);                 // drain both streams
+bool sf_single_stream_batch(const sf_fuser* f, int n, bool color, int sign);   // run_batch keeps this batch on f->stream alone
+hipStream_t sf_input_stream(const sf_fuser* f, int n, bool color, int sign);   // where the batch's frames must be staged
 int sf_compact_live(sf_fuser* f, int32_t* n_out, int include_ghosts = 1);   // live heap slots -> f->compact, synchronous

@@ -134,7 +134,6 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   int result = SF_OK;
   std::string err;
   uint64_t n_int = 0, n_skip = 0;
-  hipStream_t in_stream = f->overlap ? f->front : f->stream;
   // frames whose copies are queued but whose kernels are not: fused B at a time (one pass over the tiles per batch)
   int pend_slot[MAX_BATCH];
   const float* pend_pose[MAX_BATCH];
@@ -142,6 +141,7 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   bool pend_rgb = false;
   auto flush = [&]() -> int {
     if (pend == 0) return SF_OK;
+    hipStream_t in_stream = sf_input_stream(f, pend, pend_rgb, +1);  // the stream this batch's pre-pass runs on
     const void* dd[MAX_BATCH];
     const void* dr[MAX_BATCH];
     for (int q = 0; q < pend; q++) {
