@@ -11,6 +11,8 @@
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -23,20 +25,24 @@ int sf_fuser_run_batch(sf_fuser* f, const void* const* d_depth, const void* cons
 
 namespace {
 
-struct Slot {
-  uint16_t* h_depth = nullptr;
-  uint8_t* h_rgb = nullptr;
-  void* d_depth = nullptr;
-  void* d_rgb = nullptr;
-  hipEvent_t copied = nullptr;    // H2D of this slot finished (host buffer reusable)
-  hipEvent_t consumed = nullptr;  // pre-pass of the frame in this slot finished (device buffer reusable)
+// One ring slot = one batch of B frames: contiguous pinned host buffers, contiguous device buffers, two events.
+struct BatchSlot {
+  hipEvent_t copied = nullptr;    // H2D of this batch finished (its pinned buffers may be refilled)
+  hipEvent_t consumed = nullptr;  // pre-pass of this batch finished (its device buffers may be overwritten)
   bool used = false;
-  int decode_rc = SF_OK;
-  std::string decode_err;
+  std::atomic<int> decoded{0};    // frames of the current generation the pool has finished with
+  std::atomic<int> failed{0};
 };
 
 }  // namespace
 
+// Frames are handled in batches of B = sf_fuser_batch_frames(): batch g lives in ring slot g % NB.
+//   decode pool : frame k is decoded as soon as batch (k / B) - NB has left its pinned buffers (counter `landed`, advanced by ONE
+//                 thread that follows the copy events); the workers never enter the HIP runtime and share no lock -- progress
+//                 counters are atomics polled with a short sleep (a mutex + condition variable woke 64 threads per frame and
+//                 cost more than the decoding)
+//   this thread : waits until a batch is fully decoded, queues ONE H2D copy per run of consecutive valid frames (up to
+//                 B x 614 KB per call instead of B calls) on the copy stream, then the batch's kernels
 SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t last, int decode_threads, sf_run_stats* stats) {
   if (!f || !s) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
   const uint64_t nframes = s->frames.size();
@@ -47,8 +53,10 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
                     s->info.depth_width, s->info.depth_height);
   SF_HIP_CHECK(hipSetDevice(f->device));
   const auto t_start = std::chrono::steady_clock::now();
+  const bool timing = std::getenv("SF_RUN_TIMING") != nullptr;
+  double t_wait_ready = 0, t_api = 0, t_flush = 0;
+  auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const size_t npx = (size_t)f->p.depth_width * f->p.depth_height;
-  // colour is fused when it is stored at depth resolution (raw or JPEG); other resolutions: geometry only
   // colour is fused when its frames match what the fuser was created for: depth resolution, or the colour resolution
   // given in sf_params (raw or JPEG); anything else: geometry only
   const bool same_res = s->info.color_width == s->info.depth_width && s->info.color_height == s->info.depth_height;
@@ -60,18 +68,27 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   if (nthreads > 64) nthreads = 64;
   const uint64_t total = last - first;
   const int B = f->batch;  // frames fused per pass over the voxel tiles
-  const int R = (int)std::min<uint64_t>(std::max<uint64_t>(std::max<uint64_t>(4 * (uint64_t)nthreads, 16), 3 * (uint64_t)B), std::max<uint64_t>(total, 1));
-  std::vector<Slot> ring((size_t)R);
+  const uint64_t nbatches = (total + (uint64_t)B - 1) / (uint64_t)B;
+  // enough batch slots for every decode thread to be busy while two batches sit between copy and pre-pass
+  const int NB = (int)std::max<uint64_t>(1, std::min<uint64_t>(std::max<uint64_t>(3, ((uint64_t)nthreads + B - 1) / B + 2), std::max<uint64_t>(nbatches, 1)));
+  std::vector<BatchSlot> ring((size_t)NB);
   hipStream_t copy_stream = nullptr;
+  // ONE pinned host allocation and ONE device allocation for the whole ring
+  uint8_t* h_pool = nullptr;
+  uint8_t* d_pool = nullptr;
+  const size_t depth_b = npx * 2, rgb_b = use_rgb ? cpx * 3 : 0;
+  const size_t slot_depth = (depth_b * B + 255) & ~(size_t)255, slot_rgb = (rgb_b * B + 255) & ~(size_t)255, slot_b = slot_depth + slot_rgb;
+  auto h_depth = [&](int sl, int j) { return (uint16_t*)(h_pool + (size_t)sl * slot_b + (size_t)j * depth_b); };
+  auto d_depth = [&](int sl, int j) { return d_pool + (size_t)sl * slot_b + (size_t)j * depth_b; };
+  auto h_rgb = [&](int sl, int j) { return h_pool + (size_t)sl * slot_b + slot_depth + (size_t)j * rgb_b; };
+  auto d_rgb = [&](int sl, int j) { return d_pool + (size_t)sl * slot_b + slot_depth + (size_t)j * rgb_b; };
   auto cleanup = [&]() {
-    for (Slot& sl : ring) {
-      if (sl.h_depth) (void)hipHostFree(sl.h_depth);
-      if (sl.h_rgb) (void)hipHostFree(sl.h_rgb);
-      if (sl.d_depth) (void)hipFree(sl.d_depth);
-      if (sl.d_rgb) (void)hipFree(sl.d_rgb);
+    for (BatchSlot& sl : ring) {
       if (sl.copied) (void)hipEventDestroy(sl.copied);
       if (sl.consumed) (void)hipEventDestroy(sl.consumed);
     }
+    if (h_pool) (void)hipHostFree(h_pool);
+    if (d_pool) (void)hipFree(d_pool);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
   };
 #define RUN_CHECK(call)                                                                                   \
@@ -80,143 +97,146 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
     if (e_ != hipSuccess) { cleanup(); return sf::fail(SF_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_)); } \
   } while (0)
   RUN_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
-  for (Slot& sl : ring) {
-    RUN_CHECK(hipHostMalloc((void**)&sl.h_depth, npx * 2, hipHostMallocDefault));
-    RUN_CHECK(hipMalloc(&sl.d_depth, npx * 2));
-    if (use_rgb) {
-      RUN_CHECK(hipHostMalloc((void**)&sl.h_rgb, cpx * 3, hipHostMallocDefault));
-      RUN_CHECK(hipMalloc(&sl.d_rgb, cpx * 3));
-    }
+  RUN_CHECK(hipHostMalloc((void**)&h_pool, (size_t)NB * slot_b, hipHostMallocDefault));
+  RUN_CHECK(hipMalloc((void**)&d_pool, (size_t)NB * slot_b));
+  for (BatchSlot& sl : ring) {
     RUN_CHECK(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
     RUN_CHECK(hipEventCreateWithFlags(&sl.consumed, hipEventDisableTiming));
   }
 
-  // ---- decode pool: frame k (0-based within [first,last)) goes to slot k % R once frame k-R has been issued
-  std::mutex mu;
-  std::condition_variable cv_ready, cv_free;
-  std::vector<uint8_t> ready((size_t)R, 0);  // slot holds a decoded frame
-  uint64_t issued = 0;                       // frames the main thread has finished with (copy queued)
-  std::atomic<uint64_t> next{0};
+  std::atomic<uint64_t> next{0}, landed{0}, issued{0};  // frame counter of the pool; batches whose copies completed / were queued
   std::atomic<bool> abort{false};
   std::atomic<uint64_t> decode_ns{0};
+  std::mutex err_mu;
+  std::string pool_err;
+  int pool_rc = SF_OK;
+  auto nap = [] { std::this_thread::sleep_for(std::chrono::microseconds(20)); };
   auto worker = [&]() {
     for (;;) {
       const uint64_t k = next.fetch_add(1);
-      if (k >= total || abort.load()) return;
-      const int si = (int)(k % (uint64_t)R);
-      {
-        std::unique_lock<std::mutex> lk(mu);
-        cv_free.wait(lk, [&] { return abort.load() || k < issued + (uint64_t)R; });
-        if (abort.load()) return;
+      if (k >= total || abort.load(std::memory_order_relaxed)) return;
+      const uint64_t g = k / (uint64_t)B;
+      const int j = (int)(k % (uint64_t)B), sl = (int)(g % (uint64_t)NB);
+      while (g >= landed.load(std::memory_order_acquire) + (uint64_t)NB) {  // batch g - NB still owns the pinned buffers
+        if (abort.load(std::memory_order_relaxed)) return;
+        nap();
       }
-      Slot& sl = ring[(size_t)si];
       const uint64_t frame = first + k;
       const auto t0 = std::chrono::steady_clock::now();
       int rc = SF_OK;
-      const bool valid = s->frames[frame].pose[0] != -INFINITY;
-      if (valid) {
-        rc = sens_decode_depth(s, frame, sl.h_depth);
-        if (rc == SF_OK && use_rgb && s->frames[frame].color_bytes) rc = sf_sens_decode_color(s, frame, sl.h_rgb);
+      if (s->frames[frame].pose[0] != -INFINITY) {
+        rc = sens_decode_depth(s, frame, h_depth(sl, j));
+        if (rc == SF_OK && use_rgb && s->frames[frame].color_bytes) rc = sf_sens_decode_color(s, frame, h_rgb(sl, j));
       }
       decode_ns.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
-      {
-        std::lock_guard<std::mutex> lk(mu);
-        sl.decode_rc = rc;
-        if (rc != SF_OK) sl.decode_err = sf_last_error();
-        ready[(size_t)si] = 1;
+      if (rc != SF_OK) {
+        std::lock_guard<std::mutex> lk(err_mu);
+        if (pool_rc == SF_OK) { pool_rc = rc; pool_err = sf_last_error(); }
+        ring[(size_t)sl].failed.fetch_add(1);
       }
-      cv_ready.notify_all();
+      ring[(size_t)sl].decoded.fetch_add(1, std::memory_order_release);
     }
   };
   std::vector<std::thread> pool;
   for (int t = 0; t < nthreads; t++) pool.emplace_back(worker);
+  std::thread reaper([&]() {  // the only other thread inside the HIP runtime: copies complete in order on the copy stream
+    (void)hipSetDevice(f->device);
+    for (uint64_t g = 0; g < nbatches; g++) {
+      while (issued.load(std::memory_order_acquire) <= g) {
+        if (abort.load(std::memory_order_relaxed)) return;
+        nap();
+      }
+      (void)hipEventSynchronize(ring[(size_t)(g % (uint64_t)NB)].copied);
+      landed.store(g + 1, std::memory_order_release);
+    }
+  });
 
   int result = SF_OK;
   std::string err;
   uint64_t n_int = 0, n_skip = 0;
-  // frames whose copies are queued but whose kernels are not: fused B at a time (one pass over the tiles per batch)
-  int pend_slot[MAX_BATCH];
-  const float* pend_pose[MAX_BATCH];
-  int pend = 0;
-  bool pend_rgb = false;
-  auto flush = [&]() -> int {
-    if (pend == 0) return SF_OK;
-    hipStream_t in_stream = sf_input_stream(f, pend, pend_rgb, +1);  // the stream this batch's pre-pass runs on
-    const void* dd[MAX_BATCH];
-    const void* dr[MAX_BATCH];
-    for (int q = 0; q < pend; q++) {
-      Slot& ps = ring[(size_t)pend_slot[q]];
-      dd[q] = ps.d_depth;
-      dr[q] = pend_rgb ? ps.d_rgb : nullptr;
-      if (hipStreamWaitEvent(in_stream, ps.copied, 0) != hipSuccess) return sf::fail(SF_ERR_DEVICE, "hipStreamWaitEvent failed");
-    }
-    const int rc = sf_fuser_run_batch(f, dd, pend_rgb ? dr : nullptr, pend_pose, pend);
-    if (rc != SF_OK) return rc;
-    for (int q = 0; q < pend; q++) {
-      Slot& ps = ring[(size_t)pend_slot[q]];
-      (void)hipEventRecord(ps.consumed, in_stream);  // device buffers of the batch are free once its pre-pass has run
-      ps.used = true;
-    }
-    n_int += (uint64_t)pend;
-    pend = 0;
-    return SF_OK;
-  };
-  for (uint64_t k = 0; k < total && result == SF_OK; k++) {
-    const int si = (int)(k % (uint64_t)R);
-    Slot& sl = ring[(size_t)si];
+  for (uint64_t g = 0; g < nbatches && result == SF_OK; g++) {
+    const int sl = (int)(g % (uint64_t)NB);
+    BatchSlot& bs = ring[(size_t)sl];
+    const int cnt = (int)std::min<uint64_t>((uint64_t)B, total - g * (uint64_t)B);
     {
-      std::unique_lock<std::mutex> lk(mu);
-      cv_ready.wait(lk, [&] { return ready[(size_t)si] != 0; });
-      ready[(size_t)si] = 0;
+      const double t0 = timing ? now_s() : 0;
+      while (bs.decoded.load(std::memory_order_acquire) < cnt) nap();
+      if (timing) t_wait_ready += now_s() - t0;
     }
-    const uint64_t frame = first + k;
-    const float* pose = s->frames[frame].pose;
-    if (sl.decode_rc != SF_OK) { result = sl.decode_rc; err = sl.decode_err; }
-    else if (pose[0] == -INFINITY) { n_skip++; f->frames_skipped++; }
-    else {
-      const bool rgb = use_rgb && s->frames[frame].color_bytes;
-      if (pend > 0 && rgb != pend_rgb) {  // a batch is all-colour or all-geometry
-        const int rc = flush();
-        if (rc != SF_OK) { result = rc; err = sf_last_error(); }
-      }
-      hipError_t e = hipSuccess;
-      if (result == SF_OK) {
-        if (sl.used) e = hipStreamWaitEvent(copy_stream, sl.consumed, 0);  // device buffer still read by an earlier pre-pass?
-        if (e == hipSuccess) e = hipMemcpyAsync(sl.d_depth, sl.h_depth, npx * 2, hipMemcpyHostToDevice, copy_stream);
-        if (e == hipSuccess && rgb) e = hipMemcpyAsync(sl.d_rgb, sl.h_rgb, cpx * 3, hipMemcpyHostToDevice, copy_stream);
-        if (e == hipSuccess) e = hipEventRecord(sl.copied, copy_stream);
-        if (e != hipSuccess) { result = SF_ERR_DEVICE; err = std::string("copy pipeline: ") + hipGetErrorString(e); }
-      }
-      if (result == SF_OK) {
-        pend_slot[pend] = si;
-        pend_pose[pend] = pose;
-        pend_rgb = rgb;
-        pend++;
-        if (pend == B) {
-          const int rc = flush();
-          if (rc != SF_OK) { result = rc; err = sf_last_error(); }
-        }
-        // the pinned host buffer goes back to the decoders once its copy has landed
-        if (result == SF_OK) (void)hipEventSynchronize(sl.copied);
-      }
+    if (bs.failed.load() != 0) {
+      std::lock_guard<std::mutex> lk(err_mu);
+      result = pool_rc; err = pool_err;
+      break;
     }
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      issued = k + 1;
+    bs.decoded.store(0, std::memory_order_relaxed);  // next generation of this slot starts only after `landed` passes g
+    // ---- copies: one per run of consecutive valid frames
+    const double t1 = timing ? now_s() : 0;
+    hipError_t e = hipSuccess;
+    if (bs.used) e = hipStreamWaitEvent(copy_stream, bs.consumed, 0);  // device buffers still read by this slot's previous pre-pass?
+    bool valid[MAX_BATCH], rgbf[MAX_BATCH];
+    for (int j = 0; j < cnt; j++) {
+      const uint64_t frame = first + g * (uint64_t)B + (uint64_t)j;
+      valid[j] = s->frames[frame].pose[0] != -INFINITY;
+      rgbf[j] = valid[j] && use_rgb && s->frames[frame].color_bytes != 0;
+      if (!valid[j]) { n_skip++; f->frames_skipped++; }
     }
-    cv_free.notify_all();
+    for (int j = 0; j < cnt && e == hipSuccess;) {
+      if (!valid[j]) { j++; continue; }
+      int j1 = j;
+      while (j1 < cnt && valid[j1]) j1++;
+      e = hipMemcpyAsync(d_depth(sl, j), h_depth(sl, j), (size_t)(j1 - j) * depth_b, hipMemcpyHostToDevice, copy_stream);
+      j = j1;
+    }
+    for (int j = 0; j < cnt && e == hipSuccess;) {
+      if (!rgbf[j]) { j++; continue; }
+      int j1 = j;
+      while (j1 < cnt && rgbf[j1]) j1++;
+      e = hipMemcpyAsync(d_rgb(sl, j), h_rgb(sl, j), (size_t)(j1 - j) * rgb_b, hipMemcpyHostToDevice, copy_stream);
+      j = j1;
+    }
+    if (e == hipSuccess) e = hipEventRecord(bs.copied, copy_stream);
+    if (e != hipSuccess) { result = SF_ERR_DEVICE; err = std::string("copy pipeline: ") + hipGetErrorString(e); break; }
+    issued.store(g + 1, std::memory_order_release);
+    if (timing) t_api += now_s() - t1;
+    // ---- kernels: the valid frames in order, a sub-batch is all-colour or all-geometry
+    const double t2 = timing ? now_s() : 0;
+    hipStream_t last_stream = nullptr;
+    for (int j = 0; j < cnt && result == SF_OK;) {
+      if (!valid[j]) { j++; continue; }
+      const void* dd[MAX_BATCH];
+      const void* dr[MAX_BATCH];
+      const float* pp[MAX_BATCH];
+      int m = 0;
+      const bool rgb = rgbf[j];
+      while (j < cnt && m < B && (!valid[j] || rgbf[j] == rgb)) {
+        if (valid[j]) { dd[m] = d_depth(sl, j); dr[m] = rgb ? d_rgb(sl, j) : nullptr; pp[m] = s->frames[first + g * (uint64_t)B + (uint64_t)j].pose; m++; }
+        j++;
+      }
+      hipStream_t in_stream = sf_input_stream(f, m, rgb, +1);  // the stream this sub-batch's pre-pass runs on
+      if (hipStreamWaitEvent(in_stream, bs.copied, 0) != hipSuccess) { result = SF_ERR_DEVICE; err = "hipStreamWaitEvent failed"; break; }
+      const int rc = sf_fuser_run_batch(f, dd, rgb ? dr : nullptr, pp, m);
+      if (rc != SF_OK) { result = rc; err = sf_last_error(); break; }
+      n_int += (uint64_t)m;
+      last_stream = in_stream;
+    }
+    if (result == SF_OK && last_stream) {
+      // (sub-batches of one slot may have used both streams: the later one is ordered behind the earlier by run_batch's own events)
+      (void)hipEventRecord(bs.consumed, last_stream);
+      bs.used = true;
+    } else if (result == SF_OK) {
+      bs.used = false;  // nothing read the device buffers
+    }
+    if (timing) t_flush += now_s() - t2;
   }
-  if (result == SF_OK) {
-    const int rc = flush();
-    if (rc != SF_OK) { result = rc; err = sf_last_error(); }
-  }
-  if (result != SF_OK) {
-    abort.store(true);
-    { std::lock_guard<std::mutex> lk(mu); issued = total + (uint64_t)R; }
-    cv_free.notify_all();
-  }
+  if (result != SF_OK) abort.store(true);
+  const double t_loop_end = timing ? now_s() : 0;
   for (std::thread& t : pool) t.join();
+  if (result != SF_OK) issued.store(nbatches + 1);
+  reaper.join();
   const hipError_t qe = sf_quiesce(f);
+  if (timing)
+    std::fprintf(stderr, "sf_fuse_run: setup+loop %.3f s (wait for decoded batches %.3f, copy enqueue %.3f, kernels enqueue %.3f), join+drain %.3f s, %d batch slots x %d frames\n",
+                 t_loop_end - std::chrono::duration<double>(t_start.time_since_epoch()).count(), t_wait_ready, t_api, t_flush, now_s() - t_loop_end, NB, B);
   (void)hipStreamSynchronize(copy_stream);
   cleanup();
   if (result != SF_OK) return sf::fail(result, "%s", err.c_str());

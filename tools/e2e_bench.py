@@ -79,6 +79,16 @@ def main():
     res["clean"] = {k: cst[k] for k in ("vertices_out", "faces_out", "components_in", "components_removed")}
     cply = os.path.join(a.dir, "scene_e2e_vh_clean.ply")
     cleaned.write_ply(cply)
+    # the decimate stage: quadric edge collapse to 20 % twice, each followed by the cleaning filters (simplify.mlx)
+    cur = cleaned
+    for k in (1, 2):
+        t0 = time.perf_counter()
+        simp, sst = meshclean.simplify(cur)
+        cur, _ = meshclean.clean(simp, min_component_faces=1000)
+        res["decimate%d_s" % k] = round(time.perf_counter() - t0, 3)
+        res["decimate%d" % k] = {"faces_in": sst["faces_in"], "faces_out": cur.counts()[1], "collapses": sst["collapses"]}
+    cply = os.path.join(a.dir, "scene_e2e_vh_clean_2.ply")
+    cur.write_ply(cply)
     t0 = time.perf_counter()
     nseg = segmentator.segment_to_json(cply)
     res["segment_s"] = round(time.perf_counter() - t0, 3)
