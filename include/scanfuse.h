@@ -306,6 +306,20 @@ int sf_jpeg_encode(const uint8_t* rgb, uint32_t width, uint32_t height, int qual
                    uint64_t* out_bytes);
 
 /* ------------------------------------------------------------------------------------------------
+ * 2-D annotation filter (scannet_amd/csrc/filter2d.hip).  Replaces the CUDA kernels AnnotationTools/Filter2dAnnotations/filter.cu
+ * calls from Filter2dAnnotations.cpp:326-397 -- bilateralFilterFloatMap (:210-259), resampleFloatMap (:514-573), resampleUCharMap
+ * (:647-676), filterAnnotations (:1020-1078), convertInstanceToLabel (:1082-1103) -- and the per-frame sequence around them.
+ * Tables: FilterData::init (Filter2dAnnotations.cpp:52-61) with 256 / 80 / 256 entries; bins >= 80 cast no vote.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct sf_filter2d sf_filter2d;
+int sf_filter2d_create(int depth_width, int depth_height, int color_width, int color_height, int device, sf_filter2d** out);
+void sf_filter2d_destroy(sf_filter2d* f);
+int sf_filter2d_set_tables(sf_filter2d* f, const uint8_t instance_to_idx[256], const uint8_t idx_to_instance[80], const uint16_t instance_to_label[256]);
+/* one frame: depth W_d*H_d u16 (mm), rgb W_c*H_c*3, instance_in W_c*H_c u8 (rendered annotation) -> instance_out u8, label_out u16 */
+int sf_filter2d_frame(sf_filter2d* f, const uint16_t* depth, const uint8_t* rgb, const uint8_t* instance_in, uint8_t* instance_out,
+                      uint16_t* label_out, float* kernel_us /*nullable*/);
+
+/* ------------------------------------------------------------------------------------------------
  * Triangle meshes and the PLY surface (README.md:45-46: binary little-endian PLY, vertex float x,y,z +
  * uchar red,green,blue,alpha, face list uchar int vertex_indices).  sf_ply_read replaces tinyply as the
  * Segmentator uses it (Segmentator/segmentator.cpp:131-141, tinyply.cpp:54-108,306-360): ascii / binary

@@ -250,3 +250,33 @@ def calib_frame(cb, depth, rgb=None, lut_grid=None, lut_max_dist=0.0, shift=1000
     L.or_calib_frame(C.byref(cb), C.byref(lut) if lut is not None else None, float(shift), rin.ctypes.data if rin is not None else None,
                      rout.ctypes.data if rout is not None else None, d.ctypes.data, dout.ctypes.data)
     return dout, rout
+
+
+# ---------------------------------------------------------------- 2-D annotation filter (oracle/filter2d_oracle.c)
+def f2d_lib():
+    L = lib()
+    vp = C.c_void_p
+    L.or_exp64.restype = C.c_double
+    L.or_exp64.argtypes = [C.c_double]
+    L.or_f2d_bilateral.argtypes = [vp, vp, C.c_float, C.c_float, C.c_int, C.c_int]
+    L.or_f2d_resample_float.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int]
+    L.or_f2d_resample_uchar.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int]
+    L.or_f2d_vote.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float]
+    L.or_f2d_to_label.argtypes = [vp, vp, vp, C.c_int, C.c_int]
+    L.or_f2d_frame.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
+    return L
+
+
+def f2d_frame(depth, rgb, instance, to_idx, to_inst, to_label):
+    """Filter2dAnnotations.cpp:326-397 for one frame -> (instance_out, label_out)."""
+    L = f2d_lib()
+    d = np.ascontiguousarray(depth, np.uint16)
+    c = np.ascontiguousarray(rgb, np.uint8)
+    i = np.ascontiguousarray(instance, np.uint8)
+    a, b, t = np.ascontiguousarray(to_idx, np.uint8), np.ascontiguousarray(to_inst, np.uint8), np.ascontiguousarray(to_label, np.uint16)
+    ch, cw = c.shape[:2]
+    io = np.empty((ch, cw), np.uint8)
+    lo = np.empty((ch, cw), np.uint16)
+    L.or_f2d_frame(d.ctypes.data, d.shape[1], d.shape[0], c.ctypes.data, cw, ch, i.ctypes.data, a.ctypes.data, b.ctypes.data, t.ctypes.data,
+                   io.ctypes.data, lo.ctypes.data)
+    return io, lo
