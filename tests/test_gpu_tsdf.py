@@ -332,3 +332,46 @@ def test_colour_at_its_own_resolution(oracle):
         _assert_same(ovol, f)
         with pytest.raises(ValueError):
             f.integrate(d, pose, rgb=small)   # wrong size: the fuser expects colour-resolution frames
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_one_frame_kernels_on_sparse_and_ragged_scenes(oracle, seed, monkeypatch):
+    """The persistent one-frame kernel (k_integrate_pipe) walks the list with a stride of one grid (3072 waves): scenes with fewer
+    tiles than waves, 1..3 tiles per wave and ragged tails exercise every branch of its hand-counted waits.  Random voxel size,
+    weight step and pose; the same frames through k_integrate (SF_PIPE=0) and through the oracle."""
+    from scannet_amd import fusion
+    rng = np.random.default_rng(100 + seed)
+    W, H = 160, 120
+    voxel = float(rng.choice([0.004, 0.008, 0.016, 0.02]))
+    ws = int(rng.choice([1, 1, 2, 5]))
+    op, gp = _mk(oracle, W, H, voxel, weight_sample=ws, num_sdf_blocks=1 << 16)
+    ovol = oracle.Volume(op, threads=8)
+    frames = []
+    for k in range(6):
+        pose = synth.trajectory_pose(int(rng.integers(0, 400)), 400)
+        d = synth.render_room_depth(pose, W, H, noise_frame=k).copy()
+        mode = (seed + k) % 4
+        if mode == 0:                       # only a small patch is valid: a handful of blocks
+            keep = np.zeros_like(d, bool)
+            y0, x0 = int(rng.integers(0, H - 12)), int(rng.integers(0, W - 12))
+            keep[y0:y0 + int(rng.integers(1, 12)), x0:x0 + int(rng.integers(1, 12))] = True
+            d[~keep] = 0
+        elif mode == 1:                     # random holes
+            d[rng.random(d.shape) < 0.5] = 0
+        elif mode == 2:                     # a single pixel
+            v = d[H // 2, W // 2]
+            d[:] = 0
+            d[H // 2, W // 2] = v
+        frames.append((d, pose))
+        ovol.integrate(d, pose)
+    with fusion.Fuser(gp) as f:
+        for d, pose in frames:
+            f.integrate(d, pose)
+        _assert_same(ovol, f)
+        a_c, a_v = f.export_blocks()
+    monkeypatch.setenv("SF_PIPE", "0")
+    with fusion.Fuser(gp) as g:
+        for d, pose in frames:
+            g.integrate(d, pose)
+        b_c, b_v = g.export_blocks()
+    assert np.array_equal(a_c, b_c) and np.array_equal(a_v.view(np.uint8), b_v.view(np.uint8))
