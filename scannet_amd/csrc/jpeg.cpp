@@ -51,7 +51,7 @@ struct Component {
   int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0;
   int pred = 0;
   int bw = 0, bh = 0;  // plane size in samples (padded to whole MCUs)
-  std::vector<uint8_t> plane;
+  uint8_t* plane = nullptr;  // points into per-thread scratch (a frame is several MB: no allocation / page faults per frame)
 };
 
 struct BitSrc {
@@ -229,7 +229,9 @@ int jpeg_decode_rgb(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t expe
   const int mcux = (width + mcu_w - 1) / mcu_w, mcuy = (height + mcu_h - 1) / mcu_h;
   for (int i = 0; i < ncomp; i++) {
     comp[i].bw = mcux * comp[i].h * 8; comp[i].bh = mcuy * comp[i].v * 8;
-    comp[i].plane.assign((size_t)comp[i].bw * comp[i].bh, 0);
+    static thread_local std::vector<uint8_t> scratch[3];
+    if (scratch[i].size() < (size_t)comp[i].bw * comp[i].bh) scratch[i].resize((size_t)comp[i].bw * comp[i].bh);  // every sample is written by the IDCT
+    comp[i].plane = scratch[i].data();
     comp[i].pred = 0;
   }
   BitSrc bs{data + pos, data + n};
@@ -262,7 +264,7 @@ int jpeg_decode_rgb(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t expe
               blk[z] = (float)(extend(bs.get(s), s) * (int)q[z]);
               k++;
             }
-            idct_block(blk, c.plane.data() + (size_t)((my * c.v + by) * 8) * c.bw + (mx * c.h + bx) * 8, c.bw);
+            idct_block(blk, c.plane + (size_t)((my * c.v + by) * 8) * c.bw + (mx * c.h + bx) * 8, c.bw);
           }
       }
       if (--todo <= 0) {
@@ -284,23 +286,23 @@ int jpeg_decode_rgb(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t expe
       }
     return SF_OK;
   }
-  std::vector<uint8_t> up[3];
+  static thread_local std::vector<uint8_t> up[3];
   const uint8_t* full[3];
   int fstride[3];
   for (int ci = 0; ci < 3; ci++) {
     Component& c = comp[ci];
     const int sx = hmax / c.h, sy = vmax / c.v;
-    if (sx == 1 && sy == 1) { full[ci] = c.plane.data(); fstride[ci] = c.bw; continue; }
+    if (sx == 1 && sy == 1) { full[ci] = c.plane; fstride[ci] = c.bw; continue; }
     if ((hmax % c.h) || (vmax % c.v)) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: fractional sampling ratios are not supported");
     const int cw = (width * c.h + hmax - 1) / hmax, ch = (height * c.v + vmax - 1) / vmax;  // valid chroma samples
-    up[ci].assign((size_t)width * height, 0);
+    if (up[ci].size() < (size_t)width * height) up[ci].resize((size_t)width * height);  // fully written below
     for (int y = 0; y < height; y++) {
       // vertical: triangle filter for 2x, nearest otherwise
       int y0, y1, wy0, wy1;
       if (sy == 2) { const int cy = y >> 1; y0 = cy; y1 = (y & 1) ? (cy + 1 < ch ? cy + 1 : cy) : (cy > 0 ? cy - 1 : cy); wy0 = 3; wy1 = 1; }
       else { y0 = y1 = (y / sy < ch ? y / sy : ch - 1); wy0 = 4; wy1 = 0; }
-      const uint8_t* r0 = c.plane.data() + (size_t)y0 * c.bw;
-      const uint8_t* r1 = c.plane.data() + (size_t)y1 * c.bw;
+      const uint8_t* r0 = c.plane + (size_t)y0 * c.bw;
+      const uint8_t* r1 = c.plane + (size_t)y1 * c.bw;
       uint8_t* o = up[ci].data() + (size_t)y * width;
       for (int x = 0; x < width; x++) {
         if (sx == 2) {

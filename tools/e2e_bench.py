@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--dir", default="/tmp/sf_e2e")
     ap.add_argument("--out", default="")
+    ap.add_argument("--color", choices=["none", "raw", "jpeg"], default="none", help="store a synthetic 640x480 colour frame per depth frame")
+    ap.add_argument("--fuse-only", action="store_true", help="stop after the fusion stage")
     a = ap.parse_args()
     W, H = 640, 480
     os.makedirs(a.dir, exist_ok=True)
@@ -44,9 +46,22 @@ def main():
     _abi.check(L.sf_device_download(depth.ctypes.data_as(C.c_void_p), dptr, nbytes))
     L.sf_device_free(dptr)
     K = synth.intrinsic_matrix(W, H)
-    sd = sens.SensorData.create(0, 0, W, H, K, K, color_compression=0, depth_compression=1, sensor_name="StructureSensor")
+    cw, ch = (W, H) if a.color != "none" else (0, 0)
+    sd = sens.SensorData.create(cw, ch, W, H, K, K, color_compression=2 if a.color == "jpeg" else 0, depth_compression=1, sensor_name="StructureSensor")
+    yy, xx = np.mgrid[0:H, 0:W]
+    blobs = []
+    if a.color == "jpeg":
+        from scannet_amd import calibrate
+        for k in range(8):   # eight distinct encoded frames, cycled (encoding thousands of frames would dominate the set-up)
+            img = np.stack([(xx + 8 * k) % 256, (yy * 2) % 256, (128 + 100 * np.sin(xx / 30.0) * np.cos(yy / 20.0 + k))], -1).astype(np.uint8)
+            blobs.append(calibrate.jpeg_encode(img, 90, True))
     for i in range(a.frames):
-        sd.add_frame(depth[i], poses[i].reshape(4, 4), timestamp_depth=33333 * i)
+        color = None
+        if a.color == "raw":
+            color = np.stack([(xx + i) % 256, (yy * 2) % 256, np.full_like(xx, (i * 3) % 256)], -1).astype(np.uint8)
+        elif a.color == "jpeg":
+            color = blobs[i % 8]
+        sd.add_frame(depth[i], poses[i].reshape(4, 4), color=color, timestamp_depth=33333 * i)
     sd.save(path)
     sd.close()
     t_write = time.perf_counter() - t0
@@ -64,6 +79,12 @@ def main():
                        "decode_ms_per_frame_per_thread": round(1e3 * rs["seconds_decode_cpu"] / max(rs["frames_total"], 1), 3),
                        "blocks": st["blocks_allocated"], "alloc_failures": st["alloc_failures"],
                        "voxel_tiles_GB": round(st["blocks_allocated"] * 4096 / 1e9, 2)}
+        res["fuse"]["color_fused"] = rs["color_fused"]
+        if a.fuse_only:
+            print(json.dumps(res))
+            if a.out:
+                open(a.out, "w").write(json.dumps(res, indent=1) + "\n")
+            return
         t0 = time.perf_counter()
         mesh = f.extract_mesh()
         res["marching_cubes_s"] = round(time.perf_counter() - t0, 3)
