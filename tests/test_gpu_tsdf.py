@@ -375,3 +375,34 @@ def test_one_frame_kernels_on_sparse_and_ragged_scenes(oracle, seed, monkeypatch
             g.integrate(d, pose)
         b_c, b_v = g.export_blocks()
     assert np.array_equal(a_c, b_c) and np.array_equal(a_v.view(np.uint8), b_v.view(np.uint8))
+
+
+def test_three_schedules_one_volume_at_full_size(monkeypatch):
+    """600 frames of the 640x480 benchmark stream fused three ways -- one frame per launch through the persistent pipelined kernel,
+    one frame per launch through k_integrate, 16 frames per pass -- must leave byte-identical volumes (sha256 over coordinates and
+    voxels): the size-independent property behind the bit-exactness claims at BASELINE's full size."""
+    import ctypes as C
+    import hashlib
+    from scannet_amd import _abi, fusion
+    W, H, N = 640, 480, 600
+    L = _abi.lib()
+    dptr = C.c_void_p()
+    _abi.check(L.sf_device_malloc(0, N * W * H * 2, C.byref(dptr)))
+    try:
+        poses = np.zeros((N, 16), np.float32)
+        _abi.check(L.sf_synth_room_device(dptr, W * H * 2, 0, N, 5578, W, H, 1, poses.ctypes.data_as(C.c_void_p)))
+        params = fusion.default_params()
+        digests = []
+        for env in ({"SF_BATCH": "1"}, {"SF_BATCH": "1", "SF_PIPE": "0"}, {}):
+            for k in ("SF_BATCH", "SF_PIPE"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            with fusion.Fuser(params) as f:
+                f.integrate_batch_device(dptr.value, W * H * 2, poses)
+                f.sync()
+                c, v = f.export_blocks()
+                digests.append((len(c), hashlib.sha256(c.tobytes() + v.tobytes()).hexdigest()))
+        assert digests[0][0] > 50000 and len(set(digests)) == 1, digests
+    finally:
+        L.sf_device_free(dptr)
