@@ -72,3 +72,28 @@ class Filter2d:
         us = C.c_float(0)
         check(_lib().sf_filter2d_frame(self._h, d.ctypes.data, c.ctypes.data, i.ctypes.data, io.ctypes.data, lo.ctypes.data, C.byref(us)))
         return io, lo, us.value
+
+
+# ---- PNG images of the annotation tools (scannet_amd/csrc/png.cpp) -------------------------------------------------------
+def png_read(path):
+    """-> uint8 / uint16 array [H, W] (grey) or [H, W, C]."""
+    import os
+    L = _abi.lib()
+    L.sf_png_read.argtypes = [C.c_char_p] + [C.POINTER(C.c_uint32)] * 2 + [C.POINTER(C.c_int)] * 2 + [C.POINTER(C.c_void_p)]
+    L.sf_free.argtypes = [C.c_void_p]
+    L.sf_free.restype = None
+    w, h, c, b, d = C.c_uint32(), C.c_uint32(), C.c_int(), C.c_int(), C.c_void_p()
+    check(L.sf_png_read(os.fsencode(path), C.byref(w), C.byref(h), C.byref(c), C.byref(b), C.byref(d)))
+    ct = C.c_uint16 if b.value == 16 else C.c_uint8
+    a = np.ctypeslib.as_array(C.cast(d, C.POINTER(ct)), (h.value, w.value, c.value)).copy()
+    L.sf_free(d)
+    return a[..., 0] if c.value == 1 else a
+
+
+def png_write_gray(path, image):
+    import os
+    a = np.ascontiguousarray(image)
+    assert a.ndim == 2 and a.dtype in (np.uint8, np.uint16)
+    L = _abi.lib()
+    L.sf_png_write_gray.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]
+    check(L.sf_png_write_gray(os.fsencode(path), a.ctypes.data, a.shape[1], a.shape[0], 8 * a.dtype.itemsize))

@@ -116,6 +116,87 @@ def test_frame_golden():
     assert set(np.unique(lo)) <= {0, 4, 7, 39}
 
 
+def test_png_codec_against_pil(tmp_path):
+    """FreeImageWrapper::loadImage / saveImage of the tool (Filter2dAnnotations.cpp:340-341,400-401): 8-bit instance, 16-bit label."""
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    a8 = (np.add.outer(np.arange(97), np.arange(131)) % 256).astype(np.uint8)
+    a8[10:20, 30:60] = rng.integers(0, 256, (10, 30))
+    a16 = (np.add.outer(np.arange(97), np.arange(131)) * 37 % 65536).astype(np.uint16)
+    rgb = rng.integers(0, 256, (40, 50, 3), dtype=np.uint8)
+    # files written by PIL (adaptive scan-line filters, several IDAT strategies) -> this reader
+    for name, arr in (("a8", a8), ("a16", a16), ("rgb", rgb)):
+        for level in (1, 9):
+            p = str(tmp_path / ("%s_%d.png" % (name, level)))
+            Image.fromarray(arr).save(p, compress_level=level)
+            assert np.array_equal(filter2d.png_read(p), arr)
+    # this writer -> PIL
+    for name, arr in (("o8", a8), ("o16", a16), ("one", np.array([[7]], np.uint8))):
+        p = str(tmp_path / (name + ".png"))
+        filter2d.png_write_gray(p, arr)
+        assert np.array_equal(np.array(Image.open(p)).astype(arr.dtype), arr)
+        assert np.array_equal(filter2d.png_read(p), arr)
+    # damaged files are refused
+    blob = bytearray(open(str(tmp_path / "o8.png"), "rb").read())
+    blob[40] ^= 0xFF
+    open(str(tmp_path / "bad.png"), "wb").write(bytes(blob))
+    with pytest.raises(Exception):
+        filter2d.png_read(str(tmp_path / "bad.png"))
+    open(str(tmp_path / "not.png"), "wb").write(b"hello world, this is not a png file at all....")
+    with pytest.raises(Exception, match="not a PNG"):
+        filter2d.png_read(str(tmp_path / "not.png"))
+
+
+@pytest.mark.gpu
+def test_tool_end_to_end(tmp_path):
+    """bin/filter2dannotations on a three-frame scene: .sens + projected annotation PNGs + aggregation JSON + label map in, filtered
+    PNGs out, every frame compared with the checker; an invalid pose gives empty images; a finished scene is skipped."""
+    import subprocess
+    from scannet_amd import sens
+    K = np.eye(4, dtype=np.float32)
+    sd = sens.SensorData.create(CW, CH, DW, DH, K, K, color_compression=0, depth_compression=1)
+    scenes = [_scene(seed=s) for s in (3, 4, 5)]
+    for i, (d, rgb, inst) in enumerate(scenes):
+        pose = np.eye(4, dtype=np.float32) if i != 1 else np.full((4, 4), -np.inf, np.float32)
+        sd.add_frame(d, pose, color=rgb)
+    sens_path = str(tmp_path / "scene0.sens")
+    sd.save(sens_path)
+    sd.close()
+    ann = tmp_path / "annotations-2d" / "scene0"
+    (ann / "instance").mkdir(parents=True)
+    (ann / "label").mkdir()
+    for i, (_, _, inst) in enumerate(scenes):
+        filter2d.png_write_gray(str(ann / "instance" / ("%d.png" % i)), inst)
+        filter2d.png_write_gray(str(ann / "label" / ("%d.png" % i)), inst.astype(np.uint16) * 3)
+    agg = {"sceneId": "scannet.scene0", "appId": "Aggregator.v2", "segGroups": [
+        {"id": 0, "objectId": 0, "segments": [1, 2, 3], "label": "chair"}, {"id": 1, "objectId": 1, "segments": [4], "label": "the \"big\" table"},
+        {"id": 4, "objectId": 4, "segments": [], "label": "unknown thing"}], "segmentsFile": "scannet.scene0_vh_clean_2.0.010000.segs.json"}
+    (tmp_path / "scene0.aggregation.json").write_text(json.dumps(agg))
+    # label map: id = 1-based line number of the `category` column (LabelUtil.h:40-84)
+    rows = ["id\tcategory\tcount", "x\twall\t9", "x\tchair\t8", "x\t\t0", "x\tthe \"big\" table\t7"]
+    (tmp_path / "labels.tsv").write_text("\n".join(rows) + "\n")
+    out = tmp_path / "annotations-2d-filtered" / "scene0"
+    (tmp_path / "annotations-2d-filtered").mkdir()
+    exe = os.path.join(ROOT, "bin", "filter2dannotations")
+    cmd = [exe, str(ann), sens_path, str(tmp_path / "scene0.aggregation.json"), str(tmp_path / "labels.tsv"), str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0 and r.stderr == "", r.stderr
+    assert "read 3 labels" in r.stdout and "3 frames" in r.stdout
+    tables = filter2d.make_tables({0: 2, 1: 4, 4: 0})       # chair = line 2, the "big" table = line 4, unknown thing -> 0
+    for i, (d, rgb, inst) in enumerate(scenes):
+        gi = filter2d.png_read(str(out / "instance" / ("%d.png" % i)))
+        gl = filter2d.png_read(str(out / "label" / ("%d.png" % i)))
+        if i == 1:
+            assert not gi.any() and not gl.any()
+            continue
+        oi, ol = orc.f2d_frame(d, rgb, inst, *tables)
+        assert np.array_equal(gi, oi) and np.array_equal(gl, ol), i
+    again = subprocess.run(cmd, capture_output=True, text=True)
+    assert again.returncode == 0 and "skipping, already exists" in again.stdout
+    bad = subprocess.run([exe, str(tmp_path / "nope"), sens_path, "a", "b", str(out)], capture_output=True, text=True)
+    assert bad.returncode != 0 and "instance/label dir does not exist" in bad.stderr
+
+
 @pytest.mark.gpu
 def test_gpu_matches_the_checker_bit_for_bit():
     depth, rgb, inst = _scene()
