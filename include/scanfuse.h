@@ -327,6 +327,42 @@ int sf_png_write_gray(const char* path, const void* data, uint32_t width, uint32
 void sf_free(void* p);
 
 /* ------------------------------------------------------------------------------------------------
+ * Annotation projection (scannet_amd/csrc/project.hip, annotations.cpp).  Replaces the Direct3D 11 render + read-back + filters of
+ * AnnotationTools/ProjectAnnotations/Visualizer.cpp:57-193 (render) with shaders/drawAnnotations.hlsl:9-33, and the vertex labelling
+ * of Visualizer.cpp:259-377.  Parameters: ProjectAnnotations/zParametersScan.txt:6,12-15.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct sf_project_params {
+  uint32_t color_width, color_height;      /* render target = the .sens colour size (Visualizer.cpp:51)      */
+  uint32_t depth_width, depth_height;
+  float fx, fy;                            /* m_calibrationColor.m_intrinsic(0,0) / (1,1) (:91)              */
+  float depth_min, depth_max;              /* s_depthMin 0.1, s_depthMax 15.0                                */
+  float depth_dist_thresh;                 /* s_depthDistThresh 0.2                                          */
+  int32_t filter_using_original_depth;     /* s_filterUsingOrigialDepthImage false                           */
+} sf_project_params;
+typedef struct sf_projector sf_projector;
+int sf_projector_create(const sf_project_params* params, int device, sf_projector** out);
+void sf_projector_destroy(sf_projector* p);
+int sf_projector_max_batch(void);
+/* the mesh to draw, with the (instance, label) pair its m_Colors .z / .w hold (Visualizer.cpp:275,289); host pointers, copied */
+int sf_projector_set_mesh(sf_projector* p, const float* xyz, uint64_t num_vertices, const uint32_t* triangles, uint64_t num_triangles,
+                          const uint8_t* vertex_instance, const uint16_t* vertex_label);
+/* n <= sf_projector_max_batch() frames.  cam2world: n x 16 row-major, first element -inf = no valid transform -> empty images
+ * (:63,187-192).  orig_depth: n x depth_w*depth_h u16 millimetres (NULL: no depth-consistency filter).  Outputs n x color_w*color_h.
+ * zcam_out (nullable): rendered depth in metres at colour resolution (:123-141). */
+int sf_projector_run(sf_projector* p, int n, const float* cam2world, const uint16_t* orig_depth, uint8_t* instance_out, uint16_t* label_out,
+                     float* zcam_out /*nullable*/, float* kernel_us /*nullable*/);
+/* page-locked host buffers: images passed to / from sf_projector_run in such memory are copied at PCIe speed (pageable works, slower) */
+int sf_host_alloc(uint64_t bytes, void** out);
+void sf_host_free(void* p);
+/* computeObjectIdsAndColorsPerVertex (:259-295) for the mesh the segs.json indexes: vertex -> (instance, label), 0 = unannotated */
+int sf_annotation_vertex_ids(const char* segs_json, const char* aggregation_json, const char* label_map_tsv, uint64_t num_vertices,
+                             uint8_t* vertex_instance, uint16_t* vertex_label, uint32_t* num_labels /*nullable*/);
+/* propagateAnnotations (:297-377): ids of the decimated mesh carried to the high-resolution one (exact 3-nearest-neighbour search) */
+int sf_annotation_propagate(const float* src_xyz, uint64_t src_vertices, const uint32_t* src_tris, uint64_t src_triangles, const uint8_t* src_instance,
+                            const uint16_t* src_label, const float* dst_xyz, uint64_t dst_vertices, const uint32_t* dst_tris, uint64_t dst_triangles,
+                            float normal_thresh, uint8_t* dst_instance, uint16_t* dst_label);
+
+/* ------------------------------------------------------------------------------------------------
  * Triangle meshes and the PLY surface (README.md:45-46: binary little-endian PLY, vertex float x,y,z +
  * uchar red,green,blue,alpha, face list uchar int vertex_indices).  sf_ply_read replaces tinyply as the
  * Segmentator uses it (Segmentator/segmentator.cpp:131-141, tinyply.cpp:54-108,306-360): ascii / binary

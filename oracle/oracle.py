@@ -280,3 +280,39 @@ def f2d_frame(depth, rgb, instance, to_idx, to_inst, to_label):
     L.or_f2d_frame(d.ctypes.data, d.shape[1], d.shape[0], c.ctypes.data, cw, ch, i.ctypes.data, a.ctypes.data, b.ctypes.data, t.ctypes.data,
                    io.ctypes.data, lo.ctypes.data)
     return io, lo
+
+
+# ---------------------------------------------------------------- annotation projection (oracle/project_oracle.c)
+class OrProjectParams(C.Structure):
+    _fields_ = [("color_width", C.c_uint32), ("color_height", C.c_uint32), ("depth_width", C.c_uint32), ("depth_height", C.c_uint32),
+                ("fx", C.c_float), ("fy", C.c_float), ("depth_min", C.c_float), ("depth_max", C.c_float), ("depth_dist_thresh", C.c_float),
+                ("filter_using_original_depth", C.c_int32)]
+
+
+def project_frame(params, xyz, tris, vinst, vlabel, cam2world, orig_depth=None, want_depth=False):
+    """Visualizer.cpp:57-193 for one frame -> (instance, label[, rendered depth in metres])."""
+    L = lib()
+    vp = C.c_void_p
+    L.or_project_frame.argtypes = [C.POINTER(OrProjectParams), vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp, vp, vp, vp, vp]
+    P = OrProjectParams(*[getattr(params, f) for f, _ in OrProjectParams._fields_])
+    x = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    t = np.ascontiguousarray(tris, np.uint32).reshape(-1, 3)
+    vi, vl = np.ascontiguousarray(vinst, np.uint8), np.ascontiguousarray(vlabel, np.uint16)
+    c = np.ascontiguousarray(cam2world, np.float32).reshape(16)
+    d = None if orig_depth is None else np.ascontiguousarray(orig_depth, np.uint16)
+    io = np.empty((P.color_height, P.color_width), np.uint8)
+    lo = np.empty((P.color_height, P.color_width), np.uint16)
+    z = np.empty((P.color_height, P.color_width), np.float32) if want_depth else None
+    rc = L.or_project_frame(C.byref(P), x.ctypes.data, len(x), t.ctypes.data, len(t), vi.ctypes.data, vl.ctypes.data, c.ctypes.data,
+                            d.ctypes.data if d is not None else None, io.ctypes.data, lo.ctypes.data, z.ctypes.data if z is not None else None)
+    assert rc == 0
+    return (io, lo, z) if want_depth else (io, lo)
+
+
+def project_matrix(cam2world, fx, fy, W, H, n, f):
+    L = lib()
+    L.or_project_matrix.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_void_p]
+    c = np.ascontiguousarray(cam2world, np.float32).reshape(16)
+    M = np.zeros(16, np.float32)
+    L.or_project_matrix(c.ctypes.data, fx, fy, W, H, n, f, M.ctypes.data)
+    return M.reshape(4, 4)
