@@ -4,9 +4,10 @@
 // `nointerpolation`, so a fragment carries the ids of its triangle's first vertex).
 //
 //   k_pa_vertex      position * worldViewProj for every vertex of every frame in the batch        drawAnnotations.hlsl:16-27
-//   k_pa_raster      one wave per cluster of 64 triangles (culled as a whole against the view volume), one lane per triangle: near-plane
-//                    clip, 1/256-pixel snap, edge functions stepped over the bounding box with the top-left rule, depth test as a
-//                    64-bit atomicMin on {z bits, triangle index}; bounding boxes of more than 256 pixels go to a queue
+//   k_pa_raster      one wave per cluster of 64 triangles (culled as a whole against the view volume); set-up one lane per triangle
+//                    (near-plane clip, 1/256-pixel snap, edge functions with the top-left rule, depth plane), traversal one triangle
+//                    per wave step with the lanes on the pixels of a block; depth test = 64-bit atomicMin on {z bits, triangle
+//                    index}; triangles spanning more than 64 pixels go to a queue
 //   k_pa_raster_big  one workgroup per queued triangle, lanes strided over its bounding box
 // (measured and dropped: binning the triangles to 64 x 64 screen tiles and rasterising each tile into an LDS depth buffer -- the
 //  same-address atomics of the tile counters and the serial per-lane loops of one workgroup per tile cost 940 us per 8 frames
@@ -33,7 +34,6 @@
 namespace {
 
 constexpr int PA_MAX_BATCH = 8;
-constexpr int PA_BIG_PIXELS = 256;   // bounding boxes above this go to the workgroup-per-triangle kernel
 constexpr int PA_CLUSTER = 64;       // triangles per culling cluster = one wave of k_pa_raster
 
 struct PaK {
@@ -203,10 +203,13 @@ __global__ __launch_bounds__(256) void k_pa_cluster_bounds(const float* __restri
   }
 }
 
-// One wave per cluster, one lane per triangle.  A cluster whose box lies outside one plane of the view volume (with a margin far above
-// the rounding of the vertex transform) is dropped by the whole wave before any triangle is read.  A surviving triangle is clipped,
-// projected, snapped and set up; bounding boxes of up to PA_BIG_PIXELS pixels are walked by the lane itself, larger ones are queued
-// for k_pa_raster_big.  Depth test = 64-bit atomicMin on {z bits, triangle index}.
+// One wave per cluster.  A cluster whose box lies outside one plane of the view volume (with a margin far above the rounding of the
+// vertex transform) is dropped by the whole wave before any triangle is read.  Set-up is one lane per triangle (clip, project, snap,
+// edge functions, depth plane); the traversal is one triangle at a time for the whole wave: the owner's set-up is broadcast (readlane
+// -> SGPRs) and the 64 lanes take the pixels of a 2^s x 2^(6-s) block that walks the bounding box, so the depth tests of one row of
+// fragments fall into one or two cache lines instead of one line per fragment (a lane-per-triangle traversal was bound by exactly
+// that: 388 us per 8 frames, the same with half the arithmetic).  Triangles spanning more than 64 pixels go to k_pa_raster_big.
+// Depth test = 64-bit atomicMin on {z bits, triangle index}.
 __global__ __launch_bounds__(256) void k_pa_raster(PaK P, PaBatch Bt, const uint32_t* __restrict__ tris, const float4* __restrict__ clip_all,
                                                    const float* __restrict__ bounds, unsigned long long* __restrict__ zbuf_all,
                                                    uint32_t* __restrict__ late_all, uint32_t* __restrict__ late_count) {
@@ -224,47 +227,72 @@ __global__ __launch_bounds__(256) void k_pa_raster(PaK P, PaBatch Bt, const uint
     const float m = 1.0e-3f * (1.0f + fabsf(cw) + fmaxf(fabsf(cx), fmaxf(fabsf(cy), fabsf(cz))));
     if (__all(cx + cw < -m) || __all(cw - cx < -m) || __all(cy + cw < -m) || __all(cw - cy < -m) || __all(cz < -m)) return;
   }
+  // from here on the wave stays together: lanes without a triangle still rasterise the others' pixels
   const uint32_t t = cluster * PA_CLUSTER + lane;
-  if (t >= P.F) return;
-  ScrV s[4];
-  const int ntri = clip_and_project(P, tris, clip_all + (size_t)q * P.V, t, s);
   unsigned long long* zbuf = zbuf_all + (size_t)q * P.w * P.h;
+  ScrV s[4];
+  const int ntri = t < P.F ? clip_and_project(P, tris, clip_all + (size_t)q * P.V, t, s) : 0;
   uint32_t late_id[2];
   int nlate = 0;
-  for (int sub = 0; sub < ntri; sub++) {
-    TriSetup S;
-    if (!tri_setup(S, P.w, P.h, s[0], s[1 + sub], s[2 + sub])) continue;
-    if ((long long)(S.i1 - S.i0 + 1) * (S.j1 - S.j0 + 1) > PA_BIG_PIXELS) {
-      late_id[nlate++] = 2u * t + (uint32_t)sub;
-      continue;
-    }
-    // edge functions stepped across the bounding box (exact integers: the same values shade() gets by multiplication); in 32 bits when
-    // the triangle spans at most 64 pixels each way (|edge| <= 2^14 subpixels, |edge function| < 2^30 inside the box), else in 64
-    const long long px0 = 256ll * S.i0 + 128, py0 = 256ll * S.j0 + 128;
-    const long long q0 = S.ex0 * (py0 - S.y0) - S.ey0 * (px0 - S.x0);
-    const long long q1 = S.ex1 * (py0 - S.y1) - S.ey1 * (px0 - S.x1);
-    const long long q2 = S.ex2 * (py0 - S.y2) - S.ey2 * (px0 - S.x2);
-    auto walk = [&](auto r0, auto r1, auto r2) {
-      using T = decltype(r0);
-      const T sx0 = (T)(-(S.ey0 * 256)), sx1 = (T)(-(S.ey1 * 256)), sx2 = (T)(-(S.ey2 * 256));
-      const T sy0 = (T)(S.ex0 * 256), sy1 = (T)(S.ex1 * 256), sy2 = (T)(S.ex2 * 256);
-      for (int j = S.j0; j <= S.j1; j++) {
-        T e0 = r0, e1 = r1, e2 = r2;
-        unsigned long long* row = zbuf + (size_t)j * P.w;
-        const float zrow = (float)(j - S.j0) * S.dzdy;
-        for (int i = S.i0; i <= S.i1; i++) {
-          if ((e0 | e1 | e2) >= 0 && !((e0 == 0 && !S.tl0) || (e1 == 0 && !S.tl1) || (e2 == 0 && !S.tl2))) {
-            const float z = (S.zc + (float)(i - S.i0) * S.dzdx) + zrow;
-            if (z >= 0.0f && z <= 1.0f) atomicMin(&row[i], ((unsigned long long)__float_as_uint(z) << 32) | t);
-          }
-          e0 += sx0; e1 += sx1; e2 += sx2;
+  for (int sub = 0; sub < 2; sub++) {
+    // this lane's triangle: 32-bit set-up when it spans at most 64 pixels each way (|edge| <= 2^14 subpixels, so every edge function
+    // is below 2^30 inside the box), otherwise the queue
+    int r0 = 0, r1 = 0, r2 = 0, sx0 = 0, sx1 = 0, sx2 = 0, sy0 = 0, sy1 = 0, sy2 = 0, origin = 0, extent = 0, tl = 0;
+    float zc = 0.0f, dzdx = 0.0f, dzdy = 0.0f;
+    bool small = false;
+    if (sub < ntri) {
+      TriSetup S;
+      if (tri_setup(S, P.w, P.h, s[0], s[1 + sub], s[2 + sub])) {
+        const long long span = max(max(llabs(S.ex0), llabs(S.ex1)), max(max(llabs(S.ex2), llabs(S.ey0)), max(llabs(S.ey1), llabs(S.ey2))));
+        if (span <= 16384) {
+          const long long px0 = 256ll * S.i0 + 128, py0 = 256ll * S.j0 + 128;
+          r0 = (int)(S.ex0 * (py0 - S.y0) - S.ey0 * (px0 - S.x0));
+          r1 = (int)(S.ex1 * (py0 - S.y1) - S.ey1 * (px0 - S.x1));
+          r2 = (int)(S.ex2 * (py0 - S.y2) - S.ey2 * (px0 - S.x2));
+          sx0 = (int)(-(S.ey0 * 256)); sx1 = (int)(-(S.ey1 * 256)); sx2 = (int)(-(S.ey2 * 256));
+          sy0 = (int)(S.ex0 * 256); sy1 = (int)(S.ex1 * 256); sy2 = (int)(S.ex2 * 256);
+          origin = S.i0 | (S.j0 << 16);
+          extent = (S.i1 - S.i0 + 1) | ((S.j1 - S.j0 + 1) << 8);
+          tl = (S.tl0 ? 1 : 0) | (S.tl1 ? 2 : 0) | (S.tl2 ? 4 : 0);
+          zc = S.zc; dzdx = S.dzdx; dzdy = S.dzdy;
+          small = true;
+        } else {
+          late_id[nlate++] = 2u * t + (uint32_t)sub;
         }
-        r0 += sy0; r1 += sy1; r2 += sy2;
       }
-    };
-    const long long span = max(max(llabs(S.ex0), llabs(S.ex1)), max(max(llabs(S.ex2), llabs(S.ey0)), max(llabs(S.ey1), llabs(S.ey2))));
-    if (span <= 16384) walk((int)q0, (int)q1, (int)q2);
-    else walk(q0, q1, q2);
+    }
+    unsigned long long todo = __ballot(small);
+    while (todo) {
+      const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+      todo &= todo - 1;
+      const int R0 = __builtin_amdgcn_readlane(r0, src), R1 = __builtin_amdgcn_readlane(r1, src), R2 = __builtin_amdgcn_readlane(r2, src);
+      const int SX0 = __builtin_amdgcn_readlane(sx0, src), SX1 = __builtin_amdgcn_readlane(sx1, src), SX2 = __builtin_amdgcn_readlane(sx2, src);
+      const int SY0 = __builtin_amdgcn_readlane(sy0, src), SY1 = __builtin_amdgcn_readlane(sy1, src), SY2 = __builtin_amdgcn_readlane(sy2, src);
+      const int org = __builtin_amdgcn_readlane(origin, src), ext = __builtin_amdgcn_readlane(extent, src), TL = __builtin_amdgcn_readlane(tl, src);
+      const float ZC = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(zc), src));
+      const float DZX = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dzdx), src));
+      const float DZY = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dzdy), src));
+      const uint32_t id = cluster * PA_CLUSTER + (uint32_t)src;
+      const int i0 = org & 0xffff, j0 = org >> 16, bw = ext & 0xff, bh = ext >> 8;
+      const int sh = bw > 32 ? 6 : (bw > 16 ? 5 : (bw > 8 ? 4 : 3));   // block of 2^sh x 2^(6-sh) pixels
+      const int lx = lane & ((1 << sh) - 1), ly = lane >> sh;
+      const int step_x = 1 << sh, step_y = 64 >> sh;
+      for (int by = 0; by < bh; by += step_y) {
+        const int dy = by + ly;
+        unsigned long long* row = zbuf + (size_t)(j0 + dy) * P.w + i0;
+        const float zrow = (float)dy * DZY;
+        for (int bx = 0; bx < bw; bx += step_x) {
+          const int dx = bx + lx;
+          if (dx < bw && dy < bh) {
+            const int e0 = R0 + dx * SX0 + dy * SY0, e1 = R1 + dx * SX1 + dy * SY1, e2 = R2 + dx * SX2 + dy * SY2;
+            if ((e0 | e1 | e2) >= 0 && !((e0 == 0 && !(TL & 1)) || (e1 == 0 && !(TL & 2)) || (e2 == 0 && !(TL & 4)))) {
+              const float z = (ZC + (float)dx * DZX) + zrow;
+              if (z >= 0.0f && z <= 1.0f) atomicMin(&row[dx], ((unsigned long long)__float_as_uint(z) << 32) | id);
+            }
+          }
+        }
+      }
+    }
   }
   // queue appends, one atomic per wave and round
   for (int k = 0; k < 2; k++) {
