@@ -209,6 +209,8 @@ __global__ __launch_bounds__(256) void k_pa_cluster_bounds(const float* __restri
 // -> SGPRs) and the 64 lanes take the pixels of a 2^s x 2^(6-s) block that walks the bounding box, so the depth tests of one row of
 // fragments fall into one or two cache lines instead of one line per fragment (a lane-per-triangle traversal was bound by exactly
 // that: 388 us per 8 frames, the same with half the arithmetic).  Triangles spanning more than 64 pixels go to k_pa_raster_big.
+// (Measured and dropped: set-up and traversal as two kernels with 64-byte records read back through scalar loads -- balanced, a
+// single frame 36 us instead of 91, but 261 us instead of 200 for a batch of eight.)
 // Depth test = 64-bit atomicMin on {z bits, triangle index}.
 __global__ __launch_bounds__(256) void k_pa_raster(PaK P, PaBatch Bt, const uint32_t* __restrict__ tris, const float4* __restrict__ clip_all,
                                                    const float* __restrict__ bounds, unsigned long long* __restrict__ zbuf_all,
@@ -377,41 +379,57 @@ __global__ __launch_bounds__(256) void k_pa_resolve(PaK P, PaBatch Bt, const uin
   label_all[(size_t)q * n + i] = label;
 }
 
-// 32 x 8 pixels per workgroup, the labels of the tile and its two-pixel apron staged in LDS (1.7 loads per pixel instead of 25)
+// 64 x 8 pixels per workgroup, the labels of the tile and its two-pixel apron staged in LDS; a lane votes for two neighbouring pixels
+// and reads their 6 x 5 window as 15 aligned 32-bit words (7.5 LDS reads per pixel instead of 25 -- the kernel is LDS-issue bound)
 __global__ __launch_bounds__(256) void k_pa_vote(PaK P, const uint8_t* __restrict__ inst_in, const uint16_t* __restrict__ label_in,
                                                  uint8_t* __restrict__ inst_out, uint16_t* __restrict__ label_out) {
-  __shared__ uint16_t tile[12][40];
-  const int tiles_x = (P.w + 31) / 32;
+  __shared__ uint32_t tile32[12][36];   // 12 rows x 72 labels (68 used)
+  uint16_t(*tile)[72] = reinterpret_cast<uint16_t(*)[72]>(tile32);
+  const int tiles_x = (P.w + 63) / 64;
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
   const int q = blockIdx.y;
   const int n = P.w * P.h;
   const uint16_t* L = label_in + (size_t)q * n;
-  const int x0 = tx * 32 - 2, y0 = ty * 8 - 2;
-  for (int k = threadIdx.x; k < 12 * 36; k += 256) {
-    const int r = k / 36, c = k % 36;
+  const int x0 = tx * 64 - 2, y0 = ty * 8 - 2;
+  for (int k = threadIdx.x; k < 12 * 68; k += 256) {
+    const int r = k / 68, c = k % 68;
     const int x = x0 + c, y = y0 + r;
     tile[r][c] = (x >= 0 && x < P.w && y >= 0 && y < P.h) ? L[(size_t)y * P.w + x] : (uint16_t)0;
   }
   __syncthreads();
-  const int lx = threadIdx.x % 32, ly = threadIdx.x / 32;
-  const int x = tx * 32 + lx, y = ty * 8 + ly;
+  const int lx = 2 * (threadIdx.x % 32), ly = threadIdx.x / 32;
+  const int x = tx * 64 + lx, y = ty * 8 + ly;
   if (x >= P.w || y >= P.h) return;
-  const int i = y * P.w + x;
-  const uint16_t v = tile[ly + 2][lx + 2];
-  uint8_t inst = 0;
-  uint16_t label = 0;
-  if (v != 0) {
-    // pixels outside the image hold 0 in the tile and v != 0, so they never count; `total` is the in-image part of the window
-    unsigned count = 0;
+  const uint32_t centre = tile32[ly + 2][lx / 2 + 1];
+  const uint32_t va = centre & 0xffffu, vb = centre >> 16;   // labels of (x, y) and (x + 1, y)
+  unsigned ca = 0, cb = 0;
+  if (va != 0 || vb != 0) {
+    // pixels outside the image hold 0 in the tile and a voting label is never 0, so they never count
 #pragma unroll
-    for (int dy = 0; dy < 5; dy++)
-#pragma unroll
-      for (int dx = 0; dx < 5; dx++) count += tile[ly + dy][lx + dx] == v ? 1u : 0u;
-    const unsigned total = (unsigned)((min(x + 2, P.w - 1) - max(x - 2, 0) + 1) * (min(y + 2, P.h - 1) - max(y - 2, 0) + 1));
-    if (!((float)count / (float)total < 0.2f)) { label = v; inst = inst_in[(size_t)q * n + i]; }
+    for (int dy = 0; dy < 5; dy++) {
+      const uint32_t w0 = tile32[ly + dy][lx / 2], w1 = tile32[ly + dy][lx / 2 + 1], w2 = tile32[ly + dy][lx / 2 + 2];
+      const uint32_t c0 = w0 & 0xffffu, c1 = w0 >> 16, c2 = w1 & 0xffffu, c3 = w1 >> 16, c4 = w2 & 0xffffu, c5 = w2 >> 16;
+      ca += (c0 == va) + (c1 == va) + (c2 == va) + (c3 == va) + (c4 == va);
+      cb += (c1 == vb) + (c2 == vb) + (c3 == vb) + (c4 == vb) + (c5 == vb);
+    }
   }
-  inst_out[(size_t)q * n + i] = inst;
-  label_out[(size_t)q * n + i] = label;
+  const int rows = min(y + 2, P.h - 1) - max(y - 2, 0) + 1;
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int xx = x + k;
+    if (xx >= P.w) break;
+    const uint32_t v = k ? vb : va;
+    const unsigned count = k ? cb : ca;
+    const int i = y * P.w + xx;
+    uint8_t inst = 0;
+    uint16_t label = 0;
+    if (v != 0) {
+      const unsigned total = (unsigned)((min(xx + 2, P.w - 1) - max(xx - 2, 0) + 1) * rows);   // the in-image part of the window
+      if (!((float)count / (float)total < 0.2f)) { label = (uint16_t)v; inst = inst_in[(size_t)q * n + i]; }
+    }
+    inst_out[(size_t)q * n + i] = inst;
+    label_out[(size_t)q * n + i] = label;
+  }
 }
 
 // worldViewProj (Visualizer.cpp:91-93): view = rigid inverse of camera-to-world from its normalised columns, projection from fx, fy with
@@ -594,7 +612,7 @@ SF_API int sf_projector_run(sf_projector* p, int n, const float* cam2world, cons
   hipLaunchKernelGGL(k_pa_raster_big, dim3(512, n), dim3(256), 0, p->stream, k, b, p->tris, p->clip, p->zbuf, p->late, p->late_count);
   hipLaunchKernelGGL(k_pa_resolve, dim3((unsigned)((np + 255) / 256), n), dim3(256), 0, p->stream, k, b, p->tris, p->vinst, p->vlabel, p->zbuf, p->depth,
                      p->inst1, p->label1, zcam_out ? p->zcam : nullptr);
-  hipLaunchKernelGGL(k_pa_vote, dim3((unsigned)(((k.w + 31) / 32) * ((k.h + 7) / 8)), n), dim3(256), 0, p->stream, k, p->inst1, p->label1, p->inst2, p->label2);
+  hipLaunchKernelGGL(k_pa_vote, dim3((unsigned)(((k.w + 63) / 64) * ((k.h + 7) / 8)), n), dim3(256), 0, p->stream, k, p->inst1, p->label1, p->inst2, p->label2);
   SF_HIP_CHECK(hipGetLastError());
   if (kernel_us) SF_HIP_CHECK(hipEventRecord(p->e1, p->stream));
   SF_HIP_CHECK(hipMemcpyAsync(instance_out, p->inst2, (size_t)n * np, hipMemcpyDeviceToHost, p->stream));
