@@ -22,23 +22,57 @@
 
 #define MAX_NUM_LABELS_PER_SCENE 80 /* GlobalDefines.h:12 */
 
+/* the same sequence as scannet_amd/csrc/exp64.h: x = k ln2/32 + r, exp(x) = 2^(k >> 5) * T[k & 31] * (1 + p(r)), T as a double-double */
+static const double EXP_T[32][2] = {
+  {0x1p+0, 0x0p+0},
+  {0x1.059b0d3158574p+0, 0x1.d7p-55},
+  {0x1.0b5586cf9890fp+0, 0x1.8a8p-54},
+  {0x1.11301d0125b51p+0, -0x1.6c8p-54},
+  {0x1.172b83c7d517bp+0, -0x1.19p-55},
+  {0x1.1d4873168b9aap+0, 0x1.ep-54},
+  {0x1.2387a6e756238p+0, 0x1.9bp-54},
+  {0x1.29e9df51fdee1p+0, 0x1.61p-55},
+  {0x1.306fe0a31b715p+0, 0x1.6fp-55},
+  {0x1.371a7373aa9cbp+0, -0x1.638p-54},
+  {0x1.3dea64c123422p+0, 0x1.aep-55},
+  {0x1.44e086061892dp+0, 0x1.8p-59},
+  {0x1.4bfdad5362a27p+0, 0x1.d4p-56},
+  {0x1.5342b569d4f82p+0, -0x1.08p-55},
+  {0x1.5ab07dd485429p+0, 0x1.63p-54},
+  {0x1.6247eb03a5585p+0, -0x1.38p-54},
+  {0x1.6a09e667f3bcdp+0, -0x1.bep-54},
+  {0x1.71f75e8ec5f74p+0, -0x1.17p-55},
+  {0x1.7a11473eb0187p+0, -0x1.42p-55},
+  {0x1.82589994cce13p+0, -0x1.d5p-54},
+  {0x1.8ace5422aa0dbp+0, 0x1.6e8p-54},
+  {0x1.93737b0cdc5e5p+0, -0x1.78p-57},
+  {0x1.9c49182a3f09p+0, 0x1.c8p-56},
+  {0x1.a5503b23e255dp+0, -0x1.d3p-54},
+  {0x1.ae89f995ad3adp+0, 0x1.7ap-54},
+  {0x1.b7f76f2fb5e47p+0, -0x1.56p-56},
+  {0x1.c199bdd85529cp+0, 0x1.11p-55},
+  {0x1.cb720dcef9069p+0, 0x1.5p-56},
+  {0x1.d5818dcfba487p+0, 0x1.2fp-55},
+  {0x1.dfc97337b9b5fp+0, -0x1.1a8p-54},
+  {0x1.ea4afa2a490dap+0, -0x1.eap-54},
+  {0x1.f50765b6e454p+0, 0x1.9dp-54},
+};
 double or_exp64(double x) {
   if (x != x) return x;
   if (x > 709.782712893384) return (double)INFINITY;
   if (x < -745.2) return 0.0;
-  const double inv_ln2 = 1.4426950408889634074, ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
-  const double kf = floor(x * inv_ln2 + 0.5);
-  const double r = fma(-kf, ln2_lo, fma(-kf, ln2_hi, x));
-  const double c[14] = {1.0, 1.0, 0.5, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880, 1.0 / 3628800,
-                        1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0};
-  double p = c[13];
-  for (int i = 12; i >= 0; i--) p = fma(p, r, c[i]);  /* explicit fused multiply-add: one rounding, the same on both sides */
-  const int k = (int)kf, k1 = k / 2, k2 = k - k1;
-  const uint64_t ua = (uint64_t)(1023 + k1) << 52, ub = (uint64_t)(1023 + k2) << 52;
-  double a, b;
-  memcpy(&a, &ua, 8);
-  memcpy(&b, &ub, 8);
-  return p * a * b;
+  const double inv = 0x1.71547652b82fep+5, l_hi = 0x1.62e42feep-6, l_lo = 0x1.a39ef358p-38;
+  const double kf = floor(x * inv + 0.5);
+  const double r = fma(-kf, l_lo, fma(-kf, l_hi, x));
+  double q = 1.0 / 720;
+  q = fma(q, r, 1.0 / 120); /* explicit fused multiply-add: one rounding, the same on both sides */
+  q = fma(q, r, 1.0 / 24);
+  q = fma(q, r, 1.0 / 6);
+  q = fma(q, r, 0.5);
+  const double p = fma(r * r, q, r);
+  const int k = (int)kf, j = k & 31, m = k >> 5;
+  const double y = fma(EXP_T[j][0], p, EXP_T[j][1]) + EXP_T[j][0];
+  return ldexp(y, m);
 }
 
 static float gauss_r(float sigma, float dist) { /* filter.cu:190-193: (dist*dist) in float, the rest in double */

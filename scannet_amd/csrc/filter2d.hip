@@ -12,7 +12,7 @@
 // different banks whatever bins they vote for): no scratch buffer, no memset, no HBM traffic for votes.  The spatial Gaussian of
 // a launch is tabulated once per workgroup in LDS ((2r+1)^2 floats); the range Gaussians are evaluated per tap in binary64 as
 // the source's 2.0 literal demands (gaussR, filter.cu:190-193) -- this is fp64-ALU-bound work, which gfx950 has.
-// Arithmetic: statement by statement as the CUDA source, no contraction (-ffp-contract=off), exp() = sf_exp64 (exp64.h).
+// Arithmetic: statement by statement as the CUDA source, no contraction (-ffp-contract=off), exp() = sf_exp64_t (exp64.h, its table in LDS).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -26,11 +26,30 @@ namespace {
 constexpr int F2D_LABELS = 80;  // MAX_NUM_LABELS_PER_SCENE, GlobalDefines.h:12
 #define F2D_MINF (-INFINITY)
 
-__device__ inline float gauss_r(float sigma, float dist) {  // filter.cu:190-193
-  return (float)sf_exp64(-(double)(dist * dist) / (2.0 * (double)sigma * (double)sigma));
+// exp(-(double)(dist * dist) / (2.0 * sigma * sigma)) (filter.cu:190-193) with the divisor c = 2 sigma^2 and rc = RN(1 / c) fixed per
+// launch: q = a * rc, r = fma(-c, q, a) (exact), q + r * rc is the correctly rounded quotient a / c (Markstein; rc is the correctly
+// rounded reciprocal and q is within an ulp) -- three operations instead of the dozen of a binary64 division, same bits (the CPU
+// checker divides; 1.7e8 random (dist, sigma) pairs compared in the making).
+struct GaussR { double c, rc; };
+__device__ inline GaussR gauss_r_setup(float sigma) {
+  GaussR g;
+  g.c = 2.0 * (double)sigma * (double)sigma;
+  g.rc = 1.0 / g.c;
+  return g;
 }
-__device__ inline float gauss_d2(float sigma, int x, int y) {  // filter.cu:200-203
-  return (float)sf_exp64((double)(-((float)(x * x + y * y) / (2.0f * sigma * sigma))));
+__device__ inline float gauss_r(const GaussR& g, float dist, const double (*T)[2]) {
+  const double a = -(double)(dist * dist);
+  const double q = a * g.rc;
+  const double r = fma(-g.c, q, a);
+  return (float)sf_exp64_t(fma(r, g.rc, q), T);
+}
+__device__ inline float gauss_d2(float sigma, int x, int y, const double (*T)[2]) {  // filter.cu:200-203
+  return (float)sf_exp64_t((double)(-((float)(x * x + y * y) / (2.0f * sigma * sigma))), T);
+}
+// the 2^(j/32) table of exp64.h into LDS (all 256 lanes call it; followed by the caller's barrier)
+__device__ inline void load_exp_table(double (*T)[2]) {
+  static const double table[32][2] = SF_EXP64_TABLE;
+  if (threadIdx.x < 64) T[threadIdx.x >> 1][threadIdx.x & 1] = table[threadIdx.x >> 1][threadIdx.x & 1];
 }
 
 __global__ __launch_bounds__(256) void k_f2d_prepare(const uint16_t* __restrict__ depth16, float* __restrict__ depth, int dn,
@@ -47,9 +66,13 @@ __global__ __launch_bounds__(256) void k_f2d_prepare(const uint16_t* __restrict_
 __global__ __launch_bounds__(256) void k_f2d_bilateral(float* __restrict__ out, const float* __restrict__ in, float sigma_d, float sigma_r, int w, int h,
                                                        int radius) {
   extern __shared__ float s_gd[];  // (2r+1)^2
-  const int side = 2 * radius + 1;
-  for (int t = threadIdx.x; t < side * side; t += 256) s_gd[t] = gauss_d2(sigma_d, t / side - radius, t % side - radius);  // [dx + r][dy + r]
+  __shared__ double s_exp[32][2];
+  load_exp_table(s_exp);
   __syncthreads();
+  const int side = 2 * radius + 1;
+  for (int t = threadIdx.x; t < side * side; t += 256) s_gd[t] = gauss_d2(sigma_d, t / side - radius, t % side - radius, s_exp);  // [dx + r][dy + r]
+  __syncthreads();
+  const GaussR gr = gauss_r_setup(sigma_r);
   const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
   if (x >= w || y >= h) return;
   float result = F2D_MINF;
@@ -61,7 +84,7 @@ __global__ __launch_bounds__(256) void k_f2d_bilateral(float* __restrict__ out, 
         if (!(m >= 0 && n >= 0 && m < w && n < h)) continue;
         const float cur = in[(size_t)n * w + m];
         if (cur == F2D_MINF) continue;
-        const float weight = s_gd[(m - x + radius) * side + (n - y + radius)] * gauss_r(sigma_r, cur - center);
+        const float weight = s_gd[(m - x + radius) * side + (n - y + radius)] * gauss_r(gr, cur - center, s_exp);
         sum_weight += weight;
         sum += weight * cur;
       }
@@ -112,8 +135,12 @@ __global__ __launch_bounds__(256) void k_f2d_vote(uint8_t* __restrict__ out, con
   float* vote = s_mem;                       // F2D_LABELS x 256
   float* s_gd = s_mem + F2D_LABELS * 256;    // (2r+1)^2: [i + r][j + r]  (i = dy, j = dx)
   __shared__ uint8_t s_to_idx[256];
+  __shared__ double s_exp[32][2];
+  load_exp_table(s_exp);
+  __syncthreads();
+  const GaussR gr = gauss_r_setup(sigma_r);
   const int side = 2 * radius + 1;
-  for (int t = threadIdx.x; t < side * side; t += 256) s_gd[t] = gauss_d2(sigma_d, t % side - radius, t / side - radius);
+  for (int t = threadIdx.x; t < side * side; t += 256) s_gd[t] = gauss_d2(sigma_d, t % side - radius, t / side - radius, s_exp);
   s_to_idx[threadIdx.x] = instance_to_idx[threadIdx.x];
 #pragma unroll 4
   for (int b = 0; b < F2D_LABELS; b++) vote[b * 256 + threadIdx.x] = 0.0f;
@@ -130,7 +157,7 @@ __global__ __launch_bounds__(256) void k_f2d_vote(uint8_t* __restrict__ out, con
       const float io = fabsf(ic - in_) * intensity_scale;
       float doff = 0.0f;
       if (dc != F2D_MINF && d != F2D_MINF) doff = fabsf(dc - d);
-      const float weight = s_gd[(i + radius) * side + (j + radius)] * gauss_r(sigma_r, doff) * gauss_r(sigma_r, io);
+      const float weight = s_gd[(i + radius) * side + (j + radius)] * gauss_r(gr, doff, s_exp) * gauss_r(gr, io, s_exp);
       const uint8_t idx = s_to_idx[in[q]];
       if (idx < F2D_LABELS) vote[idx * 256 + threadIdx.x] += weight;
     }

@@ -25,6 +25,7 @@
 #include <map>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "scanfuse.h"
@@ -173,38 +174,98 @@ int main(int argc, const char** argv) {
   const int device = std::getenv("SF_DEVICE") ? std::atoi(std::getenv("SF_DEVICE")) : 0;
   if (sf_filter2d_create((int)dw, (int)dh, (int)cw, (int)ch, device, &filt) != SF_OK) return die("filter");
   if (sf_filter2d_set_tables(filt, to_idx, to_inst, to_label) != SF_OK) return die("tables");
-  std::vector<uint16_t> depth((size_t)dw * dh), label_out((size_t)cw * ch);
-  std::vector<uint8_t> rgb((size_t)cw * ch * 3), inst_out((size_t)cw * ch);
   const std::vector<std::string> files = list_files(label_dir);
-  size_t done = 0;
-  double kernel_ms = 0;
   for (const std::string& f : files) {
     const uint64_t frame = std::strtoull(f.c_str(), nullptr, 10);
     if (frame >= info.num_frames) { std::fprintf(stderr, "%s names frame %llu of %llu\n", f.c_str(), (unsigned long long)frame, (unsigned long long)info.num_frames); return 1; }
-    float pose[16];
-    int valid = 0;
-    sf_sens_pose(sd, frame, pose, &valid);
-    if (!valid) {
-      std::fill(inst_out.begin(), inst_out.end(), 0);
-      std::fill(label_out.begin(), label_out.end(), 0);
-    } else {
-      if (sf_sens_decode_depth(sd, frame, depth.data()) != SF_OK || sf_sens_decode_color(sd, frame, rgb.data()) != SF_OK) return die("frame decode");
-      uint32_t w = 0, h = 0;
-      int c = 0, b = 0;
-      void* data = nullptr;
-      if (sf_png_read((inst_dir + f).c_str(), &w, &h, &c, &b, &data) != SF_OK) return die("instance image");
-      if (w != cw || h != ch || c != 1 || b != 8) { std::fprintf(stderr, "%s%s: expected an 8-bit grey %ux%u image\n", inst_dir.c_str(), f.c_str(), cw, ch); return 1; }
-      float us = 0;
-      const int rc = sf_filter2d_frame(filt, depth.data(), rgb.data(), (const uint8_t*)data, inst_out.data(), label_out.data(), &us);
-      sf_free(data);
-      if (rc != SF_OK) return die("filter frame");
-      kernel_ms += us * 1e-3;
-    }
-    if (sf_png_write_gray((out_inst + f).c_str(), inst_out.data(), cw, ch, 8) != SF_OK || sf_png_write_gray((out_label + f).c_str(), label_out.data(), cw, ch, 16) != SF_OK)
-      return die("output image");
-    if (done % 10 == 0 || done + 1 == files.size()) { std::printf("\r[ %zu | %zu ]", done, files.size()); std::fflush(stdout); }
-    ++done;
   }
+  // Frames in chunks: while the GPU filters chunk k (one frame after the other), threads decode the inputs of chunk k+1 (depth inflate,
+  // colour JPEG, instance PNG) and write the PNGs of chunk k-1 -- the reference does all of it on one thread.
+  struct Frame {
+    std::string name;
+    bool valid = false;
+    std::vector<uint16_t> depth, label_out;
+    std::vector<uint8_t> rgb, inst_in, inst_out;
+    std::string error;
+  };
+  const size_t chunk_frames = 16;
+  struct Chunk { std::vector<Frame> frames; std::vector<std::thread> loaders, writers; size_t n = 0; };
+  Chunk chunks[2];
+  for (Chunk& c : chunks) {
+    c.frames.resize(chunk_frames);
+    for (Frame& f : c.frames) {
+      f.depth.resize((size_t)dw * dh); f.label_out.resize((size_t)cw * ch);
+      f.rgb.resize((size_t)cw * ch * 3); f.inst_in.resize((size_t)cw * ch); f.inst_out.resize((size_t)cw * ch);
+    }
+  }
+  auto start_load = [&](Chunk& c, size_t first) {
+    c.n = std::min(chunk_frames, files.size() - first);
+    for (size_t k = 0; k < c.n; k++) {
+      Frame* fr = &c.frames[k];
+      fr->name = files[first + k];
+      fr->error.clear();
+      c.loaders.emplace_back([&, fr] {
+        const uint64_t frame = std::strtoull(fr->name.c_str(), nullptr, 10);
+        float pose[16];
+        int valid = 0;
+        sf_sens_pose(sd, frame, pose, &valid);
+        fr->valid = valid != 0;
+        if (!fr->valid) return;
+        if (sf_sens_decode_depth(sd, frame, fr->depth.data()) != SF_OK || sf_sens_decode_color(sd, frame, fr->rgb.data()) != SF_OK) {
+          fr->error = std::string("frame decode: ") + sf_last_error();
+          return;
+        }
+        uint32_t w = 0, h = 0;
+        int c2 = 0, b2 = 0;
+        void* data = nullptr;
+        if (sf_png_read((inst_dir + fr->name).c_str(), &w, &h, &c2, &b2, &data) != SF_OK) { fr->error = std::string("instance image: ") + sf_last_error(); return; }
+        if (w != cw || h != ch || c2 != 1 || b2 != 8) fr->error = inst_dir + fr->name + ": expected an 8-bit grey " + std::to_string(cw) + "x" + std::to_string(ch) + " image";
+        else std::memcpy(fr->inst_in.data(), data, (size_t)cw * ch);
+        sf_free(data);
+      });
+    }
+  };
+  auto join = [](std::vector<std::thread>& v) { for (std::thread& t : v) t.join(); v.clear(); };
+  size_t done = 0;
+  double kernel_ms = 0;
+  int cur = 0;
+  if (!files.empty()) start_load(chunks[0], 0);
+  for (size_t first = 0; first < files.size(); first += chunk_frames, cur ^= 1) {
+    Chunk& c = chunks[cur];
+    Chunk& other = chunks[cur ^ 1];
+    join(c.loaders);
+    join(other.writers);
+    for (size_t k = 0; k < other.n; k++) if (!other.frames[k].error.empty()) { std::fprintf(stderr, "%s\n", other.frames[k].error.c_str()); return 1; }
+    if (first + chunk_frames < files.size()) start_load(other, first + chunk_frames);
+    for (size_t k = 0; k < c.n; k++) {
+      Frame& fr = c.frames[k];
+      if (!fr.error.empty()) { join(other.loaders); std::fprintf(stderr, "%s\n", fr.error.c_str()); return 1; }
+      if (!fr.valid) {
+        std::fill(fr.inst_out.begin(), fr.inst_out.end(), 0);
+        std::fill(fr.label_out.begin(), fr.label_out.end(), 0);
+      } else {
+        float us = 0;
+        if (sf_filter2d_frame(filt, fr.depth.data(), fr.rgb.data(), fr.inst_in.data(), fr.inst_out.data(), fr.label_out.data(), &us) != SF_OK) {
+          join(other.loaders);
+          return die("filter frame");
+        }
+        kernel_ms += us * 1e-3;
+      }
+      if (done % 10 == 0 || done + 1 == files.size()) { std::printf("\r[ %zu | %zu ]", done, files.size()); std::fflush(stdout); }
+      ++done;
+    }
+    for (size_t k = 0; k < c.n; k++) {
+      Frame* fr = &c.frames[k];
+      c.writers.emplace_back([&, fr] {
+        if (sf_png_write_gray((out_inst + fr->name).c_str(), fr->inst_out.data(), cw, ch, 8) != SF_OK ||
+            sf_png_write_gray((out_label + fr->name).c_str(), fr->label_out.data(), cw, ch, 16) != SF_OK)
+          fr->error = std::string("output image: ") + sf_last_error();
+      });
+    }
+  }
+  for (Chunk& c : chunks) { join(c.loaders); join(c.writers); }
+  for (Chunk& c : chunks)
+    for (size_t k = 0; k < c.n; k++) if (!c.frames[k].error.empty()) { std::fprintf(stderr, "%s\n", c.frames[k].error.c_str()); return 1; }
   std::printf("\n%zu frames, %.1f ms of GPU kernels\n", done, kernel_ms);
   sf_filter2d_destroy(filt);
   sf_sens_close(sd);
