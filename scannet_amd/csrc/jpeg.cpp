@@ -3,15 +3,17 @@
 // Replaces stb::stbi_load_from_memory as called by RGBDFrame::decompressColorAlloc_stb
 // (SensReader/c++/src/sensorData.h:609-616 -> sensorData/stb_image.h:1067,3411).  ScanNet colour frames are
 // baseline YCbCr 4:2:0 / 4:2:2 JPEGs written by the capture app; progressive streams are rejected with
-// SF_ERR_UNSUPPORTED.  Written from ITU-T T.81: exact separable float IDCT, triangle-filter ("fancy") 2x
-// chroma upsampling, BT.601 full-range YCbCr -> RGB.  T.81 does not define bit-exact decoding, so parity
+// SF_ERR_UNSUPPORTED.  Written from ITU-T T.81: separable float IDCT (AAN butterflies, jpeg_idct.h), triangle-filter
+// ("fancy") 2x chroma upsampling, BT.601 full-range YCbCr -> RGB.  T.81 does not define bit-exact decoding, so parity
 // with the reference's integer IDCT is a tolerance (tests/test_sens.py: max |diff| <= 4 levels, mean < 0.5).
+// Entropy decoding is the serial part; the reconstruction (jpeg_idct.h) is shared with the GPU path of the frame pipeline.
 #include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <vector>
 
 #include "common.h"
+#include "jpeg_idct.h"
 
 namespace {
 
@@ -21,6 +23,9 @@ struct HuffDC_AC {
   uint8_t vals[256];
   int32_t mincode[17], maxcode[18], valptr[17];
   uint16_t look[512];  // (len << 8) | symbol, 0 = slow path
+  // AC tables: for a 10-bit window that holds a whole short code AND the magnitude bits behind it,
+  // (value << 8) | (run << 4) | total bits; 0 = decode symbol and magnitude separately
+  int16_t fast_ac[1024];
   bool present = false;
   void build() {
     int code = 0, k = 0;
@@ -43,6 +48,16 @@ struct HuffDC_AC {
       }
       code <<= 1;
     }
+    for (int w = 0; w < 1024; w++) {
+      fast_ac[w] = 0;
+      const uint16_t e = look[w >> 1];
+      if (!e) continue;
+      const int len = e >> 8, run = (e >> 4) & 15, size = e & 15;
+      if (size == 0 || len + size > 10) continue;
+      int v = (w >> (10 - len - size)) & ((1 << size) - 1);
+      if (v < (1 << (size - 1))) v += 1 - (1 << size);   // T.81 F.2.2.1 EXTEND
+      if (v >= -128 && v <= 127) fast_ac[w] = (int16_t)(v * 256 + run * 16 + len + size);
+    }
     present = true;
   }
 };
@@ -57,25 +72,37 @@ struct Component {
 struct BitSrc {
   const uint8_t* p;
   const uint8_t* end;
-  uint32_t buf = 0;
-  int cnt = 0;
+  uint64_t buf = 0;   // the next bits of the entropy-coded segment, left-aligned
+  int cnt = 0;        // how many of them are valid
   bool hit_marker = false;
+  // top up to more than 32 valid bits: four bytes at once while none of them is 0xFF (stuffing / markers go through the byte loop)
   inline void fill() {
-    while (cnt <= 24) {
-      uint32_t b = 0;
+    if (!hit_marker && p + 4 <= end) {
+      uint32_t w;
+      std::memcpy(&w, p, 4);
+      const uint32_t n = ~w;
+      if (!((n - 0x01010101u) & ~n & 0x80808080u)) {   // no byte of w is 0xFF
+        buf |= (uint64_t)__builtin_bswap32(w) << (32 - cnt);
+        cnt += 32;
+        p += 4;
+        return;
+      }
+    }
+    while (cnt <= 56) {
+      uint64_t b = 0;
       if (!hit_marker && p < end) {
         b = *p;
         if (b == 0xFF) {
-          const uint8_t n = (p + 1 < end) ? p[1] : 0xD9;
-          if (n == 0) p += 2;
+          const uint8_t nx = (p + 1 < end) ? p[1] : 0xD9;
+          if (nx == 0) p += 2;
           else { hit_marker = true; b = 0; }
         } else p++;
       }
-      buf |= b << (24 - cnt);
+      buf |= b << (56 - cnt);
       cnt += 8;
     }
   }
-  inline int peek(int n) { return (int)(buf >> (32 - n)); }
+  inline int peek(int n) { return (int)(buf >> (64 - n)); }
   inline void drop(int n) { buf <<= n; cnt -= n; }
   inline int get(int n) {
     if (n == 0) return 0;
@@ -90,15 +117,15 @@ struct BitSrc {
 inline int extend(int v, int t) { return v < (1 << (t - 1)) ? v - (1 << t) + 1 : v; }
 
 inline int decode_huff(BitSrc& bs, const HuffDC_AC& h) {
-  if (bs.cnt < 16) bs.fill();
+  if (bs.cnt < 32) bs.fill();
   const uint16_t e = h.look[bs.peek(9)];
   if (e) { bs.drop(e >> 8); return e & 0xFF; }
   int code = bs.peek(9);
   int l = 9;
-  const uint32_t all = bs.buf;
+  const uint64_t all = bs.buf;
   while (l < 17 && code > h.maxcode[l]) {
     l++;
-    code = (int)(all >> (32 - l));
+    code = (int)(all >> (64 - l));
   }
   if (l > 16) return -1;
   bs.drop(l);
@@ -108,40 +135,29 @@ inline int decode_huff(BitSrc& bs, const HuffDC_AC& h) {
 const uint8_t ZIGZAG[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
                             35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
-struct IdctTable {
-  float c[8][8];  // c[x][u] = 0.5 * C(u) * cos((2x+1) u pi / 16)
-  IdctTable() {
-    for (int x = 0; x < 8; x++)
-      for (int u = 0; u < 8; u++) c[x][u] = (float)(0.5 * (u == 0 ? std::sqrt(0.5) : 1.0) * std::cos((2 * x + 1) * u * 3.14159265358979323846 / 16.0));
+// dequantised, AAN-scaled coefficients (natural order) -> 8 x 8 samples.  Columns first (the eight 1-D passes are independent: the
+// compiler vectorises across them), transpose, columns again (= the rows), transposed store.
+void idct_block(float* blk, bool dc_only, uint8_t* out, int stride) {
+  if (dc_only) {   // every butterfly adds or subtracts zeros: all 64 samples equal the scaled DC term, bit for bit
+    const uint8_t v = sf_jpeg_level(blk[0]);
+    for (int y = 0; y < 8; y++) std::memset(out + (size_t)y * stride, v, 8);
+    return;
   }
-};
-const IdctTable& idct_table() { static const IdctTable t; return t; }
-
-void idct_block(const float* in, uint8_t* out, int stride) {
-  const IdctTable& T = idct_table();
-  float tmp[64];
-  for (int v = 0; v < 8; v++)      // rows: over u
-    for (int x = 0; x < 8; x++) {
-      float s = 0;
-      for (int u = 0; u < 8; u++) s += T.c[x][u] * in[v * 8 + u];
-      tmp[v * 8 + x] = s;
-    }
-  for (int x = 0; x < 8; x++)
-    for (int y = 0; y < 8; y++) {
-      float s = 0;
-      for (int v = 0; v < 8; v++) s += T.c[y][v] * tmp[v * 8 + x];
-      const int q = (int)std::lrintf(s + 128.0f);
-      out[y * stride + x] = (uint8_t)(q < 0 ? 0 : (q > 255 ? 255 : q));
-    }
+  for (int c = 0; c < 8; c++) sf_idct8(blk + c, 8);
+  float t[64];
+  for (int y = 0; y < 8; y++)
+    for (int x = 0; x < 8; x++) t[x * 8 + y] = blk[y * 8 + x];
+  for (int c = 0; c < 8; c++) sf_idct8(t + c, 8);
+  for (int y = 0; y < 8; y++)
+    for (int x = 0; x < 8; x++) out[(size_t)y * stride + x] = sf_jpeg_level(t[x * 8 + y]);
 }
-
-inline uint8_t clamp8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
 
 }  // namespace
 
 int jpeg_decode_rgb(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t expect_w, uint32_t expect_h) {
   if (n < 4 || data[0] != 0xFF || data[1] != 0xD8) return sf::fail(SF_ERR_FORMAT, "jpeg: missing SOI");
   uint16_t qt[4][64];
+  float fq[4][64];   // quantiser step x AAN scale, natural order
   bool qt_ok[4] = {false, false, false, false};
   HuffDC_AC hdc[4], hac[4];
   Component comp[3];
@@ -167,6 +183,7 @@ int jpeg_decode_rgb(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t expe
         if (tq > 3 || q + (pq ? 128 : 64) > seg_end) return sf::fail(SF_ERR_FORMAT, "jpeg: bad DQT");
         for (int i = 0; i < 64; i++) { qt[tq][ZIGZAG[i]] = pq ? (uint16_t)u16(q + 2 * i) : data[q + i]; }
         q += pq ? 128 : 64;
+        for (int z = 0; z < 64; z++) fq[tq][z] = sf_jpeg_dequant(qt[tq][z], z);
         qt_ok[tq] = true;
       }
     } else if (m == 0xC4) {
@@ -241,7 +258,7 @@ int jpeg_decode_rgb(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t expe
     for (int mx = 0; mx < mcux; mx++) {
       for (int ci = 0; ci < ncomp; ci++) {
         Component& c = comp[ci];
-        const uint16_t* q = qt[c.tq];
+        const float* q = fq[c.tq];
         for (int by = 0; by < c.v; by++)
           for (int bx = 0; bx < c.h; bx++) {
             std::memset(blk, 0, sizeof(blk));
@@ -249,9 +266,23 @@ int jpeg_decode_rgb(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t expe
             if (t < 0 || t > 11) return sf::fail(SF_ERR_FORMAT, "jpeg: bad DC code");
             const int diff = t ? extend(bs.get(t), t) : 0;
             c.pred += diff;
-            blk[0] = (float)(c.pred * (int)q[0]);
+            blk[0] = (float)c.pred * q[0];
+            bool dc_only = true;
+            const HuffDC_AC& ac = hac[c.ta];
             for (int k = 1; k < 64;) {
-              const int rs = decode_huff(bs, hac[c.ta]);
+              if (bs.cnt < 32) bs.fill();
+              const int fa = ac.fast_ac[bs.peek(10)];
+              if (fa) {   // run, size and magnitude from one look-up
+                k += (fa >> 4) & 15;
+                if (k > 63) return sf::fail(SF_ERR_FORMAT, "jpeg: AC run past the end of the block");
+                bs.drop(fa & 15);
+                const int z = ZIGZAG[k];
+                blk[z] = (float)(fa >> 8) * q[z];
+                dc_only = false;
+                k++;
+                continue;
+              }
+              const int rs = decode_huff(bs, ac);
               if (rs < 0) return sf::fail(SF_ERR_FORMAT, "jpeg: bad AC code");
               const int r = rs >> 4, s = rs & 15;
               if (s == 0) {
@@ -261,10 +292,11 @@ int jpeg_decode_rgb(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t expe
               k += r;
               if (k > 63) return sf::fail(SF_ERR_FORMAT, "jpeg: AC run past the end of the block");
               const int z = ZIGZAG[k];
-              blk[z] = (float)(extend(bs.get(s), s) * (int)q[z]);
+              blk[z] = (float)extend(bs.get(s), s) * q[z];
+              dc_only = false;
               k++;
             }
-            idct_block(blk, c.plane + (size_t)((my * c.v + by) * 8) * c.bw + (mx * c.h + bx) * 8, c.bw);
+            idct_block(blk, dc_only, c.plane + (size_t)((my * c.v + by) * 8) * c.bw + (mx * c.h + bx) * 8, c.bw);
           }
       }
       if (--todo <= 0) {
@@ -286,48 +318,61 @@ int jpeg_decode_rgb(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t expe
       }
     return SF_OK;
   }
-  static thread_local std::vector<uint8_t> up[3];
+  // chroma to full resolution and YCbCr -> RGB, one output row at a time.  2x: triangle filter (3/4 of the nearer sample, 1/4 of the
+  // farther one, vertically then horizontally, the image border replicated); other integer ratios: nearest.
+  static thread_local std::vector<int16_t> vb[3];    // vertical blend of one chroma row (scaled by 4)
+  static thread_local std::vector<uint8_t> row[3];   // full-resolution row of each component
   const uint8_t* full[3];
-  int fstride[3];
   for (int ci = 0; ci < 3; ci++) {
     Component& c = comp[ci];
-    const int sx = hmax / c.h, sy = vmax / c.v;
-    if (sx == 1 && sy == 1) { full[ci] = c.plane; fstride[ci] = c.bw; continue; }
     if ((hmax % c.h) || (vmax % c.v)) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: fractional sampling ratios are not supported");
-    const int cw = (width * c.h + hmax - 1) / hmax, ch = (height * c.v + vmax - 1) / vmax;  // valid chroma samples
-    if (up[ci].size() < (size_t)width * height) up[ci].resize((size_t)width * height);  // fully written below
-    for (int y = 0; y < height; y++) {
-      // vertical: triangle filter for 2x, nearest otherwise
+    if (vb[ci].size() < (size_t)c.bw + 2) vb[ci].resize((size_t)c.bw + 2);
+    if (row[ci].size() < (size_t)width + 2) row[ci].resize((size_t)width + 2);
+  }
+  for (int y = 0; y < height; y++) {
+    for (int ci = 0; ci < 3; ci++) {
+      Component& c = comp[ci];
+      const int sx = hmax / c.h, sy = vmax / c.v;
+      if (sx == 1 && sy == 1) { full[ci] = c.plane + (size_t)y * c.bw; continue; }
+      const int cw = (width * c.h + hmax - 1) / hmax, ch = (height * c.v + vmax - 1) / vmax;  // valid chroma samples
       int y0, y1, wy0, wy1;
       if (sy == 2) { const int cy = y >> 1; y0 = cy; y1 = (y & 1) ? (cy + 1 < ch ? cy + 1 : cy) : (cy > 0 ? cy - 1 : cy); wy0 = 3; wy1 = 1; }
       else { y0 = y1 = (y / sy < ch ? y / sy : ch - 1); wy0 = 4; wy1 = 0; }
       const uint8_t* r0 = c.plane + (size_t)y0 * c.bw;
       const uint8_t* r1 = c.plane + (size_t)y1 * c.bw;
-      uint8_t* o = up[ci].data() + (size_t)y * width;
-      for (int x = 0; x < width; x++) {
-        if (sx == 2) {
+      uint8_t* o = row[ci].data();
+      if (sx == 2) {
+        int16_t* t = vb[ci].data();
+        for (int x = 0; x < cw; x++) t[x] = (int16_t)(wy0 * r0[x] + wy1 * r1[x]);   // each scaled by 4
+        // o[2 cx] = (3 t[cx] + t[cx - 1] + 8) >> 4, o[2 cx + 1] = (3 t[cx] + t[cx + 1] + 8) >> 4, neighbours clamped to [0, cw)
+        const int pairs = width >> 1;   // output pixels 2 cx and 2 cx + 1 both inside the image
+        if (cw > 0) {
+          o[0] = (uint8_t)((3 * t[0] + t[0] + 8) >> 4);
+          if (width > 1) o[1] = (uint8_t)((3 * t[0] + t[cw > 1 ? 1 : 0] + 8) >> 4);
+        }
+        const int inner = (pairs < cw - 1 ? pairs : cw - 1);
+        for (int cx = 1; cx < inner; cx++) {
+          o[2 * cx] = (uint8_t)((3 * t[cx] + t[cx - 1] + 8) >> 4);
+          o[2 * cx + 1] = (uint8_t)((3 * t[cx] + t[cx + 1] + 8) >> 4);
+        }
+        for (int x = 2 * (inner > 1 ? inner : 1); x < width; x++) {   // the last chroma column(s): neighbour index clamped
           const int cx = x >> 1;
           const int cn = (x & 1) ? (cx + 1 < cw ? cx + 1 : cx) : (cx > 0 ? cx - 1 : cx);
-          const int a = wy0 * r0[cx] + wy1 * r1[cx], b = wy0 * r0[cn] + wy1 * r1[cn];  // each scaled by 4
-          o[x] = (uint8_t)((3 * a + b + 8) >> 4);
-        } else {
+          o[x] = (uint8_t)((3 * t[cx] + t[cn] + 8) >> 4);
+        }
+      } else {
+        for (int x = 0; x < width; x++) {
           const int cx = x / sx < cw ? x / sx : cw - 1;
           o[x] = (uint8_t)((wy0 * r0[cx] + wy1 * r1[cx] + 2) >> 2);
         }
       }
+      full[ci] = o;
     }
-    full[ci] = up[ci].data();
-    fstride[ci] = width;
+    const uint8_t* __restrict__ py = full[0];
+    const uint8_t* __restrict__ pb = full[1];
+    const uint8_t* __restrict__ pr = full[2];
+    uint8_t* __restrict__ o = dst + 3 * (size_t)y * width;
+    for (int x = 0; x < width; x++) sf_jpeg_ycc_to_rgb(py[x], pb[x], pr[x], o + 3 * x);
   }
-  for (int y = 0; y < height; y++)
-    for (int x = 0; x < width; x++) {
-      const int Y = full[0][(size_t)y * fstride[0] + x];
-      const int cb = full[1][(size_t)y * fstride[1] + x] - 128, cr = full[2][(size_t)y * fstride[2] + x] - 128;
-      uint8_t* o = dst + 3 * ((size_t)y * width + x);
-      // BT.601 full range, 16.16 fixed point
-      o[0] = clamp8((Y * 65536 + 91881 * cr + 32768) >> 16);
-      o[1] = clamp8((Y * 65536 - 22554 * cb - 46802 * cr + 32768) >> 16);
-      o[2] = clamp8((Y * 65536 + 116130 * cb + 32768) >> 16);
-    }
   return SF_OK;
 }

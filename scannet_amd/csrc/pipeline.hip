@@ -28,6 +28,7 @@ namespace {
 // One ring slot = one batch of B frames: contiguous pinned host buffers, contiguous device buffers, two events.
 struct BatchSlot {
   hipEvent_t copied = nullptr;    // H2D of this batch finished (its pinned buffers may be refilled)
+  hipEvent_t copied_rgb = nullptr;  // the colour part of it, on the other copy stream
   hipEvent_t consumed = nullptr;  // pre-pass of this batch finished (its device buffers may be overwritten)
   bool used = false;
   std::atomic<int> decoded{0};    // frames of the current generation the pool has finished with
@@ -76,7 +77,7 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   // enough batch slots for every decode thread to be busy while two batches sit between copy and pre-pass
   const int NB = (int)std::max<uint64_t>(1, std::min<uint64_t>(std::max<uint64_t>(3, ((uint64_t)nthreads + B - 1) / B + 2), std::max<uint64_t>(nbatches, 1)));
   std::vector<BatchSlot> ring((size_t)NB);
-  hipStream_t copy_stream = nullptr;
+  hipStream_t copy_stream = nullptr, copy_stream2 = nullptr;   // two streams = two SDMA engines: one alone moves ~20 GB/s
   // ONE pinned host allocation and ONE device allocation for the whole ring
   uint8_t* h_pool = nullptr;
   uint8_t* d_pool = nullptr;
@@ -89,11 +90,13 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   auto cleanup = [&]() {
     for (BatchSlot& sl : ring) {
       if (sl.copied) (void)hipEventDestroy(sl.copied);
+      if (sl.copied_rgb) (void)hipEventDestroy(sl.copied_rgb);
       if (sl.consumed) (void)hipEventDestroy(sl.consumed);
     }
     if (h_pool) (void)hipHostFree(h_pool);
     if (d_pool) (void)hipFree(d_pool);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    if (copy_stream2) (void)hipStreamDestroy(copy_stream2);
   };
 #define RUN_CHECK(call)                                                                                   \
   do {                                                                                                    \
@@ -101,10 +104,12 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
     if (e_ != hipSuccess) { cleanup(); return sf::fail(SF_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_)); } \
   } while (0)
   RUN_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+  RUN_CHECK(hipStreamCreateWithFlags(&copy_stream2, hipStreamNonBlocking));
   RUN_CHECK(hipHostMalloc((void**)&h_pool, (size_t)NB * slot_b, hipHostMallocDefault));
   RUN_CHECK(hipMalloc((void**)&d_pool, (size_t)NB * slot_b));
   for (BatchSlot& sl : ring) {
     RUN_CHECK(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
+    RUN_CHECK(hipEventCreateWithFlags(&sl.copied_rgb, hipEventDisableTiming));
     RUN_CHECK(hipEventCreateWithFlags(&sl.consumed, hipEventDisableTiming));
   }
 
@@ -176,7 +181,12 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
     // ---- copies: one per run of consecutive valid frames
     const double t1 = timing ? now_s() : 0;
     hipError_t e = hipSuccess;
-    if (bs.used) e = hipStreamWaitEvent(copy_stream, bs.consumed, 0);  // device buffers still read by this slot's previous pre-pass?
+    // depth on one copy stream, colour on the other, batches alternating between them: two transfers are in flight at any time
+    hipStream_t cs_depth = (g & 1) ? copy_stream2 : copy_stream, cs_rgb = (g & 1) ? copy_stream : copy_stream2;
+    if (bs.used) {  // device buffers still read by this slot's previous pre-pass?
+      e = hipStreamWaitEvent(cs_depth, bs.consumed, 0);
+      if (e == hipSuccess) e = hipStreamWaitEvent(cs_rgb, bs.consumed, 0);
+    }
     bool valid[MAX_BATCH], rgbf[MAX_BATCH];
     for (int j = 0; j < cnt; j++) {
       const uint64_t frame = first + g * (uint64_t)B + (uint64_t)j;
@@ -188,17 +198,23 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
       if (!valid[j]) { j++; continue; }
       int j1 = j;
       while (j1 < cnt && valid[j1]) j1++;
-      e = hipMemcpyAsync(d_depth(sl, j), h_depth(sl, j), (size_t)(j1 - j) * depth_b, hipMemcpyHostToDevice, copy_stream);
+      e = hipMemcpyAsync(d_depth(sl, j), h_depth(sl, j), (size_t)(j1 - j) * depth_b, hipMemcpyHostToDevice, cs_depth);
       j = j1;
     }
+    bool any_rgb = false;
     for (int j = 0; j < cnt && e == hipSuccess;) {
       if (!rgbf[j]) { j++; continue; }
       int j1 = j;
       while (j1 < cnt && rgbf[j1]) j1++;
-      e = hipMemcpyAsync(d_rgb(sl, j), h_rgb(sl, j), (size_t)(j1 - j) * rgb_b, hipMemcpyHostToDevice, copy_stream);
+      e = hipMemcpyAsync(d_rgb(sl, j), h_rgb(sl, j), (size_t)(j1 - j) * rgb_b, hipMemcpyHostToDevice, cs_rgb);
+      any_rgb = true;
       j = j1;
     }
-    if (e == hipSuccess) e = hipEventRecord(bs.copied, copy_stream);
+    if (e == hipSuccess && any_rgb) {   // `copied` on the depth stream stands for both parts
+      e = hipEventRecord(bs.copied_rgb, cs_rgb);
+      if (e == hipSuccess) e = hipStreamWaitEvent(cs_depth, bs.copied_rgb, 0);
+    }
+    if (e == hipSuccess) e = hipEventRecord(bs.copied, cs_depth);
     if (e != hipSuccess) { result = SF_ERR_DEVICE; err = std::string("copy pipeline: ") + hipGetErrorString(e); break; }
     issued.store(g + 1, std::memory_order_release);
     if (timing) t_api += now_s() - t1;
@@ -242,6 +258,7 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
     std::fprintf(stderr, "sf_fuse_run: setup+loop %.3f s (wait for decoded batches %.3f, copy enqueue %.3f, kernels enqueue %.3f), join+drain %.3f s, %d batch slots x %d frames\n",
                  t_loop_end - std::chrono::duration<double>(t_start.time_since_epoch()).count(), t_wait_ready, t_api, t_flush, now_s() - t_loop_end, NB, B);
   (void)hipStreamSynchronize(copy_stream);
+  (void)hipStreamSynchronize(copy_stream2);
   cleanup();
   if (result != SF_OK) return sf::fail(result, "%s", err.c_str());
   if (qe != hipSuccess) return sf::fail(SF_ERR_DEVICE, "device error while fusing: %s", hipGetErrorString(qe));
