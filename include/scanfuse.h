@@ -304,6 +304,11 @@ int sf_calibrate_sens(const char* in_sens, const char* out_sens, const char* par
  * behind RGBDFrame::compressColor(TYPE_JPEG), sensorData.h:565-596.  *out_bytes is set even when dst is too small. */
 int sf_jpeg_encode(const uint8_t* rgb, uint32_t width, uint32_t height, int quality, int subsample, uint8_t* dst, uint64_t dst_capacity,
                    uint64_t* out_bytes);
+/* Baseline JPEG -> RGB as RGBDFrame::decompressColorAlloc_stb does it (sensorData.h:609-616): sf_jpeg_decode on the host (what
+ * sf_sens_decode_color runs for a TYPE_JPEG frame); sf_jpeg_decode_gpu = entropy decoding on the host, IDCT + chroma upsampling +
+ * YCbCr -> RGB on the GPU -- the split sf_fuse_run uses for colour frames -- returning the same bytes. */
+int sf_jpeg_decode(const uint8_t* data, uint64_t bytes, uint32_t width, uint32_t height, uint8_t* dst_rgb);
+int sf_jpeg_decode_gpu(const uint8_t* data, uint64_t bytes, uint32_t width, uint32_t height, int device, uint8_t* dst_rgb);
 
 /* ------------------------------------------------------------------------------------------------
  * 2-D annotation filter (scannet_amd/csrc/filter2d.hip).  Replaces the CUDA kernels AnnotationTools/Filter2dAnnotations/filter.cu

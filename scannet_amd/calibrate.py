@@ -59,6 +59,21 @@ def jpeg_encode(rgb, quality=90, subsample=True):
     return out[:n.value].tobytes()
 
 
+def jpeg_decode(blob, width, height, device=None):
+    """Baseline JPEG -> [H, W, 3] uint8: on the host (device=None: what sf_sens_decode_color runs), or entropy decoding on the host and
+    reconstruction on GPU `device` (the split sf_fuse_run uses) -- the same bytes either way."""
+    L = _lib()
+    b = np.frombuffer(blob, np.uint8)
+    out = np.empty((height, width, 3), np.uint8)
+    L.sf_jpeg_decode.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.sf_jpeg_decode_gpu.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+    if device is None:
+        check(L.sf_jpeg_decode(b.ctypes.data, b.size, width, height, out.ctypes.data))
+    else:
+        check(L.sf_jpeg_decode_gpu(b.ctypes.data, b.size, width, height, int(device), out.ctypes.data))
+    return out
+
+
 def write_params(path, p):
     """A parameter file with the keys Calib::readFromFile reads (calibration.h:22-48)."""
     with open(path, "w") as f:

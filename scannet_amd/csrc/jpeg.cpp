@@ -154,7 +154,10 @@ void idct_block(float* blk, bool dc_only, uint8_t* out, int stride) {
 
 }  // namespace
 
-int jpeg_decode_rgb(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t expect_w, uint32_t expect_h) {
+// dst != nullptr: decode to RGB.  dst == nullptr: entropy-decode only -- the layout goes to *L, the quantised coefficients to coef (the GPU
+// reconstructs: jpeg_gpu.hip); SF_ERR_UNSUPPORTED when the layout is one the GPU path does not take or coef_capacity is too small.
+static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t expect_w, uint32_t expect_h, SfJpegLayout* L, int16_t* coef,
+                       uint64_t coef_capacity) {
   if (n < 4 || data[0] != 0xFF || data[1] != 0xD8) return sf::fail(SF_ERR_FORMAT, "jpeg: missing SOI");
   uint16_t qt[4][64];
   float fq[4][64];   // quantiser step x AAN scale, natural order
@@ -244,8 +247,28 @@ int jpeg_decode_rgb(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t expe
     if (!qt_ok[comp[i].tq] || !hdc[comp[i].td].present || !hac[comp[i].ta].present) return sf::fail(SF_ERR_FORMAT, "jpeg: missing quantisation / Huffman table");
   const int mcu_w = 8 * hmax, mcu_h = 8 * vmax;
   const int mcux = (width + mcu_w - 1) / mcu_w, mcuy = (height + mcu_h - 1) / mcu_h;
+  const bool to_coef = dst == nullptr;
+  if (to_coef) {
+    if (hmax > 2 || vmax > 2) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: sampling factors above 2 take the host decoder");
+    std::memset(L, 0, sizeof(*L));
+    L->width = (uint16_t)width; L->height = (uint16_t)height;
+    L->ncomp = (uint8_t)ncomp; L->hmax = (uint8_t)hmax; L->vmax = (uint8_t)vmax;
+    uint32_t off = 0;
+    for (int i = 0; i < ncomp; i++) {
+      if ((hmax % comp[i].h) || (vmax % comp[i].v)) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: fractional sampling ratios are not supported");
+      L->h[i] = (uint8_t)comp[i].h; L->v[i] = (uint8_t)comp[i].v;
+      L->bw[i] = (uint16_t)(mcux * comp[i].h * 8); L->bh[i] = (uint16_t)(mcuy * comp[i].v * 8);
+      L->coef_off[i] = off;
+      off += (uint32_t)L->bw[i] * L->bh[i];
+      for (int z = 0; z < 64; z++) L->q[i][z] = qt[comp[i].tq][z];
+    }
+    L->coef_total = off;
+    if ((uint64_t)off > coef_capacity) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: %u coefficients do not fit the payload (%llu)", off, (unsigned long long)coef_capacity);
+    std::memset(coef, 0, (size_t)off * 2);
+  }
   for (int i = 0; i < ncomp; i++) {
     comp[i].bw = mcux * comp[i].h * 8; comp[i].bh = mcuy * comp[i].v * 8;
+    if (to_coef) { comp[i].pred = 0; continue; }
     static thread_local std::vector<uint8_t> scratch[3];
     if (scratch[i].size() < (size_t)comp[i].bw * comp[i].bh) scratch[i].resize((size_t)comp[i].bw * comp[i].bh);  // every sample is written by the IDCT
     comp[i].plane = scratch[i].data();
@@ -261,6 +284,38 @@ int jpeg_decode_rgb(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t expe
         const float* q = fq[c.tq];
         for (int by = 0; by < c.v; by++)
           for (int bx = 0; bx < c.h; bx++) {
+            if (to_coef) {   // the same walk, coefficients stored instead of reconstructed
+              int16_t* cb = coef + L->coef_off[ci] + ((size_t)(my * c.v + by) * (size_t)(c.bw / 8) + (size_t)(mx * c.h + bx)) * 64;
+              const int t = decode_huff(bs, hdc[c.td]);
+              if (t < 0 || t > 11) return sf::fail(SF_ERR_FORMAT, "jpeg: bad DC code");
+              c.pred += t ? extend(bs.get(t), t) : 0;
+              cb[0] = (int16_t)c.pred;
+              const HuffDC_AC& ac = hac[c.ta];
+              for (int k = 1; k < 64;) {
+                if (bs.cnt < 32) bs.fill();
+                const int fa = ac.fast_ac[bs.peek(10)];
+                if (fa) {
+                  k += (fa >> 4) & 15;
+                  if (k > 63) return sf::fail(SF_ERR_FORMAT, "jpeg: AC run past the end of the block");
+                  bs.drop(fa & 15);
+                  cb[ZIGZAG[k]] = (int16_t)(fa >> 8);
+                  k++;
+                  continue;
+                }
+                const int rs = decode_huff(bs, ac);
+                if (rs < 0) return sf::fail(SF_ERR_FORMAT, "jpeg: bad AC code");
+                const int r = rs >> 4, sz = rs & 15;
+                if (sz == 0) {
+                  if (r == 15) { k += 16; continue; }
+                  break;
+                }
+                k += r;
+                if (k > 63) return sf::fail(SF_ERR_FORMAT, "jpeg: AC run past the end of the block");
+                cb[ZIGZAG[k]] = (int16_t)extend(bs.get(sz), sz);
+                k++;
+              }
+              continue;
+            }
             std::memset(blk, 0, sizeof(blk));
             const int t = decode_huff(bs, hdc[c.td]);
             if (t < 0 || t > 11) return sf::fail(SF_ERR_FORMAT, "jpeg: bad DC code");
@@ -308,6 +363,7 @@ int jpeg_decode_rgb(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t expe
         todo = restart;
       }
     }
+  if (to_coef) return SF_OK;
   // upsample + colour convert
   if (ncomp == 1) {
     for (int y = 0; y < height; y++)
@@ -375,4 +431,14 @@ int jpeg_decode_rgb(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t expe
     for (int x = 0; x < width; x++) sf_jpeg_ycc_to_rgb(py[x], pb[x], pr[x], o + 3 * x);
   }
   return SF_OK;
+}
+
+int jpeg_decode_rgb(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t expect_w, uint32_t expect_h) {
+  if (!dst) return sf::fail(SF_ERR_INVALID_ARG, "jpeg_decode_rgb: NULL destination");
+  return decode_impl(data, n, dst, expect_w, expect_h, nullptr, nullptr, 0);
+}
+
+int jpeg_decode_coef(const uint8_t* data, uint64_t n, uint32_t expect_w, uint32_t expect_h, SfJpegLayout* layout, int16_t* coef, uint64_t coef_capacity) {
+  if (!layout || !coef) return sf::fail(SF_ERR_INVALID_ARG, "jpeg_decode_coef: NULL argument");
+  return decode_impl(data, n, nullptr, expect_w, expect_h, layout, coef, coef_capacity);
 }

@@ -1,0 +1,178 @@
+// jpeg_gpu.hip -- the data-parallel half of baseline JPEG decoding on gfx950.  The frame pipeline's host threads only entropy-decode
+// (jpeg.cpp: jpeg_decode_coef -- Huffman decoding is serial per frame); the quantised coefficients go over PCIe in place of the RGB
+// image (same size for 4:2:0) and two kernels reconstruct the picture where the fuser wants it anyway, in HBM:
+//   k_jpeg_idct   one lane per 8 x 8 block: dequantise (AAN scale folded in), 1-D passes down the columns and along the rows, round and
+//                 clamp, eight 8-byte stores into the component's plane
+//   k_jpeg_rgb    four pixels per lane: triangle-filter chroma upsampling, BT.601 -> RGB, three dword stores
+// Every arithmetic step is the function of jpeg_idct.h the host decoder is built from (no contraction), so the bytes are the ones
+// sf_sens_decode_color produces (tests/test_gpu_pipeline.py).  Replaces, for this path, the SSE2 IDCT + resampling of stb_image as
+// RGBDFrame::decompressColorAlloc_stb calls it (SensReader/c++/src/sensorData.h:609-616, stb_image.h:2028-2207).
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "common.h"
+#include "jpeg_idct.h"
+
+namespace {
+
+constexpr int JPEG_MAX_BATCH = 16;
+
+struct JpegBatch {
+  const uint8_t* payload[JPEG_MAX_BATCH];   // SfJpegLayout + coefficients, device
+  uint8_t* rgb[JPEG_MAX_BATCH];             // W x H x 3 out, device; nullptr: slot unused
+  uint8_t* planes[JPEG_MAX_BATCH];          // scratch for the component planes of this frame
+};
+
+__global__ __launch_bounds__(256) void k_jpeg_idct(JpegBatch B) {
+  const int f = blockIdx.y;
+  if (B.rgb[f] == nullptr) return;
+  const SfJpegLayout* __restrict__ L = reinterpret_cast<const SfJpegLayout*>(B.payload[f]);
+  const int16_t* __restrict__ coef = reinterpret_cast<const int16_t*>(B.payload[f] + sizeof(SfJpegLayout));
+  __shared__ float fq[3][64];
+  for (int t = threadIdx.x; t < 64 * L->ncomp; t += 256) fq[t >> 6][t & 63] = sf_jpeg_dequant(L->q[t >> 6][t & 63], t & 63);
+  __syncthreads();
+  uint32_t b = blockIdx.x * 256 + threadIdx.x;   // block index over all components
+  int c = 0;
+  size_t plane_off = 0;
+  for (; c < L->ncomp; c++) {
+    const uint32_t nb = (uint32_t)(L->bw[c] / 8) * (uint32_t)(L->bh[c] / 8);
+    if (b < nb) break;
+    b -= nb;
+    plane_off += (size_t)L->bw[c] * L->bh[c];
+  }
+  if (c >= L->ncomp) return;
+  const int blocks_w = L->bw[c] / 8;
+  const int16_t* __restrict__ cb = coef + L->coef_off[c] + (size_t)b * 64;
+  float blk[64];
+#pragma unroll
+  for (int z = 0; z < 64; z += 8) {
+    const uint4 w = *reinterpret_cast<const uint4*>(cb + z);   // 8 coefficients (payloads and blocks are 16-byte aligned)
+    const uint32_t u[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      blk[z + 2 * k] = (float)(int16_t)(u[k] & 0xffffu) * fq[c][z + 2 * k];
+      blk[z + 2 * k + 1] = (float)(int16_t)(u[k] >> 16) * fq[c][z + 2 * k + 1];
+    }
+  }
+#pragma unroll
+  for (int col = 0; col < 8; col++) sf_idct8(blk + col, 8);
+#pragma unroll
+  for (int row = 0; row < 8; row++) sf_idct8(blk + 8 * row, 1);
+  uint8_t* out = B.planes[f] + plane_off + (size_t)(b / blocks_w) * 8 * L->bw[c] + (size_t)(b % blocks_w) * 8;
+#pragma unroll
+  for (int y = 0; y < 8; y++) {
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+      lo |= (uint32_t)sf_jpeg_level(blk[8 * y + x]) << (8 * x);
+      hi |= (uint32_t)sf_jpeg_level(blk[8 * y + 4 + x]) << (8 * x);
+    }
+    *reinterpret_cast<uint2*>(out + (size_t)y * L->bw[c]) = make_uint2(lo, hi);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_jpeg_rgb(JpegBatch B) {
+  const int f = blockIdx.y;
+  if (B.rgb[f] == nullptr) return;
+  const SfJpegLayout* __restrict__ L = reinterpret_cast<const SfJpegLayout*>(B.payload[f]);
+  const int W = L->width, H = L->height;
+  const size_t n = (size_t)W * H;
+  const size_t i0 = 4 * ((size_t)blockIdx.x * 256 + threadIdx.x);
+  if (i0 >= n) return;
+  const uint8_t* p0 = B.planes[f];
+  uint8_t px[12];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const size_t i = i0 + k;
+    uint8_t* o = px + 3 * k;
+    o[0] = o[1] = o[2] = 0;
+    if (i >= n) continue;
+    const int x = (int)(i % (size_t)W), y = (int)(i / (size_t)W);
+    if (L->ncomp == 1) {
+      o[0] = o[1] = o[2] = p0[(size_t)y * L->bw[0] + x];
+      continue;
+    }
+    int v[3];
+    const uint8_t* plane = p0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const int sx = L->hmax / L->h[c], sy = L->vmax / L->v[c];
+      const int cw = (W * L->h[c] + L->hmax - 1) / L->hmax, ch = (H * L->v[c] + L->vmax - 1) / L->vmax;   // valid samples of the component
+      v[c] = sf_jpeg_upsample(plane, L->bw[c], cw, ch, sx, sy, x, y);
+      plane += (size_t)L->bw[c] * L->bh[c];
+    }
+    sf_jpeg_ycc_to_rgb(v[0], v[1], v[2], o);
+  }
+  uint8_t* dst = B.rgb[f];
+  if (i0 + 4 <= n && ((uintptr_t)dst & 3) == 0) {
+    uint32_t* o = reinterpret_cast<uint32_t*>(dst + 3 * i0);
+    o[0] = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16) | ((uint32_t)px[3] << 24);
+    o[1] = (uint32_t)px[4] | ((uint32_t)px[5] << 8) | ((uint32_t)px[6] << 16) | ((uint32_t)px[7] << 24);
+    o[2] = (uint32_t)px[8] | ((uint32_t)px[9] << 8) | ((uint32_t)px[10] << 16) | ((uint32_t)px[11] << 24);
+  } else {
+    for (int k = 0; k < 12 && 3 * i0 + k < 3 * n; k++) dst[3 * i0 + k] = px[k];
+  }
+}
+
+}  // namespace
+
+// Reconstruct up to 16 entropy-decoded frames on `stream`.  d_payload[i]: SfJpegLayout + coefficients (16-byte aligned), d_rgb[i]: the
+// RGB image out (nullptr: skip the slot), d_planes[i]: scratch of at least the summed plane sizes.  max_blocks / max_pixels bound the
+// grid (the layouts live on the device).
+int jpeg_gpu_reconstruct(hipStream_t stream, int n, const uint8_t* const* d_payload, uint8_t* const* d_rgb, uint8_t* const* d_planes, uint32_t max_blocks,
+                         uint64_t max_pixels) {
+  if (n < 1 || n > JPEG_MAX_BATCH) return sf::fail(SF_ERR_INVALID_ARG, "jpeg_gpu_reconstruct: %d frames", n);
+  JpegBatch b;
+  for (int i = 0; i < JPEG_MAX_BATCH; i++) {
+    b.payload[i] = i < n ? d_payload[i] : nullptr;
+    b.rgb[i] = i < n ? d_rgb[i] : nullptr;
+    b.planes[i] = i < n ? d_planes[i] : nullptr;
+  }
+  hipLaunchKernelGGL(k_jpeg_idct, dim3((max_blocks + 255) / 256, n), dim3(256), 0, stream, b);
+  hipLaunchKernelGGL(k_jpeg_rgb, dim3((unsigned)((max_pixels / 4 + 256) / 256), n), dim3(256), 0, stream, b);
+  SF_HIP_CHECK(hipGetLastError());
+  return SF_OK;
+}
+
+int jpeg_decode_rgb(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t expect_w, uint32_t expect_h);                                          // jpeg.cpp
+int jpeg_decode_coef(const uint8_t* data, uint64_t n, uint32_t expect_w, uint32_t expect_h, SfJpegLayout* layout, int16_t* coef, uint64_t coef_capacity);  // jpeg.cpp
+
+// Baseline JPEG -> RGB on the host (what sf_sens_decode_color does for a TYPE_JPEG frame)
+SF_API int sf_jpeg_decode(const uint8_t* data, uint64_t bytes, uint32_t width, uint32_t height, uint8_t* dst_rgb) {
+  if (!data || !dst_rgb) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  return jpeg_decode_rgb(data, bytes, dst_rgb, width, height);
+}
+
+// The same picture through the GPU path of the frame pipeline: entropy decoding here, reconstruction on `device`, result copied back.
+// One frame, synchronous -- an entry point for callers that want the pixels in HBM anyway and for the parity test; SF_ERR_UNSUPPORTED
+// for layouts the GPU path leaves to the host decoder (sampling factors above 2).
+SF_API int sf_jpeg_decode_gpu(const uint8_t* data, uint64_t bytes, uint32_t width, uint32_t height, int device, uint8_t* dst_rgb) {
+  if (!data || !dst_rgb || width == 0 || height == 0) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return sf::fail(SF_ERR_DEVICE, "no HIP device: libscanfuse has no CPU fallback for this entry point (sf_jpeg_decode is the host decoder)");
+  if (device < 0 || device >= ndev) return sf::fail(SF_ERR_INVALID_ARG, "device %d out of range (%d devices)", device, ndev);
+  SF_HIP_CHECK(hipSetDevice(device));
+  const uint64_t padded = (uint64_t)((width + 15) & ~15u) * ((height + 15) & ~15u);
+  const uint64_t cap = padded * 3;   // 4:4:4 at most
+  std::vector<uint8_t> host(sizeof(SfJpegLayout) + cap * 2);
+  SfJpegLayout* L = reinterpret_cast<SfJpegLayout*>(host.data());
+  const int rc = jpeg_decode_coef(data, bytes, width, height, L, reinterpret_cast<int16_t*>(host.data() + sizeof(SfJpegLayout)), cap);
+  if (rc != SF_OK) return rc;
+  uint8_t *d_pay = nullptr, *d_rgb = nullptr, *d_planes = nullptr;
+  const size_t pay_b = sizeof(SfJpegLayout) + (size_t)L->coef_total * 2, rgb_b = (size_t)width * height * 3;
+  auto release = [&]() { if (d_pay) (void)hipFree(d_pay); if (d_rgb) (void)hipFree(d_rgb); if (d_planes) (void)hipFree(d_planes); };
+  hipError_t e = hipMalloc((void**)&d_pay, pay_b);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_rgb, rgb_b);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_planes, L->coef_total);
+  if (e == hipSuccess) e = hipMemcpy(d_pay, host.data(), pay_b, hipMemcpyHostToDevice);
+  int out = SF_OK;
+  if (e == hipSuccess) {
+    const uint8_t* pp = d_pay;
+    out = jpeg_gpu_reconstruct(nullptr, 1, &pp, &d_rgb, &d_planes, L->coef_total / 64, (uint64_t)width * height);
+    if (out == SF_OK) e = hipMemcpy(dst_rgb, d_rgb, rgb_b, hipMemcpyDeviceToHost);
+  }
+  release();
+  if (e != hipSuccess) return sf::fail(SF_ERR_DEVICE, "sf_jpeg_decode_gpu: %s", hipGetErrorString(e));
+  return out;
+}

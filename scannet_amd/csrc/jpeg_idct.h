@@ -54,3 +54,38 @@ SF_JHD inline void sf_jpeg_ycc_to_rgb(int Y, int cb, int cr, uint8_t* o) {
   o[1] = sf_jpeg_clamp8((Y * 65536 - 22554 * cb - 46802 * cr + 32768) >> 16);
   o[2] = sf_jpeg_clamp8((Y * 65536 + 116130 * cb + 32768) >> 16);
 }
+
+// ---- entropy-decoded frame handed to the GPU (jpeg_gpu.hip): this header, then the quantised coefficients ------------------------
+// Component c holds (bw[c] / 8) x (bh[c] / 8) blocks in raster order starting at coef_off[c] (in int16 units behind the header), each
+// block 64 int16 in natural (row-major v, u) order.
+struct SfJpegLayout {
+  uint16_t width, height;
+  uint8_t ncomp, hmax, vmax, reserved0;
+  uint8_t h[3], v[3];
+  uint16_t bw[3], bh[3];     // plane sizes in samples, padded to whole MCUs
+  uint16_t reserved1;
+  uint32_t coef_off[3];
+  uint32_t coef_total;       // int16 count of all components
+  uint16_t q[3][64];         // quantiser steps per component, natural order
+  uint8_t pad[84];
+};
+static_assert(sizeof(SfJpegLayout) == 512, "SfJpegLayout is the 512-byte header of a coefficient payload");
+
+// full-resolution sample (x, y) of a component stored at 1/sx x 1/sy: triangle filter for a factor of 2 (3/4 nearer + 1/4 farther sample,
+// vertically then horizontally, borders replicated), nearest otherwise -- the per-pixel form of jpeg.cpp's row loops (same integers)
+SF_JHD inline int sf_jpeg_upsample(const uint8_t* plane, int bw, int cw, int ch, int sx, int sy, int x, int y) {
+  if (sx == 1 && sy == 1) return plane[(size_t)y * bw + x];
+  int y0, y1, wy0, wy1;
+  if (sy == 2) { const int cy = y >> 1; y0 = cy; y1 = (y & 1) ? (cy + 1 < ch ? cy + 1 : cy) : (cy > 0 ? cy - 1 : cy); wy0 = 3; wy1 = 1; }
+  else { y0 = y1 = (y / sy < ch ? y / sy : ch - 1); wy0 = 4; wy1 = 0; }
+  const uint8_t* r0 = plane + (size_t)y0 * bw;
+  const uint8_t* r1 = plane + (size_t)y1 * bw;
+  if (sx == 2) {
+    const int cx = x >> 1;
+    const int cn = (x & 1) ? (cx + 1 < cw ? cx + 1 : cx) : (cx > 0 ? cx - 1 : cx);
+    const int a = wy0 * r0[cx] + wy1 * r1[cx], b = wy0 * r0[cn] + wy1 * r1[cn];   // each scaled by 4
+    return (3 * a + b + 8) >> 4;
+  }
+  const int cx = x / sx < cw ? x / sx : cw - 1;
+  return (wy0 * r0[cx] + wy1 * r1[cx] + 2) >> 2;
+}

@@ -19,11 +19,36 @@
 #include <vector>
 
 #include "fuser_internal.h"
+#include "jpeg_idct.h"
 #include "sens.h"
 
 int sf_fuser_run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb, const float* const* poses, int n);  // fuser.hip
+int jpeg_decode_coef(const uint8_t* data, uint64_t n, uint32_t expect_w, uint32_t expect_h, SfJpegLayout* layout, int16_t* coef, uint64_t coef_capacity);  // jpeg.cpp
+int jpeg_gpu_reconstruct(hipStream_t stream, int n, const uint8_t* const* d_payload, uint8_t* const* d_rgb, uint8_t* const* d_planes, uint32_t max_blocks,
+                         uint64_t max_pixels);  // jpeg_gpu.hip
 
 namespace {
+
+// CPUs this process may actually use: the cgroup CPU quota when there is one (a container that shows 256 logical CPUs may be allowed
+// the time of 16: threads beyond that only add contention), else the hardware concurrency
+int usable_cpus() {
+  int hw = std::max(1, (int)std::thread::hardware_concurrency());
+  if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2: "<quota> <period>" or "max <period>"
+    char q[64] = {0};
+    long long period = 0;
+    if (std::fscanf(f, "%63s %lld", q, &period) == 2 && period > 0 && std::strcmp(q, "max") != 0) {
+      const long long quota = std::atoll(q);
+      if (quota > 0) hw = std::min(hw, (int)std::max<long long>(1, (quota + period - 1) / period));
+    }
+    std::fclose(f);
+  } else {
+    long long quota = -1, period = 0;
+    if (FILE* a = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (std::fscanf(a, "%lld", &quota) != 1) quota = -1; std::fclose(a); }
+    if (FILE* b = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(b, "%lld", &period) != 1) period = 0; std::fclose(b); }
+    if (quota > 0 && period > 0) hw = std::min(hw, (int)std::max<long long>(1, (quota + period - 1) / period));
+  }
+  return hw;
+}
 
 // One ring slot = one batch of B frames: contiguous pinned host buffers, contiguous device buffers, two events.
 struct BatchSlot {
@@ -33,6 +58,7 @@ struct BatchSlot {
   bool used = false;
   std::atomic<int> decoded{0};    // frames of the current generation the pool has finished with
   std::atomic<int> failed{0};
+  uint8_t coef_mode[16] = {0};    // per frame: 1 = the pinned colour payload holds JPEG coefficients (GPU reconstructs), 0 = RGB
 };
 
 }  // namespace
@@ -67,7 +93,7 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   // default pool size: inflating a depth frame takes ~0.13 ms, so 32 threads outrun the GPU (measured: 16 threads 28 k frames/s,
   // 64 threads 26 k); baseline-JPEG colour costs milliseconds per frame and takes up to 64 (128 measured slower: 5.0 k vs 8.1 k frames/s)
   const bool jpeg_colour = use_rgb && s->info.color_compression == 2;
-  const int hw = std::max(1, (int)std::thread::hardware_concurrency());
+  const int hw = usable_cpus();
   int nthreads = decode_threads > 0 ? decode_threads : std::min(hw, jpeg_colour ? 64 : 32);
   if (nthreads < 1) nthreads = 1;
   if (nthreads > 256) nthreads = 256;
@@ -82,11 +108,39 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   uint8_t* h_pool = nullptr;
   uint8_t* d_pool = nullptr;
   const size_t depth_b = npx * 2, rgb_b = use_rgb ? cpx * 3 : 0;
-  const size_t slot_depth = (depth_b * B + 255) & ~(size_t)255, slot_rgb = (rgb_b * B + 255) & ~(size_t)255, slot_b = slot_depth + slot_rgb;
+  // JPEG colour: the host threads only entropy-decode; the coefficients travel in place of the pixels and the GPU reconstructs
+  // (jpeg_gpu.hip).  The payload is sized from the first colour frame's layout (a scan's frames share it); a frame that does not fit,
+  // or has a layout the GPU path does not take, is decoded on the host as before.  SF_JPEG_HOST=1: always decode on the host.
+  size_t pay_b = 0, planes_b = 0;
+  uint32_t pay_coef_cap = 0;
+  if (jpeg_colour && std::getenv("SF_JPEG_HOST") == nullptr) {
+    for (uint64_t k = first; k < last && pay_b == 0; k++) {
+      const SensFrame& fr = s->frames[k];
+      if (fr.pose[0] == -INFINITY || fr.color_bytes == 0) continue;
+      const uint32_t cw_ = s->info.color_width, ch_ = s->info.color_height;
+      const uint64_t cap = (uint64_t)((cw_ + 15) & ~15u) * ((ch_ + 15) & ~15u) * 3;
+      std::vector<uint8_t> probe(sizeof(SfJpegLayout) + cap * 2);
+      SfJpegLayout* L = reinterpret_cast<SfJpegLayout*>(probe.data());
+      if (jpeg_decode_coef(fr.color, fr.color_bytes, cw_, ch_, L, reinterpret_cast<int16_t*>(probe.data() + sizeof(SfJpegLayout)), cap) != SF_OK) break;
+      pay_coef_cap = L->coef_total;
+      pay_b = (sizeof(SfJpegLayout) + (size_t)L->coef_total * 2 + 255) & ~(size_t)255;
+      planes_b = ((size_t)L->coef_total + 255) & ~(size_t)255;
+    }
+  }
+  const bool gpu_jpeg = pay_b != 0;
+  const size_t slot_depth = (depth_b * B + 255) & ~(size_t)255, slot_planes = planes_b * B;
+  // pinned slot: depth, then per frame ONE colour area that holds either pixels or coefficients (col_b = the larger of the two);
+  // device slot: depth, pixels, coefficients, planes scratch
+  const size_t col_b = std::max(rgb_b, pay_b), slot_col = (col_b * B + 255) & ~(size_t)255;
+  const size_t slot_b = slot_depth + slot_col;
+  const size_t dslot_b = slot_depth + slot_col + (gpu_jpeg ? slot_col : 0) + slot_planes;   // every colour area strides by col_b: runs copy as one piece
   auto h_depth = [&](int sl, int j) { return (uint16_t*)(h_pool + (size_t)sl * slot_b + (size_t)j * depth_b); };
-  auto d_depth = [&](int sl, int j) { return d_pool + (size_t)sl * slot_b + (size_t)j * depth_b; };
-  auto h_rgb = [&](int sl, int j) { return h_pool + (size_t)sl * slot_b + slot_depth + (size_t)j * rgb_b; };
-  auto d_rgb = [&](int sl, int j) { return d_pool + (size_t)sl * slot_b + slot_depth + (size_t)j * rgb_b; };
+  auto d_depth = [&](int sl, int j) { return d_pool + (size_t)sl * dslot_b + (size_t)j * depth_b; };
+  auto h_rgb = [&](int sl, int j) { return h_pool + (size_t)sl * slot_b + slot_depth + (size_t)j * col_b; };
+  auto d_rgb = [&](int sl, int j) { return d_pool + (size_t)sl * dslot_b + slot_depth + (size_t)j * col_b; };
+  auto h_pay = h_rgb;
+  auto d_pay = [&](int sl, int j) { return d_pool + (size_t)sl * dslot_b + slot_depth + slot_col + (size_t)j * col_b; };
+  auto d_planes = [&](int sl, int j) { return d_pool + (size_t)sl * dslot_b + slot_depth + 2 * slot_col + (size_t)j * planes_b; };
   auto cleanup = [&]() {
     for (BatchSlot& sl : ring) {
       if (sl.copied) (void)hipEventDestroy(sl.copied);
@@ -106,7 +160,7 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   RUN_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
   RUN_CHECK(hipStreamCreateWithFlags(&copy_stream2, hipStreamNonBlocking));
   RUN_CHECK(hipHostMalloc((void**)&h_pool, (size_t)NB * slot_b, hipHostMallocDefault));
-  RUN_CHECK(hipMalloc((void**)&d_pool, (size_t)NB * slot_b));
+  RUN_CHECK(hipMalloc((void**)&d_pool, (size_t)NB * dslot_b));
   for (BatchSlot& sl : ring) {
     RUN_CHECK(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
     RUN_CHECK(hipEventCreateWithFlags(&sl.copied_rgb, hipEventDisableTiming));
@@ -135,7 +189,16 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
       int rc = SF_OK;
       if (s->frames[frame].pose[0] != -INFINITY) {
         rc = sens_decode_depth(s, frame, h_depth(sl, j));
-        if (rc == SF_OK && use_rgb && s->frames[frame].color_bytes) rc = sf_sens_decode_color(s, frame, h_rgb(sl, j));
+        if (rc == SF_OK && use_rgb && s->frames[frame].color_bytes) {
+          bool coef = false;
+          if (gpu_jpeg) {
+            uint8_t* pay = h_pay(sl, j);
+            coef = jpeg_decode_coef(s->frames[frame].color, s->frames[frame].color_bytes, s->info.color_width, s->info.color_height,
+                                    reinterpret_cast<SfJpegLayout*>(pay), reinterpret_cast<int16_t*>(pay + sizeof(SfJpegLayout)), pay_coef_cap) == SF_OK;
+          }
+          ring[(size_t)sl].coef_mode[j] = coef ? 1 : 0;
+          if (!coef) rc = sf_sens_decode_color(s, frame, h_rgb(sl, j));   // raw colour, or a JPEG the GPU path does not take (errors surface here)
+        }
       }
       decode_ns.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
       if (rc != SF_OK) {
@@ -202,11 +265,23 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
       j = j1;
     }
     bool any_rgb = false;
-    for (int j = 0; j < cnt && e == hipSuccess;) {
-      if (!rgbf[j]) { j++; continue; }
+    for (int j = 0; j < cnt && e == hipSuccess;) {   // pixels: runs of frames decoded on the host
+      if (!rgbf[j] || bs.coef_mode[j]) { j++; continue; }
       int j1 = j;
-      while (j1 < cnt && rgbf[j1]) j1++;
-      e = hipMemcpyAsync(d_rgb(sl, j), h_rgb(sl, j), (size_t)(j1 - j) * rgb_b, hipMemcpyHostToDevice, cs_rgb);
+      while (j1 < cnt && rgbf[j1] && !bs.coef_mode[j1]) j1++;
+      const int jm = j + (j1 - j + 1) / 2;   // the colour part is the larger one: its second half follows the depth on the other stream
+      e = hipMemcpyAsync(d_rgb(sl, j), h_rgb(sl, j), (size_t)(jm - j) * col_b, hipMemcpyHostToDevice, cs_rgb);
+      if (e == hipSuccess && j1 > jm) e = hipMemcpyAsync(d_rgb(sl, jm), h_rgb(sl, jm), (size_t)(j1 - jm) * col_b, hipMemcpyHostToDevice, cs_depth);
+      any_rgb = true;
+      j = j1;
+    }
+    for (int j = 0; j < cnt && e == hipSuccess;) {   // coefficients: runs of entropy-decoded frames
+      if (!rgbf[j] || !bs.coef_mode[j]) { j++; continue; }
+      int j1 = j;
+      while (j1 < cnt && rgbf[j1] && bs.coef_mode[j1]) j1++;
+      const int jm = j + (j1 - j + 1) / 2;
+      e = hipMemcpyAsync(d_pay(sl, j), h_pay(sl, j), (size_t)(jm - j) * col_b, hipMemcpyHostToDevice, cs_rgb);
+      if (e == hipSuccess && j1 > jm) e = hipMemcpyAsync(d_pay(sl, jm), h_pay(sl, jm), (size_t)(j1 - jm) * col_b, hipMemcpyHostToDevice, cs_depth);
       any_rgb = true;
       j = j1;
     }
@@ -228,12 +303,25 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
       const float* pp[MAX_BATCH];
       int m = 0;
       const bool rgb = rgbf[j];
+      const int jfirst = j;
       while (j < cnt && m < B && (!valid[j] || rgbf[j] == rgb)) {
         if (valid[j]) { dd[m] = d_depth(sl, j); dr[m] = rgb ? d_rgb(sl, j) : nullptr; pp[m] = s->frames[first + g * (uint64_t)B + (uint64_t)j].pose; m++; }
         j++;
       }
       hipStream_t in_stream = sf_input_stream(f, m, rgb, +1);  // the stream this sub-batch's pre-pass runs on
       if (hipStreamWaitEvent(in_stream, bs.copied, 0) != hipSuccess) { result = SF_ERR_DEVICE; err = "hipStreamWaitEvent failed"; break; }
+      if (rgb && gpu_jpeg) {   // IDCT + upsampling + colour conversion of this sub-batch's entropy-decoded frames, ahead of its pre-pass
+        const uint8_t* pp_[MAX_BATCH];
+        uint8_t* rr_[MAX_BATCH];
+        uint8_t* pl_[MAX_BATCH];
+        int nj = 0;
+        for (int q = jfirst; q < j; q++)
+          if (valid[q] && rgbf[q] && bs.coef_mode[q]) { pp_[nj] = d_pay(sl, q); rr_[nj] = d_rgb(sl, q); pl_[nj] = d_planes(sl, q); nj++; }
+        if (nj > 0) {
+          const int rcj = jpeg_gpu_reconstruct(in_stream, nj, pp_, rr_, pl_, pay_coef_cap / 64, (uint64_t)cpx);
+          if (rcj != SF_OK) { result = rcj; err = sf_last_error(); break; }
+        }
+      }
       const int rc = sf_fuser_run_batch(f, dd, rgb ? dr : nullptr, pp, m);
       if (rc != SF_OK) { result = rc; err = sf_last_error(); break; }
       n_int += (uint64_t)m;

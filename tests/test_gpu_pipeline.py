@@ -155,3 +155,85 @@ def test_slab_partition_matches_one_gpu():
     finally:
         for f in fusers:
             f.close()
+
+
+def _smooth_image(W, H, k):
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = np.stack([(xx * 255 // W + 9 * k) % 256, (yy * 255 // H), (128 + 100 * np.sin(xx / 11.0 + k) * np.cos(yy / 7.0))], -1)
+    img[H // 4: H // 2, W // 3: 2 * W // 3] = (200, 30 + 20 * k, 60)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def test_jpeg_gpu_reconstruction_equals_the_host_decoder():
+    """sf_jpeg_decode_gpu (Huffman on the host, IDCT + chroma upsampling + colour conversion on the GPU: what sf_fuse_run does with
+    colour frames) returns the bytes of the host decoder: 4:4:4, 4:2:2, 4:2:0, grey, sizes that are not multiples of the MCU."""
+    import io
+    from PIL import Image
+    from scannet_amd import calibrate
+    cases = 0
+    for (W, H) in ((136, 104), (133, 99), (64, 48), (17, 9)):
+        img = _smooth_image(W, H, cases)
+        blobs = []
+        for sub in (0, 1, 2):
+            buf = io.BytesIO()
+            Image.fromarray(img).save(buf, format="JPEG", quality=88, subsampling=sub)
+            blobs.append(buf.getvalue())
+        buf = io.BytesIO()
+        Image.fromarray(img[..., 0]).save(buf, format="JPEG", quality=80)          # one component
+        blobs.append(buf.getvalue())
+        blobs.append(calibrate.jpeg_encode(img, 92, True))
+        blobs.append(calibrate.jpeg_encode(img, 75, False))
+        for b in blobs:
+            host = calibrate.jpeg_decode(b, W, H)
+            gpu = calibrate.jpeg_decode(b, W, H, device=0)
+            assert np.array_equal(host, gpu), "%dx%d case %d: %d bytes differ" % (W, H, cases, (host != gpu).sum())
+            cases += 1
+    assert cases == 24
+    with pytest.raises(Exception):
+        calibrate.jpeg_decode(b"\xff\xd8 not a jpeg", 8, 8, device=0)
+
+
+@pytest.mark.parametrize("kind", ["raw", "jpeg", "jpeg_host"])
+def test_fuse_run_with_colour_matches_frame_by_frame(tmp_path, kind, monkeypatch):
+    """Colour at its own resolution through the threaded pipeline (raw; JPEG with the GPU reconstruction; JPEG decoded on the host):
+    the same voxels, colours included, as integrating the host-decoded frames one by one.  One frame has no pose, one no colour."""
+    from scannet_amd import calibrate, fusion, sens
+    W, H, CW, CH = 160, 120, 324, 242
+    n = 37
+    K = synth.intrinsic_matrix(W, H)
+    KC = np.eye(4, dtype=np.float32)
+    KC[0, 0], KC[1, 1], KC[0, 2], KC[1, 2] = 340.3, 338.1, 160.2, 119.7
+    sd = sens.SensorData.create(CW, CH, W, H, KC, K, color_compression=2 if kind.startswith("jpeg") else 0, depth_compression=1)
+    frames = []
+    for i in range(n):
+        pose = synth.trajectory_pose(i * 9, 1200)
+        d = synth.render_room_depth(pose, W, H, noise_frame=i)
+        img = _smooth_image(CW, CH, i)
+        if i == 5:
+            pose = np.full((4, 4), -np.inf, np.float32)
+        color = None if i == 11 else (calibrate.jpeg_encode(img, 90, i % 2 == 0) if kind.startswith("jpeg") else img)
+        sd.add_frame(d, pose, color=color, timestamp_depth=i)
+        frames.append((d, pose))
+    p = str(tmp_path / "c.sens")
+    sd.save(p)
+    sd.close()
+    fx, fy, mx, my = synth.intrinsics(W, H)
+    gp = fusion.default_params(depth_width=W, depth_height=H, fx=fx, fy=fy, mx=mx, my=my, voxel_size=0.016, num_sdf_blocks=1 << 16)
+    gp.color_width, gp.color_height, gp.cfx, gp.cfy, gp.cmx, gp.cmy = CW, CH, 340.3, 338.1, 160.2, 119.7
+    if kind == "jpeg_host":
+        monkeypatch.setenv("SF_JPEG_HOST", "1")
+    s = sens.SensorData(p)
+    with fusion.Fuser(gp) as a, fusion.Fuser(gp) as b:
+        rs = a.run(s, decode_threads=5)
+        assert rs["frames_total"] == n and rs["color_fused"] == 1
+        for i, (d, pose) in enumerate(frames):
+            if i == 5:
+                continue
+            rgb = None if i == 11 else s.frames[i].decompress_color()
+            assert b.integrate(d, pose, rgb=rgb)
+        ca, va = a.export_blocks()
+        cb, vb = b.export_blocks()
+        oa, ob = np.lexsort(ca.T[::-1]), np.lexsort(cb.T[::-1])
+        assert np.array_equal(ca[oa], cb[ob])
+        assert np.array_equal(va[oa], vb[ob]), "voxels (sdf, weight, colour) differ"
+        assert len(ca) > 500

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--color", choices=["none", "raw", "jpeg"], default="none", help="store a synthetic 640x480 colour frame per depth frame")
     ap.add_argument("--fuse-only", action="store_true", help="stop after the fusion stage")
+    ap.add_argument("--color-res", default="", help="WxH of the colour frames when it differs from the depth size (ScanNet: 1296x968)")
     a = ap.parse_args()
     W, H = 640, 480
     os.makedirs(a.dir, exist_ok=True)
@@ -47,8 +48,12 @@ def main():
     L.sf_device_free(dptr)
     K = synth.intrinsic_matrix(W, H)
     cw, ch = (W, H) if a.color != "none" else (0, 0)
-    sd = sens.SensorData.create(cw, ch, W, H, K, K, color_compression=2 if a.color == "jpeg" else 0, depth_compression=1, sensor_name="StructureSensor")
-    yy, xx = np.mgrid[0:H, 0:W]
+    KC = K
+    if a.color != "none" and a.color_res:
+        cw, ch = (int(v) for v in a.color_res.lower().split("x"))
+        KC = synth.intrinsic_matrix(cw, ch)
+    sd = sens.SensorData.create(cw, ch, W, H, KC, K, color_compression=2 if a.color == "jpeg" else 0, depth_compression=1, sensor_name="StructureSensor")
+    yy, xx = np.mgrid[0:(ch or H), 0:(cw or W)]
     blobs = []
     if a.color == "jpeg":
         from scannet_amd import calibrate
@@ -70,6 +75,9 @@ def main():
     fx, fy, mx, my = synth.intrinsics(W, H)
     gp = fusion.default_params(depth_width=W, depth_height=H, fx=fx, fy=fy, mx=mx, my=my, voxel_size=a.voxel, num_sdf_blocks=a.blocks,
                                hash_num_buckets=a.buckets)
+    if a.color != "none" and a.color_res:
+        gp.color_width, gp.color_height = cw, ch
+        gp.cfx, gp.cfy, gp.cmx, gp.cmy = synth.intrinsics(cw, ch)
     sd = sens.SensorData(path)
     with fusion.Fuser(gp) as f:
         rs = f.run(sd, decode_threads=a.threads)
