@@ -33,7 +33,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 
 def cpu_baseline(depth_host, poses, budget_s=12.0, max_frames=96):
     """Oracle (our CPU port of the same spec, OpenMP over blocks) timed on a bounded sample of the same stream."""
     from oracle import oracle as orc
-    threads = os.cpu_count() or 1
+    from scannet_amd import _abi
+    threads = _abi.usable_cpus()   # the cgroup quota, not the 256 logical CPUs the container shows
     vol = orc.Volume(orc.default_params(W, H, 0.004), threads=threads)
     t0 = time.perf_counter()
     n = 0
@@ -45,7 +46,8 @@ def cpu_baseline(depth_host, poses, budget_s=12.0, max_frames=96):
     dt = time.perf_counter() - t0
     vol.close()
     return {"value": round(n / dt, 3), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": "first %d frames of the same stream, oracle/tsdf_oracle.c -O2 -fopenmp (%d threads), %.1f s" % (n, threads, dt)}
+            "sample": "first %d frames of the same stream, oracle/tsdf_oracle.c -O2 -fopenmp (%d threads = the CPUs this container may use, of %d visible), %.1f s"
+                      % (n, threads, os.cpu_count() or threads, dt)}
 
 
 def pmc_traffic(steps, warmup, timeout_s=300, single_frame=False):

@@ -136,3 +136,23 @@ def check(rc, allow=()):
     if rc != SF_OK and rc not in allow:
         raise ScanfuseError(rc, lib().sf_last_error().decode("utf-8", "replace"))
     return rc
+
+
+def usable_cpus():
+    """CPUs this process may actually use: the scheduler affinity capped by the cgroup CPU quota (a container can show 256 logical CPUs
+    and be allowed the time of 16 -- /sys/fs/cgroup/cpu.max); what thread pools and CPU baselines size themselves from."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max" and int(period) > 0:
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
