@@ -154,10 +154,14 @@ void idct_block(float* blk, bool dc_only, uint8_t* out, int stride) {
 
 }  // namespace
 
-// dst != nullptr: decode to RGB.  dst == nullptr: entropy-decode only -- the layout goes to *L, the quantised coefficients to coef (the GPU
-// reconstructs: jpeg_gpu.hip); SF_ERR_UNSUPPORTED when the layout is one the GPU path does not take or coef_capacity is too small.
-static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t expect_w, uint32_t expect_h, SfJpegLayout* L, int16_t* coef,
-                       uint64_t coef_capacity) {
+// dst != nullptr: decode to RGB.  dst == nullptr: entropy-decode only -- the layout goes to *L, block table and non-zero quantised
+// coefficients behind it (payload: SfJpegLayout, table, entries; the GPU reconstructs: jpeg_gpu.hip); SF_ERR_UNSUPPORTED when the layout is
+// one the GPU path does not take or the payload does not fit payload_capacity bytes.
+static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t expect_w, uint32_t expect_h, uint8_t* payload, uint64_t payload_capacity) {
+  SfJpegLayout* L = reinterpret_cast<SfJpegLayout*>(payload);
+  uint32_t* table = nullptr;
+  uint32_t* entries = nullptr;
+  uint64_t max_entries = 0, nent = 0;
   if (n < 4 || data[0] != 0xFF || data[1] != 0xD8) return sf::fail(SF_ERR_FORMAT, "jpeg: missing SOI");
   uint16_t qt[4][64];
   float fq[4][64];   // quantiser step x AAN scale, natural order
@@ -250,21 +254,25 @@ static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t e
   const bool to_coef = dst == nullptr;
   if (to_coef) {
     if (hmax > 2 || vmax > 2) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: sampling factors above 2 take the host decoder");
+    if (payload_capacity < sizeof(SfJpegLayout)) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: payload too small");
     std::memset(L, 0, sizeof(*L));
     L->width = (uint16_t)width; L->height = (uint16_t)height;
     L->ncomp = (uint8_t)ncomp; L->hmax = (uint8_t)hmax; L->vmax = (uint8_t)vmax;
-    uint32_t off = 0;
+    uint32_t nb = 0;
     for (int i = 0; i < ncomp; i++) {
       if ((hmax % comp[i].h) || (vmax % comp[i].v)) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: fractional sampling ratios are not supported");
       L->h[i] = (uint8_t)comp[i].h; L->v[i] = (uint8_t)comp[i].v;
       L->bw[i] = (uint16_t)(mcux * comp[i].h * 8); L->bh[i] = (uint16_t)(mcuy * comp[i].v * 8);
-      L->coef_off[i] = off;
-      off += (uint32_t)L->bw[i] * L->bh[i];
+      L->block_off[i] = nb;
+      nb += (uint32_t)(L->bw[i] / 8) * (uint32_t)(L->bh[i] / 8);
       for (int z = 0; z < 64; z++) L->q[i][z] = qt[comp[i].tq][z];
     }
-    L->coef_total = off;
-    if ((uint64_t)off > coef_capacity) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: %u coefficients do not fit the payload (%llu)", off, (unsigned long long)coef_capacity);
-    std::memset(coef, 0, (size_t)off * 2);
+    L->nblocks = nb;
+    if (sizeof(SfJpegLayout) + 4ull * nb > payload_capacity) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: the block table does not fit the payload");
+    table = reinterpret_cast<uint32_t*>(payload + sizeof(SfJpegLayout));
+    entries = table + nb;
+    max_entries = (payload_capacity - sizeof(SfJpegLayout) - 4ull * nb) / 4;
+    if (max_entries > (1u << 25) - 64) max_entries = (1u << 25) - 64;   // a table word keeps 25 bits of entry index
   }
   for (int i = 0; i < ncomp; i++) {
     comp[i].bw = mcux * comp[i].h * 8; comp[i].bh = mcuy * comp[i].v * 8;
@@ -284,12 +292,14 @@ static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t e
         const float* q = fq[c.tq];
         for (int by = 0; by < c.v; by++)
           for (int bx = 0; bx < c.h; bx++) {
-            if (to_coef) {   // the same walk, coefficients stored instead of reconstructed
-              int16_t* cb = coef + L->coef_off[ci] + ((size_t)(my * c.v + by) * (size_t)(c.bw / 8) + (size_t)(mx * c.h + bx)) * 64;
+            if (to_coef) {   // the same walk, the non-zero coefficients appended instead of reconstructed
+              if (nent + 64 > max_entries) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: more coefficients than the payload holds");
+              const uint32_t block = L->block_off[ci] + (uint32_t)(my * c.v + by) * (uint32_t)(c.bw / 8) + (uint32_t)(mx * c.h + bx);
+              const uint64_t first_entry = nent;
               const int t = decode_huff(bs, hdc[c.td]);
               if (t < 0 || t > 11) return sf::fail(SF_ERR_FORMAT, "jpeg: bad DC code");
               c.pred += t ? extend(bs.get(t), t) : 0;
-              cb[0] = (int16_t)c.pred;
+              if (c.pred != 0) entries[nent++] = (uint32_t)(uint16_t)(int16_t)c.pred;
               const HuffDC_AC& ac = hac[c.ta];
               for (int k = 1; k < 64;) {
                 if (bs.cnt < 32) bs.fill();
@@ -298,7 +308,7 @@ static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t e
                   k += (fa >> 4) & 15;
                   if (k > 63) return sf::fail(SF_ERR_FORMAT, "jpeg: AC run past the end of the block");
                   bs.drop(fa & 15);
-                  cb[ZIGZAG[k]] = (int16_t)(fa >> 8);
+                  entries[nent++] = ((uint32_t)ZIGZAG[k] << 16) | (uint32_t)(uint16_t)(int16_t)(fa >> 8);
                   k++;
                   continue;
                 }
@@ -311,9 +321,10 @@ static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t e
                 }
                 k += r;
                 if (k > 63) return sf::fail(SF_ERR_FORMAT, "jpeg: AC run past the end of the block");
-                cb[ZIGZAG[k]] = (int16_t)extend(bs.get(sz), sz);
+                entries[nent++] = ((uint32_t)ZIGZAG[k] << 16) | (uint32_t)(uint16_t)(int16_t)extend(bs.get(sz), sz);
                 k++;
               }
+              table[block] = ((uint32_t)first_entry << 7) | (uint32_t)(nent - first_entry);
               continue;
             }
             std::memset(blk, 0, sizeof(blk));
@@ -363,7 +374,7 @@ static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t e
         todo = restart;
       }
     }
-  if (to_coef) return SF_OK;
+  if (to_coef) { L->nentries = (uint32_t)nent; return SF_OK; }
   // upsample + colour convert
   if (ncomp == 1) {
     for (int y = 0; y < height; y++)
@@ -435,10 +446,11 @@ static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t e
 
 int jpeg_decode_rgb(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t expect_w, uint32_t expect_h) {
   if (!dst) return sf::fail(SF_ERR_INVALID_ARG, "jpeg_decode_rgb: NULL destination");
-  return decode_impl(data, n, dst, expect_w, expect_h, nullptr, nullptr, 0);
+  return decode_impl(data, n, dst, expect_w, expect_h, nullptr, 0);
 }
 
-int jpeg_decode_coef(const uint8_t* data, uint64_t n, uint32_t expect_w, uint32_t expect_h, SfJpegLayout* layout, int16_t* coef, uint64_t coef_capacity) {
-  if (!layout || !coef) return sf::fail(SF_ERR_INVALID_ARG, "jpeg_decode_coef: NULL argument");
-  return decode_impl(data, n, nullptr, expect_w, expect_h, layout, coef, coef_capacity);
+// entropy decoding only: payload = SfJpegLayout + block table + non-zero coefficients (4-byte aligned, capacity in bytes)
+int jpeg_decode_coef(const uint8_t* data, uint64_t n, uint32_t expect_w, uint32_t expect_h, uint8_t* payload, uint64_t payload_capacity) {
+  if (!payload) return sf::fail(SF_ERR_INVALID_ARG, "jpeg_decode_coef: NULL argument");
+  return decode_impl(data, n, nullptr, expect_w, expect_h, payload, payload_capacity);
 }

@@ -1,8 +1,8 @@
 // jpeg_gpu.hip -- the data-parallel half of baseline JPEG decoding on gfx950.  The frame pipeline's host threads only entropy-decode
-// (jpeg.cpp: jpeg_decode_coef -- Huffman decoding is serial per frame); the quantised coefficients go over PCIe in place of the RGB
-// image (same size for 4:2:0) and two kernels reconstruct the picture where the fuser wants it anyway, in HBM:
-//   k_jpeg_idct   one lane per 8 x 8 block: dequantise (AAN scale folded in), 1-D passes down the columns and along the rows, round and
-//                 clamp, eight 8-byte stores into the component's plane
+// (jpeg.cpp: jpeg_decode_coef -- Huffman decoding is serial per frame); the non-zero quantised coefficients go over PCIe in place of the
+// RGB image (about a third of its bytes) and two kernels reconstruct the picture where the fuser wants it anyway, in HBM:
+//   k_jpeg_idct   one lane per 8 x 8 block: its non-zero coefficients scattered into a zeroed LDS column and dequantised (AAN scale
+//                 folded in), 1-D passes down the columns and along the rows, round and clamp, eight 8-byte stores into the plane
 //   k_jpeg_rgb    four pixels per lane: triangle-filter chroma upsampling, BT.601 -> RGB, three dword stores
 // Every arithmetic step is the function of jpeg_idct.h the host decoder is built from (no contraction), so the bytes are the ones
 // sf_sens_decode_color produces (tests/test_gpu_pipeline.py).  Replaces, for this path, the SSE2 IDCT + resampling of stb_image as
@@ -25,38 +25,39 @@ struct JpegBatch {
 };
 
 __global__ __launch_bounds__(256) void k_jpeg_idct(JpegBatch B) {
+  extern __shared__ float s_blk[];   // [64][256]: coefficient z of lane t at z * 256 + t (no bank conflicts either way)
   const int f = blockIdx.y;
   if (B.rgb[f] == nullptr) return;
   const SfJpegLayout* __restrict__ L = reinterpret_cast<const SfJpegLayout*>(B.payload[f]);
-  const int16_t* __restrict__ coef = reinterpret_cast<const int16_t*>(B.payload[f] + sizeof(SfJpegLayout));
+  const uint32_t* __restrict__ table = reinterpret_cast<const uint32_t*>(B.payload[f] + sizeof(SfJpegLayout));
+  const uint32_t* __restrict__ entries = table + L->nblocks;
   __shared__ float fq[3][64];
   for (int t = threadIdx.x; t < 64 * L->ncomp; t += 256) fq[t >> 6][t & 63] = sf_jpeg_dequant(L->q[t >> 6][t & 63], t & 63);
   __syncthreads();
-  uint32_t b = blockIdx.x * 256 + threadIdx.x;   // block index over all components
-  int c = 0;
+  const uint32_t block = blockIdx.x * 256 + threadIdx.x;   // block index over all components
+  if (block >= L->nblocks) return;
+  int c = L->ncomp - 1;
+  while (c > 0 && block < L->block_off[c]) c--;
   size_t plane_off = 0;
-  for (; c < L->ncomp; c++) {
-    const uint32_t nb = (uint32_t)(L->bw[c] / 8) * (uint32_t)(L->bh[c] / 8);
-    if (b < nb) break;
-    b -= nb;
-    plane_off += (size_t)L->bw[c] * L->bh[c];
-  }
-  if (c >= L->ncomp) return;
+  for (int i = 0; i < c; i++) plane_off += (size_t)L->bw[i] * L->bh[i];
+  const uint32_t b = block - L->block_off[c];
   const int blocks_w = L->bw[c] / 8;
-  const int16_t* __restrict__ cb = coef + L->coef_off[c] + (size_t)b * 64;
+  // the block's non-zero coefficients scattered into a zeroed LDS column, dequantised on the way
+  float* col = s_blk + threadIdx.x;
+#pragma unroll
+  for (int z = 0; z < 64; z++) col[z * 256] = 0.0f;
+  const uint32_t te = table[block];
+  const uint32_t* e = entries + (te >> 7);
+  for (uint32_t k = 0; k < (te & 127u); k++) {
+    const uint32_t w = e[k];
+    const int z = (int)((w >> 16) & 63u);
+    col[z * 256] = (float)(int16_t)(w & 0xffffu) * fq[c][z];
+  }
   float blk[64];
 #pragma unroll
-  for (int z = 0; z < 64; z += 8) {
-    const uint4 w = *reinterpret_cast<const uint4*>(cb + z);   // 8 coefficients (payloads and blocks are 16-byte aligned)
-    const uint32_t u[4] = {w.x, w.y, w.z, w.w};
+  for (int z = 0; z < 64; z++) blk[z] = col[z * 256];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      blk[z + 2 * k] = (float)(int16_t)(u[k] & 0xffffu) * fq[c][z + 2 * k];
-      blk[z + 2 * k + 1] = (float)(int16_t)(u[k] >> 16) * fq[c][z + 2 * k + 1];
-    }
-  }
-#pragma unroll
-  for (int col = 0; col < 8; col++) sf_idct8(blk + col, 8);
+  for (int cc = 0; cc < 8; cc++) sf_idct8(blk + cc, 8);
 #pragma unroll
   for (int row = 0; row < 8; row++) sf_idct8(blk + 8 * row, 1);
   uint8_t* out = B.planes[f] + plane_off + (size_t)(b / blocks_w) * 8 * L->bw[c] + (size_t)(b % blocks_w) * 8;
@@ -129,14 +130,19 @@ int jpeg_gpu_reconstruct(hipStream_t stream, int n, const uint8_t* const* d_payl
     b.rgb[i] = i < n ? d_rgb[i] : nullptr;
     b.planes[i] = i < n ? d_planes[i] : nullptr;
   }
-  hipLaunchKernelGGL(k_jpeg_idct, dim3((max_blocks + 255) / 256, n), dim3(256), 0, stream, b);
+  static bool lds_set = false;   // 64 KiB of dynamic LDS per workgroup
+  if (!lds_set) {
+    SF_HIP_CHECK(hipFuncSetAttribute((const void*)k_jpeg_idct, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 256 * (int)sizeof(float)));
+    lds_set = true;
+  }
+  hipLaunchKernelGGL(k_jpeg_idct, dim3((max_blocks + 255) / 256, n), dim3(256), 64 * 256 * sizeof(float), stream, b);
   hipLaunchKernelGGL(k_jpeg_rgb, dim3((unsigned)((max_pixels / 4 + 256) / 256), n), dim3(256), 0, stream, b);
   SF_HIP_CHECK(hipGetLastError());
   return SF_OK;
 }
 
 int jpeg_decode_rgb(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t expect_w, uint32_t expect_h);                                          // jpeg.cpp
-int jpeg_decode_coef(const uint8_t* data, uint64_t n, uint32_t expect_w, uint32_t expect_h, SfJpegLayout* layout, int16_t* coef, uint64_t coef_capacity);  // jpeg.cpp
+int jpeg_decode_coef(const uint8_t* data, uint64_t n, uint32_t expect_w, uint32_t expect_h, uint8_t* payload, uint64_t payload_capacity);  // jpeg.cpp
 
 // Baseline JPEG -> RGB on the host (what sf_sens_decode_color does for a TYPE_JPEG frame)
 SF_API int sf_jpeg_decode(const uint8_t* data, uint64_t bytes, uint32_t width, uint32_t height, uint8_t* dst_rgb) {
@@ -154,22 +160,21 @@ SF_API int sf_jpeg_decode_gpu(const uint8_t* data, uint64_t bytes, uint32_t widt
   if (device < 0 || device >= ndev) return sf::fail(SF_ERR_INVALID_ARG, "device %d out of range (%d devices)", device, ndev);
   SF_HIP_CHECK(hipSetDevice(device));
   const uint64_t padded = (uint64_t)((width + 15) & ~15u) * ((height + 15) & ~15u);
-  const uint64_t cap = padded * 3;   // 4:4:4 at most
-  std::vector<uint8_t> host(sizeof(SfJpegLayout) + cap * 2);
-  SfJpegLayout* L = reinterpret_cast<SfJpegLayout*>(host.data());
-  const int rc = jpeg_decode_coef(data, bytes, width, height, L, reinterpret_cast<int16_t*>(host.data() + sizeof(SfJpegLayout)), cap);
+  std::vector<uint32_t> host((sizeof(SfJpegLayout) + padded * 3 / 64 * 4 + padded * 3 * 4) / 4 + 64);   // every coefficient of a 4:4:4 frame non-zero
+  const int rc = jpeg_decode_coef(data, bytes, width, height, reinterpret_cast<uint8_t*>(host.data()), host.size() * 4);
   if (rc != SF_OK) return rc;
+  const SfJpegLayout* L = reinterpret_cast<const SfJpegLayout*>(host.data());
   uint8_t *d_pay = nullptr, *d_rgb = nullptr, *d_planes = nullptr;
-  const size_t pay_b = sizeof(SfJpegLayout) + (size_t)L->coef_total * 2, rgb_b = (size_t)width * height * 3;
+  const size_t pay_b = sf_jpeg_payload_bytes(*L), rgb_b = (size_t)width * height * 3;
   auto release = [&]() { if (d_pay) (void)hipFree(d_pay); if (d_rgb) (void)hipFree(d_rgb); if (d_planes) (void)hipFree(d_planes); };
   hipError_t e = hipMalloc((void**)&d_pay, pay_b);
   if (e == hipSuccess) e = hipMalloc((void**)&d_rgb, rgb_b);
-  if (e == hipSuccess) e = hipMalloc((void**)&d_planes, L->coef_total);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_planes, sf_jpeg_plane_bytes(*L));
   if (e == hipSuccess) e = hipMemcpy(d_pay, host.data(), pay_b, hipMemcpyHostToDevice);
   int out = SF_OK;
   if (e == hipSuccess) {
     const uint8_t* pp = d_pay;
-    out = jpeg_gpu_reconstruct(nullptr, 1, &pp, &d_rgb, &d_planes, L->coef_total / 64, (uint64_t)width * height);
+    out = jpeg_gpu_reconstruct(nullptr, 1, &pp, &d_rgb, &d_planes, L->nblocks, (uint64_t)width * height);
     if (out == SF_OK) e = hipMemcpy(dst_rgb, d_rgb, rgb_b, hipMemcpyDeviceToHost);
   }
   release();

@@ -23,7 +23,7 @@
 #include "sens.h"
 
 int sf_fuser_run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb, const float* const* poses, int n);  // fuser.hip
-int jpeg_decode_coef(const uint8_t* data, uint64_t n, uint32_t expect_w, uint32_t expect_h, SfJpegLayout* layout, int16_t* coef, uint64_t coef_capacity);  // jpeg.cpp
+int jpeg_decode_coef(const uint8_t* data, uint64_t n, uint32_t expect_w, uint32_t expect_h, uint8_t* payload, uint64_t payload_capacity);  // jpeg.cpp
 int jpeg_gpu_reconstruct(hipStream_t stream, int n, const uint8_t* const* d_payload, uint8_t* const* d_rgb, uint8_t* const* d_planes, uint32_t max_blocks,
                          uint64_t max_pixels);  // jpeg_gpu.hip
 
@@ -59,6 +59,7 @@ struct BatchSlot {
   std::atomic<int> decoded{0};    // frames of the current generation the pool has finished with
   std::atomic<int> failed{0};
   uint8_t coef_mode[16] = {0};    // per frame: 1 = the pinned colour payload holds JPEG coefficients (GPU reconstructs), 0 = RGB
+  uint32_t pay_used[16] = {0};    // bytes of that payload
 };
 
 }  // namespace
@@ -112,19 +113,21 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   // (jpeg_gpu.hip).  The payload is sized from the first colour frame's layout (a scan's frames share it); a frame that does not fit,
   // or has a layout the GPU path does not take, is decoded on the host as before.  SF_JPEG_HOST=1: always decode on the host.
   size_t pay_b = 0, planes_b = 0;
-  uint32_t pay_coef_cap = 0;
+  uint32_t pay_blocks = 0;
   if (jpeg_colour && std::getenv("SF_JPEG_HOST") == nullptr) {
     for (uint64_t k = first; k < last && pay_b == 0; k++) {
       const SensFrame& fr = s->frames[k];
       if (fr.pose[0] == -INFINITY || fr.color_bytes == 0) continue;
       const uint32_t cw_ = s->info.color_width, ch_ = s->info.color_height;
-      const uint64_t cap = (uint64_t)((cw_ + 15) & ~15u) * ((ch_ + 15) & ~15u) * 3;
-      std::vector<uint8_t> probe(sizeof(SfJpegLayout) + cap * 2);
-      SfJpegLayout* L = reinterpret_cast<SfJpegLayout*>(probe.data());
-      if (jpeg_decode_coef(fr.color, fr.color_bytes, cw_, ch_, L, reinterpret_cast<int16_t*>(probe.data() + sizeof(SfJpegLayout)), cap) != SF_OK) break;
-      pay_coef_cap = L->coef_total;
-      pay_b = (sizeof(SfJpegLayout) + (size_t)L->coef_total * 2 + 255) & ~(size_t)255;
-      planes_b = ((size_t)L->coef_total + 255) & ~(size_t)255;
+      const uint64_t padded = (uint64_t)((cw_ + 15) & ~15u) * ((ch_ + 15) & ~15u);
+      std::vector<uint32_t> probe((sizeof(SfJpegLayout) + padded * 3 / 64 * 4 + padded * 3 * 4) / 4 + 64);
+      if (jpeg_decode_coef(fr.color, fr.color_bytes, cw_, ch_, reinterpret_cast<uint8_t*>(probe.data()), probe.size() * 4) != SF_OK) break;
+      const SfJpegLayout* L = reinterpret_cast<const SfJpegLayout*>(probe.data());
+      pay_blocks = L->nblocks;
+      // room for the table and as many entries as the pixels have bytes: a frame with more non-zero coefficients than that (finer than
+      // anything a camera compresses to) is decoded on the host
+      pay_b = (sizeof(SfJpegLayout) + 4 * (size_t)L->nblocks + rgb_b + 255) & ~(size_t)255;
+      planes_b = (sf_jpeg_plane_bytes(*L) + 255) & ~(size_t)255;
     }
   }
   const bool gpu_jpeg = pay_b != 0;
@@ -193,8 +196,9 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
           bool coef = false;
           if (gpu_jpeg) {
             uint8_t* pay = h_pay(sl, j);
-            coef = jpeg_decode_coef(s->frames[frame].color, s->frames[frame].color_bytes, s->info.color_width, s->info.color_height,
-                                    reinterpret_cast<SfJpegLayout*>(pay), reinterpret_cast<int16_t*>(pay + sizeof(SfJpegLayout)), pay_coef_cap) == SF_OK;
+            coef = jpeg_decode_coef(s->frames[frame].color, s->frames[frame].color_bytes, s->info.color_width, s->info.color_height, pay, pay_b) == SF_OK &&
+                   reinterpret_cast<const SfJpegLayout*>(pay)->nblocks == pay_blocks;
+            if (coef) ring[(size_t)sl].pay_used[j] = (uint32_t)sf_jpeg_payload_bytes(*reinterpret_cast<const SfJpegLayout*>(pay));
           }
           ring[(size_t)sl].coef_mode[j] = coef ? 1 : 0;
           if (!coef) rc = sf_sens_decode_color(s, frame, h_rgb(sl, j));   // raw colour, or a JPEG the GPU path does not take (errors surface here)
@@ -275,15 +279,10 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
       any_rgb = true;
       j = j1;
     }
-    for (int j = 0; j < cnt && e == hipSuccess;) {   // coefficients: runs of entropy-decoded frames
-      if (!rgbf[j] || !bs.coef_mode[j]) { j++; continue; }
-      int j1 = j;
-      while (j1 < cnt && rgbf[j1] && bs.coef_mode[j1]) j1++;
-      const int jm = j + (j1 - j + 1) / 2;
-      e = hipMemcpyAsync(d_pay(sl, j), h_pay(sl, j), (size_t)(jm - j) * col_b, hipMemcpyHostToDevice, cs_rgb);
-      if (e == hipSuccess && j1 > jm) e = hipMemcpyAsync(d_pay(sl, jm), h_pay(sl, jm), (size_t)(j1 - jm) * col_b, hipMemcpyHostToDevice, cs_depth);
+    for (int j = 0, k = 0; j < cnt && e == hipSuccess; j++) {   // coefficients: what each entropy-decoded frame really holds, alternating streams
+      if (!rgbf[j] || !bs.coef_mode[j]) continue;
+      e = hipMemcpyAsync(d_pay(sl, j), h_pay(sl, j), bs.pay_used[j], hipMemcpyHostToDevice, (k++ & 1) ? cs_depth : cs_rgb);
       any_rgb = true;
-      j = j1;
     }
     if (e == hipSuccess && any_rgb) {   // `copied` on the depth stream stands for both parts
       e = hipEventRecord(bs.copied_rgb, cs_rgb);
@@ -318,7 +317,7 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
         for (int q = jfirst; q < j; q++)
           if (valid[q] && rgbf[q] && bs.coef_mode[q]) { pp_[nj] = d_pay(sl, q); rr_[nj] = d_rgb(sl, q); pl_[nj] = d_planes(sl, q); nj++; }
         if (nj > 0) {
-          const int rcj = jpeg_gpu_reconstruct(in_stream, nj, pp_, rr_, pl_, pay_coef_cap / 64, (uint64_t)cpx);
+          const int rcj = jpeg_gpu_reconstruct(in_stream, nj, pp_, rr_, pl_, pay_blocks, (uint64_t)cpx);
           if (rcj != SF_OK) { result = rcj; err = sf_last_error(); break; }
         }
       }
