@@ -66,7 +66,7 @@ def pmc_traffic(steps, warmup, timeout_s=300, single_frame=False):
         try:
             env = dict(os.environ, TMPDIR="/tmp")
             cmd = [exe, "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--steps", str(steps),
-                   "--warmup", str(warmup), "--no-cpu-baseline", "--no-profile", "--no-pmc"] + (["--single-frame"] if single_frame else [])
+                   "--warmup", str(warmup), "--no-cpu-baseline", "--no-profile", "--no-pmc", "--teardown"] + (["--single-frame"] if single_frame else [])
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
             dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
             if r.returncode != 0 or not dbs:
@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--pmc-steps", type=int, default=400)
     ap.add_argument("--single-frame", action="store_true", help="one frame per launch (SF_BATCH=1) for the main measurement")
     ap.add_argument("--no-single-frame", action="store_true", help="skip the secondary one-frame-per-launch roofline pass")
+    ap.add_argument("--teardown", action="store_true", help="leave through the interpreter's normal teardown (set for the runs under rocprofv3)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -260,7 +261,9 @@ def main():
     # port each register exit handlers, and their order is nobody's contract)
     sys.stdout.flush()
     sys.stderr.flush()
-    os._exit(0)
+    under_profiler = args.teardown or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if not under_profiler:   # a profiler writes its results from exactly those exit handlers
+        os._exit(0)
 
 
 if __name__ == "__main__":
