@@ -132,8 +132,15 @@ struct HeapElem {
   uint32_t v0, v1;
   uint32_t mark;
 };
-// 4-ary min-heap on the priority (four 16-byte children share one cache line: about half the misses of a binary heap on
-// the multi-million-entry heap of a scan-sized mesh)
+// The order collapses are taken in: by priority, ties by (v0, v1, mark) -- a total order, so the sequence of collapses is a property
+// of the mesh and the parameters, not of the queue's internals.
+inline bool elem_less(const HeapElem& a, const HeapElem& b) {
+  if (a.pri != b.pri) return a.pri < b.pri;
+  if (a.v0 != b.v0) return a.v0 < b.v0;
+  if (a.v1 != b.v1) return a.v1 < b.v1;
+  return a.mark < b.mark;
+}
+// 4-ary min-heap (four 16-byte children share one cache line: about half the misses of a binary heap)
 struct Heap4 {
   std::vector<HeapElem> h;
   bool empty() const { return h.empty(); }
@@ -143,52 +150,91 @@ struct Heap4 {
     h.push_back(e);
     while (i > 0) {
       const size_t p = (i - 1) >> 2;
-      if (!(e.pri < h[p].pri)) break;
+      if (!elem_less(e, h[p])) break;
       h[i] = h[p];
       i = p;
+    }
+    h[i] = e;
+  }
+  void sift_down(size_t i, const HeapElem& e) {
+    const size_t n = h.size();
+    for (;;) {
+      const size_t c0 = 4 * i + 1;
+      if (c0 >= n) break;
+      size_t m = c0;
+      const size_t ce = std::min(c0 + 4, n);
+      for (size_t c = c0 + 1; c < ce; c++)
+        if (elem_less(h[c], h[m])) m = c;
+      if (!elem_less(h[m], e)) break;
+      h[i] = h[m];
+      i = m;
     }
     h[i] = e;
   }
   HeapElem pop() {
     const HeapElem top = h[0], last = h.back();
     h.pop_back();
-    const size_t n = h.size();
-    if (n) {
-      size_t i = 0;
-      for (;;) {
-        const size_t c0 = 4 * i + 1;
-        if (c0 >= n) break;
-        size_t m = c0;
-        const size_t ce = std::min(c0 + 4, n);
-        for (size_t c = c0 + 1; c < ce; c++)
-          if (h[c].pri < h[m].pri) m = c;
-        if (!(h[m].pri < last.pri)) break;
-        h[i] = h[m];
-        i = m;
-      }
-      h[i] = last;
-    }
+    if (!h.empty()) sift_down(0, last);
     return top;
   }
   void heapify() {  // Floyd
     const size_t n = h.size();
     if (n < 2) return;
-    for (size_t s = (n - 2) / 4 + 1; s-- > 0;) {
-      const HeapElem e = h[s];
-      size_t i = s;
-      for (;;) {
-        const size_t c0 = 4 * i + 1;
-        if (c0 >= n) break;
-        size_t m = c0;
-        const size_t ce = std::min(c0 + 4, n);
-        for (size_t c = c0 + 1; c < ce; c++)
-          if (h[c].pri < h[m].pri) m = c;
-        if (!(h[m].pri < e.pri)) break;
-        h[i] = h[m];
-        i = m;
+    for (size_t s = (n - 2) / 4 + 1; s-- > 0;) { const HeapElem e = h[s]; sift_down(s, e); }
+  }
+};
+
+// The queue of a scan-sized mesh holds tens of millions of entries, and a heap that large misses the cache on every level of every
+// pop -- microseconds per collapse.  Only the entries that can be popped soon need a heap: `hot` holds everything with priority <=
+// threshold (a few MiB, cache-resident), `cold` is an unsorted append-only array of the rest.  When `hot` runs dry the stale entries of
+// `cold` are dropped, a new threshold is taken from a sample of its priorities so that about HOT_TARGET entries qualify, and those move
+// over.  Every entry <= threshold is in the heap at all times, so the pop order is exactly that of one big heap under elem_less.
+struct LadderQueue {
+  static constexpr size_t HOT_TARGET = 1u << 19;
+  Heap4 hot;
+  std::vector<HeapElem> cold;
+  float threshold = -INFINITY;
+  size_t size() const { return hot.size() + cold.size(); }
+  void push(const HeapElem& e) {
+    if (e.pri <= threshold) hot.push(e);
+    else cold.push_back(e);
+  }
+  // drop what `keep` rejects everywhere (the stale entries); rebuild the heap
+  template <class Keep>
+  void compact(Keep keep) {
+    size_t w = 0;
+    for (size_t i = 0; i < hot.h.size(); i++) if (keep(hot.h[i])) hot.h[w++] = hot.h[i];
+    hot.h.resize(w);
+    hot.heapify();
+    w = 0;
+    for (size_t i = 0; i < cold.size(); i++) if (keep(cold[i])) cold[w++] = cold[i];
+    cold.resize(w);
+  }
+  // make `hot` non-empty if anything is left; false when the queue is exhausted
+  template <class Keep>
+  bool refill(Keep keep) {
+    while (hot.empty()) {
+      size_t w = 0;
+      for (size_t i = 0; i < cold.size(); i++) if (keep(cold[i])) cold[w++] = cold[i];
+      cold.resize(w);
+      if (cold.empty()) return false;
+      if (cold.size() <= 2 * HOT_TARGET) threshold = INFINITY;
+      else {   // the HOT_TARGET / size quantile of an evenly spaced sample of 4096 priorities
+        std::vector<float> sample(4096);
+        for (size_t k = 0; k < sample.size(); k++) sample[k] = cold[(size_t)((double)k * (double)cold.size() / (double)sample.size())].pri;
+        const size_t q = std::min(sample.size() - 1, (size_t)((double)sample.size() * (double)HOT_TARGET / (double)cold.size()));
+        std::nth_element(sample.begin(), sample.begin() + (long)q, sample.end());
+        threshold = sample[q];
       }
-      h[i] = e;
+      w = 0;
+      for (size_t i = 0; i < cold.size(); i++) {
+        if (cold[i].pri <= threshold) hot.h.push_back(cold[i]);
+        else cold[w++] = cold[i];
+      }
+      cold.resize(w);
+      hot.heapify();
     }
+    return true;
   }
 };
 
@@ -204,7 +250,8 @@ struct Simplifier {
   std::vector<uint8_t> vf_idx;    // head per vertex: corner
   std::vector<int32_t> nx_face;   // per (face, corner): next face or -1
   std::vector<uint8_t> nx_idx;
-  Heap4 heap;
+  LadderQueue heap;
+  std::vector<std::pair<int32_t, int>> both, only0;   // scratch of collapse()
   uint32_t global_mark = 0;
   uint64_t nfaces = 0;
   double scale = 1.0;
@@ -432,10 +479,9 @@ struct Simplifier {
       for (std::thread& th : pool) th.join();
       size_t total = 0;
       for (const auto& v : part) total += v.size();
-      heap.h.reserve(std::max(total + 16, 3 * (size_t)nfaces + 4096 + 16));
-      for (const auto& v : part) heap.h.insert(heap.h.end(), v.begin(), v.end());
+      heap.cold.reserve(std::max(total + 16, 3 * (size_t)nfaces + 4096 + 16));
+      for (const auto& v : part) heap.cold.insert(heap.cold.end(), v.begin(), v.end());
     }
-    heap.heapify();
     return SF_OK;
   }
 
@@ -448,7 +494,8 @@ struct Simplifier {
     optimal(v0, v1, q, x);
     Q[v1] = q;
     // FindSets over VF(v0): faces with both vertices die, the others are re-pointed
-    std::vector<std::pair<int32_t, int>> both, only0;
+    both.clear();
+    only0.clear();
     {
       int32_t f = vf_face[v0];
       int j = vf_idx[v0];
@@ -496,16 +543,11 @@ struct Simplifier {
   }
 
   void run(uint64_t target) {
-    while (nfaces > target && !heap.empty()) {
-      if (heap.size() > 3 * (size_t)nfaces + 4096) {  // ClearHeap: drop the stale entries, rebuild
-        size_t w = 0;
-        for (size_t i = 0; i < heap.h.size(); i++)
-          if (up_to_date(heap.h[i])) heap.h[w++] = heap.h[i];
-        heap.h.resize(w);
-        heap.heapify();
-        if (heap.empty()) break;
-      }
-      const HeapElem h = heap.pop();
+    const auto keep = [this](const HeapElem& e) { return up_to_date(e); };
+    while (nfaces > target) {
+      if (heap.size() > 3 * (size_t)nfaces + 4096) heap.compact(keep);  // ClearHeap: drop the stale entries
+      if (!heap.refill(keep)) break;
+      const HeapElem h = heap.hot.pop();
       if (!up_to_date(h)) { st.stale_popped++; continue; }
       if (h.pri > st.max_priority) st.max_priority = h.pri;
       collapse(h.v0, h.v1);
