@@ -530,7 +530,16 @@ struct Simplifier {
       int j = vf_idx[v1];
       while (f >= 0) {
         const uint32_t w1 = tri[3 * (size_t)f + (j + 1) % 3], w2 = tri[3 * (size_t)f + (j + 2) % 3];
-        if (pass == 0) { visited[w1] = 0; visited[w2] = 0; }
+        if (pass == 0) {
+          visited[w1] = 0; visited[w2] = 0;
+          // the second pass evaluates one collapse per neighbour: start fetching what it will read (quadric, fan head, first fan face)
+          for (uint32_t w : {w1, w2}) {
+            __builtin_prefetch(&Q[w]);
+            __builtin_prefetch(reinterpret_cast<const char*>(&Q[w]) + 64);
+            const int32_t wf = vf_face[w];
+            if (wf >= 0) { __builtin_prefetch(&tri[3 * (size_t)wf]); __builtin_prefetch(&nx_face[3 * (size_t)wf]); }
+          }
+        }
         else {
           if (!visited[w1]) { visited[w1] = 1; push(v1, w1); }
           if (!visited[w2]) { visited[w2] = 1; push(w2, v1); }
@@ -548,6 +557,13 @@ struct Simplifier {
       if (heap.size() > 3 * (size_t)nfaces + 4096) heap.compact(keep);  // ClearHeap: drop the stale entries
       if (!heap.refill(keep)) break;
       const HeapElem h = heap.hot.pop();
+      // whichever entry comes next is among the first few of the array: start fetching what its validity test and its collapse read
+      for (size_t c = 0; c < 5 && c < heap.hot.h.size(); c++) {
+        const HeapElem& nx = heap.hot.h[c];
+        __builtin_prefetch(&imark[nx.v0]); __builtin_prefetch(&imark[nx.v1]);
+        __builtin_prefetch(&vdel[nx.v0]); __builtin_prefetch(&vdel[nx.v1]);
+        if (c < 2) { __builtin_prefetch(&Q[nx.v0]); __builtin_prefetch(&Q[nx.v1]); __builtin_prefetch(&vf_face[nx.v0]); __builtin_prefetch(&vf_face[nx.v1]); }
+      }
       if (!up_to_date(h)) { st.stale_popped++; continue; }
       if (h.pri > st.max_priority) st.max_priority = h.pri;
       collapse(h.v0, h.v1);
