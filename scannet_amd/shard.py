@@ -9,7 +9,9 @@ tests).  Without a process group the queue degenerates to "rank 0 takes everythi
 
     torchrun --nproc-per-node 8 -m scannet_amd.shard scans.txt        # one .sens path per line
 
-runs the whole stage chain per scan (sf_fuse_run -> mesh -> clean -> segs.json) on the rank's own GPU.
+runs the stage chain per scan: sf_fuse_run -> mesh on the rank's own GPU, then clean -> decimate x 2 -> segs.json on a pool of host
+threads (SF_HOST_WORKERS, default: the usable CPUs divided among the local ranks) while the GPU takes the next scan -- the
+sequential quadric collapse is ~20 s per scan-sized mesh, a hundred times the GPU part.
 """
 import os
 import sys
@@ -72,24 +74,68 @@ def run_sharded(items, costs, work, key="scanfuse/queue"):
     return done
 
 
-def process_scan(sens_path, device=0, params_file=None, clean_min_faces=7500, kthresh=0.01, seg_min_verts=20):
-    """The improve + segment stage chain for one scan on one GPU: <id>_vh.ply, <id>_vh_clean.ply, segs.json."""
-    from . import fusion, meshclean, segmentator, sens
+def fuse_scan(sens_path, device=0, params_file=None):
+    """The GPU part of a scan: .sens -> fusion -> marching cubes.  Returns (mesh, info)."""
+    from . import fusion, sens
     sd = sens.SensorData(sens_path)
     p = fusion.load_params(params_file) if params_file else fusion.default_params()
     p.depth_width, p.depth_height = sd.depth_width, sd.depth_height
     K = sd.intrinsic_depth
     p.fx, p.fy, p.mx, p.my, p.depth_shift = float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), sd.depth_shift
-    base = os.path.splitext(sens_path)[0]
     t0 = time.perf_counter()
     with fusion.Fuser(p, device=device) as f:
         rs = f.run(sd)
         mesh = f.extract_mesh()
+    return mesh, {"scan": sens_path, "frames": rs["frames_integrated"], "gpu_seconds": time.perf_counter() - t0}
+
+
+def finish_scan(mesh, sens_path, clean_min_faces=7500, kthresh=0.01, seg_min_verts=20):
+    """The host part (Server/scan_processor.py:141-156): <id>_vh.ply, clean.mlx -> <id>_vh_clean.ply, simplify.mlx twice (each
+    followed by cleanLoRes) -> <id>_vh_clean_2.ply, Segmentator -> <id>_vh_clean_2.0.010000.segs.json.  One thread, tens of seconds
+    for a scan-sized mesh (the quadric collapse is sequential): run several of these side by side."""
+    from . import meshclean, segmentator
+    base = os.path.splitext(sens_path)[0]
+    t0 = time.perf_counter()
     mesh.write_ply(base + "_vh.ply")
     cleaned, cst = meshclean.clean(mesh, meshclean.CLEAN_MLX_MERGE_DISTANCE, clean_min_faces)
     cleaned.write_ply(base + "_vh_clean.ply")
-    nseg = segmentator.segment_to_json(base + "_vh_clean.ply", kthresh, seg_min_verts)
-    return {"scan": sens_path, "frames": rs["frames_integrated"], "seconds": time.perf_counter() - t0, "faces": cst["faces_out"], "segments": nseg}
+    cur = cleaned
+    for _ in range(2):
+        simp, _ = meshclean.simplify(cur)
+        cur, _ = meshclean.clean(simp, meshclean.CLEAN_MLX_MERGE_DISTANCE, meshclean.CLEAN_LORES_MIN_COMPONENT)
+    cur.write_ply(base + "_vh_clean_2.ply")
+    nseg = segmentator.segment_to_json(base + "_vh_clean_2.ply", kthresh, seg_min_verts)
+    return {"faces": cst["faces_out"], "faces_decimated": cur.counts()[1], "segments": nseg, "host_seconds": time.perf_counter() - t0}
+
+
+def process_scan(sens_path, device=0, params_file=None, clean_min_faces=7500, kthresh=0.01, seg_min_verts=20):
+    """Both parts of one scan, one after the other."""
+    mesh, info = fuse_scan(sens_path, device, params_file)
+    info.update(finish_scan(mesh, sens_path, clean_min_faces, kthresh, seg_min_verts))
+    info["seconds"] = info["gpu_seconds"] + info["host_seconds"]
+    return info
+
+
+def run_pipelined(items, costs, gpu_stage, host_stage, host_workers, key="scanfuse/queue"):
+    """run_sharded with the work split in two: `gpu_stage(item)` runs on this rank as items are popped, `host_stage(item, x)` (x = what
+    the GPU stage returned) runs on a pool of `host_workers` threads, so the GPU takes the next scan while the meshes of the previous
+    ones are cleaned, decimated and segmented (ctypes calls release the GIL).  At most 2 * host_workers results wait for a thread at
+    any time (a scan-sized mesh is a few hundred MB).  Returns [(item index, host result)] in the order the items were popped."""
+    from concurrent.futures import ThreadPoolExecutor
+    order = order_longest_first(costs)
+    q = WorkQueue(len(items), key)
+    pending = []
+    with ThreadPoolExecutor(max_workers=max(1, int(host_workers))) as pool:
+        while True:
+            pos = q.pop()
+            if pos is None:
+                break
+            i = order[pos]
+            x = gpu_stage(items[i])
+            pending.append((i, pool.submit(host_stage, items[i], x)))
+            while sum(1 for _, fut in pending if not fut.done()) >= 2 * max(1, int(host_workers)):
+                time.sleep(0.01)
+        return [(i, fut.result()) for i, fut in pending]
 
 
 def main(argv=None):
@@ -102,7 +148,15 @@ def main(argv=None):
     if world > 1:
         dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
     costs = [os.path.getsize(s) for s in scans]  # compressed size tracks the frame count
-    res = run_sharded(scans, costs, lambda s: process_scan(s, device=local_rank))
+    from . import _abi
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    workers = int(os.environ.get("SF_HOST_WORKERS", "0")) or max(1, _abi.usable_cpus() // max(1, local_world))
+
+    def host(path, x):
+        mesh, info = x
+        info.update(finish_scan(mesh, path))
+        return info
+    res = run_pipelined(scans, costs, lambda s: fuse_scan(s, device=local_rank), host, workers)
     for i, r in res:
         print("rank %d: %s" % (int(os.environ.get("RANK", "0")), r))
     if world > 1:

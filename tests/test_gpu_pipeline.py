@@ -237,3 +237,29 @@ def test_fuse_run_with_colour_matches_frame_by_frame(tmp_path, kind, monkeypatch
         assert np.array_equal(ca[oa], cb[ob])
         assert np.array_equal(va[oa], vb[ob]), "voxels (sdf, weight, colour) differ"
         assert len(ca) > 500
+
+
+def test_shard_main_runs_the_whole_chain(tmp_path, capsys, monkeypatch):
+    """python -m scannet_amd.shard on two small scans (one process, no process group): the GPU part of the second scan runs while host
+    threads clean, decimate (twice) and segment the first; every output file of the reference's improve / decimate / segment stages."""
+    from scannet_amd import segmentator, shard
+    paths = []
+    for k, n in enumerate((24, 16)):
+        p = str(tmp_path / ("scene%d.sens" % k))
+        _write_sens(p, n, 320, 240, 1200)
+        paths.append(p)
+    lst = tmp_path / "scans.txt"
+    lst.write_text("\n".join(paths) + "\n")
+    monkeypatch.setenv("SF_HOST_WORKERS", "2")
+    shard.main([str(lst)])
+    out = capsys.readouterr().out
+    assert out.count("rank 0:") == 2
+    for p in paths:
+        base = os.path.splitext(p)[0]
+        for suffix in ("_vh.ply", "_vh_clean.ply", "_vh_clean_2.ply", "_vh_clean_2.0.010000.segs.json"):
+            assert os.path.getsize(base + suffix) > 0, suffix
+        hi = segmentator.Mesh.read(base + "_vh_clean.ply").counts()[1]
+        lo = segmentator.Mesh.read(base + "_vh_clean_2.ply").counts()[1]
+        assert hi > 20000 and lo < 0.06 * hi          # 20 % of 20 %, minus what cleanLoRes drops
+        segs = json.load(open(base + "_vh_clean_2.0.010000.segs.json"))
+        assert len(segs["segIndices"]) == segmentator.Mesh.read(base + "_vh_clean_2.ply").counts()[0]

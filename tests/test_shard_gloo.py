@@ -71,6 +71,59 @@ def test_queue_without_process_group_and_static_lpt():
     assert max(loads) == 300 and parts[0] == [4]
 
 
+def _worker_pipelined(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import threading
+    import time
+    import torch.distributed as dist
+    from scannet_amd import shard
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    costs = [5, 90, 17, 17, 300, 1, 42, 8, 8, 64, 3]
+    items = ["scan%02d" % i for i in range(len(costs))]
+    gpu_thread = threading.get_ident()
+    live, peak = [0], [0]
+    lock = threading.Lock()
+
+    def gpu(item):                      # always on the calling thread, one at a time, in queue order
+        assert threading.get_ident() == gpu_thread
+        return item + "/mesh"
+
+    def host(item, x):                  # on the pool: several at once
+        assert x == item + "/mesh" and threading.get_ident() != gpu_thread
+        with lock:
+            live[0] += 1
+            peak[0] = max(peak[0], live[0])
+        time.sleep(0.03)
+        with lock:
+            live[0] -= 1
+        return costs[items.index(item)]
+
+    done = shard.run_pipelined(items, costs, gpu, host, 3, key="scanfuse/queue/pipelined")
+    assert all(r == costs[i] for i, r in done) and peak[0] <= 3
+    np.save(os.path.join(out_dir, "p%d.npy" % rank), np.array([i for i, _ in done] + [-1, peak[0]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pipelined_queue_two_ranks(tmp_path):
+    """shard.run_pipelined: the GPU stage of the next scan runs while a pool of host threads finishes the previous ones; every scan
+    exactly once over the two ranks, popped longest first."""
+    port = _free_port()
+    mp.spawn(_worker_pipelined, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    from scannet_amd import shard
+    order = shard.order_longest_first([5, 90, 17, 17, 300, 1, 42, 8, 8, 64, 3])
+    got, peaks = [], []
+    for r in range(2):
+        lst = np.load(str(tmp_path / ("p%d.npy" % r))).tolist()
+        cut = lst.index(-1)
+        got.append(lst[:cut])
+        peaks.append(lst[cut + 1])
+        pos = [order.index(i) for i in lst[:cut]]
+        assert pos == sorted(pos)
+    assert sorted(got[0] + got[1]) == list(range(11))
+    assert max(peaks) >= 2, "host stages overlapped"
+
+
 def _worker_gather(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
