@@ -19,6 +19,8 @@ import sqlite3
 import subprocess
 import sys
 import tempfile
+
+import numpy as np
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -45,9 +47,48 @@ def cpu_baseline(depth_host, poses, budget_s=12.0, max_frames=2048):
             break
     dt = time.perf_counter() - t0
     vol.close()
-    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": threads, "kind": "port",
+    decode = reference_decode_ms(depth_host[:32], poses[:32])
+    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": threads, "kind": "port", "reference_decode": decode,
             "sample": "first %d frames of the same stream, oracle/tsdf_oracle.c -O2 -fopenmp (%d threads = the CPUs this container may use, of %d visible), %.1f s"
                       % (n, threads, os.cpu_count() or threads, dt)}
+
+
+def reference_decode_ms(depth_host, poses):
+    """The part of the path the reference DOES have a CPU implementation of: per-frame depth decode (SensReader, compiled from the
+    reference's sources into oracle/_ref/libref_sens.so when this repo was built) beside this library's decoder, one core each,
+    on a .sens written from the first frames of the stream.  None when the reference build is not there."""
+    try:
+        from oracle import oracle as orc
+        from scannet_amd import _abi, sens, synth
+        if not orc.ref_sens_available():
+            return None
+        d = tempfile.mkdtemp(prefix="sf_refdec_", dir="/tmp")
+        path = os.path.join(d, "s.sens")
+        K = synth.intrinsic_matrix(W, H)
+        sd = sens.SensorData.create(0, 0, W, H, K, K, depth_compression=1)
+        for i in range(len(depth_host)):
+            sd.add_frame(depth_host[i], poses[i].reshape(4, 4))
+        sd.save(path)
+        sd.close()
+        out = np.zeros((H, W), np.uint16)
+        R = orc.ref_sens()
+        h = R.ref_sens_open(path.encode())
+        t0 = time.perf_counter()
+        for i in range(len(depth_host)):
+            R.ref_sens_decode_depth(h, i, out.ctypes.data_as(C.c_void_p))
+        t_ref = (time.perf_counter() - t0) / len(depth_host)
+        R.ref_sens_close(h)
+        L = _abi.lib()
+        s2 = sens.SensorData(path)
+        t0 = time.perf_counter()
+        for i in range(len(depth_host)):
+            L.sf_sens_decode_depth(s2._h, C.c_uint64(i), out.ctypes.data_as(C.c_void_p))
+        t_ours = (time.perf_counter() - t0) / len(depth_host)
+        shutil.rmtree(d, ignore_errors=True)
+        return {"unit": "ms per 640x480 depth frame, one core", "reference_sensreader": round(t_ref * 1e3, 3), "this_library": round(t_ours * 1e3, 3),
+                "kind": "reference", "sample": "%d frames, zlib depth, oracle/_ref/libref_sens.so (the reference's sensorData.h + stb, -O2)" % len(depth_host)}
+    except Exception:
+        return None
 
 
 def pmc_traffic(steps, warmup, timeout_s=300, single_frame=False):
