@@ -572,11 +572,11 @@ __device__ inline void fuse_update(const ParamsK& P, const v2f (&rcp_m)[NJ], con
         const uint32_t w = cw >> 24;
         uint32_t rgb = cw & 0xFFFFFFu;
         if (COLOR) {
+          // (a + b + 1) >> 1 per channel, the three channels at once: (a | b) - ((a ^ b) >> 1) on each byte (no borrow crosses a byte:
+          // a | b >= (a ^ b) >> 1; the mask keeps a byte's low bit out of its neighbour's top bit)
           const uint32_t ck = c[2 * j + hx];
-          const uint32_t r8 = ((rgb & 0xFF) + (ck & 0xFF) + 1) >> 1;
-          const uint32_t g8 = (((rgb >> 8) & 0xFF) + ((ck >> 8) & 0xFF) + 1) >> 1;
-          const uint32_t b8 = (((rgb >> 16) & 0xFF) + ((ck >> 16) & 0xFF) + 1) >> 1;
-          rgb = w == 0 ? ck : (r8 | (g8 << 8) | (b8 << 16));
+          const uint32_t avg = (rgb | ck) - (((rgb ^ ck) & 0xFEFEFEu) >> 1);
+          rgb = w == 0 ? ck : avg;
         }
         uint32_t nw = w + (uint32_t)P.wsample;
         if (nw > (uint32_t)P.wmax) nw = (uint32_t)P.wmax;
