@@ -2,7 +2,7 @@
 // (label), 8-bit RGB / RGBA (read only; debug renderings).  Replaces FreeImageWrapper::loadImage / saveImage as
 // AnnotationTools/Filter2dAnnotations/Filter2dAnnotations.cpp:340-341,400-401 and ProjectAnnotations/Visualizer.cpp:185-186 use
 // them (FreeImage is an external binary dependency of mLib).  Non-interlaced images, bit depth 8 or 16, colour types 0, 2, 4, 6;
-// the five scan-line filters of the PNG specification on the way in, filter 0 on the way out; zlib through this library's
+// the five scan-line filters of the PNG specification on the way in, filter 2 (Up) on the way out; zlib through this library's
 // own codec (zlib_codec.cpp).  Samples of 16-bit images are big-endian in the file and host-endian (little) in memory.
 #include <cstdint>
 #include <cstdio>
@@ -125,11 +125,17 @@ SF_API int sf_png_write_gray(const char* path, const void* data, uint32_t width,
   const size_t bpp = bits / 8, stride = (size_t)width * bpp;
   std::vector<uint8_t> raw((stride + 1) * height);
   const uint8_t* src = (const uint8_t*)data;
+  // filter 2 (Up) on every row but the first: label and instance images are piecewise constant, so the difference to the row above is
+  // almost all zeros -- smaller files and a faster deflate than filter 0
+  std::vector<uint8_t> cur(stride), prev(stride, 0);
   for (uint32_t y = 0; y < height; y++) {
     uint8_t* o = &raw[(stride + 1) * y];
-    *o++ = 0;  // filter: none
-    if (bits == 8) std::memcpy(o, src + stride * y, stride);
-    else for (size_t i = 0; i < stride; i += 2) { o[i] = src[stride * y + i + 1]; o[i + 1] = src[stride * y + i]; }
+    if (bits == 8) std::memcpy(cur.data(), src + stride * y, stride);
+    else for (size_t i = 0; i < stride; i += 2) { cur[i] = src[stride * y + i + 1]; cur[i + 1] = src[stride * y + i]; }
+    *o++ = y == 0 ? 0 : 2;
+    if (y == 0) std::memcpy(o, cur.data(), stride);
+    else for (size_t i = 0; i < stride; i++) o[i] = (uint8_t)(cur[i] - prev[i]);
+    cur.swap(prev);
   }
   std::vector<uint8_t> z((size_t)sf_zlib_deflate_bound(raw.size()));
   uint64_t zn = 0;
