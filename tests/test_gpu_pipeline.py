@@ -189,6 +189,12 @@ def test_jpeg_gpu_reconstruction_equals_the_host_decoder():
             assert np.array_equal(host, gpu), "%dx%d case %d: %d bytes differ" % (W, H, cases, (host != gpu).sum())
             cases += 1
     assert cases == 24
+    W, H = 1296, 968                                   # ScanNet's colour size, 4:2:0 and 4:2:2
+    img = _smooth_image(W, H, 3)
+    img = np.clip(img.astype(np.int32) + np.random.default_rng(0).integers(-9, 10, img.shape), 0, 255).astype(np.uint8)   # busy blocks too
+    for sub, q in ((True, 90), (False, 97)):
+        b = calibrate.jpeg_encode(img, q, sub)
+        assert np.array_equal(calibrate.jpeg_decode(b, W, H), calibrate.jpeg_decode(b, W, H, device=0))
     with pytest.raises(Exception):
         calibrate.jpeg_decode(b"\xff\xd8 not a jpeg", 8, 8, device=0)
 
