@@ -83,41 +83,46 @@ struct Out {
   }
 };
 
-struct DctTable {
-  double C[8][8];
-  DctTable() {
-    for (int u = 0; u < 8; u++)
-      for (int x = 0; x < 8; x++) C[u][x] = (u == 0 ? std::sqrt(0.125) : 0.5) * std::cos((2 * x + 1) * u * 3.14159265358979323846 / 16.0);
+// One 8-point forward pass after Arai / Agui / Nakajima, in place over v[0], v[s], ..., v[7 s]; after both passes coefficient (v, u)
+// carries the factor 8 * a[u] * a[v] (a[0] = 1, a[k] = sqrt(2) cos(k pi / 16)), which the quantisation multipliers absorb
+inline void fdct8(float* v, int s) {
+  const float t0 = v[0] + v[7 * s], t7 = v[0] - v[7 * s], t1 = v[s] + v[6 * s], t6 = v[s] - v[6 * s];
+  const float t2 = v[2 * s] + v[5 * s], t5 = v[2 * s] - v[5 * s], t3 = v[3 * s] + v[4 * s], t4 = v[3 * s] - v[4 * s];
+  const float e10 = t0 + t3, e13 = t0 - t3, e11 = t1 + t2, e12 = t1 - t2;
+  v[0] = e10 + e11; v[4 * s] = e10 - e11;
+  const float z1 = (e12 + e13) * 0.707106781f;
+  v[2 * s] = e13 + z1; v[6 * s] = e13 - z1;
+  const float o10 = t4 + t5, o11 = t5 + t6, o12 = t6 + t7;
+  const float z5 = (o10 - o12) * 0.382683433f, z2 = 0.541196100f * o10 + z5, z4 = 1.306562965f * o12 + z5, z3 = o11 * 0.707106781f;
+  const float z11 = t7 + z3, z13 = t7 - z3;
+  v[5 * s] = z13 + z2; v[3 * s] = z13 - z2; v[s] = z11 + z4; v[7 * s] = z11 - z4;
+}
+
+// quantiser steps -> multipliers 1 / (q * 8 a[u] a[v]) in natural order
+struct QuantMul {
+  float m[64];
+  explicit QuantMul(const uint8_t* q) {
+    const double a[8] = {1.0, 1.387039845, 1.306562965, 1.175875602, 1.0, 0.785694958, 0.541196100, 0.275899379};
+    for (int v = 0; v < 8; v++)
+      for (int u = 0; u < 8; u++) m[8 * v + u] = (float)(1.0 / ((double)q[8 * v + u] * 8.0 * a[u] * a[v]));
   }
 };
 
-void fdct8x8(const float* in, double* out) {
-  static const DctTable T;  // thread-safe initialisation (encoders run in a pool)
-  const double (*C)[8] = T.C;
-  double tmp[64];
+void encode_block(Out& o, float* px, const QuantMul& qm, int& dc_pred, const HuffEnc& dc, const HuffEnc& ac) {
+  // columns first (eight independent 1-D passes: the compiler vectorises across them), transpose, columns again (= the rows)
+  for (int c = 0; c < 8; c++) fdct8(px + c, 8);
+  float t[64];
   for (int y = 0; y < 8; y++)
-    for (int u = 0; u < 8; u++) {
-      double s = 0;
-      for (int x = 0; x < 8; x++) s += C[u][x] * in[8 * y + x];
-      tmp[8 * y + u] = s;
-    }
+    for (int x = 0; x < 8; x++) t[x * 8 + y] = px[y * 8 + x];
+  for (int c = 0; c < 8; c++) fdct8(t + c, 8);   // t[u * 8 + v] = coefficient (v, u)
+  int nat[64];
   for (int v = 0; v < 8; v++)
-    for (int u = 0; u < 8; u++) {
-      double s = 0;
-      for (int y = 0; y < 8; y++) s += C[v][y] * tmp[8 * y + u];
-      out[8 * v + u] = s;
-    }
-}
-
-void encode_block(Out& o, const float* px, const uint8_t* q, int& dc_pred, const HuffEnc& dc, const HuffEnc& ac) {
-  double f[64];
-  fdct8x8(px, f);
+    for (int u = 0; u < 8; u++) nat[8 * v + u] = (int)std::lrintf(t[u * 8 + v] * qm.m[8 * v + u]);
   int zz[64];
-  for (int i = 0; i < 64; i++) zz[i] = (int)std::lround(f[kZigzag[i]] / (double)q[kZigzag[i]]);
+  for (int i = 0; i < 64; i++) zz[i] = nat[kZigzag[i]];
   auto magnitude = [](int v, int& nbits, uint32_t& bitsv) {
-    int a = v < 0 ? -v : v;
-    nbits = 0;
-    while (a) { nbits++; a >>= 1; }
+    const unsigned a = (unsigned)(v < 0 ? -v : v);
+    nbits = a ? 32 - __builtin_clz(a) : 0;
     bitsv = (uint32_t)(v < 0 ? v - 1 : v) & ((1u << nbits) - 1u);
   };
   int nb;
@@ -155,7 +160,9 @@ int jpeg_encode_rgb(const uint8_t* rgb, uint32_t width, uint32_t height, int qua
     ql[i] = (uint8_t)(a < 1 ? 1 : (a > 255 ? 255 : a));
     qc[i] = (uint8_t)(b < 1 ? 1 : (b > 255 ? 255 : b));
   }
+  const QuantMul qml(ql), qmc(qc);
   static const HuffEnc dcl(kDcLumaBits, kDcVals), dcc(kDcChromaBits, kDcVals), acl(kAcLumaBits, kAcLumaVals), acc(kAcChromaBits, kAcChromaVals);
+  out.reserve(out.size() + (size_t)width * height / 2 + 1024);
   Out o(out);
   o.word(0xFFD8);
   o.word(0xFFE0); o.word(16); o.byte('J'); o.byte('F'); o.byte('I'); o.byte('F'); o.byte(0); o.word(0x0101); o.byte(0); o.word(1); o.word(1); o.byte(0); o.byte(0);
@@ -182,34 +189,40 @@ int jpeg_encode_rgb(const uint8_t* rgb, uint32_t width, uint32_t height, int qua
   std::vector<float> Y((size_t)mcu * mcu), Cb((size_t)mcu * mcu), Cr((size_t)mcu * mcu);
   for (uint32_t by = 0; by < my; by++)
     for (uint32_t bx = 0; bx < mx; bx++) {
-      for (int y = 0; y < mcu; y++)
+      const bool inside = (bx + 1) * mcu <= width && (by + 1) * mcu <= height;
+      for (int y = 0; y < mcu; y++) {
+        const uint32_t sy = std::min(by * mcu + y, height - 1);  // edge replication
+        const uint8_t* row = rgb + 3 * ((size_t)sy * width);
+        float* yo = &Y[(size_t)y * mcu];
+        float* bo = &Cb[(size_t)y * mcu];
+        float* ro = &Cr[(size_t)y * mcu];
         for (int x = 0; x < mcu; x++) {
-          const uint32_t sx = std::min(bx * mcu + x, width - 1), sy = std::min(by * mcu + y, height - 1);  // edge replication
-          const uint8_t* p = rgb + 3 * ((size_t)sy * width + sx);
+          const uint8_t* p = row + 3 * (size_t)(inside ? bx * mcu + x : std::min(bx * mcu + x, width - 1));
           const float r = p[0], g = p[1], b = p[2];
-          Y[(size_t)y * mcu + x] = 0.299f * r + 0.587f * g + 0.114f * b - 128.0f;
-          Cb[(size_t)y * mcu + x] = -0.168736f * r - 0.331264f * g + 0.5f * b;
-          Cr[(size_t)y * mcu + x] = 0.5f * r - 0.418688f * g - 0.081312f * b;
+          yo[x] = 0.299f * r + 0.587f * g + 0.114f * b - 128.0f;
+          bo[x] = -0.168736f * r - 0.331264f * g + 0.5f * b;
+          ro[x] = 0.5f * r - 0.418688f * g - 0.081312f * b;
         }
+      }
       float blk[64];
       if (subsample) {
         for (int q = 0; q < 4; q++) {
           const int oy = (q >> 1) * 8, ox = (q & 1) * 8;
           for (int y = 0; y < 8; y++)
             for (int x = 0; x < 8; x++) blk[8 * y + x] = Y[(size_t)(oy + y) * 16 + ox + x];
-          encode_block(o, blk, ql, pred[0], dcl, acl);
+          encode_block(o, blk, qml, pred[0], dcl, acl);
         }
         for (int c = 0; c < 2; c++) {
           const std::vector<float>& S = c ? Cr : Cb;
           for (int y = 0; y < 8; y++)
             for (int x = 0; x < 8; x++)
               blk[8 * y + x] = 0.25f * (S[(size_t)(2 * y) * 16 + 2 * x] + S[(size_t)(2 * y) * 16 + 2 * x + 1] + S[(size_t)(2 * y + 1) * 16 + 2 * x] + S[(size_t)(2 * y + 1) * 16 + 2 * x + 1]);
-          encode_block(o, blk, qc, pred[1 + c], dcc, acc);
+          encode_block(o, blk, qmc, pred[1 + c], dcc, acc);
         }
       } else {
-        encode_block(o, Y.data(), ql, pred[0], dcl, acl);
-        encode_block(o, Cb.data(), qc, pred[1], dcc, acc);
-        encode_block(o, Cr.data(), qc, pred[2], dcc, acc);
+        encode_block(o, Y.data(), qml, pred[0], dcl, acl);
+        encode_block(o, Cb.data(), qmc, pred[1], dcc, acc);
+        encode_block(o, Cr.data(), qmc, pred[2], dcc, acc);
       }
     }
   o.flush();
