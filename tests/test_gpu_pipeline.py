@@ -183,12 +183,15 @@ def test_jpeg_gpu_reconstruction_equals_the_host_decoder():
         blobs.append(buf.getvalue())
         blobs.append(calibrate.jpeg_encode(img, 92, True))
         blobs.append(calibrate.jpeg_encode(img, 75, False))
+        buf = io.BytesIO()
+        Image.fromarray(img).save(buf, format="JPEG", quality=85, subsampling=2, restart_marker_blocks=3)   # DRI / RSTn
+        blobs.append(buf.getvalue())
         for b in blobs:
             host = calibrate.jpeg_decode(b, W, H)
             gpu = calibrate.jpeg_decode(b, W, H, device=0)
             assert np.array_equal(host, gpu), "%dx%d case %d: %d bytes differ" % (W, H, cases, (host != gpu).sum())
             cases += 1
-    assert cases == 24
+    assert cases == 28
     W, H = 1296, 968                                   # ScanNet's colour size, 4:2:0 and 4:2:2
     img = _smooth_image(W, H, 3)
     img = np.clip(img.astype(np.int32) + np.random.default_rng(0).integers(-9, 10, img.shape), 0, 255).astype(np.uint8)   # busy blocks too

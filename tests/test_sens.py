@@ -216,3 +216,25 @@ def test_jpeg_decode_against_pil_and_reference(oracle, tmp_path, subsampling):
         # stb's h2v1 resampler treats the last two columns differently from libjpeg(-turbo) (which we match
         # exactly above): allow a handful of edge pixels, keep the bulk within the T.81 accuracy band
         assert (d2.max(-1) > 4).mean() < 0.002 and d2.mean() < 0.5
+
+
+def test_jpeg_restart_intervals_against_pil(tmp_path):
+    """DRI / RSTn (T.81 B.2.4.4, E.2.4): the predictors restart, the bit reader realigns on the marker -- with and without chroma
+    subsampling, an interval that does not divide the MCU count."""
+    PIL = pytest.importorskip("PIL")
+    from PIL import Image
+    from scannet_amd import calibrate
+    W, H = 136, 104
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = np.stack([(xx * 255 // W), (yy * 255 // H), ((xx + yy) * 3 % 256)], -1).astype(np.uint8)
+    img[30:60, 40:90] = (200, 30, 60)
+    for sub, blocks in ((0, 3), (2, 5), (1, 1)):
+        buf = io.BytesIO()
+        Image.fromarray(img).save(buf, format="JPEG", quality=90, subsampling=sub, restart_marker_blocks=blocks)
+        blob = buf.getvalue()
+        assert b"\xff\xdd" in blob and any(bytes([0xFF, 0xD0 + k]) in blob for k in range(8))
+        ours = calibrate.jpeg_decode(blob, W, H).astype(np.int32)
+        pil = np.asarray(Image.open(io.BytesIO(blob)).convert("RGB")).astype(np.int32)
+        diff = np.abs(ours - pil)
+        assert diff.max() <= 4 and diff.mean() < 0.5, (sub, blocks, diff.max())
+
