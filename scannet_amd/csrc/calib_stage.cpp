@@ -17,15 +17,22 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "common.h"
+#include "jpeg_idct.h"
 #include "sens.h"
 
 int jpeg_encode_rgb(const uint8_t* rgb, uint32_t width, uint32_t height, int quality, int subsample, std::vector<uint8_t>& out);  // jpeg_enc.cpp
+int jpeg_decode_coef(const uint8_t* data, uint64_t n, uint32_t expect_w, uint32_t expect_h, uint8_t* payload, uint64_t payload_capacity);  // jpeg.cpp
+size_t calibrator_payload_capacity(const sf_calibrator* c);                                                                            // calibrate.hip
+int calibrator_run_payload(sf_calibrator* c, int n, const uint8_t* const* rgb_in, const uint8_t* const* payload, const uint32_t* payload_bytes,
+                           uint8_t* const* rgb_out, const uint16_t* const* depth_in, uint16_t* const* depth_out);                      // calibrate.hip
+namespace sf { int usable_cpus(); }
 
 namespace {
 bool file_exists(const char* p) { struct stat st; return ::stat(p, &st) == 0; }
@@ -95,8 +102,16 @@ SF_API int sf_calibrate_sens(const char* in_sens, const char* out_sens, const ch
   const uint64_t nframes = in->frames.size();
   const size_t npx = (size_t)hi.depth_width * hi.depth_height, cbytes = (size_t)hi.color_width * hi.color_height * 3;
   const int B = sf_calibrator_max_batch();
-  int nthreads = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+  int nthreads = threads > 0 ? threads : sf::usable_cpus();   // the cgroup quota, not the logical CPUs the container shows
   nthreads = std::max(1, std::min(nthreads, 64));
+  // JPEG colour: the threads only entropy-decode; the coefficients go to the GPU, which reconstructs the picture into the stage's input
+  // buffer (jpeg_gpu.hip, the bytes of the host decoder).  A frame whose coefficients do not fit, or whose layout the GPU path does not
+  // take, is decoded on the host.
+  const bool jpeg_in = hi.color_compression == 2 && std::getenv("SF_JPEG_HOST") == nullptr;
+  const size_t pay_cap = jpeg_in ? calibrator_payload_capacity(cal) : 0;
+  std::vector<std::vector<uint32_t>> pay((size_t)B);
+  std::vector<uint32_t> pay_bytes((size_t)B, 0);
+  if (jpeg_in) for (auto& v : pay) v.resize(pay_cap / 4);
   std::vector<uint16_t> d_in((size_t)B * npx), d_out((size_t)B * npx);
   std::vector<uint8_t> c_in((size_t)B * cbytes), c_out((size_t)B * cbytes);
   std::vector<std::vector<uint8_t>> jpg((size_t)B);
@@ -117,7 +132,14 @@ SF_API int sf_calibrate_sens(const char* in_sens, const char* out_sens, const ch
     for (int k = 0; k < cnt; k++) rgb = rgb && in->frames[f0 + k].color_bytes != 0;
     parallel(cnt, [&](int k) {
       rcs[k] = sens_decode_depth(in, f0 + k, &d_in[(size_t)k * npx]);
-      if (rcs[k] == SF_OK && rgb) rcs[k] = sf_sens_decode_color(in, f0 + k, &c_in[(size_t)k * cbytes]);
+      pay_bytes[k] = 0;
+      if (rcs[k] == SF_OK && rgb && jpeg_in) {
+        const SensFrame& fr = in->frames[f0 + k];
+        uint8_t* pp = reinterpret_cast<uint8_t*>(pay[k].data());
+        if (jpeg_decode_coef(fr.color, fr.color_bytes, hi.color_width, hi.color_height, pp, pay_cap) == SF_OK)
+          pay_bytes[k] = (uint32_t)sf_jpeg_payload_bytes(*reinterpret_cast<const SfJpegLayout*>(pp));
+      }
+      if (rcs[k] == SF_OK && rgb && pay_bytes[k] == 0) rcs[k] = sf_sens_decode_color(in, f0 + k, &c_in[(size_t)k * cbytes]);
       if (rcs[k] != SF_OK) errs[k] = sf_last_error();
     });
     for (int k = 0; k < cnt; k++)
@@ -127,7 +149,11 @@ SF_API int sf_calibrate_sens(const char* in_sens, const char* out_sens, const ch
       di[k] = &d_in[(size_t)k * npx]; dou[k] = &d_out[(size_t)k * npx];
       ri[k] = &c_in[(size_t)k * cbytes]; ro[k] = &c_out[(size_t)k * cbytes];
     }
-    if ((rc = sf_calibrator_run(cal, cnt, rgb ? ri : nullptr, rgb ? ro : nullptr, di, dou)) != SF_OK) return done(rc);
+    if (rgb && jpeg_in) {
+      const uint8_t* pl[16];
+      for (int k = 0; k < cnt; k++) pl[k] = pay_bytes[k] ? reinterpret_cast<const uint8_t*>(pay[k].data()) : nullptr;
+      if ((rc = calibrator_run_payload(cal, cnt, ri, pl, pay_bytes.data(), ro, di, dou)) != SF_OK) return done(rc);
+    } else if ((rc = sf_calibrator_run(cal, cnt, rgb ? ri : nullptr, rgb ? ro : nullptr, di, dou)) != SF_OK) return done(rc);
     if (rgb && hi.color_compression == 2) {
       parallel(cnt, [&](int k) {
         jpg[k].clear();

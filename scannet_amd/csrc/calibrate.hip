@@ -22,6 +22,7 @@
 // Built with -ffp-contract=off; fp32 division is IEEE.  mLib's math::round is taken as floor(x + 0.5).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <fstream>
@@ -30,6 +31,7 @@
 #include <vector>
 
 #include "common.h"
+#include "jpeg_idct.h"
 
 namespace {
 
@@ -294,6 +296,8 @@ struct sf_calibrator {
   float4* vert = nullptr;    // CALIB_MAX_BATCH x W*H mesh vertices {target x, target y, projected z, valid}
   // staging for the host-pointer entry point
   uint8_t *d_rgb_in = nullptr, *d_rgb_out = nullptr;
+  uint8_t *d_pay = nullptr, *d_planes = nullptr;   // JPEG coefficient payloads and plane scratch (allocated on first use)
+  size_t pay_cap = 0, planes_cap = 0;
   uint16_t *d_depth_in = nullptr, *d_depth_out = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
 };
@@ -375,7 +379,7 @@ SF_API void sf_calibrator_destroy(sf_calibrator* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (void* p : {(void*)c->lut, (void*)c->und, (void*)c->zbuf, (void*)c->vert, (void*)c->d_rgb_in, (void*)c->d_rgb_out, (void*)c->d_depth_in, (void*)c->d_depth_out})
+  for (void* p : {(void*)c->lut, (void*)c->und, (void*)c->zbuf, (void*)c->vert, (void*)c->d_rgb_in, (void*)c->d_rgb_out, (void*)c->d_depth_in, (void*)c->d_depth_out, (void*)c->d_pay, (void*)c->d_planes})
     if (p) (void)hipFree(p);
   if (c->e0) (void)hipEventDestroy(c->e0);
   if (c->e1) (void)hipEventDestroy(c->e1);
@@ -513,3 +517,71 @@ SF_API int sf_calibrator_run(sf_calibrator* c, int n, const uint8_t* const* rgb_
   SF_HIP_CHECK(hipStreamSynchronize(c->stream));
   return SF_OK;
 }
+
+int jpeg_gpu_reconstruct(hipStream_t stream, int n, const uint8_t* const* d_payload, uint8_t* const* d_rgb, uint8_t* const* d_planes, uint32_t max_blocks,
+                         uint64_t max_pixels);  // jpeg_gpu.hip
+
+// bytes a frame's coefficient payload may take in sf_calibrator_run_payload (header + block table + as many entries as the pixels have bytes)
+size_t calibrator_payload_capacity(const sf_calibrator* c) {
+  const size_t padded = (size_t)((c->k.cw + 15) & ~15) * (size_t)((c->k.ch + 15) & ~15);
+  return (sizeof(SfJpegLayout) + padded * 3 / 64 * 4 + (size_t)c->k.cw * c->k.ch * 3 + 255) & ~(size_t)255;
+}
+
+// sf_calibrator_run where a colour frame may arrive as an entropy-decoded JPEG payload (jpeg.cpp: jpeg_decode_coef) instead of pixels:
+// payload[j] != NULL -> its coefficients are uploaded and reconstructed on the GPU straight into the stage's input buffer, the same
+// bytes the host decoder would have produced; payload[j] == NULL -> rgb_in[j] as in sf_calibrator_run.  Internal to the calibrate stage.
+int calibrator_run_payload(sf_calibrator* c, int n, const uint8_t* const* rgb_in, const uint8_t* const* payload, const uint32_t* payload_bytes,
+                           uint8_t* const* rgb_out, const uint16_t* const* depth_in, uint16_t* const* depth_out) {
+  if (!c || !rgb_in || !payload || !payload_bytes || !rgb_out || !depth_in || !depth_out) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  if (n < 1 || n > CALIB_MAX_BATCH) return sf::fail(SF_ERR_INVALID_ARG, "batch of %d frames (limit %d)", n, CALIB_MAX_BATCH);
+  SF_HIP_CHECK(hipSetDevice(c->device));
+  const CalibK& k = c->k;
+  const size_t nb = (size_t)k.w * k.h * 2, cb = (size_t)k.cw * k.ch * 3;
+  if (!c->d_pay) {
+    c->pay_cap = calibrator_payload_capacity(c);
+    c->planes_cap = ((size_t)((k.cw + 15) & ~15) * (size_t)((k.ch + 15) & ~15) * 3 + 255) & ~(size_t)255;
+    SF_HIP_CHECK(hipMalloc((void**)&c->d_pay, c->pay_cap * CALIB_MAX_BATCH));
+    SF_HIP_CHECK(hipMalloc((void**)&c->d_planes, c->planes_cap * CALIB_MAX_BATCH));
+  }
+  const void* di[CALIB_MAX_BATCH];
+  void* dout[CALIB_MAX_BATCH];
+  const void* ri[CALIB_MAX_BATCH];
+  void* ro[CALIB_MAX_BATCH];
+  const uint8_t* pp[CALIB_MAX_BATCH];
+  uint8_t* pr[CALIB_MAX_BATCH];
+  uint8_t* pl[CALIB_MAX_BATCH];
+  int np = 0;
+  uint32_t max_blocks = 0;
+  for (int j = 0; j < n; j++) {
+    if (!depth_in[j] || !depth_out[j] || !rgb_out[j] || (!payload[j] && !rgb_in[j])) return sf::fail(SF_ERR_INVALID_ARG, "NULL frame pointer in batch");
+    di[j] = (uint8_t*)c->d_depth_in + j * nb;
+    dout[j] = (uint8_t*)c->d_depth_out + j * nb;
+    ri[j] = c->d_rgb_in + j * cb;
+    ro[j] = c->d_rgb_out + j * cb;
+    SF_HIP_CHECK(hipMemcpyAsync((void*)di[j], depth_in[j], nb, hipMemcpyHostToDevice, c->stream));
+    if (payload[j]) {
+      const SfJpegLayout* L = reinterpret_cast<const SfJpegLayout*>(payload[j]);
+      if (payload_bytes[j] > c->pay_cap || L->width != k.cw || L->height != k.ch) return sf::fail(SF_ERR_INVALID_ARG, "frame %d: coefficient payload does not fit this calibrator", j);
+      uint8_t* d = c->d_pay + (size_t)j * c->pay_cap;
+      SF_HIP_CHECK(hipMemcpyAsync(d, payload[j], payload_bytes[j], hipMemcpyHostToDevice, c->stream));
+      pp[np] = d; pr[np] = (uint8_t*)ri[j]; pl[np] = c->d_planes + (size_t)j * c->planes_cap;
+      np++;
+      max_blocks = std::max(max_blocks, L->nblocks);
+    } else {
+      SF_HIP_CHECK(hipMemcpyAsync((void*)ri[j], rgb_in[j], cb, hipMemcpyHostToDevice, c->stream));
+    }
+  }
+  if (np > 0) {
+    const int rcj = jpeg_gpu_reconstruct(c->stream, np, pp, pr, pl, max_blocks, (uint64_t)k.cw * k.ch);
+    if (rcj != SF_OK) return rcj;
+  }
+  const int rc = sf_calibrator_run_device(c, n, ri, ro, di, dout, nullptr);
+  if (rc != SF_OK) return rc;
+  for (int j = 0; j < n; j++) {
+    SF_HIP_CHECK(hipMemcpyAsync(depth_out[j], dout[j], nb, hipMemcpyDeviceToHost, c->stream));
+    SF_HIP_CHECK(hipMemcpyAsync(rgb_out[j], ro[j], cb, hipMemcpyDeviceToHost, c->stream));
+  }
+  SF_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return SF_OK;
+}
+

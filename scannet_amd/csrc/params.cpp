@@ -12,7 +12,10 @@
 #include <fstream>
 #include <map>
 #include <sstream>
+#include <algorithm>
+#include <cstdio>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -150,3 +153,30 @@ SF_API int sf_params_load_file(const char* path, sf_params* p) {
     return sf::fail(SF_ERR_FORMAT, "%s: non-positive voxel size / hash size", path);
   return SF_OK;
 }
+
+namespace {
+// CPUs this process may actually use: the cgroup CPU quota when there is one (a container that shows 256 logical CPUs may be allowed
+// the time of 16: threads beyond that only add contention), else the hardware concurrency
+int usable_cpus_impl() {
+  int hw = std::max(1, (int)std::thread::hardware_concurrency());
+  if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2: "<quota> <period>" or "max <period>"
+    char q[64] = {0};
+    long long period = 0;
+    if (std::fscanf(f, "%63s %lld", q, &period) == 2 && period > 0 && std::strcmp(q, "max") != 0) {
+      const long long quota = std::atoll(q);
+      if (quota > 0) hw = std::min(hw, (int)std::max<long long>(1, (quota + period - 1) / period));
+    }
+    std::fclose(f);
+  } else {
+    long long quota = -1, period = 0;
+    if (FILE* a = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (std::fscanf(a, "%lld", &quota) != 1) quota = -1; std::fclose(a); }
+    if (FILE* b = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(b, "%lld", &period) != 1) period = 0; std::fclose(b); }
+    if (quota > 0 && period > 0) hw = std::min(hw, (int)std::max<long long>(1, (quota + period - 1) / period));
+  }
+  return hw;
+}
+}  // namespace
+
+namespace sf {
+int usable_cpus() { return usable_cpus_impl(); }
+}  // namespace sf

@@ -27,28 +27,9 @@ int jpeg_decode_coef(const uint8_t* data, uint64_t n, uint32_t expect_w, uint32_
 int jpeg_gpu_reconstruct(hipStream_t stream, int n, const uint8_t* const* d_payload, uint8_t* const* d_rgb, uint8_t* const* d_planes, uint32_t max_blocks,
                          uint64_t max_pixels);  // jpeg_gpu.hip
 
-namespace {
+namespace sf { int usable_cpus(); }   // params.cpp
 
-// CPUs this process may actually use: the cgroup CPU quota when there is one (a container that shows 256 logical CPUs may be allowed
-// the time of 16: threads beyond that only add contention), else the hardware concurrency
-int usable_cpus() {
-  int hw = std::max(1, (int)std::thread::hardware_concurrency());
-  if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2: "<quota> <period>" or "max <period>"
-    char q[64] = {0};
-    long long period = 0;
-    if (std::fscanf(f, "%63s %lld", q, &period) == 2 && period > 0 && std::strcmp(q, "max") != 0) {
-      const long long quota = std::atoll(q);
-      if (quota > 0) hw = std::min(hw, (int)std::max<long long>(1, (quota + period - 1) / period));
-    }
-    std::fclose(f);
-  } else {
-    long long quota = -1, period = 0;
-    if (FILE* a = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (std::fscanf(a, "%lld", &quota) != 1) quota = -1; std::fclose(a); }
-    if (FILE* b = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(b, "%lld", &period) != 1) period = 0; std::fclose(b); }
-    if (quota > 0 && period > 0) hw = std::min(hw, (int)std::max<long long>(1, (quota + period - 1) / period));
-  }
-  return hw;
-}
+namespace {
 
 // One ring slot = one batch of B frames: contiguous pinned host buffers, contiguous device buffers, two events.
 struct BatchSlot {
@@ -94,7 +75,7 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   // default pool size: inflating a depth frame takes ~0.13 ms, so 32 threads outrun the GPU (measured: 16 threads 28 k frames/s,
   // 64 threads 26 k); baseline-JPEG colour costs milliseconds per frame and takes up to 64 (128 measured slower: 5.0 k vs 8.1 k frames/s)
   const bool jpeg_colour = use_rgb && s->info.color_compression == 2;
-  const int hw = usable_cpus();
+  const int hw = sf::usable_cpus();
   int nthreads = decode_threads > 0 ? decode_threads : std::min(hw, jpeg_colour ? 64 : 32);
   if (nthreads < 1) nthreads = 1;
   if (nthreads > 256) nthreads = 256;
