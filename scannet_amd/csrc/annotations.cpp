@@ -302,7 +302,7 @@ SF_API int sf_annotation_propagate(const float* src_xyz, uint64_t src_vertices, 
       else if (all_same) { dst_instance[i] = src_instance[v_first]; dst_label[i] = src_label[v_first]; }
     }
   };
-  unsigned nt = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+  unsigned nt = std::max(1u, std::min(64u, (unsigned)sf::usable_cpus()));
   if (dst_vertices < 4096) nt = 1;
   std::vector<std::thread> pool;
   const uint64_t chunk = (dst_vertices + nt - 1) / nt;

@@ -32,7 +32,6 @@ int jpeg_decode_coef(const uint8_t* data, uint64_t n, uint32_t expect_w, uint32_
 size_t calibrator_payload_capacity(const sf_calibrator* c);                                                                            // calibrate.hip
 int calibrator_run_payload(sf_calibrator* c, int n, const uint8_t* const* rgb_in, const uint8_t* const* payload, const uint32_t* payload_bytes,
                            uint8_t* const* rgb_out, const uint16_t* const* depth_in, uint16_t* const* depth_out);                      // calibrate.hip
-namespace sf { int usable_cpus(); }
 
 namespace {
 bool file_exists(const char* p) { struct stat st; return ::stat(p, &st) == 0; }

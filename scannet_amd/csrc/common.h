@@ -10,6 +10,9 @@ namespace sf {
 
 std::string& last_error_ref();
 
+// CPUs this process may really use: hardware concurrency capped by the cgroup CPU quota (params.cpp)
+int usable_cpus();
+
 inline int fail(int code, const char* fmt, ...) {
   char buf[1024];
   va_list ap;

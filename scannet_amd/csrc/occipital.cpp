@@ -370,7 +370,7 @@ SF_API int sf_capture_convert(const sf_capture* c, const char* out_sens, sf_capt
   uint64_t n = std::min(m.num_depth_frames, m.num_color_frames ? m.num_color_frames : m.num_depth_frames);  // main.cpp:62-63
   n = std::min<uint64_t>(n, c->frame_off.size());
   const uint64_t npx = (uint64_t)m.depth_width * m.depth_height;
-  int nthreads = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+  int nthreads = threads > 0 ? threads : sf::usable_cpus();
   nthreads = std::max(1, std::min(nthreads, 64));
   // decode in parallel batches, append in order
   const uint64_t batch = (uint64_t)nthreads * 4;

@@ -27,8 +27,6 @@ int jpeg_decode_coef(const uint8_t* data, uint64_t n, uint32_t expect_w, uint32_
 int jpeg_gpu_reconstruct(hipStream_t stream, int n, const uint8_t* const* d_payload, uint8_t* const* d_rgb, uint8_t* const* d_planes, uint32_t max_blocks,
                          uint64_t max_pixels);  // jpeg_gpu.hip
 
-namespace sf { int usable_cpus(); }   // params.cpp
-
 namespace {
 
 // One ring slot = one batch of B frames: contiguous pinned host buffers, contiguous device buffers, two events.

@@ -443,7 +443,7 @@ struct Simplifier {
     // computed by all host threads over contiguous vertex ranges and concatenated in vertex order: same heap content as the
     // sequential loop
     {
-      int nt = (int)std::thread::hardware_concurrency();
+      int nt = sf::usable_cpus();   // the cgroup quota, not the logical CPUs the container shows
       nt = std::max(1, std::min(nt, 64));
       if (n_v < 20000) nt = 1;
       std::vector<std::vector<HeapElem>> part((size_t)nt);
