@@ -23,11 +23,11 @@ struct HuffDC_AC {
   uint8_t vals[256];
   int32_t mincode[17], maxcode[18], valptr[17];
   uint16_t look[512];  // (len << 8) | symbol, 0 = slow path
-  // AC tables: for a 10-bit window that holds a whole short code AND the magnitude bits behind it,
+  // AC tables: for a 12-bit window that holds a whole short code AND the magnitude bits behind it,
   // (value << 8) | (run << 4) | total bits; 0 = decode symbol and magnitude separately
-  int16_t fast_ac[1024];
+  int16_t fast_ac[4096];
   bool present = false;
-  void build() {
+  void build(bool with_fast_ac) {
     int code = 0, k = 0;
     for (int l = 1; l <= 16; l++) {
       valptr[l] = k;
@@ -48,13 +48,13 @@ struct HuffDC_AC {
       }
       code <<= 1;
     }
-    for (int w = 0; w < 1024; w++) {
+    for (int w = 0; w < 4096 && with_fast_ac; w++) {
       fast_ac[w] = 0;
-      const uint16_t e = look[w >> 1];
+      const uint16_t e = look[w >> 3];
       if (!e) continue;
       const int len = e >> 8, run = (e >> 4) & 15, size = e & 15;
-      if (size == 0 || len + size > 10) continue;
-      int v = (w >> (10 - len - size)) & ((1 << size) - 1);
+      if (size == 0 || len + size > 12) continue;
+      int v = (w >> (12 - len - size)) & ((1 << size) - 1);
       if (v < (1 << (size - 1))) v += 1 - (1 << size);   // T.81 F.2.2.1 EXTEND
       if (v >= -128 && v <= 127) fast_ac[w] = (int16_t)(v * 256 + run * 16 + len + size);
     }
@@ -207,7 +207,7 @@ static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t e
         if (total > 256 || q + total > seg_end) return sf::fail(SF_ERR_FORMAT, "jpeg: bad DHT counts");
         std::memcpy(h.vals, data + q, (size_t)total);
         q += total;
-        h.build();
+        h.build(tc != 0);
       }
     } else if (m == 0xC0 || m == 0xC1) {
       if (len < 8 || data[seg] != 8) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: only 8-bit precision is supported");
@@ -303,7 +303,7 @@ static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t e
               const HuffDC_AC& ac = hac[c.ta];
               for (int k = 1; k < 64;) {
                 if (bs.cnt < 32) bs.fill();
-                const int fa = ac.fast_ac[bs.peek(10)];
+                const int fa = ac.fast_ac[bs.peek(12)];
                 if (fa) {
                   k += (fa >> 4) & 15;
                   if (k > 63) return sf::fail(SF_ERR_FORMAT, "jpeg: AC run past the end of the block");
@@ -337,7 +337,7 @@ static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t e
             const HuffDC_AC& ac = hac[c.ta];
             for (int k = 1; k < 64;) {
               if (bs.cnt < 32) bs.fill();
-              const int fa = ac.fast_ac[bs.peek(10)];
+              const int fa = ac.fast_ac[bs.peek(12)];
               if (fa) {   // run, size and magnitude from one look-up
                 k += (fa >> 4) & 15;
                 if (k > 63) return sf::fail(SF_ERR_FORMAT, "jpeg: AC run past the end of the block");
