@@ -187,8 +187,8 @@ struct Heap4 {
 // The queue of a scan-sized mesh holds tens of millions of entries, and a heap that large misses the cache on every level of every
 // pop -- microseconds per collapse.  Only the entries that can be popped soon need a heap: `hot` holds everything with priority <=
 // threshold (a few MiB, cache-resident), `cold` is an unsorted append-only array of the rest.  When `hot` runs dry the stale entries of
-// `cold` are dropped, a new threshold is taken from a sample of its priorities so that about HOT_TARGET entries qualify, and those move
-// over.  Every entry <= threshold is in the heap at all times, so the pop order is exactly that of one big heap under elem_less.
+// `cold` are dropped, a new threshold is taken from a sample of its priorities so that HOT_TARGET entries or a sixth of `cold` qualify,
+// and those move over.  Every entry <= threshold is in the heap at all times, so the pop order is exactly that of one big heap under elem_less.
 struct LadderQueue {
   static constexpr size_t HOT_TARGET = 1u << 19;
   Heap4 hot;
@@ -218,11 +218,14 @@ struct LadderQueue {
       for (size_t i = 0; i < cold.size(); i++) if (keep(cold[i])) cold[w++] = cold[i];
       cold.resize(w);
       if (cold.empty()) return false;
-      if (cold.size() <= 2 * HOT_TARGET) threshold = INFINITY;
-      else {   // the HOT_TARGET / size quantile of an evenly spaced sample of 4096 priorities
+      // how much moves over: at least HOT_TARGET, and a sixth of what is left -- every refill reads all of `cold`, so the number of
+      // refills has to stay logarithmic in its size (a fixed HOT_TARGET meant ~85 passes over 6 M entries on a 2 M-face mesh)
+      const size_t want = std::max(HOT_TARGET, cold.size() / 6);
+      if (cold.size() <= 2 * want) threshold = INFINITY;
+      else {   // the want / size quantile of an evenly spaced sample of 4096 priorities
         std::vector<float> sample(4096);
         for (size_t k = 0; k < sample.size(); k++) sample[k] = cold[(size_t)((double)k * (double)cold.size() / (double)sample.size())].pri;
-        const size_t q = std::min(sample.size() - 1, (size_t)((double)sample.size() * (double)HOT_TARGET / (double)cold.size()));
+        const size_t q = std::min(sample.size() - 1, (size_t)((double)sample.size() * (double)want / (double)cold.size()));
         std::nth_element(sample.begin(), sample.begin() + (long)q, sample.end());
         threshold = sample[q];
       }
