@@ -254,6 +254,7 @@ static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t e
   const bool to_coef = dst == nullptr;
   if (to_coef) {
     if (hmax > 2 || vmax > 2) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: sampling factors above 2 take the host decoder");
+    if (mcux * mcu_w > 65535 || mcuy * mcu_h > 65535) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: picture too large for the coefficient layout");
     if (payload_capacity < sizeof(SfJpegLayout)) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: payload too small");
     std::memset(L, 0, sizeof(*L));
     L->width = (uint16_t)width; L->height = (uint16_t)height;
