@@ -132,6 +132,39 @@ inline int decode_huff(BitSrc& bs, const HuffDC_AC& h) {
   return h.vals[h.valptr[l] + code - h.mincode[l]];
 }
 
+// One AC symbol with a single refill check: a code (<= 16 bits) and its magnitude bits (<= 11) always fit the 32 bits that are valid
+// after fill().  Returns 0 = a coefficient (`run` zeros, then `value`), 1 = end of block, 2 = sixteen zeros, -1 = invalid code.
+inline int decode_ac(BitSrc& bs, const HuffDC_AC& h, int& run, int& value) {
+  if (bs.cnt < 32) bs.fill();
+  const uint32_t w = (uint32_t)(bs.buf >> 32);
+  const int fa = h.fast_ac[w >> 20];
+  if (fa) {   // run, size and magnitude from one look-up
+    run = (fa >> 4) & 15;
+    value = fa >> 8;
+    bs.drop(fa & 15);
+    return 0;
+  }
+  int len, rs;
+  const uint16_t e = h.look[w >> 23];
+  if (e) { len = e >> 8; rs = e & 0xFF; }
+  else {
+    len = 9;
+    int code = (int)(w >> 23);
+    while (len < 17 && code > h.maxcode[len]) {
+      len++;
+      code = (int)(w >> (32 - len));
+    }
+    if (len > 16) return -1;
+    rs = h.vals[h.valptr[len] + code - h.mincode[len]];
+  }
+  const int sz = rs & 15;
+  run = rs >> 4;
+  if (sz == 0) { bs.drop(len); return run == 15 ? 2 : 1; }
+  value = extend((int)((w << len) >> (32 - sz)), sz);
+  bs.drop(len + sz);
+  return 0;
+}
+
 const uint8_t ZIGZAG[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
                             35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
@@ -303,27 +336,16 @@ static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t e
               if (c.pred != 0) entries[nent++] = (uint32_t)(uint16_t)(int16_t)c.pred;
               const HuffDC_AC& ac = hac[c.ta];
               for (int k = 1; k < 64;) {
-                if (bs.cnt < 32) bs.fill();
-                const int fa = ac.fast_ac[bs.peek(12)];
-                if (fa) {
-                  k += (fa >> 4) & 15;
+                int run, value;
+                const int what = decode_ac(bs, ac, run, value);
+                if (what == 0) {
+                  k += run;
                   if (k > 63) return sf::fail(SF_ERR_FORMAT, "jpeg: AC run past the end of the block");
-                  bs.drop(fa & 15);
-                  entries[nent++] = ((uint32_t)ZIGZAG[k] << 16) | (uint32_t)(uint16_t)(int16_t)(fa >> 8);
+                  entries[nent++] = ((uint32_t)ZIGZAG[k] << 16) | (uint32_t)(uint16_t)(int16_t)value;
                   k++;
-                  continue;
-                }
-                const int rs = decode_huff(bs, ac);
-                if (rs < 0) return sf::fail(SF_ERR_FORMAT, "jpeg: bad AC code");
-                const int r = rs >> 4, sz = rs & 15;
-                if (sz == 0) {
-                  if (r == 15) { k += 16; continue; }
-                  break;
-                }
-                k += r;
-                if (k > 63) return sf::fail(SF_ERR_FORMAT, "jpeg: AC run past the end of the block");
-                entries[nent++] = ((uint32_t)ZIGZAG[k] << 16) | (uint32_t)(uint16_t)(int16_t)extend(bs.get(sz), sz);
-                k++;
+                } else if (what == 2) k += 16;
+                else if (what == 1) break;
+                else return sf::fail(SF_ERR_FORMAT, "jpeg: bad AC code");
               }
               table[block] = ((uint32_t)first_entry << 7) | (uint32_t)(nent - first_entry);
               continue;
@@ -337,31 +359,18 @@ static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t e
             bool dc_only = true;
             const HuffDC_AC& ac = hac[c.ta];
             for (int k = 1; k < 64;) {
-              if (bs.cnt < 32) bs.fill();
-              const int fa = ac.fast_ac[bs.peek(12)];
-              if (fa) {   // run, size and magnitude from one look-up
-                k += (fa >> 4) & 15;
+              int run, value;
+              const int what = decode_ac(bs, ac, run, value);
+              if (what == 0) {
+                k += run;
                 if (k > 63) return sf::fail(SF_ERR_FORMAT, "jpeg: AC run past the end of the block");
-                bs.drop(fa & 15);
                 const int z = ZIGZAG[k];
-                blk[z] = (float)(fa >> 8) * q[z];
+                blk[z] = (float)value * q[z];
                 dc_only = false;
                 k++;
-                continue;
-              }
-              const int rs = decode_huff(bs, ac);
-              if (rs < 0) return sf::fail(SF_ERR_FORMAT, "jpeg: bad AC code");
-              const int r = rs >> 4, s = rs & 15;
-              if (s == 0) {
-                if (r == 15) { k += 16; continue; }
-                break;
-              }
-              k += r;
-              if (k > 63) return sf::fail(SF_ERR_FORMAT, "jpeg: AC run past the end of the block");
-              const int z = ZIGZAG[k];
-              blk[z] = (float)extend(bs.get(s), s) * q[z];
-              dc_only = false;
-              k++;
+              } else if (what == 2) k += 16;
+              else if (what == 1) break;
+              else return sf::fail(SF_ERR_FORMAT, "jpeg: bad AC code");
             }
             idct_block(blk, dc_only, c.plane + (size_t)((my * c.v + by) * 8) * c.bw + (mx * c.h + bx) * 8, c.bw);
           }
