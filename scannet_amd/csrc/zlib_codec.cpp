@@ -390,9 +390,11 @@ SF_API int sf_zlib_deflate(const void* src_, uint64_t n, void* dst, uint64_t dst
       const int ds = fe.dist_sym(best_dist);
       bw.put(reverse_bits((uint32_t)ds, 5), 5);
       if (DIST_EXTRA[ds]) bw.put(best_dist - DIST_BASE[ds], DIST_EXTRA[ds]);
-      // index the skipped positions so later matches can reach them
+      // index the skipped positions so later matches can reach them -- all of them for ordinary matches; inside a long one (a run: a
+      // constant image region, the zeros of an Up-filtered PNG row) only its first and last 16, which is where the next match starts
       const uint64_t stop = i + (uint64_t)best_len;
       for (uint64_t j = i + 1; j < stop && j + MIN_MATCH <= n; j++) {
+        if (best_len >= 64 && j == i + 17) { j = stop - 17; continue; }
         const uint32_t h = hash3(src + j);
         prev[j & (WINDOW - 1)] = head[h];
         head[h] = (int32_t)j;
