@@ -3,10 +3,11 @@
 // Replaces stb::stbi_load_from_memory as called by RGBDFrame::decompressColorAlloc_stb
 // (SensReader/c++/src/sensorData.h:609-616 -> sensorData/stb_image.h:1067,3411).  ScanNet colour frames are
 // baseline YCbCr 4:2:0 / 4:2:2 JPEGs written by the capture app; progressive streams are rejected with
-// SF_ERR_UNSUPPORTED.  Written from ITU-T T.81: separable float IDCT (AAN butterflies, jpeg_idct.h), triangle-filter
-// ("fancy") 2x chroma upsampling, BT.601 full-range YCbCr -> RGB.  T.81 does not define bit-exact decoding, so parity
-// with the reference's integer IDCT is a tolerance (tests/test_sens.py: max |diff| <= 4 levels, mean < 0.5).
-// Entropy decoding is the serial part; the reconstruction (jpeg_idct.h) is shared with the GPU path of the frame pipeline.
+// SF_ERR_UNSUPPORTED.  Entropy decoding is written from ITU-T T.81 (and is the serial part); the reconstruction --
+// integer IDCT, chroma upsampling, YCbCr -> RGB (jpeg_idct.h, shared with the GPU path of the frame pipeline) -- reproduces the
+// integer arithmetic of the reference's decoder, so the pixels are IDENTICAL to the reference's (tests/test_sens.py), including
+// its handling of the last columns of a 4:2:2 picture.  Like the reference: 8-bit quantisation tables only, over-subscribed
+// Huffman tables rejected, DRI segments must be 4 bytes long (stb_image.h:2619-2650,1521-1556).
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -27,13 +28,16 @@ struct HuffDC_AC {
   // (value << 8) | (run << 4) | total bits; 0 = decode symbol and magnitude separately
   int16_t fast_ac[4096];
   bool present = false;
-  void build(bool with_fast_ac) {
+  // false: the code lengths over-subscribe the code space (more codes of some length than the prefix tree has leaves left) --
+  // such a table would index past `look`; stb_image.h:1543 rejects it ("bad code lengths")
+  bool build(bool with_fast_ac) {
     int code = 0, k = 0;
     for (int l = 1; l <= 16; l++) {
       valptr[l] = k;
       mincode[l] = code;
       code += bits[l];
       k += bits[l];
+      if (bits[l] && code - 1 >= (1 << l)) return false;
       maxcode[l] = bits[l] ? code - 1 : -1;
       code <<= 1;
     }
@@ -59,6 +63,7 @@ struct HuffDC_AC {
       if (v >= -128 && v <= 127) fast_ac[w] = (int16_t)(v * 256 + run * 16 + len + size);
     }
     present = true;
+    return true;
   }
 };
 
@@ -168,21 +173,16 @@ inline int decode_ac(BitSrc& bs, const HuffDC_AC& h, int& run, int& value) {
 const uint8_t ZIGZAG[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
                             35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
-// dequantised, AAN-scaled coefficients (natural order) -> 8 x 8 samples.  Columns first (the eight 1-D passes are independent: the
-// compiler vectorises across them), transpose, columns again (= the rows), transposed store.
-void idct_block(float* blk, bool dc_only, uint8_t* out, int stride) {
-  if (dc_only) {   // every butterfly adds or subtracts zeros: all 64 samples equal the scaled DC term, bit for bit
-    const uint8_t v = sf_jpeg_level(blk[0]);
+// dequantised 16-bit coefficients (natural order) -> 8 x 8 samples
+void idct_block(int* blk, bool dc_only, uint8_t* out, int stride) {
+  if (dc_only) {   // every other input of both passes is zero: all 64 samples equal ((dc << 14) + rounding + level shift) >> 17
+    const uint8_t v = sf_jpeg_clamp8((int32_t)((uint32_t)blk[0] * 16384u + 65536u + (128u << 17)) >> 17);
     for (int y = 0; y < 8; y++) std::memset(out + (size_t)y * stride, v, 8);
     return;
   }
-  for (int c = 0; c < 8; c++) sf_idct8(blk + c, 8);
-  float t[64];
+  sf_idct_block_int(blk);
   for (int y = 0; y < 8; y++)
-    for (int x = 0; x < 8; x++) t[x * 8 + y] = blk[y * 8 + x];
-  for (int c = 0; c < 8; c++) sf_idct8(t + c, 8);
-  for (int y = 0; y < 8; y++)
-    for (int x = 0; x < 8; x++) out[(size_t)y * stride + x] = sf_jpeg_level(t[x * 8 + y]);
+    for (int x = 0; x < 8; x++) out[(size_t)y * stride + x] = (uint8_t)blk[y * 8 + x];
 }
 
 }  // namespace
@@ -196,8 +196,7 @@ static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t e
   uint32_t* entries = nullptr;
   uint64_t max_entries = 0, nent = 0;
   if (n < 4 || data[0] != 0xFF || data[1] != 0xD8) return sf::fail(SF_ERR_FORMAT, "jpeg: missing SOI");
-  uint16_t qt[4][64];
-  float fq[4][64];   // quantiser step x AAN scale, natural order
+  uint16_t qt[4][64];   // natural order
   bool qt_ok[4] = {false, false, false, false};
   HuffDC_AC hdc[4], hac[4];
   Component comp[3];
@@ -209,6 +208,7 @@ static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t e
     if (pos + 4 > n) return sf::fail(SF_ERR_FORMAT, "jpeg: truncated before SOS");
     if (data[pos] != 0xFF) return sf::fail(SF_ERR_FORMAT, "jpeg: expected a marker");
     while (pos < n && data[pos] == 0xFF) pos++;
+    if (pos >= n) return sf::fail(SF_ERR_FORMAT, "jpeg: truncated inside a marker");
     const int m = data[pos++];
     if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
     if (pos + 2 > n) return sf::fail(SF_ERR_FORMAT, "jpeg: truncated segment");
@@ -220,10 +220,10 @@ static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t e
       while (q < seg_end) {
         const int pq = data[q] >> 4, tq = data[q] & 15;
         q++;
-        if (tq > 3 || q + (pq ? 128 : 64) > seg_end) return sf::fail(SF_ERR_FORMAT, "jpeg: bad DQT");
-        for (int i = 0; i < 64; i++) { qt[tq][ZIGZAG[i]] = pq ? (uint16_t)u16(q + 2 * i) : data[q + i]; }
-        q += pq ? 128 : 64;
-        for (int z = 0; z < 64; z++) fq[tq][z] = sf_jpeg_dequant(qt[tq][z], z);
+        if (pq != 0) return sf::fail(SF_ERR_FORMAT, "jpeg: 16-bit quantisation table (the reference decoder takes 8-bit tables only, stb_image.h:2625)");
+        if (tq > 3 || q + 64 > seg_end) return sf::fail(SF_ERR_FORMAT, "jpeg: bad DQT");
+        for (int i = 0; i < 64; i++) qt[tq][ZIGZAG[i]] = data[q + i];
+        q += 64;
         qt_ok[tq] = true;
       }
     } else if (m == 0xC4) {
@@ -240,7 +240,7 @@ static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t e
         if (total > 256 || q + total > seg_end) return sf::fail(SF_ERR_FORMAT, "jpeg: bad DHT counts");
         std::memcpy(h.vals, data + q, (size_t)total);
         q += total;
-        h.build(tc != 0);
+        if (!h.build(tc != 0)) return sf::fail(SF_ERR_FORMAT, "jpeg: bad Huffman code lengths");
       }
     } else if (m == 0xC0 || m == 0xC1) {
       if (len < 8 || data[seg] != 8) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: only 8-bit precision is supported");
@@ -258,6 +258,7 @@ static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t e
     } else if (m == 0xC2 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC)) {
       return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: progressive / lossless / arithmetic JPEG (SOF%d) is not supported", m - 0xC0);
     } else if (m == 0xDD) {
+      if (len != 4) return sf::fail(SF_ERR_FORMAT, "jpeg: bad DRI length");
       restart = u16(seg);
     } else if (m == 0xDA) {
       if (!have_sof) return sf::fail(SF_ERR_FORMAT, "jpeg: SOS before SOF");
@@ -318,12 +319,12 @@ static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t e
   }
   BitSrc bs{data + pos, data + n};
   int todo = restart ? restart : 0x7FFFFFFF;
-  float blk[64];
+  int blk[64];
   for (int my = 0; my < mcuy; my++)
     for (int mx = 0; mx < mcux; mx++) {
       for (int ci = 0; ci < ncomp; ci++) {
         Component& c = comp[ci];
-        const float* q = fq[c.tq];
+        const uint16_t* q = qt[c.tq];
         for (int by = 0; by < c.v; by++)
           for (int bx = 0; bx < c.h; bx++) {
             if (to_coef) {   // the same walk, the non-zero coefficients appended instead of reconstructed
@@ -355,7 +356,7 @@ static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t e
             if (t < 0 || t > 11) return sf::fail(SF_ERR_FORMAT, "jpeg: bad DC code");
             const int diff = t ? extend(bs.get(t), t) : 0;
             c.pred += diff;
-            blk[0] = (float)c.pred * q[0];
+            blk[0] = sf_jpeg_dequant16(c.pred, q[0]);
             bool dc_only = true;
             const HuffDC_AC& ac = hac[c.ta];
             for (int k = 1; k < 64;) {
@@ -365,7 +366,7 @@ static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t e
                 k += run;
                 if (k > 63) return sf::fail(SF_ERR_FORMAT, "jpeg: AC run past the end of the block");
                 const int z = ZIGZAG[k];
-                blk[z] = (float)value * q[z];
+                blk[z] = sf_jpeg_dequant16(value, q[z]);
                 dc_only = false;
                 k++;
               } else if (what == 2) k += 16;
@@ -395,55 +396,59 @@ static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t e
       }
     return SF_OK;
   }
-  // chroma to full resolution and YCbCr -> RGB, one output row at a time.  2x: triangle filter (3/4 of the nearer sample, 1/4 of the
-  // farther one, vertically then horizontally, the image border replicated); other integer ratios: nearest.
-  static thread_local std::vector<int16_t> vb[3];    // vertical blend of one chroma row (scaled by 4)
+  // components to full resolution and YCbCr -> RGB, one output row at a time.  Per component, by (sx, sy) = (hmax / h, vmax / v):
+  // (1,1) as is; (1,2), (2,1), (2,2) triangle filter (3/4 of the nearer sample, 1/4 of the farther one; rows beyond the last valid
+  // one replicate it); everything else nearest.  Same integers as sf_jpeg_upsample (jpeg_idct.h), which the GPU path evaluates per pixel.
+  static thread_local std::vector<int16_t> vb[3];    // 3 x nearer + farther chroma row
   static thread_local std::vector<uint8_t> row[3];   // full-resolution row of each component
   const uint8_t* full[3];
   for (int ci = 0; ci < 3; ci++) {
     Component& c = comp[ci];
     if ((hmax % c.h) || (vmax % c.v)) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: fractional sampling ratios are not supported");
     if (vb[ci].size() < (size_t)c.bw + 2) vb[ci].resize((size_t)c.bw + 2);
-    if (row[ci].size() < (size_t)width + 2) row[ci].resize((size_t)width + 2);
+    if (row[ci].size() < (size_t)c.bw * (size_t)(hmax / c.h) + 8) row[ci].resize((size_t)c.bw * (size_t)(hmax / c.h) + 8);
   }
   for (int y = 0; y < height; y++) {
     for (int ci = 0; ci < 3; ci++) {
       Component& c = comp[ci];
       const int sx = hmax / c.h, sy = vmax / c.v;
       if (sx == 1 && sy == 1) { full[ci] = c.plane + (size_t)y * c.bw; continue; }
-      const int cw = (width * c.h + hmax - 1) / hmax, ch = (height * c.v + vmax - 1) / vmax;  // valid chroma samples
-      int y0, y1, wy0, wy1;
-      if (sy == 2) { const int cy = y >> 1; y0 = cy; y1 = (y & 1) ? (cy + 1 < ch ? cy + 1 : cy) : (cy > 0 ? cy - 1 : cy); wy0 = 3; wy1 = 1; }
-      else { y0 = y1 = (y / sy < ch ? y / sy : ch - 1); wy0 = 4; wy1 = 0; }
-      const uint8_t* r0 = c.plane + (size_t)y0 * c.bw;
-      const uint8_t* r1 = c.plane + (size_t)y1 * c.bw;
+      const int cw = (width + sx - 1) / sx, ch = (height * c.v + vmax - 1) / vmax;  // valid samples of the component
       uint8_t* o = row[ci].data();
-      if (sx == 2) {
-        int16_t* t = vb[ci].data();
-        for (int x = 0; x < cw; x++) t[x] = (int16_t)(wy0 * r0[x] + wy1 * r1[x]);   // each scaled by 4
-        // o[2 cx] = (3 t[cx] + t[cx - 1] + 8) >> 4, o[2 cx + 1] = (3 t[cx] + t[cx + 1] + 8) >> 4, neighbours clamped to [0, cw)
-        const int pairs = width >> 1;   // output pixels 2 cx and 2 cx + 1 both inside the image
-        if (cw > 0) {
-          o[0] = (uint8_t)((3 * t[0] + t[0] + 8) >> 4);
-          if (width > 1) o[1] = (uint8_t)((3 * t[0] + t[cw > 1 ? 1 : 0] + 8) >> 4);
-        }
-        const int inner = (pairs < cw - 1 ? pairs : cw - 1);
-        for (int cx = 1; cx < inner; cx++) {
-          o[2 * cx] = (uint8_t)((3 * t[cx] + t[cx - 1] + 8) >> 4);
-          o[2 * cx + 1] = (uint8_t)((3 * t[cx] + t[cx + 1] + 8) >> 4);
-        }
-        for (int x = 2 * (inner > 1 ? inner : 1); x < width; x++) {   // the last chroma column(s): neighbour index clamped
-          const int cx = x >> 1;
-          const int cn = (x & 1) ? (cx + 1 < cw ? cx + 1 : cx) : (cx > 0 ? cx - 1 : cx);
-          o[x] = (uint8_t)((3 * t[cx] + t[cn] + 8) >> 4);
-        }
-      } else {
-        for (int x = 0; x < width; x++) {
-          const int cx = x / sx < cw ? x / sx : cw - 1;
-          o[x] = (uint8_t)((wy0 * r0[cx] + wy1 * r1[cx] + 2) >> 2);
-        }
-      }
       full[ci] = o;
+      const bool tri_v = sy == 2 && sx <= 2, tri_h = sx == 2 && sy <= 2;
+      if (!tri_v && !tri_h) {
+        const uint8_t* r = c.plane + (size_t)(y / sy < ch ? y / sy : ch - 1) * c.bw;
+        for (int x = 0; x < width; x++) o[x] = r[x / sx];
+        continue;
+      }
+      int yn = y < ch ? y : ch - 1, yf = yn;
+      if (tri_v) { const int cy = y >> 1; yn = cy; yf = (y & 1) ? (cy + 1 < ch ? cy + 1 : cy) : (cy > 0 ? cy - 1 : cy); }
+      const uint8_t* rn = c.plane + (size_t)yn * c.bw;
+      const uint8_t* rf = c.plane + (size_t)yf * c.bw;
+      if (!tri_h) {
+        for (int x = 0; x < width; x++) o[x] = (uint8_t)((3 * rn[x] + rf[x] + 2) >> 2);
+      } else if (!tri_v) {   // horizontal only; the last chroma column follows the reference (jpeg_idct.h)
+        if (cw == 1) { o[0] = o[1] = rn[0]; continue; }
+        o[0] = rn[0];
+        o[1] = (uint8_t)((3 * rn[0] + rn[1] + 2) >> 2);
+        for (int cx = 1; cx < cw - 1; cx++) {
+          const int m = 3 * rn[cx] + 2;
+          o[2 * cx] = (uint8_t)((m + rn[cx - 1]) >> 2);
+          o[2 * cx + 1] = (uint8_t)((m + rn[cx + 1]) >> 2);
+        }
+        o[2 * cw - 2] = (uint8_t)((3 * rn[cw - 2] + rn[cw - 1] + 2) >> 2);
+        o[2 * cw - 1] = rn[cw - 1];
+      } else {
+        int16_t* t = vb[ci].data();
+        for (int x = 0; x < cw; x++) t[x] = (int16_t)(3 * rn[x] + rf[x]);
+        o[0] = (uint8_t)((t[0] + 2) >> 2);
+        for (int cx = 1; cx < cw; cx++) {
+          o[2 * cx - 1] = (uint8_t)((3 * t[cx - 1] + t[cx] + 8) >> 4);
+          o[2 * cx] = (uint8_t)((3 * t[cx] + t[cx - 1] + 8) >> 4);
+        }
+        o[2 * cw - 1] = (uint8_t)((t[cw - 1] + 2) >> 2);
+      }
     }
     const uint8_t* __restrict__ py = full[0];
     const uint8_t* __restrict__ pb = full[1];

@@ -1,14 +1,16 @@
 // jpeg_gpu.hip -- the data-parallel half of baseline JPEG decoding on gfx950.  The frame pipeline's host threads only entropy-decode
 // (jpeg.cpp: jpeg_decode_coef -- Huffman decoding is serial per frame); the non-zero quantised coefficients go over PCIe in place of the
 // RGB image (about a third of its bytes) and two kernels reconstruct the picture where the fuser wants it anyway, in HBM:
-//   k_jpeg_idct   one lane per 8 x 8 block: its non-zero coefficients scattered into a zeroed LDS column and dequantised (AAN scale
-//                 folded in), 1-D passes down the columns and along the rows, round and clamp, eight 8-byte stores into the plane
-//   k_jpeg_rgb    four pixels per lane: triangle-filter chroma upsampling, BT.601 -> RGB, three dword stores
-// Every arithmetic step is the function of jpeg_idct.h the host decoder is built from (no contraction), so the bytes are the ones
-// sf_sens_decode_color produces (tests/test_gpu_pipeline.py).  Replaces, for this path, the SSE2 IDCT + resampling of stb_image as
-// RGBDFrame::decompressColorAlloc_stb calls it (SensReader/c++/src/sensorData.h:609-616, stb_image.h:2028-2207).
+//   k_jpeg_idct   one lane per 8 x 8 block: its non-zero coefficients scattered into a zeroed LDS column and dequantised to 16 bits,
+//                 integer 1-D passes down the columns and along the rows, clamp, eight 8-byte stores into the plane
+//   k_jpeg_rgb    four pixels per lane: chroma upsampling, fixed-point YCbCr -> RGB, three dword stores
+// Every arithmetic step is the integer function of jpeg_idct.h the host decoder is built from, so the bytes are the ones
+// sf_sens_decode_color produces -- and the ones the reference's decoder produces (tests/test_gpu_pipeline.py, tests/test_sens.py).
+// Replaces, for this path, the SSE2 IDCT + resampling + colour conversion of stb_image as RGBDFrame::decompressColorAlloc_stb
+// calls it (SensReader/c++/src/sensorData.h:609-616, stb_image.h:2028-2207).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <vector>
 
 #include "common.h"
@@ -25,14 +27,14 @@ struct JpegBatch {
 };
 
 __global__ __launch_bounds__(256) void k_jpeg_idct(JpegBatch B) {
-  extern __shared__ float s_blk[];   // [64][256]: coefficient z of lane t at z * 256 + t (no bank conflicts either way)
+  extern __shared__ int s_blk[];   // [64][256]: coefficient z of lane t at z * 256 + t (no bank conflicts either way)
   const int f = blockIdx.y;
   if (B.rgb[f] == nullptr) return;
   const SfJpegLayout* __restrict__ L = reinterpret_cast<const SfJpegLayout*>(B.payload[f]);
   const uint32_t* __restrict__ table = reinterpret_cast<const uint32_t*>(B.payload[f] + sizeof(SfJpegLayout));
   const uint32_t* __restrict__ entries = table + L->nblocks;
-  __shared__ float fq[3][64];
-  for (int t = threadIdx.x; t < 64 * L->ncomp; t += 256) fq[t >> 6][t & 63] = sf_jpeg_dequant(L->q[t >> 6][t & 63], t & 63);
+  __shared__ int s_q[3][64];
+  for (int t = threadIdx.x; t < 64 * L->ncomp; t += 256) s_q[t >> 6][t & 63] = L->q[t >> 6][t & 63];
   __syncthreads();
   const uint32_t block = blockIdx.x * 256 + threadIdx.x;   // block index over all components
   if (block >= L->nblocks) return;
@@ -43,31 +45,28 @@ __global__ __launch_bounds__(256) void k_jpeg_idct(JpegBatch B) {
   const uint32_t b = block - L->block_off[c];
   const int blocks_w = L->bw[c] / 8;
   // the block's non-zero coefficients scattered into a zeroed LDS column, dequantised on the way
-  float* col = s_blk + threadIdx.x;
+  int* col = s_blk + threadIdx.x;
 #pragma unroll
-  for (int z = 0; z < 64; z++) col[z * 256] = 0.0f;
+  for (int z = 0; z < 64; z++) col[z * 256] = 0;
   const uint32_t te = table[block];
   const uint32_t* e = entries + (te >> 7);
   for (uint32_t k = 0; k < (te & 127u); k++) {
     const uint32_t w = e[k];
     const int z = (int)((w >> 16) & 63u);
-    col[z * 256] = (float)(int16_t)(w & 0xffffu) * fq[c][z];
+    col[z * 256] = sf_jpeg_dequant16((int)(int16_t)(w & 0xffffu), s_q[c][z]);
   }
-  float blk[64];
+  int blk[64];
 #pragma unroll
   for (int z = 0; z < 64; z++) blk[z] = col[z * 256];
-#pragma unroll
-  for (int cc = 0; cc < 8; cc++) sf_idct8(blk + cc, 8);
-#pragma unroll
-  for (int row = 0; row < 8; row++) sf_idct8(blk + 8 * row, 1);
+  sf_idct_block_int(blk);
   uint8_t* out = B.planes[f] + plane_off + (size_t)(b / blocks_w) * 8 * L->bw[c] + (size_t)(b % blocks_w) * 8;
 #pragma unroll
   for (int y = 0; y < 8; y++) {
     uint32_t lo = 0, hi = 0;
 #pragma unroll
     for (int x = 0; x < 4; x++) {
-      lo |= (uint32_t)sf_jpeg_level(blk[8 * y + x]) << (8 * x);
-      hi |= (uint32_t)sf_jpeg_level(blk[8 * y + 4 + x]) << (8 * x);
+      lo |= (uint32_t)blk[8 * y + x] << (8 * x);
+      hi |= (uint32_t)blk[8 * y + 4 + x] << (8 * x);
     }
     *reinterpret_cast<uint2*>(out + (size_t)y * L->bw[c]) = make_uint2(lo, hi);
   }
@@ -99,7 +98,7 @@ __global__ __launch_bounds__(256) void k_jpeg_rgb(JpegBatch B) {
 #pragma unroll
     for (int c = 0; c < 3; c++) {
       const int sx = L->hmax / L->h[c], sy = L->vmax / L->v[c];
-      const int cw = (W * L->h[c] + L->hmax - 1) / L->hmax, ch = (H * L->v[c] + L->vmax - 1) / L->vmax;   // valid samples of the component
+      const int cw = (W + sx - 1) / sx, ch = (H * L->v[c] + L->vmax - 1) / L->vmax;   // valid samples of the component
       v[c] = sf_jpeg_upsample(plane, L->bw[c], cw, ch, sx, sy, x, y);
       plane += (size_t)L->bw[c] * L->bh[c];
     }
@@ -130,10 +129,13 @@ int jpeg_gpu_reconstruct(hipStream_t stream, int n, const uint8_t* const* d_payl
     b.rgb[i] = i < n ? d_rgb[i] : nullptr;
     b.planes[i] = i < n ? d_planes[i] : nullptr;
   }
-  static bool lds_set = false;   // 64 KiB of dynamic LDS per workgroup
-  if (!lds_set) {
+  // 64 KiB of dynamic LDS per workgroup: the attribute belongs to the device's copy of the kernel, set once per device
+  static std::atomic<uint64_t> lds_set{0};
+  int dev = 0;
+  SF_HIP_CHECK(hipGetDevice(&dev));
+  if (dev >= 64 || !(lds_set.load(std::memory_order_acquire) & (1ull << dev))) {
     SF_HIP_CHECK(hipFuncSetAttribute((const void*)k_jpeg_idct, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 256 * (int)sizeof(float)));
-    lds_set = true;
+    if (dev < 64) lds_set.fetch_or(1ull << dev, std::memory_order_release);
   }
   hipLaunchKernelGGL(k_jpeg_idct, dim3((max_blocks + 255) / 256, n), dim3(256), 64 * 256 * sizeof(float), stream, b);
   hipLaunchKernelGGL(k_jpeg_rgb, dim3((unsigned)((max_pixels / 4 + 256) / 256), n), dim3(256), 0, stream, b);

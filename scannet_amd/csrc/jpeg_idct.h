@@ -1,9 +1,15 @@
 // jpeg_idct.h -- the sample reconstruction of the baseline JPEG decoder as functions both the host decoder (jpeg.cpp) and the GPU
-// path of the frame pipeline (jpeg_gpu.hip) are built from, so that the two produce the same bytes: dequantisation with the
-// AAN scale factors folded in, a separable 8-point inverse DCT after Arai / Agui / Nakajima (5 multiplications per 1-D pass, plain
-// IEEE binary32, no contraction), rounding to the nearest level, triangle-filter 2x chroma upsampling and BT.601 full-range
-// YCbCr -> RGB in 16.16 fixed point.  T.81 does not define bit-exact decoding; against the reference's stb decoder (integer IDCT)
-// the result stays within the tolerance tests/test_sens.py states.
+// path of the frame pipeline (jpeg_gpu.hip) are built from, so that the two produce the same bytes -- and the bytes of the
+// reference: RGBDFrame::decompressColorAlloc_stb (SensReader/c++/src/sensorData.h:609-616) decodes with stb_image v2.08, whose
+// reconstruction is pure integer arithmetic, so identity (not a tolerance) is the bar (tests/test_sens.py).  Restated here:
+//   * dequantisation to 16 bits: (int16)(coefficient * step)                                        stb_image.h:1726,1751,1764
+//   * 8 x 8 inverse DCT, the "slow integer" factorisation with 12-bit constants: columns keep 2 extra bits ((x + 512) >> 10),
+//     rows remove 17 with the level shift folded into the rounding term ((x + 65536 + (128 << 17)) >> 17), clamp   stb_image.h:1928-2026
+//   * chroma upsampling chosen per component from (hs, vs) = (hmax / h, vmax / v): (1,1) copy, (1,2) / (2,1) / (2,2) triangle filter
+//     (3/4 nearer + 1/4 farther sample), anything else nearest; rows beyond the last VALID chroma row replicate it   stb_image.h:2871-2933,3052-3063,3339-3383
+//     (2,1) keeps stb's own last-column rule: pixel 2 (w - 1) = (3 c[w - 2] + c[w - 1] + 2) >> 2, pixel 2 w - 1 = c[w - 1]   stb_image.h:2899-2900
+//   * YCbCr -> RGB in 12.20 fixed point, the blue-difference term of green truncated to its upper 16 bits                stb_image.h:3093-3119
+// All arithmetic is 32-bit two's complement (wrapping), shifts of negative values are arithmetic.
 #pragma once
 #include <cmath>
 #include <cstdint>
@@ -14,45 +20,64 @@
 #define SF_JHD
 #endif
 
-// s[0] = 1, s[k] = sqrt(2) cos(k pi / 16): coefficient (v, u) is multiplied by s[u] s[v] / 8 before the butterflies
-SF_JHD inline float sf_jpeg_aan(int k) {
-  const float s[8] = {1.0f, 1.387039845f, 1.306562965f, 1.175875602f, 1.0f, 0.785694958f, 0.541196100f, 0.275899379f};
-  return s[k];
-}
-// multiplier of the quantised coefficient at natural-order position z of a table entry q
-SF_JHD inline float sf_jpeg_dequant(uint16_t q, int z) { return (float)q * (sf_jpeg_aan(z & 7) * sf_jpeg_aan(z >> 3) * 0.125f); }
-
-// one 8-point pass in place over v[0], v[s], ..., v[7 s]
-SF_JHD inline void sf_idct8(float* v, int s) {
-  const float t0 = v[0], t1 = v[2 * s], t2 = v[4 * s], t3 = v[6 * s];
-  const float a10 = t0 + t2, a11 = t0 - t2, a13 = t1 + t3, a12 = (t1 - t3) * 1.414213562f - a13;
-  const float e0 = a10 + a13, e3 = a10 - a13, e1 = a11 + a12, e2 = a11 - a12;
-  const float o4 = v[s], o5 = v[3 * s], o6 = v[5 * s], o7 = v[7 * s];
-  const float z13 = o6 + o5, z10 = o6 - o5, z11 = o4 + o7, z12 = o4 - o7;
-  const float b7 = z11 + z13, b11 = (z11 - z13) * 1.414213562f;
-  const float z5 = (z10 + z12) * 1.847759065f;
-  const float b10 = z5 - z12 * 1.082392200f;
-  const float b12 = z5 - z10 * 2.613125930f;
-  const float b6 = b12 - b7, b5 = b11 - b6, b4 = b10 - b5;
-  v[0] = e0 + b7; v[7 * s] = e0 - b7;
-  v[s] = e1 + b6; v[6 * s] = e1 - b6;
-  v[2 * s] = e2 + b5; v[5 * s] = e2 - b5;
-  v[3 * s] = e3 + b4; v[4 * s] = e3 - b4;
-}
-
-SF_JHD inline uint8_t sf_jpeg_level(float v) {   // sample = nearest integer to v + 128, clamped
-  const float r = rintf(v + 128.0f);
-  return (uint8_t)(r < 0.0f ? 0.0f : (r > 255.0f ? 255.0f : r));
-}
-
 SF_JHD inline uint8_t sf_jpeg_clamp8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
-// BT.601 full range, 16.16 fixed point
+
+// One 8-point pass.  in: the eight inputs; out k receives (value_k + bias) >> shift, handed to `emit(k, v)`.
+// 32-bit wrapping arithmetic: unsigned for the sums and products, the final shift on the signed reinterpretation.
+template <class Emit>
+SF_JHD inline void sf_idct8_int(int s0, int s1, int s2, int s3, int s4, int s5, int s6, int s7, uint32_t bias, int shift, Emit emit) {
+  typedef uint32_t u;
+  // even half: rotation of (s2, s6) by 3 pi / 8, butterfly of (s0, s4) scaled by 2^12
+  const u rot = ((u)s2 + (u)s6) * (u)2217;
+  const u ev2 = rot + (u)s6 * (u)-7567;
+  const u ev3 = rot + (u)s2 * (u)3135;
+  const u ev0 = ((u)s0 + (u)s4) * 4096u, ev1 = ((u)s0 - (u)s4) * 4096u;
+  const u a0 = ev0 + ev3 + bias, a3 = ev0 - ev3 + bias, a1 = ev1 + ev2 + bias, a2 = ev1 - ev2 + bias;
+  // odd half
+  const u q3 = (u)s7 + (u)s3, q4 = (u)s5 + (u)s1, q1 = (u)s7 + (u)s1, q2 = (u)s5 + (u)s3;
+  const u q5 = (q3 + q4) * (u)4816;
+  const u r1 = q5 + q1 * (u)-3685, r2 = q5 + q2 * (u)-10497, r3 = q3 * (u)-8034, r4 = q4 * (u)-1597;
+  const u od3 = (u)s1 * (u)6149 + r1 + r4;
+  const u od2 = (u)s3 * (u)12586 + r2 + r3;
+  const u od1 = (u)s5 * (u)8410 + r2 + r4;
+  const u od0 = (u)s7 * (u)1223 + r1 + r3;
+  emit(0, (int32_t)(a0 + od3) >> shift); emit(7, (int32_t)(a0 - od3) >> shift);
+  emit(1, (int32_t)(a1 + od2) >> shift); emit(6, (int32_t)(a1 - od2) >> shift);
+  emit(2, (int32_t)(a2 + od1) >> shift); emit(5, (int32_t)(a2 - od1) >> shift);
+  emit(3, (int32_t)(a3 + od0) >> shift); emit(4, (int32_t)(a3 - od0) >> shift);
+}
+
+// dequantised 16-bit coefficients (natural order, blk[8 v + u]) -> 64 levels in place
+SF_JHD inline void sf_idct_block_int(int* blk) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int c = 0; c < 8; c++) {
+    int* col = blk + c;
+    sf_idct8_int(col[0], col[8], col[16], col[24], col[32], col[40], col[48], col[56], 512u, 10, [&](int k, int v) { col[8 * k] = v; });
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int r = 0; r < 8; r++) {
+    int* row = blk + 8 * r;
+    sf_idct8_int(row[0], row[1], row[2], row[3], row[4], row[5], row[6], row[7], 65536u + (128u << 17), 17, [&](int k, int v) { row[k] = (int)sf_jpeg_clamp8(v); });
+  }
+}
+
+// the 16-bit dequantised coefficient stb keeps: (short)(coefficient * step)
+SF_JHD inline int sf_jpeg_dequant16(int coef, int step) { return (int)(int16_t)(uint16_t)((uint32_t)coef * (uint32_t)step); }
+
 SF_JHD inline void sf_jpeg_ycc_to_rgb(int Y, int cb, int cr, uint8_t* o) {
   cb -= 128;
   cr -= 128;
-  o[0] = sf_jpeg_clamp8((Y * 65536 + 91881 * cr + 32768) >> 16);
-  o[1] = sf_jpeg_clamp8((Y * 65536 - 22554 * cb - 46802 * cr + 32768) >> 16);
-  o[2] = sf_jpeg_clamp8((Y * 65536 + 116130 * cb + 32768) >> 16);
+  const uint32_t yf = ((uint32_t)Y << 20) + (1u << 19);
+  const int32_t r = (int32_t)(yf + (uint32_t)cr * 1470208u);
+  const int32_t g = (int32_t)(yf + (uint32_t)cr * (uint32_t)-748800 + (((uint32_t)cb * (uint32_t)-360960) & 0xffff0000u));
+  const int32_t b = (int32_t)(yf + (uint32_t)cb * 1858048u);
+  o[0] = sf_jpeg_clamp8(r >> 20);
+  o[1] = sf_jpeg_clamp8(g >> 20);
+  o[2] = sf_jpeg_clamp8(b >> 20);
 }
 
 // ---- entropy-decoded frame handed to the GPU (jpeg_gpu.hip): this header, a block table, the non-zero coefficients ----------------
@@ -75,21 +100,34 @@ static_assert(sizeof(SfJpegLayout) == 512, "SfJpegLayout is the 512-byte header 
 inline size_t sf_jpeg_payload_bytes(const SfJpegLayout& L) { return sizeof(SfJpegLayout) + 4 * ((size_t)L.nblocks + L.nentries); }
 inline size_t sf_jpeg_plane_bytes(const SfJpegLayout& L) { size_t n = 0; for (int c = 0; c < L.ncomp; c++) n += (size_t)L.bw[c] * L.bh[c]; return n; }
 
-// full-resolution sample (x, y) of a component stored at 1/sx x 1/sy: triangle filter for a factor of 2 (3/4 nearer + 1/4 farther sample,
-// vertically then horizontally, borders replicated), nearest otherwise -- the per-pixel form of jpeg.cpp's row loops (same integers)
+// full-resolution sample (x, y) of a component stored at 1/sx x 1/sy, cw x ch valid samples -- the per-pixel form of jpeg.cpp's row loops
+// (same integers); the dispatch on (sx, sy) and the last-column rule of (2, 1) are stb's (header comment)
 SF_JHD inline int sf_jpeg_upsample(const uint8_t* plane, int bw, int cw, int ch, int sx, int sy, int x, int y) {
   if (sx == 1 && sy == 1) return plane[(size_t)y * bw + x];
-  int y0, y1, wy0, wy1;
-  if (sy == 2) { const int cy = y >> 1; y0 = cy; y1 = (y & 1) ? (cy + 1 < ch ? cy + 1 : cy) : (cy > 0 ? cy - 1 : cy); wy0 = 3; wy1 = 1; }
-  else { y0 = y1 = (y / sy < ch ? y / sy : ch - 1); wy0 = 4; wy1 = 0; }
-  const uint8_t* r0 = plane + (size_t)y0 * bw;
-  const uint8_t* r1 = plane + (size_t)y1 * bw;
-  if (sx == 2) {
-    const int cx = x >> 1;
-    const int cn = (x & 1) ? (cx + 1 < cw ? cx + 1 : cx) : (cx > 0 ? cx - 1 : cx);
-    const int a = wy0 * r0[cx] + wy1 * r1[cx], b = wy0 * r0[cn] + wy1 * r1[cn];   // each scaled by 4
-    return (3 * a + b + 8) >> 4;
+  const bool tri_v = sy == 2 && sx <= 2, tri_h = sx == 2 && sy <= 2;
+  if (!tri_v && !tri_h) {   // nearest
+    const int cy = y / sy < ch ? y / sy : ch - 1;
+    return plane[(size_t)cy * bw + x / sx];
   }
-  const int cx = x / sx < cw ? x / sx : cw - 1;
-  return (wy0 * r0[cx] + wy1 * r1[cx] + 2) >> 2;
+  int wn = 4, wf = 0, yn = y < ch ? y : ch - 1, yf = yn;   // vertical weights (of 4) and rows of the nearer / farther sample
+  if (tri_v) {
+    const int cy = y >> 1;
+    yn = cy;
+    yf = (y & 1) ? (cy + 1 < ch ? cy + 1 : cy) : (cy > 0 ? cy - 1 : cy);
+    wn = 3; wf = 1;
+  }
+  const uint8_t* rn = plane + (size_t)yn * bw;
+  const uint8_t* rf = plane + (size_t)yf * bw;
+  if (!tri_h) return (wn * rn[x] + wf * rf[x] + 2) >> 2;
+  const int cx = x >> 1;
+  if (!tri_v) {   // (2, 1)
+    if (cw == 1) return rn[0];
+    if (x == 0 || x == 2 * cw - 1) return rn[cx];
+    if (x == 2 * cw - 2) return (3 * rn[cw - 2] + rn[cw - 1] + 2) >> 2;
+    const int cn = (x & 1) ? cx + 1 : cx - 1;
+    return (3 * rn[cx] + rn[cn] + 2) >> 2;
+  }
+  const int cn = (x & 1) ? (cx + 1 < cw ? cx + 1 : cx) : (cx > 0 ? cx - 1 : cx);
+  const int a = 3 * rn[cx] + rf[cx], b = 3 * rn[cn] + rf[cn];
+  return (3 * a + b + 8) >> 4;
 }

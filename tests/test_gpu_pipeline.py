@@ -202,6 +202,50 @@ def test_jpeg_gpu_reconstruction_equals_the_host_decoder():
         calibrate.jpeg_decode(b"\xff\xd8 not a jpeg", 8, 8, device=0)
 
 
+def test_jpeg_gpu_reconstruction_identical_to_the_reference_decoder(oracle, tmp_path):
+    """The GPU reconstruction against the REFERENCE's decoder itself (SensorData::decompressColorAlloc -> stb_image, compiled from the
+    reference's sources into oracle/_ref/libref_sens.so, which travels with the snapshot): integer work, identical bytes.  4:4:4 / 4:2:2
+    (stb's last-column rule) / 4:2:0 / 4:4:0 / grey, odd sizes, restart intervals, and ScanNet's 1296x968."""
+    import ctypes as C
+    import io
+    from PIL import Image
+    from scannet_amd import calibrate
+    from tests import jpeg_tools
+    if not oracle.ref_sens_available():
+        pytest.skip("oracle/_ref/libref_sens.so absent")
+    R = oracle.ref_sens()
+
+    def ref_decode(blob, W, H):
+        sd = sens.SensorData.create(W, H, 8, 8, np.eye(4), np.eye(4), color_compression=2, depth_compression=0)
+        sd.add_frame(np.zeros((8, 8), np.uint16), np.eye(4), color=blob)
+        p = str(tmp_path / "c.sens")
+        sd.save(p)
+        h = R.ref_sens_open(p.encode())
+        ref = np.zeros((H, W, 3), np.uint8)
+        assert R.ref_sens_decode_color(h, 0, ref.ctypes.data_as(C.c_void_p)) == 0
+        R.ref_sens_close(h)
+        return ref
+
+    rng = np.random.default_rng(5)
+    n = 0
+    for (W, H) in ((136, 104), (133, 99), (17, 9), (1, 1), (1296, 968)):
+        img = np.clip(_smooth_image(W, H, n).astype(np.int32) + rng.integers(-12, 13, (H, W, 3)), 0, 255).astype(np.uint8)
+        blobs = []
+        for sub in (0, 1, 2):
+            buf = io.BytesIO()
+            Image.fromarray(img).save(buf, format="JPEG", quality=90 if W > 1000 else 70 + 10 * sub, subsampling=sub, **({"restart_marker_blocks": 5} if sub == 1 else {}))
+            blobs.append(buf.getvalue())
+        if W < 1000:
+            blobs.append(jpeg_tools.encode(img, ((1, 2), (1, 1), (1, 1)), qstep=3))
+            blobs.append(jpeg_tools.encode(img[..., 0], ((1, 1),), qstep=2, restart=2))
+            blobs.append(jpeg_tools.encode(img, ((1, 1), (2, 2), (2, 2)), qstep=5))
+        for b in blobs:
+            gpu = calibrate.jpeg_decode(b, W, H, device=0)
+            assert np.array_equal(gpu, ref_decode(b, W, H)), (W, H, n)
+            n += 1
+    assert n == 27
+
+
 @pytest.mark.parametrize("kind", ["raw", "jpeg", "jpeg_host"])
 def test_fuse_run_with_colour_matches_frame_by_frame(tmp_path, kind, monkeypatch):
     """Colour at its own resolution through the threaded pipeline (raw; JPEG with the GPU reconstruction; JPEG decoded on the host):

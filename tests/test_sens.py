@@ -189,33 +189,113 @@ def _jpeg_bytes(img, quality, subsampling):
     return buf.getvalue()
 
 
+def _test_picture(W, H, seed=1, noise=20):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = np.stack([(xx * 255 // W), (yy * 255 // H), ((xx + yy) * 3 % 256)], -1).astype(np.int32)
+    img[H // 3:H // 2 + 1, W // 3:W // 2 + 1] = (200, 30, 60)
+    return (img + rng.integers(-noise, noise + 1, img.shape)).clip(0, 255).astype(np.uint8)
+
+
+def _decode_both(oracle, tmp_path, blob, W, H, color_compression=2):
+    """The blob as the colour frame of a one-frame .sens, decoded by this library and by the reference's SensorData (stb_image)."""
+    sd = sens.SensorData.create(W, H, 8, 8, np.eye(4), np.eye(4), color_compression=color_compression, depth_compression=0)
+    sd.add_frame(np.zeros((8, 8), np.uint16), np.eye(4), color=blob)
+    p = str(tmp_path / "c.sens")
+    sd.save(p)
+    ours = sens.SensorData(p).frames[0].decompress_color()
+    R = oracle.ref_sens()
+    h = R.ref_sens_open(p.encode())
+    ref = np.zeros((H, W, 3), np.uint8)
+    rc = R.ref_sens_decode_color(h, 0, ref.ctypes.data_as(C.c_void_p))
+    R.ref_sens_close(h)
+    assert rc == 0
+    return ours, ref
+
+
 @pytest.mark.parametrize("subsampling", [0, 1, 2])
-def test_jpeg_decode_against_pil_and_reference(oracle, tmp_path, subsampling):
+def test_jpeg_decode_against_pil(subsampling):
+    """An independent decoder (libjpeg-turbo through PIL): T.81 defines no bit-exact IDCT, so this one is a tolerance."""
     PIL = pytest.importorskip("PIL")
     from PIL import Image
+    from scannet_amd import calibrate
     W, H = 136, 104  # not a multiple of the 16x16 MCU
     yy, xx = np.mgrid[0:H, 0:W]
     img = np.stack([(xx * 255 // W), (yy * 255 // H), ((xx + yy) * 3 % 256)], -1).astype(np.uint8)
     img[30:60, 40:90] = (200, 30, 60)
     blob = _jpeg_bytes(img, 90, subsampling)
-    sd = sens.SensorData.create(W, H, 8, 8, np.eye(4), np.eye(4), color_compression=2, depth_compression=0)
-    sd.add_frame(np.zeros((8, 8), np.uint16), np.eye(4), color=blob)
-    p = str(tmp_path / "j.sens")
-    sd.save(p)
-    ours = sens.SensorData(p).frames[0].decompress_color().astype(np.int32)
+    ours = calibrate.jpeg_decode(blob, W, H).astype(np.int32)
     pil = np.asarray(Image.open(io.BytesIO(blob)).convert("RGB")).astype(np.int32)
     diff = np.abs(ours - pil)
-    assert diff.max() <= 4 and diff.mean() < 0.5
-    if oracle.ref_sens_available():
-        R = oracle.ref_sens()
-        h = R.ref_sens_open(p.encode())
-        ref = np.zeros((H, W, 3), np.uint8)
-        assert R.ref_sens_decode_color(h, 0, ref.ctypes.data_as(C.c_void_p)) == 0
-        R.ref_sens_close(h)
-        d2 = np.abs(ours - ref.astype(np.int32))
-        # stb's h2v1 resampler treats the last two columns differently from libjpeg(-turbo) (which we match
-        # exactly above): allow a handful of edge pixels, keep the bulk within the T.81 accuracy band
-        assert (d2.max(-1) > 4).mean() < 0.002 and d2.mean() < 0.5
+    # 4:2:2: the reference's (hence our) resampler weights the last chroma column differently from libjpeg (jpeg_idct.h)
+    assert (diff.max(-1) > 4).mean() < 0.02 and diff.mean() < 0.6
+
+
+@pytest.mark.parametrize("size", [(136, 104), (17, 9), (1, 1), (2, 3), (33, 31), (16, 16), (15, 16), (3, 50), (640, 480)])
+def test_jpeg_decode_identical_to_reference(oracle, tmp_path, size):
+    """the reference decodes colour with stb_image's integer IDCT / resampler / YCbCr (sensorData.h:609-616,
+    stb_image.h:1969,2871-2933,3095) -- integer work, so the bar is identity: 4:4:4 / 4:2:2 / 4:2:0, sizes that are not whole MCUs,
+    three qualities, with and without restart markers."""
+    PIL = pytest.importorskip("PIL")
+    from PIL import Image
+    if not oracle.ref_sens_available():
+        pytest.skip("reference build absent")
+    W, H = size
+    img = _test_picture(W, H)
+    for sub in (0, 1, 2):
+        for q, rst in ((90, 0), (30, 3), (100, 0)) if W * H < 100000 else ((90, 0),):
+            buf = io.BytesIO()
+            kw = dict(restart_marker_blocks=rst) if rst else {}
+            Image.fromarray(img).save(buf, format="JPEG", quality=q, subsampling=sub, **kw)
+            ours, ref = _decode_both(oracle, tmp_path, buf.getvalue(), W, H)
+            assert np.array_equal(ours, ref), (size, sub, q, rst, int(np.abs(ours.astype(int) - ref).max()))
+
+
+LAYOUTS = {"440": ((1, 2), (1, 1), (1, 1)), "411": ((4, 1), (1, 1), (1, 1)), "410": ((4, 2), (1, 1), (1, 1)), "422": ((2, 1), (1, 1), (1, 1)),
+           "420": ((2, 2), (1, 1), (1, 1)), "v4": ((1, 4), (1, 1), (1, 1)), "h2v4": ((2, 4), (1, 1), (1, 1)), "luma-subsampled": ((1, 1), (2, 2), (2, 2)),
+           "mixed": ((2, 2), (2, 1), (1, 2)), "h3": ((3, 1), (1, 1), (1, 1)), "grey": ((1, 1),)}
+
+
+@pytest.mark.parametrize("layout", sorted(LAYOUTS))
+def test_jpeg_unusual_layouts_identical_to_reference(oracle, tmp_path, layout):
+    """Sampling factors PIL cannot write (tests/jpeg_tools.py): stb resamples (1,2) / (2,1) / (2,2) with the triangle filter and everything
+    else with nearest neighbour (stb_image.h:3356-3361); grey pictures become r = g = b."""
+    if not oracle.ref_sens_available():
+        pytest.skip("reference build absent")
+    from tests import jpeg_tools
+    for W, H in ((40, 24), (17, 9), (1, 1), (33, 35)):
+        img = _test_picture(W, H, seed=W, noise=30)
+        if layout == "grey":
+            img = img[..., 0]
+        for rst in (0, 2):
+            blob = jpeg_tools.encode(img, LAYOUTS[layout], qstep=3, restart=rst)
+            ours, ref = _decode_both(oracle, tmp_path, blob, W, H)
+            assert np.array_equal(ours, ref), (layout, W, H, rst)
+
+
+def test_jpeg_rejects_what_the_reference_rejects():
+    """Over-subscribed Huffman code lengths (stb_image.h:1543 'bad code lengths'; before this check a 230-byte file wrote 100 KB past
+    the look-up table), 16-bit quantisation tables (stb_image.h:2625), a DRI segment that is not 4 bytes long (:2612), a stream
+    that ends inside a run of 0xFF fill bytes."""
+    from tests import jpeg_tools
+    from scannet_amd import calibrate
+    good = jpeg_tools.encode(_test_picture(16, 16), ((2, 2), (1, 1), (1, 1)))
+    assert calibrate.jpeg_decode(good, 16, 16).shape == (16, 16, 3)
+    i = good.index(b"\xff\xc4")
+    bad = bytearray(good)
+    bad[i + 5:i + 5 + 16] = bytes([3, 9] + [0] * 14)   # three codes of length 1 (and still 12 values: only the code-space check can object)
+    with pytest.raises(_abi.ScanfuseError, match="code lengths"):
+        calibrate.jpeg_decode(bytes(bad), 16, 16)
+    j = good.index(b"\xff\xdb")
+    bad = bytearray(good)
+    bad[j + 4] = 0x10
+    with pytest.raises(_abi.ScanfuseError, match="16-bit quantisation"):
+        calibrate.jpeg_decode(bytes(bad), 16, 16)
+    k = good.index(b"\xff\xda")
+    with pytest.raises(_abi.ScanfuseError, match="DRI"):
+        calibrate.jpeg_decode(good[:k] + b"\xff\xdd\x00\x02" + good[k:], 16, 16)
+    with pytest.raises(_abi.ScanfuseError):
+        calibrate.jpeg_decode(good[:k] + b"\xff\xff\xff", 16, 16)
 
 
 def test_jpeg_restart_intervals_against_pil(tmp_path):
@@ -236,5 +316,6 @@ def test_jpeg_restart_intervals_against_pil(tmp_path):
         ours = calibrate.jpeg_decode(blob, W, H).astype(np.int32)
         pil = np.asarray(Image.open(io.BytesIO(blob)).convert("RGB")).astype(np.int32)
         diff = np.abs(ours - pil)
-        assert diff.max() <= 4 and diff.mean() < 0.5, (sub, blocks, diff.max())
+        # not identity: libjpeg's IDCT differs, and at 4:2:2 so does its last chroma column (identity is against the reference, above)
+        assert (diff.max(-1) > 4).mean() < 0.02 and diff.mean() < 0.6, (sub, blocks, diff.max())
 
