@@ -68,7 +68,7 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   // given in sf_params (raw or JPEG); anything else: geometry only
   const bool same_res = s->info.color_width == s->info.depth_width && s->info.color_height == s->info.depth_height;
   const bool own_res = f->pk.cW > 0 && (int)s->info.color_width == f->pk.cW && (int)s->info.color_height == f->pk.cH;
-  const bool use_rgb = ((same_res && f->pk.cW == 0) || own_res) && (s->info.color_compression == 0 || s->info.color_compression == 2);
+  const bool use_rgb = ((same_res && f->pk.cW == 0) || own_res) && (s->info.color_compression >= 0 && s->info.color_compression <= 2);   // raw, PNG (host decode), JPEG
   const size_t cpx = f->pk.cW > 0 ? (size_t)f->pk.cW * f->pk.cH : npx;
   // default pool size: inflating a depth frame takes ~0.13 ms, so 32 threads outrun the GPU (measured: 16 threads 28 k frames/s,
   // 64 threads 26 k); baseline-JPEG colour costs milliseconds per frame and takes up to 64 (128 measured slower: 5.0 k vs 8.1 k frames/s)

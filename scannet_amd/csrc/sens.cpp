@@ -22,6 +22,7 @@
 #include "sens.h"
 
 int jpeg_decode_rgb(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t expect_w, uint32_t expect_h);  // jpeg.cpp
+int png_decode_rgb(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t expect_w, uint32_t expect_h);   // png.cpp
 
 namespace {
 
@@ -144,8 +145,13 @@ int sens_decode_depth(const sf_sens* s, uint64_t i, uint16_t* dst) {
       if (got != want) return sf::fail(SF_ERR_FORMAT, "depth frame %llu inflates to %llu bytes, expected %llu", (unsigned long long)i, (unsigned long long)got, (unsigned long long)want);
       return SF_OK;
     }
-    case 2:
-      return sf::fail(SF_ERR_UNSUPPORTED, "TYPE_OCCI_USHORT depth needs the Windows-only uplinksimple codec (sensorData.h:711-722)");
+    case 2: {  // TYPE_OCCI_USHORT, sensorData.h:711-722: uplinksimple::decode + shift2depth (built only under _USE_UPLINK_COMPRESSION there)
+      if (!f.depth || f.depth_bytes == 0) return sf::fail(SF_ERR_FORMAT, "frame %llu has no depth data", (unsigned long long)i);
+      const uint64_t npx = (uint64_t)s->info.depth_width * s->info.depth_height;
+      const int rc = sf_occ_decode(f.depth, f.depth_bytes, npx, dst);
+      if (rc != SF_OK) return rc;
+      return sf_occ_shift2depth_buffer(dst, npx, 0);
+    }
     default:
       return sf::fail(SF_ERR_FORMAT, "unknown depth compression type %d", s->info.depth_compression);
   }
@@ -169,8 +175,8 @@ SF_API int sf_sens_decode_color(const sf_sens* s, uint64_t frame, uint8_t* dst) 
       return SF_OK;
     case 2:  // TYPE_JPEG, sensorData.h:609-616
       return jpeg_decode_rgb(f.color, f.color_bytes, dst, s->info.color_width, s->info.color_height);
-    case 1:
-      return sf::fail(SF_ERR_UNSUPPORTED, "TYPE_PNG colour is not produced by any ScanNet tool (Converter/main.cpp:37) and is not implemented");
+    case 1:  // TYPE_PNG: the same stb call as JPEG in the reference (sensorData.h:609-616)
+      return png_decode_rgb(f.color, f.color_bytes, dst, s->info.color_width, s->info.color_height);
     default:
       return sf::fail(SF_ERR_FORMAT, "unknown colour compression type %d", s->info.color_compression);
   }
@@ -196,8 +202,8 @@ SF_API int sf_sens_frame_meta(const sf_sens* s, uint64_t frame, sf_sens_frame_me
 // ------------------------------------------------------------------------------------------------ writer
 SF_API int sf_sens_create(const sf_sens_info* header, sf_sens** out) {
   if (!header || !out) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
-  if (header->depth_compression != 0 && header->depth_compression != 1)
-    return sf::fail(SF_ERR_UNSUPPORTED, "writer supports depth compression 0 (raw) and 1 (zlib) only");
+  if (header->depth_compression < 0 || header->depth_compression > 2)
+    return sf::fail(SF_ERR_UNSUPPORTED, "writer supports depth compression 0 (raw), 1 (zlib) and 2 (Occipital shift code) only");
   sf_sens* s = new sf_sens();
   s->info = *header;
   s->info.version = 4;
@@ -224,6 +230,14 @@ SF_API int sf_sens_add_frame(sf_sens* s, const uint8_t* color, uint64_t color_by
       f.owned.resize(color_bytes + raw);
       std::memcpy(f.owned.data() + color_bytes, depth, raw);
       dbytes = raw;
+    } else if (s->info.depth_compression == 2) {
+      // TYPE_OCCI_USHORT as the reference writes it (sensorData.h:672-684): the values are coded AS GIVEN -- they are sensor shift
+      // values, the reader maps them to millimetres through the shift table (sensorData.h:715-716)
+      const uint64_t bound = sf_occ_encode_bound(raw / 2);
+      f.owned.resize(color_bytes + bound);
+      const int rc = sf_occ_encode(depth, raw / 2, f.owned.data() + color_bytes, bound, &dbytes);
+      if (rc != SF_OK) return rc;
+      f.owned.resize(color_bytes + dbytes);
     } else {
       const uint64_t bound = sf_zlib_deflate_bound(raw);
       f.owned.resize(color_bytes + bound);

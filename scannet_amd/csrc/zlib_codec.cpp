@@ -154,7 +154,7 @@ int inflate_block(BitReader& br, const Huffman& lit, const Huffman& dist, uint8_
     if (sym < 256) {
       if (pos >= cap) return sf::fail(SF_ERR_BOUNDS, "inflate: output exceeds %llu bytes", (unsigned long long)cap);
       out[pos++] = (uint8_t)sym;
-      // a second literal without refilling: the reservoir still holds >= 41 bits
+      // a second symbol without refilling: the reservoir still holds >= 41 bits, a code takes at most 15
       sym = decode_sym(br, lit);
       if (sym < 0) return sf::fail(SF_ERR_FORMAT, "inflate: bad literal/length code");
       if (sym < 256) {
@@ -170,6 +170,8 @@ int inflate_block(BitReader& br, const Huffman& lit, const Huffman& dist, uint8_
     sym -= 257;
     if (sym >= 29) return sf::fail(SF_ERR_FORMAT, "inflate: bad length symbol");
     uint32_t len = LEN_BASE[sym] + br.take(LEN_EXTRA[sym]);
+    // worst case so far 15 + 15 + 5 of the >= 56 bits; a distance needs up to 15 + 13 more (dynamic codes of maximum length)
+    if (br.cnt < 28) br.refill();
     const int ds = decode_sym(br, dist);
     if (ds < 0 || ds >= 30) return sf::fail(SF_ERR_FORMAT, "inflate: bad distance code");
     const uint32_t d = DIST_BASE[ds] + br.take(DIST_EXTRA[ds]);
