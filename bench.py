@@ -117,7 +117,7 @@ def pmc_traffic(steps, warmup, timeout_s=300, single_frame=False):
                     child_line = json.loads(ln)
             db = sqlite3.connect(dbs[0])
             # the integrate launches of the timed region are the LAST `steps` dispatches of the kernel (warm-up comes first)
-            # one frame per launch (SF_BATCH=1) runs the software-pipelined k_integrate_pipe, batches run k_integrate
+            # one frame per launch (batch = 1) runs the software-pipelined k_integrate_pipe, batches run k_integrate
             pat = "%k_integrate_pipe%" if single_frame else "%k_integrate<1, false%"
             rows = [v for (v,) in db.execute("select value from counters_collection where counter_name = ? and kernel_name like ? "
                                              "order by dispatch_id", (counter, pat))]
@@ -149,7 +149,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not bracket the integrate kernel with HIP events")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes that measure roofline.traffic")
     ap.add_argument("--pmc-steps", type=int, default=400)
-    ap.add_argument("--single-frame", action="store_true", help="one frame per launch (SF_BATCH=1) for the main measurement")
+    ap.add_argument("--single-frame", action="store_true", help="one frame per launch (batch = 1) for the main measurement")
     ap.add_argument("--no-single-frame", action="store_true", help="skip the secondary one-frame-per-launch roofline pass")
     ap.add_argument("--teardown", action="store_true", help="leave through the interpreter's normal teardown (set for the runs under rocprofv3)")
     args = ap.parse_args()
@@ -184,10 +184,7 @@ def main():
 
     def run(n_warm, n_timed, profile, single_frame=False):
         """Fuse frames [0, n_warm) untimed, then frames [n_warm, n_warm + n_timed) between two barrier+synchronize pairs."""
-        if single_frame:
-            os.environ["SF_BATCH"] = "1"   # read once, at sf_fuser_create
-        fuser = fusion.Fuser(params, device=local_rank)
-        os.environ.pop("SF_BATCH", None)
+        fuser = fusion.Fuser(params, device=local_rank, **({"batch": 1} if single_frame else {}))
 
         def sync_all():
             fuser.sync()
@@ -275,7 +272,7 @@ def main():
             # the same kernel HBM-bound: one frame per launch (what sf_fuser_integrate does for a live stream)
             ks = min(K, 1200)
             m1 = run(Wm, ks, True, single_frame=True)
-            r1 = roofline(m1, ks, "k_integrate_pipe<true,true>: one frame per launch (SF_BATCH=1), persistent, software-pipelined "
+            r1 = roofline(m1, ks, "k_integrate_pipe<true,true>: one frame per launch (batch = 1), persistent, software-pipelined "
                                   "(tiles and depth gathers of later tiles in flight into LDS), everything on one stream")
             if r1 is not None:
                 r1["frames_per_s"] = round(ks / m1["elapsed"], 1)

@@ -1,0 +1,56 @@
+/* scanfuse_internal.h -- NOT part of the drop-in boundary.
+ *
+ * Entry points libscanfuse.so exports for this repository's own bench.py, tools/ and tests/: measurement aids, scheduling
+ * switches, a device self-test and the synthetic stream source.  Nothing a pipeline stage needs is declared here; the
+ * product ABI is include/scanfuse.h.  (Round 1 kept these in the public header and read the switches from SF_* environment
+ * variables inside sf_fuser_create; they now live behind this header and sf_fuser_tune.)
+ */
+#ifndef SCANFUSE_INTERNAL_H
+#define SCANFUSE_INTERNAL_H
+
+#include "scanfuse.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Scheduling switches of a fuser (results are bit-identical under all of them; tests/test_gpu_tsdf.py runs the matrix):
+ *   "batch"       1..16  frames fused per pass over the voxel tiles (default 16; 1 = what sf_fuser_integrate gives a live stream)
+ *   "overlap"     0/1    pre-pass / allocation / compaction of the next batch on a second stream (default 1)
+ *   "xcd_walk"    0/1    each XCD walks one contiguous eighth of the block list (default 1)
+ *   "pipe"        0/1    colourless one-frame passes run the software-pipelined persistent kernel (default 1)
+ *   "pipe_wgs"    1..3   persistent workgroups per CU of that kernel (default 3)
+ *   "pipe_overlap" 0/1   the next frame's pre-pass / allocation / compaction runs on the second stream beside that kernel (default 1)
+ *   "alloc_group" 1..16  consecutive frames one allocation workgroup walks (default 4)
+ * Synchronises the fuser.  SF_ERR_INVALID_ARG for an unknown key or a value out of range. */
+int sf_fuser_tune(sf_fuser* f, const char* key, int value);
+
+/* Kernel timing with HIP events on the fuser's stream: when enabled, every integrate launch is bracketed
+ * by an event pair; sf_fuser_profile_read sums and clears them (synchronises). */
+int sf_fuser_profile_enable(sf_fuser* f, int on);
+int sf_fuser_profile_read(sf_fuser* f, double* integrate_ms, uint64_t* launches, uint64_t* blocks);
+
+/* Synthetic stream source (benchmark input): renders frames
+ * [first_frame, first_frame+n) of the `total_frames`-frame box-room walk as u16 millimetre depth directly
+ * into device memory and returns the n camToWorld poses (n*16 floats, host).
+ */
+int sf_synth_room_device(void* d_depth, uint64_t frame_stride_bytes, uint64_t first_frame, uint64_t n, uint64_t total_frames,
+                         int width, int height, int noise, float* poses_out);
+
+/* Device self-test: the hand-expanded correctly rounded divisions of the integrate kernel against the hardware's IEEE
+ * division -- all 2^23 mantissas x 9 exponents for 1/x, 511 integer divisors x 2^21 numerators for n/m.  Both counts
+ * must be 0 (tests/test_gpu_tsdf.py). */
+int sf_selftest_division(int device, uint64_t* recip_mismatches, uint64_t* quot_mismatches);
+
+/* Measurement aid (bench.py roofline_single_frame.pattern_ceiling): the memory traffic of the most recent integrate pass
+ * without its arithmetic -- every tile of that pass's list is read and (read_only == 0) written back unchanged, with the
+ * integrate kernel's launch geometry; iters timed launches, average duration in microseconds.  The volume is unchanged. */
+int sf_fuser_calib_tile_rmw(sf_fuser* f, int read_only, int iters, double* avg_us, uint32_t* tiles);
+
+/* PMC calibration stream (tools/pmc_calibrate.py): known-byte-count 16 B/lane RMW + read-only launches. */
+int sf_calib_stream(int device, uint64_t bytes, int iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -114,6 +114,11 @@ def _declare_optional(L):
         "sf_fuser_set_slab": ([vp, C.c_int, i32, i32], C.c_int),
         "sf_fuser_export_blocks_where": ([vp, C.c_int, i32, i32, C.c_int, vp, vp, u64, C.POINTER(u64), C.c_int], C.c_int),
         "sf_fuser_import_blocks": ([vp, vp, vp, u64, C.c_int, C.c_int], C.c_int),
+        "sf_fuser_set_stripes": ([vp, C.c_int, i32, i32, C.c_int, C.c_int], C.c_int),
+        "sf_fuser_export_boundary": ([vp, vp, vp, u64, C.POINTER(u64), C.c_int], C.c_int),
+        "sf_fuser_import_ghosts": ([vp, vp, vp, u64, C.c_int, C.POINTER(u64)], C.c_int),
+        "sf_fuser_tune": ([vp, C.c_char_p, C.c_int], C.c_int),
+        "sf_mesh_copy_face_keys": ([vp, vp], C.c_int),
         "sf_calib_stream": ([C.c_int, u64, C.c_int], C.c_int),
         "sf_fuser_calib_tile_rmw": ([vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint32)], C.c_int),
         "sf_fuser_extract_mesh": ([vp, C.POINTER(vp)], C.c_int),

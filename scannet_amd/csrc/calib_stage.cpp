@@ -124,15 +124,17 @@ SF_API int sf_calibrate_sens(const char* in_sens, const char* out_sens, const ch
     work();
     for (std::thread& t : pool) t.join();
   };
+  // colour is a property of the FILE, not of where a frame falls in a batch: a scan without any colour blob is calibrated depth-only; in a
+  // scan that has colour, a frame without a blob is an error, as it is for the reference (which decompresses colour per frame,
+  // calibration.h:185-190, and throws on an empty blob, sensorData.h:607)
+  bool rgb = false;
+  for (uint64_t k = 0; k < nframes && !rgb; k++) rgb = in->frames[k].color_bytes != 0;
   for (uint64_t f0 = 0; f0 < nframes; f0 += (uint64_t)B) {
     const int cnt = (int)std::min<uint64_t>((uint64_t)B, nframes - f0);
-    // a batch is processed with colour only when every frame of it has a colour blob (real scans: all or none)
-    bool rgb = true;
-    for (int k = 0; k < cnt; k++) rgb = rgb && in->frames[f0 + k].color_bytes != 0;
     parallel(cnt, [&](int k) {
       rcs[k] = sens_decode_depth(in, f0 + k, &d_in[(size_t)k * npx]);
       pay_bytes[k] = 0;
-      if (rcs[k] == SF_OK && rgb && jpeg_in) {
+      if (rcs[k] == SF_OK && rgb && jpeg_in && in->frames[f0 + k].color_bytes != 0) {
         const SensFrame& fr = in->frames[f0 + k];
         uint8_t* pp = reinterpret_cast<uint8_t*>(pay[k].data());
         if (jpeg_decode_coef(fr.color, fr.color_bytes, hi.color_width, hi.color_height, pp, pay_cap) == SF_OK)

@@ -5,6 +5,7 @@
 #include <string>
 
 #include "../../include/scanfuse.h"
+#include "../../include/scanfuse_internal.h"
 
 namespace sf {
 

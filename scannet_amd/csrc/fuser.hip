@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "fuser_internal.h"
@@ -722,7 +723,8 @@ __global__ __launch_bounds__(256, 4) void k_integrate(uint4* __restrict__ voxels
 //   mid : the gathers of tile k (issued last turn) have landed -- younger: D(k+2) 4, S(k-1), G(k+1) 8, D(k+3) 4 => vmcnt(16)
 // (stores only make the true count larger, i.e. the waits conservative).  hipcc never sees these loads (it would wait
 // vmcnt(0) at every use while an LDS-DMA is in flight); it only sees ordinary ds_reads after the waits.
-// LDS per wave: 2 x 4 KiB tiles + 2 x 2 KiB gathers = 12 KiB => 3 workgroups (12 waves) per CU.  Geometry only, no colour:
+// LDS per wave: 2 x 4 KiB tiles + 2 x 2 KiB gathers = 12 KiB => 3 workgroups (12 waves, 144 KiB) per CU, and 16 KiB left for a workgroup of
+// the next frame's allocation (10.6 KiB for one frame per launch) to run beside it.  Geometry only, no colour:
 // the colour variant stays on k_integrate.  Arithmetic = fuse_project / fuse_update, bit-identical to k_integrate.
 // ---------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -731,7 +733,6 @@ template <bool TAB, bool WS1>
 __global__ __launch_bounds__(256, 3) void k_integrate_pipe(uint4* __restrict__ voxels, const uint64_t* __restrict__ block_keys,
                                                         const int32_t* __restrict__ compact, const float* __restrict__ depthf, int32_t* counters,
                                                         int32_t* host_mirror, int compact_counter, ParamsK P, BatchTi B) {
-  __shared__ float s_rtab[RTAB];
   __shared__ uint4 s_tile[4][2][256];   // per wave: two 4 KiB tile slots
   __shared__ float s_gath[4][2][512];   // per wave: two slots of 8 gathers x 64 lanes
   const int lane = threadIdx.x & 63;
@@ -780,10 +781,6 @@ __global__ __launch_bounds__(256, 3) void k_integrate_pipe(uint4* __restrict__ v
           [d] "s"(depthf), [b] "s"(base)
         : "memory", "scc");
   };
-  if (TAB) {
-    for (int t = threadIdx.x; t < RTAB; t += 256) s_rtab[t] = 1.0f / (float)(t > 0 ? t : 1);
-    __syncthreads();
-  }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     atomicExch(&counters[C_LAST_BLOCKS], counters[compact_counter + 1]);
     if (host_mirror) *host_mirror = n;
@@ -863,10 +860,13 @@ __global__ __launch_bounds__(256, 3) void k_integrate_pipe(uint4* __restrict__ v
     float d[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) d[k] = gath[par * 512 + k * 64 + lane];
+    // RN(1 / (weight + sample)) by v_rcp_f32 + two Newton steps (recip_rn: correctly rounded for every normal divisor, the same bits
+    // as k_integrate's LDS table) -- this kernel has VALU slots to spare and its LDS decides who may run beside it: 48 KiB per
+    // workgroup x 3 leaves 16 KiB per CU, room for one workgroup of the NEXT frame's allocation / compaction on the front stream
     v2f rcp_m[4];
     if (TAB) {
 #pragma unroll
-      for (int j = 0; j < 4; j++) rcp_m[j] = (v2f){s_rtab[(v[j].y >> 24) + (uint32_t)P.wsample], s_rtab[(v[j].w >> 24) + (uint32_t)P.wsample]};
+      for (int j = 0; j < 4; j++) rcp_m[j] = recip_rn((v2f){(float)((v[j].y >> 24) + (uint32_t)P.wsample), (float)((v[j].w >> 24) + (uint32_t)P.wsample)});
     }
     bool ok[8];
 #pragma unroll
@@ -998,11 +998,11 @@ __global__ __launch_bounds__(256) void k_gather(const uint4* __restrict__ voxels
   }
 }
 
-// Filtered export: the live blocks whose coordinate on `axis` lies in [lo, hi) (axis < 0: all), appended in no
-// particular order.  One workgroup per candidate block.
+// Filtered export: the live blocks whose coordinate on `axis` lies in [lo, hi) (axis == -1: all; axis == -2: the boundary layers
+// of this fuser's slab / stripes), appended in no particular order.  One workgroup per candidate block.
 __global__ __launch_bounds__(256) void k_gather_where(const uint4* __restrict__ voxels, const uint64_t* __restrict__ block_keys,
                                                       const int32_t* __restrict__ live, int n, int axis, int lo, int hi, int capacity,
-                                                      int32_t* counter, int32_t* coords, uint4* out) {
+                                                      int32_t* counter, int32_t* coords, uint4* out, ParamsK P) {
   __shared__ int s_pos;
   for (int i = blockIdx.x; i < n; i += gridDim.x) {
     const int slot = live[i];
@@ -1010,6 +1010,7 @@ __global__ __launch_bounds__(256) void k_gather_where(const uint4* __restrict__ 
     unpack_key(block_keys[slot], bx, by, bz);
     const int c = axis == 0 ? bx : (axis == 1 ? by : bz);
     if (axis >= 0 && (c < lo || c >= hi)) continue;  // uniform per workgroup
+    if (axis == -2 && !slab_boundary(P, bx, by, bz)) continue;  // the boundary layers of this fuser's slab / stripes
     if (threadIdx.x == 0) s_pos = atomicAdd(counter, 1);
     __syncthreads();
     const int pos = s_pos;
@@ -1021,8 +1022,9 @@ __global__ __launch_bounds__(256) void k_gather_where(const uint4* __restrict__ 
   }
 }
 
-// Import: one workgroup per block; lane 0 finds or creates the entry (+ heap pop), all lanes copy the 4 KiB tile.
-__global__ __launch_bounds__(256) void k_import(const int32_t* __restrict__ coords, const uint4* __restrict__ src, int n, int ghost,
+// Import: one workgroup per block; lane 0 finds or creates the entry (+ heap pop), all lanes copy the 4 KiB tile.  only_wanted: of an
+// all-gathered payload keep just the blocks this fuser needs as ghosts (slab_wants_ghost), counted in C_IMPORTED.
+__global__ __launch_bounds__(256) void k_import(const int32_t* __restrict__ coords, const uint4* __restrict__ src, int n, int ghost, int only_wanted,
                                                 uint4* voxels, HashEntry* table, int32_t* heap, uint64_t* block_keys, int32_t* block_entry,
                                                 uint8_t* block_flags, int32_t* counters, ParamsK P) {
   __shared__ int s_slot;
@@ -1030,17 +1032,19 @@ __global__ __launch_bounds__(256) void k_import(const int32_t* __restrict__ coor
   for (int i = blockIdx.x; i < n; i += gridDim.x) {
     if (threadIdx.x == 0) {
       const int bx = coords[3 * i], by = coords[3 * i + 1], bz = coords[3 * i + 2];
-      const uint64_t key = pack_key(bx, by, bz);
-      HashEntry* e = hash_find_or_claim(h, P, key, bx, by, bz, 0u);
       int slot = -1;
-      if (e) {
-        atomicAdd(&counters[C_SLOTS_USED], 1);
-        give_block(h, e, key, atomicSub(&counters[C_HEAP_FREE], 1) - 1);
-        slot = e->ptr >= 0 && block_keys[e->ptr] == key ? e->ptr : -1;  // -1: heap exhausted
-      } else {
-        slot = hash_lookup(table, P, bx, by, bz);  // already present (re-import): overwrite
+      if (!only_wanted || slab_wants_ghost(P, bx, by, bz)) {
+        const uint64_t key = pack_key(bx, by, bz);
+        HashEntry* e = hash_find_or_claim(h, P, key, bx, by, bz, 0u);
+        if (e) {
+          atomicAdd(&counters[C_SLOTS_USED], 1);
+          give_block(h, e, key, atomicSub(&counters[C_HEAP_FREE], 1) - 1);
+          slot = e->ptr >= 0 && block_keys[e->ptr] == key ? e->ptr : -1;  // -1: heap exhausted
+        } else {
+          slot = hash_lookup(table, P, bx, by, bz);  // already present (re-import): overwrite
+        }
+        if (slot >= 0) { block_flags[slot] = ghost ? 1 : 0; atomicAdd(&counters[C_IMPORTED], 1); }
       }
-      if (slot >= 0) block_flags[slot] = ghost ? 1 : 0;
       s_slot = slot;
     }
     __syncthreads();
@@ -1106,10 +1110,11 @@ bool frame_setup(const sf_params& p, const float* pose, FrameK& f) {
 // One frame per launch without colour runs the persistent k_integrate_pipe, which fills every CU: kernels of the next frame
 // on the front stream would only get CUs by starving some of its waves (measured: 113 us overlapped vs 90 us alone, and no
 // more frames/s), so such a batch goes down ONE stream, pre-pass to integrate.
-bool sf_single_stream_batch(const sf_fuser* f, int n, bool color, int sign) {
+static bool pipe_batch(const sf_fuser* f, int n, bool color, int sign) {
   const bool tab_ok = f->p.weight_sample >= 1 && f->p.weight_sample <= RTAB - 256;
   return sign > 0 && n == 1 && !color && tab_ok && f->pipe_mode != 0;
 }
+bool sf_single_stream_batch(const sf_fuser* f, int n, bool color, int sign) { return pipe_batch(f, n, color, sign) && !f->pipe_overlap; }
 // the stream the pre-pass of such a batch reads its frames on: where callers must have staged them
 hipStream_t sf_input_stream(const sf_fuser* f, int n, bool color, int sign) {
   return (f->overlap && !sf_single_stream_batch(f, n, color, sign)) ? f->front : f->stream;
@@ -1143,7 +1148,7 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
   // on the front stream would only get CUs by starving some of its waves (measured: 113 us overlapped vs 90 us alone, and
   // no more frames/s), so for such a frame everything goes down ONE stream.
   const bool tab_ok = f->p.weight_sample >= 1 && f->p.weight_sample <= RTAB - 256;
-  const bool pipe = sf_single_stream_batch(f, n, col, sign);
+  const bool pipe = pipe_batch(f, n, col, sign);
   hipStream_t sa = sf_input_stream(f, n, col, sign);  // callers stage the batch's frames on this stream too
   if (f->overlap && sa != s) {
     if (f->serial_tail) {  // single-stream batches came before: the front stream starts behind everything they queued
@@ -1257,14 +1262,19 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
   if (device < 0 || device >= ndev) return sf::fail(SF_ERR_INVALID_ARG, "device %d out of range (%d devices)", device, ndev);
   SF_HIP_CHECK(hipSetDevice(device));
   sf_fuser* f = new sf_fuser();
+  // every failure below leaves through sf_fuser_destroy (streams, events, device and pinned allocations made so far)
+#define SF_CREATE_CHECK(call)                                                                               \
+  do {                                                                                                      \
+    hipError_t e_ = (call);                                                                                 \
+    if (e_ != hipSuccess) {                                                                                 \
+      sf_fuser_destroy(f);                                                                                  \
+      return sf::fail(SF_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_));                        \
+    }                                                                                                       \
+  } while (0)
   f->p = *p;
   if (f->p.weight_max > 255) f->p.weight_max = 255;  // uchar weight saturates (SURVEY App. C decision)
   if (f->p.weight_max < 1) f->p.weight_max = 1;
   f->device = device;
-  if (const char* e = getenv("SF_NO_XCD")) f->xcd_walk = atoi(e) == 0;
-  if (const char* e = getenv("SF_PIPE")) f->pipe_mode = atoi(e);
-  if (const char* e = getenv("SF_PIPE_WGS")) f->pipe_wgs = std::max(1, std::min(3, atoi(e)));
-  if (const char* e = getenv("SF_ALLOC_GROUP")) { f->alloc_group = atoi(e); if (f->alloc_group < 1) f->alloc_group = 1; }
   {
     // longest ray segment 2 * trunc(max distance) in blocks decides the LDS window size of k_alloc
     const float seg = 2.0f * (p->trunc_base + p->trunc_scale * p->max_integration_dist) / (8.0f * p->voxel_size);
@@ -1277,12 +1287,12 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
   k.wsample = p->weight_sample; k.wmax = f->p.weight_max;
   k.num_buckets = p->hash_num_buckets; k.bucket_size = p->hash_bucket_size;
   k.total_slots = p->hash_num_buckets * p->hash_bucket_size; k.num_blocks = p->num_sdf_blocks;
-  k.slab_axis = -1; k.slab_lo = 0; k.slab_hi = 0;
+  k.slab_axis = -1; k.slab_lo = 0; k.slab_hi = 0; k.slab_thick = 0; k.slab_world = 1; k.slab_rank = 0;
   k.cW = p->color_width > 0 && p->color_height > 0 ? p->color_width : 0;
   k.cH = k.cW ? p->color_height : 0;
   k.cfx = p->cfx; k.cfy = p->cfy; k.cmx = p->cmx; k.cmy = p->cmy;
   hipDeviceProp_t prop;
-  SF_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+  SF_CREATE_CHECK(hipGetDeviceProperties(&prop, device));
   f->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   f->compact_grid = (int)((k.num_blocks + 1023) / 1024);
   if (f->compact_grid > f->num_cus * 8) f->compact_grid = f->num_cus * 8;
@@ -1295,22 +1305,19 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
       return sf::fail(SF_ERR_DEVICE, "hipMalloc(%zu bytes) failed: %s", (size_t)(bytes), hipGetErrorString(e_)); \
     }                                                                                             \
   } while (0)
-  SF_HIP_CHECK(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
+  SF_CREATE_CHECK(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
   {
     // the front stream runs short latency-bound kernels that must slip in between the workgroups of the
     // bandwidth-bound integrate kernel: give it the highest priority the device offers
     int prio_lo = 0, prio_hi = 0;
-    SF_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    if (getenv("SF_NO_PRIORITY")) prio_hi = prio_lo;
-    SF_HIP_CHECK(hipStreamCreateWithPriority(&f->front, hipStreamNonBlocking, prio_hi));
+    SF_CREATE_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    SF_CREATE_CHECK(hipStreamCreateWithPriority(&f->front, hipStreamNonBlocking, prio_hi));
   }
   for (int q = 0; q < 2; q++) {
-    SF_HIP_CHECK(hipEventCreateWithFlags(&f->ev_compact[q], hipEventDisableTiming));
-    SF_HIP_CHECK(hipEventCreateWithFlags(&f->ev_fused[q], hipEventDisableTiming));
+    SF_CREATE_CHECK(hipEventCreateWithFlags(&f->ev_compact[q], hipEventDisableTiming));
+    SF_CREATE_CHECK(hipEventCreateWithFlags(&f->ev_fused[q], hipEventDisableTiming));
   }
-  SF_HIP_CHECK(hipEventCreateWithFlags(&f->ev_input, hipEventDisableTiming));
-  if (const char* e = getenv("SF_NO_OVERLAP")) f->overlap = atoi(e) == 0;
-  if (const char* e = getenv("SF_BATCH")) { f->batch = atoi(e); if (f->batch < 1) f->batch = 1; if (f->batch > MAX_BATCH) f->batch = MAX_BATCH; }
+  SF_CREATE_CHECK(hipEventCreateWithFlags(&f->ev_input, hipEventDisableTiming));
   SF_ALLOC(f->table, (size_t)k.total_slots * sizeof(HashEntry));
   SF_ALLOC(f->heap, (size_t)k.num_blocks * 4);
   SF_ALLOC(f->block_keys, (size_t)k.num_blocks * 8);
@@ -1328,16 +1335,17 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
   SF_ALLOC(f->staging_depth, npx * 2);
   SF_ALLOC(f->staging_rgb, (k.cW ? (size_t)k.cW * k.cH : npx) * 3);
 #undef SF_ALLOC
-  SF_HIP_CHECK(hipHostMalloc((void**)&f->host_mirror, 64, hipHostMallocMapped));
+  SF_CREATE_CHECK(hipHostMalloc((void**)&f->host_mirror, 64, hipHostMallocMapped));
   *f->host_mirror = 0;
-  SF_HIP_CHECK(hipMemsetAsync(f->table, 0xFF, (size_t)k.total_slots * sizeof(HashEntry), f->stream));
-  SF_HIP_CHECK(hipMemsetAsync(f->voxels, 0, (size_t)k.num_blocks * 4096, f->stream));
-  SF_HIP_CHECK(hipMemsetAsync(f->block_flags, 0, (size_t)k.num_blocks, f->stream));
-  SF_HIP_CHECK(hipMemsetAsync(f->counters, 0, C_COUNT * 4, f->stream));
+  SF_CREATE_CHECK(hipMemsetAsync(f->table, 0xFF, (size_t)k.total_slots * sizeof(HashEntry), f->stream));
+  SF_CREATE_CHECK(hipMemsetAsync(f->voxels, 0, (size_t)k.num_blocks * 4096, f->stream));
+  SF_CREATE_CHECK(hipMemsetAsync(f->block_flags, 0, (size_t)k.num_blocks, f->stream));
+  SF_CREATE_CHECK(hipMemsetAsync(f->counters, 0, C_COUNT * 4, f->stream));
   hipLaunchKernelGGL(k_init_heap, dim3((k.num_blocks + 255) / 256), dim3(256), 0, f->stream, f->heap, f->block_keys, (int)k.num_blocks);
   const int32_t free0 = (int32_t)k.num_blocks;
-  SF_HIP_CHECK(hipMemcpyAsync(&f->counters[C_HEAP_FREE], &free0, 4, hipMemcpyHostToDevice, f->stream));
-  SF_HIP_CHECK(sf_quiesce(f));
+  SF_CREATE_CHECK(hipMemcpyAsync(&f->counters[C_HEAP_FREE], &free0, 4, hipMemcpyHostToDevice, f->stream));
+  SF_CREATE_CHECK(sf_quiesce(f));
+#undef SF_CREATE_CHECK
   *out = f;
   return SF_OK;
 }
@@ -1411,6 +1419,24 @@ SF_API int sf_fuser_integrate_batch_device(sf_fuser* f, const void* d_depth, uin
 }
 
 SF_API int sf_fuser_batch_frames(const sf_fuser* f) { return f ? f->batch : 0; }
+
+// scanfuse_internal.h: scheduling switches (bench.py, tests); every setting leaves the voxels bit-identical
+SF_API int sf_fuser_tune(sf_fuser* f, const char* key, int value) {
+  if (!f || !key) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  SF_HIP_CHECK(hipSetDevice(f->device));
+  SF_HIP_CHECK(sf_quiesce(f));
+  const std::string k(key);
+  auto in = [&](int lo, int hi) { return value >= lo && value <= hi; };
+  if (k == "batch" && in(1, MAX_BATCH)) f->batch = value;
+  else if (k == "overlap" && in(0, 1)) f->overlap = value != 0;
+  else if (k == "xcd_walk" && in(0, 1)) f->xcd_walk = value != 0;
+  else if (k == "pipe" && in(0, 1)) f->pipe_mode = value;
+  else if (k == "pipe_wgs" && in(1, 3)) f->pipe_wgs = value;
+  else if (k == "pipe_overlap" && in(0, 1)) f->pipe_overlap = value != 0;
+  else if (k == "alloc_group" && in(1, MAX_BATCH)) f->alloc_group = value;
+  else return sf::fail(SF_ERR_INVALID_ARG, "sf_fuser_tune: unknown key or value out of range: %s = %d", key, value);
+  return SF_OK;
+}
 
 // Internal (pipeline.hip): fuse n <= MAX_BATCH device-resident frames with valid poses in one pass.
 int sf_fuser_run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb, const float* const* poses, int n) {
@@ -1586,7 +1612,25 @@ SF_API int sf_fuser_set_slab(sf_fuser* f, int axis, int32_t lo_block, int32_t hi
   f->pk.slab_axis = axis < 0 ? -1 : axis;
   f->pk.slab_lo = lo_block;
   f->pk.slab_hi = hi_block;
+  f->pk.slab_thick = 0; f->pk.slab_world = 1; f->pk.slab_rank = 0;
   return SF_OK;
+}
+
+SF_API int sf_fuser_set_stripes(sf_fuser* f, int axis, int32_t origin_block, int32_t thickness_blocks, int world, int rank) {
+  if (!f) return sf::fail(SF_ERR_INVALID_ARG, "NULL fuser");
+  if (axis < 0 || axis > 2 || thickness_blocks < 1 || world < 1 || rank < 0 || rank >= world)
+    return sf::fail(SF_ERR_INVALID_ARG, "sf_fuser_set_stripes: axis %d, thickness %d, rank %d of %d", axis, thickness_blocks, rank, world);
+  SF_HIP_CHECK(hipSetDevice(f->device));
+  SF_HIP_CHECK(sf_quiesce(f));
+  f->pk.slab_axis = axis;
+  f->pk.slab_lo = origin_block;
+  f->pk.slab_hi = 0;
+  f->pk.slab_thick = thickness_blocks; f->pk.slab_world = world; f->pk.slab_rank = rank;
+  return SF_OK;
+}
+
+SF_API int sf_fuser_export_boundary(sf_fuser* f, int32_t* coords, void* voxels, uint64_t capacity, uint64_t* n_out, int dst_on_device) {
+  return sf_fuser_export_blocks_where(f, -2, 0, 0, 0, coords, voxels, capacity, n_out, dst_on_device);
 }
 
 SF_API int sf_fuser_export_blocks_where(sf_fuser* f, int axis, int32_t lo, int32_t hi, int include_ghosts, int32_t* coords, void* voxels,
@@ -1612,7 +1656,7 @@ SF_API int sf_fuser_export_blocks_where(sf_fuser* f, int axis, int32_t lo, int32
     d_vox = (uint4*)voxels;
   }
   hipLaunchKernelGGL(k_gather_where, dim3(n_live < 65535 ? n_live : 65535), dim3(256), 0, f->stream, f->voxels, f->block_keys, f->compact, n_live, axis, lo, hi,
-                     want ? cap : 0, &f->counters[C_GC_FREED], d_coords, want && cap > 0 ? d_vox : nullptr);
+                     want ? cap : 0, &f->counters[C_GC_FREED], d_coords, want && cap > 0 ? d_vox : nullptr, f->pk);
   int32_t n = 0;
   hipError_t e = hipMemcpyAsync(&n, &f->counters[C_GC_FREED], 4, hipMemcpyDeviceToHost, f->stream);
   if (e == hipSuccess) e = sf_quiesce(f);
@@ -1628,7 +1672,17 @@ SF_API int sf_fuser_export_blocks_where(sf_fuser* f, int axis, int32_t lo, int32
   return SF_OK;
 }
 
+static int import_blocks(sf_fuser* f, const int32_t* coords, const void* voxels, uint64_t n, int ghost, int src_on_device, int only_wanted, uint64_t* imported);
+
 SF_API int sf_fuser_import_blocks(sf_fuser* f, const int32_t* coords, const void* voxels, uint64_t n, int ghost, int src_on_device) {
+  return import_blocks(f, coords, voxels, n, ghost, src_on_device, 0, nullptr);
+}
+SF_API int sf_fuser_import_ghosts(sf_fuser* f, const int32_t* coords, const void* voxels, uint64_t n, int src_on_device, uint64_t* imported) {
+  return import_blocks(f, coords, voxels, n, 1, src_on_device, 1, imported);
+}
+
+static int import_blocks(sf_fuser* f, const int32_t* coords, const void* voxels, uint64_t n, int ghost, int src_on_device, int only_wanted, uint64_t* imported) {
+  if (imported) *imported = 0;
   if (!f || (n && (!coords || !voxels))) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
   if (n == 0) return SF_OK;
   if (n > 0x7FFFFFFFull) return sf::fail(SF_ERR_INVALID_ARG, "too many blocks");
@@ -1647,12 +1701,15 @@ SF_API int sf_fuser_import_blocks(sf_fuser* f, const int32_t* coords, const void
     d_coords = tmp_c;
     d_vox = tmp_v;
   }
-  int32_t fail0 = 0, fail1 = 0;
+  int32_t fail0 = 0, fail1 = 0, took = 0;
   (void)hipMemcpy(&fail0, &f->counters[C_ALLOC_FAIL], 4, hipMemcpyDeviceToHost);
-  hipLaunchKernelGGL(k_import, dim3(n < 65535 ? (unsigned)n : 65535u), dim3(256), 0, f->stream, d_coords, d_vox, (int)n, ghost, f->voxels, f->table, f->heap,
-                     f->block_keys, f->block_entry, f->block_flags, f->counters, f->pk);
+  (void)hipMemsetAsync(&f->counters[C_IMPORTED], 0, 4, f->stream);
+  hipLaunchKernelGGL(k_import, dim3(n < 65535 ? (unsigned)n : 65535u), dim3(256), 0, f->stream, d_coords, d_vox, (int)n, ghost, only_wanted, f->voxels, f->table,
+                     f->heap, f->block_keys, f->block_entry, f->block_flags, f->counters, f->pk);
   hipError_t e = hipMemcpyAsync(&fail1, &f->counters[C_ALLOC_FAIL], 4, hipMemcpyDeviceToHost, f->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(&took, &f->counters[C_IMPORTED], 4, hipMemcpyDeviceToHost, f->stream);
   if (e == hipSuccess) e = sf_quiesce(f);
+  if (imported) *imported = (uint64_t)took;
   if (tmp_c) { (void)hipFree(tmp_c); (void)hipFree(tmp_v); }
   if (e != hipSuccess) return sf::fail(SF_ERR_DEVICE, "import failed: %s", hipGetErrorString(e));
   if (fail1 != fail0) return sf::fail(SF_ERR_CAPACITY, "%d imported blocks did not fit (heap or hash table exhausted)", fail1 - fail0);

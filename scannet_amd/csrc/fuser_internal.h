@@ -27,18 +27,39 @@ struct ParamsK {
   float voxel, tbase, tscale, maxd;
   int wsample, wmax;
   uint32_t num_buckets, bucket_size, total_slots, num_blocks;
-  // slab partition of one large scan over several GPUs: this fuser only allocates blocks whose
-  // coordinate on slab_axis lies in [slab_lo, slab_hi); slab_axis < 0 = no partition
-  int slab_axis, slab_lo, slab_hi;
+  // partition of one large scan over several GPUs: this fuser only allocates blocks it owns; slab_axis < 0 = no partition.
+  //   slab_thick == 0: one contiguous slab, coordinate on slab_axis in [slab_lo, slab_hi)
+  //   slab_thick  > 0: stripes of slab_thick block layers dealt round-robin from slab_lo: owner = floor((c - slab_lo) / thick) mod world
+  //                    (every frame's blocks spread over all GPUs; a slab per GPU leaves all but one idle while the camera is elsewhere)
+  int slab_axis, slab_lo, slab_hi, slab_thick, slab_world, slab_rank;
   // colour frames at their own resolution (cW == 0: same as depth)
   int cW, cH;
   float cfx, cfy, cmx, cmy;
 };
 
+__host__ __device__ inline bool slab_owns_coord(const ParamsK& P, int c) {
+  if (P.slab_thick <= 0) return c >= P.slab_lo && c < P.slab_hi;
+  const int d = c - P.slab_lo;
+  const int q = d >= 0 ? d / P.slab_thick : -((P.slab_thick - 1 - d) / P.slab_thick);   // floor division
+  int m = q % P.slab_world;
+  if (m < 0) m += P.slab_world;
+  return m == P.slab_rank;
+}
 __host__ __device__ inline bool slab_owns(const ParamsK& P, int bx, int by, int bz) {
   if (P.slab_axis < 0) return true;
+  return slab_owns_coord(P, P.slab_axis == 0 ? bx : (P.slab_axis == 1 ? by : bz));
+}
+// lowest layer of one of this fuser's slabs / stripes: owned, the block below it on the partition axis is somebody else's
+__host__ __device__ inline bool slab_boundary(const ParamsK& P, int bx, int by, int bz) {
+  if (P.slab_axis < 0) return false;
   const int c = P.slab_axis == 0 ? bx : (P.slab_axis == 1 ? by : bz);
-  return c >= P.slab_lo && c < P.slab_hi;
+  return slab_owns_coord(P, c) && !slab_owns_coord(P, c - 1);
+}
+// what this fuser needs from the others before meshing: their boundary blocks that sit right above one of its own layers
+__host__ __device__ inline bool slab_wants_ghost(const ParamsK& P, int bx, int by, int bz) {
+  if (P.slab_axis < 0) return false;
+  const int c = P.slab_axis == 0 ? bx : (P.slab_axis == 1 ? by : bz);
+  return !slab_owns_coord(P, c) && slab_owns_coord(P, c - 1);
 }
 
 struct FrameK {
@@ -70,6 +91,7 @@ enum Counter {
   C_SLOTS_USED = 4,
   C_LAST_BLOCKS = 5,
   C_GC_FREED = 7,
+  C_IMPORTED = 8,
   // 64-bit compaction counters (8-byte aligned, own cache line): low word = entries in the compact list,
   // high word = blocks the LAST frame of the batch updates
   C_COMPACT = 16,
@@ -138,7 +160,7 @@ struct sf_fuser {
   hipEvent_t ev_input = nullptr;                   // front: the caller's staging work queued so far (single-stream batches wait for it)
   int slot = 0;
   bool serial_tail = false;  // the most recent batches ran on `stream` alone (front has not been ordered behind them yet)
-  bool overlap = true;  // SF_NO_OVERLAP=1 runs everything on one stream
+  bool overlap = true;  // sf_fuser_tune("overlap", 0) runs everything on one stream
   float* depthf2[2] = {nullptr, nullptr};      // MAX_BATCH x W*H per batch slot
   uint32_t* color2[2] = {nullptr, nullptr};    // MAX_BATCH x W*H per batch slot
   int32_t* compact2[2] = {nullptr, nullptr};   // heap slots of the blocks some frame of the batch sees
@@ -146,7 +168,7 @@ struct sf_fuser {
   int32_t* block_entry = nullptr;              // directory: table index of the entry of the block in heap slot i
   uint8_t* block_flags = nullptr;              // directory: bit 0 = ghost (imported copy of a neighbour slab's block: read by meshing, never fused or meshed)
   uint32_t frame_seq = 1;                      // sequence number of the next frame
-  int batch = MAX_BATCH;                       // frames per pass (SF_BATCH overrides, 1..MAX_BATCH)
+  int batch = MAX_BATCH;                       // frames per pass (sf_fuser_tune "batch", 1..MAX_BATCH)
   HashEntry* table = nullptr;
   int32_t* heap = nullptr;
   uint64_t* block_keys = nullptr;
@@ -158,10 +180,11 @@ struct sf_fuser {
   int32_t* host_mirror = nullptr;  // pinned, device-visible: N_blk of the most recent integrate
   int num_cus = 256;
   bool alloc_win64 = false;  // 64^3-block LDS window when a ray segment spans more than ~20 blocks
-  bool xcd_walk = true;  // k_integrate: each XCD walks one contiguous eighth of the list (SF_NO_XCD=1: plain grid-stride)
-  int pipe_mode = 1;    // 1: colourless one-frame launches run k_integrate_pipe (SF_PIPE=0: k_integrate)
-  int pipe_wgs = 3;     // persistent workgroups per CU of k_integrate_pipe (50 KiB of LDS each)
-  int alloc_group = 4;  // consecutive frames of a batch one k_alloc workgroup walks (SF_ALLOC_GROUP)
+  bool xcd_walk = true;  // k_integrate: each XCD walks one contiguous eighth of the list (tune "xcd_walk" 0: plain grid-stride)
+  int pipe_mode = 1;    // 1: colourless one-frame launches run k_integrate_pipe (tune "pipe" 0: k_integrate)
+  int pipe_wgs = 3;     // persistent workgroups per CU of k_integrate_pipe (48 KiB of LDS each)
+  bool pipe_overlap = true;  // the next frame's pre-pass / allocation / compaction runs on the front stream beside k_integrate_pipe (tune "pipe_overlap")
+  int alloc_group = 4;  // consecutive frames of a batch one k_alloc workgroup walks (tune "alloc_group")
   int compact_grid = 1024;  // 1024 directory entries per workgroup, grid-stride beyond
   uint64_t frames_integrated = 0, frames_skipped = 0;
   bool profile = false;

@@ -298,6 +298,8 @@ SF_API int sf_fuser_extract_mesh(sf_fuser* f, sf_mesh** out) {
   m->col.resize((size_t)NU * 4);
   m->keys.resize(NU);
   m->tri.resize((size_t)T * 3);
+  m->tkeys.resize(T);
+  MC_CHECK(hipMemcpyAsync(m->tkeys.data(), d_tkey_s.p, (size_t)T * 8, hipMemcpyDeviceToHost, s));
   MC_CHECK(hipMemcpyAsync(m->pos.data(), d_opos.p, (size_t)NU * 12, hipMemcpyDeviceToHost, s));
   MC_CHECK(hipMemcpyAsync(m->col.data(), d_ocol.p, (size_t)NU * 4, hipMemcpyDeviceToHost, s));
   MC_CHECK(hipMemcpyAsync(m->keys.data(), d_okey.p, (size_t)NU * 8, hipMemcpyDeviceToHost, s));

@@ -348,6 +348,13 @@ SF_API int sf_mesh_counts(const sf_mesh* m, uint64_t* nv, uint64_t* nf) {
   return SF_OK;
 }
 
+SF_API int sf_mesh_copy_face_keys(const sf_mesh* m, uint64_t* face_keys) {
+  if (!m || !face_keys) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  if (m->tkeys.size() * 3 != m->tri.size()) return sf::fail(SF_ERR_INVALID_ARG, "mesh has no face keys");
+  std::memcpy(face_keys, m->tkeys.data(), m->tkeys.size() * 8);
+  return SF_OK;
+}
+
 SF_API int sf_mesh_copy(const sf_mesh* m, float* xyz, uint8_t* rgba, uint32_t* tris, uint64_t* keys) {
   if (!m) return sf::fail(SF_ERR_INVALID_ARG, "NULL mesh");
   if (xyz) std::memcpy(xyz, m->pos.data(), m->pos.size() * 4);

@@ -55,12 +55,22 @@ def _ptr(a):
 
 
 class Fuser:
-    def __init__(self, params=None, device=0):
+    def __init__(self, params=None, device=0, **tune):
         self.params = params if params is not None else default_params()
         self.device = device
         h = C.c_void_p()
         check(_abi.lib().sf_fuser_create(C.byref(self.params), int(device), C.byref(h)))
         self._h = h
+        self.tune(**tune)
+
+    def tune(self, **switches):
+        """Scheduling switches (include/scanfuse_internal.h sf_fuser_tune: batch, overlap, xcd_walk, pipe, pipe_wgs, alloc_group);
+        the voxels are bit-identical under all of them -- bench.py and the tests use this, a pipeline stage never needs to."""
+        L = _abi.lib()
+        L.sf_fuser_tune.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        for k, v in switches.items():
+            check(L.sf_fuser_tune(self._h, k.encode(), int(v)))
+        return self
 
     def close(self):
         if getattr(self, "_h", None):
@@ -117,7 +127,7 @@ class Fuser:
 
     @property
     def batch_frames(self):
-        """Frames fused per pass over the voxel tiles by integrate_batch_device / run (SF_BATCH, default 16)."""
+        """Frames fused per pass over the voxel tiles by integrate_batch_device / run (default 16; tune(batch=...))."""
         return int(_abi.lib().sf_fuser_batch_frames(self._h))
 
     def garbage_collect(self):
@@ -180,6 +190,44 @@ class Fuser:
         if voxels.nbytes != len(coords) * 4096:
             raise ValueError("voxels must hold 4096 bytes per block")
         check(_abi.lib().sf_fuser_import_blocks(self._h, _ptr(coords), _ptr(voxels), len(coords), int(bool(ghost)), 0))
+
+    def set_stripes(self, axis, origin_block, thickness_blocks, world, rank):
+        """Own the stripes floor((coord[axis] - origin) / thickness) mod world == rank (sf_fuser_set_stripes)."""
+        check(_abi.lib().sf_fuser_set_stripes(self._h, int(axis), int(origin_block), int(thickness_blocks), int(world), int(rank)))
+
+    def count_boundary(self):
+        n = C.c_uint64(0)
+        check(_abi.lib().sf_fuser_export_boundary(self._h, None, None, 0, C.byref(n), 0))
+        return n.value
+
+    def export_boundary(self, coords=None, voxels=None):
+        """The lowest block layer of each of this fuser's slabs / stripes.  Without arguments: numpy (coords int32 [n,3], voxels
+        VOXEL_DTYPE [n,512]).  With `coords` / `voxels` = device buffers (torch CUDA tensors or raw pointers, at least count_boundary()
+        blocks): written in place on the GPU, returns n -- nothing touches host memory."""
+        L = _abi.lib()
+        n = C.c_uint64(0)
+        if coords is None:
+            m = self.count_boundary()
+            c = np.zeros((m, 3), np.int32)
+            v = np.zeros((m, 512), VOXEL_DTYPE)
+            if m:
+                check(L.sf_fuser_export_boundary(self._h, _ptr(c), _ptr(v), m, C.byref(n), 0))
+            return c, v
+        cap = coords.shape[0] if hasattr(coords, "shape") else self.count_boundary()
+        check(L.sf_fuser_export_boundary(self._h, _ptr(coords), _ptr(voxels), int(cap), C.byref(n), 1))
+        return n.value
+
+    def import_ghosts(self, coords, voxels, n=None):
+        """Of a (gathered) payload keep the blocks this fuser needs as ghosts.  numpy arrays or device buffers; returns how many were kept."""
+        L = _abi.lib()
+        on_dev = not isinstance(coords, np.ndarray)
+        if not on_dev:
+            coords = np.ascontiguousarray(coords, np.int32).reshape(-1, 3)
+            voxels = np.ascontiguousarray(voxels)
+        cnt = int(coords.shape[0] if n is None else n)
+        got = C.c_uint64(0)
+        check(L.sf_fuser_import_ghosts(self._h, _ptr(coords), _ptr(voxels), cnt, 1 if on_dev else 0, C.byref(got)))
+        return got.value
 
     def extract_mesh(self):
         """Marching cubes over all live blocks -> segmentator.Mesh (vertices in edge-key order, deterministic)."""

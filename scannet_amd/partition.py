@@ -1,17 +1,28 @@
-"""One large scan over several GPUs (BASELINE configs[4]): slab partition of the block space along x.
+"""One large scan over several GPUs (BASELINE configs[4]): the block space partitioned along x.
 
 Integration is independent per block given the frame, so every rank sees every depth frame (614 KB) and fuses only the
-blocks whose x block-coordinate lies in its slab [planes[r], planes[r+1]) -- `Fuser.set_slab`.  The only exchange step
-comes before marching cubes: a cube on the last voxel layer of a slab needs the +1 neighbours, i.e. the lowest block
-layer of the slab above.  Each rank exports that one-block-thick layer, the layers are all-gathered (torch.distributed:
-RCCL over xGMI with device tensors under the nccl backend, gloo on CPU tensors in the tests) and each rank imports the
-layer that sits on its upper plane as GHOST blocks (read as neighbours, never fused or meshed).
+blocks it owns.  Two ways to own blocks (include/scanfuse.h):
+
+  * one contiguous SLAB per rank, [planes[r], planes[r+1]) -- `Fuser.set_slab`.  Fewest boundary blocks, but a camera that
+    is inside one slab keeps one GPU busy and leaves the others idle: the scan is no faster than on one GPU.
+  * STRIPES `thickness` block layers thick dealt round-robin -- `Fuser.set_stripes`.  Every frame's blocks spread over all
+    ranks (the default here: 16 layers = 0.5 m at 4 mm voxels, a fraction of the view frustum), 1/16 of the blocks take
+    part in the exchange.
+
+The only exchange step comes before marching cubes: a cube on the last voxel layer of a slab / stripe needs the +1
+neighbours, i.e. the lowest block layer of whatever lies above it.  `exchange_boundary` does it without touching host
+memory: sf_fuser_export_boundary writes that layer of every owned stripe into a device buffer, the buffers are
+all-gathered (torch.distributed: RCCL over xGMI under the nccl backend; gloo with CPU tensors in the tests), and
+sf_fuser_import_ghosts keeps, on the device, exactly the blocks this rank needs as GHOSTS (read as neighbours, never
+fused or meshed).
 
 Why x: the canonical mesh orders vertices by edge key and triangles by cube key, and x is the most significant field
-of both -- the per-slab meshes concatenate, in slab order, into exactly the mesh one GPU would have produced; boundary
-vertices (an edge shared by cubes of two slabs yields the same key and the same position on both ranks) are welded by key.
+of both -- the per-rank meshes merge by key into exactly the mesh one GPU would have produced; boundary vertices (an
+edge shared by cubes of two ranks yields the same key and the same position on both) are welded by key.
 """
 import numpy as np
+
+STRIPE_BLOCKS = 16
 
 
 def slab_planes(x_lo_block, x_hi_block, world):
@@ -31,38 +42,96 @@ def planes_from_poses(poses, voxel_size, max_depth, world):
     return slab_planes(lo, hi, world)
 
 
+def planes_from_histogram(x_blocks, world):
+    """Slab planes that give every rank the same number of blocks: `x_blocks` = x block-coordinates of the blocks a prefix of the
+    scan allocated (one fuser without a partition, or the all-gathered coordinates).  Quantiles of that histogram."""
+    x = np.sort(np.asarray(x_blocks, np.int64).reshape(-1))
+    edges = [-(1 << 20) + 1]
+    for r in range(1, world):
+        edges.append(int(x[min(len(x) - 1, (len(x) * r) // world)]) if len(x) else 0)
+    edges.append((1 << 20) - 1)
+    for r in range(1, world + 1):   # strictly increasing, whatever the histogram looks like
+        edges[r] = max(edges[r], edges[r - 1] + 1)
+    return edges
+
+
+def owner_of(x_block, origin, thickness, world):
+    """Rank that owns block layer x under set_stripes(0, origin, thickness, world, rank) -- the host-side mirror of slab_owns."""
+    return int(np.floor_divide(int(x_block) - int(origin), int(thickness)) % int(world))
+
+
+def _dist_device(group=None):
+    import torch
+    import torch.distributed as dist
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+
+
 def _all_gather_ragged(arr, group=None):
-    """All-gather numpy arrays whose first dimension differs per rank (pad to the maximum, trim after)."""
+    """All-gather arrays whose first dimension differs per rank (pad to the maximum, trim after).  numpy in -> list of numpy out
+    (staged through the backend's device); torch tensor in (already on the backend's device) -> list of tensors, no host copy."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    n = torch.tensor([arr.shape[0]], dtype=torch.int64, device=dev)
+    dev = _dist_device(group)
+    as_numpy = isinstance(arr, np.ndarray)
+    t_in = torch.from_numpy(np.ascontiguousarray(arr)).to(dev) if as_numpy else arr
+    n = torch.tensor([t_in.shape[0]], dtype=torch.int64, device=dev)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n, group=group)
     counts = [int(c.item()) for c in counts]
     m = max(counts + [1])
-    flat = np.zeros((m,) + arr.shape[1:], arr.dtype)
-    flat[:arr.shape[0]] = arr
-    t = torch.from_numpy(flat.view(np.uint8).reshape(m, -1)).to(dev)
-    outs = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(outs, t, group=group)   # the boundary all-gather of the north star (padded to the max count)
-    res = []
-    for c, o in zip(counts, outs):
-        a = o.cpu().numpy().reshape(-1).view(arr.dtype).reshape((m,) + arr.shape[1:])[:c]
-        res.append(a)
-    return res
+    flat = torch.zeros((m,) + tuple(t_in.shape[1:]), dtype=t_in.dtype, device=dev)
+    flat[:t_in.shape[0]] = t_in
+    outs = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(outs, flat, group=group)   # the boundary all-gather of the north star (padded to the max count)
+    if as_numpy:
+        return [o[:c].cpu().numpy() for c, o in zip(counts, outs)]
+    return [o[:c] for c, o in zip(counts, outs)]
+
+
+def exchange_boundary(fuser, rank=None, group=None, gather=None):
+    """Before meshing: export this rank's boundary layers, all-gather, import what this rank needs as ghosts.
+    With a process group on the nccl backend everything stays in HBM (device export -> RCCL all-gather -> device import with the
+    ownership filter in the kernel).  `gather(coords, voxels) -> (list, list)` replaces torch.distributed in single-process tests
+    (numpy).  Returns (blocks sent, ghost blocks received)."""
+    if gather is not None:
+        c, v = fuser.export_boundary()
+        all_c, all_v = gather(c, v)
+        me = rank
+    else:
+        import torch
+        import torch.distributed as dist
+        me = dist.get_rank(group) if rank is None else rank
+        dev = _dist_device(group)
+        if dev.type == "cuda":
+            n = fuser.count_boundary()
+            c = torch.empty((max(n, 1), 3), dtype=torch.int32, device=dev)
+            v = torch.empty((max(n, 1), 4096), dtype=torch.uint8, device=dev)
+            n = fuser.export_boundary(c, v) if n else 0
+            c, v = c[:n], v[:n]
+        else:   # gloo: host tensors (CPU tests)
+            cn, vn = fuser.export_boundary()
+            c, v = torch.from_numpy(cn), torch.from_numpy(np.ascontiguousarray(vn).view(np.uint8).reshape(len(cn), 4096))
+        all_c = _all_gather_ragged(c, group)
+        all_v = _all_gather_ragged(v, group)
+    got = 0
+    for r, (cc, vv) in enumerate(zip(all_c, all_v)):
+        if r == me or len(cc) == 0:
+            continue
+        if not isinstance(cc, np.ndarray) and cc.device.type == "cpu":
+            cc, vv = cc.numpy(), vv.numpy()
+        got += fuser.import_ghosts(cc, vv)
+    return int(len(c)), got
 
 
 def exchange_boundary_layers(fuser, planes, rank, group=None, gather=None):
-    """Export this rank's lowest block layer, all-gather, import the layer on this rank's upper plane as ghosts.
-    `gather(coords, voxels) -> (list of coords, list of voxels)` replaces torch.distributed (single-process tests).
-    Returns (blocks sent, ghost blocks received)."""
+    """Round-1 interface (contiguous slabs, host arrays): export the lowest block layer of this rank's slab, all-gather, import the layer
+    on this rank's upper plane.  Kept for callers that hold numpy arrays; `exchange_boundary` is the device-resident form."""
     lo, hi = planes[rank], planes[rank + 1]
     coords, vox = fuser.export_blocks_where(0, lo, lo + 1) if rank > 0 else (np.zeros((0, 3), np.int32), np.zeros((0, 512), fuser_voxel_dtype()))
     if gather is None:
         all_c = _all_gather_ragged(coords, group)
-        all_v = _all_gather_ragged(vox, group)
+        all_v = _all_gather_ragged(np.ascontiguousarray(vox).view(np.uint8).reshape(len(coords), 4096), group)
     else:
         all_c, all_v = gather(coords, vox)
     got = 0
@@ -81,12 +150,17 @@ def fuser_voxel_dtype():
 
 
 def merge_slab_meshes(parts):
-    """parts: per rank, in slab order, (xyz [n,3] f32, rgba [n,4] u8, tris [m,3] u32, keys [n] u64) of the rank's canonical
-    mesh.  Returns the canonical mesh of the whole scan: vertices unique by key in key order, triangles concatenated."""
+    """parts: per rank (xyz [n,3] f32, rgba [n,4] u8, tris [m,3] u32, keys [n] u64[, face keys [m] u64]) of the rank's canonical mesh.
+    Returns the canonical mesh of the whole scan: vertices unique by key in key order; triangles concatenated in rank order (the
+    one-GPU order for contiguous slabs) or, when every part carries face keys (Mesh.face_keys(): needed for stripes), stably sorted by
+    cube key -- every cube belongs to one rank, so that is the one-GPU order whatever the partition."""
     keys = np.concatenate([p[3] for p in parts]) if parts else np.zeros(0, np.uint64)
     xyz = np.concatenate([p[0] for p in parts]) if parts else np.zeros((0, 3), np.float32)
     rgba = np.concatenate([p[1] for p in parts]) if parts else np.zeros((0, 4), np.uint8)
     ukeys, first = np.unique(keys, return_index=True)
     tris = [np.searchsorted(ukeys, p[3][p[2].astype(np.int64)]).astype(np.uint32) for p in parts if len(p[2])]
     tris = np.concatenate(tris) if tris else np.zeros((0, 3), np.uint32)
+    if parts and all(len(p) > 4 for p in parts):
+        fk = np.concatenate([p[4] for p in parts if len(p[2])]) if len(tris) else np.zeros(0, np.uint64)
+        tris = tris[np.argsort(fk, kind="stable")]
     return xyz[first], rgba[first], tris, ukeys

@@ -54,6 +54,13 @@ class Mesh:
         check(_abi.lib().sf_mesh_copy(self._h, _ptr(xyz), _ptr(rgba), _ptr(tris), _ptr(k)))
         return (xyz, rgba, tris, k) if keys else (xyz, rgba, tris)
 
+    def face_keys(self):
+        """Marching-cubes meshes: the cube key of every face (ascending)."""
+        nv, nf = self.counts()
+        k = np.zeros(nf, np.uint64)
+        check(_abi.lib().sf_mesh_copy_face_keys(self._h, _ptr(k)))
+        return k
+
     def write_ply(self, path):
         check(_abi.lib().sf_mesh_write_ply(self._h, os.fsencode(path)))
 

@@ -157,6 +157,89 @@ def test_slab_partition_matches_one_gpu():
             f.close()
 
 
+@pytest.mark.parametrize("thickness", [4, 16])
+def test_stripe_partition_device_resident_exchange_matches_one_gpu(thickness):
+    """configs[4] with STRIPES (sf_fuser_set_stripes): block layers dealt round-robin to three fusers, so every frame's blocks spread over
+    all of them.  The boundary exchange never touches host memory: sf_fuser_export_boundary into device buffers (torch tensors stand in
+    for the all-gather output), sf_fuser_import_ghosts filters on the device.  Owned blocks partition the one-GPU block set bit for bit;
+    the merged mesh (vertices by edge key, faces by cube key) is the one-GPU mesh byte for byte."""
+    import torch
+    from scannet_amd import fusion, partition
+    W, H = 320, 240
+    fx, fy, mx, my = synth.intrinsics(W, H)
+    gp = fusion.default_params(depth_width=W, depth_height=H, fx=fx, fy=fy, mx=mx, my=my, voxel_size=0.01, num_sdf_blocks=1 << 17)
+    frames = _room_frames(24, W, H, 1200, stride=40)
+    with fusion.Fuser(gp) as whole:
+        for d, pose in frames:
+            whole.integrate(d, pose)
+        ref = whole.extract_mesh()
+        ref_arr, ref_fk = ref.arrays(keys=True), ref.face_keys()
+        wc, wv = whole.export_blocks()
+    world, origin = 3, -7
+    fusers = [fusion.Fuser(gp) for _ in range(world)]
+    try:
+        for r, f in enumerate(fusers):
+            f.set_stripes(0, origin, thickness, world, r)
+            for d, pose in frames:
+                f.integrate(d, pose)
+        owned = [f.export_blocks() for f in fusers]
+        assert sum(len(c) for c, _ in owned) == len(wc) and min(len(c) for c, _ in owned) > 0.2 * len(wc) / world
+        allc = np.concatenate([c for c, _ in owned]); allv = np.concatenate([v for _, v in owned])
+        order = np.lexsort((allc[:, 2], allc[:, 1], allc[:, 0]))
+        assert np.array_equal(allc[order], wc) and np.array_equal(allv[order].view(np.uint8), wv.view(np.uint8))
+        for r, (c, _) in enumerate(owned):
+            assert all(partition.owner_of(x, origin, thickness, world) == r for x in np.unique(c[:, 0]))
+        # exchange on the device
+        payload = []
+        for f in fusers:
+            n = f.count_boundary()
+            c = torch.empty((max(n, 1), 3), dtype=torch.int32, device="cuda")
+            v = torch.empty((max(n, 1), 4096), dtype=torch.uint8, device="cuda")
+            assert f.export_boundary(c, v) == n and n > 0
+            payload.append((c[:n], v[:n]))
+            cn, vn = f.export_boundary()                     # the host form returns the same blocks
+            assert np.array_equal(np.sort(cn.view([("", cn.dtype)] * 3), axis=0), np.sort(c[:n].cpu().numpy().view([("", cn.dtype)] * 3), axis=0))
+            assert all(partition.owner_of(x - 1, origin, thickness, world) != partition.owner_of(x, origin, thickness, world) for x in np.unique(cn[:, 0]))
+        got = [sum(f.import_ghosts(c, v) for q, (c, v) in enumerate(payload) if q != r) for r, f in enumerate(fusers)]
+        assert min(got) > 0
+        for f, (c, _) in zip(fusers, owned):                 # ghosts are not owned blocks
+            assert len(f.export_blocks_where(-1, 0, 0)[0]) == len(c)
+        parts = []
+        for f in fusers:
+            m = f.extract_mesh()
+            parts.append(m.arrays(keys=True) + (m.face_keys(),))
+        xyz, rgba, tris, keys = partition.merge_slab_meshes(parts)
+        assert np.array_equal(keys, ref_arr[3]) and np.array_equal(xyz.view(np.uint32), ref_arr[0].view(np.uint32))
+        assert np.array_equal(rgba, ref_arr[1]) and np.array_equal(tris, ref_arr[2])
+        assert np.all(np.diff(ref_fk.astype(np.int64)) >= 0)
+    finally:
+        for f in fusers:
+            f.close()
+
+
+def test_exchange_boundary_over_the_nccl_backend_on_one_gpu(tmp_path):
+    """partition.exchange_boundary through torch.distributed with the nccl (= RCCL) backend, world size 1: the device export and the
+    all-gather of device tensors run as they do on 8 GPUs (the import of the other ranks' layers is covered above)."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from scannet_amd import fusion, partition
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        W, H = 160, 120
+        fx, fy, mx, my = synth.intrinsics(W, H)
+        gp = fusion.default_params(depth_width=W, depth_height=H, fx=fx, fy=fy, mx=mx, my=my, voxel_size=0.02, num_sdf_blocks=1 << 15)
+        with fusion.Fuser(gp) as f:
+            f.set_stripes(0, 0, 2, 2, 0)     # this rank plays rank 0 of 2: it owns every other pair of layers
+            for d, pose in _room_frames(4, W, H, 400, stride=30):
+                f.integrate(d, pose)
+            sent, got = partition.exchange_boundary(f)
+            assert sent == f.count_boundary() and sent > 0 and got == 0
+    finally:
+        dist.destroy_process_group()
+
+
 def _smooth_image(W, H, k):
     yy, xx = np.mgrid[0:H, 0:W]
     img = np.stack([(xx * 255 // W + 9 * k) % 256, (yy * 255 // H), (128 + 100 * np.sin(xx / 11.0 + k) * np.cos(yy / 7.0))], -1)

@@ -338,7 +338,7 @@ def test_colour_at_its_own_resolution(oracle):
 def test_one_frame_kernels_on_sparse_and_ragged_scenes(oracle, seed, monkeypatch):
     """The persistent one-frame kernel (k_integrate_pipe) walks the list with a stride of one grid (3072 waves): scenes with fewer
     tiles than waves, 1..3 tiles per wave and ragged tails exercise every branch of its hand-counted waits.  Random voxel size,
-    weight step and pose; the same frames through k_integrate (SF_PIPE=0) and through the oracle."""
+    weight step and pose; the same frames through k_integrate (tune pipe=0), with and without the second stream, and through the oracle."""
     from scannet_amd import fusion
     rng = np.random.default_rng(100 + seed)
     W, H = 160, 120
@@ -369,17 +369,17 @@ def test_one_frame_kernels_on_sparse_and_ragged_scenes(oracle, seed, monkeypatch
             f.integrate(d, pose)
         _assert_same(ovol, f)
         a_c, a_v = f.export_blocks()
-    monkeypatch.setenv("SF_PIPE", "0")
-    with fusion.Fuser(gp) as g:
-        for d, pose in frames:
-            g.integrate(d, pose)
-        b_c, b_v = g.export_blocks()
-    assert np.array_equal(a_c, b_c) and np.array_equal(a_v.view(np.uint8), b_v.view(np.uint8))
+    for switches in ({"pipe": 0}, {"overlap": 0}, {"pipe": 0, "overlap": 0}):
+        with fusion.Fuser(gp, **switches) as g:
+            for d, pose in frames:
+                g.integrate(d, pose)
+            b_c, b_v = g.export_blocks()
+        assert np.array_equal(a_c, b_c) and np.array_equal(a_v.view(np.uint8), b_v.view(np.uint8)), switches
 
 
-def test_three_schedules_one_volume_at_full_size(monkeypatch):
-    """600 frames of the 640x480 benchmark stream fused three ways -- one frame per launch through the persistent pipelined kernel,
-    one frame per launch through k_integrate, 16 frames per pass -- must leave byte-identical volumes (sha256 over coordinates and
+def test_four_schedules_one_volume_at_full_size():
+    """600 frames of the 640x480 benchmark stream fused four ways -- one frame per pass through the persistent pipelined kernel (with the
+    next frame's allocation on a second stream, and on one stream), one frame per pass through k_integrate, 16 frames per pass -- must leave byte-identical volumes (sha256 over coordinates and
     voxels): the size-independent property behind the bit-exactness claims at BASELINE's full size."""
     import ctypes as C
     import hashlib
@@ -393,12 +393,8 @@ def test_three_schedules_one_volume_at_full_size(monkeypatch):
         _abi.check(L.sf_synth_room_device(dptr, W * H * 2, 0, N, 5578, W, H, 1, poses.ctypes.data_as(C.c_void_p)))
         params = fusion.default_params()
         digests = []
-        for env in ({"SF_BATCH": "1"}, {"SF_BATCH": "1", "SF_PIPE": "0"}, {}):
-            for k in ("SF_BATCH", "SF_PIPE"):
-                monkeypatch.delenv(k, raising=False)
-            for k, v in env.items():
-                monkeypatch.setenv(k, v)
-            with fusion.Fuser(params) as f:
+        for switches in ({"batch": 1}, {"batch": 1, "pipe": 0}, {"batch": 1, "overlap": 0}, {}):
+            with fusion.Fuser(params, **switches) as f:
                 f.integrate_batch_device(dptr.value, W * H * 2, poses)
                 f.sync()
                 c, v = f.export_blocks()

@@ -169,6 +169,70 @@ def test_boundary_all_gather_two_ranks(tmp_path):
     assert np.array_equal(a, b) and len(a) == 37 * 3 + 37 * 4096
 
 
+def _worker_exchange(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from scannet_amd import partition
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    origin, thick = -3, 4
+
+    class FakeFuser:                        # the exchange logic of partition.exchange_boundary without a GPU
+        """Owns the stripes of `rank`; holds one block per x layer in [-20, 20) it owns, each voxel byte = the layer's x + 64."""
+        def __init__(self):
+            self.ghosts = {}
+
+        def _layers(self):
+            return [x for x in range(-20, 20) if partition.owner_of(x, origin, thick, world) == rank]
+
+        def export_boundary(self):
+            xs = [x for x in self._layers() if partition.owner_of(x - 1, origin, thick, world) != rank]
+            c = np.array([[x, 1, 2] for x in xs], np.int32).reshape(-1, 3)
+            v = np.stack([np.full(4096, x + 64, np.uint8) for x in xs]) if xs else np.zeros((0, 4096), np.uint8)
+            return c, v
+
+        def count_boundary(self):
+            return len(self.export_boundary()[0])
+
+        def import_ghosts(self, c, v):
+            n = 0
+            for (x, y, z), tile in zip(np.asarray(c), np.asarray(v)):
+                if partition.owner_of(x, origin, thick, world) != rank and partition.owner_of(x - 1, origin, thick, world) == rank:
+                    assert (tile == x + 64).all()
+                    self.ghosts[int(x)] = True
+                    n += 1
+            return n
+
+    f = FakeFuser()
+    sent, got = partition.exchange_boundary(f)
+    mine = f._layers()
+    want = sorted(x + 1 for x in mine if x + 1 < 20 and partition.owner_of(x + 1, origin, thick, world) != rank)
+    assert sent == f.count_boundary() and sorted(f.ghosts) == want and got == len(want), (rank, sorted(f.ghosts), want)
+    np.save(os.path.join(out_dir, "x%d.npy" % rank), np.array([sent, got]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_stripe_boundary_exchange_two_ranks(tmp_path):
+    """partition.exchange_boundary (the all-gather of every rank's boundary layers + the ownership filter on import) at world size 2."""
+    port = _free_port()
+    mp.spawn(_worker_exchange, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(str(tmp_path / "x0.npy")), np.load(str(tmp_path / "x1.npy"))
+    assert a[0] > 0 and b[0] > 0 and a[1] > 0 and b[1] > 0
+
+
+def test_stripe_ownership_and_balanced_planes():
+    from scannet_amd import partition
+    # floor division for negative layers; every layer has exactly one owner; stripes are `thickness` layers thick
+    owners = [partition.owner_of(x, -3, 4, 3) for x in range(-15, 15)]
+    assert owners[12:16] == [0, 0, 0, 0] and owners[16:20] == [1, 1, 1, 1] and owners[8:12] == [2, 2, 2, 2] and owners[0:4] == [0, 0, 0, 0]
+    # slab planes from the block histogram of a prefix: equal counts per slab whatever the geometry (a long corridor with one busy room)
+    x = np.concatenate([np.arange(0, 1000), np.full(3000, 1500), np.arange(2000, 2200)])
+    planes = partition.planes_from_histogram(x, 4)
+    counts = [int(((x >= planes[r]) & (x < planes[r + 1])).sum()) for r in range(4)]
+    assert sum(counts) == len(x) and planes[0] < -(1 << 19) and planes[-1] > (1 << 19) and all(planes[r] < planes[r + 1] for r in range(4))
+    assert max(counts) <= 3000 + 1050   # the 3000 blocks of one layer cannot be split; the rest is even
+
+
 def test_slab_planes_and_mesh_merge():
     from scannet_amd import partition
     p = partition.slab_planes(-40, 40, 4)
