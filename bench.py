@@ -1,13 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py -- RGB-D frames/s integrated (640x480, 4 mm voxels) on MI355X + HBM roofline of the integrate kernel.
+"""bench.py -- RGB-D frames/s integrated on MI355X + the roofline of the integrate kernel.
 
-One "step" = one depth frame of the scene0000_00-scale synthetic stream (BASELINE.json configs[1]: 5 578 frames,
-640x480, 4 mm voxels, 2^19 hash buckets) pushed through the whole per-frame hot path (depth pre-pass, block
-allocation, frustum compaction, TSDF integrate).  The stream is rendered into HBM before the timed region;
-every rank fuses its own scan (independent scans shard scan-per-GPU, no data-path collective => weak scaling).
-
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 4mm|1mm|scans|partition]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+--config (BASELINE.json `configs`; the default is the one the metric is quoted on):
+  4mm        configs[1]  scene0000_00-scale synthetic stream (5 578 frames, 640x480, 4 mm voxels, 2^19 hash buckets).  One step = one depth
+                         frame through the whole per-frame hot path (pre-pass, block allocation, frustum compaction, TSDF integrate); the
+                         stream is rendered into HBM before the timed region; with N > 1 every rank fuses its own scan (weak scaling).
+  1mm        configs[2]  the same stream at 1 mm voxels / 2^22 buckets / 2^25 SDF blocks (137 GB of tiles): ~1.4 M tiles = 5.9 GB touched
+                         per frame, far beyond the 256 MiB Infinity Cache -- the out-of-cache HBM roofline of the one-frame kernel.
+  scans      configs[3]  independent scans (room size +-20 %, 300..6000 frames) popped longest-first from one queue by all ranks, no
+                         collective; one step = one scan through fusion + marching cubes (+ the host stage: clean, decimate x 2, segment).
+  partition  configs[4]  ONE long scan (default 50 000 frames through a 10-room corridor world) with the block space dealt in stripes
+                         to the ranks, boundary layers all-gathered over RCCL before marching cubes; one step = one frame (strong scaling).
+
+`roofline` describes the dominant kernel of the timed region and every `frac` is a fraction of a hardware peak (<= 1):
+  * 16 frames per launch (the default schedule) is VALU-issue bound: bound = "valu", frac = SQ_ACTIVE_INST_VALU over the SIMD issue
+    slots of the launch (separate rocprofv3 --pmc pass), hbm_frac = counter traffic / time / 8 TB/s, alg_equiv_GBs = what the launch
+    would have moved without temporal blocking (SURVEY 8d algorithmic bytes / time: NOT a roofline fraction).
+  * `roofline_single_frame` (one frame per launch, what a live stream gets) is HBM bound: achieved = algorithmic bytes / time.
 """
 import argparse
 import ctypes as C
@@ -19,9 +31,9 @@ import sqlite3
 import subprocess
 import sys
 import tempfile
+import time
 
 import numpy as np
-import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -29,15 +41,27 @@ if ROOT not in sys.path:
 
 TOTAL_FRAMES = 5578
 W, H = 640, 480
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s is what a float4 copy reaches)
+NUM_SIMDS = 1024        # 256 CUs x 4 SIMDs
+MALL_BYTES = 256 << 20  # Infinity Cache: a per-frame tile footprint below this is served on-die between launches
+
+CONFIGS = {
+    "4mm": dict(voxel_size=0.004, hash_num_buckets=1 << 19, num_sdf_blocks=1 << 20, steps=TOTAL_FRAMES - 64, warmup=64,
+                label="configs[1]: scene0000_00-scale synthetic stream (5578-frame box-room walk, 640x480 u16 depth, 4 mm voxels, 2^19 hash buckets x 10, 2^20 SDF blocks)"),
+    "1mm": dict(voxel_size=0.001, hash_num_buckets=1 << 22, num_sdf_blocks=1 << 25, steps=192, warmup=16,
+                label="configs[2]: the same stream at 1 mm voxels, 2^22 hash buckets x 10, 2^25 SDF blocks (137 GB of tiles reserved)"),
+}
 
 
-def cpu_baseline(depth_host, poses, budget_s=12.0, max_frames=2048):
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1): the oracle port on a bounded sample; the reference's own SensReader decode beside ours
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(depth_host, poses, voxel, budget_s=12.0, max_frames=2048):
     """Oracle (our CPU port of the same spec, OpenMP over blocks) timed on a bounded sample of the same stream."""
     from oracle import oracle as orc
     from scannet_amd import _abi
     threads = _abi.usable_cpus()   # the cgroup quota, not the 256 logical CPUs the container shows
-    vol = orc.Volume(orc.default_params(W, H, 0.004), threads=threads)
+    vol = orc.Volume(orc.default_params(W, H, voxel), threads=threads)
     t0 = time.perf_counter()
     n = 0
     for i in range(min(max_frames, len(depth_host))):
@@ -91,96 +115,99 @@ def reference_decode_ms(depth_host, poses):
         return None
 
 
-def pmc_traffic(steps, warmup, timeout_s=300, single_frame=False):
-    """HBM traffic of k_integrate from the PMC counters, per launch: two SEPARATE rocprofv3 passes (--pmc FETCH_SIZE,
-    --pmc WRITE_SIZE; no trace domains) over the first `steps` timed frames of this same script.  Corrections as
-    MI355X_MICROARCH.md (HBM) prescribes and tools/pmc_calibrate.py confirmed for this kernel's 16 B/lane pattern
-    (profiles/r01_b_alloc_bitmap_rocprofv3.txt): both counters are KiB per dispatch, FETCH_SIZE reports exactly half of
-    the bytes read, WRITE_SIZE the bytes written.  Returns None when rocprofv3 is missing or a pass fails."""
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# PMC passes: this script re-run as a child under rocprofv3 --pmc (no trace domains), per-launch averages of the integrate kernel
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def pmc_pass(counters, config, steps, warmup, single_frame, timeout_s=420):
+    """One rocprofv3 --pmc pass over the first `steps` timed frames of this same script.  Returns ({counter: average per integrate launch of
+    the timed region}, the child's JSON line) or None."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None
-    per_launch = {}
-    child_line = None
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        d = tempfile.mkdtemp(prefix="sf_pmc_", dir="/tmp")
-        try:
-            env = dict(os.environ, TMPDIR="/tmp")
-            cmd = [exe, "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--steps", str(steps),
-                   "--warmup", str(warmup), "--no-cpu-baseline", "--no-profile", "--no-pmc", "--teardown"] + (["--single-frame"] if single_frame else [])
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
-            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
-            if r.returncode != 0 or not dbs:
-                return None
-            for ln in r.stdout.splitlines():
-                if ln.startswith("{") and '"metric"' in ln:
-                    child_line = json.loads(ln)
-            db = sqlite3.connect(dbs[0])
-            # the integrate launches of the timed region are the LAST `steps` dispatches of the kernel (warm-up comes first)
-            # one frame per launch (batch = 1) runs the software-pipelined k_integrate_pipe, batches run k_integrate
-            pat = "%k_integrate_pipe%" if single_frame else "%k_integrate<1, false%"
-            rows = [v for (v,) in db.execute("select value from counters_collection where counter_name = ? and kernel_name like ? "
-                                             "order by dispatch_id", (counter, pat))]
-            db.close()
-            launches = child_line["config"]["integrate_launches"] if child_line else 0
-            if launches <= 0 or len(rows) < launches:
-                return None
-            per_launch[counter] = sum(rows[-launches:]) / launches * 1024.0
-        except Exception:
+    d = tempfile.mkdtemp(prefix="sf_pmc_", dir="/tmp")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp")
+        cmd = [exe, "--pmc"] + list(counters) + ["-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--config", config, "--steps", str(steps),
+               "--warmup", str(warmup), "--no-cpu-baseline", "--no-profile", "--no-pmc", "--teardown"] + (["--single-frame"] if single_frame else [])
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+        dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+        if r.returncode != 0 or not dbs:
             return None
-        finally:
-            shutil.rmtree(d, ignore_errors=True)
-    read_b = 2.0 * per_launch["FETCH_SIZE"]
-    write_b = per_launch["WRITE_SIZE"]
-    alg = child_line["config"].get("alg_bytes_per_launch") if child_line else None
+        child = None
+        for ln in r.stdout.splitlines():
+            if ln.startswith("{") and '"metric"' in ln:
+                child = json.loads(ln)
+        if child is None:
+            return None
+        launches = child["config"]["integrate_launches"]
+        # one frame per launch runs the software-pipelined k_integrate_pipe, batches run k_integrate; the integrate launches of the timed
+        # region are the LAST `launches` dispatches of the kernel (warm-up comes first)
+        pat = "%k_integrate_pipe%" if single_frame else "%k_integrate<1, false%"
+        db = sqlite3.connect(dbs[0])
+        out = {}
+        for c in counters:
+            rows = [v for (v,) in db.execute("select value from counters_collection where counter_name = ? and kernel_name like ? order by dispatch_id", (c, pat))]
+            if launches <= 0 or len(rows) < launches:
+                db.close()
+                return None
+            out[c] = sum(rows[-launches:]) / launches
+        db.close()
+        return out, child
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def pmc_traffic(config, steps, warmup, single_frame):
+    """HBM-side traffic of the integrate kernel per launch: FETCH_SIZE and WRITE_SIZE in SEPARATE passes.  Corrections as
+    MI355X_MICROARCH.md (HBM) prescribes and tools/pmc_calibrate.py confirmed for this kernel's 16 B/lane pattern
+    (profiles/r01_b_alloc_bitmap_rocprofv3.txt): both counters are KiB per dispatch, FETCH_SIZE reports exactly half of the bytes read,
+    WRITE_SIZE the bytes written.  Infinity-Cache hits are counted (fabric-side counters), so this is an upper bound on DRAM traffic."""
+    a = pmc_pass(["FETCH_SIZE"], config, steps, warmup, single_frame)
+    b = pmc_pass(["WRITE_SIZE"], config, steps, warmup, single_frame) if a else None
+    if not a or not b:
+        return None
+    read_b, write_b = 2.0 * a[0]["FETCH_SIZE"] * 1024.0, b[0]["WRITE_SIZE"] * 1024.0
+    alg = a[1]["config"].get("alg_bytes_per_launch")
     return {"bytes": round(read_b + write_b), "read_bytes": round(read_b), "write_bytes": round(write_b),
-            "sample": "k_integrate launches of frames %d..%d, rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; "
-                      "FETCH_SIZE x2 (gfx950 128-B requests tallied at 64 B), WRITE_SIZE x1, KiB -> bytes" % (warmup, warmup + steps - 1),
-            "alg_bytes_same_launches": alg,
-            "traffic_over_alg": round((read_b + write_b) / alg, 4) if alg else None}
+            "sample": "integrate launches of frames %d..%d, rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; FETCH_SIZE x2 "
+                      "(gfx950 128-B requests tallied at 64 B), WRITE_SIZE x1, KiB -> bytes; Infinity-Cache hits are counted" % (warmup, warmup + steps - 1),
+            "alg_bytes_same_launches": alg, "traffic_over_alg": round((read_b + write_b) / alg, 4) if alg else None}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=TOTAL_FRAMES - 64)
-    ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-profile", action="store_true", help="do not bracket the integrate kernel with HIP events")
-    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes that measure roofline.traffic")
-    ap.add_argument("--pmc-steps", type=int, default=400)
-    ap.add_argument("--single-frame", action="store_true", help="one frame per launch (batch = 1) for the main measurement")
-    ap.add_argument("--no-single-frame", action="store_true", help="skip the secondary one-frame-per-launch roofline pass")
-    ap.add_argument("--teardown", action="store_true", help="leave through the interpreter's normal teardown (set for the runs under rocprofv3)")
-    args = ap.parse_args()
+def pmc_valu(config, steps, warmup, single_frame):
+    """VALU issue utilisation of the integrate kernel: SQ_ACTIVE_INST_VALU (quad-cycles a SIMD spends issuing VALU, summed over SIMDs)
+    over the SIMD quad-cycles of the launch = 1024 SIMDs x (GRBM_GUI_ACTIVE / 8 XCDs) / 4 -- the method of profiles/r01_c."""
+    a = pmc_pass(["SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"], config, steps, warmup, single_frame)
+    if not a:
+        return None
+    v, child = a
+    slots = NUM_SIMDS * (v["GRBM_GUI_ACTIVE"] / 8.0) / 4.0
+    blk = child["roofline_inputs"]["block_frames_per_launch"] if "roofline_inputs" in child else None
+    return {"valu_util": round(v["SQ_ACTIVE_INST_VALU"] / slots, 4) if slots else None, "active_inst_valu": round(v["SQ_ACTIVE_INST_VALU"]),
+            "insts_valu": round(v["SQ_INSTS_VALU"]), "gui_active_clocks_per_xcd": round(v["GRBM_GUI_ACTIVE"] / 8.0),
+            "valu_insts_per_voxel_frame": round(v["SQ_INSTS_VALU"] * 64.0 / (blk * 512.0), 2) if blk else None,
+            "sample": "rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE (own pass, kernels serialised by the profiler), integrate launches of frames %d..%d"
+                      % (warmup, warmup + steps - 1)}
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
 
-    import numpy as np
-    import torch
-    import torch.distributed as dist
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# configs[1] / configs[2]: one resident stream per rank
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
     from scannet_amd import _abi, fusion
-
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-
-    K, Wm = args.steps, args.warmup
+    cfg = CONFIGS[cfg_name]
+    K = args.steps if args.steps is not None else cfg["steps"]
+    Wm = args.warmup if args.warmup is not None else cfg["warmup"]
     n_frames = K + Wm
-    # every rank walks the same room from a different starting frame (an independent scan per GPU)
-    first = (rank * 697) % TOTAL_FRAMES
+    first = (rank * 697) % TOTAL_FRAMES   # every rank walks the same room from a different starting frame (an independent scan per GPU)
     stride = W * H * 2
     frames = torch.empty((n_frames, H, W), dtype=torch.int16, device="cuda")
     poses = np.zeros((n_frames, 16), np.float32)
     L = _abi.lib()
-    _abi.check(L.sf_synth_room_device(C.c_void_p(frames.data_ptr()), stride, first, n_frames, TOTAL_FRAMES, W, H, 1,
-                                      poses.ctypes.data_as(C.c_void_p)))
-
-    params = fusion.default_params()  # 640x480, 4 mm, 2^19 buckets x 10, 2^20 SDF blocks
+    _abi.check(L.sf_synth_room_device(C.c_void_p(frames.data_ptr()), stride, first, n_frames, TOTAL_FRAMES, W, H, 1, poses.ctypes.data_as(C.c_void_p)))
+    params = fusion.default_params(voxel_size=cfg["voxel_size"], hash_num_buckets=cfg["hash_num_buckets"], num_sdf_blocks=cfg["num_sdf_blocks"])
 
     def run(n_warm, n_timed, profile, single_frame=False):
         """Fuse frames [0, n_warm) untimed, then frames [n_warm, n_warm + n_timed) between two barrier+synchronize pairs."""
@@ -200,7 +227,7 @@ def main():
         sync_all()
         t0 = time.perf_counter()
         fuser.integrate_batch_device(frames[n_warm:].data_ptr(), stride, poses[n_warm:n_warm + n_timed])
-        t_enq = time.perf_counter() - t0  # host time to enqueue (launch-bound if ~= elapsed)
+        t_enq = time.perf_counter() - t0
         sync_all()
         elapsed = time.perf_counter() - t0
         if world > 1:
@@ -213,8 +240,8 @@ def main():
         ceiling = None
         if single_frame and profile:
             # the last frame's tile traffic without the arithmetic: what this access pattern (scattered 4 KiB RMW) can reach
-            rmw_us, tiles = fuser.calib_tile_rmw(read_only=False, iters=50)
-            ro_us, _ = fuser.calib_tile_rmw(read_only=True, iters=50)
+            rmw_us, tiles = fuser.calib_tile_rmw(read_only=False, iters=20)
+            ro_us, _ = fuser.calib_tile_rmw(read_only=True, iters=20)
             if tiles > 0:
                 ceiling = {"tiles": tiles, "rmw_copy_us": round(rmw_us, 2), "rmw_copy_GBs": round(tiles * 8192 / rmw_us / 1e3, 1),
                            "read_only_us": round(ro_us, 2), "read_only_GBs": round(tiles * 4096 / ro_us / 1e3, 1)}
@@ -223,75 +250,325 @@ def main():
         blocks = st1["total_frame_blocks"] - st0["total_frame_blocks"]
         # B_frame = N_blk*(512*8 read + 512*8 write + 16) + W*H*2 + 64, summed over the frames
         alg_bytes = blocks * (4096 + 4096 + 16) + n_timed * (W * H * 2 + 64)
-        return {"elapsed": elapsed, "t_enq": t_enq, "kernel_ms": kernel_ms, "launches": launches, "blocks": blocks,
-                "alg_bytes": alg_bytes, "batch": batch, "n_launch": (n_timed + batch - 1) // batch, "st1": st1, "ceiling": ceiling}
+        return {"elapsed": elapsed, "t_enq": t_enq, "kernel_ms": kernel_ms, "launches": launches, "blocks": blocks, "alg_bytes": alg_bytes,
+                "batch": batch, "n_launch": (n_timed + batch - 1) // batch, "st1": st1, "ceiling": ceiling}
 
-    def roofline(m, n_timed, kernel):
+    def per_launch(m, n_timed):
+        return {"avg_kernel_us": round(m["kernel_ms"] * 1e3 / m["launches"], 2), "launches": m["launches"],
+                "frames_per_launch": round(n_timed / m["launches"], 2), "avg_frame_blocks_per_launch": round(m["blocks"] / m["launches"], 1),
+                "alg_bytes_per_launch": round(m["alg_bytes"] / m["launches"])}
+
+    def roofline_hbm(m, n_timed, kernel):
+        """One frame per launch: HBM bound, achieved = SURVEY 8d algorithmic bytes over the launch duration (HIP events on the fuser's stream)."""
         if not m["launches"]:
             return None
         achieved = m["alg_bytes"] / (m["kernel_ms"] * 1e-3) / 1e9
-        return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kernel,
-                "avg_kernel_us": round(m["kernel_ms"] * 1e3 / m["launches"], 2), "launches": m["launches"],
-                "frames_per_launch": round(n_timed / m["launches"], 2),
-                "avg_frame_blocks_per_launch": round(m["blocks"] / m["launches"], 1),
-                "alg_bytes_per_launch": round(m["alg_bytes"] / m["launches"])}
+        r = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+             "traffic": None, "kernel": kernel}
+        r.update(per_launch(m, n_timed))
+        fp = m["blocks"] / m["launches"] * 4096
+        r["tile_footprint_bytes_per_launch"] = round(fp)
+        r["footprint_vs_infinity_cache"] = round(fp / MALL_BYTES, 2)
+        r["footprint_note"] = ("the launch's tile set is %.1f x the 256 MiB Infinity Cache: %s" %
+                               (fp / MALL_BYTES, "tiles come from HBM every launch" if fp > 4 * MALL_BYTES else
+                                "consecutive frames re-touch tiles that may still be on-die (FETCH_SIZE counts those hits): see --config 1mm for the out-of-cache figure"))
+        return r
+
+    def roofline_valu(m, n_timed, kernel, valu, traffic):
+        """16 frames per launch: VALU-issue bound.  frac = measured VALU issue utilisation; hbm_frac from the counter traffic."""
+        if not m["launches"]:
+            return None
+        t_s = m["kernel_ms"] * 1e-3 / m["launches"]
+        alg_equiv = m["alg_bytes"] / m["launches"] / t_s / 1e9
+        r = {"bound": "valu", "achieved": valu["valu_util"] if valu else None, "peak": 1.0, "unit": "fraction of SIMD VALU issue slots",
+             "frac": valu["valu_util"] if valu else None, "traffic": traffic["bytes"] if traffic else None, "kernel": kernel,
+             "hbm_frac": round(traffic["bytes"] / t_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+             "hbm_GBs": round(traffic["bytes"] / t_s / 1e9, 1) if traffic else None,
+             "alg_equiv_GBs": round(alg_equiv, 1),
+             "alg_equiv_note": "SURVEY 8d algorithmic bytes of frame-by-frame fusion over the launch duration: what the launch replaces, not bytes it moves "
+                               "(temporal blocking keeps each tile in registers for all frames of the batch) -- not a roofline fraction"}
+        r.update(per_launch(m, n_timed))
+        if valu:
+            r["valu_detail"] = valu
+        if traffic:
+            r["traffic_detail"] = traffic
+        return r
 
     m = run(Wm, K, not args.no_profile, single_frame=args.single_frame)
+    out = None
     if rank == 0:
-        roof = roofline(m, K, "k_integrate_pipe<true,true>" if m["batch"] == 1 else "k_integrate<1,false,true,true>")
-        if roof is not None and m["ceiling"]:
-            roof["pattern_ceiling"] = dict(m["ceiling"], frac_of_ceiling=round(roof["achieved"] / m["ceiling"]["rmw_copy_GBs"], 4))
-        if roof is not None and m["batch"] > 1:
-            roof["note"] = ("one launch fuses frames_per_launch frames into each 4 KiB tile while it sits in registers (temporal blocking): "
-                            "algorithmic bytes = sum of the per-frame SURVEY 8d figures, so achieved can exceed the HBM peak; the HBM "
-                            "traffic really moved is `traffic` (~1/frames_per_launch of it) and the kernel is VALU-issue bound "
-                            "(SQ_ACTIVE_INST_VALU ~ 90 %, profiles/); roofline_single_frame is the same kernel at one frame per launch")
+        pmc_on = world == 1 and not args.no_pmc and not args.no_profile
+        psteps = min(args.pmc_steps, K)
+        if m["batch"] == 1:
+            roof = roofline_hbm(m, K, "k_integrate_pipe<true,true>")
+            if roof is not None and m["ceiling"]:
+                roof["pattern_ceiling"] = dict(m["ceiling"], frac_of_ceiling=round(roof["achieved"] / m["ceiling"]["rmw_copy_GBs"], 4))
+        else:
+            valu = pmc_valu(cfg_name, psteps, Wm, False) if pmc_on else None
+            traffic = pmc_traffic(cfg_name, psteps, Wm, False) if pmc_on else None
+            roof = roofline_valu(m, K, "k_integrate<1,false,true,true>", valu, traffic)
         out = {
-            "metric": "RGB-D frames/sec integrated (640x480, 4 mm voxel)",
+            "metric": "RGB-D frames/sec integrated (640x480, %s voxel)" % ("4 mm" if cfg_name == "4mm" else "1 mm"),
             "value": round(world * K / m["elapsed"], 2), "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": round(m["elapsed"] * 1e3 / max(K, 1), 5),
             "host_enqueue_ms_per_step": round(m["t_enq"] * 1e3 / max(K, 1), 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: scene0000_00-scale synthetic stream (5578-frame box-room walk, 640x480 u16 depth, "
-                                   "4 mm voxels, 2^19 hash buckets x 10, 2^20 SDF blocks), frames %d..%d per rank, depth resident in HBM" % (Wm, n_frames - 1),
+            "config": {"workload": cfg["label"] + ", frames %d..%d per rank, depth resident in HBM" % (Wm, n_frames - 1),
                        "sharding": "one independent scan per GPU, no collective on the data path",
                        "blocks_live_end": m["st1"]["blocks_allocated"], "alloc_failures": m["st1"]["alloc_failures"],
                        "frames_per_pass": m["batch"], "integrate_launches": m["n_launch"],
                        "alg_bytes_per_launch": round(m["alg_bytes"] / max(m["n_launch"], 1))},
+            "roofline_inputs": {"block_frames_per_launch": round(m["blocks"] / max(m["n_launch"], 1), 1)},
             "roofline": roof,
         }
-        if roof is not None and world == 1 and not args.no_pmc:
-            t = pmc_traffic(min(args.pmc_steps, K), Wm)
-            if t is not None:
-                roof["traffic"] = t["bytes"]
-                roof["traffic_detail"] = t
         if world == 1 and not args.no_profile and not args.single_frame and not args.no_single_frame and K > 1:
-            # the same kernel HBM-bound: one frame per launch (what sf_fuser_integrate does for a live stream)
+            # the same update HBM-bound: one frame per launch (what sf_fuser_integrate does for a live stream)
             ks = min(K, 1200)
             m1 = run(Wm, ks, True, single_frame=True)
-            r1 = roofline(m1, ks, "k_integrate_pipe<true,true>: one frame per launch (batch = 1), persistent, software-pipelined "
-                                  "(tiles and depth gathers of later tiles in flight into LDS), everything on one stream")
+            r1 = roofline_hbm(m1, ks, "k_integrate_pipe<true,true>: one frame per launch (batch = 1), persistent, software-pipelined (tiles and depth gathers "
+                                      "of later tiles in flight into LDS); the next frame's pre-pass / allocation / compaction on a second stream")
             if r1 is not None:
                 r1["frames_per_s"] = round(ks / m1["elapsed"], 1)
+                r1["ms_per_frame"] = round(m1["elapsed"] * 1e3 / ks, 5)
                 if m1["ceiling"]:
                     r1["pattern_ceiling"] = dict(m1["ceiling"], frac_of_ceiling=round(r1["achieved"] / m1["ceiling"]["rmw_copy_GBs"], 4),
-                                                 note="k_tile_rmw: the same tiles of the last timed frame read and written back unchanged, no "
-                                                      "arithmetic, same launch geometry -- what scattered 4 KiB read-modify-write reaches on this HBM")
-                if not args.no_pmc:
-                    t = pmc_traffic(min(args.pmc_steps, ks), Wm, single_frame=True)
+                                                 note="k_tile_rmw: the same tiles of the last timed frame read and written back unchanged, no arithmetic, same "
+                                                      "launch geometry -- what scattered 4 KiB read-modify-write reaches on this HBM")
+                if pmc_on:
+                    t = pmc_traffic(cfg_name, min(psteps, ks), Wm, True)
                     if t is not None:
                         r1["traffic"] = t["bytes"]
                         r1["traffic_detail"] = t
                 out["roofline_single_frame"] = r1
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
-            ns = min(2048, n_frames)   # ~12 s of the port at ~120 frames/s on 16 CPUs; 1.2 GB of depth pulled back to the host
-            out["cpu_baseline"] = cpu_baseline(frames[:ns].cpu().numpy().view(np.uint16), poses[:ns].reshape(-1, 4, 4))
-        print(json.dumps(out))
+            ns = min(2048, n_frames)   # ~12 s of the port; the depth of the sample pulled back to the host
+            out["cpu_baseline"] = cpu_baseline(frames[:ns].cpu().numpy().view(np.uint16), poses[:ns].reshape(-1, 4, 4), cfg["voxel_size"])
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# configs[3]: independent scans, scan-per-GPU, one shared longest-first queue, no collective
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def run_scans(args, rank, local_rank, world, dist, torch):
+    from scannet_amd import _abi, fusion, meshclean, segmentator, shard, synth
+    K = args.steps if args.steps is not None else 12      # scans per GPU (weak scaling: N x K scans in the queue)
+    Wm = args.warmup if args.warmup is not None else 1
+    n_scans = K * world
+    specs = [synth.scan_spec(args.first_scan + i) for i in range(n_scans)]
+    if args.max_scan_frames:
+        specs = [(room, min(n, args.max_scan_frames)) for room, n in specs]
+    costs = [n for _, n in specs]
+    stride = W * H * 2
+    chunk = 2048
+    buf = torch.empty((chunk, H, W), dtype=torch.int16, device="cuda")
+    params = fusion.default_params()
+    gpu_busy = [0.0]
+    frames_done = [0]
+    outdir = tempfile.mkdtemp(prefix="sf_scans_r%d_" % rank, dir="/tmp")
+
+    def gpu_stage(i):
+        room, n = specs[i]
+        t0 = time.perf_counter()
+        with fusion.Fuser(params, device=local_rank) as f:
+            for a in range(0, n, chunk):
+                m = min(chunk, n - a)
+                poses = synth.render_scan_device(buf.data_ptr(), stride, a, m, n, W, H, room=room)
+                f.integrate_batch_device(buf.data_ptr(), stride, poses)
+                f.sync()
+            mesh = f.extract_mesh()
+        gpu_busy[0] += time.perf_counter() - t0
+        frames_done[0] += n
+        return mesh
+
+    def host_stage(i, mesh):
+        t0 = time.perf_counter()
+        nv, nf = mesh.counts()
+        res = {"scan": args.first_scan + i, "frames": specs[i][1], "faces": nf}
+        if args.host_stage != "none":
+            cleaned, _ = meshclean.clean(mesh, meshclean.CLEAN_MLX_MERGE_DISTANCE, 7500)
+            cur = cleaned
+            if args.host_stage == "full":
+                for _ in range(2):
+                    simp, _ = meshclean.simplify(cur)
+                    cur, _ = meshclean.clean(simp, meshclean.CLEAN_MLX_MERGE_DISTANCE, meshclean.CLEAN_LORES_MIN_COMPONENT)
+            ply = os.path.join(outdir, "scan%04d_vh_clean_2.ply" % i)
+            cur.write_ply(ply)
+            res["segments"] = segmentator.segment_to_json(ply, 0.01, 20)
+            res["faces_out"] = cur.counts()[1]
+        res["host_s"] = time.perf_counter() - t0
+        return res
+
+    workers = max(1, _abi.usable_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))))
+    for w in range(Wm):   # untimed: pages in the library, the kernels and the host stage
+        host_stage(0, gpu_stage(0)) if args.host_stage != "none" else gpu_stage(0)
+    gpu_busy[0], frames_done[0] = 0.0, 0
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    done = shard.run_pipelined(list(range(n_scans)), costs, gpu_stage, host_stage, workers, key="scanfuse/bench/scans")
+    t_gpu_done = time.perf_counter() - t0   # run_pipelined returns when the host pool has drained too
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    stats = torch.tensor([elapsed, gpu_busy[0], float(frames_done[0]), float(len(done))], dtype=torch.float64, device="cuda")
+    if world > 1:
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = stats.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed, busy_sum, frames_sum, scans_sum = float(mx[0]), float(sm[1]), float(sm[2]), float(sm[3])
     else:
-        pass
+        busy_sum, frames_sum, scans_sum = gpu_busy[0], float(frames_done[0]), float(len(done))
+    shutil.rmtree(outdir, ignore_errors=True)
+    if rank != 0:
+        return None
+    host_s = [r["host_s"] for _, r in done]
+    return {
+        "metric": "scans/min rebuilt (independent 640x480 scans, 4 mm voxel, scan-per-GPU)",
+        "value": round(scans_sum / elapsed * 60.0, 3), "unit": "scans/min", "n_gpus": world, "steps": K, "warmup": Wm,
+        "ms_per_step": round(elapsed * 1e3 / max(K, 1), 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "frames_per_s": round(frames_sum / elapsed, 1),
+        "config": {"workload": "configs[3]: scans %d..%d of the 1513-scan synthetic rebuild (room size +-20 %%, 300..6000 frames each, 640x480, 4 mm voxels), "
+                               "%d per GPU popped longest-first from ONE queue in the rendezvous store" % (args.first_scan, args.first_scan + n_scans - 1, K),
+                   "sharding": "scan-per-GPU, no collective on the data path",
+                   "host_stage": {"full": "clean.mlx + quadric collapse to 20 % twice + cleanLoRes + Segmentator per scan on a pool of %d host threads per rank" % workers,
+                                  "clean": "clean.mlx + Segmentator per scan on a pool of %d host threads per rank" % workers, "none": "none (fusion + marching cubes only)"}[args.host_stage],
+                   "frames_total": int(frames_sum)},
+        "gpu_busy_s_sum": round(busy_sum, 3), "gpu_idle_pct": round(100.0 * (1.0 - busy_sum / (elapsed * world)), 1),
+        "host_stage_s_mean_rank0": round(float(np.mean(host_s)), 3) if host_s else None,
+        "roofline": None,
+        "note": "per scan: frames rendered into HBM in chunks of %d (input generation, counted as GPU-busy), fused 16 frames per pass, marching cubes; the host "
+                "stage runs on threads while the GPU takes the next scan.  With the full host stage the CPUs, not the GPU, set scans/min" % chunk,
+    }
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# configs[4]: one long scan, block space dealt in stripes to the ranks, boundary all-gather (RCCL) before marching cubes
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def run_partition(args, rank, local_rank, world, dist, torch):
+    from scannet_amd import fusion, partition, synth
+    total = args.scan_frames
+    Wm = args.warmup if args.warmup is not None else 64
+    K = args.steps if args.steps is not None else total - Wm
+    n_frames = K + Wm
+    stride = W * H * 2
+    frames = torch.empty((n_frames, H, W), dtype=torch.int16, device="cuda")   # every rank holds every frame (614 KB each)
+    poses = np.zeros((n_frames, 16), np.float32)
+    a = 0
+    while a < n_frames:   # room by room
+        room, inside, per = synth.corridor_room(a, total)
+        m = min(per - inside, n_frames - a)
+        poses[a:a + m] = synth.render_scan_device(frames[a:].data_ptr(), stride, inside, m, per, W, H, origin=(room * synth.CORRIDOR_PITCH, 0.0, 0.0))
+        a += m
+    blocks = 1 << 23 if world == 1 else max(1 << 20, (1 << 23) // world * 2)
+    params = fusion.default_params(num_sdf_blocks=blocks, hash_num_buckets=max(1 << 19, blocks // 2))
+    fuser = fusion.Fuser(params, device=local_rank)
+    if world > 1 or args.stripes_at_one:
+        if args.partition == "stripes":
+            fuser.set_stripes(0, 0, args.stripe_blocks, max(world, 1), rank)
+        else:
+            planes = partition.slab_planes(0, int(np.ceil(synth.CORRIDOR_ROOMS * synth.CORRIDOR_PITCH / (8 * params.voxel_size))), world)
+            fuser.set_slab(0, planes[rank], planes[rank + 1])
+
+    def sync_all():
+        fuser.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    fuser.integrate_batch_device(frames[:Wm].data_ptr(), stride, poses[:Wm])
+    sync_all()
+    t0 = time.perf_counter()
+    fuser.integrate_batch_device(frames[Wm:].data_ptr(), stride, poses[Wm:])
+    sync_all()
+    t_fuse = time.perf_counter() - t0
+    # the exchange step + meshing (reported beside the metric, not part of the K timed steps)
+    t1 = time.perf_counter()
+    sent, got = partition.exchange_boundary(fuser) if world > 1 else (fuser.count_boundary(), 0)
+    sync_all()
+    t_exch = time.perf_counter() - t1
+    t2 = time.perf_counter()
+    mesh = fuser.extract_mesh()
+    nv, nf = mesh.counts()
+    sync_all()
+    t_mc = time.perf_counter() - t2
+    st = fuser.stats()
+    vals = torch.tensor([t_fuse, t_exch, t_mc, float(st["blocks_allocated"]), float(sent), float(got), float(nf), float(st["alloc_failures"])], dtype=torch.float64, device="cuda")
+    if world > 1:
+        mx = vals.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = vals.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        mn = vals.clone(); dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+    else:
+        mx = sm = mn = vals
+    fuser.close()
+    if rank != 0:
+        return None
+    t_fuse = float(mx[0])
+    return {
+        "metric": "RGB-D frames/sec integrated (640x480, 4 mm voxel), one scan partitioned over the GPUs",
+        "value": round(K / t_fuse, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(t_fuse * 1e3 / K, 5),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[4]: one %d-frame walk through a corridor of %d box rooms (6x4x3 m, %.1f m pitch), 640x480, 4 mm voxels; every rank sees every frame"
+                               % (total, synth.CORRIDOR_ROOMS, synth.CORRIDOR_PITCH),
+                   "partition": ("stripes of %d block layers along x dealt round-robin" % args.stripe_blocks) if args.partition == "stripes" else "one contiguous slab along x per rank",
+                   "collective": "RCCL all-gather of the boundary block layers (device tensors) once, before marching cubes" if world > 1 else "none at N = 1",
+                   "blocks_per_rank_max": int(mx[3]), "blocks_per_rank_min": int(mn[3]), "blocks_total": int(sm[3]), "alloc_failures": int(sm[7])},
+        "exchange": {"seconds": round(float(mx[1]), 4), "boundary_blocks_sent_total": int(sm[4]), "ghost_blocks_received_total": int(sm[5]),
+                     "bytes_all_gathered_per_rank": int(sm[4]) * 4108},
+        "marching_cubes": {"seconds": round(float(mx[2]), 4), "faces_total": int(sm[6])},
+        "roofline": None,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", choices=["4mm", "1mm", "scans", "partition"], default="4mm")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket the integrate kernel with HIP events")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes (VALU utilisation, HBM traffic)")
+    ap.add_argument("--pmc-steps", type=int, default=None)
+    ap.add_argument("--single-frame", action="store_true", help="one frame per launch (batch = 1) for the main measurement")
+    ap.add_argument("--no-single-frame", action="store_true", help="skip the secondary one-frame-per-launch roofline pass")
+    ap.add_argument("--teardown", action="store_true", help="leave through the interpreter's normal teardown (set for the runs under rocprofv3)")
+    ap.add_argument("--host-stage", choices=["full", "clean", "none"], default="full", help="--config scans: what follows marching cubes on the host threads")
+    ap.add_argument("--first-scan", type=int, default=0)
+    ap.add_argument("--max-scan-frames", type=int, default=0)
+    ap.add_argument("--scan-frames", type=int, default=50000, help="--config partition: length of the long scan")
+    ap.add_argument("--partition", choices=["stripes", "slabs"], default="stripes")
+    ap.add_argument("--stripe-blocks", type=int, default=16)
+    ap.add_argument("--stripes-at-one", action="store_true", help="set the partition even at N = 1 (rank 0 of 1 owns everything)")
+    args = ap.parse_args()
+    if args.pmc_steps is None:
+        args.pmc_steps = 400 if args.config == "4mm" else 64
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    if args.config in CONFIGS:
+        out = run_stream(args, args.config, rank, local_rank, world, dist, torch)
+    elif args.config == "scans":
+        out = run_scans(args, rank, local_rank, world, dist, torch)
+    else:
+        out = run_partition(args, rank, local_rank, world, dist, torch)
+    if rank == 0 and out is not None:
+        print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -36,6 +36,10 @@ int sf_fuser_profile_read(sf_fuser* f, double* integrate_ms, uint64_t* launches,
  */
 int sf_synth_room_device(void* d_depth, uint64_t frame_stride_bytes, uint64_t first_frame, uint64_t n, uint64_t total_frames,
                          int width, int height, int noise, float* poses_out);
+/* The same walk through a box room of room_m = {x, y, z} metres whose corner sits at origin_m (NULL: the world origin): the other scans
+ * of SURVEY 8d config 4 (room size +-20 %) and the rooms of config 5's corridor world (one origin per room). */
+int sf_synth_scan_device(void* d_depth, uint64_t frame_stride_bytes, uint64_t first_frame, uint64_t n, uint64_t total_frames,
+                         int width, int height, int noise, const double room_m[3], const double origin_m[3], float* poses_out);
 
 /* Device self-test: the hand-expanded correctly rounded divisions of the integrate kernel against the hardware's IEEE
  * division -- all 2^23 mantissas x 9 exponents for 1/x, 511 integer divisors x 2^21 numerators for n/m.  Both counts

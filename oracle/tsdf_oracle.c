@@ -191,10 +191,12 @@ static int frame_setup(const or_params* p, const float* pose, or_frame* f) {
   }
   const double rad = 4.0 * sqrt(3.0) * (double)p->voxel_size;
   f->radius = (float)rad;
-  /* image bounds in continuous pixel coordinates: u in [-0.5, W-0.5), v in [-0.5, H-0.5) */
+  /* image bounds in continuous pixel coordinates.  The integrate rule casts (int)(u + 0.5f) and THEN tests the pixel, and
+   * a C cast truncates towards zero: u + 0.5 in (-1, 0) lands on pixel 0.  So a voxel is "inside" for u in (-1.5, W - 0.5), and the
+   * block test must not reject what the voxel rule would update: lower planes at -1.5, upper planes at W - 0.5 / H - 0.5. */
   const double fx = p->fx, fy = p->fy, mx = p->mx, my = p->my;
-  const double xl = mx + 0.5, xh = ((double)p->width - 0.5) - mx;
-  const double yl = my + 0.5, yh = ((double)p->height - 0.5) - my;
+  const double xl = mx + 1.5, xh = ((double)p->width - 0.5) - mx;
+  const double yl = my + 1.5, yh = ((double)p->height - 0.5) - my;
   f->xa[0] = (float)fx;  f->xc[0] = (float)xl; f->xr[0] = (float)(rad * sqrt(fx * fx + xl * xl));
   f->xa[1] = (float)-fx; f->xc[1] = (float)xh; f->xr[1] = (float)(rad * sqrt(fx * fx + xh * xh));
   f->ya[0] = (float)fy;  f->yc[0] = (float)yl; f->yr[0] = (float)(rad * sqrt(fy * fy + yl * yl));
@@ -335,7 +337,9 @@ static void fuse_block(or_volume* v, const or_frame* f, int32_t slot, const uint
       const float rz = 1.0f / pcz;
       const float uf = fmaf(pcx * p->fx, rz, p->mx) + 0.5f;
       const float vf = fmaf(pcy * p->fy, rz, p->my) + 0.5f;
-      if (!(uf >= 0.0f && uf < (float)p->width && vf >= 0.0f && vf < (float)p->height)) continue;
+      /* App. C: pixel = (int)(... + 0.5f), then "skip if outside the image" -- the cast truncates towards zero, so (-1, 0) is pixel 0
+       * (the range guard keeps the cast defined for far-away projections) */
+      if (!(uf > -1.0f && uf < (float)p->width && vf > -1.0f && vf < (float)p->height)) continue;
       const int ix = (int)uf, iy = (int)vf;
       const float d = v->depthf[iy * p->width + ix];
       if (d == -INFINITY) continue;
@@ -352,9 +356,9 @@ static void fuse_block(or_volume* v, const or_frame* f, int32_t slot, const uint
           const uint8_t* c = rgb + 3 * (size_t)(iy * p->width + ix);
           if (q->w == 0) { q->r = c[0]; q->g = c[1]; q->b = c[2]; }
           else {
-            q->r = (uint8_t)((q->r + c[0] + 1) >> 1);
-            q->g = (uint8_t)((q->g + c[1] + 1) >> 1);
-            q->b = (uint8_t)((q->b + c[2] + 1) >> 1);
+            q->r = (uint8_t)((q->r + c[0]) / 2);   /* App. C: (v.color + c) / 2 per channel, integer division */
+            q->g = (uint8_t)((q->g + c[1]) / 2);
+            q->b = (uint8_t)((q->b + c[2]) / 2);
           }
         }
         int w = (int)q->w + p->weight_sample;

@@ -502,7 +502,7 @@ __device__ inline int cvt_i32(float x) {  // v_cvt_i32_f32: truncates, saturates
 template <int J0, int NJ>
 __device__ inline void fuse_project(const ParamsK& P, const float* __restrict__ Ti, v2f wx, float wy, const float (&wz)[4], v2f (&pz)[NJ],
                                     uint32_t (&pix)[2 * NJ], bool (&ok)[2 * NJ]) {
-  const uint32_t wbits = __float_as_uint((float)P.W), hbits = __float_as_uint((float)P.H);
+  const uint32_t uw = (uint32_t)P.W, uh = (uint32_t)P.H;
   // Row constants first, two rows or two components per packed instruction:
   //      a{x,y}_j = fma(Ti[1|5], wy, fma(Ti[2|6], wz_j, Ti[3|7])),  az_j = fma(Ti[9], wy, fma(Ti[10], wz_j, Ti[11]))
   v2f axy[NJ], azz[NJ / 2];
@@ -523,9 +523,11 @@ __device__ inline void fuse_project(const ParamsK& P, const float* __restrict__ 
     pz[j] = pcz;
 #pragma unroll
     for (int hx = 0; hx < 2; hx++) {
-      // 0 <= u < W as ONE unsigned compare of the float bits (negative, NaN and inf all compare high; u is never -0)
-      const bool in = (pcz[hx] > 0.0f) && (__float_as_uint(uf[hx]) < wbits) && (__float_as_uint(vf[hx]) < hbits);
-      const uint32_t p = (uint32_t)cvt_i32(vf[hx]) * (uint32_t)P.W + (uint32_t)cvt_i32(uf[hx]);
+      // pixel = (int)(u + 0.5f), THEN "skip if outside the image".  v_cvt_i32_f32 truncates towards zero like the C cast
+      // ((-1, 0) -> pixel 0) and saturates, so "0 <= pixel < W" is ONE unsigned compare of the converted value
+      const uint32_t px = (uint32_t)cvt_i32(uf[hx]), py = (uint32_t)cvt_i32(vf[hx]);
+      const bool in = (pcz[hx] > 0.0f) && (px < uw) && (py < uh);
+      const uint32_t p = py * uw + px;
       ok[2 * j + hx] = in;
       pix[2 * j + hx] = in ? p : 0u;
     }
@@ -573,10 +575,10 @@ __device__ inline void fuse_update(const ParamsK& P, const v2f (&rcp_m)[NJ], con
         const uint32_t w = cw >> 24;
         uint32_t rgb = cw & 0xFFFFFFu;
         if (COLOR) {
-          // (a + b + 1) >> 1 per channel, the three channels at once: (a | b) - ((a ^ b) >> 1) on each byte (no borrow crosses a byte:
-          // a | b >= (a ^ b) >> 1; the mask keeps a byte's low bit out of its neighbour's top bit)
+          // (a + b) / 2 per channel (integer division), the three channels at once: (a & b) + ((a ^ b) >> 1) on each byte
+          // (no carry crosses a byte: the sum is at most 255; the mask keeps a byte's low bit out of its neighbour's top bit)
           const uint32_t ck = c[2 * j + hx];
-          const uint32_t avg = (rgb | ck) - (((rgb ^ ck) & 0xFEFEFEu) >> 1);
+          const uint32_t avg = (rgb & ck) + (((rgb ^ ck) & 0xFEFEFEu) >> 1);
           rgb = w == 0 ? ck : avg;
         }
         uint32_t nw = w + (uint32_t)P.wsample;
@@ -1090,8 +1092,10 @@ bool frame_setup(const sf_params& p, const float* pose, FrameK& f) {
   const double rad = 4.0 * std::sqrt(3.0) * (double)p.voxel_size;
   f.radius = (float)rad;
   const double fx = p.fx, fy = p.fy, mx = p.mx, my = p.my;
-  const double xl = mx + 0.5, xh = ((double)p.depth_width - 0.5) - mx;
-  const double yl = my + 0.5, yh = ((double)p.depth_height - 0.5) - my;
+  // lower planes at u = -1.5: the voxel rule casts (int)(u + 0.5f) before it tests the pixel, and the cast truncates (-1, 0) to pixel 0
+  // (DESIGN.md 3.2 / 3.5); the block test must keep every block the voxel rule would touch
+  const double xl = mx + 1.5, xh = ((double)p.depth_width - 0.5) - mx;
+  const double yl = my + 1.5, yh = ((double)p.depth_height - 0.5) - my;
   f.xa[0] = (float)fx;  f.xc[0] = (float)xl; f.xr[0] = (float)(rad * std::sqrt(fx * fx + xl * xl));
   f.xa[1] = (float)-fx; f.xc[1] = (float)xh; f.xr[1] = (float)(rad * std::sqrt(fx * fx + xh * xh));
   f.ya[0] = (float)fy;  f.yc[0] = (float)yl; f.yr[0] = (float)(rad * std::sqrt(fy * fy + yl * yl));

@@ -74,10 +74,13 @@ static void trajectory_pose(uint64_t i, uint64_t n_frames, const double room[3],
   for (int k = 0; k < 16; k++) pose[k] = m[k];
 }
 
-SF_API int sf_synth_room_device(void* d_depth, uint64_t frame_stride_bytes, uint64_t first_frame, uint64_t n, uint64_t total_frames,
-                                int width, int height, int noise, float* poses_out) {
-  if (!d_depth || !poses_out || width <= 0 || height <= 0 || total_frames == 0) return sf::fail(SF_ERR_INVALID_ARG, "bad argument");
-  const double room[3] = {6.0, 4.0, 3.0};
+// frames [first_frame, first_frame + n) of the `total_frames`-frame walk through a box room of `room` metres whose corner sits at `origin`
+SF_API int sf_synth_scan_device(void* d_depth, uint64_t frame_stride_bytes, uint64_t first_frame, uint64_t n, uint64_t total_frames,
+                                int width, int height, int noise, const double room_m[3], const double origin_m[3], float* poses_out) {
+  if (!d_depth || !poses_out || !room_m || width <= 0 || height <= 0 || total_frames == 0) return sf::fail(SF_ERR_INVALID_ARG, "bad argument");
+  if (!(room_m[0] > 2.5 && room_m[1] > 2.5 && room_m[2] > 1.6)) return sf::fail(SF_ERR_INVALID_ARG, "room too small for the walk (1 m inset, camera at 1.5 m)");
+  const double room[3] = {room_m[0], room_m[1], room_m[2]};
+  const double org[3] = {origin_m ? origin_m[0] : 0.0, origin_m ? origin_m[1] : 0.0, origin_m ? origin_m[2] : 0.0};
   const double fx = 577.87 * width / 640.0, mx = (width - 1) / 2.0, my = (height - 1) / 2.0;
   for (uint64_t k = 0; k < n; k++) {
     double pose[16];
@@ -85,8 +88,9 @@ SF_API int sf_synth_room_device(void* d_depth, uint64_t frame_stride_bytes, uint
     float* pf = poses_out + 16 * k;
     for (int q = 0; q < 16; q++) pf[q] = (float)pose[q];
     SynthFrame fr;
-    // render from the float-rounded pose: that is the pose the fuser is given
+    // render from the float-rounded pose (room coordinates); the pose handed to the fuser carries the room's place in the world
     for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) fr.R[3 * r + c] = (double)pf[4 * r + c]; fr.o[r] = (double)pf[4 * r + 3]; }
+    for (int r = 0; r < 3; r++) pf[4 * r + 3] = (float)((double)pf[4 * r + 3] + org[r]);
     uint16_t* out = (uint16_t*)((uint8_t*)d_depth + k * frame_stride_bytes);
     hipLaunchKernelGGL(k_synth_room, dim3((width * height + 255) / 256), dim3(256), 0, 0, out, width, height, fx, fx, mx, my, room[0],
                        room[1], room[2], fr, noise, (unsigned long long)(first_frame + k));
@@ -94,4 +98,10 @@ SF_API int sf_synth_room_device(void* d_depth, uint64_t frame_stride_bytes, uint
   SF_HIP_CHECK(hipGetLastError());
   SF_HIP_CHECK(hipDeviceSynchronize());
   return SF_OK;
+}
+
+SF_API int sf_synth_room_device(void* d_depth, uint64_t frame_stride_bytes, uint64_t first_frame, uint64_t n, uint64_t total_frames,
+                                int width, int height, int noise, float* poses_out) {
+  const double room[3] = {6.0, 4.0, 3.0};
+  return sf_synth_scan_device(d_depth, frame_stride_bytes, first_frame, n, total_frames, width, height, noise, room, nullptr, poses_out);
 }

@@ -109,3 +109,41 @@ def room_stream(n_frames, total_frames=None, width=640, height=480, noise=False,
     for i in range(start, start + n_frames):
         pose = trajectory_pose(i, total)
         yield render_room_depth(pose, width, height, noise_frame=i if noise else None), pose
+
+
+# ---- the other synthetic workloads of SURVEY 8d (bench.py --config scans / partition) ---------------------------------------------------
+def scan_spec(index):
+    """Config 4: scan `index` of the 1513-scan rebuild -- room size +-20 % and 300..6000 frames from an LCG seeded with the index."""
+    s = (int(index) * 2654435761 + 12345) & 0xFFFFFFFF
+    out = []
+    for _ in range(4):
+        for _ in range(3):   # neighbouring seeds stay close for the first steps of an LCG: mix between draws
+            s = (s * 1664525 + 1013904223) & 0xFFFFFFFF
+            s ^= s >> 15
+        out.append((s >> 8) / float(1 << 24))
+    room = (ROOM[0] * (0.8 + 0.4 * out[0]), ROOM[1] * (0.8 + 0.4 * out[1]), ROOM[2] * (0.8 + 0.4 * out[2]))
+    return room, 300 + int(out[3] * 5700)
+
+
+CORRIDOR_ROOMS = 10
+CORRIDOR_PITCH = 6.5   # metres between room corners along x: 6 m rooms, 0.5 m walls (wider than the truncation band)
+
+
+def corridor_room(frame, total_frames):
+    """Config 5: the 50 000-frame walk through a corridor of 10 rooms -- (room index, frame inside the room, frames per room)."""
+    per = -(-int(total_frames) // CORRIDOR_ROOMS)
+    return int(frame) // per, int(frame) % per, per
+
+
+def render_scan_device(d_depth, stride, first, n, total, width, height, room=ROOM, origin=(0.0, 0.0, 0.0), noise=True):
+    """Render frames into device memory (sf_synth_scan_device, scanfuse_internal.h); returns the n poses [n, 16] float32."""
+    import ctypes as C
+    from . import _abi
+    L = _abi.lib()
+    L.sf_synth_scan_device.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    poses = np.zeros((n, 16), np.float32)
+    r = np.asarray(room, np.float64)
+    o = np.asarray(origin, np.float64)
+    _abi.check(L.sf_synth_scan_device(C.c_void_p(int(d_depth)), int(stride), int(first), int(n), int(total), int(width), int(height), 1 if noise else 0,
+                                      r.ctypes.data, o.ctypes.data, poses.ctypes.data))
+    return poses

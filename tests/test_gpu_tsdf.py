@@ -170,6 +170,70 @@ def test_one_mm_voxels(oracle):
         _assert_same(ovol, f)
 
 
+def test_one_mm_voxels_at_full_size(oracle):
+    """BASELINE configs[2] at its real size: eight full 640x480 frames of the box-room walk at 1 mm voxels / 2^22 hash buckets -- every
+    ray segment spans 25-35 blocks, so allocation takes the 64^3-block LDS window (k_alloc<6, false>, one frame per workgroup) and a frame
+    touches ~1.2 M tiles (4.7 GB).  Block set and voxels against the oracle, through the 16-frame pass; the one-frame schedule (persistent
+    pipelined kernel, next frame's allocation on the second stream) must leave the same bytes (sha256 over coordinates and voxels)."""
+    import hashlib
+    from scannet_amd import fusion
+    op, gp = _mk(oracle, voxel=0.001, hash_num_buckets=1 << 22, num_sdf_blocks=1 << 21)
+    frames = []
+    for i in range(8):
+        pose = synth.trajectory_pose(3 * i, 5578)
+        frames.append((synth.render_room_depth(pose, noise_frame=i), pose))
+    ovol = oracle.Volume(op, threads=16)
+    counts = [ovol.integrate(d, pose) for d, pose in frames]
+    assert min(counts) > 500000
+    import torch
+    dev = torch.from_numpy(np.stack([d for d, _ in frames]).view(np.int16)).cuda()
+    poses = np.stack([p.reshape(16) for _, p in frames]).astype(np.float32)
+    with fusion.Fuser(gp) as f:
+        f.integrate_batch_device(dev.data_ptr(), 640 * 480 * 2, poses)
+        f.sync()
+        st = f.stats()
+        assert st["alloc_failures"] == 0 and st["last_frame_blocks"] == counts[-1] and st["blocks_allocated"] == ovol.num_blocks
+        assert st["total_frame_blocks"] == sum(counts)
+        _assert_same(ovol, f)
+        c, v = f.export_blocks()
+        want = hashlib.sha256(c.tobytes() + v.tobytes()).hexdigest()
+        del c, v
+    ovol.close()
+    for switches in ({"batch": 1}, {"batch": 1, "pipe_overlap": 0}):
+        with fusion.Fuser(gp, **switches) as g:
+            g.integrate_batch_device(dev.data_ptr(), 640 * 480 * 2, poses)
+            g.sync()
+            c, v = g.export_blocks()
+            assert hashlib.sha256(c.tobytes() + v.tobytes()).hexdigest() == want, switches
+            del c, v
+
+
+def test_spec_literal_tolerance_on_baseline_frames():
+    """The north-star tolerance, measured: the HIP volume of eight 640x480 / 4 mm frames of the configs[1] stream against the float64,
+    division-form, statement-by-statement evaluation of SURVEY App. C (oracle/spec_literal.py -- independent of tsdf_oracle.c and of the
+    kernel's fmaf / reciprocal forms).  Weights equal wherever no pixel cast or skip test sits within fp32 rounding distance of its
+    threshold; TSDF values within 1e-4 m (measured ~5e-7)."""
+    from scannet_amd import fusion
+    from tests.test_oracle_tsdf import _births, spec_literal_check
+    W, H = 640, 480
+    fx, fy, mx, my = synth.intrinsics(W, H)
+    gp = fusion.default_params(num_sdf_blocks=1 << 18)
+    frames, after = [], []
+    with fusion.Fuser(gp) as f:
+        for i in (0, 1, 2, 3, 700, 701, 1400, 1401):
+            pose = synth.trajectory_pose(i, 5578)
+            d = synth.render_room_depth(pose, noise_frame=i)
+            assert f.integrate(d, pose)
+            frames.append((d, pose))
+            after.append(f.export_blocks()[0])
+        coords, vox = f.export_blocks()
+    final, birth = _births(after)
+    assert np.array_equal(final, coords)
+    res = spec_literal_check(frames, coords, birth, vox, dict(voxel=0.004, fx=fx, fy=fy, mx=mx, my=my, width=W, height=H), sample=12000)
+    assert res["max_abs_sdf_err_m"] < 1e-5, res
+    print("spec-literal check:", res)
+
+
 def test_heap_exhaustion_is_reported(oracle):
     from scannet_amd import fusion
     _, gp = _mk(oracle, 160, 120, voxel=0.004, num_sdf_blocks=256)

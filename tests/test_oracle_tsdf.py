@@ -61,7 +61,8 @@ def test_plane_known_answer(oracle, plane_volume):
         # fmaf(pc.x*fx, rz, mx): emulate the fused op in float64 (exact product of two f32 fits in f64)
         u = ((X * fx).astype(np.float64) * rz.astype(np.float64) + np.float64(mx)).astype(np.float32) + f32(0.5)
         v = ((Y * fy).astype(np.float64) * rz.astype(np.float64) + np.float64(my)).astype(np.float32) + f32(0.5)
-    inside = (Z > 0) & (u >= 0) & (u < 640) & (v >= 0) & (v < 480)
+    # pixel = (int)(... + 0.5f), then the image test: a C cast truncates towards zero, so (-1, 0) is pixel 0
+    inside = (Z > 0) & (u > -1) & (u < 640) & (v > -1) & (v < 480)
     sdf = f32(2.0) - Z
     upd = inside & (sdf > -t)
     exp = np.where(upd, np.minimum(sdf, t), f32(0)).astype(np.float32)
@@ -133,7 +134,8 @@ def test_colour_average(oracle):
     _, v = vol.export()
     m = v["w"] == 2
     assert m.any()
-    assert (v["r"][m] == 16).all() and (v["g"][m] == 150).all() and (v["b"][m] == 31).all()
+    # (v.color + c) / 2 per channel, integer division: (10 + 21) / 2 = 15, (31 + 30) / 2 = 30
+    assert (v["r"][m] == 15).all() and (v["g"][m] == 150).all() and (v["b"][m] == 30).all()
 
 
 def test_room_mesh_on_walls(oracle):
@@ -201,3 +203,62 @@ def test_oracle_matches_committed_digests(oracle, case):
         return vol
 
     assert mod.run(factory, name, size, voxel, idx, colour, deint) == gold[name]
+
+
+def _births(volume_after_each_frame_coords):
+    """coords exported after every frame -> (final coords, first frame index at which each block exists)."""
+    final = volume_after_each_frame_coords[-1]
+    key = lambda c: (c[:, 0].astype(np.int64) << 42) | ((c[:, 1].astype(np.int64) & 0x1FFFFF) << 21) | (c[:, 2].astype(np.int64) & 0x1FFFFF)
+    kf = key(final)
+    birth = np.full(len(final), len(volume_after_each_frame_coords), np.int64)
+    for k in range(len(volume_after_each_frame_coords) - 1, -1, -1):
+        birth[np.isin(kf, key(volume_after_each_frame_coords[k]))] = k
+    return final, birth
+
+
+def spec_literal_check(frames, coords, birth, vox, params, sample=None, seed=0):
+    """The fp32 volume `vox` (VOXEL_DTYPE [n,512]) against the float64 literal evaluation of SURVEY App. C (oracle/spec_literal.py).
+    Returns a dict of what was measured; asserts the north-star tolerance (1e-4 m on TSDF values) and weight equality away from ties."""
+    from oracle import spec_literal
+    if sample is not None and sample < len(coords):
+        pick = np.sort(np.random.default_rng(seed).choice(len(coords), sample, replace=False))
+        coords, birth, vox = coords[pick], birth[pick], vox[pick]
+    sdf, w, tie = spec_literal.evaluate(frames, coords, birth, **params)
+    ok = ~tie
+    wrong_w = ok & (w != vox["w"])
+    seen = ok & (w > 0)
+    err = np.abs(sdf - vox["sdf"].astype(np.float64))
+    out = {"voxels": int(ok.size), "ties": int(tie.sum()), "tie_frac": float(tie.mean()), "observed": int(seen.sum()),
+           "weight_mismatches": int(wrong_w.sum()), "max_abs_sdf_err_m": float(err[seen].max()) if seen.any() else 0.0,
+           "mean_abs_sdf_err_m": float(err[seen].mean()) if seen.any() else 0.0}
+    assert out["observed"] > 0.2 * ok.sum(), out
+    eps_px = 1e-6 * max(params["width"], params["height"])
+    assert out["tie_frac"] < 6 * eps_px * len(frames) + 0.002, out   # discontinuities within rounding distance of their threshold are rare ...
+    assert out["weight_mismatches"] == 0, out              # ... and away from them every voxel saw exactly the same frames
+    assert out["max_abs_sdf_err_m"] < 1e-4, out            # the north-star tolerance; fp32 lands around 1e-6
+    # inside the tie set the two may differ by whole observations -- but only there; count them for the record
+    out["tie_weight_mismatches"] = int((tie & (w != vox["w"])).sum())
+    return out
+
+
+def test_oracle_within_tolerance_of_the_literal_specification(oracle):
+    """The fp32 oracle (fused multiply-adds, reciprocal projection: DESIGN.md 3.5 -- the forms the HIP kernel shares) against the float64,
+    division-form, statement-by-statement evaluation of SURVEY App. C: equal weights away from pixel-rounding / threshold ties, TSDF values
+    within 1e-4 m.  The same check runs on the HIP volume at 640x480 in tests/test_gpu_tsdf.py."""
+    W, H = 160, 120
+    p = oracle.default_params(W, H, voxel=0.008)
+    fx, fy, mx, my = synth.intrinsics(W, H)
+    p.fx, p.fy, p.mx, p.my = fx, fy, mx, my
+    vol = oracle.Volume(p, threads=8)
+    frames, after = [], []
+    for i in (0, 1, 2, 150, 151, 300):
+        pose = synth.trajectory_pose(i, 1200)
+        d = synth.render_room_depth(pose, W, H, noise_frame=i)
+        vol.integrate(d, pose)
+        frames.append((d, pose))
+        after.append(vol.export()[0])
+    coords, vox = vol.export()
+    final, birth = _births(after)
+    assert np.array_equal(final, coords)
+    res = spec_literal_check(frames, coords, birth, vox, dict(voxel=0.008, fx=fx, fy=fy, mx=mx, my=my, width=W, height=H), sample=6000)
+    assert res["max_abs_sdf_err_m"] < 2e-5
