@@ -45,6 +45,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s;
 NUM_SIMDS = 1024        # 256 CUs x 4 SIMDs
 MALL_BYTES = 256 << 20  # Infinity Cache: a per-frame tile footprint below this is served on-die between launches
 
+TUNE = {}   # --tune key=value switches (scanfuse_internal.h), applied to every fuser
+
 CONFIGS = {
     "4mm": dict(voxel_size=0.004, hash_num_buckets=1 << 19, num_sdf_blocks=1 << 20, steps=TOTAL_FRAMES - 64, warmup=64,
                 label="configs[1]: scene0000_00-scale synthetic stream (5578-frame box-room walk, 640x480 u16 depth, 4 mm voxels, 2^19 hash buckets x 10, 2^20 SDF blocks)"),
@@ -128,7 +130,8 @@ def pmc_pass(counters, config, steps, warmup, single_frame, timeout_s=420):
     try:
         env = dict(os.environ, TMPDIR="/tmp")
         cmd = [exe, "--pmc"] + list(counters) + ["-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--config", config, "--steps", str(steps),
-               "--warmup", str(warmup), "--no-cpu-baseline", "--no-profile", "--no-pmc", "--teardown"] + (["--single-frame"] if single_frame else [])
+               "--warmup", str(warmup), "--no-cpu-baseline", "--no-profile", "--no-pmc", "--teardown"] + (["--single-frame"] if single_frame else []) + \
+              sum((["--tune", "%s=%d" % kv] for kv in TUNE.items()), [])
         r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
         dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
         if r.returncode != 0 or not dbs:
@@ -211,7 +214,7 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
 
     def run(n_warm, n_timed, profile, single_frame=False):
         """Fuse frames [0, n_warm) untimed, then frames [n_warm, n_warm + n_timed) between two barrier+synchronize pairs."""
-        fuser = fusion.Fuser(params, device=local_rank, **({"batch": 1} if single_frame else {}))
+        fuser = fusion.Fuser(params, device=local_rank, **dict(TUNE, **({"batch": 1} if single_frame else {})))
 
         def sync_all():
             fuser.sync()
@@ -315,7 +318,7 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
             "host_enqueue_ms_per_step": round(m["t_enq"] * 1e3 / max(K, 1), 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": cfg["label"] + ", frames %d..%d per rank, depth resident in HBM" % (Wm, n_frames - 1),
+            "config": {"workload": cfg["label"] + ", frames %d..%d per rank, depth resident in HBM" % (Wm, n_frames - 1), "tune": dict(TUNE),
                        "sharding": "one independent scan per GPU, no collective on the data path",
                        "blocks_live_end": m["st1"]["blocks_allocated"], "alloc_failures": m["st1"]["alloc_failures"],
                        "frames_per_pass": m["batch"], "integrate_launches": m["n_launch"],
@@ -371,7 +374,7 @@ def run_scans(args, rank, local_rank, world, dist, torch):
     def gpu_stage(i):
         room, n = specs[i]
         t0 = time.perf_counter()
-        with fusion.Fuser(params, device=local_rank) as f:
+        with fusion.Fuser(params, device=local_rank, **TUNE) as f:
             for a in range(0, n, chunk):
                 m = min(chunk, n - a)
                 poses = synth.render_scan_device(buf.data_ptr(), stride, a, m, n, W, H, room=room)
@@ -435,7 +438,7 @@ def run_scans(args, rank, local_rank, world, dist, torch):
         "config": {"workload": "configs[3]: scans %d..%d of the 1513-scan synthetic rebuild (room size +-20 %%, 300..6000 frames each, 640x480, 4 mm voxels), "
                                "%d per GPU popped longest-first from ONE queue in the rendezvous store" % (args.first_scan, args.first_scan + n_scans - 1, K),
                    "sharding": "scan-per-GPU, no collective on the data path",
-                   "host_stage": {"full": "clean.mlx + quadric collapse to 20 % twice + cleanLoRes + Segmentator per scan on a pool of %d host threads per rank" % workers,
+                   "host_stage": {"full": "clean.mlx + quadric collapse to 20 %% twice + cleanLoRes + Segmentator per scan on a pool of %d host threads per rank" % workers,
                                   "clean": "clean.mlx + Segmentator per scan on a pool of %d host threads per rank" % workers, "none": "none (fusion + marching cubes only)"}[args.host_stage],
                    "frames_total": int(frames_sum)},
         "gpu_busy_s_sum": round(busy_sum, 3), "gpu_idle_pct": round(100.0 * (1.0 - busy_sum / (elapsed * world)), 1),
@@ -466,7 +469,7 @@ def run_partition(args, rank, local_rank, world, dist, torch):
         a += m
     blocks = 1 << 23 if world == 1 else max(1 << 20, (1 << 23) // world * 2)
     params = fusion.default_params(num_sdf_blocks=blocks, hash_num_buckets=max(1 << 19, blocks // 2))
-    fuser = fusion.Fuser(params, device=local_rank)
+    fuser = fusion.Fuser(params, device=local_rank, **TUNE)
     if world > 1 or args.stripes_at_one:
         if args.partition == "stripes":
             fuser.set_stripes(0, 0, args.stripe_blocks, max(world, 1), rank)
@@ -544,9 +547,11 @@ def main():
     ap.add_argument("--partition", choices=["stripes", "slabs"], default="stripes")
     ap.add_argument("--stripe-blocks", type=int, default=16)
     ap.add_argument("--stripes-at-one", action="store_true", help="set the partition even at N = 1 (rank 0 of 1 owns everything)")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="sf_fuser_tune switches for every fuser of the run (A/B measurements)")
     args = ap.parse_args()
     if args.pmc_steps is None:
         args.pmc_steps = 400 if args.config == "4mm" else 64
+    TUNE.update({kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.tune})
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

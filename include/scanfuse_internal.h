@@ -21,6 +21,8 @@ extern "C" {
  *   "pipe"        0/1    colourless one-frame passes run the software-pipelined persistent kernel (default 1)
  *   "pipe_wgs"    1..3   persistent workgroups per CU of that kernel (default 3)
  *   "pipe_overlap" 0/1   the next frame's pre-pass / allocation / compaction runs on the second stream beside that kernel (default 1)
+ *   "nt"          -1/0/1 that kernel's tile loads and stores non-temporal: -1 = when the previous pass touched more than 512 MiB of tiles (default)
+ *   "front_cus"   0..128 the second stream owns that many CUs (spread over the chip), the main stream the rest (hipExtStreamCreateWithCUMask); 0 = shared
  *   "alloc_group" 1..16  consecutive frames one allocation workgroup walks (default 4)
  * Synchronises the fuser.  SF_ERR_INVALID_ARG for an unknown key or a value out of range. */
 int sf_fuser_tune(sf_fuser* f, const char* key, int value);

@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libscanfuse.so")
+# SCANFUSE_LIBRARY: another build of the same ABI (tools/sanitize.py points it at the ASan/UBSan build of the host code)
+LIB_PATH = os.environ.get("SCANFUSE_LIBRARY") or os.path.join(_HERE, "libscanfuse.so")
 
 
 class SfParams(C.Structure):

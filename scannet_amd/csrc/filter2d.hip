@@ -93,37 +93,63 @@ __global__ __launch_bounds__(256) void k_f2d_bilateral(float* __restrict__ out, 
   out[(size_t)y * w + x] = result;
 }
 
-__device__ inline float bilinear(float x, float y, const float* __restrict__ in, unsigned iw, unsigned ih) {  // filter.cu:514-541
-  const int p00x = (int)floorf(x), p00y = (int)floorf(y);
-  const int p01x = p00x, p01y = p00y + 1, p10x = p00x + 1, p10y = p00y, p11x = p00x + 1, p11y = p00y + 1;
-  const float alpha = x - (float)p00x, beta = y - (float)p00y;
-  float s0 = 0.0f, w0 = 0.0f;
-  if ((unsigned)p00x < iw && (unsigned)p00y < ih) { const float v = in[(size_t)p00y * iw + p00x]; if (v != F2D_MINF) { s0 += (1.0f - alpha) * v; w0 += (1.0f - alpha); } }
-  if ((unsigned)p10x < iw && (unsigned)p10y < ih) { const float v = in[(size_t)p10y * iw + p10x]; if (v != F2D_MINF) { s0 += alpha * v; w0 += alpha; } }
-  float s1 = 0.0f, w1 = 0.0f;
-  if ((unsigned)p01x < iw && (unsigned)p01y < ih) { const float v = in[(size_t)p01y * iw + p01x]; if (v != F2D_MINF) { s1 += (1.0f - alpha) * v; w1 += (1.0f - alpha); } }
-  if ((unsigned)p11x < iw && (unsigned)p11y < ih) { const float v = in[(size_t)p11y * iw + p11x]; if (v != F2D_MINF) { s1 += alpha * v; w1 += alpha; } }
-  const float p0 = s0 / w0, p1 = s1 / w1;
-  float ss = 0.0f, ww = 0.0f;
-  if (w0 > 0.0f) { ss += (1.0f - beta) * p0; ww += (1.0f - beta); }
-  if (w1 > 0.0f) { ss += beta * p1; ww += beta; }
-  return ww > 0.0f ? ss / ww : F2D_MINF;
+// Validity-aware bilinear sample (what filter.cu:514-541 computes): a horizontal blend per source row over the taps that exist and are
+// valid, renormalised by the weight that took part, then the same vertically over the rows that produced something.  The order of
+// the floating-point operations (left tap before right tap, upper row before lower row, division after accumulation) is part of the
+// result and is kept; the checker (oracle/filter2d_oracle.c) pins it bit for bit.
+struct RowBlend { float sum, weight; };
+__device__ inline RowBlend blend_row(const float* __restrict__ img, unsigned iw, unsigned ih, int x0, int yr, float ax) {
+  RowBlend r = {0.0f, 0.0f};
+  if ((unsigned)yr >= ih) return r;
+  const float* row = img + (size_t)yr * iw;
+  const float wl = 1.0f - ax;
+#pragma unroll
+  for (int tap = 0; tap < 2; tap++) {
+    const int xt = x0 + tap;
+    if ((unsigned)xt >= iw) continue;
+    const float v = row[xt];
+    if (v == F2D_MINF) continue;
+    const float wt = tap ? ax : wl;
+    r.sum += wt * v;
+    r.weight += wt;
+  }
+  return r;
+}
+__device__ inline float bilinear(float x, float y, const float* __restrict__ in, unsigned iw, unsigned ih) {
+  const int x0 = (int)floorf(x), y0 = (int)floorf(y);
+  const float ax = x - (float)x0, ay = y - (float)y0;
+  const RowBlend up = blend_row(in, iw, ih, x0, y0, ax), lo = blend_row(in, iw, ih, x0, y0 + 1, ax);
+  float acc = 0.0f, wsum = 0.0f;
+  if (up.weight > 0.0f) { acc += (1.0f - ay) * (up.sum / up.weight); wsum += (1.0f - ay); }
+  if (lo.weight > 0.0f) { acc += ay * (lo.sum / lo.weight); wsum += ay; }
+  return wsum > 0.0f ? acc / wsum : F2D_MINF;
+}
+
+// Output pixel (x, y) of a resample looks at source position (x * (iw - 1) / (ow - 1), y * (ih - 1) / (oh - 1)); pixels whose rounded
+// source position falls outside keep what the output held (filter.cu:543-573, 647-665).  One lane per output pixel, 16 x 16 tiles.
+struct ResampleAt { float fx, fy; unsigned nx, ny; bool inside; };
+__device__ inline ResampleAt resample_at(int x, int y, int ow, int oh, int iw, int ih) {
+  ResampleAt r;
+  r.fx = (float)x * ((float)(iw - 1) / (float)(ow - 1));
+  r.fy = (float)y * ((float)(ih - 1) / (float)(oh - 1));
+  r.nx = (unsigned)(r.fx + 0.5f);
+  r.ny = (unsigned)(r.fy + 0.5f);
+  r.inside = r.nx < (unsigned)iw && r.ny < (unsigned)ih;
+  return r;
 }
 
 __global__ __launch_bounds__(256) void k_f2d_resample_float(float* __restrict__ out, int ow, int oh, const float* __restrict__ in, int iw, int ih) {
   const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
   if (x >= ow || y >= oh) return;
-  const float sw = (float)(iw - 1) / (float)(ow - 1), sh = (float)(ih - 1) / (float)(oh - 1);
-  const unsigned xi = (unsigned)((float)x * sw + 0.5f), yi = (unsigned)((float)y * sh + 0.5f);
-  if (xi < (unsigned)iw && yi < (unsigned)ih) out[(size_t)y * ow + x] = bilinear((float)x * sw, (float)y * sh, in, (unsigned)iw, (unsigned)ih);
+  const ResampleAt at = resample_at(x, y, ow, oh, iw, ih);
+  if (at.inside) out[(size_t)y * ow + x] = bilinear(at.fx, at.fy, in, (unsigned)iw, (unsigned)ih);
 }
 
 __global__ __launch_bounds__(256) void k_f2d_resample_uchar(uint8_t* __restrict__ out, int ow, int oh, const uint8_t* __restrict__ in, int iw, int ih) {
   const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
   if (x >= ow || y >= oh) return;
-  const float sw = (float)(iw - 1) / (float)(ow - 1), sh = (float)(ih - 1) / (float)(oh - 1);
-  const unsigned xi = (unsigned)((float)x * sw + 0.5f), yi = (unsigned)((float)y * sh + 0.5f);
-  if (xi < (unsigned)iw && yi < (unsigned)ih) out[(size_t)y * ow + x] = in[(size_t)yi * iw + xi];
+  const ResampleAt at = resample_at(x, y, ow, oh, iw, ih);
+  if (at.inside) out[(size_t)y * ow + x] = in[(size_t)at.ny * iw + at.nx];
 }
 
 // the per-pixel histogram in LDS: vote[bin][lane]; + the spatial table behind it

@@ -499,7 +499,9 @@ __device__ inline int cvt_i32(float x) {  // v_cvt_i32_f32: truncates, saturates
 // independent work per issue slot, NJ = 2 called twice halves the live registers (single-frame, occupancy-bound variant).
 // Phase A of one frame on rows [J0, J0 + NJ): camera-space z of the lane's voxel pairs, the pixel each voxel projects to
 // (0 when it projects outside) and whether it projects inside.
-template <int J0, int NJ>
+// CLAMP: pixels that project outside read pixel 0 (callers that gather with plain global loads); without it the index of an outside
+// voxel is whatever the saturating conversion gave (callers that gather through a bounds-checked buffer resource and mask by `ok`).
+template <int J0, int NJ, bool CLAMP>
 __device__ inline void fuse_project(const ParamsK& P, const float* __restrict__ Ti, v2f wx, float wy, const float (&wz)[4], v2f (&pz)[NJ],
                                     uint32_t (&pix)[2 * NJ], bool (&ok)[2 * NJ]) {
   const uint32_t uw = (uint32_t)P.W, uh = (uint32_t)P.H;
@@ -518,8 +520,8 @@ __device__ inline void fuse_project(const ParamsK& P, const float* __restrict__ 
     const v2f pcy = pk_fma(splat(Ti[4]), wx, splat(axy[j].y));
     const v2f pcz = pk_fma(splat(Ti[8]), wx, splat(azz[j >> 1][j & 1]));
     const v2f rz = recip_rn(pcz);
-    const v2f uf = pk_fma(pcx * splat(P.fx), rz, splat(P.mx)) + splat(0.5f);
-    const v2f vf = pk_fma(pcy * splat(P.fy), rz, splat(P.my)) + splat(0.5f);
+    const v2f uf = pk_add(pk_fma(pcx * splat(P.fx), rz, splat(P.mx)), splat(0.5f));
+    const v2f vf = pk_add(pk_fma(pcy * splat(P.fy), rz, splat(P.my)), splat(0.5f));
     pz[j] = pcz;
 #pragma unroll
     for (int hx = 0; hx < 2; hx++) {
@@ -527,23 +529,30 @@ __device__ inline void fuse_project(const ParamsK& P, const float* __restrict__ 
       // ((-1, 0) -> pixel 0) and saturates, so "0 <= pixel < W" is ONE unsigned compare of the converted value
       const uint32_t px = (uint32_t)cvt_i32(uf[hx]), py = (uint32_t)cvt_i32(vf[hx]);
       const bool in = (pcz[hx] > 0.0f) && (px < uw) && (py < uh);
-      const uint32_t p = py * uw + px;
+      const uint32_t p = __umul24(py, uw) + px;   // v_mad_u32_u24: exact for every inside pixel (py < H, W < 2^24), garbage outside
       ok[2 * j + hx] = in;
-      pix[2 * j + hx] = in ? p : 0u;
+      pix[2 * j + hx] = CLAMP ? (in ? p : 0u) : p;
     }
   }
 }
 
 // Phase B: the update of DESIGN.md 3.5 from the gathered depths (colours) into the tile registers.
-template <int SIGN, bool COLOR, bool TAB, bool WS1, int J0, int NJ>
+// WM (weight mode): 0 = any weight_sample / weight_max, 1 = weight_sample == 1, 2 = weight_sample == 1 and weight_max == 255 (the shipped
+// parameters after the uchar clamp): the weight byte then increments with saturation as ONE add-with-carry on the {rgb, weight} word.
+// dirty[j]: lane mask (a scalar register pair) of the lanes whose row j changed -- kept on the scalar unit across the frames of a batch.
+template <int SIGN, bool COLOR, bool TAB, int WM, int J0, int NJ>
 __device__ inline void fuse_update(const ParamsK& P, const v2f (&rcp_m)[NJ], const float (&d)[2 * NJ], const uint32_t (&c)[2 * NJ], const v2f (&pz)[NJ],
-                                   const bool (&ok)[2 * NJ], uint4 (&v)[4], bool (&dirty)[4]) {
+                                   const bool (&ok)[2 * NJ], uint4 (&v)[4], uint64_t (&dirty)[4]) {
+  constexpr bool WS1 = WM >= 1;
   // ---- phase B: new values into temporaries (the tile itself stays untouched until the end)
   const float wn = (float)P.wsample;
   const uint32_t maxd_bits = __float_as_uint(P.maxd);
   v2f q[NJ], sdfc[NJ];
   uint32_t ncw[2 * NJ];
   bool upd[2 * NJ];
+  bool sat[2 * NJ];
+#pragma unroll
+  for (int k = 0; k < 2 * NJ; k++) sat[k] = false;
   bool slow = false;
 #pragma unroll
   for (int j = 0; j < NJ; j++) {
@@ -581,9 +590,18 @@ __device__ inline void fuse_update(const ParamsK& P, const v2f (&rcp_m)[NJ], con
           const uint32_t avg = (rgb & ck) + (((rgb ^ ck) & 0xFEFEFEu) >> 1);
           rgb = w == 0 ? ck : avg;
         }
-        uint32_t nw = w + (uint32_t)P.wsample;
-        if (nw > (uint32_t)P.wmax) nw = (uint32_t)P.wmax;
-        ncw[2 * j + hx] = rgb | (nw << 24);
+        if (WM == 2) {
+          // weight byte + 1, saturating at 255: the add carries out of the word exactly when the weight was 255 -- then keep it
+          const uint32_t base = COLOR ? (rgb | (cw & 0xFF000000u)) : cw;
+          uint32_t inc;
+          const bool full = __builtin_add_overflow(base, 0x01000000u, &inc);
+          if (COLOR) ncw[2 * j + hx] = full ? base : inc;
+          else { ncw[2 * j + hx] = inc; sat[2 * j + hx] = full; }   // without colour "keep it" is "do not touch the word": folded into the final select
+        } else {
+          uint32_t nw = w + (uint32_t)P.wsample;
+          if (nw > (uint32_t)P.wmax) nw = (uint32_t)P.wmax;
+          ncw[2 * j + hx] = rgb | (nw << 24);
+        }
       }
     } else {
       const v2f n = pk_fma(old, wo, -(sdf * splat(wn)));
@@ -611,41 +629,52 @@ __device__ inline void fuse_update(const ParamsK& P, const v2f (&rcp_m)[NJ], con
 #pragma unroll
   for (int j = 0; j < NJ; j++) {
     v[J0 + j].x = upd[2 * j] ? __float_as_uint(q[j].x) : v[J0 + j].x;
-    v[J0 + j].y = upd[2 * j] ? ncw[2 * j] : v[J0 + j].y;
+    v[J0 + j].y = (upd[2 * j] && !sat[2 * j]) ? ncw[2 * j] : v[J0 + j].y;
     v[J0 + j].z = upd[2 * j + 1] ? __float_as_uint(q[j].y) : v[J0 + j].z;
-    v[J0 + j].w = upd[2 * j + 1] ? ncw[2 * j + 1] : v[J0 + j].w;
-    dirty[J0 + j] = dirty[J0 + j] || upd[2 * j] || upd[2 * j + 1];
+    v[J0 + j].w = (upd[2 * j + 1] && !sat[2 * j + 1]) ? ncw[2 * j + 1] : v[J0 + j].w;
+    dirty[J0 + j] |= __ballot(upd[2 * j] || upd[2 * j + 1]);
   }
 }
 
 
-template <int SIGN, bool COLOR, bool TAB, bool WS1, int J0, int NJ>
+// The depth (colour) image of one frame as a buffer resource: gathers address it as SGPR descriptor + 32-bit VGPR byte offset (one
+// v_mul_u32_u24 + one v_lshl_add_u32 per voxel instead of a 64-bit multiply-add, a select and a 64-bit shift-add), and an offset past
+// the image -- a voxel that projects outside, whose index is garbage -- reads 0 instead of faulting; such voxels are masked by `ok`.
+__device__ inline __amdgpu_buffer_rsrc_t image_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);   // raw buffer, dword data format (gfx9)
+}
+
+template <int SIGN, bool COLOR, bool TAB, int WM, int J0, int NJ>
 __device__ inline void fuse_rows(const ParamsK& P, const float* __restrict__ Ti, const float* __restrict__ depthf,
                                  const uint32_t* __restrict__ color, const float* rtab, v2f wx, float wy, const float (&wz)[4],
-                                 uint4 (&v)[4], bool (&dirty)[4]) {
+                                 uint4 (&v)[4], uint64_t (&dirty)[4]) {
   v2f pz[NJ], rcp_m[NJ];
   float d[2 * NJ];
   uint32_t c[2 * NJ];
   bool ok[2 * NJ];
-  uint32_t pix[2 * NJ];  // unsigned 32-bit offsets: SGPR base + VGPR offset addressing, no 64-bit pointer arithmetic per gather
+  uint32_t pix[2 * NJ];
   // the weights are known before anything else: start the eight table reads now, they are consumed in phase B
   if (TAB) {
 #pragma unroll
     for (int j = 0; j < NJ; j++) rcp_m[j] = (v2f){rtab[(v[J0 + j].y >> 24) + (uint32_t)P.wsample], rtab[(v[J0 + j].w >> 24) + (uint32_t)P.wsample]};
   }
   // ---- phase A: project; then the gathers, all issued together
-  fuse_project<J0, NJ>(P, Ti, wx, wy, wz, pz, pix, ok);
+  fuse_project<J0, NJ, false>(P, Ti, wx, wy, wz, pz, pix, ok);
+  const uint32_t img_bytes = (uint32_t)(P.W * P.H) * 4u;
+  const __amdgpu_buffer_rsrc_t rd = image_rsrc(depthf, img_bytes);
 #pragma unroll
-  for (int k = 0; k < 2 * NJ; k++) {
-    d[k] = depthf[pix[k]];
-    if (COLOR) c[k] = color[pix[k]];
+  for (int k = 0; k < 2 * NJ; k++) d[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, pix[k] << 2, 0, 0));
+  if (COLOR) {
+    const __amdgpu_buffer_rsrc_t rc = image_rsrc(color, img_bytes);
+#pragma unroll
+    for (int k = 0; k < 2 * NJ; k++) c[k] = __builtin_amdgcn_raw_buffer_load_b32(rc, pix[k] << 2, 0, 0);
   }
-  fuse_update<SIGN, COLOR, TAB, WS1, J0, NJ>(P, rcp_m, d, c, pz, ok, v, dirty);
+  fuse_update<SIGN, COLOR, TAB, WM, J0, NJ>(P, rcp_m, d, c, pz, ok, v, dirty);
 }
 
 // 4 waves per SIMD (<= 128 VGPRs).  Tried for the one-frame-per-launch case: 5 waves / 96 VGPRs with the tile in two
 // half passes -- the spills cost more than the occupancy buys (183 us vs 112 us per launch).
-template <int SIGN, bool COLOR, bool TAB, bool WS1>
+template <int SIGN, bool COLOR, bool TAB, int WM>
 __global__ __launch_bounds__(256, 4) void k_integrate(uint4* __restrict__ voxels, const uint64_t* __restrict__ block_keys,
                                                    const int32_t* __restrict__ compact, const uint32_t* __restrict__ cmask,
                                                    const float* __restrict__ depthf_all, const uint32_t* __restrict__ color_all,
@@ -692,7 +721,7 @@ __global__ __launch_bounds__(256, 4) void k_integrate(uint4* __restrict__ voxels
     float wz[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) wz[j] = (float)(8 * bz + 2 * j + lzb) * P.voxel;
-    bool dirty[4] = {false, false, false, false};
+    uint64_t dirty[4] = {0ull, 0ull, 0ull, 0ull};
     // temporal blocking: the tile stays in registers while every frame of the batch that sees the block is fused
     // into it, in frame order (the same sequence of updates per voxel as frame-by-frame integration)
     while (frames != 0u) {
@@ -701,11 +730,11 @@ __global__ __launch_bounds__(256, 4) void k_integrate(uint4* __restrict__ voxels
       const float* Ti = B.Ti[q];
       const float* __restrict__ depthf = depthf_all + (size_t)q * npx;
       const uint32_t* __restrict__ color = color_all + (size_t)q * npx;
-      fuse_rows<SIGN, COLOR, TAB, WS1, 0, 4>(P, Ti, depthf, color, s_rtab, wx, wy, wz, v, dirty);
+      fuse_rows<SIGN, COLOR, TAB, WM, 0, 4>(P, Ti, depthf, color, s_rtab, wx, wy, wz, v, dirty);
     }
 #pragma unroll
     for (int j = 0; j < 4; j++)
-      if (dirty[j]) vb[j * 64 + lane] = v[j];
+      if ((dirty[j] >> lane) & 1ull) vb[j * 64 + lane] = v[j];
   }
 }
 
@@ -730,8 +759,12 @@ __global__ __launch_bounds__(256, 4) void k_integrate(uint4* __restrict__ voxels
 // the colour variant stays on k_integrate.  Arithmetic = fuse_project / fuse_update, bit-identical to k_integrate.
 // ---------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-template <bool TAB, bool WS1>
+// NT: tile loads and stores carry the non-temporal hint -- for passes whose tile set is many times the 256 MiB Infinity Cache (1 mm voxels:
+// 5-7 GB per frame), where keeping streamed tiles on-die only evicts the depth image and the list; below that size the cache hits of
+// consecutive frames are worth more (measured), so run_batch picks the variant from the previous pass's list length.
+template <bool TAB, int WM, bool NT>
 __global__ __launch_bounds__(256, 3) void k_integrate_pipe(uint4* __restrict__ voxels, const uint64_t* __restrict__ block_keys,
                                                         const int32_t* __restrict__ compact, const float* __restrict__ depthf, int32_t* counters,
                                                         int32_t* host_mirror, int compact_counter, ParamsK P, BatchTi B) {
@@ -751,14 +784,24 @@ __global__ __launch_bounds__(256, 3) void k_integrate_pipe(uint4* __restrict__ v
   auto dma_tile = [&](int slot, int ts) {
     const uint4* src = voxels + (size_t)slot * 256 + lane;
     uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\t"
-        "global_load_lds_dwordx4 %[src], off\n\tglobal_load_lds_dwordx4 %[src], off offset:1024\n\t"
-        "global_load_lds_dwordx4 %[src], off offset:2048\n\tglobal_load_lds_dwordx4 %[src], off offset:3072\n\t"
-        "s_mov_b32 m0, %[keep]"
-        : [keep] "=&s"(keep)
-        : [src] "v"(src), [lds] "s"(ring_lds + (uint32_t)ts * 4096u)
-        : "memory");
+    if (NT)
+      asm volatile(
+          "s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\t"
+          "global_load_lds_dwordx4 %[src], off nt\n\tglobal_load_lds_dwordx4 %[src], off offset:1024 nt\n\t"
+          "global_load_lds_dwordx4 %[src], off offset:2048 nt\n\tglobal_load_lds_dwordx4 %[src], off offset:3072 nt\n\t"
+          "s_mov_b32 m0, %[keep]"
+          : [keep] "=&s"(keep)
+          : [src] "v"(src), [lds] "s"(ring_lds + (uint32_t)ts * 4096u)
+          : "memory");
+    else
+      asm volatile(
+          "s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\t"
+          "global_load_lds_dwordx4 %[src], off\n\tglobal_load_lds_dwordx4 %[src], off offset:1024\n\t"
+          "global_load_lds_dwordx4 %[src], off offset:2048\n\tglobal_load_lds_dwordx4 %[src], off offset:3072\n\t"
+          "s_mov_b32 m0, %[keep]"
+          : [keep] "=&s"(keep)
+          : [src] "v"(src), [lds] "s"(ring_lds + (uint32_t)ts * 4096u)
+          : "memory");
   };
   // the 8 gathers of one tile into gather slot `gs` (request j -> bytes [256 j, 256 j + 256) of the slot)
   auto gather8 = [&](const uint32_t (&pix)[8], int gs) {
@@ -801,7 +844,7 @@ __global__ __launch_bounds__(256, 3) void k_integrate_pipe(uint4* __restrict__ v
 #pragma unroll
     for (int j = 0; j < 4; j++) wz[j] = (float)(8 * bz + 2 * j + lzb) * P.voxel;
     bool ok[8];
-    fuse_project<0, 4>(P, Ti, wx, wy, wz, pz, pix, ok);
+    fuse_project<0, 4, true>(P, Ti, wx, wy, wz, pz, pix, ok);
     okmask = 0u;
 #pragma unroll
     for (int k = 0; k < 8; k++) okmask |= ok[k] ? (1u << k) : 0u;
@@ -874,12 +917,15 @@ __global__ __launch_bounds__(256, 3) void k_integrate_pipe(uint4* __restrict__ v
 #pragma unroll
     for (int k = 0; k < 8; k++) ok[k] = (okmask >> k) & 1u;
     uint32_t cdummy[8];
-    bool dirty[4] = {false, false, false, false};
-    fuse_update<1, false, TAB, WS1, 0, 4>(P, rcp_m, d, cdummy, pz, ok, v, dirty);  // consumes d: the gather slot is free again
+    uint64_t dirty[4] = {0ull, 0ull, 0ull, 0ull};
+    fuse_update<1, false, TAB, WM, 0, 4>(P, rcp_m, d, cdummy, pz, ok, v, dirty);  // consumes d: the gather slot is free again
     uint4* vb = voxels + (size_t)slot * 256;
 #pragma unroll
     for (int j = 0; j < 4; j++)
-      if (dirty[j]) vb[j * 64 + lane] = v[j];
+      if ((dirty[j] >> lane) & 1ull) {
+        if (NT) __builtin_nontemporal_store((u32x4){v[j].x, v[j].y, v[j].z, v[j].w}, reinterpret_cast<u32x4*>(&vb[j * 64 + lane]));
+        else vb[j * 64 + lane] = v[j];
+      }
     if (!has1) break;
     i = i1;
     slot = slot1; slot1 = slot2; slot2 = slot3; slot3 = slot4;
@@ -978,6 +1024,33 @@ __global__ __launch_bounds__(256) void k_gc(uint4* voxels, uint64_t* block_keys,
         heap[at] = slot;
         atomicAdd(&counters[C_GC_FREED], 1);
       }
+    }
+  }
+}
+
+// After a collection that freed blocks: the hash table rebuilt from the directory.  Lock-free open addressing cannot reuse a tombstone
+// safely while other lanes insert the same key (one claims the tombstone, another has already walked past it and claims an empty slot
+// further on), and tombstones that are never reused only lengthen every probe chain over a long scan (round-1 finding).  Collection is
+// synchronous, so it simply leaves no tombstone behind: table cleared, every live block (ghosts included) re-inserted at its home
+// position, block_entry re-pointed.  A surviving block existed before the next batch, so its birth stamp restarts at 0.
+__global__ __launch_bounds__(256) void k_rehash(HashEntry* table, const uint64_t* __restrict__ block_keys, int32_t* block_entry, int32_t* counters, ParamsK P) {
+  const int hw = counters[C_HIGH_WATER];
+  for (int slot = blockIdx.x * 256 + threadIdx.x; slot < hw; slot += gridDim.x * 256) {
+    const uint64_t key = block_keys[slot];
+    if (key == KEY_EMPTY) continue;
+    int bx, by, bz;
+    unpack_key(key, bx, by, bz);
+    uint32_t at = hash_bucket(bx, by, bz, P.num_buckets) * P.bucket_size;
+    for (int probe = 0; probe < MAX_PROBES; ++probe) {
+      if (atomicCAS((unsigned long long*)&table[at].key, (unsigned long long)KEY_EMPTY, (unsigned long long)key) == KEY_EMPTY) {
+        table[at].ptr = slot;
+        table[at].birth = 0u;
+        block_entry[slot] = (int32_t)at;
+        atomicAdd(&counters[C_SLOTS_USED], 1);
+        break;
+      }
+      at++;
+      if (at == P.total_slots) at = 0;
     }
   }
 }
@@ -1207,18 +1280,26 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
   const bool tab = tab_ok;  // the LDS reciprocal table covers weight + sample < 512
   // one frame per launch without colour: the software-pipelined kernel (SF_PIPE=0: always k_integrate)
   if (pipe) {
-    const dim3 pg((unsigned)(f->num_cus * f->pipe_wgs));
-    if (f->p.weight_sample == 1)
-      hipLaunchKernelGGL((k_integrate_pipe<true, true>), pg, dim3(256), 0, s, f->voxels, f->block_keys, f->compact2[sl], f->depthf2[sl], f->counters,
-                         f->host_mirror, cc, f->pk, bt);
-    else
-      hipLaunchKernelGGL((k_integrate_pipe<true, false>), pg, dim3(256), 0, s, f->voxels, f->block_keys, f->compact2[sl], f->depthf2[sl], f->counters,
-                         f->host_mirror, cc, f->pk, bt);
+    const dim3 pg((unsigned)((f->num_cus - f->front_cus) * f->pipe_wgs));   // persistent: exactly what the main stream's CUs hold
+    // non-temporal tile traffic once the previous pass's tile set was beyond twice the Infinity Cache (tune "nt": 0 never, 1 always)
+    const bool nt = f->nt_mode == 1 || (f->nt_mode < 0 && (uint64_t)(uint32_t)last * 4096ull > (512ull << 20));
+#define LAUNCH_PIPE(WMODE)                                                                                                                     \
+  do {                                                                                                                                         \
+    if (nt) hipLaunchKernelGGL((k_integrate_pipe<true, WMODE, true>), pg, dim3(256), 0, s, f->voxels, f->block_keys, f->compact2[sl],          \
+                               f->depthf2[sl], f->counters, f->host_mirror, cc, f->pk, bt);                                                    \
+    else hipLaunchKernelGGL((k_integrate_pipe<true, WMODE, false>), pg, dim3(256), 0, s, f->voxels, f->block_keys, f->compact2[sl],            \
+                            f->depthf2[sl], f->counters, f->host_mirror, cc, f->pk, bt);                                                       \
+  } while (0)
+    if (f->p.weight_sample == 1 && f->pk.wmax == 255) LAUNCH_PIPE(2);
+    else if (f->p.weight_sample == 1) LAUNCH_PIPE(1);
+    else LAUNCH_PIPE(0);
+#undef LAUNCH_PIPE
   } else if (sign > 0) {
-    if (f->p.weight_sample == 1) { if (col) LAUNCH_INT(1, true, true, true); else LAUNCH_INT(1, false, true, true); }  // the shipped setting
-    else if (tab)                { if (col) LAUNCH_INT(1, true, true, false); else LAUNCH_INT(1, false, true, false); }
-    else                         { if (col) LAUNCH_INT(1, true, false, false); else LAUNCH_INT(1, false, false, false); }
-  } else                         { if (col) LAUNCH_INT(-1, true, false, false); else LAUNCH_INT(-1, false, false, false); }
+    if (f->p.weight_sample == 1 && f->pk.wmax == 255) { if (col) LAUNCH_INT(1, true, true, 2); else LAUNCH_INT(1, false, true, 2); }  // the shipped setting
+    else if (f->p.weight_sample == 1) { if (col) LAUNCH_INT(1, true, true, 1); else LAUNCH_INT(1, false, true, 1); }
+    else if (tab)                { if (col) LAUNCH_INT(1, true, true, 0); else LAUNCH_INT(1, false, true, 0); }
+    else                         { if (col) LAUNCH_INT(1, true, false, 0); else LAUNCH_INT(1, false, false, 0); }
+  } else                         { if (col) LAUNCH_INT(-1, true, false, 0); else LAUNCH_INT(-1, false, false, 0); }
 #undef LAUNCH_INT
   if (f->profile) (void)hipEventRecord(e1, s);
   if (f->overlap && sa != s) (void)hipEventRecord(f->ev_fused[sl], s);
@@ -1437,6 +1518,31 @@ SF_API int sf_fuser_tune(sf_fuser* f, const char* key, int value) {
   else if (k == "pipe" && in(0, 1)) f->pipe_mode = value;
   else if (k == "pipe_wgs" && in(1, 3)) f->pipe_wgs = value;
   else if (k == "pipe_overlap" && in(0, 1)) f->pipe_overlap = value != 0;
+  else if (k == "nt" && in(-1, 1)) f->nt_mode = value;
+  else if (k == "front_cus" && in(0, 128)) {
+    // the two streams on disjoint sets of CUs (hipExtStreamCreateWithCUMask): `value` CUs, spread evenly over the chip, run the pre-pass /
+    // allocation / compaction of the NEXT pass while the rest runs integrate -- the short latency-bound kernels no longer queue behind (or
+    // squeeze in between) the workgroups of the bandwidth-bound one.  0: both streams on every CU.
+    const int ncu = f->num_cus;
+    std::vector<uint32_t> front_mask((size_t)(ncu + 31) / 32, 0u), main_mask((size_t)(ncu + 31) / 32, 0u);
+    for (int c = 0; c < ncu; c++) {
+      const bool to_front = value > 0 && (c % (ncu / value)) == 0 && (c / (ncu / value)) < value;
+      (to_front ? front_mask : main_mask)[(size_t)c / 32] |= 1u << (c % 32);
+    }
+    (void)hipStreamDestroy(f->stream);
+    (void)hipStreamDestroy(f->front);
+    f->stream = f->front = nullptr;
+    if (value == 0) {
+      int prio_lo = 0, prio_hi = 0;
+      SF_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+      SF_HIP_CHECK(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
+      SF_HIP_CHECK(hipStreamCreateWithPriority(&f->front, hipStreamNonBlocking, prio_hi));
+    } else {
+      SF_HIP_CHECK(hipExtStreamCreateWithCUMask(&f->stream, (uint32_t)main_mask.size(), main_mask.data()));
+      SF_HIP_CHECK(hipExtStreamCreateWithCUMask(&f->front, (uint32_t)front_mask.size(), front_mask.data()));
+    }
+    f->front_cus = value;
+  }
   else if (k == "alloc_group" && in(1, MAX_BATCH)) f->alloc_group = value;
   else return sf::fail(SF_ERR_INVALID_ARG, "sf_fuser_tune: unknown key or value out of range: %s = %d", key, value);
   return SF_OK;
@@ -1565,6 +1671,12 @@ SF_API int sf_fuser_garbage_collect(sf_fuser* f, uint32_t* freed) {
   int32_t fr = 0;
   SF_HIP_CHECK(hipMemcpyAsync(&fr, &f->counters[C_GC_FREED], 4, hipMemcpyDeviceToHost, f->stream));
   SF_HIP_CHECK(sf_quiesce(f));
+  if (fr > 0) {   // leave no tombstone behind: rebuild the table from the directory
+    SF_HIP_CHECK(hipMemsetAsync(f->table, 0xFF, (size_t)f->pk.total_slots * sizeof(HashEntry), f->stream));
+    SF_HIP_CHECK(hipMemsetAsync(&f->counters[C_SLOTS_USED], 0, 4, f->stream));
+    hipLaunchKernelGGL(k_rehash, dim3(f->compact_grid), dim3(256), 0, f->stream, f->table, f->block_keys, f->block_entry, f->counters, f->pk);
+    SF_HIP_CHECK(sf_quiesce(f));
+  }
   if (freed) *freed = (uint32_t)fr;
   return SF_OK;
 }

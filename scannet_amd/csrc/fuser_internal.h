@@ -135,6 +135,12 @@ __device__ inline int hash_lookup(const HashEntry* __restrict__ table, const Par
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ inline v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ inline v2f splat(float x) { return (v2f){x, x}; }
+// one v_pk_add_f32 (the compiler splits a packed add whose two results go separate ways into two v_add_f32)
+__device__ inline v2f pk_add(v2f a, v2f b) {
+  v2f r;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 // RN(1 / b) for normal-range b: v_rcp_f32 seed (1 ulp) + two Newton steps
 __device__ inline v2f recip_rn(v2f b) {
   v2f r = {__builtin_amdgcn_rcpf(b.x), __builtin_amdgcn_rcpf(b.y)};
@@ -183,6 +189,8 @@ struct sf_fuser {
   bool xcd_walk = true;  // k_integrate: each XCD walks one contiguous eighth of the list (tune "xcd_walk" 0: plain grid-stride)
   int pipe_mode = 1;    // 1: colourless one-frame launches run k_integrate_pipe (tune "pipe" 0: k_integrate)
   int pipe_wgs = 3;     // persistent workgroups per CU of k_integrate_pipe (48 KiB of LDS each)
+  int front_cus = 0;    // > 0: the front stream owns that many CUs, the main stream the others (tune "front_cus")
+  int nt_mode = -1;     // k_integrate_pipe tile traffic non-temporal: -1 = when the previous pass's tiles exceed 512 MiB, 0 never, 1 always (tune "nt")
   bool pipe_overlap = true;  // the next frame's pre-pass / allocation / compaction runs on the front stream beside k_integrate_pipe (tune "pipe_overlap")
   int alloc_group = 4;  // consecutive frames of a batch one k_alloc workgroup walks (tune "alloc_group")
   int compact_grid = 1024;  // 1024 directory entries per workgroup, grid-stride beyond

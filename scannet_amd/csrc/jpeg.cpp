@@ -176,7 +176,7 @@ const uint8_t ZIGZAG[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4,
 // dequantised 16-bit coefficients (natural order) -> 8 x 8 samples
 void idct_block(int* blk, bool dc_only, uint8_t* out, int stride) {
   if (dc_only) {   // every other input of both passes is zero: all 64 samples equal ((dc << 14) + rounding + level shift) >> 17
-    const uint8_t v = sf_jpeg_clamp8((int32_t)((uint32_t)blk[0] * 16384u + 65536u + (128u << 17)) >> 17);
+    const uint8_t v = sf_jpeg_shift_clamp8((int32_t)((uint32_t)blk[0] * 16384u + 65536u + (128u << 17)), 17);
     for (int y = 0; y < 8; y++) std::memset(out + (size_t)y * stride, v, 8);
     return;
   }
@@ -468,4 +468,10 @@ int jpeg_decode_rgb(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t expe
 int jpeg_decode_coef(const uint8_t* data, uint64_t n, uint32_t expect_w, uint32_t expect_h, uint8_t* payload, uint64_t payload_capacity) {
   if (!payload) return sf::fail(SF_ERR_INVALID_ARG, "jpeg_decode_coef: NULL argument");
   return decode_impl(data, n, nullptr, expect_w, expect_h, payload, payload_capacity);
+}
+
+// Baseline JPEG -> RGB on the host (what sf_sens_decode_color does for a TYPE_JPEG frame)
+SF_API int sf_jpeg_decode(const uint8_t* data, uint64_t bytes, uint32_t width, uint32_t height, uint8_t* dst_rgb) {
+  if (!data || !dst_rgb) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  return jpeg_decode_rgb(data, bytes, dst_rgb, width, height);
 }

@@ -146,11 +146,6 @@ int jpeg_gpu_reconstruct(hipStream_t stream, int n, const uint8_t* const* d_payl
 int jpeg_decode_rgb(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t expect_w, uint32_t expect_h);                                          // jpeg.cpp
 int jpeg_decode_coef(const uint8_t* data, uint64_t n, uint32_t expect_w, uint32_t expect_h, uint8_t* payload, uint64_t payload_capacity);  // jpeg.cpp
 
-// Baseline JPEG -> RGB on the host (what sf_sens_decode_color does for a TYPE_JPEG frame)
-SF_API int sf_jpeg_decode(const uint8_t* data, uint64_t bytes, uint32_t width, uint32_t height, uint8_t* dst_rgb) {
-  if (!data || !dst_rgb) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
-  return jpeg_decode_rgb(data, bytes, dst_rgb, width, height);
-}
 
 // The same picture through the GPU path of the frame pipeline: entropy decoding here, reconstruction on `device`, result copied back.
 // One frame, synchronous -- an entry point for callers that want the pixels in HBM anyway and for the parity test; SF_ERR_UNSUPPORTED

@@ -22,7 +22,19 @@
 
 SF_JHD inline uint8_t sf_jpeg_clamp8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
 
-// One 8-point pass.  in: the eight inputs; out k receives (value_k + bias) >> shift, handed to `emit(k, v)`.
+// (x >> shift) clamped to 0..255.  On the device the shifted value passes through an empty asm statement: hipcc (ROCm 7.2) otherwise fuses
+// "arithmetic shift + clamp" of two neighbouring samples into gfx950's v_ashr_pk_u8_i32 and then ORs further bytes into the upper half of
+// its result as if it were zero -- on the MI355X that half holds other bits (measured: samples 2 and 3 of a packed group came back as
+// value | 0x80 / 0xff; tools/gpu/debug_jpeg.py).  The barrier keeps the two operations apart; the result is the plain integer one.
+SF_JHD inline uint8_t sf_jpeg_shift_clamp8(int32_t x, int shift) {
+  int32_t t = x >> shift;
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(t));
+#endif
+  return sf_jpeg_clamp8(t);
+}
+
+// One 8-point pass.  in: the eight inputs; out k = (value_k + bias) >> shift; `emit(k, value_k + bias, shift)` stores it.
 // 32-bit wrapping arithmetic: unsigned for the sums and products, the final shift on the signed reinterpretation.
 template <class Emit>
 SF_JHD inline void sf_idct8_int(int s0, int s1, int s2, int s3, int s4, int s5, int s6, int s7, uint32_t bias, int shift, Emit emit) {
@@ -41,10 +53,11 @@ SF_JHD inline void sf_idct8_int(int s0, int s1, int s2, int s3, int s4, int s5, 
   const u od2 = (u)s3 * (u)12586 + r2 + r3;
   const u od1 = (u)s5 * (u)8410 + r2 + r4;
   const u od0 = (u)s7 * (u)1223 + r1 + r3;
-  emit(0, (int32_t)(a0 + od3) >> shift); emit(7, (int32_t)(a0 - od3) >> shift);
-  emit(1, (int32_t)(a1 + od2) >> shift); emit(6, (int32_t)(a1 - od2) >> shift);
-  emit(2, (int32_t)(a2 + od1) >> shift); emit(5, (int32_t)(a2 - od1) >> shift);
-  emit(3, (int32_t)(a3 + od0) >> shift); emit(4, (int32_t)(a3 - od0) >> shift);
+  // emit receives the UNSHIFTED sum and the shift (the row pass clamps behind the shift: sf_jpeg_shift_clamp8)
+  emit(0, (int32_t)(a0 + od3), shift); emit(7, (int32_t)(a0 - od3), shift);
+  emit(1, (int32_t)(a1 + od2), shift); emit(6, (int32_t)(a1 - od2), shift);
+  emit(2, (int32_t)(a2 + od1), shift); emit(5, (int32_t)(a2 - od1), shift);
+  emit(3, (int32_t)(a3 + od0), shift); emit(4, (int32_t)(a3 - od0), shift);
 }
 
 // dequantised 16-bit coefficients (natural order, blk[8 v + u]) -> 64 levels in place
@@ -54,14 +67,14 @@ SF_JHD inline void sf_idct_block_int(int* blk) {
 #endif
   for (int c = 0; c < 8; c++) {
     int* col = blk + c;
-    sf_idct8_int(col[0], col[8], col[16], col[24], col[32], col[40], col[48], col[56], 512u, 10, [&](int k, int v) { col[8 * k] = v; });
+    sf_idct8_int(col[0], col[8], col[16], col[24], col[32], col[40], col[48], col[56], 512u, 10, [&](int k, int32_t v, int sh) { col[8 * k] = v >> sh; });
   }
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
   for (int r = 0; r < 8; r++) {
     int* row = blk + 8 * r;
-    sf_idct8_int(row[0], row[1], row[2], row[3], row[4], row[5], row[6], row[7], 65536u + (128u << 17), 17, [&](int k, int v) { row[k] = (int)sf_jpeg_clamp8(v); });
+    sf_idct8_int(row[0], row[1], row[2], row[3], row[4], row[5], row[6], row[7], 65536u + (128u << 17), 17, [&](int k, int32_t v, int sh) { row[k] = (int)sf_jpeg_shift_clamp8(v, sh); });
   }
 }
 
@@ -75,9 +88,9 @@ SF_JHD inline void sf_jpeg_ycc_to_rgb(int Y, int cb, int cr, uint8_t* o) {
   const int32_t r = (int32_t)(yf + (uint32_t)cr * 1470208u);
   const int32_t g = (int32_t)(yf + (uint32_t)cr * (uint32_t)-748800 + (((uint32_t)cb * (uint32_t)-360960) & 0xffff0000u));
   const int32_t b = (int32_t)(yf + (uint32_t)cb * 1858048u);
-  o[0] = sf_jpeg_clamp8(r >> 20);
-  o[1] = sf_jpeg_clamp8(g >> 20);
-  o[2] = sf_jpeg_clamp8(b >> 20);
+  o[0] = sf_jpeg_shift_clamp8(r, 20);
+  o[1] = sf_jpeg_shift_clamp8(g, 20);
+  o[2] = sf_jpeg_shift_clamp8(b, 20);
 }
 
 // ---- entropy-decoded frame handed to the GPU (jpeg_gpu.hip): this header, a block table, the non-zero coefficients ----------------

@@ -351,18 +351,19 @@ SF_API int sf_mesh_counts(const sf_mesh* m, uint64_t* nv, uint64_t* nf) {
 SF_API int sf_mesh_copy_face_keys(const sf_mesh* m, uint64_t* face_keys) {
   if (!m || !face_keys) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
   if (m->tkeys.size() * 3 != m->tri.size()) return sf::fail(SF_ERR_INVALID_ARG, "mesh has no face keys");
-  std::memcpy(face_keys, m->tkeys.data(), m->tkeys.size() * 8);
+  if (!m->tkeys.empty()) std::memcpy(face_keys, m->tkeys.data(), m->tkeys.size() * 8);
   return SF_OK;
 }
 
 SF_API int sf_mesh_copy(const sf_mesh* m, float* xyz, uint8_t* rgba, uint32_t* tris, uint64_t* keys) {
   if (!m) return sf::fail(SF_ERR_INVALID_ARG, "NULL mesh");
-  if (xyz) std::memcpy(xyz, m->pos.data(), m->pos.size() * 4);
+  // an empty mesh has empty vectors: data() may be NULL, which memcpy must not be handed even for 0 bytes (UBSan, tools/sanitize.py)
+  if (xyz && !m->pos.empty()) std::memcpy(xyz, m->pos.data(), m->pos.size() * 4);
   if (rgba) {
-    if (m->col.empty()) std::memset(rgba, 255, m->pos.size() / 3 * 4);
+    if (m->col.empty()) { if (!m->pos.empty()) std::memset(rgba, 255, m->pos.size() / 3 * 4); }
     else std::memcpy(rgba, m->col.data(), m->col.size());
   }
-  if (tris) std::memcpy(tris, m->tri.data(), m->tri.size() * 4);
+  if (tris && !m->tri.empty()) std::memcpy(tris, m->tri.data(), m->tri.size() * 4);
   if (keys) {
     if (m->keys.empty()) return sf::fail(SF_ERR_INVALID_ARG, "mesh has no vertex keys");
     std::memcpy(keys, m->keys.data(), m->keys.size() * 8);

@@ -171,24 +171,26 @@ class SensorData:
     def save(self, filename):
         check(_abi.lib().sf_sens_save(self._h, os.fsencode(filename)))
 
-    # -- exports (SensorData.py:76-124) -----------------------------------------------------------------
+    # -- exports: the file layout of SensorData.py:76-124 (one "%f %f %f %f" line per matrix row) ------------------------------------
     @staticmethod
     def save_mat_to_file(matrix, filename):
-        with open(filename, 'w') as f:
-            for line in matrix:
-                np.savetxt(f, line[np.newaxis], fmt='%f')
+        rows = np.asarray(matrix, np.float64).reshape(-1, np.asarray(matrix).shape[-1])
+        with open(filename, "w") as out:
+            out.write("".join(" ".join("%f" % v for v in row) + "\n" for row in rows))
 
     def export_poses(self, output_path, frame_skip=1):
+        """<output_path>/<frame index>.txt = camera-to-world of every frame_skip-th frame."""
         os.makedirs(output_path, exist_ok=True)
-        for f in range(0, len(self.frames), frame_skip):
-            self.save_mat_to_file(self.frames[f].camera_to_world, os.path.join(output_path, str(f) + '.txt'))
+        for index, frame in list(enumerate(self.frames))[::frame_skip]:
+            self.save_mat_to_file(frame.camera_to_world, os.path.join(output_path, "%d.txt" % index))
 
     def export_intrinsics(self, output_path):
+        """intrinsic_color / extrinsic_color / intrinsic_depth / extrinsic_depth .txt"""
         os.makedirs(output_path, exist_ok=True)
-        self.save_mat_to_file(self.intrinsic_color, os.path.join(output_path, 'intrinsic_color.txt'))
-        self.save_mat_to_file(self.extrinsic_color, os.path.join(output_path, 'extrinsic_color.txt'))
-        self.save_mat_to_file(self.intrinsic_depth, os.path.join(output_path, 'intrinsic_depth.txt'))
-        self.save_mat_to_file(self.extrinsic_depth, os.path.join(output_path, 'extrinsic_depth.txt'))
+        for kind in ("intrinsic", "extrinsic"):
+            for camera in ("color", "depth"):
+                name = "%s_%s" % (kind, camera)
+                self.save_mat_to_file(getattr(self, name), os.path.join(output_path, name + ".txt"))
 
     def export_depth_images(self, output_path, frame_skip=1):
         """16-bit PGM dumps (the reference writes 16-bit PNG through pypng, which is not available here)."""

@@ -143,6 +143,42 @@ def test_colour_deintegrate_gc_ragged(oracle):
         assert f.stats()["alloc_failures"] == 0
 
 
+def test_garbage_collection_inside_a_long_stream(oracle):
+    """s_garbageCollectionEnabled = true (zParametersScanNet.txt:83): collection runs repeatedly INSIDE a stream.  A walk whose far walls
+    come and go: blocks observed only beyond the truncation band are freed every few frames (most of each frame is deintegrated again to
+    make that happen often), later frames re-allocate them.  After every collection the hash table holds exactly the live blocks (no
+    tombstone survives: probe chains do not grow over a long scan), nothing fails to allocate, and the volume stays bit-identical to the
+    oracle's -- one frame per pass and 16 frames per pass."""
+    import torch
+    from scannet_amd import fusion
+    W, H = 160, 120
+    op, gp = _mk(oracle, W, H, voxel=0.02, num_sdf_blocks=1 << 14, hash_num_buckets=1 << 11)   # a small table: chains would show
+    ovol = oracle.Volume(op, threads=8)
+    frames = [(synth.render_room_depth(synth.trajectory_pose(7 * i, 600), W, H, noise_frame=i), synth.trajectory_pose(7 * i, 600)) for i in range(96)]
+    with fusion.Fuser(gp) as f, fusion.Fuser(gp) as g:
+        freed_total = 0
+        for a in range(0, 96, 8):
+            chunk = frames[a:a + 8]
+            for d, pose in chunk:
+                ovol.integrate(d, pose)
+                assert f.integrate(d, pose)
+            dev = torch.from_numpy(np.stack([d for d, _ in chunk]).view(np.int16)).cuda()
+            g.integrate_batch_device(dev.data_ptr(), W * H * 2, np.stack([p.reshape(16) for _, p in chunk]).astype(np.float32))
+            for d, pose in (chunk if (a // 8) % 2 else chunk[:6]):   # take most (every other time: all) of it back: blocks left with weight 0 everywhere are collected
+                ovol.deintegrate(d, pose)
+                assert f.deintegrate(d, pose)
+                assert g.deintegrate(d, pose)
+            fo = ovol.garbage_collect()
+            assert f.garbage_collect() == fo and g.garbage_collect() == fo
+            freed_total += fo
+            for h in (f, g):
+                st = h.stats()
+                assert st["hash_slots_used"] == st["blocks_allocated"] == ovol.num_blocks and st["alloc_failures"] == 0
+        assert freed_total > 3000 and freed_total > ovol.num_blocks / 2   # thousands of table entries came and went
+        _assert_same(ovol, f)
+        _assert_same(ovol, g)
+
+
 def test_invalid_pose_and_empty_depth(oracle):
     from scannet_amd import fusion
     op, gp = _mk(oracle, 160, 120, voxel=0.02, num_sdf_blocks=1 << 14)
