@@ -58,6 +58,12 @@ typedef struct sf_params {
    * black outside the colour image -- depth and colour share the extrinsics in ScanNet's .sens files. */
   int32_t color_width, color_height;
   float cfx, cfy, cmx, cmy;            /* colour intrinsics (m_calibrationColor, sensorData.h:1264) */
+  /* s_integrationWidth / s_integrationHeight (zParametersScanNet.txt:20-21, shipped as 320 x 240: "input depth gets re-sampled to this
+   * width").  0 x 0: integrate at depth_width x depth_height.  Otherwise every frame is resampled to this size before anything else:
+   * integration pixel (x, y) takes input pixel ((uint)(x * (depth_width - 1) / (integration_width - 1) + 0.5f), same in y) -- nearest, the
+   * sampling convention of the reference's own resample kernels (AnnotationTools/Filter2dAnnotations/filter.cu:647-665) --, the intrinsics
+   * follow it (fx * iw / dw, mx * (iw - 1) / (dw - 1): Calibrate/src/calibration.h:125-128), colour is looked up under the same ray. */
+  int32_t integration_width, integration_height;
 } sf_params;
 
 /* SURVEY 8d camera + zParametersScanNet.txt values with BASELINE.json's 4 mm / 2^19-bucket overrides */

@@ -20,7 +20,8 @@ extern "C" {
  *   "xcd_walk"    0/1    each XCD walks one contiguous eighth of the block list (default 1)
  *   "pipe"        0/1    colourless one-frame passes run the software-pipelined persistent kernel (default 1)
  *   "pipe_wgs"    1..3   persistent workgroups per CU of that kernel (default 3)
- *   "pipe_overlap" 0/1   the next frame's pre-pass / allocation / compaction runs on the second stream beside that kernel (default 1)
+ *   "pipe_overlap" -1/0/1 the next frame's pre-pass / allocation / compaction runs on the second stream beside that kernel: -1 = when the previous
+ *                        pass touched more than 512 MiB of tiles (default), 0 never, 1 always
  *   "nt"          -1/0/1 that kernel's tile loads and stores non-temporal: -1 = when the previous pass touched more than 512 MiB of tiles (default)
  *   "front_cus"   0..128 the second stream owns that many CUs (spread over the chip), the main stream the rest (hipExtStreamCreateWithCUMask); 0 = shared
  *   "alloc_group" 1..16  consecutive frames one allocation workgroup walks (default 4)

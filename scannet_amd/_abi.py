@@ -21,6 +21,7 @@ class SfParams(C.Structure):
         ("mc_max_triangles", C.c_uint32), ("gc_enabled", C.c_int32),
         ("color_width", C.c_int32), ("color_height", C.c_int32),
         ("cfx", C.c_float), ("cfy", C.c_float), ("cmx", C.c_float), ("cmy", C.c_float),
+        ("integration_width", C.c_int32), ("integration_height", C.c_int32),
     ]
 
 

@@ -68,7 +68,15 @@ __global__ __launch_bounds__(256) void k_prepass(BatchIn in, float* __restrict__
   }
   if (i0 >= n) return;
   uint16_t u[8];
-  if (i0 + 8 <= n) {
+  if (P.inW > 0) {
+    // s_integrationWidth / Height: nearest resample of the inW x inH input (scanfuse.h sf_params::integration_width)
+    for (int k = 0; k < 8; k++) {
+      const int i = i0 + k;
+      if (i >= n) { u[k] = 0; continue; }
+      const unsigned xi = (unsigned)((float)(i % P.W) * P.rsx + 0.5f), yi = (unsigned)((float)(i / P.W) * P.rsy + 0.5f);
+      u[k] = (xi < (unsigned)P.inW && yi < (unsigned)P.inH) ? depth[(size_t)yi * P.inW + xi] : (uint16_t)0;
+    }
+  } else if (i0 + 8 <= n) {
     const uint4 raw = *reinterpret_cast<const uint4*>(depth + i0);
     u[0] = raw.x & 0xFFFF; u[1] = raw.x >> 16; u[2] = raw.y & 0xFFFF; u[3] = raw.y >> 16;
     u[4] = raw.z & 0xFFFF; u[5] = raw.z >> 16; u[6] = raw.w & 0xFFFF; u[7] = raw.w >> 16;
@@ -544,31 +552,41 @@ template <int SIGN, bool COLOR, bool TAB, int WM, int J0, int NJ>
 __device__ inline void fuse_update(const ParamsK& P, const v2f (&rcp_m)[NJ], const float (&d)[2 * NJ], const uint32_t (&c)[2 * NJ], const v2f (&pz)[NJ],
                                    const bool (&ok)[2 * NJ], uint4 (&v)[4], uint64_t (&dirty)[4]) {
   constexpr bool WS1 = WM >= 1;
-  // ---- phase B: new values into temporaries (the tile itself stays untouched until the end)
+  // ---- phase B1: which voxels does this frame update?  Then a wave-uniform early-out: 10-25 % of the (block, frame) pairs the frustum
+  // test lets through update nothing (blocks behind the surface, beyond the integration distance, over invalid depth, in the sliver
+  // between the image border and the conservative sphere test) -- everything below (weighted mean, weights, selects: ~40 % of the
+  // instructions of a frame) is skipped for them.  Measured on the configs[1] stream with the CPU checker: tools/waste.py.
   const float wn = (float)P.wsample;
   const uint32_t maxd_bits = __float_as_uint(P.maxd);
   v2f q[NJ], sdfc[NJ];
   uint32_t ncw[2 * NJ];
   bool upd[2 * NJ];
   bool sat[2 * NJ];
-#pragma unroll
-  for (int k = 0; k < 2 * NJ; k++) sat[k] = false;
-  bool slow = false;
+  bool any_upd = false;
 #pragma unroll
   for (int j = 0; j < NJ; j++) {
     const v2f dk = {d[2 * j], d[2 * j + 1]};
     v2f sdf = dk - pz[j];
     const v2f t = pk_fma(splat(P.tscale), dk, splat(P.tbase));
-    const uint32_t cwj[2] = {v[J0 + j].y, v[J0 + j].w};
-    const v2f wo = {(float)(cwj[0] >> 24), (float)(cwj[1] >> 24)};
-    const v2f old = {__uint_as_float(v[J0 + j].x), __uint_as_float(v[J0 + j].z)};
 #pragma unroll
     for (int hx = 0; hx < 2; hx++) {
       // valid depth (-inf has the sign bit set, valid depths are positive) below the integration distance, not behind the band
       upd[2 * j + hx] = ok[2 * j + hx] && (__float_as_uint(dk[hx]) < maxd_bits) && (sdf[hx] > -t[hx]);
       sdf[hx] = fminf(sdf[hx], t[hx]);
+      sat[2 * j + hx] = false;
+      any_upd = any_upd || upd[2 * j + hx];
     }
     sdfc[j] = sdf;
+  }
+  if (!__any((int)any_upd)) return;
+  // ---- phase B2: new values into temporaries (the tile itself stays untouched until the end)
+  bool slow = false;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    const v2f sdf = sdfc[j];
+    const uint32_t cwj[2] = {v[J0 + j].y, v[J0 + j].w};
+    const v2f wo = {(float)(cwj[0] >> 24), (float)(cwj[1] >> 24)};
+    const v2f old = {__uint_as_float(v[J0 + j].x), __uint_as_float(v[J0 + j].z)};
     if (SIGN > 0) {
       const v2f n = pk_fma(old, wo, WS1 ? sdf : sdf * splat(wn));  // x * 1.0f == x bit for bit
       const v2f m = wo + splat(wn);
@@ -943,6 +961,7 @@ __global__ __launch_bounds__(256, 3) void k_integrate_pipe(uint4* __restrict__ v
 // is the ceiling the access pattern itself (scattered 4 KiB read-modify-write) allows on this HBM; bench.py reports
 // the one-frame-per-launch kernel against it (sf_fuser_calib_tile_rmw).  The volume is left bit-identical.
 // ---------------------------------------------------------------------------------------------------
+template <bool NT>
 __global__ __launch_bounds__(256, 4) void k_tile_rmw(uint4* __restrict__ voxels, const int32_t* __restrict__ compact,
                                                   const int32_t* __restrict__ counters, int compact_counter, int xcd_walk, int read_only,
                                                   uint32_t* sink) {
@@ -961,7 +980,10 @@ __global__ __launch_bounds__(256, 4) void k_tile_rmw(uint4* __restrict__ voxels,
     uint4* vb = voxels + (size_t)compact[i] * 256;
     uint4 v[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) v[j] = vb[j * 64 + lane];
+    for (int j = 0; j < 4; j++) {
+      if (NT) { const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(&vb[j * 64 + lane])); v[j] = make_uint4(t.x, t.y, t.z, t.w); }
+      else v[j] = vb[j * 64 + lane];
+    }
     if (read_only) {
 #pragma unroll
       for (int j = 0; j < 4; j++) acc ^= v[j].x ^ v[j].y ^ v[j].z ^ v[j].w;
@@ -969,7 +991,8 @@ __global__ __launch_bounds__(256, 4) void k_tile_rmw(uint4* __restrict__ voxels,
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         asm volatile("" : "+v"(v[j].x));  // opaque to the optimiser: the store below stays
-        vb[j * 64 + lane] = v[j];
+        if (NT) __builtin_nontemporal_store((u32x4){v[j].x, v[j].y, v[j].z, v[j].w}, reinterpret_cast<u32x4*>(&vb[j * 64 + lane]));
+        else vb[j * 64 + lane] = v[j];
       }
     }
   }
@@ -1191,7 +1214,14 @@ static bool pipe_batch(const sf_fuser* f, int n, bool color, int sign) {
   const bool tab_ok = f->p.weight_sample >= 1 && f->p.weight_sample <= RTAB - 256;
   return sign > 0 && n == 1 && !color && tab_ok && f->pipe_mode != 0;
 }
-bool sf_single_stream_batch(const sf_fuser* f, int n, bool color, int sign) { return pipe_batch(f, n, color, sign) && !f->pipe_overlap; }
+// Whether the next frame's pre-pass / allocation / compaction should run on the front stream beside the persistent kernel.  Measured on
+// MI355X (profiles/r02): at 4 mm (48-67 k tiles per frame, front kernels 36 us) running them beside k_integrate_pipe stretches it by more
+// than it hides (7.8 k frames/s serial, 7.5 k overlapped, also with the two streams on disjoint CU masks); at 1 mm (1.7 M tiles, front
+// kernels 1 ms) it hides 0.5 ms per frame (310 vs 269 frames/s).  So: overlap once the previous pass's tile set is beyond 512 MiB.
+static bool big_pass(const sf_fuser* f) { return (uint64_t)(uint32_t)*f->host_mirror * 4096ull > (512ull << 20); }
+// The decision is latched at the end of every pass (run_batch) so that a caller's staging (sf_input_stream) and the pass that follows see the
+// same answer: host_mirror is written by the device while they run.
+bool sf_single_stream_batch(const sf_fuser* f, int n, bool color, int sign) { return pipe_batch(f, n, color, sign) && !f->pipe_beside; }
 // the stream the pre-pass of such a batch reads its frames on: where callers must have staged them
 hipStream_t sf_input_stream(const sf_fuser* f, int n, bool color, int sign) {
   return (f->overlap && !sf_single_stream_batch(f, n, color, sign)) ? f->front : f->stream;
@@ -1282,7 +1312,7 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
   if (pipe) {
     const dim3 pg((unsigned)((f->num_cus - f->front_cus) * f->pipe_wgs));   // persistent: exactly what the main stream's CUs hold
     // non-temporal tile traffic once the previous pass's tile set was beyond twice the Infinity Cache (tune "nt": 0 never, 1 always)
-    const bool nt = f->nt_mode == 1 || (f->nt_mode < 0 && (uint64_t)(uint32_t)last * 4096ull > (512ull << 20));
+    const bool nt = f->nt_mode == 1 || (f->nt_mode < 0 && big_pass(f));
 #define LAUNCH_PIPE(WMODE)                                                                                                                     \
   do {                                                                                                                                         \
     if (nt) hipLaunchKernelGGL((k_integrate_pipe<true, WMODE, true>), pg, dim3(256), 0, s, f->voxels, f->block_keys, f->compact2[sl],          \
@@ -1304,6 +1334,7 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
   if (f->profile) (void)hipEventRecord(e1, s);
   if (f->overlap && sa != s) (void)hipEventRecord(f->ev_fused[sl], s);
   if (f->overlap && sa == s) f->serial_tail = true;  // no cross-stream traffic at all while single-stream batches follow each other
+  f->pipe_beside = f->pipe_overlap == 1 || (f->pipe_overlap < 0 && big_pass(f));
   const hipError_t err = hipGetLastError();
   if (err != hipSuccess) return sf::fail(SF_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(err));
   f->frames_integrated += (uint64_t)n;
@@ -1339,6 +1370,9 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
     return sf::fail(SF_ERR_INVALID_ARG, "invalid reconstruction parameters");
   if (p->color_width > 0 && p->color_height > 0 && !(p->cfx > 0 && p->cfy > 0))
     return sf::fail(SF_ERR_INVALID_ARG, "colour resolution given without colour intrinsics");
+  if ((p->integration_width > 0) != (p->integration_height > 0) || p->integration_width == 1 || p->integration_height == 1 ||
+      (p->integration_width > 0 && (p->depth_width < 2 || p->depth_height < 2)))
+    return sf::fail(SF_ERR_INVALID_ARG, "integration size %d x %d", p->integration_width, p->integration_height);
   if ((uint64_t)p->hash_num_buckets * p->hash_bucket_size > 0x7FFFFFFFull || p->num_sdf_blocks > 0x3FFFFFFFu)
     return sf::fail(SF_ERR_INVALID_ARG, "hash table / heap too large for 32-bit slot indices");
   int ndev = 0;
@@ -1367,6 +1401,21 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
   }
   ParamsK& k = f->pk;
   k.W = p->depth_width; k.H = p->depth_height; k.fx = p->fx; k.fy = p->fy; k.mx = p->mx; k.my = p->my;
+  k.inW = k.inH = 0; k.rsx = k.rsy = 1.0f;
+  const bool resample = p->integration_width > 0 && p->integration_height > 0 &&
+                        (p->integration_width != p->depth_width || p->integration_height != p->depth_height);
+  if (resample) {
+    // everything behind the pre-pass works at the integration size with the intrinsics that follow the resample
+    k.inW = p->depth_width; k.inH = p->depth_height;
+    k.W = p->integration_width; k.H = p->integration_height;
+    k.rsx = (float)(k.inW - 1) / (float)(k.W - 1);
+    k.rsy = (float)(k.inH - 1) / (float)(k.H - 1);
+    k.fx = p->fx * ((float)k.W / (float)k.inW); k.fy = p->fy * ((float)k.H / (float)k.inH);
+    k.mx = p->mx * ((float)(k.W - 1) / (float)(k.inW - 1)); k.my = p->my * ((float)(k.H - 1) / (float)(k.inH - 1));
+    f->p.depth_width = k.W; f->p.depth_height = k.H; f->p.fx = k.fx; f->p.fy = k.fy; f->p.mx = k.mx; f->p.my = k.my;   // frame_setup sees the integration camera
+  }
+  f->in_W = p->depth_width; f->in_H = p->depth_height;
+  f->in_px = (size_t)p->depth_width * p->depth_height;
   k.depth_shift = p->depth_shift; k.dmin = p->depth_min; k.dmax = p->depth_max; k.voxel = p->voxel_size;
   k.tbase = p->trunc_base; k.tscale = p->trunc_scale; k.maxd = p->max_integration_dist;
   k.wsample = p->weight_sample; k.wmax = f->p.weight_max;
@@ -1376,6 +1425,10 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
   k.cW = p->color_width > 0 && p->color_height > 0 ? p->color_width : 0;
   k.cH = k.cW ? p->color_height : 0;
   k.cfx = p->cfx; k.cfy = p->cfy; k.cmx = p->cmx; k.cmy = p->cmy;
+  if (resample && k.cW == 0) {   // colour frames at the INPUT depth resolution: "their own resolution" as far as the integration camera is concerned
+    k.cW = p->depth_width; k.cH = p->depth_height;
+    k.cfx = p->fx; k.cfy = p->fy; k.cmx = p->mx; k.cmy = p->my;
+  }
   hipDeviceProp_t prop;
   SF_CREATE_CHECK(hipGetDeviceProperties(&prop, device));
   f->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -1417,7 +1470,7 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
   }
   f->compact = f->compact2[0];
   SF_ALLOC(f->counters, C_COUNT * 4);
-  SF_ALLOC(f->staging_depth, npx * 2);
+  SF_ALLOC(f->staging_depth, f->in_px * 2);
   SF_ALLOC(f->staging_rgb, (k.cW ? (size_t)k.cW * k.cH : npx) * 3);
 #undef SF_ALLOC
   SF_CREATE_CHECK(hipHostMalloc((void**)&f->host_mirror, 64, hipHostMallocMapped));
@@ -1456,11 +1509,11 @@ static int fuse_host(sf_fuser* f, const uint16_t* depth, const uint8_t* rgb, con
   if (!f || !depth || !pose) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
   if (pose[0] == -INFINITY) { f->frames_skipped++; return sf::fail(SF_ERR_SKIPPED, "frame skipped: camToWorld is -inf (tracking lost)"); }
   SF_HIP_CHECK(hipSetDevice(f->device));
-  const size_t npx = (size_t)f->p.depth_width * f->p.depth_height;
+  const size_t npx = (size_t)f->pk.W * f->pk.H;
   // the staging buffer is reused: wait for the previous frame's kernels before overwriting it
   SF_HIP_CHECK(sf_quiesce(f));
   hipStream_t in_stream = sf_input_stream(f, 1, rgb != nullptr, sign);  // the stream the pre-pass reads the frame on
-  SF_HIP_CHECK(hipMemcpyAsync(f->staging_depth, depth, npx * 2, hipMemcpyHostToDevice, in_stream));
+  SF_HIP_CHECK(hipMemcpyAsync(f->staging_depth, depth, f->in_px * 2, hipMemcpyHostToDevice, in_stream));
   if (rgb) SF_HIP_CHECK(hipMemcpyAsync(f->staging_rgb, rgb, (f->pk.cW ? (size_t)f->pk.cW * f->pk.cH : npx) * 3, hipMemcpyHostToDevice, in_stream));
   return run_frame(f, f->staging_depth, rgb ? f->staging_rgb : nullptr, pose, sign);
 }
@@ -1517,7 +1570,7 @@ SF_API int sf_fuser_tune(sf_fuser* f, const char* key, int value) {
   else if (k == "xcd_walk" && in(0, 1)) f->xcd_walk = value != 0;
   else if (k == "pipe" && in(0, 1)) f->pipe_mode = value;
   else if (k == "pipe_wgs" && in(1, 3)) f->pipe_wgs = value;
-  else if (k == "pipe_overlap" && in(0, 1)) f->pipe_overlap = value != 0;
+  else if (k == "pipe_overlap" && in(-1, 1)) { f->pipe_overlap = value; f->pipe_beside = value == 1; }
   else if (k == "nt" && in(-1, 1)) f->nt_mode = value;
   else if (k == "front_cus" && in(0, 128)) {
     // the two streams on disjoint sets of CUs (hipExtStreamCreateWithCUMask): `value` CUs, spread evenly over the chip, run the pre-pass /
@@ -1628,8 +1681,13 @@ SF_API int sf_fuser_calib_tile_rmw(sf_fuser* f, int read_only, int iters, double
   double total_ms = 0;
   for (int it = 0; it < iters + 1; it++) {  // first launch untimed
     SF_HIP_CHECK(hipEventRecord(e0, f->stream));
-    hipLaunchKernelGGL(k_tile_rmw, dim3(grid), dim3(256), 0, f->stream, f->voxels, f->compact2[sl], f->counters, cc, f->xcd_walk ? 1 : 0,
-                       read_only ? 1 : 0, sink);
+    // the same cache policy the integrate kernel would pick for this tile set (non-temporal beyond 512 MiB)
+    if (f->nt_mode == 1 || (f->nt_mode < 0 && (uint64_t)(uint32_t)n * 4096ull > (512ull << 20)))
+      hipLaunchKernelGGL(k_tile_rmw<true>, dim3(grid), dim3(256), 0, f->stream, f->voxels, f->compact2[sl], f->counters, cc, f->xcd_walk ? 1 : 0,
+                         read_only ? 1 : 0, sink);
+    else
+      hipLaunchKernelGGL(k_tile_rmw<false>, dim3(grid), dim3(256), 0, f->stream, f->voxels, f->compact2[sl], f->counters, cc, f->xcd_walk ? 1 : 0,
+                         read_only ? 1 : 0, sink);
     SF_HIP_CHECK(hipEventRecord(e1, f->stream));
     SF_HIP_CHECK(hipEventSynchronize(e1));
     float ms = 0;

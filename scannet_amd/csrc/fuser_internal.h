@@ -35,6 +35,9 @@ struct ParamsK {
   // colour frames at their own resolution (cW == 0: same as depth)
   int cW, cH;
   float cfx, cfy, cmx, cmy;
+  // input depth frames at inW x inH resampled (nearest) to W x H by the pre-pass; inW == 0: the frames are W x H already
+  int inW, inH;
+  float rsx, rsy;   // (inW - 1) / (W - 1), (inH - 1) / (H - 1)
 };
 
 __host__ __device__ inline bool slab_owns_coord(const ParamsK& P, int c) {
@@ -158,6 +161,8 @@ __device__ inline v2f quot_rn(v2f n, v2f m, v2f r) {
 struct sf_fuser {
   sf_params p;
   ParamsK pk;
+  int in_W = 0, in_H = 0;   // size of an INPUT depth frame as given to sf_fuser_create (p.depth_width / height hold the integration size pk.W x pk.H)
+  size_t in_px = 0;
   int device = 0;
   hipStream_t stream = nullptr;  // integrate / deintegrate and everything synchronous
   hipStream_t front = nullptr;   // pre-pass, allocation, compaction of the NEXT frame (overlaps integrate)
@@ -191,7 +196,8 @@ struct sf_fuser {
   int pipe_wgs = 3;     // persistent workgroups per CU of k_integrate_pipe (48 KiB of LDS each)
   int front_cus = 0;    // > 0: the front stream owns that many CUs, the main stream the others (tune "front_cus")
   int nt_mode = -1;     // k_integrate_pipe tile traffic non-temporal: -1 = when the previous pass's tiles exceed 512 MiB, 0 never, 1 always (tune "nt")
-  bool pipe_overlap = true;  // the next frame's pre-pass / allocation / compaction runs on the front stream beside k_integrate_pipe (tune "pipe_overlap")
+  bool pipe_beside = false;  // the latched decision for the next pass (see sf_single_stream_batch)
+  int pipe_overlap = -1;  // the next frame's pre-pass / allocation / compaction on the front stream beside k_integrate_pipe: -1 = when the previous pass's tiles exceed 512 MiB, 0 never, 1 always (tune "pipe_overlap")
   int alloc_group = 4;  // consecutive frames of a batch one k_alloc workgroup walks (tune "alloc_group")
   int compact_grid = 1024;  // 1024 directory entries per workgroup, grid-stride beyond
   uint64_t frames_integrated = 0, frames_skipped = 0;

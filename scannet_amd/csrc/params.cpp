@@ -51,6 +51,7 @@ SF_API void sf_params_default(sf_params* p) {
   p->gc_enabled = 0;
   p->color_width = 0; p->color_height = 0;
   p->cfx = p->cfy = p->cmx = p->cmy = 0.0f;
+  p->integration_width = p->integration_height = 0;   // integrate at the input resolution (BASELINE.json's 640x480)
 }
 
 namespace {
@@ -147,8 +148,9 @@ SF_API int sf_params_load_file(const char* path, sf_params* p) {
   v = p->num_sdf_blocks;   if ((rc = geti("s_hashNumSDFBlocks", &v)) != SF_OK) return rc; p->num_sdf_blocks = (uint32_t)v;
   v = p->mc_max_triangles; if ((rc = geti("s_marchingCubesMaxNumTriangles", &v)) != SF_OK) return rc; p->mc_max_triangles = (uint32_t)v;
   v = p->gc_enabled;       if ((rc = geti("s_garbageCollectionEnabled", &v)) != SF_OK) return rc; p->gc_enabled = (int32_t)v;
-  v = p->depth_width;      if ((rc = geti("s_integrationWidth", &v)) != SF_OK) return rc; p->depth_width = (int32_t)v;
-  v = p->depth_height;     if ((rc = geti("s_integrationHeight", &v)) != SF_OK) return rc; p->depth_height = (int32_t)v;
+  // zParametersScanNet.txt:20-21: the size the input depth is resampled to (the input size itself comes from the .sens file)
+  v = p->integration_width;  if ((rc = geti("s_integrationWidth", &v)) != SF_OK) return rc; p->integration_width = (int32_t)v;
+  v = p->integration_height; if ((rc = geti("s_integrationHeight", &v)) != SF_OK) return rc; p->integration_height = (int32_t)v;
   if (!(p->voxel_size > 0) || p->hash_num_buckets == 0 || p->num_sdf_blocks == 0)
     return sf::fail(SF_ERR_FORMAT, "%s: non-positive voxel size / hash size", path);
   return SF_OK;

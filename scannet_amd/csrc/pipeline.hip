@@ -55,15 +55,15 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   const uint64_t nframes = s->frames.size();
   if (last == 0 || last > nframes) last = nframes;
   if (first > last) return sf::fail(SF_ERR_BOUNDS, "first frame %llu beyond last %llu", (unsigned long long)first, (unsigned long long)last);
-  if ((int)s->info.depth_width != f->p.depth_width || (int)s->info.depth_height != f->p.depth_height)
-    return sf::fail(SF_ERR_INVALID_ARG, "fuser was created for %dx%d depth frames, the .sens file holds %ux%u", f->p.depth_width, f->p.depth_height,
+  if ((int)s->info.depth_width != f->in_W || (int)s->info.depth_height != f->in_H)
+    return sf::fail(SF_ERR_INVALID_ARG, "fuser was created for %dx%d depth frames, the .sens file holds %ux%u", f->in_W, f->in_H,
                     s->info.depth_width, s->info.depth_height);
   SF_HIP_CHECK(hipSetDevice(f->device));
   const auto t_start = std::chrono::steady_clock::now();
   const bool timing = std::getenv("SF_RUN_TIMING") != nullptr;
   double t_wait_ready = 0, t_api = 0, t_flush = 0;
   auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  const size_t npx = (size_t)f->p.depth_width * f->p.depth_height;
+  const size_t npx = f->in_px;   // of an input frame (the pre-pass resamples to the integration size when the two differ)
   // colour is fused when its frames match what the fuser was created for: depth resolution, or the colour resolution
   // given in sf_params (raw or JPEG); anything else: geometry only
   const bool same_res = s->info.color_width == s->info.depth_width && s->info.color_height == s->info.depth_height;

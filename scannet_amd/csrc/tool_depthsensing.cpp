@@ -35,9 +35,12 @@ int main(int argc, const char** argv) {
   sf_sens_get_info(sens, &info);
   std::printf("Loaded %s: %llu frames, depth %ux%u, color %ux%u, sensor '%s'\n", sens_path, (unsigned long long)info.num_frames, info.depth_width,
               info.depth_height, info.color_width, info.color_height, info.sensor_name);
-  // integrate at the file's depth resolution with the file's calibration (row-major intrinsic, sensorData.h:305-312)
+  // the frames come at the file's depth resolution with the file's calibration (row-major intrinsic, sensorData.h:305-312); the fuser
+  // resamples them to s_integrationWidth x s_integrationHeight when the parameter file asks for another size (zParametersScanNet.txt:20-21)
   p.depth_width = (int32_t)info.depth_width;
   p.depth_height = (int32_t)info.depth_height;
+  if (p.integration_width > 0 && p.integration_height > 0 && (p.integration_width != p.depth_width || p.integration_height != p.depth_height))
+    std::printf("Depth resampled to s_integrationWidth x s_integrationHeight = %d x %d\n", p.integration_width, p.integration_height);
   p.fx = info.depth_intrinsic[0]; p.fy = info.depth_intrinsic[5]; p.mx = info.depth_intrinsic[2]; p.my = info.depth_intrinsic[6];
   p.depth_shift = info.depth_shift;
   if ((info.color_width != info.depth_width || info.color_height != info.depth_height) && info.color_width > 0 && info.color_height > 0 &&

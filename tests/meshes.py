@@ -92,3 +92,44 @@ def write_ply(path, v, f, fmt="ascii", index_name="vertex_indices", colors=False
                     fh.write(bytes([i % 256, (i * 7) % 256, (i * 13) % 256, 255]))
             for t in f:
                 fh.write(b"\x03" + struct.pack(e + "iii", *[int(k) for k in t]))
+
+
+def bumpy_large(n=700, seed=11):
+    """The same kind of heightfield at scan size (n = 700: 490 007 vertices, 977 202 faces), built without Python loops."""
+    rng = np.random.default_rng(seed)
+    x, y = np.meshgrid(np.arange(n, dtype=np.float32) * 0.01, np.arange(n, dtype=np.float32) * 0.01)
+    z = 0.05 * np.sin(x * 7) * np.cos(y * 5) + 0.3 * (np.abs(x - 2.0) < 0.6) + 0.2 * np.maximum(0, y - 4.5) + 0.15 * (np.hypot(x - 5, y - 2) < 0.8)
+    z = z + rng.normal(0, 0.0005, z.shape)
+    v = np.stack([x, y, z], -1).reshape(-1, 3).astype(np.float32)
+    j, i = np.meshgrid(np.arange(n - 1), np.arange(n - 1), indexing="ij")
+    a = (j * n + i).reshape(-1).astype(np.uint32)
+    odd = ((i + j) % 2).reshape(-1).astype(bool)
+    t0 = np.where(odd[:, None], np.stack([a, a + 1, a + n], -1), np.stack([a, a + 1, a + n + 1], -1))
+    t1 = np.where(odd[:, None], np.stack([a + 1, a + n + 1, a + n], -1), np.stack([a, a + n + 1, a + n], -1))
+    f = np.concatenate([t0, t1]).astype(np.uint32)
+    rng.shuffle(f)
+    v = np.concatenate([v, rng.normal(0, 1, (7, 3)).astype(np.float32)])  # unreferenced vertices
+    return v, f
+
+
+def write_ply_le_fast(path, v, f, colors=True):
+    """Binary little-endian PLY in ScanNet's layout (float x y z, uchar red green blue alpha, list uchar int vertex_indices), vectorised."""
+    v = np.asarray(v, np.float32)
+    f = np.asarray(f, np.uint32)
+    vt = np.dtype([("xyz", "<f4", 3)] + ([("rgba", "u1", 4)] if colors else []))
+    va = np.zeros(len(v), vt)
+    va["xyz"] = v
+    if colors:
+        i = np.arange(len(v))
+        va["rgba"] = np.stack([i % 256, (i * 7) % 256, (i * 13) % 256, np.full(len(v), 255)], -1).astype(np.uint8)
+    fa = np.zeros(len(f), np.dtype([("n", "u1"), ("idx", "<i4", 3)]))
+    fa["n"] = 3
+    fa["idx"] = f.astype(np.int32)
+    hdr = ["ply", "format binary_little_endian 1.0", "element vertex %d" % len(v), "property float x", "property float y", "property float z"]
+    if colors:
+        hdr += ["property uchar red", "property uchar green", "property uchar blue", "property uchar alpha"]
+    hdr += ["element face %d" % len(f), "property list uchar int vertex_indices", "end_header"]
+    with open(path, "wb") as fh:
+        fh.write(("\n".join(hdr) + "\n").encode())
+        fh.write(va.tobytes())
+        fh.write(fa.tobytes())

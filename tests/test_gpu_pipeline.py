@@ -95,6 +95,34 @@ def test_drop_in_executables(tmp_path):
     assert bad.returncode != 0 and "could not open" in bad.stderr
 
 
+def test_depthsensing_honours_the_shipped_integration_size(tmp_path):
+    """The shipped parameter file integrates at s_integrationWidth x s_integrationHeight = 320 x 240 whatever the sensor delivers
+    (zParametersScanNet.txt:20-21): `depthsensing` on a 640x480 .sens must say so and write the mesh a fuser created with
+    integration_width / height = 320 / 240 produces from the same frames."""
+    from scannet_amd import fusion, segmentator
+    W, H = 640, 480
+    sens_path = str(tmp_path / "scan.sens")
+    frames = _write_sens(sens_path, 12, W, H, 600)
+    params = tmp_path / "zParametersScanNet.txt"
+    params.write_text("s_integrationWidth = 320;\ns_integrationHeight = 240;\ns_SDFVoxelSize = 0.010f;\ns_SDFTruncation = 0.06f;\n"
+                      "s_SDFTruncationScale = 0.02f;\ns_hashNumSDFBlocks = 200000;\ns_hashNumBuckets = 100000;\n")
+    (tmp_path / "t.txt").write_text("// tracking\n")
+    out = subprocess.run([os.path.join(ROOT, "bin", "depthsensing"), str(params), str(tmp_path / "t.txt"), sens_path], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stderr == "", out.stderr
+    assert "resampled to s_integrationWidth x s_integrationHeight = 320 x 240" in out.stdout
+    got = segmentator.Mesh.read(str(tmp_path / "scan_vh.ply")).arrays()
+    fx, fy, mx, my = synth.intrinsics(W, H)
+    gp = fusion.load_params(str(params), fusion.default_params(depth_width=W, depth_height=H, fx=fx, fy=fy, mx=mx, my=my))
+    assert (gp.integration_width, gp.integration_height, gp.depth_width) == (320, 240, 640)
+    with fusion.Fuser(gp) as f:
+        for d, pose in frames:
+            f.integrate(d, pose)
+        want = f.extract_mesh().arrays()
+    assert len(want[2]) > 10000
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+
+
 def _room_frames(n, W, H, total, stride=9):
     out = []
     for i in range(n):

@@ -270,6 +270,47 @@ def test_spec_literal_tolerance_on_baseline_frames():
     print("spec-literal check:", res)
 
 
+def test_integration_size_resample(oracle):
+    """s_integrationWidth / s_integrationHeight (zParametersScanNet.txt:20-21, shipped as 320 x 240): 640x480 frames handed to a fuser that
+    integrates at 320x240.  The pre-pass resamples (nearest, x_in = (uint)(x * (W_in - 1) / (W - 1) + 0.5f)), the intrinsics follow; the
+    volume must be bit-identical to the oracle fed the same resample done in numpy -- geometry and colour (colour is looked up in the
+    full-resolution image under the integration pixel's ray)."""
+    from scannet_amd import fusion
+    Wi, Hi, W, H = 640, 480, 320, 240
+    fx, fy, mx, my = (np.float32(v) for v in synth.intrinsics(Wi, Hi))
+    sx = np.float32(Wi - 1) / np.float32(W - 1)
+    sy = np.float32(Hi - 1) / np.float32(H - 1)
+    xi = (np.arange(W, dtype=np.float32) * sx + np.float32(0.5)).astype(np.uint32)
+    yi = (np.arange(H, dtype=np.float32) * sy + np.float32(0.5)).astype(np.uint32)
+    fxs, fys = fx * (np.float32(W) / np.float32(Wi)), fy * (np.float32(H) / np.float32(Hi))
+    mxs, mys = mx * (np.float32(W - 1) / np.float32(Wi - 1)), my * (np.float32(H - 1) / np.float32(Hi - 1))
+    op = oracle.default_params(W, H, 0.01)
+    op.fx, op.fy, op.mx, op.my = float(fxs), float(fys), float(mxs), float(mys)
+    gp = fusion.default_params(depth_width=Wi, depth_height=Hi, fx=float(fx), fy=float(fy), mx=float(mx), my=float(my), voxel_size=0.01,
+                               integration_width=W, integration_height=H, num_sdf_blocks=1 << 17)
+    rng = np.random.default_rng(3)
+    for colour in (False, True):
+        ovol = oracle.Volume(op, threads=8)
+        with fusion.Fuser(gp) as f:
+            for i in (0, 20, 40, 41):
+                pose = synth.trajectory_pose(i, 400)
+                d = synth.render_room_depth(pose, Wi, Hi, noise_frame=i)
+                rgb = rng.integers(0, 256, (Hi, Wi, 3), dtype=np.uint8) if colour else None
+                ds = d[yi][:, xi]
+                rs = None
+                if colour:   # the colour pixel under the integration pixel's ray, in the full-resolution image
+                    u = ((np.arange(W, dtype=np.float32) - mxs) / fxs * fx + mx + np.float32(0.5))
+                    v = ((np.arange(H, dtype=np.float32) - mys) / fys * fy + my + np.float32(0.5))
+                    uu, vv = np.meshgrid(u, v)
+                    ok = (uu >= 0) & (uu < Wi) & (vv >= 0) & (vv < Hi)
+                    rs = np.where(ok[..., None], rgb[np.clip(vv.astype(np.int64), 0, Hi - 1), np.clip(uu.astype(np.int64), 0, Wi - 1)], 0).astype(np.uint8)
+                n = ovol.integrate(ds, pose, rgb=rs)
+                assert f.integrate(d, pose, rgb=rgb)
+                assert f.stats()["last_frame_blocks"] == n
+            _assert_same(ovol, f)
+        ovol.close()
+
+
 def test_heap_exhaustion_is_reported(oracle):
     from scannet_amd import fusion
     _, gp = _mk(oracle, 160, 120, voxel=0.004, num_sdf_blocks=256)

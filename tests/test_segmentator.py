@@ -72,6 +72,30 @@ def test_against_reference_binary(oracle, tmp_path, fmt, index_name, colors, ext
         assert ref_out.replace(str(a), "X") == ours.stdout.replace(str(b), "X")
 
 
+def test_scan_sized_mesh_against_reference_binary(oracle, tmp_path):
+    """A mesh the size of a real _vh_clean_2.ply and beyond (490 007 vertices, 977 202 faces, ScanNet's binary PLY layout): segs.json
+    byte-identical to the reference binary's, stdout lines included -- std::sort's order on 2.9 M edges with many equal weights is part
+    of the result."""
+    ref = oracle.ref_segmentator_path()
+    if ref is None:
+        pytest.skip("oracle/_ref/segmentator_ref not built (needs /root/reference)")
+    v, f = meshes.bumpy_large(700)
+    assert len(v) == 490007 and len(f) == 977202
+    a = tmp_path / "a"; a.mkdir()
+    b = tmp_path / "b"; b.mkdir()
+    for d in (a, b):
+        meshes.write_ply_le_fast(str(d / "scene_vh_clean_2.ply"), v, f)
+    ref_out = _run_ref(ref, str(a / "scene_vh_clean_2.ply"))
+    ours = subprocess.run([os.path.join(os.path.dirname(HERE), "bin", "segmentator"), str(b / "scene_vh_clean_2.ply")], capture_output=True, text=True)
+    assert ours.returncode == 0 and ours.stderr == ""
+    name = "scene_vh_clean_2.0.010000.segs.json"
+    ja, jb = (a / name).read_bytes(), (b / name).read_bytes()
+    assert len(ja) > 3000000 and ja.replace(str(a).encode(), b"X") == jb.replace(str(b).encode(), b"X")
+    assert ref_out.replace(str(a), "X") == ours.stdout.replace(str(b), "X")
+    segs = json.loads(jb)["segIndices"]
+    assert len(segs) == len(v) and 50 < len(set(segs)) < 20000
+
+
 def test_scene_id_and_naming_quirks(oracle, tmp_path):
     v, f = meshes.bent_strip()
     meshes.write_ply(str(tmp_path / "t.ply"), v, f)

@@ -124,10 +124,22 @@ def main():
     res["segments"] = nseg
     ref = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "segmentator_ref")
     if os.path.exists(ref):
+        # the reference binary on a COPY of the same mesh (it names its output after the input, so it would overwrite ours): timed AND compared
+        import shutil
         import subprocess
+        refdir = os.path.join(a.dir, "reference_segmentator")
+        os.makedirs(refdir, exist_ok=True)
+        rply = os.path.join(refdir, os.path.basename(cply))
+        shutil.copyfile(cply, rply)
         t0 = time.perf_counter()
-        subprocess.run([ref, cply], capture_output=True)
+        subprocess.run([ref, rply], capture_output=True)
         res["segment_reference_binary_s"] = round(time.perf_counter() - t0, 3)
+        name = os.path.basename(cply)[:-4] + ".0.010000.segs.json"
+        ours = json.load(open(os.path.join(a.dir, name)))
+        theirs = json.load(open(os.path.join(refdir, name)))
+        res["segment_identical_to_reference"] = ours["segIndices"] == theirs["segIndices"] and ours["params"] == theirs["params"]
+        if not res["segment_identical_to_reference"]:
+            raise SystemExit("segIndices differ from the reference binary's on %s" % cply)
     print(json.dumps(res))
     if a.out:
         open(a.out, "w").write(json.dumps(res, indent=1) + "\n")
