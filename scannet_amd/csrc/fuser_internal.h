@@ -186,6 +186,8 @@ struct sf_fuser {
   uint4* voxels = nullptr;
   int32_t* compact = nullptr;  // alias of compact2[0], used by the synchronous paths (export, GC)
   int32_t* counters = nullptr;
+  float* ray_kx = nullptr;   // (x - mx) / fx per column, (y - my) / fy per row of the integration image (colour look-up of the pre-pass)
+  float* ray_ky = nullptr;
   void* staging_depth = nullptr;  // device copies of host-supplied frames
   void* staging_rgb = nullptr;
   int32_t* host_mirror = nullptr;  // pinned, device-visible: N_blk of the most recent integrate

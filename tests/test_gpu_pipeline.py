@@ -320,7 +320,7 @@ def test_jpeg_gpu_reconstruction_identical_to_the_reference_decoder(oracle, tmp_
     import ctypes as C
     import io
     from PIL import Image
-    from scannet_amd import calibrate
+    from scannet_amd import calibrate, sens
     from tests import jpeg_tools
     if not oracle.ref_sens_available():
         pytest.skip("oracle/_ref/libref_sens.so absent")

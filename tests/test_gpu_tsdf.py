@@ -299,8 +299,11 @@ def test_integration_size_resample(oracle):
                 ds = d[yi][:, xi]
                 rs = None
                 if colour:   # the colour pixel under the integration pixel's ray, in the full-resolution image
-                    u = ((np.arange(W, dtype=np.float32) - mxs) / fxs * fx + mx + np.float32(0.5))
-                    v = ((np.arange(H, dtype=np.float32) - mys) / fys * fy + my + np.float32(0.5))
+                    # u = fmaf((x - mx') / fx', fx, mx) + 0.5f: the fused step emulated in binary64 (the product of two floats is exact there)
+                    kx = (np.arange(W, dtype=np.float32) - mxs) / fxs
+                    ky = (np.arange(H, dtype=np.float32) - mys) / fys
+                    u = (kx.astype(np.float64) * np.float64(fx) + np.float64(mx)).astype(np.float32) + np.float32(0.5)
+                    v = (ky.astype(np.float64) * np.float64(fy) + np.float64(my)).astype(np.float32) + np.float32(0.5)
                     uu, vv = np.meshgrid(u, v)
                     ok = (uu >= 0) & (uu < Wi) & (vv >= 0) & (vv < Hi)
                     rs = np.where(ok[..., None], rgb[np.clip(vv.astype(np.int64), 0, Hi - 1), np.clip(uu.astype(np.int64), 0, Wi - 1)], 0).astype(np.uint8)
