@@ -392,9 +392,9 @@ def run_scans(args, rank, local_rank, world, dist, torch):
         if args.host_stage != "none":
             cleaned, _ = meshclean.clean(mesh, meshclean.CLEAN_MLX_MERGE_DISTANCE, 7500)
             cur = cleaned
-            if args.host_stage == "full":
+            if args.host_stage in ("full", "gpu-decimate"):
                 for _ in range(2):
-                    simp, _ = meshclean.simplify(cur)
+                    simp, _ = meshclean.simplify(cur, gpu=local_rank if args.host_stage == "gpu-decimate" else None)
                     cur, _ = meshclean.clean(simp, meshclean.CLEAN_MLX_MERGE_DISTANCE, meshclean.CLEAN_LORES_MIN_COMPONENT)
             ply = os.path.join(outdir, "scan%04d_vh_clean_2.ply" % i)
             cur.write_ply(ply)
@@ -439,6 +439,8 @@ def run_scans(args, rank, local_rank, world, dist, torch):
                                "%d per GPU popped longest-first from ONE queue in the rendezvous store" % (args.first_scan, args.first_scan + n_scans - 1, K),
                    "sharding": "scan-per-GPU, no collective on the data path",
                    "host_stage": {"full": "clean.mlx + quadric collapse to 20 %% twice + cleanLoRes + Segmentator per scan on a pool of %d host threads per rank" % workers,
+                                  "gpu-decimate": "clean.mlx + quadric collapse to 20 %% twice ON THE GPU (rounds of independent collapses) + cleanLoRes + Segmentator, "
+                                                  "driven by a pool of %d host threads per rank" % workers,
                                   "clean": "clean.mlx + Segmentator per scan on a pool of %d host threads per rank" % workers, "none": "none (fusion + marching cubes only)"}[args.host_stage],
                    "frames_total": int(frames_sum)},
         "gpu_busy_s_sum": round(busy_sum, 3), "gpu_idle_pct": round(100.0 * (1.0 - busy_sum / (elapsed * world)), 1),
@@ -540,7 +542,9 @@ def main():
     ap.add_argument("--single-frame", action="store_true", help="one frame per launch (batch = 1) for the main measurement")
     ap.add_argument("--no-single-frame", action="store_true", help="skip the secondary one-frame-per-launch roofline pass")
     ap.add_argument("--teardown", action="store_true", help="leave through the interpreter's normal teardown (set for the runs under rocprofv3)")
-    ap.add_argument("--host-stage", choices=["full", "clean", "none"], default="full", help="--config scans: what follows marching cubes on the host threads")
+    ap.add_argument("--host-stage", choices=["full", "gpu-decimate", "clean", "none"], default="full",
+                    help="--config scans: what follows marching cubes -- full: clean + sequential quadric collapse x 2 + segment on host threads; gpu-decimate: the "
+                         "same chain with the collapse on the GPU (sf_mesh_simplify_gpu); clean: clean + segment; none: nothing")
     ap.add_argument("--first-scan", type=int, default=0)
     ap.add_argument("--max-scan-frames", type=int, default=0)
     ap.add_argument("--scan-frames", type=int, default=50000, help="--config partition: length of the long scan")

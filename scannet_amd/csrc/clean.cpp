@@ -328,6 +328,7 @@ SF_API int sf_mlx_load(const char* path, sf_clean_script* out) {
   const std::string text = ss.str();
   if (text.find("<FilterScript") == std::string::npos) return sf::fail(SF_ERR_FORMAT, "%s is not a MeshLab FilterScript", path);
   std::memset(out, 0, sizeof(*out));
+  out->simplify_device = -1;   // the sequential host filter unless the caller opts into the GPU one
   int stage = 0;  // the four filters must come in the shipped order; each may appear at most once
   size_t p = 0;
   std::string current;
@@ -383,7 +384,8 @@ SF_API int sf_mesh_clean_script(const sf_mesh* in, sf_clean_script* s, sf_mesh**
   if (!s) return sf::fail(SF_ERR_INVALID_ARG, "NULL script");
   sf_mesh* simplified = nullptr;
   if (s->simplify) {
-    const int rc = sf_mesh_simplify(in, &s->simplify_params, &simplified, &s->simplify_stats);
+    const int rc = s->simplify_device >= 0 ? sf_mesh_simplify_gpu(in, &s->simplify_params, s->simplify_device, &simplified, &s->simplify_stats)
+                                           : sf_mesh_simplify(in, &s->simplify_params, &simplified, &s->simplify_stats);
     if (rc != SF_OK) return rc;
     in = simplified;
     if (!s->merge_close_vertices && !s->remove_duplicate_faces && !s->remove_small_components && !s->remove_unreferenced) {

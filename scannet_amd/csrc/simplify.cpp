@@ -36,96 +36,12 @@
 #include <vector>
 
 #include "mesh.h"
+#include "simplify_math.h"
 
 namespace {
 
-struct Quadric {
-  double a[6], b[3], c;
-  void zero() { std::memset(this, 0, sizeof(*this)); }
-  void by_plane(const double n[3], double off) {
-    a[0] = n[0] * n[0]; a[1] = n[0] * n[1]; a[2] = n[0] * n[2];
-    a[3] = n[1] * n[1]; a[4] = n[1] * n[2]; a[5] = n[2] * n[2];
-    b[0] = -2.0 * off * n[0]; b[1] = -2.0 * off * n[1]; b[2] = -2.0 * off * n[2];
-    c = off * off;
-  }
-  void add(const Quadric& q) {
-    for (int i = 0; i < 6; i++) a[i] += q.a[i];
-    for (int i = 0; i < 3; i++) b[i] += q.b[i];
-    c += q.c;
-  }
-  double apply(const double p[3]) const {
-    return p[0] * p[0] * a[0] + 2 * p[0] * p[1] * a[1] + 2 * p[0] * p[2] * a[2] + p[0] * b[0] + p[1] * p[1] * a[3] + 2 * p[1] * p[2] * a[4] +
-           p[1] * b[1] + p[2] * p[2] * a[5] + p[2] * b[2] + c;
-  }
-};
-
-// symmetric 3x3 eigen-decomposition (cyclic Jacobi): A = V diag(w) V^T
-void eigen_sym3(const double a[6], double w[3], double V[3][3]) {
-  double A[3][3] = {{a[0], a[1], a[2]}, {a[1], a[3], a[4]}, {a[2], a[4], a[5]}};
-  for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 3; j++) V[i][j] = i == j ? 1.0 : 0.0;
-  for (int sweep = 0; sweep < 32; sweep++) {
-    const double off = std::fabs(A[0][1]) + std::fabs(A[0][2]) + std::fabs(A[1][2]);
-    const double diag = std::fabs(A[0][0]) + std::fabs(A[1][1]) + std::fabs(A[2][2]);
-    if (off <= 1e-18 * diag || off == 0.0) break;
-    for (int p = 0; p < 2; p++)
-      for (int q = p + 1; q < 3; q++) {
-        if (A[p][q] == 0.0) continue;
-        const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
-        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-        const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
-        for (int k = 0; k < 3; k++) {  // A <- A J
-          const double akp = A[k][p], akq = A[k][q];
-          A[k][p] = cs * akp - sn * akq;
-          A[k][q] = sn * akp + cs * akq;
-        }
-        for (int k = 0; k < 3; k++) {  // A <- J^T A
-          const double apk = A[p][k], aqk = A[q][k];
-          A[p][k] = cs * apk - sn * aqk;
-          A[q][k] = sn * apk + cs * aqk;
-        }
-        for (int k = 0; k < 3; k++) {
-          const double vkp = V[k][p], vkq = V[k][q];
-          V[k][p] = cs * vkp - sn * vkq;
-          V[k][q] = sn * vkp + cs * vkq;
-        }
-      }
-  }
-  for (int i = 0; i < 3; i++) w[i] = A[i][i];
-}
-
-// minimiser of q closest to `mid`: x = mid + pinv(A) (-b/2 - A mid)
-void minimise(const Quadric& q, const double mid[3], double x[3]) {
-  // Well conditioned (the usual case off the flat areas): plain inverse through the adjugate.  For a positive
-  // semi-definite A, lambda_min >= det / trace^2 and lambda_max <= trace, so det > 1e-6 trace^3 guarantees a condition
-  // number below 1e6 -- the pseudo-inverse below would use all three eigenvalues and return the same point.
-  {
-    const double* a = q.a;
-    const double c00 = a[3] * a[5] - a[4] * a[4], c01 = a[2] * a[4] - a[1] * a[5], c02 = a[1] * a[4] - a[2] * a[3];
-    const double det = a[0] * c00 + a[1] * c01 + a[2] * c02, tr = a[0] + a[3] + a[5];
-    if (det > 1e-6 * tr * tr * tr && tr > 0.0) {
-      const double c11 = a[0] * a[5] - a[2] * a[2], c12 = a[1] * a[2] - a[0] * a[4], c22 = a[0] * a[3] - a[1] * a[1];
-      const double r0 = -0.5 * q.b[0], r1 = -0.5 * q.b[1], r2 = -0.5 * q.b[2], inv = 1.0 / det;
-      x[0] = (c00 * r0 + c01 * r1 + c02 * r2) * inv;
-      x[1] = (c01 * r0 + c11 * r1 + c12 * r2) * inv;
-      x[2] = (c02 * r0 + c12 * r1 + c22 * r2) * inv;
-      return;
-    }
-  }
-  double w[3], V[3][3];
-  eigen_sym3(q.a, w, V);
-  const double wmax = std::max(std::fabs(w[0]), std::max(std::fabs(w[1]), std::fabs(w[2])));
-  const double Am[3] = {q.a[0] * mid[0] + q.a[1] * mid[1] + q.a[2] * mid[2], q.a[1] * mid[0] + q.a[3] * mid[1] + q.a[4] * mid[2],
-                        q.a[2] * mid[0] + q.a[4] * mid[1] + q.a[5] * mid[2]};
-  const double r[3] = {-0.5 * q.b[0] - Am[0], -0.5 * q.b[1] - Am[1], -0.5 * q.b[2] - Am[2]};
-  x[0] = mid[0]; x[1] = mid[1]; x[2] = mid[2];
-  if (!(wmax > 0.0)) return;
-  for (int k = 0; k < 3; k++) {
-    if (!(std::fabs(w[k]) > 1e-9 * wmax)) continue;
-    const double proj = (V[0][k] * r[0] + V[1][k] * r[1] + V[2][k] * r[2]) / w[k];
-    for (int i = 0; i < 3; i++) x[i] += V[i][k] * proj;
-  }
-}
+using sfq::Quadric;
+using sfq::minimise;
 
 struct HeapElem {
   float pri;
@@ -265,22 +181,7 @@ struct Simplifier {
   size_t nv() const { return pos.size() / 3; }
   void pd(uint32_t v, double p[3]) const { p[0] = pos[3 * v]; p[1] = pos[3 * v + 1]; p[2] = pos[3 * v + 2]; }
 
-  // vcg::Quality(p0, p1, p2) = 2 area / longest edge squared, in float as CMeshO does
-  static float quality(const float* p0, const float* p1, const float* p2) {
-    const float d10[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
-    const float d20[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
-    const float d12[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
-    const float x[3] = {d10[1] * d20[2] - d10[2] * d20[1], d10[2] * d20[0] - d10[0] * d20[2], d10[0] * d20[1] - d10[1] * d20[0]};
-    const float a = std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
-    if (a == 0) return 0;
-    float b = d10[0] * d10[0] + d10[1] * d10[1] + d10[2] * d10[2];
-    if (b == 0) return 0;
-    float t = d20[0] * d20[0] + d20[1] * d20[1] + d20[2] * d20[2];
-    if (b < t) b = t;
-    t = d12[0] * d12[0] + d12[1] * d12[1] + d12[2] * d12[2];
-    if (b < t) b = t;
-    return a / b;
-  }
+  static float quality(const float* p0, const float* p1, const float* p2) { return sfq::quality(p0, p1, p2); }
 
   void vf_prepend(uint32_t v, int32_t f, int j) {
     nx_face[3 * (size_t)f + j] = vf_face[v];
@@ -576,6 +477,74 @@ struct Simplifier {
 
 }  // namespace
 
+// The end of the filter, shared by the sequential and the GPU variant: AutoClean (zero-area faces, duplicate vertices -- bit-identical
+// positions -> lowest index --, unreferenced vertices), compaction in index order, colours travel with the surviving vertex.
+sf_mesh* simplify_finish(const sf_mesh* in, const sf_simplify_params& P, std::vector<float>& pos, std::vector<uint32_t>& tri_in, std::vector<uint8_t>& fdel,
+                         std::vector<uint8_t>& vdel, uint64_t nfaces, sf_simplify_stats& st) {
+  // AutoClean: zero-area faces, duplicate vertices (bit-identical positions -> lowest index), unreferenced vertices
+  const size_t n_v = (pos.size() / 3), n_f = tri_in.size() / 3;
+  std::vector<uint32_t> target_of(n_v);
+  for (size_t v = 0; v < n_v; v++) target_of[v] = (uint32_t)v;
+  if (P.auto_clean) {
+    for (size_t f = 0; f < n_f; f++) {
+      if (fdel[f]) continue;
+      const uint32_t* t = &tri_in[3 * f];
+      const float *a = &pos[3 * (size_t)t[0]], *b = &pos[3 * (size_t)t[1]], *c = &pos[3 * (size_t)t[2]];
+      const float e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+      const float n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+      if (!(std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]) > 0.0f)) { fdel[f] = 1; nfaces--; st.faces_zero_area++; }
+    }
+    std::vector<uint32_t> order;
+    order.reserve(n_v);
+    for (size_t v = 0; v < n_v; v++)
+      if (!vdel[v]) order.push_back((uint32_t)v);
+    auto canon = [&](uint32_t v, float* q) { for (int c = 0; c < 3; c++) q[c] = pos[3 * (size_t)v + c] + 0.0f; };
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+      float a[3], b[3];
+      canon(x, a); canon(y, b);
+      const int c = std::memcmp(a, b, 12);
+      return c != 0 ? c < 0 : x < y;
+    });
+    for (size_t i = 0; i < order.size();) {
+      size_t j = i + 1;
+      float a[3], b[3];
+      canon(order[i], a);
+      while (j < order.size() && (canon(order[j], b), std::memcmp(a, b, 12) == 0)) j++;
+      for (size_t k = i + 1; k < j; k++) { target_of[order[k]] = order[i]; st.vertices_duplicate++; }
+      i = j;
+    }
+  }
+  std::vector<uint8_t> used(n_v, 0);
+  std::vector<uint32_t> tri;
+  tri.reserve(3 * (size_t)nfaces);
+  for (size_t f = 0; f < n_f; f++) {
+    if (fdel[f]) continue;
+    const uint32_t a = target_of[tri_in[3 * f]], b = target_of[tri_in[3 * f + 1]], c = target_of[tri_in[3 * f + 2]];
+    if (P.auto_clean && (a == b || b == c || a == c)) { st.faces_zero_area++; continue; }
+    tri.push_back(a); tri.push_back(b); tri.push_back(c);
+    used[a] = used[b] = used[c] = 1;
+  }
+  std::vector<uint32_t> remap(n_v, 0xFFFFFFFFu);
+  uint32_t w = 0;
+  for (size_t v = 0; v < n_v; v++) {
+    const bool keep = P.auto_clean ? used[v] != 0 : (!vdel[v]);
+    if (keep) remap[v] = w++;
+  }
+  sf_mesh* m = new sf_mesh();
+  m->pos.resize(3 * (size_t)w);
+  if (!in->col.empty()) m->col.resize(4 * (size_t)w);
+  for (size_t v = 0; v < n_v; v++) {
+    if (remap[v] == 0xFFFFFFFFu) continue;
+    std::memcpy(&m->pos[3 * (size_t)remap[v]], &pos[3 * v], 12);
+    if (!in->col.empty()) std::memcpy(&m->col[4 * (size_t)remap[v]], &in->col[4 * v], 4);
+  }
+  m->tri.resize(tri.size());
+  for (size_t i = 0; i < tri.size(); i++) m->tri[i] = remap[tri[i]];
+  st.vertices_out = w;
+  st.faces_out = tri.size() / 3;
+  return m;
+}
+
 SF_API void sf_simplify_default_params(sf_simplify_params* p) {
   if (!p) return;
   std::memset(p, 0, sizeof(*p));
@@ -608,67 +577,7 @@ SF_API int sf_mesh_simplify(const sf_mesh* in, const sf_simplify_params* p, sf_m
   uint64_t target = p->target_faces;
   if (p->target_perc != 0.0f) target = (uint64_t)((double)(in->tri.size() / 3) * (double)p->target_perc);
   S.run(target);
-  // AutoClean: zero-area faces, duplicate vertices (bit-identical positions -> lowest index), unreferenced vertices
-  const size_t n_v = S.nv(), n_f = S.tri.size() / 3;
-  std::vector<uint32_t> target_of(n_v);
-  for (size_t v = 0; v < n_v; v++) target_of[v] = (uint32_t)v;
-  if (p->auto_clean) {
-    for (size_t f = 0; f < n_f; f++) {
-      if (S.fdel[f]) continue;
-      const uint32_t* t = &S.tri[3 * f];
-      const float *a = &S.pos[3 * (size_t)t[0]], *b = &S.pos[3 * (size_t)t[1]], *c = &S.pos[3 * (size_t)t[2]];
-      const float e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
-      const float n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
-      if (!(std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]) > 0.0f)) { S.fdel[f] = 1; S.nfaces--; S.st.faces_zero_area++; }
-    }
-    std::vector<uint32_t> order;
-    order.reserve(n_v);
-    for (size_t v = 0; v < n_v; v++)
-      if (!S.vdel[v]) order.push_back((uint32_t)v);
-    auto canon = [&](uint32_t v, float* q) { for (int c = 0; c < 3; c++) q[c] = S.pos[3 * (size_t)v + c] + 0.0f; };
-    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-      float a[3], b[3];
-      canon(x, a); canon(y, b);
-      const int c = std::memcmp(a, b, 12);
-      return c != 0 ? c < 0 : x < y;
-    });
-    for (size_t i = 0; i < order.size();) {
-      size_t j = i + 1;
-      float a[3], b[3];
-      canon(order[i], a);
-      while (j < order.size() && (canon(order[j], b), std::memcmp(a, b, 12) == 0)) j++;
-      for (size_t k = i + 1; k < j; k++) { target_of[order[k]] = order[i]; S.st.vertices_duplicate++; }
-      i = j;
-    }
-  }
-  std::vector<uint8_t> used(n_v, 0);
-  std::vector<uint32_t> tri;
-  tri.reserve(3 * (size_t)S.nfaces);
-  for (size_t f = 0; f < n_f; f++) {
-    if (S.fdel[f]) continue;
-    const uint32_t a = target_of[S.tri[3 * f]], b = target_of[S.tri[3 * f + 1]], c = target_of[S.tri[3 * f + 2]];
-    if (p->auto_clean && (a == b || b == c || a == c)) { S.st.faces_zero_area++; continue; }
-    tri.push_back(a); tri.push_back(b); tri.push_back(c);
-    used[a] = used[b] = used[c] = 1;
-  }
-  std::vector<uint32_t> remap(n_v, 0xFFFFFFFFu);
-  uint32_t w = 0;
-  for (size_t v = 0; v < n_v; v++) {
-    const bool keep = p->auto_clean ? used[v] != 0 : (!S.vdel[v]);
-    if (keep) remap[v] = w++;
-  }
-  sf_mesh* m = new sf_mesh();
-  m->pos.resize(3 * (size_t)w);
-  if (!in->col.empty()) m->col.resize(4 * (size_t)w);
-  for (size_t v = 0; v < n_v; v++) {
-    if (remap[v] == 0xFFFFFFFFu) continue;
-    std::memcpy(&m->pos[3 * (size_t)remap[v]], &S.pos[3 * v], 12);
-    if (!in->col.empty()) std::memcpy(&m->col[4 * (size_t)remap[v]], &in->col[4 * v], 4);
-  }
-  m->tri.resize(tri.size());
-  for (size_t i = 0; i < tri.size(); i++) m->tri[i] = remap[tri[i]];
-  S.st.vertices_out = w;
-  S.st.faces_out = tri.size() / 3;
+  sf_mesh* m = simplify_finish(in, *p, S.pos, S.tri, S.fdel, S.vdel, S.nfaces, S.st);
   S.st.target_faces = target;
   if (stats) *stats = S.st;
   *out = m;

@@ -6,6 +6,7 @@
 // non-zero exit + stderr message on failure (Server/util.py:38-50).  The same executable serves the decimate stage:
 //     meshlabserver -i X_vh_clean.ply -o X_vh_clean_1.ply -m vc -s <dir>/simplify.mlx   (Server/scan_processor.py:144-145)
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -18,20 +19,23 @@ static int die(const char* what) {
 
 int main(int argc, const char** argv) {
   const char *in = nullptr, *out = nullptr, *script = nullptr;
+  int gpu = -1;   // --gpu [device]: the quadric collapse of simplify.mlx runs as rounds of independent collapses on that MI355X
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
     if (a == "-i" && i + 1 < argc) in = argv[++i];
     else if (a == "-o" && i + 1 < argc) out = argv[++i];
     else if (a == "-s" && i + 1 < argc) script = argv[++i];
     else if (a == "-m") { while (i + 1 < argc && argv[i + 1][0] != '-') i++; }  // vc vn fc ... : colours are always saved
+    else if (a == "--gpu") { gpu = 0; if (i + 1 < argc && argv[i + 1][0] >= '0' && argv[i + 1][0] <= '9') gpu = std::atoi(argv[++i]); }  // not a meshlabserver flag: opt-in
     else { std::fprintf(stderr, "unknown option %s\n", argv[i]); return 255; }
   }
   if (!in || !out || !script) {
-    std::printf("Usage: meshclean -i input.ply -o output.ply [-m vc] -s clean.mlx|simplify.mlx\n");
+    std::printf("Usage: meshclean -i input.ply -o output.ply [-m vc] -s clean.mlx|simplify.mlx [--gpu [device]]\n");
     return 255;
   }
   sf_clean_script sc;
   if (sf_mlx_load(script, &sc) != SF_OK) return die("filter script");
+  sc.simplify_device = gpu;
   sf_mesh* m = nullptr;
   if (sf_ply_read(in, &m) != SF_OK) return die("input mesh");
   uint64_t nv = 0, nf = 0;

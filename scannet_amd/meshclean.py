@@ -33,7 +33,7 @@ class SfSimplifyStats(C.Structure):
 class SfCleanScript(C.Structure):
     _fields_ = [("merge_close_vertices", C.c_int32), ("remove_duplicate_faces", C.c_int32), ("remove_small_components", C.c_int32),
                 ("remove_unreferenced", C.c_int32), ("merge_distance", C.c_float), ("min_component_faces", C.c_uint32),
-                ("simplify", C.c_int32), ("simplify_params", SfSimplifyParams), ("simplify_stats", SfSimplifyStats)]
+                ("simplify", C.c_int32), ("simplify_params", SfSimplifyParams), ("simplify_stats", SfSimplifyStats), ("simplify_device", C.c_int32)]
 
 
 def _lib():
@@ -48,9 +48,10 @@ def _lib():
     return L
 
 
-def simplify(mesh, **overrides):
+def simplify(mesh, gpu=None, **overrides):
     """"Quadric Edge Collapse Decimation" with simplify.mlx's parameters (keep 20 % of the faces) unless overridden;
-    returns (Mesh, stats dict)."""
+    returns (Mesh, stats dict).  gpu=<device>: rounds of independent collapses on that GPU (sf_mesh_simplify_gpu) instead of the
+    sequential host filter -- different triangles, same guarantees, a fraction of the time."""
     p = SfSimplifyParams()
     _lib().sf_simplify_default_params(C.byref(p))
     for k, v in overrides.items():
@@ -58,7 +59,12 @@ def simplify(mesh, **overrides):
             raise TypeError("unknown simplify parameter %r" % k)
         setattr(p, k, v)
     h, st = C.c_void_p(), SfSimplifyStats()
-    check(_lib().sf_mesh_simplify(mesh._h, C.byref(p), C.byref(h), C.byref(st)))
+    if gpu is None:
+        check(_lib().sf_mesh_simplify(mesh._h, C.byref(p), C.byref(h), C.byref(st)))
+    else:
+        L = _lib()
+        L.sf_mesh_simplify_gpu.argtypes = [C.c_void_p, C.POINTER(SfSimplifyParams), C.c_int, C.POINTER(C.c_void_p), C.POINTER(SfSimplifyStats)]
+        check(L.sf_mesh_simplify_gpu(mesh._h, C.byref(p), int(gpu), C.byref(h), C.byref(st)))
     return Mesh(h), {n: getattr(st, n) for n, _ in SfSimplifyStats._fields_}
 
 

@@ -89,7 +89,7 @@ def fuse_scan(sens_path, device=0, params_file=None):
     return mesh, {"scan": sens_path, "frames": rs["frames_integrated"], "gpu_seconds": time.perf_counter() - t0}
 
 
-def finish_scan(mesh, sens_path, clean_min_faces=7500, kthresh=0.01, seg_min_verts=20):
+def finish_scan(mesh, sens_path, clean_min_faces=7500, kthresh=0.01, seg_min_verts=20, gpu_decimate=None):
     """The host part (Server/scan_processor.py:141-156): <id>_vh.ply, clean.mlx -> <id>_vh_clean.ply, simplify.mlx twice (each
     followed by cleanLoRes) -> <id>_vh_clean_2.ply, Segmentator -> <id>_vh_clean_2.0.010000.segs.json.  One thread, tens of seconds
     for a scan-sized mesh (the quadric collapse is sequential): run several of these side by side."""
@@ -101,7 +101,7 @@ def finish_scan(mesh, sens_path, clean_min_faces=7500, kthresh=0.01, seg_min_ver
     cleaned.write_ply(base + "_vh_clean.ply")
     cur = cleaned
     for _ in range(2):
-        simp, _ = meshclean.simplify(cur)
+        simp, _ = meshclean.simplify(cur, gpu=gpu_decimate)   # gpu_decimate = a device index: sf_mesh_simplify_gpu instead of the sequential filter
         cur, _ = meshclean.clean(simp, meshclean.CLEAN_MLX_MERGE_DISTANCE, meshclean.CLEAN_LORES_MIN_COMPONENT)
     cur.write_ply(base + "_vh_clean_2.ply")
     nseg = segmentator.segment_to_json(base + "_vh_clean_2.ply", kthresh, seg_min_verts)

@@ -1,0 +1,87 @@
+"""The GPU variant of the decimate stage's quadric edge collapse (scannet_amd/csrc/simplify_gpu.hip: rounds of independent collapses) under
+the SAME property tests as the sequential filter (tests/test_simplify.py): face budget, planarity and outline of flat regions, closedness and
+Euler characteristic of a closed surface, geometric error, determinism -- the triangles differ from the sequential result, the guarantees do not."""
+import time
+
+import numpy as np
+import pytest
+from scipy.spatial import cKDTree
+
+from scannet_amd import meshclean
+from scannet_amd.segmentator import Mesh
+from tests import meshes
+from tests.test_simplify import _edge_counts, _icosphere, _plane
+
+pytestmark = pytest.mark.gpu
+
+
+def test_plane_stays_planar_and_keeps_its_border_gpu():
+    v, t = _plane(120)
+    out, st = meshclean.simplify(Mesh.from_arrays(v, t), gpu=0)
+    xyz, _, tris = out.arrays()
+    assert st["faces_in"] == len(t) and st["target_faces"] == int(len(t) * 0.2)
+    assert st["faces_out"] == len(tris) <= st["target_faces"] and st["faces_out"] >= st["target_faces"] - 2
+    assert np.abs(xyz[:, 2]).max() == 0.0                      # flat stays exactly flat
+    assert xyz[:, :2].min() >= -1e-6 and xyz[:, :2].max() <= 1 + 1e-6
+    a, b, c = xyz[tris[:, 0]], xyz[tris[:, 1]], xyz[tris[:, 2]]
+    area = 0.5 * np.linalg.norm(np.cross(b - a, c - a), axis=1)
+    assert abs(area.sum() - 1.0) < 1e-3 and area.min() > 0
+    assert (np.cross(b - a, c - a)[:, 2] > 0).all()
+
+
+def test_closed_surface_stays_closed_gpu():
+    v, t = _icosphere(5)  # 20480 faces
+    out, st = meshclean.simplify(Mesh.from_arrays(v, t), gpu=0)
+    xyz, _, tris = out.arrays()
+    assert len(tris) == st["faces_out"] == int(len(t) * 0.2)
+    assert (_edge_counts(tris) == 2).all()
+    assert len(xyz) - len(tris) * 3 // 2 + len(tris) == 2
+    r = np.linalg.norm(xyz, axis=1)
+    assert abs(r - 1).max() < 2e-3
+    a, b, c = xyz[tris[:, 0]], xyz[tris[:, 1]], xyz[tris[:, 2]]
+    n = np.cross(b - a, c - a)
+    assert (np.einsum("ij,ij->i", n, (a + b + c)) > 0).all()
+
+
+def test_heightfield_error_and_determinism_gpu():
+    v, t = meshes.bumpy(120, creases=True)
+    m = Mesh.from_arrays(v, t)
+    out1, st1 = meshclean.simplify(m, gpu=0)
+    out2, st2 = meshclean.simplify(m, gpu=0)
+    x1, _, t1 = out1.arrays()
+    x2, _, t2 = out2.arrays()
+    assert np.array_equal(x1.view(np.uint32), x2.view(np.uint32)) and np.array_equal(t1, t2) and st1 == st2
+    assert st1["faces_out"] <= st1["target_faces"]
+    used = np.unique(t)
+    d, _ = cKDTree(v[used]).query(x1)
+    assert d.max() < 0.02 and np.median(d) < 0.01
+    assert len(x1) == len(np.unique(t1)) and (t1[:, 0] != t1[:, 1]).all() and (t1[:, 1] != t1[:, 2]).all() and (t1[:, 0] != t1[:, 2]).all()
+    # and the quality of what it keeps is that of the sequential filter: the same budget, a comparable distance to the input surface
+    xs, _, ts = meshclean.simplify(m)[0].arrays()
+    ds, _ = cKDTree(v[used]).query(xs)
+    assert len(t1) == len(ts) or abs(len(t1) - len(ts)) <= 2
+    assert np.median(d) < 2.0 * np.median(ds) + 1e-4
+
+
+def test_scan_sized_mesh_gpu_against_sequential():
+    """977 202 faces to 20 %, twice (the decimate stage): face budgets met, surface error of the same order as the sequential filter's, and the
+    time of both printed (the reason the variant exists: the sequential collapse is most of a scan's host time)."""
+    v, f = meshes.bumpy_large(700)
+    m = Mesh.from_arrays(v, f)
+    t0 = time.perf_counter()
+    g1, sg1 = meshclean.simplify(m, gpu=0)
+    g2, sg2 = meshclean.simplify(g1, gpu=0)
+    t_gpu = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    h1, sh1 = meshclean.simplify(m)
+    h2, sh2 = meshclean.simplify(h1)
+    t_host = time.perf_counter() - t0
+    assert sg1["faces_out"] <= sg1["target_faces"] and sg1["faces_out"] >= sg1["target_faces"] - 2 - sg1["faces_zero_area"]
+    assert sg2["faces_out"] <= sg2["target_faces"]
+    tree = cKDTree(v[np.unique(f)])
+    dg = tree.query(g2.arrays()[0])[0]
+    dh = tree.query(h2.arrays()[0])[0]
+    print("decimate 977k faces x 0.2 x 0.2: gpu %.2f s, sequential %.2f s; median distance to the input vertices gpu %.4f, sequential %.4f" %
+          (t_gpu, t_host, np.median(dg), np.median(dh)))
+    assert np.median(dg) < 2.0 * np.median(dh) + 1e-4 and dg.max() < 3.0 * dh.max() + 0.01
+    assert t_gpu < t_host
