@@ -130,7 +130,7 @@ def pmc_pass(counters, config, steps, warmup, single_frame, timeout_s=420):
     try:
         env = dict(os.environ, TMPDIR="/tmp")
         cmd = [exe, "--pmc"] + list(counters) + ["-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--config", config, "--steps", str(steps),
-               "--warmup", str(warmup), "--no-cpu-baseline", "--no-profile", "--no-pmc", "--teardown"] + (["--single-frame"] if single_frame else []) + \
+               "--warmup", str(warmup), "--no-cpu-baseline", "--no-profile", "--no-pmc", "--no-colour", "--teardown"] + (["--single-frame"] if single_frame else []) + \
               sum((["--tune", "%s=%d" % kv] for kv in TUNE.items()), [])
         r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
         dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
@@ -212,9 +212,22 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
     _abi.check(L.sf_synth_room_device(C.c_void_p(frames.data_ptr()), stride, first, n_frames, TOTAL_FRAMES, W, H, 1, poses.ctypes.data_as(C.c_void_p)))
     params = fusion.default_params(voxel_size=cfg["voxel_size"], hash_num_buckets=cfg["hash_num_buckets"], num_sdf_blocks=cfg["num_sdf_blocks"])
 
-    def run(n_warm, n_timed, profile, single_frame=False):
+    colour_frames = [None]
+
+    def colour_tensor(n):
+        """A synthetic RGB frame per depth frame, resident in HBM: smooth gradients that move with the frame index (uint8 [n, H, W, 3])."""
+        if colour_frames[0] is None or colour_frames[0].shape[0] < n:
+            yy = torch.arange(H, device="cuda").view(1, H, 1)
+            xx = torch.arange(W, device="cuda").view(1, 1, W)
+            k = torch.arange(n, device="cuda").view(n, 1, 1)
+            colour_frames[0] = torch.stack([(xx * 255 // W + k) % 256, (yy * 255 // H + 3 * k) % 256, (xx + yy + 7 * k) % 256], -1).to(torch.uint8).contiguous()
+        return colour_frames[0]
+
+    def run(n_warm, n_timed, profile, single_frame=False, colour=False):
         """Fuse frames [0, n_warm) untimed, then frames [n_warm, n_warm + n_timed) between two barrier+synchronize pairs."""
         fuser = fusion.Fuser(params, device=local_rank, **dict(TUNE, **({"batch": 1} if single_frame else {})))
+        rgb = colour_tensor(n_warm + n_timed) if colour else None
+        cstride = W * H * 3
 
         def sync_all():
             fuser.sync()
@@ -222,14 +235,14 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
             if world > 1:
                 dist.barrier()
 
-        fuser.integrate_batch_device(frames[:n_warm].data_ptr(), stride, poses[:n_warm])
+        fuser.integrate_batch_device(frames[:n_warm].data_ptr(), stride, poses[:n_warm], rgb.data_ptr() if colour else None, cstride)
         sync_all()
         st0 = fuser.stats()
         if profile:
             fuser.profile(True)
         sync_all()
         t0 = time.perf_counter()
-        fuser.integrate_batch_device(frames[n_warm:].data_ptr(), stride, poses[n_warm:n_warm + n_timed])
+        fuser.integrate_batch_device(frames[n_warm:].data_ptr(), stride, poses[n_warm:n_warm + n_timed], rgb[n_warm:].data_ptr() if colour else None, cstride)
         t_enq = time.perf_counter() - t0
         sync_all()
         elapsed = time.perf_counter() - t0
@@ -252,7 +265,7 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
         fuser.close()
         blocks = st1["total_frame_blocks"] - st0["total_frame_blocks"]
         # B_frame = N_blk*(512*8 read + 512*8 write + 16) + W*H*2 + 64, summed over the frames
-        alg_bytes = blocks * (4096 + 4096 + 16) + n_timed * (W * H * 2 + 64)
+        alg_bytes = blocks * (4096 + 4096 + 16) + n_timed * (W * H * (5 if colour else 2) + 64)
         return {"elapsed": elapsed, "t_enq": t_enq, "kernel_ms": kernel_ms, "launches": launches, "blocks": blocks, "alg_bytes": alg_bytes,
                 "batch": batch, "n_launch": (n_timed + batch - 1) // batch, "st1": st1, "ceiling": ceiling}
 
@@ -345,6 +358,19 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
                         r1["traffic"] = t["bytes"]
                         r1["traffic_detail"] = t
                 out["roofline_single_frame"] = r1
+        if world == 1 and not args.no_profile and not args.single_frame and not args.no_colour and cfg_name == "4mm" and K > 1:
+            # the colour variant of the same pass (a colour frame per depth frame, resident in HBM): k_integrate<1, true, ...>
+            kc = min(K, 2000)
+            mc = run(Wm, kc, True, colour=True)
+            if mc["launches"]:
+                t_s = mc["kernel_ms"] * 1e-3 / mc["launches"]
+                rc = {"bound": "valu", "frames_per_s": round(kc / mc["elapsed"], 1), "ms_per_frame": round(mc["elapsed"] * 1e3 / kc, 5),
+                      "kernel": "k_integrate<1,true,true,2>", "alg_equiv_GBs": round(mc["alg_bytes"] / mc["launches"] / t_s / 1e9, 1),
+                      "note": "16 frames per launch with a colour gather and blend per voxel on top of the geometry update; VALU-issue bound like the geometry kernel "
+                              "(frac: see roofline.frac; no separate counter pass is run for it).  End to end from a .sens the colour path is PCIe-bound "
+                              "(1.5 MB per frame: profiles/)"}
+                rc.update(per_launch(mc, kc))
+                out["roofline_colour"] = rc
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
             ns = min(2048, n_frames)   # ~12 s of the port; the depth of the sample pulled back to the host
             out["cpu_baseline"] = cpu_baseline(frames[:ns].cpu().numpy().view(np.uint16), poses[:ns].reshape(-1, 4, 4), cfg["voxel_size"])
@@ -541,6 +567,7 @@ def main():
     ap.add_argument("--pmc-steps", type=int, default=None)
     ap.add_argument("--single-frame", action="store_true", help="one frame per launch (batch = 1) for the main measurement")
     ap.add_argument("--no-single-frame", action="store_true", help="skip the secondary one-frame-per-launch roofline pass")
+    ap.add_argument("--no-colour", action="store_true", help="skip the secondary colour-fusion pass")
     ap.add_argument("--teardown", action="store_true", help="leave through the interpreter's normal teardown (set for the runs under rocprofv3)")
     ap.add_argument("--host-stage", choices=["full", "gpu-decimate", "clean", "none"], default="full",
                     help="--config scans: what follows marching cubes -- full: clean + sequential quadric collapse x 2 + segment on host threads; gpu-decimate: the "

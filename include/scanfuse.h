@@ -109,6 +109,10 @@ int sf_fuser_deintegrate_device(sf_fuser* f, const void* d_depth, const void* d_
  * the batch in frame order (temporal blocking) -- the result is bit-identical to frame-by-frame integration. */
 int sf_fuser_integrate_batch_device(sf_fuser* f, const void* d_depth, uint64_t frame_stride_bytes,
                                     const float* poses, uint64_t n);
+/* The same with a colour frame per depth frame (rgb: depth_width x depth_height x 3 bytes, or color_width x color_height x 3 when sf_params
+ * gives a colour resolution), `rgb_stride_bytes` apart. */
+int sf_fuser_integrate_batch_device_rgb(sf_fuser* f, const void* d_depth, uint64_t frame_stride_bytes, const void* d_rgb, uint64_t rgb_stride_bytes,
+                                        const float* poses, uint64_t n);
 int sf_fuser_batch_frames(const sf_fuser* f);   /* 16 */
 
 int sf_fuser_garbage_collect(sf_fuser* f, uint32_t* freed);

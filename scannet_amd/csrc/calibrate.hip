@@ -519,7 +519,7 @@ SF_API int sf_calibrator_run(sf_calibrator* c, int n, const uint8_t* const* rgb_
 }
 
 int jpeg_gpu_reconstruct(hipStream_t stream, int n, const uint8_t* const* d_payload, uint8_t* const* d_rgb, uint8_t* const* d_planes, uint32_t max_blocks,
-                         uint64_t max_pixels);  // jpeg_gpu.hip
+                         uint32_t max_width, uint32_t max_height);  // jpeg_gpu.hip
 
 // bytes a frame's coefficient payload may take in sf_calibrator_run_payload (header + block table + as many entries as the pixels have bytes)
 size_t calibrator_payload_capacity(const sf_calibrator* c) {
@@ -572,7 +572,7 @@ int calibrator_run_payload(sf_calibrator* c, int n, const uint8_t* const* rgb_in
     }
   }
   if (np > 0) {
-    const int rcj = jpeg_gpu_reconstruct(c->stream, np, pp, pr, pl, max_blocks, (uint64_t)k.cw * k.ch);
+    const int rcj = jpeg_gpu_reconstruct(c->stream, np, pp, pr, pl, max_blocks, (uint32_t)k.cw, (uint32_t)k.ch);
     if (rcj != SF_OK) return rcj;
   }
   const int rc = sf_calibrator_run_device(c, n, ri, ro, di, dout, nullptr);

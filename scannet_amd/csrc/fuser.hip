@@ -1568,26 +1568,37 @@ SF_API int sf_fuser_deintegrate_device(sf_fuser* f, const void* d_depth, const v
   SF_HIP_CHECK(hipSetDevice(f->device));
   return run_frame(f, d_depth, d_rgb, pose, -1);
 }
-SF_API int sf_fuser_integrate_batch_device(sf_fuser* f, const void* d_depth, uint64_t frame_stride_bytes, const float* poses, uint64_t n) {
+static int integrate_batch_device(sf_fuser* f, const void* d_depth, uint64_t frame_stride_bytes, const void* d_rgb, uint64_t rgb_stride_bytes, const float* poses,
+                                  uint64_t n) {
   if (!f || !d_depth || !poses) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
   SF_HIP_CHECK(hipSetDevice(f->device));
   const void* dd[MAX_BATCH];
+  const void* dr[MAX_BATCH];
   const float* pp[MAX_BATCH];
   int m = 0;
   for (uint64_t i = 0; i <= n; i++) {
     if (i < n) {
       if (poses[16 * i] == -INFINITY) { f->frames_skipped++; continue; }  // tracking lost: skip (sensorData.h:382)
       dd[m] = (const uint8_t*)d_depth + i * frame_stride_bytes;
+      dr[m] = d_rgb ? (const uint8_t*)d_rgb + i * rgb_stride_bytes : nullptr;
       pp[m] = poses + 16 * i;
       m++;
     }
     if (m == f->batch || (i == n && m > 0)) {
-      const int rc = run_batch(f, dd, nullptr, pp, m, +1);
+      const int rc = run_batch(f, dd, d_rgb ? dr : nullptr, pp, m, +1);
       if (rc != SF_OK) return rc;
       m = 0;
     }
   }
   return SF_OK;
+}
+SF_API int sf_fuser_integrate_batch_device(sf_fuser* f, const void* d_depth, uint64_t frame_stride_bytes, const float* poses, uint64_t n) {
+  return integrate_batch_device(f, d_depth, frame_stride_bytes, nullptr, 0, poses, n);
+}
+SF_API int sf_fuser_integrate_batch_device_rgb(sf_fuser* f, const void* d_depth, uint64_t frame_stride_bytes, const void* d_rgb, uint64_t rgb_stride_bytes,
+                                               const float* poses, uint64_t n) {
+  if (!d_rgb) return sf::fail(SF_ERR_INVALID_ARG, "NULL colour frames (sf_fuser_integrate_batch_device is the geometry-only entry point)");
+  return integrate_batch_device(f, d_depth, frame_stride_bytes, d_rgb, rgb_stride_bytes, poses, n);
 }
 
 SF_API int sf_fuser_batch_frames(const sf_fuser* f) { return f ? f->batch : 0; }

@@ -36,23 +36,37 @@ SF_JHD inline uint8_t sf_jpeg_shift_clamp8(int32_t x, int shift) {
 
 // One 8-point pass.  in: the eight inputs; out k = (value_k + bias) >> shift; `emit(k, value_k + bias, shift)` stores it.
 // 32-bit wrapping arithmetic: unsigned for the sums and products, the final shift on the signed reinterpretation.
+#if defined(__HIP_DEVICE_COMPILE__)
+extern "C" __device__ __attribute__((const)) int __ockl_mul24_i32(int, int);
+#endif
+// a * c in 32-bit wrapping arithmetic where `a` is known to fit 24 signed bits (below: dequantised 16-bit coefficients, sums of two of them,
+// and -- in the row pass -- column results, which are 32-bit values shifted right by 10, and sums of up to four of those: < 2^23 in magnitude)
+// and `c` a 14-bit constant: on the device that is the full-rate v_mul_i32_i24 instead of the quarter-rate 32-bit multiply; same low 32 bits.
+SF_JHD inline uint32_t sf_mul24c(uint32_t a, int c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__ockl_mul24_i32((int)a, c);   // what HIP's __mul24 is (this header is also included where <hip/hip_runtime.h> is not)
+#else
+  return a * (uint32_t)c;
+#endif
+}
+
 template <class Emit>
 SF_JHD inline void sf_idct8_int(int s0, int s1, int s2, int s3, int s4, int s5, int s6, int s7, uint32_t bias, int shift, Emit emit) {
   typedef uint32_t u;
   // even half: rotation of (s2, s6) by 3 pi / 8, butterfly of (s0, s4) scaled by 2^12
-  const u rot = ((u)s2 + (u)s6) * (u)2217;
-  const u ev2 = rot + (u)s6 * (u)-7567;
-  const u ev3 = rot + (u)s2 * (u)3135;
+  const u rot = sf_mul24c((u)s2 + (u)s6, 2217);
+  const u ev2 = rot + sf_mul24c((u)s6, -7567);
+  const u ev3 = rot + sf_mul24c((u)s2, 3135);
   const u ev0 = ((u)s0 + (u)s4) * 4096u, ev1 = ((u)s0 - (u)s4) * 4096u;
   const u a0 = ev0 + ev3 + bias, a3 = ev0 - ev3 + bias, a1 = ev1 + ev2 + bias, a2 = ev1 - ev2 + bias;
   // odd half
   const u q3 = (u)s7 + (u)s3, q4 = (u)s5 + (u)s1, q1 = (u)s7 + (u)s1, q2 = (u)s5 + (u)s3;
-  const u q5 = (q3 + q4) * (u)4816;
-  const u r1 = q5 + q1 * (u)-3685, r2 = q5 + q2 * (u)-10497, r3 = q3 * (u)-8034, r4 = q4 * (u)-1597;
-  const u od3 = (u)s1 * (u)6149 + r1 + r4;
-  const u od2 = (u)s3 * (u)12586 + r2 + r3;
-  const u od1 = (u)s5 * (u)8410 + r2 + r4;
-  const u od0 = (u)s7 * (u)1223 + r1 + r3;
+  const u q5 = sf_mul24c(q3 + q4, 4816);
+  const u r1 = q5 + sf_mul24c(q1, -3685), r2 = q5 + sf_mul24c(q2, -10497), r3 = sf_mul24c(q3, -8034), r4 = sf_mul24c(q4, -1597);
+  const u od3 = sf_mul24c((u)s1, 6149) + r1 + r4;
+  const u od2 = sf_mul24c((u)s3, 12586) + r2 + r3;
+  const u od1 = sf_mul24c((u)s5, 8410) + r2 + r4;
+  const u od0 = sf_mul24c((u)s7, 1223) + r1 + r3;
   // emit receives the UNSHIFTED sum and the shift (the row pass clamps behind the shift: sf_jpeg_shift_clamp8)
   emit(0, (int32_t)(a0 + od3), shift); emit(7, (int32_t)(a0 - od3), shift);
   emit(1, (int32_t)(a1 + od2), shift); emit(6, (int32_t)(a1 - od2), shift);

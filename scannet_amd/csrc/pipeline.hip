@@ -25,7 +25,7 @@
 int sf_fuser_run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb, const float* const* poses, int n);  // fuser.hip
 int jpeg_decode_coef(const uint8_t* data, uint64_t n, uint32_t expect_w, uint32_t expect_h, uint8_t* payload, uint64_t payload_capacity);  // jpeg.cpp
 int jpeg_gpu_reconstruct(hipStream_t stream, int n, const uint8_t* const* d_payload, uint8_t* const* d_rgb, uint8_t* const* d_planes, uint32_t max_blocks,
-                         uint64_t max_pixels);  // jpeg_gpu.hip
+                         uint32_t max_width, uint32_t max_height);  // jpeg_gpu.hip
 
 namespace {
 
@@ -296,7 +296,7 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
         for (int q = jfirst; q < j; q++)
           if (valid[q] && rgbf[q] && bs.coef_mode[q]) { pp_[nj] = d_pay(sl, q); rr_[nj] = d_rgb(sl, q); pl_[nj] = d_planes(sl, q); nj++; }
         if (nj > 0) {
-          const int rcj = jpeg_gpu_reconstruct(in_stream, nj, pp_, rr_, pl_, pay_blocks, (uint64_t)cpx);
+          const int rcj = jpeg_gpu_reconstruct(in_stream, nj, pp_, rr_, pl_, pay_blocks, s->info.color_width, s->info.color_height);
           if (rcj != SF_OK) { result = rcj; err = sf_last_error(); break; }
         }
       }

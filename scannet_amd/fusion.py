@@ -121,9 +121,14 @@ class Fuser:
         rc = check(_abi.lib().sf_fuser_deintegrate_device(self._h, _ptr(d_depth), _ptr(d_rgb), _ptr(pose)), allow=(_abi.SF_ERR_SKIPPED,))
         return rc == 0
 
-    def integrate_batch_device(self, d_depth, frame_stride_bytes, poses):
+    def integrate_batch_device(self, d_depth, frame_stride_bytes, poses, d_rgb=None, rgb_stride_bytes=0):
         poses = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 16)
-        check(_abi.lib().sf_fuser_integrate_batch_device(self._h, _ptr(d_depth), int(frame_stride_bytes), _ptr(poses), len(poses)))
+        if d_rgb is None:
+            check(_abi.lib().sf_fuser_integrate_batch_device(self._h, _ptr(d_depth), int(frame_stride_bytes), _ptr(poses), len(poses)))
+        else:
+            L = _abi.lib()
+            L.sf_fuser_integrate_batch_device_rgb.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+            check(L.sf_fuser_integrate_batch_device_rgb(self._h, _ptr(d_depth), int(frame_stride_bytes), _ptr(d_rgb), int(rgb_stride_bytes), _ptr(poses), len(poses)))
 
     @property
     def batch_frames(self):
