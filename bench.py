@@ -220,7 +220,11 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
             yy = torch.arange(H, device="cuda").view(1, H, 1)
             xx = torch.arange(W, device="cuda").view(1, 1, W)
             k = torch.arange(n, device="cuda").view(n, 1, 1)
-            colour_frames[0] = torch.stack([(xx * 255 // W + k) % 256, (yy * 255 // H + 3 * k) % 256, (xx + yy + 7 * k) % 256], -1).to(torch.uint8).contiguous()
+            out = torch.empty((n, H, W, 3), dtype=torch.uint8, device="cuda")
+            out[..., 0] = (xx * 255 // W + k) % 256
+            out[..., 1] = (yy * 255 // H + 3 * k) % 256
+            out[..., 2] = (xx + yy + 7 * k) % 256
+            colour_frames[0] = out
         return colour_frames[0]
 
     def run(n_warm, n_timed, profile, single_frame=False, colour=False):
@@ -416,15 +420,25 @@ def run_scans(args, rank, local_rank, world, dist, torch):
         nv, nf = mesh.counts()
         res = {"scan": args.first_scan + i, "frames": specs[i][1], "faces": nf}
         if args.host_stage != "none":
+            ta = time.perf_counter()
             cleaned, _ = meshclean.clean(mesh, meshclean.CLEAN_MLX_MERGE_DISTANCE, 7500)
+            res["clean_s"] = time.perf_counter() - ta
             cur = cleaned
+            res["decimate_s"] = res["clean_lores_s"] = 0.0
             if args.host_stage in ("full", "gpu-decimate"):
                 for _ in range(2):
-                    simp, _ = meshclean.simplify(cur, gpu=local_rank if args.host_stage == "gpu-decimate" else None)
+                    ta = time.perf_counter()
+                    simp, sst = meshclean.simplify(cur, gpu=local_rank if args.host_stage == "gpu-decimate" else None)
+                    tb = time.perf_counter()
                     cur, _ = meshclean.clean(simp, meshclean.CLEAN_MLX_MERGE_DISTANCE, meshclean.CLEAN_LORES_MIN_COMPONENT)
+                    res["decimate_s"] += tb - ta
+                    res["clean_lores_s"] += time.perf_counter() - tb
+                    res["decimate_rounds"] = res.get("decimate_rounds", 0) + sst["rounds"]
+            ta = time.perf_counter()
             ply = os.path.join(outdir, "scan%04d_vh_clean_2.ply" % i)
             cur.write_ply(ply)
             res["segments"] = segmentator.segment_to_json(ply, 0.01, 20)
+            res["segment_s"] = time.perf_counter() - ta
             res["faces_out"] = cur.counts()[1]
         res["host_s"] = time.perf_counter() - t0
         return res
@@ -471,6 +485,8 @@ def run_scans(args, rank, local_rank, world, dist, torch):
                    "frames_total": int(frames_sum)},
         "gpu_busy_s_sum": round(busy_sum, 3), "gpu_idle_pct": round(100.0 * (1.0 - busy_sum / (elapsed * world)), 1),
         "host_stage_s_mean_rank0": round(float(np.mean(host_s)), 3) if host_s else None,
+        "host_stage_parts_s_mean_rank0": {k: round(float(np.mean([r.get(k, 0.0) for _, r in done])), 3)
+                                          for k in ("clean_s", "decimate_s", "clean_lores_s", "segment_s", "decimate_rounds", "faces")} if host_s else None,
         "roofline": None,
         "note": "per scan: frames rendered into HBM in chunks of %d (input generation, counted as GPU-busy), fused 16 frames per pass, marching cubes; the host "
                 "stage runs on threads while the GPU takes the next scan.  With the full host stage the CPUs, not the GPU, set scans/min" % chunk,

@@ -445,6 +445,7 @@ typedef struct sf_simplify_stats {
   uint64_t faces_zero_area, vertices_duplicate;   /* AutoClean */
   uint64_t vertices_out, faces_out;
   float max_priority;              /* largest scaled quadric error / quality of an executed collapse */
+  uint32_t rounds;                 /* sf_mesh_simplify_gpu: rounds of independent collapses (0 from the sequential filter) */
 } sf_simplify_stats;
 void sf_simplify_default_params(sf_simplify_params* p);   /* the values simplify.mlx ships */
 int sf_mesh_simplify(const sf_mesh* in, const sf_simplify_params* p, sf_mesh** out, sf_simplify_stats* stats /*nullable*/);

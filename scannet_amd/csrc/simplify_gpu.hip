@@ -49,6 +49,11 @@ struct DevBuf {
   template <typename T> T* as() { return (T*)p; }
 };
 
+struct StreamGuard {
+  hipStream_t s = nullptr;
+  ~StreamGuard() { if (s) (void)hipStreamDestroy(s); }
+};
+
 #define DEC_CHECK(call)                                                                                                \
   do {                                                                                                                 \
     hipError_t e_ = (call);                                                                                            \
@@ -235,24 +240,38 @@ __device__ inline void for_closed_rings(const Mesh& M, uint32_t v0, uint32_t v1,
     }
   }
 }
-__global__ void k_lock(Mesh M, const uint64_t* __restrict__ ukey, uint32_t E, const float* __restrict__ pri, float tau, unsigned long long* lock) {
+// Lock key of an edge: its priority (positive, so the bit pattern orders it), ties broken by a BIJECTIVE scramble of the edge index salted
+// with the round.  Not by the index itself: edge indices follow the vertex order, which on a marching-cubes mesh follows space, and the
+// flat parts of a room carry the same floored priority on every edge -- the lowest index of a neighbourhood is then the lowest of a
+// whole wall, one collapse per wall and round.  Scrambled, a constant fraction of the tied edges is a local minimum every round.
+__device__ inline unsigned long long lock_key(float p, uint32_t e, uint32_t salt) {
+  uint32_t h = e + salt;
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;   // invertible steps: distinct edges keep distinct keys
+  return ((unsigned long long)__float_as_uint(p) << 32) | h;
+}
+__global__ void k_lock(Mesh M, const uint64_t* __restrict__ ukey, uint32_t E, const float* __restrict__ pri, float tau, uint32_t salt, unsigned long long* lock) {
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
   const float p = pri[e];
   if (!(p <= tau)) return;
-  const unsigned long long key = ((unsigned long long)__float_as_uint(p) << 32) | e;   // priorities are positive: the bit pattern orders them
+  const unsigned long long key = lock_key(p, e, salt);
   for_closed_rings(M, (uint32_t)(ukey[e] >> 32), (uint32_t)ukey[e], [&](uint32_t u) { atomicMin(&lock[u], key); });
 }
-__global__ void k_winners(Mesh M, const uint64_t* __restrict__ ukey, uint32_t E, const float* __restrict__ pri, float tau, const unsigned long long* __restrict__ lock,
-                          unsigned long long* win, uint32_t* nwin) {
+// counters: [0] winners, [1] faces their collapses remove (2 per interior edge, 1 per border edge), [2] bit pattern of the largest priority
+__global__ void k_winners(Mesh M, const uint64_t* __restrict__ ukey, const uint32_t* __restrict__ ucnt, uint32_t E, const float* __restrict__ pri, float tau, uint32_t salt,
+                          const unsigned long long* __restrict__ lock, unsigned long long* win, uint32_t* counters) {
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
   const float p = pri[e];
   if (!(p <= tau)) return;
-  const unsigned long long key = ((unsigned long long)__float_as_uint(p) << 32) | e;
+  const unsigned long long key = lock_key(p, e, salt);
   bool mine = true;
   for_closed_rings(M, (uint32_t)(ukey[e] >> 32), (uint32_t)ukey[e], [&](uint32_t u) { mine = mine && lock[u] == key; });
-  if (mine) win[atomicAdd(nwin, 1u)] = key;
+  if (mine) {
+    win[atomicAdd(&counters[0], 1u)] = ((unsigned long long)__float_as_uint(p) << 32) | e;
+    atomicAdd(&counters[1], ucnt[e]);
+    atomicMax(&counters[2], __float_as_uint(p));
+  }
 }
 
 // ---- 5. collapse ------------------------------------------------------------------------------------------------------------------------------
@@ -326,7 +345,9 @@ SF_API int sf_mesh_simplify_gpu(const sf_mesh* in, const sf_simplify_params* p, 
     scale = diag > 0.0 ? 1e8 * std::pow(1.0 / diag, 6.0) : 1.0;
   }
   if (F > 0 && V > 0 && nalive > target) {
-    hipStream_t s = nullptr;
+    StreamGuard sg;   // its own stream: host threads finishing several meshes, and the fuser of the next scan, share the device
+    DEC_CHECK(hipStreamCreateWithFlags(&sg.s, hipStreamNonBlocking));
+    hipStream_t s = sg.s;
     const size_t NC = 3 * (size_t)F;
     DevBuf d_pos, d_tri, d_alive, d_vdel, d_Q, d_vbeg, d_vcnt, d_ckey, d_cval, d_ckey2, d_cval2, d_ekey, d_ekey2, d_ukey, d_ucnt, d_nruns, d_pri, d_pri2, d_pri3, d_x, d_lock,
         d_win, d_win2, d_nwin, d_tmp;
@@ -335,11 +356,11 @@ SF_API int sf_mesh_simplify_gpu(const sf_mesh* in, const sf_simplify_params* p, 
     DEC_CHECK(d_ckey.alloc(NC * 4)); DEC_CHECK(d_cval.alloc(NC * 4)); DEC_CHECK(d_ckey2.alloc(NC * 4)); DEC_CHECK(d_cval2.alloc(NC * 4));
     DEC_CHECK(d_ekey.alloc(NC * 8)); DEC_CHECK(d_ekey2.alloc(NC * 8)); DEC_CHECK(d_ukey.alloc(NC * 8)); DEC_CHECK(d_ucnt.alloc(NC * 4)); DEC_CHECK(d_nruns.alloc(8));
     DEC_CHECK(d_pri.alloc(NC * 4)); DEC_CHECK(d_pri2.alloc(NC * 4)); DEC_CHECK(d_pri3.alloc(NC * 4)); DEC_CHECK(d_x.alloc(NC * 12)); DEC_CHECK(d_lock.alloc((size_t)V * 8));
-    DEC_CHECK(d_win.alloc(NC * 8)); DEC_CHECK(d_win2.alloc(NC * 8)); DEC_CHECK(d_nwin.alloc(4));
-    DEC_CHECK(hipMemcpy(d_pos.p, pos.data(), (size_t)V * 12, hipMemcpyHostToDevice));
-    DEC_CHECK(hipMemcpy(d_tri.p, tri.data(), NC * 4, hipMemcpyHostToDevice));
-    DEC_CHECK(hipMemcpy(d_alive.p, alive_h.data(), F, hipMemcpyHostToDevice));
-    DEC_CHECK(hipMemset(d_vdel.p, 0, V));
+    DEC_CHECK(d_win.alloc(NC * 8)); DEC_CHECK(d_win2.alloc(NC * 8)); DEC_CHECK(d_nwin.alloc(16));
+    DEC_CHECK(hipMemcpyAsync(d_pos.p, pos.data(), (size_t)V * 12, hipMemcpyHostToDevice, s));
+    DEC_CHECK(hipMemcpyAsync(d_tri.p, tri.data(), NC * 4, hipMemcpyHostToDevice, s));
+    DEC_CHECK(hipMemcpyAsync(d_alive.p, alive_h.data(), F, hipMemcpyHostToDevice, s));
+    DEC_CHECK(hipMemsetAsync(d_vdel.p, 0, V, s));
     // scratch for the rocprim calls: sized once for the largest request
     size_t tmp_bytes = 0, need = 0;
     DEC_CHECK(rocprim::radix_sort_pairs(nullptr, need, d_ckey.as<uint32_t>(), d_ckey2.as<uint32_t>(), d_cval.as<uint32_t>(), d_cval2.as<uint32_t>(), NC, 0, 32, s));
@@ -378,7 +399,8 @@ SF_API int sf_mesh_simplify_gpu(const sf_mesh* in, const sf_simplify_params* p, 
       DEC_CHECK(hipStreamSynchronize(s));
       if (E > 0) {   // the run of dead faces' keys (~0) sorts last
         uint64_t lastkey = 0;
-        DEC_CHECK(hipMemcpy(&lastkey, d_ukey.as<uint64_t>() + (E - 1), 8, hipMemcpyDeviceToHost));
+        DEC_CHECK(hipMemcpyAsync(&lastkey, d_ukey.as<uint64_t>() + (E - 1), 8, hipMemcpyDeviceToHost, s));
+        DEC_CHECK(hipStreamSynchronize(s));
         if (lastkey == ~0ull) E--;
       }
       if (E == 0) break;
@@ -403,24 +425,33 @@ SF_API int sf_mesh_simplify_gpu(const sf_mesh* in, const sf_simplify_params* p, 
       }
       if (!(tau < 3.0e38f)) tau = 3.0e38f;   // never an edge the link test rejected (infinite priority)
       // 4. winners
+      const uint32_t salt = (uint32_t)st.rounds * 0x9E3779B9u;
       hipLaunchKernelGGL(k_iota64, dim3(gV), dim3(256), 0, s, d_lock.as<unsigned long long>(), ~0ull, V);
-      hipLaunchKernelGGL(k_lock, dim3(gE), dim3(256), 0, s, M, d_ukey.as<uint64_t>(), E, d_pri.as<float>(), tau, d_lock.as<unsigned long long>());
-      DEC_CHECK(hipMemsetAsync(d_nwin.p, 0, 4, s));
-      hipLaunchKernelGGL(k_winners, dim3(gE), dim3(256), 0, s, M, d_ukey.as<uint64_t>(), E, d_pri.as<float>(), tau, d_lock.as<unsigned long long>(),
-                         d_win.as<unsigned long long>(), d_nwin.as<uint32_t>());
-      uint32_t nwin = 0;
-      DEC_CHECK(hipMemcpyAsync(&nwin, d_nwin.p, 4, hipMemcpyDeviceToHost, s));
+      hipLaunchKernelGGL(k_lock, dim3(gE), dim3(256), 0, s, M, d_ukey.as<uint64_t>(), E, d_pri.as<float>(), tau, salt, d_lock.as<unsigned long long>());
+      DEC_CHECK(hipMemsetAsync(d_nwin.p, 0, 16, s));
+      hipLaunchKernelGGL(k_winners, dim3(gE), dim3(256), 0, s, M, d_ukey.as<uint64_t>(), d_ucnt.as<uint32_t>(), E, d_pri.as<float>(), tau, salt,
+                         d_lock.as<unsigned long long>(), d_win.as<unsigned long long>(), d_nwin.as<uint32_t>());
+      uint32_t cnt[4] = {0, 0, 0, 0};
+      DEC_CHECK(hipMemcpyAsync(cnt, d_nwin.p, 16, hipMemcpyDeviceToHost, s));
       DEC_CHECK(hipStreamSynchronize(s));
+      const uint32_t nwin = cnt[0];
+      st.rounds++;
       if (nwin == 0) {
         if (stalled++ >= 1) break;   // nothing collapsible even without the threshold
         continue;
       }
       stalled = 0;
-      tb = tmp_bytes;
-      DEC_CHECK(rocprim::radix_sort_keys(d_tmp.p, tb, d_win.as<uint64_t>(), d_win2.as<uint64_t>(), (size_t)nwin, 0, 64, s));
-      // the budget: winners in key order until the face count reaches the target (a collapse removes the faces on its edge: 2, or 1 on a border)
       uint32_t take = nwin;
-      {
+      const unsigned long long* d_take = d_win.as<unsigned long long>();
+      if (nalive - cnt[1] >= target) {   // every winner fits under the budget: winners are independent, their order does not matter
+        float mp;
+        std::memcpy(&mp, &cnt[2], 4);
+        if (mp > st.max_priority) st.max_priority = mp;
+        nalive -= cnt[1];
+      } else {   // the last round: winners in (priority, edge) order until the face count reaches the target
+        tb = tmp_bytes;
+        DEC_CHECK(rocprim::radix_sort_keys(d_tmp.p, tb, d_win.as<uint64_t>(), d_win2.as<uint64_t>(), (size_t)nwin, 0, 64, s));
+        d_take = d_win2.as<unsigned long long>();
         win_h.resize(nwin);
         DEC_CHECK(hipMemcpyAsync(win_h.data(), d_win2.p, (size_t)nwin * 8, hipMemcpyDeviceToHost, s));
         ucnt_h.resize(E);
@@ -437,17 +468,18 @@ SF_API int sf_mesh_simplify_gpu(const sf_mesh* in, const sf_simplify_params* p, 
         std::memcpy(&mp, &top, 4);
         if (mp > st.max_priority) st.max_priority = mp;
         nalive -= removed;
-        st.collapses += take;
       }
+      st.collapses += take;
       // 5. collapse
-      hipLaunchKernelGGL(k_collapse, dim3((take + 255) / 256), dim3(256), 0, s, M, d_ukey.as<uint64_t>(), d_x.as<float>(), d_win2.as<unsigned long long>(), take);
+      hipLaunchKernelGGL(k_collapse, dim3((take + 255) / 256), dim3(256), 0, s, M, d_ukey.as<uint64_t>(), d_x.as<float>(), d_take, take);
       DEC_CHECK(hipGetLastError());
     }
     DEC_CHECK(hipStreamSynchronize(s));
-    DEC_CHECK(hipMemcpy(pos.data(), d_pos.p, (size_t)V * 12, hipMemcpyDeviceToHost));
-    DEC_CHECK(hipMemcpy(tri.data(), d_tri.p, NC * 4, hipMemcpyDeviceToHost));
-    DEC_CHECK(hipMemcpy(alive_h.data(), d_alive.p, F, hipMemcpyDeviceToHost));
-    DEC_CHECK(hipMemcpy(vdel_h.data(), d_vdel.p, V, hipMemcpyDeviceToHost));
+    DEC_CHECK(hipMemcpyAsync(pos.data(), d_pos.p, (size_t)V * 12, hipMemcpyDeviceToHost, s));
+    DEC_CHECK(hipMemcpyAsync(tri.data(), d_tri.p, NC * 4, hipMemcpyDeviceToHost, s));
+    DEC_CHECK(hipMemcpyAsync(alive_h.data(), d_alive.p, F, hipMemcpyDeviceToHost, s));
+    DEC_CHECK(hipMemcpyAsync(vdel_h.data(), d_vdel.p, V, hipMemcpyDeviceToHost, s));
+    DEC_CHECK(hipStreamSynchronize(s));
   }
   std::vector<uint8_t> fdel(F);
   uint64_t nf = 0;

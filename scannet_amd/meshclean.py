@@ -27,7 +27,7 @@ class SfSimplifyParams(C.Structure):
 
 class SfSimplifyStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("vertices_in", "faces_in", "target_faces", "collapses", "stale_popped", "faces_zero_area",
-                                          "vertices_duplicate", "vertices_out", "faces_out")] + [("max_priority", C.c_float)]
+                                          "vertices_duplicate", "vertices_out", "faces_out")] + [("max_priority", C.c_float), ("rounds", C.c_uint32)]
 
 
 class SfCleanScript(C.Structure):

@@ -85,3 +85,21 @@ def test_scan_sized_mesh_gpu_against_sequential():
           (t_gpu, t_host, np.median(dg), np.median(dh)))
     assert np.median(dg) < 2.0 * np.median(dh) + 1e-4 and dg.max() < 3.0 * dh.max() + 0.01
     assert t_gpu < t_host
+
+
+def test_large_flat_region_takes_few_rounds_gpu():
+    """A reconstructed room is mostly flat walls: every edge there carries the same (floored) priority.  Ties broken by the edge index --
+    which follows space on a marching-cubes mesh -- leave one local minimum per wall and round (a real scan then takes minutes); broken by a
+    scrambled index a constant fraction of the tied edges collapses every round."""
+    v, t = _plane(700)     # 977 202 faces, all coplanar, vertices in raster order
+    m = Mesh.from_arrays(v, t)
+    meshclean.simplify(m, gpu=0)      # the first call pays the module load
+    t0 = time.perf_counter()
+    out, st = meshclean.simplify(m, gpu=0)
+    dt = time.perf_counter() - t0
+    xyz, _, tris = out.arrays()
+    assert st["faces_out"] == len(tris) <= st["target_faces"] and st["faces_out"] >= st["target_faces"] - 2
+    assert np.abs(xyz[:, 2]).max() == 0.0
+    assert 0 < st["rounds"] < 120, st
+    assert dt < 5.0, dt
+    print("flat 977k faces -> %d in %d rounds, %.3f s" % (len(tris), st["rounds"], dt))
