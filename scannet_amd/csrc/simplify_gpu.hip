@@ -49,6 +49,8 @@ struct DevBuf {
   template <typename T> T* as() { return (T*)p; }
 };
 
+struct Tri { uint32_t a, b, c; };
+
 struct StreamGuard {
   hipStream_t s = nullptr;
   ~StreamGuard() { if (s) (void)hipStreamDestroy(s); }
@@ -348,43 +350,60 @@ SF_API int sf_mesh_simplify_gpu(const sf_mesh* in, const sf_simplify_params* p, 
     StreamGuard sg;   // its own stream: host threads finishing several meshes, and the fuser of the next scan, share the device
     DEC_CHECK(hipStreamCreateWithFlags(&sg.s, hipStreamNonBlocking));
     hipStream_t s = sg.s;
-    const size_t NC = 3 * (size_t)F;
+    const size_t NC0 = 3 * (size_t)F;
     DevBuf d_pos, d_tri, d_alive, d_vdel, d_Q, d_vbeg, d_vcnt, d_ckey, d_cval, d_ckey2, d_cval2, d_ekey, d_ekey2, d_ukey, d_ucnt, d_nruns, d_pri, d_pri2, d_pri3, d_x, d_lock,
         d_win, d_win2, d_nwin, d_tmp;
-    DEC_CHECK(d_pos.alloc((size_t)V * 12)); DEC_CHECK(d_tri.alloc(NC * 4)); DEC_CHECK(d_alive.alloc(F)); DEC_CHECK(d_vdel.alloc(V));
+    DEC_CHECK(d_pos.alloc((size_t)V * 12)); DEC_CHECK(d_tri.alloc(NC0 * 4)); DEC_CHECK(d_alive.alloc(F)); DEC_CHECK(d_vdel.alloc(V));
     DEC_CHECK(d_Q.alloc((size_t)V * sizeof(Quadric))); DEC_CHECK(d_vbeg.alloc((size_t)V * 4)); DEC_CHECK(d_vcnt.alloc((size_t)V * 4));
-    DEC_CHECK(d_ckey.alloc(NC * 4)); DEC_CHECK(d_cval.alloc(NC * 4)); DEC_CHECK(d_ckey2.alloc(NC * 4)); DEC_CHECK(d_cval2.alloc(NC * 4));
-    DEC_CHECK(d_ekey.alloc(NC * 8)); DEC_CHECK(d_ekey2.alloc(NC * 8)); DEC_CHECK(d_ukey.alloc(NC * 8)); DEC_CHECK(d_ucnt.alloc(NC * 4)); DEC_CHECK(d_nruns.alloc(8));
-    DEC_CHECK(d_pri.alloc(NC * 4)); DEC_CHECK(d_pri2.alloc(NC * 4)); DEC_CHECK(d_pri3.alloc(NC * 4)); DEC_CHECK(d_x.alloc(NC * 12)); DEC_CHECK(d_lock.alloc((size_t)V * 8));
-    DEC_CHECK(d_win.alloc(NC * 8)); DEC_CHECK(d_win2.alloc(NC * 8)); DEC_CHECK(d_nwin.alloc(16));
+    DEC_CHECK(d_ckey.alloc(NC0 * 4)); DEC_CHECK(d_cval.alloc(NC0 * 4)); DEC_CHECK(d_ckey2.alloc(NC0 * 4)); DEC_CHECK(d_cval2.alloc(NC0 * 4));
+    DEC_CHECK(d_ekey.alloc(NC0 * 8)); DEC_CHECK(d_ekey2.alloc(NC0 * 8)); DEC_CHECK(d_ukey.alloc(NC0 * 8)); DEC_CHECK(d_ucnt.alloc(NC0 * 4)); DEC_CHECK(d_nruns.alloc(8));
+    DEC_CHECK(d_pri.alloc(NC0 * 4)); DEC_CHECK(d_pri2.alloc(NC0 * 4)); DEC_CHECK(d_pri3.alloc(NC0 * 4)); DEC_CHECK(d_x.alloc(NC0 * 12)); DEC_CHECK(d_lock.alloc((size_t)V * 8));
+    DEC_CHECK(d_win.alloc(NC0 * 8)); DEC_CHECK(d_win2.alloc(NC0 * 8)); DEC_CHECK(d_nwin.alloc(16));
     DEC_CHECK(hipMemcpyAsync(d_pos.p, pos.data(), (size_t)V * 12, hipMemcpyHostToDevice, s));
-    DEC_CHECK(hipMemcpyAsync(d_tri.p, tri.data(), NC * 4, hipMemcpyHostToDevice, s));
+    DEC_CHECK(hipMemcpyAsync(d_tri.p, tri.data(), NC0 * 4, hipMemcpyHostToDevice, s));
     DEC_CHECK(hipMemcpyAsync(d_alive.p, alive_h.data(), F, hipMemcpyHostToDevice, s));
     DEC_CHECK(hipMemsetAsync(d_vdel.p, 0, V, s));
     // scratch for the rocprim calls: sized once for the largest request
     size_t tmp_bytes = 0, need = 0;
-    DEC_CHECK(rocprim::radix_sort_pairs(nullptr, need, d_ckey.as<uint32_t>(), d_ckey2.as<uint32_t>(), d_cval.as<uint32_t>(), d_cval2.as<uint32_t>(), NC, 0, 32, s));
+    DEC_CHECK(rocprim::radix_sort_pairs(nullptr, need, d_ckey.as<uint32_t>(), d_ckey2.as<uint32_t>(), d_cval.as<uint32_t>(), d_cval2.as<uint32_t>(), NC0, 0, 32, s));
     tmp_bytes = std::max(tmp_bytes, need);
-    DEC_CHECK(rocprim::radix_sort_keys(nullptr, need, d_ekey.as<uint64_t>(), d_ekey2.as<uint64_t>(), NC, 0, 64, s));
+    DEC_CHECK(rocprim::radix_sort_keys(nullptr, need, d_ekey.as<uint64_t>(), d_ekey2.as<uint64_t>(), NC0, 0, 64, s));
     tmp_bytes = std::max(tmp_bytes, need);
-    DEC_CHECK(rocprim::run_length_encode(nullptr, need, d_ekey2.as<uint64_t>(), (unsigned int)NC, d_ukey.as<uint64_t>(), d_ucnt.as<uint32_t>(), d_nruns.as<uint32_t>(), s));
+    DEC_CHECK(rocprim::run_length_encode(nullptr, need, d_ekey2.as<uint64_t>(), (unsigned int)NC0, d_ukey.as<uint64_t>(), d_ucnt.as<uint32_t>(), d_nruns.as<uint32_t>(), s));
     tmp_bytes = std::max(tmp_bytes, need);
-    DEC_CHECK(rocprim::radix_sort_keys(nullptr, need, d_pri.as<uint32_t>(), d_pri2.as<uint32_t>(), NC, 0, 32, s));
+    DEC_CHECK(rocprim::radix_sort_keys(nullptr, need, d_pri.as<uint32_t>(), d_pri2.as<uint32_t>(), NC0, 0, 32, s));
     tmp_bytes = std::max(tmp_bytes, need);
-    DEC_CHECK(rocprim::radix_sort_keys(nullptr, need, d_win.as<uint64_t>(), d_win2.as<uint64_t>(), NC, 0, 64, s));
+    DEC_CHECK(rocprim::radix_sort_keys(nullptr, need, d_win.as<uint64_t>(), d_win2.as<uint64_t>(), NC0, 0, 64, s));
+    tmp_bytes = std::max(tmp_bytes, need);
+    DEC_CHECK(rocprim::select(nullptr, need, d_tri.as<Tri>(), d_alive.as<uint8_t>(), d_ckey.as<Tri>(), d_nruns.as<uint32_t>(), (size_t)F, s));
     tmp_bytes = std::max(tmp_bytes, need);
     DEC_CHECK(d_tmp.alloc(tmp_bytes));
     Mesh M{d_pos.as<float>(), d_tri.as<uint32_t>(), d_alive.as<uint8_t>(), d_vdel.as<uint8_t>(), d_Q.as<Quadric>(), d_vbeg.as<uint32_t>(), d_vcnt.as<uint32_t>(),
            d_cval2.as<uint32_t>(), V, F};
-    const unsigned gF = (F + 255) / 256, gC = (unsigned)((NC + 255) / 256), gV = (V + 255) / 256;
+    const unsigned gV = (V + 255) / 256;
+    uint32_t Fc = F;   // faces in the device arrays: dead ones are squeezed out (in order) when a quarter has gone, the sorts shrink with the mesh
     bool first = true;
     int stalled = 0;
     std::vector<unsigned long long> win_h;
     std::vector<uint32_t> ucnt_h;
     while (nalive > target) {
-      // 1. adjacency of the live faces
-      hipLaunchKernelGGL(k_emit, dim3(gF), dim3(256), 0, s, M.tri, M.alive, F, d_ckey.as<uint32_t>(), d_cval.as<uint32_t>(), d_ekey.as<uint64_t>());
       size_t tb = tmp_bytes;
+      if (nalive * 4 < (uint64_t)Fc * 3) {
+        DEC_CHECK(rocprim::select(d_tmp.p, tb, d_tri.as<Tri>(), d_alive.as<uint8_t>(), d_ckey.as<Tri>(), d_nruns.as<uint32_t>(), (size_t)Fc, s));
+        uint32_t kept = 0;
+        DEC_CHECK(hipMemcpyAsync(&kept, d_nruns.p, 4, hipMemcpyDeviceToHost, s));
+        DEC_CHECK(hipStreamSynchronize(s));
+        if (kept != nalive) return sf::fail(SF_ERR_DEVICE, "simplify_gpu: %u faces alive on the device, %llu counted", kept, (unsigned long long)nalive);
+        DEC_CHECK(hipMemcpyAsync(d_tri.p, d_ckey.p, (size_t)kept * 12, hipMemcpyDeviceToDevice, s));
+        DEC_CHECK(hipMemsetAsync(d_alive.p, 1, kept, s));
+        Fc = kept;
+        M.F = Fc;
+      }
+      const size_t NC = 3 * (size_t)Fc;
+      const unsigned gF = (Fc + 255) / 256, gC = (unsigned)((NC + 255) / 256);
+      // 1. adjacency of the live faces
+      hipLaunchKernelGGL(k_emit, dim3(gF), dim3(256), 0, s, M.tri, M.alive, Fc, d_ckey.as<uint32_t>(), d_cval.as<uint32_t>(), d_ekey.as<uint64_t>());
+      tb = tmp_bytes;
       DEC_CHECK(rocprim::radix_sort_pairs(d_tmp.p, tb, d_ckey.as<uint32_t>(), d_ckey2.as<uint32_t>(), d_cval.as<uint32_t>(), d_cval2.as<uint32_t>(), NC, 0, 32, s));
       DEC_CHECK(hipMemsetAsync(d_vbeg.p, 0, (size_t)V * 4, s));
       DEC_CHECK(hipMemsetAsync(d_vcnt.p, 0, (size_t)V * 4, s));
@@ -476,14 +495,17 @@ SF_API int sf_mesh_simplify_gpu(const sf_mesh* in, const sf_simplify_params* p, 
     }
     DEC_CHECK(hipStreamSynchronize(s));
     DEC_CHECK(hipMemcpyAsync(pos.data(), d_pos.p, (size_t)V * 12, hipMemcpyDeviceToHost, s));
-    DEC_CHECK(hipMemcpyAsync(tri.data(), d_tri.p, NC * 4, hipMemcpyDeviceToHost, s));
-    DEC_CHECK(hipMemcpyAsync(alive_h.data(), d_alive.p, F, hipMemcpyDeviceToHost, s));
+    tri.resize(3 * (size_t)Fc);
+    alive_h.resize(Fc);
+    DEC_CHECK(hipMemcpyAsync(tri.data(), d_tri.p, (size_t)Fc * 12, hipMemcpyDeviceToHost, s));
+    DEC_CHECK(hipMemcpyAsync(alive_h.data(), d_alive.p, Fc, hipMemcpyDeviceToHost, s));
     DEC_CHECK(hipMemcpyAsync(vdel_h.data(), d_vdel.p, V, hipMemcpyDeviceToHost, s));
     DEC_CHECK(hipStreamSynchronize(s));
   }
-  std::vector<uint8_t> fdel(F);
+  const size_t Fh = alive_h.size();   // the device squeezes dead faces out of its arrays as it goes
+  std::vector<uint8_t> fdel(Fh);
   uint64_t nf = 0;
-  for (uint32_t f = 0; f < F; f++) { fdel[f] = alive_h[f] ? 0 : 1; nf += alive_h[f] ? 1 : 0; }
+  for (size_t f = 0; f < Fh; f++) { fdel[f] = alive_h[f] ? 0 : 1; nf += alive_h[f] ? 1 : 0; }
   sf_mesh* m = simplify_finish(in, *p, pos, tri, fdel, vdel_h, nf, st);
   st.target_faces = target;
   if (stats) *stats = st;

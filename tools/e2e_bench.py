@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--dir", default="/tmp/sf_e2e")
     ap.add_argument("--out", default="")
     ap.add_argument("--color", choices=["none", "raw", "jpeg"], default="none", help="store a synthetic 640x480 colour frame per depth frame")
+    ap.add_argument("--gpu-decimate", action="store_true", help="the decimate stage on the GPU (sf_mesh_simplify_gpu) instead of the sequential filter")
     ap.add_argument("--fuse-only", action="store_true", help="stop after the fusion stage")
     ap.add_argument("--color-res", default="", help="WxH of the colour frames when it differs from the depth size (ScanNet: 1296x968)")
     a = ap.parse_args()
@@ -112,10 +113,12 @@ def main():
     cur = cleaned
     for k in (1, 2):
         t0 = time.perf_counter()
-        simp, sst = meshclean.simplify(cur)
+        simp, sst = meshclean.simplify(cur, gpu=0 if a.gpu_decimate else None)
+        t1 = time.perf_counter()
         cur, _ = meshclean.clean(simp, min_component_faces=1000)
         res["decimate%d_s" % k] = round(time.perf_counter() - t0, 3)
-        res["decimate%d" % k] = {"faces_in": sst["faces_in"], "faces_out": cur.counts()[1], "collapses": sst["collapses"]}
+        res["decimate%d" % k] = {"faces_in": sst["faces_in"], "faces_out": cur.counts()[1], "collapses": sst["collapses"], "rounds": sst["rounds"],
+                                 "collapse_s": round(t1 - t0, 3), "where": "gpu" if a.gpu_decimate else "host"}
     cply = os.path.join(a.dir, "scene_e2e_vh_clean_2.ply")
     cur.write_ply(cply)
     t0 = time.perf_counter()
