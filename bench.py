@@ -267,13 +267,10 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
                            "read_only_us": round(ro_us, 2), "read_only_GBs": round(tiles * 4096 / ro_us / 1e3, 1)}
         batch = fuser.batch_frames
         fuser.close()
-        # block-frames that reach the integrate kernel: N_blk (allocated and in the frustum) minus those k_compactify proves cannot change
-        # (wholly behind what the frame sees); the kernel neither reads nor writes the dropped ones, so they are not algorithmic bytes
-        blocks = st1["total_frame_blocks_fused"] - st0["total_frame_blocks_fused"]
-        frustum_blocks = st1["total_frame_blocks"] - st0["total_frame_blocks"]
+        blocks = st1["total_frame_blocks"] - st0["total_frame_blocks"]
         # B_frame = N_blk*(512*8 read + 512*8 write + 16) + W*H*2 + 64, summed over the frames
         alg_bytes = blocks * (4096 + 4096 + 16) + n_timed * (W * H * (5 if colour else 2) + 64)
-        return {"elapsed": elapsed, "t_enq": t_enq, "kernel_ms": kernel_ms, "launches": launches, "blocks": blocks, "frustum_blocks": frustum_blocks, "alg_bytes": alg_bytes,
+        return {"elapsed": elapsed, "t_enq": t_enq, "kernel_ms": kernel_ms, "launches": launches, "blocks": blocks, "alg_bytes": alg_bytes,
                 "batch": batch, "n_launch": (n_timed + batch - 1) // batch, "st1": st1, "ceiling": ceiling}
 
     def per_launch(m, n_timed):
@@ -343,9 +340,7 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
                        "blocks_live_end": m["st1"]["blocks_allocated"], "alloc_failures": m["st1"]["alloc_failures"],
                        "frames_per_pass": m["batch"], "integrate_launches": m["n_launch"],
                        "alg_bytes_per_launch": round(m["alg_bytes"] / max(m["n_launch"], 1))},
-            "roofline_inputs": {"block_frames_per_launch": round(m["blocks"] / max(m["n_launch"], 1), 1),
-                                "block_frames_in_frustum_per_launch": round(m["frustum_blocks"] / max(m["n_launch"], 1), 1),
-                                "occluded_block_frames_dropped_pct": round(100.0 * (1.0 - m["blocks"] / max(m["frustum_blocks"], 1)), 2)},
+            "roofline_inputs": {"block_frames_per_launch": round(m["blocks"] / max(m["n_launch"], 1), 1)},
             "roofline": roof,
         }
         if world == 1 and not args.no_profile and not args.single_frame and not args.no_single_frame and K > 1:

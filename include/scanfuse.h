@@ -89,8 +89,6 @@ typedef struct sf_stats {
   uint64_t total_frame_blocks;   /* sum of N_blk over all frames since create / reset_counters   */
   uint32_t hash_slots_used;
   uint32_t high_water;           /* 1 + highest heap block index ever handed out                 */
-  uint64_t total_frame_blocks_fused; /* of total_frame_blocks, the block-frames that reached the integrate kernel: a block wholly
-                                        behind what the frame sees (further than the truncation band) cannot change and is skipped */
 } sf_stats;
 
 int sf_device_count(int* count);

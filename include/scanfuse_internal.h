@@ -25,7 +25,6 @@ extern "C" {
  *   "nt"          -1/0/1 that kernel's tile loads and stores non-temporal: -1 = when the previous pass touched more than 512 MiB of tiles (default)
  *   "front_cus"   0..128 the second stream owns that many CUs (spread over the chip), the main stream the rest (hipExtStreamCreateWithCUMask); 0 = shared
  *   "alloc_group" 1..16  consecutive frames one allocation workgroup walks (default 4)
- *   "cull"        0/1    block-frames wholly behind what the frame sees (beyond the truncation band) are dropped from the integrate list (default 1)
  * Synchronises the fuser.  SF_ERR_INVALID_ARG for an unknown key or a value out of range. */
 int sf_fuser_tune(sf_fuser* f, const char* key, int value);
 

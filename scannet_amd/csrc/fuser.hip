@@ -28,13 +28,13 @@
 namespace {
 
 // bounding sphere of the block against the four side planes and the z range of the frustum
-__device__ inline bool block_in_frustum(const ParamsK& P, const FrameK& F, int bx, int by, int bz, float& px, float& py, float& pz) {
+__device__ inline bool block_in_frustum(const ParamsK& P, const FrameK& F, int bx, int by, int bz) {
   const float cx = ((float)(8 * bx) + 3.5f) * P.voxel;
   const float cy = ((float)(8 * by) + 3.5f) * P.voxel;
   const float cz = ((float)(8 * bz) + 3.5f) * P.voxel;
-  px = fmaf(F.Ti[0], cx, fmaf(F.Ti[1], cy, fmaf(F.Ti[2], cz, F.Ti[3])));
-  py = fmaf(F.Ti[4], cx, fmaf(F.Ti[5], cy, fmaf(F.Ti[6], cz, F.Ti[7])));
-  pz = fmaf(F.Ti[8], cx, fmaf(F.Ti[9], cy, fmaf(F.Ti[10], cz, F.Ti[11])));
+  const float px = fmaf(F.Ti[0], cx, fmaf(F.Ti[1], cy, fmaf(F.Ti[2], cz, F.Ti[3])));
+  const float py = fmaf(F.Ti[4], cx, fmaf(F.Ti[5], cy, fmaf(F.Ti[6], cz, F.Ti[7])));
+  const float pz = fmaf(F.Ti[8], cx, fmaf(F.Ti[9], cy, fmaf(F.Ti[10], cz, F.Ti[11])));
   bool in = pz > -F.radius;
   in = in && (pz < F.zfar + F.radius);
   in = in && (fmaf(F.xa[0], px, F.xc[0] * pz) >= -F.xr[0]);
@@ -42,36 +42,6 @@ __device__ inline bool block_in_frustum(const ParamsK& P, const FrameK& F, int b
   in = in && (fmaf(F.ya[0], py, F.yc[0] * pz) >= -F.yr[0]);
   in = in && (fmaf(F.ya[1], py, F.yc[1] * pz) >= -F.yr[1]);
   return in;
-}
-__device__ inline bool block_in_frustum(const ParamsK& P, const FrameK& F, int bx, int by, int bz) {
-  float px, py, pz;
-  return block_in_frustum(P, F, bx, by, bz, px, py, pz);
-}
-
-// Can a block whose voxel centres lie within cull_r of (px, py, pz) (camera space) receive ANY update from this frame?  A voxel is
-// updated iff its pixel holds a valid depth d < maxDist with d - z > -trunc(d), i.e. d + trunc(d) > z (voxels in FRONT of the
-// surface always are: free space is carved).  d + trunc(d) grows with d, so when its maximum over every pixel the block can project
-// to is no larger than the block's smallest z, nothing in the block changes: the block-frame is dropped from the integrate list (a
-// tenth to a quarter of the in-frustum block-frames of a room walk are behind what the camera sees).  Conservative on every count --
-// footprint from the bounding sphere plus 1.5 pixels, tiles of 8 x 8 pixels, relative and absolute slack on the comparison, large
-// footprints and blocks near the camera plane kept -- so the set of voxels written is exactly that of the unculled pass.
-__device__ inline bool block_occluded(const ParamsK& P, const uint32_t* __restrict__ tilemax, float px, float py, float pz) {
-  const float r = P.cull_r;
-  const float zn = pz - r;
-  if (!(zn > 0.05f)) return false;
-  const float inv = 1.0f / pz, s = r / zn;
-  const float uc = fmaf(P.fx * px, inv, P.mx), vc = fmaf(P.fy * py, inv, P.my);
-  const float ru = fmaf(P.fx * s, 1.0f + fabsf(px) * inv, 1.5f), rv = fmaf(P.fy * s, 1.0f + fabsf(py) * inv, 1.5f);
-  const float u0 = uc - ru, u1 = uc + ru, v0 = vc - rv, v1 = vc + rv;
-  if (!(u0 == u0 && u1 == u1 && v0 == v0 && v1 == v1)) return false;
-  if (u1 < -1.0f || v1 < -1.0f || u0 > (float)P.W || v0 > (float)P.H) return true;   // projects beside the image altogether
-  const int tx0 = max(0, (int)floorf(u0 * 0.125f)), tx1 = min(P.tW - 1, (int)floorf(u1 * 0.125f));
-  const int ty0 = max(0, (int)floorf(v0 * 0.125f)), ty1 = min(P.tH - 1, (int)floorf(v1 * 0.125f));
-  if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > 64) return false;
-  uint32_t m = 0u;
-  for (int ty = ty0; ty <= ty1; ty++)
-    for (int tx = tx0; tx <= tx1; tx++) m = max(m, tilemax[ty * P.tW + tx]);   // non-negative floats order like their bit patterns
-  return fmaf(__uint_as_float(m), 1.0f + 1e-5f, 1e-6f) <= zn;
 }
 
 __device__ inline int world_to_block(float w, float voxel) {
@@ -87,7 +57,7 @@ __device__ inline int world_to_block(float w, float voxel) {
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_prepass(BatchIn in, float* __restrict__ depthf_all, uint32_t* __restrict__ color_all, int n,
                                                  float shift, float dmin, float dmax, int32_t* counters, int compact_counter, ParamsK P,
-                                                 const float* __restrict__ ray_kx, const float* __restrict__ ray_ky, uint32_t* __restrict__ tilemax_all) {
+                                                 const float* __restrict__ ray_kx, const float* __restrict__ ray_ky) {
   const int j = blockIdx.y;  // frame of the batch
   const uint16_t* __restrict__ depth = in.depth[j];
   const uint8_t* __restrict__ rgb = in.rgb[j];
@@ -126,20 +96,6 @@ __global__ __launch_bounds__(256) void k_prepass(BatchIn in, float* __restrict__
     *reinterpret_cast<float4*>(depthf + i0 + 4) = make_float4(d[4], d[5], d[6], d[7]);
   } else {
     for (int k = 0; k < 8 && i0 + k < n; k++) depthf[i0 + k] = d[k];
-  }
-  if (P.cull_r > 0.0f) {
-    // block_occluded's input: max over the tile of d + trunc(d) for the pixels that can update a voxel at all (valid, d < maxDist)
-    uint32_t* __restrict__ tm = tilemax_all + (size_t)j * (P.tW * P.tH);
-    float e[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) e[k] = (d[k] > 0.0f && d[k] < P.maxd) ? d[k] + fmaf(P.tscale, d[k], P.tbase) : 0.0f;
-    if ((P.W & 7) == 0 && i0 + 8 <= n) {   // the lane's 8 pixels are one row of one tile
-      const float m = fmaxf(fmaxf(fmaxf(e[0], e[1]), fmaxf(e[2], e[3])), fmaxf(fmaxf(e[4], e[5]), fmaxf(e[6], e[7])));
-      if (m > 0.0f) atomicMax(&tm[(i0 / P.W >> 3) * P.tW + (i0 % P.W >> 3)], __float_as_uint(m));
-    } else {
-      for (int k = 0; k < 8 && i0 + k < n; k++)
-        if (e[k] > 0.0f) atomicMax(&tm[((i0 + k) / P.W >> 3) * P.tW + ((i0 + k) % P.W >> 3)], __float_as_uint(e[k]));
-    }
   }
   if (rgb) {
     if (P.cW == 0) {
@@ -477,8 +433,8 @@ __global__ __launch_bounds__(256) void k_compactify(const uint64_t* __restrict__
                                                     const uint8_t* __restrict__ block_flags, const HashEntry* __restrict__ table,
                                                     int32_t* __restrict__ compact,
                                                     uint32_t* __restrict__ cmask, int32_t* counters, int counter_id, int all_live, ParamsK P,
-                                                    BatchFrames B, const uint32_t* __restrict__ tilemax_all) {
-  __shared__ int s_wtot[4], s_wlast[4], s_wpop[4], s_wfus[4];
+                                                    BatchFrames B) {
+  __shared__ int s_wtot[4], s_wlast[4], s_wpop[4];
   __shared__ int s_base;
   const int hw = counters[C_HIGH_WATER];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -486,61 +442,48 @@ __global__ __launch_bounds__(256) void k_compactify(const uint64_t* __restrict__
   for (int base = blockIdx.x * 1024; base < hw; base += gridDim.x * 1024) {
     uint32_t m[4];
     int rank[4];
-    int wtotal = 0, wlast = 0, pop = 0, fus = 0;
+    int wtotal = 0, wlast = 0, pop = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const int i = base + j * 256 + threadIdx.x;
       m[j] = 0u;
-      uint32_t mf = 0u;   // frames whose frustum holds the block (N_blk of DESIGN 3.3 / sf_stats); m[j]: those of them that can change it
       if (i < hw) {
         const uint64_t k = block_keys[i];
         if (k != KEY_EMPTY && !(all_live != 1 && (block_flags[i] & 1))) {  // ghosts are listed by all_live == 1 only
-          if (all_live) m[j] = mf = 1u;
+          if (all_live) m[j] = 1u;
           else {
             int bx, by, bz;
             unpack_key(k, bx, by, bz);
-            uint32_t occ = 0u;
-            for (int q = 0; q < B.n; q++) {
-              float px, py, pz;
-              if (block_in_frustum(P, B.f[q], bx, by, bz, px, py, pz)) {
-                mf |= 1u << q;
-                if (P.cull_r > 0.0f && block_occluded(P, tilemax_all + (size_t)q * (P.tW * P.tH), px, py, pz)) occ |= 1u << q;
-              }
-            }
-            if (mf != 0u && B.n > 1) {
+            for (int q = 0; q < B.n; q++)
+              if (block_in_frustum(P, B.f[q], bx, by, bz)) m[j] |= 1u << q;
+            if (m[j] != 0u && B.n > 1) {
               const uint32_t birth = table[block_entry[i]].birth;
               if (birth > B.seq0) {
                 const uint32_t d = birth - B.seq0;
-                mf = d >= 32u ? 0u : (mf & ~((1u << d) - 1u));
+                m[j] = d >= 32u ? 0u : (m[j] & ~((1u << d) - 1u));
               }
             }
-            m[j] = mf & ~occ;
           }
         }
       }
       const uint64_t bal = __ballot(m[j] != 0u);
       rank[j] = wtotal + __popcll((unsigned long long)(bal & ((1ull << lane) - 1ull)));
       wtotal += __popcll((unsigned long long)bal);
-      wlast += __popcll((unsigned long long)__ballot((mf & last_bit) != 0u));
-      pop += __popc(mf);
-      fus += __popc(m[j]);
+      wlast += __popcll((unsigned long long)__ballot((m[j] & last_bit) != 0u));
+      pop += __popc(m[j]);
     }
-    for (int o = 32; o > 0; o >>= 1) { pop += __shfl_xor(pop, o); fus += __shfl_xor(fus, o); }
-    if (lane == 0) { s_wtot[wave] = wtotal; s_wlast[wave] = wlast; s_wpop[wave] = pop; s_wfus[wave] = fus; }
+    for (int o = 32; o > 0; o >>= 1) pop += __shfl_xor(pop, o);
+    if (lane == 0) { s_wtot[wave] = wtotal; s_wlast[wave] = wlast; s_wpop[wave] = pop; }
     __syncthreads();
     if (threadIdx.x == 0) {
       const int total = s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
       const int tlast = s_wlast[0] + s_wlast[1] + s_wlast[2] + s_wlast[3];
       const int tpop = s_wpop[0] + s_wpop[1] + s_wpop[2] + s_wpop[3];
-      const int tfus = s_wfus[0] + s_wfus[1] + s_wfus[2] + s_wfus[3];
       s_base = 0;
-      if (total | tlast) {
+      if (total) {
         const unsigned long long add = (unsigned long long)(uint32_t)total | ((unsigned long long)(uint32_t)tlast << 32);
         s_base = (int)(uint32_t)atomicAdd(reinterpret_cast<unsigned long long*>(&counters[counter_id]), add);
-      }
-      if (!all_live && tpop) {
-        atomicAdd(reinterpret_cast<unsigned long long*>(&counters[C_TOTAL_LO]), (unsigned long long)tpop);
-        atomicAdd(reinterpret_cast<unsigned long long*>(&counters[C_FUSED_LO]), (unsigned long long)tfus);
+        if (!all_live) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[C_TOTAL_LO]), (unsigned long long)tpop);
       }
     }
     __syncthreads();
@@ -1353,9 +1296,8 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
     }
     (void)hipStreamWaitEvent(sa, f->ev_fused[sl], 0);
   }
-  if (f->pk.cull_r > 0.0f) (void)hipMemsetAsync(f->tilemax2[sl], 0, (size_t)n * f->pk.tW * f->pk.tH * 4, sa);
   hipLaunchKernelGGL(k_prepass, dim3((npx / 8 + 255) / 256 + 1, n), dim3(256), 0, sa, in, f->depthf2[sl], f->color2[sl], npx, f->p.depth_shift,
-                     f->p.depth_min, f->p.depth_max, f->counters, cc, f->pk, f->ray_kx, f->ray_ky, f->tilemax2[sl]);
+                     f->p.depth_min, f->p.depth_max, f->counters, cc, f->pk, f->ray_kx, f->ray_ky);
   if (sign > 0) {
     // WIN 64 (32 KiB bitmap) has no room for the second bitmap: one frame per workgroup there
     const int gf = f->alloc_win64 ? 1 : std::min(f->alloc_group, n);
@@ -1368,7 +1310,7 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
 #undef LAUNCH_ALLOC
   }
   hipLaunchKernelGGL(k_compactify, dim3(f->compact_grid), dim3(256), 0, sa, f->block_keys, f->block_entry, f->block_flags, f->table, f->compact2[sl],
-                     f->cmask2[sl], f->counters, cc, 0, f->pk, bf, f->tilemax2[sl]);
+                     f->cmask2[sl], f->counters, cc, 0, f->pk, bf);
   if (f->overlap && sa != s) {
     (void)hipEventRecord(f->ev_compact[sl], sa);
     (void)hipStreamWaitEvent(s, f->ev_compact[sl], 0);
@@ -1511,9 +1453,6 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
   k.num_buckets = p->hash_num_buckets; k.bucket_size = p->hash_bucket_size;
   k.total_slots = p->hash_num_buckets * p->hash_bucket_size; k.num_blocks = p->num_sdf_blocks;
   k.slab_axis = -1; k.slab_lo = 0; k.slab_hi = 0; k.slab_thick = 0; k.slab_world = 1; k.slab_rank = 0;
-  k.tW = (k.W + 7) >> 3; k.tH = (k.H + 7) >> 3;
-  f->cull_radius = 3.5f * 1.7320508f * p->voxel_size * 1.01f + 1e-5f;   // voxel centres of a block lie within 3.5 * sqrt(3) voxels of its centre
-  k.cull_r = f->cull_radius;
   k.cW = p->color_width > 0 && p->color_height > 0 ? p->color_width : 0;
   k.cH = k.cW ? p->color_height : 0;
   k.cfx = p->cfx; k.cfy = p->cfy; k.cmx = p->cmx; k.cmy = p->cmy;
@@ -1557,7 +1496,6 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
   for (int q = 0; q < 2; q++) {
     SF_ALLOC(f->depthf2[q], npx * 4 * MAX_BATCH);
     SF_ALLOC(f->color2[q], npx * 4 * MAX_BATCH);
-    SF_ALLOC(f->tilemax2[q], (size_t)f->pk.tW * f->pk.tH * 4 * MAX_BATCH);
     SF_ALLOC(f->compact2[q], (size_t)k.num_blocks * 4);
     SF_ALLOC(f->cmask2[q], (size_t)k.num_blocks * 4);
   }
@@ -1590,7 +1528,7 @@ SF_API void sf_fuser_destroy(sf_fuser* f) {
   if (f->stream) (void)hipStreamSynchronize(f->stream);
   for (auto& e : f->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   (void)hipFree(f->table); (void)hipFree(f->heap); (void)hipFree(f->block_keys); (void)hipFree(f->block_entry); (void)hipFree(f->block_flags); (void)hipFree(f->voxels);
-  for (int q = 0; q < 2; q++) { (void)hipFree(f->depthf2[q]); (void)hipFree(f->color2[q]); (void)hipFree(f->tilemax2[q]); (void)hipFree(f->compact2[q]); (void)hipFree(f->cmask2[q]); }
+  for (int q = 0; q < 2; q++) { (void)hipFree(f->depthf2[q]); (void)hipFree(f->color2[q]); (void)hipFree(f->compact2[q]); (void)hipFree(f->cmask2[q]); }
   (void)hipFree(f->counters); (void)hipFree(f->ray_kx); (void)hipFree(f->ray_ky);
   for (int q = 0; q < 2; q++) { if (f->ev_compact[q]) (void)hipEventDestroy(f->ev_compact[q]); if (f->ev_fused[q]) (void)hipEventDestroy(f->ev_fused[q]); }
   if (f->ev_input) (void)hipEventDestroy(f->ev_input);
@@ -1704,7 +1642,6 @@ SF_API int sf_fuser_tune(sf_fuser* f, const char* key, int value) {
     f->front_cus = value;
   }
   else if (k == "alloc_group" && in(1, MAX_BATCH)) f->alloc_group = value;
-  else if (k == "cull" && in(0, 1)) f->pk.cull_r = value ? f->cull_radius : 0.0f;   // occlusion cull of block-frames in k_compactify (same voxels either way)
   else return sf::fail(SF_ERR_INVALID_ARG, "sf_fuser_tune: unknown key or value out of range: %s = %d", key, value);
   return SF_OK;
 }
@@ -1739,8 +1676,6 @@ SF_API int sf_fuser_stats(sf_fuser* f, sf_stats* out) {
   uint64_t tot;
   std::memcpy(&tot, &c[C_TOTAL_LO], 8);
   out->total_frame_blocks = tot;
-  std::memcpy(&tot, &c[C_FUSED_LO], 8);
-  out->total_frame_blocks_fused = tot;
   out->hash_slots_used = (uint32_t)c[C_SLOTS_USED];
   out->high_water = (uint32_t)c[C_HIGH_WATER];
   return SF_OK;
@@ -1819,7 +1754,7 @@ int sf_compact_live(sf_fuser* f, int32_t* n_out, int include_ghosts) {
   dummy.n = 1;
   SF_HIP_CHECK(hipMemsetAsync(&f->counters[C_EXPORT], 0, 8, f->stream));
   hipLaunchKernelGGL(k_compactify, dim3(f->compact_grid), dim3(256), 0, f->stream, f->block_keys, f->block_entry, f->block_flags, f->table, f->compact,
-                     f->cmask2[0], f->counters, (int)C_EXPORT, include_ghosts ? 1 : 2, f->pk, dummy, f->tilemax2[0]);
+                     f->cmask2[0], f->counters, (int)C_EXPORT, include_ghosts ? 1 : 2, f->pk, dummy);
   SF_HIP_CHECK(hipMemcpyAsync(n_out, &f->counters[C_EXPORT], 4, hipMemcpyDeviceToHost, f->stream));
   SF_HIP_CHECK(sf_quiesce(f));
   return SF_OK;

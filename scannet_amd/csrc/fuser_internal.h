@@ -38,11 +38,6 @@ struct ParamsK {
   // input depth frames at inW x inH resampled (nearest) to W x H by the pre-pass; inW == 0: the frames are W x H already
   int inW, inH;
   float rsx, rsy;   // (inW - 1) / (W - 1), (inH - 1) / (H - 1)
-  // occlusion cull of block-frames (k_compactify): the pre-pass leaves max(d + trunc(d)) over every 8 x 8 pixel tile; a block whose
-  // nearest voxel lies behind that for every tile its projection can touch updates nothing in that frame.  cull_r = radius of the
-  // block's voxel centres (with margin); <= 0 switches the test off
-  int tW, tH;
-  float cull_r;
 };
 
 __host__ __device__ inline bool slab_owns_coord(const ParamsK& P, int c) {
@@ -106,7 +101,6 @@ enum Counter {
   C_COMPACT_B = 18,  // second batch slot (batches alternate between two sets of per-batch buffers)
   C_EXPORT = 20,
   C_TOTAL_LO = 32,   // 64-bit sum of N_blk over all frames lives in counters[32..33] (own cache line)
-  C_FUSED_LO = 40,   // 64-bit sum of the block-frames that reach the integrate kernel (N_blk minus the occluded ones), own cache line
   C_COUNT = 48
 };
 
@@ -180,7 +174,6 @@ struct sf_fuser {
   bool overlap = true;  // sf_fuser_tune("overlap", 0) runs everything on one stream
   float* depthf2[2] = {nullptr, nullptr};      // MAX_BATCH x W*H per batch slot
   uint32_t* color2[2] = {nullptr, nullptr};    // MAX_BATCH x W*H per batch slot
-  uint32_t* tilemax2[2] = {nullptr, nullptr};  // MAX_BATCH x tW*tH per batch slot: bit pattern of max(d + trunc(d)) over the tile's valid pixels
   int32_t* compact2[2] = {nullptr, nullptr};   // heap slots of the blocks some frame of the batch sees
   uint32_t* cmask2[2] = {nullptr, nullptr};    // per compact entry: bit j = frame j of the batch updates this block
   int32_t* block_entry = nullptr;              // directory: table index of the entry of the block in heap slot i
@@ -207,7 +200,6 @@ struct sf_fuser {
   int nt_mode = -1;     // k_integrate_pipe tile traffic non-temporal: -1 = when the previous pass's tiles exceed 512 MiB, 0 never, 1 always (tune "nt")
   bool pipe_beside = false;  // the latched decision for the next pass (see sf_single_stream_batch)
   int pipe_overlap = -1;  // the next frame's pre-pass / allocation / compaction on the front stream beside k_integrate_pipe: -1 = when the previous pass's tiles exceed 512 MiB, 0 never, 1 always (tune "pipe_overlap")
-  float cull_radius = 0.0f;   // ParamsK::cull_r when the occlusion cull is on (tune "cull")
   int alloc_group = 4;  // consecutive frames of a batch one k_alloc workgroup walks (tune "alloc_group")
   int compact_grid = 1024;  // 1024 directory entries per workgroup, grid-stride beyond
   uint64_t frames_integrated = 0, frames_skipped = 0;

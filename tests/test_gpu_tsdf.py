@@ -536,22 +536,13 @@ def test_four_schedules_one_volume_at_full_size():
         poses = np.zeros((N, 16), np.float32)
         _abi.check(L.sf_synth_room_device(dptr, W * H * 2, 0, N, 5578, W, H, 1, poses.ctypes.data_as(C.c_void_p)))
         params = fusion.default_params()
-        digests, fused = [], {}
-        for switches in ({"batch": 1}, {"batch": 1, "pipe": 0}, {"batch": 1, "overlap": 0}, {}, {"cull": 0}, {"batch": 1, "cull": 0}):
+        digests = []
+        for switches in ({"batch": 1}, {"batch": 1, "pipe": 0}, {"batch": 1, "overlap": 0}, {}):
             with fusion.Fuser(params, **switches) as f:
                 f.integrate_batch_device(dptr.value, W * H * 2, poses)
                 f.sync()
                 c, v = f.export_blocks()
                 digests.append((len(c), hashlib.sha256(c.tobytes() + v.tobytes()).hexdigest()))
-                st = f.stats()
-                fused[tuple(sorted(switches.items()))] = (st["total_frame_blocks"], st["total_frame_blocks_fused"])
         assert digests[0][0] > 50000 and len(set(digests)) == 1, digests
-        # the occlusion cull (block-frames wholly behind what the frame sees) changes how many block-frames reach the integrate kernel, never
-        # the volume; N_blk -- allocated and in the frustum -- is the same number under every schedule
-        assert len({t for t, _ in fused.values()}) == 1, fused
-        total, kept = fused[()]
-        assert fused[(("cull", 0),)] == (total, total) and fused[(("batch", 1), ("cull", 0))] == (total, total)
-        assert 0.5 * total < kept < 0.97 * total and fused[(("batch", 1),)][1] == kept, fused
-        print("block-frames in frustum %d, fused %d (%.1f %% dropped as occluded)" % (total, kept, 100.0 * (total - kept) / total))
     finally:
         L.sf_device_free(dptr)
