@@ -12,9 +12,11 @@
 //                 from pinching the surface, nothing does here
 //              3. candidates = the edges at or below the priority the sequential filter would reach for the collapses still needed
 //                 (a quantile of this round's priorities), so no edge is taken that the global order would have left alone
-//              4. a candidate WINS when its key (priority, edge id) is the minimum over every vertex of the closed 1-rings of both its
-//                 end points (64-bit atomicMin into a lock word per vertex): winners touch disjoint sets of faces and do not change each
-//                 other's priorities, so they are collapsed together; the last round takes the winners in key order up to the face budget
+//              4. every candidate writes its key (priority, scrambled edge id) over the closed 1-rings of both its end points (64-bit
+//                 atomicMin into a lock word per vertex) and WINS when it still holds the minimum at its own end points: winners touch
+//                 disjoint sets of faces and do not change what each other's priority, placement and link test read, so they are
+//                 collapsed together; three such passes per round, the later ones among the candidates the earlier winners left
+//                 untouched; the last round takes the winners in key order up to the face budget
 //              5. collapse: the faces holding both vertices die, v0's other faces are re-pointed to v1, v1 moves to x and takes the
 //                 summed quadric (and keeps its own colour, as VCG does)
 //   then the shared end of the filter (simplify_finish: AutoClean, compaction).
@@ -251,29 +253,38 @@ __device__ inline unsigned long long lock_key(float p, uint32_t e, uint32_t salt
   h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;   // invertible steps: distinct edges keep distinct keys
   return ((unsigned long long)__float_as_uint(p) << 32) | h;
 }
-__global__ void k_lock(Mesh M, const uint64_t* __restrict__ ukey, uint32_t E, const float* __restrict__ pri, float tau, uint32_t salt, unsigned long long* lock) {
+// Two collapses e = (a, b) and w = (v0, v1) are independent iff neither has an end point inside the closed 1-rings of the other's end points
+// (the relation is symmetric: a in ring(v0) <=> v0 in ring(a)): they then touch disjoint faces, and nothing either one's priority, placement
+// or link test read is changed by the other.  Every candidate writes its key over its closed rings; it WINS iff it still holds the minimum
+// at its own two end points -- any conflicting edge has one of them in its rings and a smaller key would show there.  `taken` marks the
+// closed rings of the winners of earlier passes of the same round: an edge with a marked end point conflicts with one of them and sits
+// the round out, the others are unaffected by what those winners will do and may compete again (more collapses per rebuild of the
+// adjacency, which is what a round costs).
+__global__ void k_lock(Mesh M, const uint64_t* __restrict__ ukey, uint32_t E, const float* __restrict__ pri, float tau, uint32_t salt, const uint8_t* __restrict__ taken,
+                       unsigned long long* lock) {
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
   const float p = pri[e];
   if (!(p <= tau)) return;
+  const uint32_t v0 = (uint32_t)(ukey[e] >> 32), v1 = (uint32_t)ukey[e];
+  if (taken[v0] | taken[v1]) return;
   const unsigned long long key = lock_key(p, e, salt);
-  for_closed_rings(M, (uint32_t)(ukey[e] >> 32), (uint32_t)ukey[e], [&](uint32_t u) { atomicMin(&lock[u], key); });
+  for_closed_rings(M, v0, v1, [&](uint32_t u) { atomicMin(&lock[u], key); });
 }
 // counters: [0] winners, [1] faces their collapses remove (2 per interior edge, 1 per border edge), [2] bit pattern of the largest priority
 __global__ void k_winners(Mesh M, const uint64_t* __restrict__ ukey, const uint32_t* __restrict__ ucnt, uint32_t E, const float* __restrict__ pri, float tau, uint32_t salt,
-                          const unsigned long long* __restrict__ lock, unsigned long long* win, uint32_t* counters) {
+                          const unsigned long long* __restrict__ lock, uint8_t* taken_next, unsigned long long* win, uint32_t* counters) {
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
   const float p = pri[e];
   if (!(p <= tau)) return;
+  const uint32_t v0 = (uint32_t)(ukey[e] >> 32), v1 = (uint32_t)ukey[e];
   const unsigned long long key = lock_key(p, e, salt);
-  bool mine = true;
-  for_closed_rings(M, (uint32_t)(ukey[e] >> 32), (uint32_t)ukey[e], [&](uint32_t u) { mine = mine && lock[u] == key; });
-  if (mine) {
-    win[atomicAdd(&counters[0], 1u)] = ((unsigned long long)__float_as_uint(p) << 32) | e;
-    atomicAdd(&counters[1], ucnt[e]);
-    atomicMax(&counters[2], __float_as_uint(p));
-  }
+  if (lock[v0] != key || lock[v1] != key) return;   // only candidates that were still free wrote keys: no need to look at `taken` again
+  win[atomicAdd(&counters[0], 1u)] = ((unsigned long long)__float_as_uint(p) << 32) | e;
+  atomicAdd(&counters[1], ucnt[e]);
+  atomicMax(&counters[2], __float_as_uint(p));
+  for_closed_rings(M, v0, v1, [&](uint32_t u) { taken_next[u] = 1; });
 }
 
 // ---- 5. collapse ------------------------------------------------------------------------------------------------------------------------------
@@ -352,13 +363,13 @@ SF_API int sf_mesh_simplify_gpu(const sf_mesh* in, const sf_simplify_params* p, 
     hipStream_t s = sg.s;
     const size_t NC0 = 3 * (size_t)F;
     DevBuf d_pos, d_tri, d_alive, d_vdel, d_Q, d_vbeg, d_vcnt, d_ckey, d_cval, d_ckey2, d_cval2, d_ekey, d_ekey2, d_ukey, d_ucnt, d_nruns, d_pri, d_pri2, d_pri3, d_x, d_lock,
-        d_win, d_win2, d_nwin, d_tmp;
+        d_win, d_win2, d_nwin, d_taken, d_tmp;
     DEC_CHECK(d_pos.alloc((size_t)V * 12)); DEC_CHECK(d_tri.alloc(NC0 * 4)); DEC_CHECK(d_alive.alloc(F)); DEC_CHECK(d_vdel.alloc(V));
     DEC_CHECK(d_Q.alloc((size_t)V * sizeof(Quadric))); DEC_CHECK(d_vbeg.alloc((size_t)V * 4)); DEC_CHECK(d_vcnt.alloc((size_t)V * 4));
     DEC_CHECK(d_ckey.alloc(NC0 * 4)); DEC_CHECK(d_cval.alloc(NC0 * 4)); DEC_CHECK(d_ckey2.alloc(NC0 * 4)); DEC_CHECK(d_cval2.alloc(NC0 * 4));
     DEC_CHECK(d_ekey.alloc(NC0 * 8)); DEC_CHECK(d_ekey2.alloc(NC0 * 8)); DEC_CHECK(d_ukey.alloc(NC0 * 8)); DEC_CHECK(d_ucnt.alloc(NC0 * 4)); DEC_CHECK(d_nruns.alloc(8));
     DEC_CHECK(d_pri.alloc(NC0 * 4)); DEC_CHECK(d_pri2.alloc(NC0 * 4)); DEC_CHECK(d_pri3.alloc(NC0 * 4)); DEC_CHECK(d_x.alloc(NC0 * 12)); DEC_CHECK(d_lock.alloc((size_t)V * 8));
-    DEC_CHECK(d_win.alloc(NC0 * 8)); DEC_CHECK(d_win2.alloc(NC0 * 8)); DEC_CHECK(d_nwin.alloc(16));
+    DEC_CHECK(d_win.alloc(NC0 * 8)); DEC_CHECK(d_win2.alloc(NC0 * 8)); DEC_CHECK(d_nwin.alloc(16)); DEC_CHECK(d_taken.alloc(V));
     DEC_CHECK(hipMemcpyAsync(d_pos.p, pos.data(), (size_t)V * 12, hipMemcpyHostToDevice, s));
     DEC_CHECK(hipMemcpyAsync(d_tri.p, tri.data(), NC0 * 4, hipMemcpyHostToDevice, s));
     DEC_CHECK(hipMemcpyAsync(d_alive.p, alive_h.data(), F, hipMemcpyHostToDevice, s));
@@ -384,6 +395,7 @@ SF_API int sf_mesh_simplify_gpu(const sf_mesh* in, const sf_simplify_params* p, 
     uint32_t Fc = F;   // faces in the device arrays: dead ones are squeezed out (in order) when a quarter has gone, the sorts shrink with the mesh
     bool first = true;
     int stalled = 0;
+    constexpr int PASSES = 3;
     std::vector<unsigned long long> win_h;
     std::vector<uint32_t> ucnt_h;
     while (nalive > target) {
@@ -443,13 +455,16 @@ SF_API int sf_mesh_simplify_gpu(const sf_mesh* in, const sf_simplify_params* p, 
         DEC_CHECK(hipStreamSynchronize(s));
       }
       if (!(tau < 3.0e38f)) tau = 3.0e38f;   // never an edge the link test rejected (infinite priority)
-      // 4. winners
-      const uint32_t salt = (uint32_t)st.rounds * 0x9E3779B9u;
-      hipLaunchKernelGGL(k_iota64, dim3(gV), dim3(256), 0, s, d_lock.as<unsigned long long>(), ~0ull, V);
-      hipLaunchKernelGGL(k_lock, dim3(gE), dim3(256), 0, s, M, d_ukey.as<uint64_t>(), E, d_pri.as<float>(), tau, salt, d_lock.as<unsigned long long>());
+      // 4. winners: up to PASSES independent sets per round, each among the candidates the earlier ones left untouched
       DEC_CHECK(hipMemsetAsync(d_nwin.p, 0, 16, s));
-      hipLaunchKernelGGL(k_winners, dim3(gE), dim3(256), 0, s, M, d_ukey.as<uint64_t>(), d_ucnt.as<uint32_t>(), E, d_pri.as<float>(), tau, salt,
-                         d_lock.as<unsigned long long>(), d_win.as<unsigned long long>(), d_nwin.as<uint32_t>());
+      DEC_CHECK(hipMemsetAsync(d_taken.p, 0, V, s));
+      for (int pass = 0; pass < PASSES; pass++) {
+        const uint32_t salt = ((uint32_t)st.rounds * PASSES + (uint32_t)pass) * 0x9E3779B9u;
+        hipLaunchKernelGGL(k_iota64, dim3(gV), dim3(256), 0, s, d_lock.as<unsigned long long>(), ~0ull, V);
+        hipLaunchKernelGGL(k_lock, dim3(gE), dim3(256), 0, s, M, d_ukey.as<uint64_t>(), E, d_pri.as<float>(), tau, salt, d_taken.as<uint8_t>(), d_lock.as<unsigned long long>());
+        hipLaunchKernelGGL(k_winners, dim3(gE), dim3(256), 0, s, M, d_ukey.as<uint64_t>(), d_ucnt.as<uint32_t>(), E, d_pri.as<float>(), tau, salt,
+                           d_lock.as<unsigned long long>(), d_taken.as<uint8_t>(), d_win.as<unsigned long long>(), d_nwin.as<uint32_t>());
+      }
       uint32_t cnt[4] = {0, 0, 0, 0};
       DEC_CHECK(hipMemcpyAsync(cnt, d_nwin.p, 16, hipMemcpyDeviceToHost, s));
       DEC_CHECK(hipStreamSynchronize(s));
