@@ -81,6 +81,8 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   const int B = f->batch;  // frames fused per pass over the voxel tiles
   const uint64_t nbatches = (total + (uint64_t)B - 1) / (uint64_t)B;
   // enough batch slots for every decode thread to be busy while two batches sit between copy and pre-pass
+  // 3 slots (one decoding, one in flight, one being read by the pre-pass) are enough: 4, 6 and 10 measured no faster (tools/gpu/h2d_bw.hip:
+  // the link moves 57 GB/s from pinned memory on two streams; a colour run is bound by the fusion kernels and ~15 ms of set-up)
   const int NB = (int)std::max<uint64_t>(1, std::min<uint64_t>(std::max<uint64_t>(3, ((uint64_t)nthreads + B - 1) / B + 2), std::max<uint64_t>(nbatches, 1)));
   std::vector<BatchSlot> ring((size_t)NB);
   hipStream_t copy_stream = nullptr, copy_stream2 = nullptr;   // two streams = two SDMA engines: one alone moves ~20 GB/s
@@ -149,6 +151,7 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
     RUN_CHECK(hipEventCreateWithFlags(&sl.consumed, hipEventDisableTiming));
   }
 
+  const double t_setup_end = timing ? now_s() : 0;
   std::atomic<uint64_t> next{0}, landed{0}, issued{0};  // frame counter of the pool; batches whose copies completed / were queued
   std::atomic<bool> abort{false};
   std::atomic<uint64_t> decode_ns{0};
@@ -321,8 +324,10 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   reaper.join();
   const hipError_t qe = sf_quiesce(f);
   if (timing)
-    std::fprintf(stderr, "sf_fuse_run: setup+loop %.3f s (wait for decoded batches %.3f, copy enqueue %.3f, kernels enqueue %.3f), join+drain %.3f s, %d batch slots x %d frames\n",
-                 t_loop_end - std::chrono::duration<double>(t_start.time_since_epoch()).count(), t_wait_ready, t_api, t_flush, now_s() - t_loop_end, NB, B);
+    std::fprintf(stderr, "sf_fuse_run: setup %.3f s (streams, %.0f MB pinned, %.0f MB device), loop %.3f s (wait for decoded batches %.3f, copy enqueue %.3f, kernels enqueue %.3f), "
+                         "join+drain %.3f s, %d batch slots x %d frames\n",
+                 t_setup_end - std::chrono::duration<double>(t_start.time_since_epoch()).count(), (double)NB * slot_b / 1e6, (double)NB * dslot_b / 1e6, t_loop_end - t_setup_end,
+                 t_wait_ready, t_api, t_flush, now_s() - t_loop_end, NB, B);
   (void)hipStreamSynchronize(copy_stream);
   (void)hipStreamSynchronize(copy_stream2);
   cleanup();
