@@ -371,8 +371,7 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
                 rc = {"bound": "valu", "frames_per_s": round(kc / mc["elapsed"], 1), "ms_per_frame": round(mc["elapsed"] * 1e3 / kc, 5),
                       "kernel": "k_integrate<1,true,true,2>", "alg_equiv_GBs": round(mc["alg_bytes"] / mc["launches"] / t_s / 1e9, 1),
                       "note": "16 frames per launch with a colour gather and blend per voxel on top of the geometry update; VALU-issue bound like the geometry kernel "
-                              "(frac: see roofline.frac; no separate counter pass is run for it).  End to end from a .sens the colour path is PCIe-bound "
-                              "(1.5 MB per frame: profiles/)"}
+                              "(frac: see roofline.frac; no separate counter pass is run for it).  End to end from a .sens (tools/e2e_bench.py --color raw) the same path runs at 17-19 k frames/s"}
                 rc.update(per_launch(mc, kc))
                 out["roofline_colour"] = rc
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
