@@ -227,9 +227,9 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
             colour_frames[0] = out
         return colour_frames[0]
 
-    def run(n_warm, n_timed, profile, single_frame=False, colour=False):
+    def run(n_warm, n_timed, profile, single_frame=False, colour=False, extra_tune=None):
         """Fuse frames [0, n_warm) untimed, then frames [n_warm, n_warm + n_timed) between two barrier+synchronize pairs."""
-        fuser = fusion.Fuser(params, device=local_rank, **dict(TUNE, **({"batch": 1} if single_frame else {})))
+        fuser = fusion.Fuser(params, device=local_rank, **dict(dict(TUNE, **({"batch": 1} if single_frame else {})), **(extra_tune or {})))
         rgb = colour_tensor(n_warm + n_timed) if colour else None
         cstride = W * H * 3
 
@@ -361,6 +361,15 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
                     if t is not None:
                         r1["traffic"] = t["bytes"]
                         r1["traffic_detail"] = t
+                if "pipe_overlap" not in TUNE:
+                    # the kernel with the GPU to itself (the next frame's pre-pass / allocation / compaction serialised behind it): what the
+                    # KERNEL reaches; the schedule above is the one the fuser picks because it gives more frames/s when the tile set is large
+                    ma = run(Wm, min(ks, 400), True, single_frame=True, extra_tune={"pipe_overlap": 0})
+                    if ma["launches"]:
+                        ach = ma["alg_bytes"] / (ma["kernel_ms"] * 1e-3) / 1e9
+                        r1["kernel_alone"] = {"tune": "pipe_overlap=0", "avg_kernel_us": round(ma["kernel_ms"] * 1e3 / ma["launches"], 2), "achieved": round(ach, 1),
+                                              "frac": round(ach / HBM_PEAK_GBS, 4), "frames_per_s": round(min(ks, 400) / ma["elapsed"], 1),
+                                              "frac_of_ceiling": round(ach / m1["ceiling"]["rmw_copy_GBs"], 4) if m1["ceiling"] else None}
                 out["roofline_single_frame"] = r1
         if world == 1 and not args.no_profile and not args.single_frame and not args.no_colour and cfg_name == "4mm" and K > 1:
             # the colour variant of the same pass (a colour frame per depth frame, resident in HBM): k_integrate<1, true, ...>
@@ -420,16 +429,17 @@ def run_scans(args, rank, local_rank, world, dist, torch):
         res = {"scan": args.first_scan + i, "frames": specs[i][1], "faces": nf}
         if args.host_stage != "none":
             ta = time.perf_counter()
-            cleaned, _ = meshclean.clean(mesh, meshclean.CLEAN_MLX_MERGE_DISTANCE, 7500)
+            gpu_filters = local_rank if args.host_stage == "gpu" else None
+            cleaned, _ = meshclean.clean(mesh, meshclean.CLEAN_MLX_MERGE_DISTANCE, 7500, gpu=gpu_filters)
             res["clean_s"] = time.perf_counter() - ta
             cur = cleaned
             res["decimate_s"] = res["clean_lores_s"] = 0.0
-            if args.host_stage in ("full", "gpu-decimate"):
+            if args.host_stage in ("full", "gpu-decimate", "gpu"):
                 for _ in range(2):
                     ta = time.perf_counter()
-                    simp, sst = meshclean.simplify(cur, gpu=local_rank if args.host_stage == "gpu-decimate" else None)
+                    simp, sst = meshclean.simplify(cur, gpu=local_rank if args.host_stage in ("gpu-decimate", "gpu") else None)
                     tb = time.perf_counter()
-                    cur, _ = meshclean.clean(simp, meshclean.CLEAN_MLX_MERGE_DISTANCE, meshclean.CLEAN_LORES_MIN_COMPONENT)
+                    cur, _ = meshclean.clean(simp, meshclean.CLEAN_MLX_MERGE_DISTANCE, meshclean.CLEAN_LORES_MIN_COMPONENT, gpu=gpu_filters)
                     res["decimate_s"] += tb - ta
                     res["clean_lores_s"] += time.perf_counter() - tb
                     res["decimate_rounds"] = res.get("decimate_rounds", 0) + sst["rounds"]
@@ -480,6 +490,8 @@ def run_scans(args, rank, local_rank, world, dist, torch):
                    "host_stage": {"full": "clean.mlx + quadric collapse to 20 %% twice + cleanLoRes + Segmentator per scan on a pool of %d host threads per rank" % workers,
                                   "gpu-decimate": "clean.mlx + quadric collapse to 20 %% twice ON THE GPU (rounds of independent collapses) + cleanLoRes + Segmentator, "
                                                   "driven by a pool of %d host threads per rank" % workers,
+                                  "gpu": "clean.mlx, quadric collapse to 20 %% twice and cleanLoRes ALL ON THE GPU (sf_mesh_clean_gpu, sf_mesh_simplify_gpu) + Segmentator, "
+                                         "driven by a pool of %d host threads per rank" % workers,
                                   "clean": "clean.mlx + Segmentator per scan on a pool of %d host threads per rank" % workers, "none": "none (fusion + marching cubes only)"}[args.host_stage],
                    "frames_total": int(frames_sum)},
         "gpu_busy_s_sum": round(busy_sum, 3), "gpu_idle_pct": round(100.0 * (1.0 - busy_sum / (elapsed * world)), 1),
@@ -584,7 +596,7 @@ def main():
     ap.add_argument("--no-single-frame", action="store_true", help="skip the secondary one-frame-per-launch roofline pass")
     ap.add_argument("--no-colour", action="store_true", help="skip the secondary colour-fusion pass")
     ap.add_argument("--teardown", action="store_true", help="leave through the interpreter's normal teardown (set for the runs under rocprofv3)")
-    ap.add_argument("--host-stage", choices=["full", "gpu-decimate", "clean", "none"], default="full",
+    ap.add_argument("--host-stage", choices=["full", "gpu-decimate", "gpu", "clean", "none"], default="full",
                     help="--config scans: what follows marching cubes -- full: clean + sequential quadric collapse x 2 + segment on host threads; gpu-decimate: the "
                          "same chain with the collapse on the GPU (sf_mesh_simplify_gpu); clean: clean + segment; none: nothing")
     ap.add_argument("--first-scan", type=int, default=0)

@@ -449,6 +449,7 @@ typedef struct sf_simplify_stats {
 } sf_simplify_stats;
 void sf_simplify_default_params(sf_simplify_params* p);   /* the values simplify.mlx ships */
 int sf_mesh_simplify(const sf_mesh* in, const sf_simplify_params* p, sf_mesh** out, sf_simplify_stats* stats /*nullable*/);
+
 /* The same filter on HIP device `device` as rounds of independent collapses (scannet_amd/csrc/simplify_gpu.hip): same quadrics, placement,
  * priority and stop rule, a different order -- different triangles with the same guarantees (face budget, flat stays flat, closed stays
  * closed, deterministic) in a fraction of the time: the sequential filter is 22 s of a scan's 24 s of host time.  Opt-in; SF_ERR_DEVICE
@@ -463,9 +464,14 @@ typedef struct sf_clean_script {   /* what a .mlx FilterScript asks for */
   sf_simplify_params simplify_params;
   sf_simplify_stats simplify_stats;  /* filled by sf_mesh_clean_script when simplify != 0 */
   int32_t simplify_device;           /* -1 (what sf_mlx_load sets): the sequential host filter; >= 0: sf_mesh_simplify_gpu on that device */
+  int32_t clean_device;              /* -1 (what sf_mlx_load sets): the host cleaning filters; >= 0: sf_mesh_clean_gpu on that device (same output) */
 } sf_clean_script;
 
 int sf_mesh_clean(const sf_mesh* in, float merge_distance, uint32_t min_component_faces, sf_mesh** out, sf_clean_stats* stats /*nullable*/);
+/* The same four filters on HIP device `device` (scannet_amd/csrc/clean_gpu.hip): identical arrays and statistics -- the greedy clustering
+ * resolved in rounds down the index order, duplicate faces and connected components by radix sorts and a lock-free union-find --, a
+ * few tens of milliseconds for a scan-sized mesh instead of 1.7 s of one host thread.  Opt-in; SF_ERR_DEVICE without a GPU. */
+int sf_mesh_clean_gpu(const sf_mesh* in, float merge_distance, uint32_t min_component_faces, int device, sf_mesh** out, sf_clean_stats* stats /*nullable*/);
 int sf_mlx_load(const char* mlx_path, sf_clean_script* out);
 int sf_mesh_clean_script(const sf_mesh* in, sf_clean_script* script, sf_mesh** out, sf_clean_stats* stats /*nullable*/);
 

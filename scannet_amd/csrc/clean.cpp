@@ -21,8 +21,8 @@
 //      MinComponentSize faces are deleted.
 //   4. tri::Clean::RemoveUnreferencedVertex, then compaction in index order (what the PLY exporter writes).
 // The clustering sweep (greedy in index order) and the component labelling are sequential / pointer-chasing work:
-// ~0.5 s on the host for a 3.4 M face mesh (SF_CLEAN_TIMING=1 prints the split); there is no bandwidth-bound kernel here
-// to move to the GPU.
+// ~0.5 s on the host for a 3.4 M face mesh, 1.7 s for 7.9 M (SF_CLEAN_TIMING=1 prints the split).  clean_gpu.hip holds the same filters
+// as sorts, a round-by-round resolution of the greedy clustering and a lock-free union-find (sf_mesh_clean_gpu: identical output).
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -329,6 +329,7 @@ SF_API int sf_mlx_load(const char* path, sf_clean_script* out) {
   if (text.find("<FilterScript") == std::string::npos) return sf::fail(SF_ERR_FORMAT, "%s is not a MeshLab FilterScript", path);
   std::memset(out, 0, sizeof(*out));
   out->simplify_device = -1;   // the sequential host filter unless the caller opts into the GPU one
+  out->clean_device = -1;      // likewise the cleaning filters
   int stage = 0;  // the four filters must come in the shipped order; each may appear at most once
   size_t p = 0;
   std::string current;
@@ -404,6 +405,7 @@ SF_API int sf_mesh_clean_script(const sf_mesh* in, sf_clean_script* s, sf_mesh**
   if (!s->remove_duplicate_faces || !s->remove_unreferenced)
     rc = sf::fail(SF_ERR_UNSUPPORTED, "scripts without \"Remove Duplicate Faces\" / \"Remove Unreferenced Vertex\" are not supported");
   else if (dist < 0.0f) rc = sf::fail(SF_ERR_UNSUPPORTED, "scripts without \"Merge Close Vertices\" are not supported");
+  else if (s->clean_device >= 0) rc = sf_mesh_clean_gpu(in, dist, s->remove_small_components ? s->min_component_faces : 0u, s->clean_device, out, stats);
   else rc = sf_mesh_clean(in, dist, s->remove_small_components ? s->min_component_faces : 0u, out, stats);
   if (simplified) sf_mesh_free(simplified);
   return rc;

@@ -36,6 +36,7 @@ int main(int argc, const char** argv) {
   sf_clean_script sc;
   if (sf_mlx_load(script, &sc) != SF_OK) return die("filter script");
   sc.simplify_device = gpu;
+  sc.clean_device = gpu;
   sf_mesh* m = nullptr;
   if (sf_ply_read(in, &m) != SF_OK) return die("input mesh");
   uint64_t nv = 0, nf = 0;

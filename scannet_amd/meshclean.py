@@ -33,7 +33,7 @@ class SfSimplifyStats(C.Structure):
 class SfCleanScript(C.Structure):
     _fields_ = [("merge_close_vertices", C.c_int32), ("remove_duplicate_faces", C.c_int32), ("remove_small_components", C.c_int32),
                 ("remove_unreferenced", C.c_int32), ("merge_distance", C.c_float), ("min_component_faces", C.c_uint32),
-                ("simplify", C.c_int32), ("simplify_params", SfSimplifyParams), ("simplify_stats", SfSimplifyStats), ("simplify_device", C.c_int32)]
+                ("simplify", C.c_int32), ("simplify_params", SfSimplifyParams), ("simplify_stats", SfSimplifyStats), ("simplify_device", C.c_int32), ("clean_device", C.c_int32)]
 
 
 def _lib():
@@ -68,10 +68,16 @@ def simplify(mesh, gpu=None, **overrides):
     return Mesh(h), {n: getattr(st, n) for n, _ in SfSimplifyStats._fields_}
 
 
-def clean(mesh, merge_distance=CLEAN_MLX_MERGE_DISTANCE, min_component_faces=CLEAN_MLX_MIN_COMPONENT):
-    """The four clean.mlx filters on a Mesh; returns (Mesh, stats dict)."""
+def clean(mesh, merge_distance=CLEAN_MLX_MERGE_DISTANCE, min_component_faces=CLEAN_MLX_MIN_COMPONENT, gpu=None):
+    """The four clean.mlx filters on a Mesh; returns (Mesh, stats dict).  gpu=<device>: the same filters on that GPU (sf_mesh_clean_gpu),
+    identical arrays and statistics."""
     h, st = C.c_void_p(), SfCleanStats()
-    check(_lib().sf_mesh_clean(mesh._h, float(merge_distance), int(min_component_faces), C.byref(h), C.byref(st)))
+    if gpu is None:
+        check(_lib().sf_mesh_clean(mesh._h, float(merge_distance), int(min_component_faces), C.byref(h), C.byref(st)))
+    else:
+        L = _lib()
+        L.sf_mesh_clean_gpu.argtypes = [C.c_void_p, C.c_float, C.c_uint32, C.c_int, C.POINTER(C.c_void_p), C.POINTER(SfCleanStats)]
+        check(L.sf_mesh_clean_gpu(mesh._h, float(merge_distance), int(min_component_faces), int(gpu), C.byref(h), C.byref(st)))
     return Mesh(h), {n: getattr(st, n) for n, _ in SfCleanStats._fields_}
 
 

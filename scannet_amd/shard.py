@@ -89,7 +89,7 @@ def fuse_scan(sens_path, device=0, params_file=None):
     return mesh, {"scan": sens_path, "frames": rs["frames_integrated"], "gpu_seconds": time.perf_counter() - t0}
 
 
-def finish_scan(mesh, sens_path, clean_min_faces=7500, kthresh=0.01, seg_min_verts=20, gpu_decimate=None):
+def finish_scan(mesh, sens_path, clean_min_faces=7500, kthresh=0.01, seg_min_verts=20, gpu_decimate=None, gpu_clean=None):
     """The host part (Server/scan_processor.py:141-156): <id>_vh.ply, clean.mlx -> <id>_vh_clean.ply, simplify.mlx twice (each
     followed by cleanLoRes) -> <id>_vh_clean_2.ply, Segmentator -> <id>_vh_clean_2.0.010000.segs.json.  One thread, tens of seconds
     for a scan-sized mesh (the quadric collapse is sequential): run several of these side by side."""
@@ -97,12 +97,12 @@ def finish_scan(mesh, sens_path, clean_min_faces=7500, kthresh=0.01, seg_min_ver
     base = os.path.splitext(sens_path)[0]
     t0 = time.perf_counter()
     mesh.write_ply(base + "_vh.ply")
-    cleaned, cst = meshclean.clean(mesh, meshclean.CLEAN_MLX_MERGE_DISTANCE, clean_min_faces)
+    cleaned, cst = meshclean.clean(mesh, meshclean.CLEAN_MLX_MERGE_DISTANCE, clean_min_faces, gpu=gpu_clean)   # gpu_clean = a device index: sf_mesh_clean_gpu, same output
     cleaned.write_ply(base + "_vh_clean.ply")
     cur = cleaned
     for _ in range(2):
         simp, _ = meshclean.simplify(cur, gpu=gpu_decimate)   # gpu_decimate = a device index: sf_mesh_simplify_gpu instead of the sequential filter
-        cur, _ = meshclean.clean(simp, meshclean.CLEAN_MLX_MERGE_DISTANCE, meshclean.CLEAN_LORES_MIN_COMPONENT)
+        cur, _ = meshclean.clean(simp, meshclean.CLEAN_MLX_MERGE_DISTANCE, meshclean.CLEAN_LORES_MIN_COMPONENT, gpu=gpu_clean)
     cur.write_ply(base + "_vh_clean_2.ply")
     nseg = segmentator.segment_to_json(base + "_vh_clean_2.ply", kthresh, seg_min_verts)
     return {"faces": cst["faces_out"], "faces_decimated": cur.counts()[1], "segments": nseg, "host_seconds": time.perf_counter() - t0}

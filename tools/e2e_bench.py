@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--color", choices=["none", "raw", "jpeg"], default="none", help="store a synthetic 640x480 colour frame per depth frame")
     ap.add_argument("--gpu-decimate", action="store_true", help="the decimate stage on the GPU (sf_mesh_simplify_gpu) instead of the sequential filter")
+    ap.add_argument("--gpu-clean", action="store_true", help="the cleaning filters on the GPU (sf_mesh_clean_gpu: same output) instead of the host filters")
     ap.add_argument("--fuse-only", action="store_true", help="stop after the fusion stage")
     ap.add_argument("--color-res", default="", help="WxH of the colour frames when it differs from the depth size (ScanNet: 1296x968)")
     a = ap.parse_args()
@@ -104,7 +105,8 @@ def main():
     mesh.write_ply(ply)
     res["ply_write_s"] = round(time.perf_counter() - t0, 3)
     t0 = time.perf_counter()
-    cleaned, cst = meshclean.clean(mesh)
+    cleaned, cst = meshclean.clean(mesh, gpu=0 if a.gpu_clean else None)
+    res["clean_where"] = "gpu" if a.gpu_clean else "host"
     res["clean_s"] = round(time.perf_counter() - t0, 3)
     res["clean"] = {k: cst[k] for k in ("vertices_out", "faces_out", "components_in", "components_removed")}
     cply = os.path.join(a.dir, "scene_e2e_vh_clean.ply")
@@ -115,7 +117,7 @@ def main():
         t0 = time.perf_counter()
         simp, sst = meshclean.simplify(cur, gpu=0 if a.gpu_decimate else None)
         t1 = time.perf_counter()
-        cur, _ = meshclean.clean(simp, min_component_faces=1000)
+        cur, _ = meshclean.clean(simp, min_component_faces=1000, gpu=0 if a.gpu_clean else None)
         res["decimate%d_s" % k] = round(time.perf_counter() - t0, 3)
         res["decimate%d" % k] = {"faces_in": sst["faces_in"], "faces_out": cur.counts()[1], "collapses": sst["collapses"], "rounds": sst["rounds"],
                                  "collapse_s": round(t1 - t0, 3), "where": "gpu" if a.gpu_decimate else "host"}
