@@ -24,21 +24,15 @@
 #include <rocprim/rocprim.hpp>
 
 #include "common.h"
+#include "hip_util.h"
 #include "mesh.h"
 #include "scanfuse.h"
 
 namespace {
 
-struct DevBuf {
-  void* p = nullptr;
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  hipError_t alloc(size_t bytes) { if (p) { (void)hipFree(p); p = nullptr; } return hipMalloc(&p, bytes ? bytes : 16); }
-  template <typename T> T* as() { return (T*)p; }
-};
-struct StreamGuard {
-  hipStream_t s = nullptr;
-  ~StreamGuard() { if (s) (void)hipStreamDestroy(s); }
-};
+using sf::DevBuf;
+using sf::StreamGuard;
+
 struct Tri { uint32_t a, b, c; };
 
 #define CL_CHECK(call)                                                                                                                    \

@@ -32,6 +32,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "common.h"
+#include "hip_util.h"
 #include "mesh.h"
 #include "simplify_math.h"
 
@@ -40,23 +41,16 @@ sf_mesh* simplify_finish(const sf_mesh* in, const sf_simplify_params& P, std::ve
 
 namespace {
 
+using sf::DevBuf;
+using sf::StreamGuard;
+
 using sfq::Quadric;
 
 constexpr int MAX_RING = 96;   // neighbours of one vertex held in registers / scratch for the link test; a longer ring rejects the collapse
 
-struct DevBuf {
-  void* p = nullptr;
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  hipError_t alloc(size_t bytes) { if (p) { (void)hipFree(p); p = nullptr; } return hipMalloc(&p, bytes ? bytes : 16); }
-  template <typename T> T* as() { return (T*)p; }
-};
 
 struct Tri { uint32_t a, b, c; };
 
-struct StreamGuard {
-  hipStream_t s = nullptr;
-  ~StreamGuard() { if (s) (void)hipStreamDestroy(s); }
-};
 
 #define DEC_CHECK(call)                                                                                                \
   do {                                                                                                                 \
