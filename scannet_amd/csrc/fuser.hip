@@ -1576,6 +1576,7 @@ static int integrate_batch_device(sf_fuser* f, const void* d_depth, uint64_t fra
   const void* dr[MAX_BATCH];
   const float* pp[MAX_BATCH];
   int m = 0;
+  bool first_pass = true;
   for (uint64_t i = 0; i <= n; i++) {
     if (i < n) {
       if (poses[16 * i] == -INFINITY) { f->frames_skipped++; continue; }  // tracking lost: skip (sensorData.h:382)
@@ -1584,10 +1585,14 @@ static int integrate_batch_device(sf_fuser* f, const void* d_depth, uint64_t fra
       pp[m] = poses + 16 * i;
       m++;
     }
-    if (m == f->batch || (i == n && m > 0)) {
+    // the first pass of a call has nothing to hide its pre-pass / allocation / compaction behind: a short one (f->ramp frames) gets the
+    // integrate stream busy sooner and the full-size passes after it overlap as usual (same voxels under any batching)
+    const int want = (first_pass && f->ramp > 0 && f->ramp < f->batch && n > (uint64_t)f->ramp) ? f->ramp : f->batch;
+    if (m == want || (i == n && m > 0)) {
       const int rc = run_batch(f, dd, d_rgb ? dr : nullptr, pp, m, +1);
       if (rc != SF_OK) return rc;
       m = 0;
+      first_pass = false;
     }
   }
   return SF_OK;
@@ -1642,6 +1647,7 @@ SF_API int sf_fuser_tune(sf_fuser* f, const char* key, int value) {
     f->front_cus = value;
   }
   else if (k == "alloc_group" && in(1, MAX_BATCH)) f->alloc_group = value;
+  else if (k == "ramp" && in(0, MAX_BATCH)) f->ramp = value;
   else return sf::fail(SF_ERR_INVALID_ARG, "sf_fuser_tune: unknown key or value out of range: %s = %d", key, value);
   return SF_OK;
 }
