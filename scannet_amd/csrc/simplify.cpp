@@ -494,24 +494,29 @@ sf_mesh* simplify_finish(const sf_mesh* in, const sf_simplify_params& P, std::ve
       const float n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
       if (!(std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]) > 0.0f)) { fdel[f] = 1; nfaces--; st.faces_zero_area++; }
     }
-    std::vector<uint32_t> order;
-    order.reserve(n_v);
-    for (size_t v = 0; v < n_v; v++)
-      if (!vdel[v]) order.push_back((uint32_t)v);
-    auto canon = [&](uint32_t v, float* q) { for (int c = 0; c < 3; c++) q[c] = pos[3 * (size_t)v + c] + 0.0f; };
-    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-      float a[3], b[3];
-      canon(x, a); canon(y, b);
-      const int c = std::memcmp(a, b, 12);
-      return c != 0 ? c < 0 : x < y;
-    });
-    for (size_t i = 0; i < order.size();) {
-      size_t j = i + 1;
-      float a[3], b[3];
-      canon(order[i], a);
-      while (j < order.size() && (canon(order[j], b), std::memcmp(a, b, 12) == 0)) j++;
-      for (size_t k = i + 1; k < j; k++) { target_of[order[k]] = order[i]; st.vertices_duplicate++; }
-      i = j;
+    // duplicate vertices: bit-identical positions (-0.0 == +0.0) go to the lowest index.  One pass in index order over an open-addressing
+    // table keyed by the canonical 12 bytes (a sort by position did the same in O(n log n): 0.15 s of a scan's decimation on the GPU path)
+    size_t live = 0;
+    for (size_t v = 0; v < n_v; v++) live += vdel[v] ? 0 : 1;
+    size_t cap = 16;
+    while (cap < 2 * live + 2) cap <<= 1;
+    std::vector<uint32_t> slot(cap, 0xFFFFFFFFu);
+    auto canon = [&](uint32_t v, uint32_t* q) {
+      for (int c = 0; c < 3; c++) { const float f = pos[3 * (size_t)v + c] + 0.0f; std::memcpy(&q[c], &f, 4); }
+    };
+    for (size_t v = 0; v < n_v; v++) {
+      if (vdel[v]) continue;
+      uint32_t a[3], b[3];
+      canon((uint32_t)v, a);
+      uint64_t h = ((uint64_t)a[0] * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)a[1] * 0xC2B2AE3D27D4EB4Full) ^ ((uint64_t)a[2] * 0x165667B19E3779F9ull);
+      h ^= h >> 29;
+      size_t i = (size_t)(h * 0xBF58476D1CE4E5B9ull >> 20) & (cap - 1);
+      for (;;) {
+        if (slot[i] == 0xFFFFFFFFu) { slot[i] = (uint32_t)v; break; }   // first (lowest) index with this position
+        canon(slot[i], b);
+        if (a[0] == b[0] && a[1] == b[1] && a[2] == b[2]) { target_of[v] = slot[i]; st.vertices_duplicate++; break; }
+        i = (i + 1) & (cap - 1);
+      }
     }
   }
   std::vector<uint8_t> used(n_v, 0);
