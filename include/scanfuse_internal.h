@@ -46,10 +46,10 @@ int sf_synth_room_device(void* d_depth, uint64_t frame_stride_bytes, uint64_t fi
 int sf_synth_scan_device(void* d_depth, uint64_t frame_stride_bytes, uint64_t first_frame, uint64_t n, uint64_t total_frames,
                          int width, int height, int noise, const double room_m[3], const double origin_m[3], float* poses_out);
 
-/* Device self-test: the hand-expanded correctly rounded divisions of the integrate kernel against the hardware's IEEE
- * division -- all 2^23 mantissas x 9 exponents for 1/x, 511 integer divisors x 2^21 numerators for n/m.  Both counts
- * must be 0 (tests/test_gpu_tsdf.py). */
-int sf_selftest_division(int device, uint64_t* recip_mismatches, uint64_t* quot_mismatches);
+/* Device self-test: the hand-expanded correctly rounded divisions of the integrate and allocation kernels against the hardware's IEEE
+ * division -- all 2^23 mantissas x 9 exponents for 1/x, 511 integer divisors x 2^21 numerators for n/m, 2^28 general operand pairs
+ * (incl. near-exact and near-half-way quotients) for a/b.  All three counts must be 0 (tests/test_gpu_tsdf.py). */
+int sf_selftest_division(int device, uint64_t* recip_mismatches, uint64_t* quot_mismatches, uint64_t* div_mismatches);
 
 /* Measurement aid (bench.py roofline_single_frame.pattern_ceiling): the memory traffic of the most recent integrate pass
  * without its arithmetic -- every tile of that pass's list is read and (read_only == 0) written back unchanged, with the

@@ -44,8 +44,9 @@ __device__ inline bool block_in_frustum(const ParamsK& P, const FrameK& F, int b
   return in;
 }
 
-__device__ inline int world_to_block(float w, float voxel) {
-  const float q = w / voxel;
+// rv = RN(1 / voxel): the division itself through div_rn (fuser_internal.h), bit for bit w / voxel
+__device__ inline int world_to_block(float w, float voxel, float rv) {
+  const float q = div_rn(w, voxel, rv);
   const int vi = (int)(q >= 0.0f ? q + 0.5f : q - 0.5f);
   return vi >> 3;
 }
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_
 
   const bool in_image = x < P.W && y < P.H;
   const float kx = ((float)x - P.mx) / P.fx, ky = ((float)y - P.my) / P.fy;  // the pixel's ray direction is the same for every frame
+  const float rvoxel = 1.0f / P.voxel;                                        // RN(1 / voxel) for world_to_block
   float d_next = in_image && j_begin < j_end ? depthf_all[(size_t)j_begin * npx + (size_t)(y * P.W + x)] : -INFINITY;
   for (int j = j_begin; j < j_end; ++j) {
     const FrameK& F = B.f[j];  // uniform index: scalar loads from the kernarg segment
@@ -291,16 +293,17 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_
 #pragma unroll
           for (int c = 0; c < 3; c++) {
             const float dir = p1[c] - p0[c];
-            cur[c] = world_to_block(p0[c], P.voxel);
-            const int e = world_to_block(p1[c], P.voxel);
+            cur[c] = world_to_block(p0[c], P.voxel, rvoxel);
+            const int e = world_to_block(p1[c], P.voxel, rvoxel);
             stp[c] = dir > 0.0f ? 1 : (dir < 0.0f ? -1 : 0);
             bnd[c] = e + stp[c];
             if (stp[c] == 0) { tm[c] = INFINITY; td[c] = INFINITY; }
             else {
               const int nb = cur[c] + (stp[c] > 0 ? 1 : 0);
               const float plane = ((float)(8 * nb) - 0.5f) * P.voxel;
-              tm[c] = (plane - p0[c]) / dir;
-              td[c] = ((float)stp[c] * bsize) / dir;
+              const float rdir = recip_rn(dir);   // one reciprocal for both quotients
+              tm[c] = div_rn(plane - p0[c], dir, rdir);
+              td[c] = div_rn((float)stp[c] * bsize, dir, rdir);
             }
           }
           a_cx = cur[0]; a_cy = cur[1]; a_cz = cur[2];

@@ -151,6 +151,20 @@ __device__ inline v2f recip_rn(v2f b) {
   r = pk_fma(pk_fma(-b, r, one), r, r);
   return pk_fma(pk_fma(-b, r, one), r, r);
 }
+// RN(1 / b) and RN(a / b) for normal-range scalars: the reciprocal as above; the quotient is the core of the correctly rounded sequence the
+// compiler itself emits for a / b (q0 = a * y, two residual corrections) without its v_div_scale / v_div_fixup range handling -- given
+// y = RN(1 / b) it costs 5 instructions where the full expansion costs ten and a quarter-rate v_rcp_f32.  k_alloc divides twelve times per
+// ray (world -> block through / voxel, the DDA's tMax / tDelta through / direction); device self-test: sf_selftest_division.
+__device__ inline float recip_rn(float b) {
+  float r = __builtin_amdgcn_rcpf(b);
+  r = fmaf(fmaf(-b, r, 1.0f), r, r);
+  return fmaf(fmaf(-b, r, 1.0f), r, r);
+}
+__device__ inline float div_rn(float a, float b, float y) {
+  const float q0 = a * y;
+  const float q1 = fmaf(fmaf(-b, q0, a), y, q0);
+  return fmaf(fmaf(-b, q1, a), y, q1);
+}
 // RN(n / m) given r = RN(1 / m): one Markstein correction (|n| >= 2^-100, m a small integer)
 __device__ inline v2f quot_rn(v2f n, v2f m, v2f r) {
   const v2f q0 = n * r;

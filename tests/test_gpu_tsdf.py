@@ -403,16 +403,17 @@ def test_marching_cubes_plane_full_size(oracle):
 
 
 def test_hand_expanded_divisions_on_device():
-    """k_integrate expands its two IEEE divisions by hand (rcp + Newton; table reciprocal + Markstein correction).  On the
-    device itself: identical bits to the hardware division for every mantissa / every divisor (tools/check_division.c is
-    the CPU-side proof sketch; this closes the loop on the real v_rcp_f32)."""
+    """k_integrate expands its two IEEE divisions by hand (rcp + Newton; table reciprocal + Markstein correction), k_alloc its twelve per ray
+    (reciprocal + two residual corrections).  On the device itself: identical bits to the hardware division for every mantissa / every
+    divisor / 2^28 general operand pairs incl. near-exact and near-half-way quotients (tools/check_division.c is the CPU-side proof sketch;
+    this closes the loop on the real v_rcp_f32)."""
     import ctypes as C
     from scannet_amd import _abi
     L = _abi.lib()
-    a, b = C.c_uint64(1), C.c_uint64(1)
-    L.sf_selftest_division.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
-    _abi.check(L.sf_selftest_division(0, C.byref(a), C.byref(b)))
-    assert (a.value, b.value) == (0, 0)
+    a, b, c = C.c_uint64(1), C.c_uint64(1), C.c_uint64(1)
+    L.sf_selftest_division.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    _abi.check(L.sf_selftest_division(0, C.byref(a), C.byref(b), C.byref(c)))
+    assert (a.value, b.value, c.value) == (0, 0, 0)
 
 
 @pytest.mark.parametrize("case", [0, 1, 2])
