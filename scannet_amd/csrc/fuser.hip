@@ -51,6 +51,15 @@ __device__ inline int world_to_block(float w, float voxel, float rv) {
   return vi >> 3;
 }
 
+// min(a, b) as ONE v_min_f32: fminf() makes clang canonicalise both operands first (v_max_f32 x, x, x each -- three instructions per voxel
+// where the spec's min needs one; 16 of the 267 VALU instructions of a lane's frame).  The operands here are never NaN (depths come from
+// 16-bit integers), and on equal or infinite operands v_min_f32 and fminf agree.
+__device__ inline float min_f32(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // K1: depth pre-pass.  u16 -> metres (sensorData.h:968-977: d = depth / depthShift, 0 invalid), range
 // gate (zParametersScanNet.txt:34-35) -> -inf; optional rgb -> packed u32.  8 pixels per lane; blockIdx.y = frame
@@ -273,8 +282,8 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_
       const float d = d_cur;
       if (d != -INFINITY && d < P.maxd) {
         const float t = fmaf(P.tscale, d, P.tbase);
-        const float lo = fminf(P.maxd, d - t);
-        const float hi = fminf(P.maxd, d + t);
+        const float lo = min_f32(P.maxd, d - t);
+        const float hi = min_f32(P.maxd, d + t);
         if (lo < hi) {
           float p0[3], p1[3];
           {
@@ -606,7 +615,7 @@ __device__ inline void fuse_update(const ParamsK& P, const v2f (&rcp_m)[NJ], con
     for (int hx = 0; hx < 2; hx++) {
       // valid depth (-inf has the sign bit set, valid depths are positive) below the integration distance, not behind the band
       upd[2 * j + hx] = ok[2 * j + hx] && (__float_as_uint(dk[hx]) < maxd_bits) && (sdf[hx] > -t[hx]);
-      sdf[hx] = fminf(sdf[hx], t[hx]);
+      sdf[hx] = min_f32(sdf[hx], t[hx]);
       sat[2 * j + hx] = false;
       any_upd = any_upd || upd[2 * j + hx];
     }
@@ -708,7 +717,11 @@ __device__ inline void fuse_rows(const ParamsK& P, const float* __restrict__ Ti,
   // the weights are known before anything else: start the eight table reads now, they are consumed in phase B
   if (TAB) {
 #pragma unroll
-    for (int j = 0; j < NJ; j++) rcp_m[j] = (v2f){rtab[(v[J0 + j].y >> 24) + (uint32_t)P.wsample], rtab[(v[J0 + j].w >> 24) + (uint32_t)P.wsample]};
+    for (int j = 0; j < NJ; j++) {
+      // weight_sample == 1 in the shipped parameters (WM >= 1): a constant index offset folds into the LDS instruction's immediate
+      const uint32_t ws = WM >= 1 ? 1u : (uint32_t)P.wsample;
+      rcp_m[j] = (v2f){rtab[(v[J0 + j].y >> 24) + ws], rtab[(v[J0 + j].w >> 24) + ws]};
+    }
   }
   // ---- phase A: project; then the gathers, all issued together
   fuse_project<J0, NJ, false>(P, Ti, wx, wy, wz, pz, pix, ok);
