@@ -33,8 +33,10 @@ namespace {
 struct BatchSlot {
   hipEvent_t copied = nullptr;    // H2D of this batch finished (its pinned buffers may be refilled)
   hipEvent_t copied_rgb = nullptr;  // the colour part of it, on the other copy stream
-  hipEvent_t consumed = nullptr;  // pre-pass of this batch finished (its device buffers may be overwritten)
-  bool used = false;
+  // pre-pass of this batch finished (its device buffers may be overwritten): one event per input stream a sub-batch of the slot ran on --
+  // the fuser orders its two streams among themselves, but the ring does not lean on that
+  hipEvent_t consumed[2] = {nullptr, nullptr};
+  bool used[2] = {false, false};
   std::atomic<int> decoded{0};    // frames of the current generation the pool has finished with
   std::atomic<int> failed{0};
   uint8_t coef_mode[16] = {0};    // per frame: 1 = the pinned colour payload holds JPEG coefficients (GPU reconstructs), 0 = RGB
@@ -129,7 +131,7 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
     for (BatchSlot& sl : ring) {
       if (sl.copied) (void)hipEventDestroy(sl.copied);
       if (sl.copied_rgb) (void)hipEventDestroy(sl.copied_rgb);
-      if (sl.consumed) (void)hipEventDestroy(sl.consumed);
+      for (hipEvent_t ev : sl.consumed) if (ev) (void)hipEventDestroy(ev);
     }
     if (h_pool) (void)hipHostFree(h_pool);
     if (d_pool) (void)hipFree(d_pool);
@@ -148,7 +150,8 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   for (BatchSlot& sl : ring) {
     RUN_CHECK(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
     RUN_CHECK(hipEventCreateWithFlags(&sl.copied_rgb, hipEventDisableTiming));
-    RUN_CHECK(hipEventCreateWithFlags(&sl.consumed, hipEventDisableTiming));
+    RUN_CHECK(hipEventCreateWithFlags(&sl.consumed[0], hipEventDisableTiming));
+    RUN_CHECK(hipEventCreateWithFlags(&sl.consumed[1], hipEventDisableTiming));
   }
 
   const double t_setup_end = timing ? now_s() : 0;
@@ -232,10 +235,11 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
     hipError_t e = hipSuccess;
     // depth on one copy stream, colour on the other, batches alternating between them: two transfers are in flight at any time
     hipStream_t cs_depth = (g & 1) ? copy_stream2 : copy_stream, cs_rgb = (g & 1) ? copy_stream : copy_stream2;
-    if (bs.used) {  // device buffers still read by this slot's previous pre-pass?
-      e = hipStreamWaitEvent(cs_depth, bs.consumed, 0);
-      if (e == hipSuccess) e = hipStreamWaitEvent(cs_rgb, bs.consumed, 0);
-    }
+    for (int q = 0; q < 2 && e == hipSuccess; q++)
+      if (bs.used[q]) {  // device buffers still read by this slot's previous pre-pass?
+        e = hipStreamWaitEvent(cs_depth, bs.consumed[q], 0);
+        if (e == hipSuccess) e = hipStreamWaitEvent(cs_rgb, bs.consumed[q], 0);
+      }
     bool valid[MAX_BATCH], rgbf[MAX_BATCH];
     for (int j = 0; j < cnt; j++) {
       const uint64_t frame = first + g * (uint64_t)B + (uint64_t)j;
@@ -276,7 +280,7 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
     if (timing) t_api += now_s() - t1;
     // ---- kernels: the valid frames in order, a sub-batch is all-colour or all-geometry
     const double t2 = timing ? now_s() : 0;
-    hipStream_t last_stream = nullptr;
+    hipStream_t used_streams[2] = {nullptr, nullptr};   // the input streams this slot's sub-batches ran on
     for (int j = 0; j < cnt && result == SF_OK;) {
       if (!valid[j]) { j++; continue; }
       const void* dd[MAX_BATCH];
@@ -306,14 +310,14 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
       const int rc = sf_fuser_run_batch(f, dd, rgb ? dr : nullptr, pp, m);
       if (rc != SF_OK) { result = rc; err = sf_last_error(); break; }
       n_int += (uint64_t)m;
-      last_stream = in_stream;
+      if (used_streams[0] == nullptr || used_streams[0] == in_stream) used_streams[0] = in_stream;
+      else used_streams[1] = in_stream;
     }
-    if (result == SF_OK && last_stream) {
-      // (sub-batches of one slot may have used both streams: the later one is ordered behind the earlier by run_batch's own events)
-      (void)hipEventRecord(bs.consumed, last_stream);
-      bs.used = true;
-    } else if (result == SF_OK) {
-      bs.used = false;  // nothing read the device buffers
+    if (result == SF_OK) {
+      for (int q = 0; q < 2; q++) {
+        bs.used[q] = used_streams[q] != nullptr;   // false: nothing on that stream read the device buffers
+        if (bs.used[q]) (void)hipEventRecord(bs.consumed[q], used_streams[q]);
+      }
     }
     if (timing) t_flush += now_s() - t2;
   }
