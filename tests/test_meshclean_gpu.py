@@ -116,3 +116,26 @@ def test_scan_sized_mesh_identical_and_faster():
     assert gst["components_removed"] >= 1000 and gst["faces_duplicate"] == 3000 and gst["vertices_merged"] > 15000, gst
     print("clean %d faces: host %.3f s, gpu %.3f s" % (len(t), t1 - t0, t3 - t2))
     assert t3 - t2 < t1 - t0
+
+
+def test_many_random_soups_gpu():
+    """Differential run over 60 random triangle soups: clustered vertices (dense enough that chains of the greedy clustering are several
+    vertices long), random duplicate and degenerate faces, components around the size threshold, merge distance 0 and > 0."""
+    rng = np.random.default_rng(2024)
+    for it in range(60):
+        nv = int(rng.integers(50, 3000))
+        centres = rng.uniform(0, 0.2, (max(nv // 4, 2), 3))
+        v = (centres[rng.integers(0, len(centres), nv)] + rng.normal(0, 0.0007, (nv, 3)) * (rng.random((nv, 1)) < 0.7)).astype(np.float32)
+        v[rng.random(nv) < 0.05] *= np.float32(-0.0)          # a few exact (signed) zeros
+        nf = int(rng.integers(10, 6000))
+        t = rng.integers(0, nv, (nf, 3)).astype(np.uint32)
+        k = max(1, nf // 10)
+        t[rng.integers(0, nf, k)] = t[rng.integers(0, nf, k)][:, rng.permutation(3)]     # duplicates with permuted corners
+        t[rng.integers(0, nf, max(1, nf // 50)), 1] = t[rng.integers(0, nf, max(1, nf // 50)), 0]   # degenerate faces
+        radius = float(rng.choice([0.0, 0.0005, 0.0010689, 0.003]))
+        min_cc = int(rng.choice([0, 1, 2, 5, 50]))
+        m = Mesh.from_arrays(v, t, rng.integers(0, 256, (nv, 4), dtype=np.uint8))
+        host, hst = meshclean.clean(m, radius, min_cc)
+        gpu, gst = meshclean.clean(m, radius, min_cc, gpu=0)
+        _same(host, gpu)
+        assert gst == hst, (it, radius, min_cc, gst, hst)
