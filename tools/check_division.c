@@ -1,4 +1,4 @@
-/* tools/check_division.c -- CPU brute-force check of the two hand-expanded divisions of k_integrate (fuser.hip, fuse_tile).
+/* tools/check_division.c -- CPU brute-force check of the hand-expanded divisions of k_integrate and k_alloc (fuser.hip, fuser_internal.h).
  *
  *   gcc -O2 -mfma -ffp-contract=off -o /tmp/check_division tools/check_division.c -lm && /tmp/check_division
  *
@@ -10,6 +10,10 @@
  *     Claim: r2 is bit-identical to the result of the compiler's full fdiv expansion (one more correction step) for
  *     every mantissa and every such seed -- so dropping the third step and the div_scale/div_fixup range handling does
  *     not change a bit for normal-range b.  Checked exhaustively over all 2^23 mantissas x 3 exponents x 5 seed errors.
+ * (3) a / b for general normal-range operands (k_alloc: world -> block through / voxel, the DDA's tMax / tDelta through / direction):
+ *     y = RN(1/b), q0 = RN(a*y), q1 = fma(fma(-b, q0, a), y, q0), q = fma(fma(-b, q1, a), y, q1) -- the quotient part of the compiler's
+ *     own expansion without div_scale / div_fixup.  Claim: q == RN(a/b).  Checked on 2^30 operand pairs: random bit patterns in the
+ *     ranges k_alloc sees, dividends within 3 ulp of exact multiples and of half-way multiples of the divisor.
  */
 #include <math.h>
 #include <stdint.h>
@@ -50,5 +54,24 @@ int main(void) {
       }
     }
   printf("(2) two Newton steps vs the compiler's three: %ld differences; exact seed -> wrong result %ld times\n", differ, wrong_exact_seed);
-  return (bad1 || differ || wrong_exact_seed) ? 1 : 0;
+  long bad3 = 0, tot3 = 0;
+  for (long it = 0; it < (1l << 28); it++) {
+    const uint64_t x = rnd(), z = rnd();
+    const float b = asf(((uint32_t)x & 0x807fffffu) | ((103u + (uint32_t)(x >> 58) % 41u) << 23));
+    const float a0 = asf(((uint32_t)z & 0x807fffffu) | ((97u + (uint32_t)(z >> 58) % 43u) << 23));
+    const float qf = asf(0x3f800000u | ((uint32_t)(z >> 24) & 0x7fffffu));
+    const float a1 = asf(asu(qf * b) + ((uint32_t)(x >> 50) & 7u) - 3u);
+    const float qh = asf(asu(qf) & 0xfffffffeu);
+    const float a2 = asf(asu(fmaf(qh, b, 0x1p-24f * b)) + ((uint32_t)(z >> 50) & 7u) - 3u);
+    const float a3 = asf(asu(a0) ^ 0x00400000u);
+    const float y = 1.0f / b;
+    const float as[4] = {a0, a1, a2, a3};
+    for (int k = 0; k < 4; k++) {
+      const float a = as[k], q0 = a * y, q1 = fmaf(fmaf(-b, q0, a), y, q0), q = fmaf(fmaf(-b, q1, a), y, q1);
+      tot3++;
+      if (asu(q) != asu(a / b)) bad3++;
+    }
+  }
+  printf("(3) reciprocal + two residual corrections: %ld cases, %ld mismatches vs a/b\n", tot3, bad3);
+  return (bad1 || differ || wrong_exact_seed || bad3) ? 1 : 0;
 }
