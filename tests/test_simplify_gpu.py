@@ -103,3 +103,33 @@ def test_large_flat_region_takes_few_rounds_gpu():
     assert 0 < st["rounds"] < 120, st
     assert dt < 5.0, dt
     print("flat 977k faces -> %d in %d rounds, %.3f s" % (len(tris), st["rounds"], dt))
+
+
+def test_wild_inputs_terminate_and_stay_valid_gpu():
+    """Random triangle soups (non-manifold edges, duplicate and degenerate faces, isolated vertices, tiny meshes) through the GPU collapse:
+    it must terminate, reference only existing vertices, never grow, emit no degenerate face and be deterministic -- whatever the input."""
+    rng = np.random.default_rng(99)
+    for it in range(40):
+        nv = int(rng.integers(4, 1500))
+        v = rng.uniform(0, 1, (nv, 3)).astype(np.float32)
+        if it % 5 == 0:
+            v[:, 2] = 0.0                                      # all coplanar: every quadric is rank deficient
+        nf = int(rng.integers(1, 4000))
+        t = rng.integers(0, nv, (nf, 3)).astype(np.uint32)
+        if it % 3 == 0:
+            t[: nf // 4] = t[nf // 2: nf // 2 + nf // 4][:, ::-1] if nf >= 8 else t[: nf // 4]   # duplicated faces, flipped
+        m = Mesh.from_arrays(v, t)
+        out1, st1 = meshclean.simplify(m, gpu=0)
+        out2, st2 = meshclean.simplify(m, gpu=0)
+        x1, _, t1 = out1.arrays()
+        x2, _, t2 = out2.arrays()
+        assert np.array_equal(x1.view(np.uint32), x2.view(np.uint32)) and np.array_equal(t1, t2) and st1 == st2, it
+        assert len(t1) <= nf and (len(t1) == 0 or t1.max() < len(x1)), it
+        if len(t1):
+            assert (t1[:, 0] != t1[:, 1]).all() and (t1[:, 1] != t1[:, 2]).all() and (t1[:, 0] != t1[:, 2]).all(), it
+        assert np.isfinite(x1).all(), it
+    # nothing to do: empty mesh, single face
+    out, st = meshclean.simplify(Mesh.from_arrays(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint32)), gpu=0)
+    assert out.counts() == (0, 0)
+    out, st = meshclean.simplify(Mesh.from_arrays(np.eye(3, dtype=np.float32), np.array([[0, 1, 2]], np.uint32)), gpu=0)
+    assert out.counts()[1] <= 1
