@@ -427,3 +427,21 @@ def test_shard_main_runs_the_whole_chain(tmp_path, capsys, monkeypatch):
         assert hi > 20000 and lo < 0.06 * hi          # 20 % of 20 %, minus what cleanLoRes drops
         segs = json.load(open(base + "_vh_clean_2.0.010000.segs.json"))
         assert len(segs["segIndices"]) == segmentator.Mesh.read(base + "_vh_clean_2.ply").counts()[0]
+    # the cleaning filters ran on the GPU (the default of the tool): with --host-clean every file is byte for byte the same
+    first = {p: {sfx: open(os.path.splitext(p)[0] + sfx, "rb").read() for sfx in ("_vh_clean.ply", "_vh_clean_2.ply", "_vh_clean_2.0.010000.segs.json")} for p in paths}
+    shard.main([str(lst), "--host-clean"])
+    capsys.readouterr()
+    for p in paths:
+        for sfx, blob in first[p].items():
+            assert open(os.path.splitext(p)[0] + sfx, "rb").read() == blob, (p, sfx)
+    # and with the quadric collapse on the GPU as well: the same stages, other triangles
+    shard.main([str(lst), "--gpu-decimate"])
+    capsys.readouterr()
+    for p in paths:
+        base = os.path.splitext(p)[0]
+        assert open(base + "_vh_clean.ply", "rb").read() == first[p]["_vh_clean.ply"]
+        hi = segmentator.Mesh.read(base + "_vh_clean.ply").counts()[1]
+        lo = segmentator.Mesh.read(base + "_vh_clean_2.ply").counts()[1]
+        assert 0 < lo < 0.06 * hi
+    with pytest.raises(SystemExit):
+        shard.main([str(lst), "--no-such-flag"])
