@@ -97,7 +97,8 @@ void sf_fuser_destroy(sf_fuser* f);
 
 /* Host-buffer entry points: depth = W*H u16 (row-major, as decompressDepthAlloc returns it,
  * sensorData.h:943-946), rgb = W*H*3 u8 at depth resolution or NULL, pose = row-major camToWorld
- * (RGBDFrame::getCameraToWorld, sensorData.h:432).  Asynchronous; returns SF_ERR_SKIPPED for -inf poses. */
+ * (RGBDFrame::getCameraToWorld, sensorData.h:432).  The buffers have been read when the call returns (they may be reused or freed at once);
+ * the fusion itself runs asynchronously (sf_fuser_sync / any later call orders behind it).  SF_ERR_SKIPPED for -inf poses. */
 int sf_fuser_integrate(sf_fuser* f, const uint16_t* depth, const uint8_t* rgb, const float pose[16]);
 int sf_fuser_deintegrate(sf_fuser* f, const uint16_t* depth, const uint8_t* rgb, const float pose[16]);
 

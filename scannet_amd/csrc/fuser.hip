@@ -1565,6 +1565,10 @@ static int fuse_host(sf_fuser* f, const uint16_t* depth, const uint8_t* rgb, con
   hipStream_t in_stream = sf_input_stream(f, 1, rgb != nullptr, sign);  // the stream the pre-pass reads the frame on
   SF_HIP_CHECK(hipMemcpyAsync(f->staging_depth, depth, f->in_px * 2, hipMemcpyHostToDevice, in_stream));
   if (rgb) SF_HIP_CHECK(hipMemcpyAsync(f->staging_rgb, rgb, (f->pk.cW ? (size_t)f->pk.cW * f->pk.cH : npx) * 3, hipMemcpyHostToDevice, in_stream));
+  // The caller's buffers are ordinary (pageable) memory and are its own again the moment this call returns -- a live stream decodes the
+  // next frame into the same buffer, a binding may free it: the copies must have READ them by then (the runtime may pin pageable pages in
+  // place and let the DMA run on), so wait for the copies; only the kernels run asynchronously.
+  SF_HIP_CHECK(hipStreamSynchronize(in_stream));
   return run_frame(f, f->staging_depth, rgb ? f->staging_rgb : nullptr, pose, sign);
 }
 

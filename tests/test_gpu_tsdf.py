@@ -547,3 +547,25 @@ def test_four_schedules_one_volume_at_full_size():
         assert digests[0][0] > 50000 and len(set(digests)) == 1, digests
     finally:
         L.sf_device_free(dptr)
+
+
+def test_gpu_mesh_matches_the_literal_marching_cubes():
+    """The HIP mesh against the independent float64 marching cubes (oracle/spec_literal_mc.py) over the volume the HIP path itself exports:
+    the same vertices (grid edges), positions within 1e-6 m, colours within one level, the same number of triangles -- no call into
+    mc_oracle.c, whose agreement with the kernel would otherwise be the only evidence for the stage."""
+    from scannet_amd import fusion
+    from tests.test_oracle_tsdf import spec_literal_mc_check
+    W, H = 320, 240
+    fx, fy, mx, my = synth.intrinsics(W, H)
+    gp = fusion.default_params(depth_width=W, depth_height=H, voxel_size=0.01, fx=fx, fy=fy, mx=mx, my=my, num_sdf_blocks=1 << 17)
+    rng = np.random.default_rng(8)
+    with fusion.Fuser(gp) as f:
+        for i in range(10):
+            pose = synth.trajectory_pose(40 * i, 600)
+            assert f.integrate(synth.render_room_depth(pose, W, H, noise_frame=i), pose, rgb=rng.integers(0, 256, (H, W, 3), dtype=np.uint8))
+        coords, vox = f.export_blocks()
+        xyz, rgba, tris, keys = f.extract_mesh().arrays(keys=True)
+    order = np.lexsort((coords[:, 2], coords[:, 1], coords[:, 0]))
+    res = spec_literal_mc_check(coords[order], vox[order], dict(keys=keys, pos=xyz, col=rgba[:, :3], idx=tris), 0.01, gp.mc_thresh_factor)
+    assert res["vertices"] > 20000, res
+    print("literal marching cubes:", res)
