@@ -43,12 +43,15 @@ namespace {
 struct FlatMap {
   std::vector<uint64_t> keys;
   std::vector<uint32_t> vals;
+  std::vector<uint64_t> home;   // one bit per slot: some key has this slot as its home -- a cache-resident filter in front of the
+                                // table (most look-ups of the clustering sweep are for cells that do not exist: each one a DRAM miss otherwise)
   uint64_t mask = 0;
   explicit FlatMap(size_t n) {
-    size_t cap = 16;
+    size_t cap = 64;
     while (cap < 2 * n + 2) cap <<= 1;
     keys.assign(cap, ~0ull);
     vals.assign(cap, 0u);
+    home.assign(cap / 64, 0ull);
     mask = cap - 1;
   }
   static uint64_t mix(uint64_t k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33; return k; }
@@ -57,12 +60,18 @@ struct FlatMap {
     size_t i = (size_t)(mix(k) & mask);
     for (;;) {
       if (keys[i] == k) { *fresh = false; return i; }
-      if (keys[i] == ~0ull) { keys[i] = k; vals[i] = v; *fresh = true; return i; }
+      if (keys[i] == ~0ull) {
+        keys[i] = k; vals[i] = v; *fresh = true;
+        const size_t h = (size_t)(mix(k) & mask);
+        home[h >> 6] |= 1ull << (h & 63);
+        return i;
+      }
       i = (i + 1) & mask;
     }
   }
   const uint32_t* find(uint64_t k) const {
     size_t i = (size_t)(mix(k) & mask);
+    if (!((home[i >> 6] >> (i & 63)) & 1ull)) return nullptr;
     for (;;) {
       if (keys[i] == k) return &vals[i];
       if (keys[i] == ~0ull) return nullptr;
@@ -78,6 +87,14 @@ uint32_t uf_find(std::vector<uint32_t>& p, uint32_t x) {
 
 // filter 1: returns for every vertex the index of the vertex it is merged into (itself for survivors)
 int merge_close(const std::vector<float>& pos, float radius, std::vector<uint32_t>& target) {
+  const bool timing = std::getenv("SF_CLEAN_TIMING") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::printf("clean:   merge: %-19s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+    t_last = now;
+  };
   const size_t nv = pos.size() / 3;
   target.resize(nv);
   std::iota(target.begin(), target.end(), 0u);
@@ -123,10 +140,12 @@ int merge_close(const std::vector<float>& pos, float radius, std::vector<uint32_
       cell_id[i] = cells.vals[slot];
       count[cell_id[i]]++;
     }
+    lap("cells");
     std::vector<uint32_t> start(count.size() + 1, 0);
     for (size_t c = 0; c < count.size(); c++) start[c + 1] = start[c] + count[c];
     std::vector<uint32_t> members(nv), fill(start.begin(), start.end() - 1);
     for (size_t i = 0; i < nv; i++) members[fill[cell_id[i]]++] = (uint32_t)i;  // index order inside a cell
+    lap("buckets");
     std::vector<uint8_t> visited(nv, 0);
     for (size_t i = 0; i < nv; i++) {
       if (visited[i]) continue;
@@ -148,6 +167,7 @@ int merge_close(const std::vector<float>& pos, float radius, std::vector<uint32_
             }
           }
     }
+    lap("sweep");
     // RemoveDuplicateVertex: members now share their centre's position; two centres never coincide (distance 0 < radius
     // would have clustered them), so the cluster assignment IS the duplicate-vertex merge.
     return SF_OK;
@@ -240,27 +260,40 @@ SF_API int sf_mesh_clean(const sf_mesh* in, float merge_distance, uint32_t min_c
     const size_t n = tri.size() / 3;
     std::vector<uint32_t> parent(n);
     std::iota(parent.begin(), parent.end(), 0u);
-    // vertex -> incident faces (CSR by counting sort: sequential passes, no hashing); two faces are adjacent iff a face
-    // incident to the edge's lower vertex also holds its other vertex
-    std::vector<uint32_t> vstart(nv + 1, 0);
-    for (uint32_t v : tri) vstart[v + 1]++;
-    for (size_t v = 0; v < nv; v++) vstart[v + 1] += vstart[v];
-    std::vector<uint32_t> vfaces(tri.size()), vfill(vstart.begin(), vstart.end() - 1);
+    // faces sharing an edge: every directed half-edge is filed under its lower vertex (counting sort: sequential passes, no hashing), then
+    // inside a vertex's short list the half-edges with the same other end point are linked (the lists average six entries: a quadratic
+    // scan of one list touches a cache line or two, where looking the edge up through the faces around the vertex chased 3 x 6 pointers)
+    std::vector<uint32_t> estart(nv + 1, 0);
     for (size_t f = 0; f < n; f++)
-      for (int e = 0; e < 3; e++) vfaces[vfill[tri[3 * f + e]]++] = (uint32_t)f;
-    for (size_t f = 0; f < n; f++)
+      for (int e = 0; e < 3; e++) estart[std::min(tri[3 * f + e], tri[3 * f + (e + 1) % 3]) + 1]++;
+    for (size_t v = 0; v < nv; v++) estart[v + 1] += estart[v];
+    std::vector<uint32_t> ehi(tri.size()), eface(tri.size()), efill(estart.begin(), estart.end() - 1);
+    for (size_t f = 0; f < n; f++)   // faces in index order: inside a list the faces ascend
       for (int e = 0; e < 3; e++) {
         const uint32_t a = tri[3 * f + e], b = tri[3 * f + (e + 1) % 3];
-        const uint32_t lo_v = std::min(a, b), hi_v = std::max(a, b);
-        for (uint32_t k = vstart[lo_v]; k < vstart[lo_v + 1]; k++) {
-          const uint32_t g = vfaces[k];
-          if (g <= f) continue;  // every unordered pair once
-          if (tri[3 * g] == hi_v || tri[3 * g + 1] == hi_v || tri[3 * g + 2] == hi_v) {
-            const uint32_t ra = uf_find(parent, (uint32_t)f), rb = uf_find(parent, g);
-            if (ra != rb) parent[std::max(ra, rb)] = std::min(ra, rb);
-          }
-        }
+        const uint32_t k = efill[std::min(a, b)]++;
+        ehi[k] = std::max(a, b);
+        eface[k] = (uint32_t)f;
       }
+    auto link = [&](uint32_t fa, uint32_t fb) {
+      const uint32_t ra = uf_find(parent, fa), rb = uf_find(parent, fb);
+      if (ra != rb) parent[std::max(ra, rb)] = std::min(ra, rb);
+    };
+    std::vector<std::pair<uint32_t, uint32_t>> big;
+    for (size_t v = 0; v < nv; v++) {
+      const uint32_t lo = estart[v], hi = estart[v + 1];
+      if (hi - lo <= 48) {
+        for (uint32_t i = lo; i < hi; i++)
+          for (uint32_t j = i + 1; j < hi; j++)
+            if (ehi[i] == ehi[j] && eface[i] != eface[j]) link(eface[i], eface[j]);
+      } else {   // a hub vertex: sort its list by the other end point instead of comparing all pairs
+        big.clear();
+        for (uint32_t i = lo; i < hi; i++) big.emplace_back(ehi[i], eface[i]);
+        std::sort(big.begin(), big.end());
+        for (size_t i = 1; i < big.size(); i++)
+          if (big[i].first == big[i - 1].first && big[i].second != big[i - 1].second) link(big[i].second, big[i - 1].second);
+      }
+    }
     std::vector<uint32_t> size(n, 0);
     for (size_t f = 0; f < n; f++) size[uf_find(parent, (uint32_t)f)]++;
     for (size_t f = 0; f < n; f++)
