@@ -14,19 +14,21 @@
 
 namespace {
 
-uint32_t crc_table[256];
-bool crc_ready = false;
-void crc_init() {
-  for (uint32_t n = 0; n < 256; n++) {
-    uint32_t c = n;
-    for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-    crc_table[n] = c;
+// the CRC-32 table of the PNG specification, built once (a function-local static: the decode pool of sf_fuse_run reads PNG colour frames on
+// many threads, a lazily filled global table raced its own "ready" flag)
+struct CrcTable {
+  uint32_t t[256];
+  CrcTable() {
+    for (uint32_t n = 0; n < 256; n++) {
+      uint32_t c = n;
+      for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+      t[n] = c;
+    }
   }
-  crc_ready = true;
-}
+};
 uint32_t crc32(const uint8_t* p, size_t n, uint32_t c = 0xFFFFFFFFu) {
-  if (!crc_ready) crc_init();
-  for (size_t i = 0; i < n; i++) c = crc_table[(c ^ p[i]) & 0xFF] ^ (c >> 8);
+  static const CrcTable table;
+  for (size_t i = 0; i < n; i++) c = table.t[(c ^ p[i]) & 0xFF] ^ (c >> 8);
   return c;
 }
 uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }

@@ -22,3 +22,11 @@ def test_asan_ubsan_host_suite():
 def test_tsan_fuse_run_pipeline():
     r = subprocess.run(["bash", os.path.join(ROOT, "tools", "tsan", "run.sh"), "200", "8"], capture_output=True, text=True, cwd=ROOT, timeout=900)
     assert r.returncode == 0 and "tsan: clean" in r.stdout and r.stdout.count("checksum ok") == 3, (r.stdout[-3000:], r.stderr[-3000:])
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
+def test_codec_mutation_fuzz_under_asan():
+    """tools/fuzz_codecs.py: truncated, bit-flipped, spliced and length-poked JPEG / zlib / PNG / PLY / Occipital inputs through the
+    ASan + UBSan build: every call returns, none trips a sanitizer (a short run here; the tool takes an iteration count)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_codecs.py"), "600", "11"], capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert r.returncode == 0 and "fuzz: no sanitizer report" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
