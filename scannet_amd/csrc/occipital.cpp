@@ -40,17 +40,16 @@ namespace {
 
 constexpr int OCC_TABLE = 1105;
 
-const uint16_t* shift_table() {
-  static uint16_t table[OCC_TABLE];
-  static std::atomic<bool> ready{false};
-  if (!ready.load(std::memory_order_acquire)) {
-    uint16_t t[OCC_TABLE];
+struct ShiftTable {   // built once (thread-safe function-local static: decode pools call this from many threads)
+  uint16_t t[OCC_TABLE];
+  ShiftTable() {
     t[0] = 0;
     for (int s = 1; s < OCC_TABLE; s++) t[s] = (uint16_t)(3000000000ll / (11348335ll - 10000ll * s));
-    std::memcpy(table, t, sizeof(table));  // idempotent: concurrent first calls write the same bytes
-    ready.store(true, std::memory_order_release);
   }
-  return table;
+};
+const uint16_t* shift_table() {
+  static const ShiftTable table;
+  return table.t;
 }
 
 struct BitReader {
