@@ -64,6 +64,24 @@ typedef struct sf_params {
    * sampling convention of the reference's own resample kernels (AnnotationTools/Filter2dAnnotations/filter.cu:647-665) --, the intrinsics
    * follow it (fx * iw / dw, mx * (iw - 1) / (dw - 1): Calibrate/src/calibration.h:125-128), colour is looked up under the same ray. */
   int32_t integration_width, integration_height;
+  /* Upstream-conformance switches (DESIGN.md section 6b "upstream vs this specification").  The TSDF algorithm lives in external code
+   * (VoxelHashing / BundleFusion) that is not in the reference tree; SURVEY.md App. C is the specification built here and 0 selects it
+   * everywhere.  Where the public upstream sources are remembered to differ, the other value reproduces THAT behaviour -- in the kernels,
+   * in the CPU checker (oracle/tsdf_oracle.c) and in the float64 literal evaluator (oracle/spec_literal.py) alike -- so that a maintainer
+   * who holds the Windows binaries can pick the semantics that match them.
+   *   frustum_mode  0: a block is allocated / fused in a frame when its bounding sphere touches the view frustum (conservative: every voxel
+   *                    that projects into the image is visited).
+   *                 1: VoxelHashing's isSDFBlockInCameraFrustumApprox: the block CENTRE is projected, its normalised device coordinates
+   *                    are scaled by 0.95 and must lie in [-1, 1]^2 x [0, 1] (z against s_sensorDepthMin / Max) -- border blocks whose
+   *                    centre falls outside are neither allocated nor fused although some of their voxels project into the image.
+   *   colour_round  0: running colour average (old + new) / 2 in integer arithmetic (App. C as written: truncation).
+   *                 1: (uchar)(0.5f * old + 0.5f * new + 0.5f) per channel (combineVoxel upstream: round half up).
+   *   colour_first  0: a voxel with weight 0 takes the observed colour as it is.
+   *                 1: a voxel whose accumulated colour is black (r + g + b == 0) does (combineVoxel upstream).
+   *   weight_mode   0: every observation weighs s_SDFIntegrationWeightSample (BundleFusion forces this; App. C).
+   *                 1: VoxelHashing: (uchar)max(weightSample * 1.5f * (1 - (d - depthMin) / (depthMax - depthMin)), 1.0f).  With the shipped
+   *                    weightSample = 1 (zParametersScanNet.txt:52) both give 1 for every depth. */
+  int32_t frustum_mode, colour_round, colour_first, weight_mode;
 } sf_params;
 
 /* SURVEY 8d camera + zParametersScanNet.txt values with BASELINE.json's 4 mm / 2^19-bucket overrides */
@@ -116,6 +134,9 @@ int sf_fuser_integrate_batch_device_rgb(sf_fuser* f, const void* d_depth, uint64
                                         const float* poses, uint64_t n);
 int sf_fuser_batch_frames(const sf_fuser* f);   /* 16 */
 
+/* Empty volume again (table, heap, tiles, counters, frame numbering); parameters, streams and tuning stay.  The reference's tools are
+ * one process per scan (Server/scan_processor.py:137-141); a caller that fuses scan after scan keeps its allocation this way. */
+int sf_fuser_reset(sf_fuser* f);
 int sf_fuser_garbage_collect(sf_fuser* f, uint32_t* freed);
 int sf_fuser_sync(sf_fuser* f);
 int sf_fuser_stats(sf_fuser* f, sf_stats* out); /* synchronises */

@@ -46,6 +46,15 @@ int sf_synth_room_device(void* d_depth, uint64_t frame_stride_bytes, uint64_t fi
 int sf_synth_scan_device(void* d_depth, uint64_t frame_stride_bytes, uint64_t first_frame, uint64_t n, uint64_t total_frames,
                          int width, int height, int noise, const double room_m[3], const double origin_m[3], float* poses_out);
 
+/* The same with the scene and the noise model chosen ("real-entropy inputs").  noise 0: none; 1: the round-1 LCG ramp (kept
+ * for the committed digests); 2: three LSBs hashed per pixel and frame.  scene 0: the empty box room; 1: the room furnished with the 48 boxes of
+ * sf_synth_clutter_boxes(room, seed) -- wall furniture, a table island, shelves, lamps -- and, under noise 2, sensor holes (grazing
+ * incidence, 0.4 % speckle).  scannet_amd/synth.py renders the same scenes on the host. */
+int sf_synth_scene_device(void* d_depth, uint64_t frame_stride_bytes, uint64_t first_frame, uint64_t n, uint64_t total_frames,
+                          int width, int height, int noise, int scene, uint32_t seed, const double room_m[3], const double origin_m[3],
+                          float* poses_out);
+int sf_synth_clutter_boxes(const double room_m[3], uint32_t seed, float* lo_out /* 48 x 3 */, float* hi_out /* 48 x 3 */, int* n_out);
+
 /* Device self-test: the hand-expanded correctly rounded divisions of the integrate and allocation kernels against the hardware's IEEE
  * division -- all 2^23 mantissas x 9 exponents for 1/x, 511 integer divisors x 2^21 numerators for n/m, 2^28 general operand pairs
  * (incl. near-exact and near-half-way quotients) for a/b.  All three counts must be 0 (tests/test_gpu_tsdf.py). */

@@ -31,6 +31,7 @@ class OrParams(C.Structure):
         ("max_integration_dist", C.c_float),
         ("weight_sample", C.c_int32), ("weight_max", C.c_int32),
         ("mc_thresh_factor", C.c_float),
+        ("frustum_mode", C.c_int32), ("colour_round", C.c_int32), ("colour_first", C.c_int32), ("weight_mode", C.c_int32),
     ]
 
 

@@ -29,10 +29,30 @@ def depth_to_metres(depth_u16, depth_shift=1000.0, dmin=0.1, dmax=6.0):
     return np.where(bad, -np.inf, d)
 
 
+def centre_in_frustum(coords, Ti, *, voxel, fx, fy, mx, my, width, height, dmin, dmax, eps=1e-5):
+    """sf_params::frustum_mode 1 (VoxelHashing isSDFBlockInCameraFrustumApprox as remembered from the public sources, DESIGN 6b), literally in
+    float64: the block centre ((8 b + 3.5) voxel) to camera space, projected, x / y normalised over (W - 1) / (H - 1) and z over the sensor depth
+    range, everything scaled by 0.95 and tested against [-1, 1]^2 x [0, 1].  -> (inside bool [n], near bool [n]: within eps of a boundary)."""
+    c = (np.asarray(coords, np.float64) * 8.0 + 3.5) * voxel
+    pc = c @ Ti[:3, :3].T + Ti[:3, 3]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        u = pc[:, 0] * fx / pc[:, 2] + mx
+        v = pc[:, 1] * fy / pc[:, 2] + my
+        nx = (2.0 * u - (width - 1.0)) / (width - 1.0) * 0.95
+        ny = ((height - 1.0) - 2.0 * v) / (height - 1.0) * 0.95
+        nz = (pc[:, 2] - dmin) / (dmax - dmin) * 0.95
+        inside = (nx >= -1) & (nx <= 1) & (ny >= -1) & (ny <= 1) & (nz >= 0) & (nz <= 1) & (pc[:, 2] > 0)
+        near = (np.abs(np.abs(nx) - 1) < eps) | (np.abs(np.abs(ny) - 1) < eps) | (np.abs(nz) < eps) | (np.abs(nz - 1) < eps)
+    return inside, near
+
+
 def evaluate(frames, coords, birth, *, voxel, fx, fy, mx, my, width, height, trunc_base=0.06, trunc_scale=0.02, max_dist=4.0, weight_sample=1,
-             weight_max=255, depth_shift=1000.0, dmin=0.1, dmax=6.0, eps_px=None, eps_m=2e-5):
+             weight_max=255, depth_shift=1000.0, dmin=0.1, dmax=6.0, eps_px=None, eps_m=2e-5, frustum_mode=0, weight_mode=0):
     """frames: [(depth u16 [H,W], camToWorld 4x4)], in order.  coords: int [n,3] block coordinates.  birth: int [n] index of the first frame
     at which block i exists (allocation is a separate rule; the caller takes it from the implementation under test).
+    frustum_mode 0: every existing block is visited (the sphere test of App. C is conservative: it never keeps a voxel that projects into the
+    image from being visited, so it is not evaluated here).  frustum_mode 1: only blocks whose centre passes `centre_in_frustum` for the frame.
+    weight_mode 1: an observation weighs (uchar)max(weight_sample * 1.5 * (1 - (d - dmin) / (dmax - dmin)), 1) (VoxelHashing).
     Returns (sdf float64 [n,512], weight int [n,512], tie bool [n,512])."""
     if eps_px is None:
         eps_px = 1e-6 * max(width, height)   # ~8 ulp of a pixel coordinate at the far edge of the image: what a few fp32 roundings can move it
@@ -59,6 +79,10 @@ def evaluate(frames, coords, birth, *, voxel, fx, fy, mx, my, width, height, tru
         Ti = np.linalg.inv(pose)
         df = depth_to_metres(np.asarray(depth), depth_shift, dmin, dmax)
         live = birth <= k
+        if frustum_mode == 1:
+            inside, near = centre_in_frustum(coords, Ti, voxel=voxel, fx=fx, fy=fy, mx=mx, my=my, width=width, height=height, dmin=dmin, dmax=dmax)
+            tie[live & near] = True   # the fp32 test may fall on the other side for the whole block
+            live = live & inside
         if not live.any():
             continue
         x, y, z = X[live], Y[live], Z[live]
@@ -87,8 +111,16 @@ def evaluate(frames, coords, birth, *, voxel, fx, fy, mx, my, width, height, tru
         t_here |= np.abs(pcz) < eps_m
         t_here |= valid & (np.abs(raw + t) < eps_m)
         so, wo = sdf_acc[live], w_acc[live]
-        new_s = (so * wo + s * wn) / (wo + wn)
+        if weight_mode == 1:
+            z01 = (dd - dmin) / (dmax - dmin)
+            wk = np.minimum(np.trunc(np.maximum(weight_sample * 1.5 * (1.0 - z01), 1.0)), 255.0)
+            # the (uchar) cast is a step: an observation whose float weight sits within rounding distance of an integer is a tie
+            raw_w = weight_sample * 1.5 * (1.0 - z01)
+            t_here |= valid & (raw_w > 1.0) & (np.abs(raw_w - np.rint(raw_w)) < 1e-5)
+        else:
+            wk = np.full(dd.shape, wn)
+        new_s = (so * wo + s * wk) / (wo + wk)
         sdf_acc[live] = np.where(upd, new_s, so)
-        w_acc[live] = np.where(upd, np.minimum(wmax, wo + int(weight_sample)), wo)
+        w_acc[live] = np.where(upd, np.minimum(wmax, wo + wk.astype(np.int64)), wo)
         tie[live] |= t_here
     return sdf_acc, w_acc, tie

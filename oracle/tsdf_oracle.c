@@ -51,6 +51,11 @@ typedef struct {
   int32_t weight_sample;        /* s_SDFIntegrationWeightSample */
   int32_t weight_max;           /* min(s_SDFIntegrationWeightMax, 255) */
   float mc_thresh_factor;       /* s_SDFMarchingCubeThreshFactor */
+  /* upstream-conformance switches (include/scanfuse.h sf_params); 0 everywhere = SURVEY App. C */
+  int32_t frustum_mode;         /* 1: block centre, NDC x 0.95 (VoxelHashing isSDFBlockInCameraFrustumApprox) */
+  int32_t colour_round;         /* 1: (uchar)(0.5f a + 0.5f b + 0.5f) */
+  int32_t colour_first;         /* 1: a black accumulated colour, not a zero weight, marks the first observation */
+  int32_t weight_mode;          /* 1: depth-dependent observation weight (VoxelHashing) */
 } or_params;
 
 typedef struct {
@@ -214,6 +219,19 @@ static int block_in_frustum(const or_params* p, const or_frame* f, int32_t bx, i
   const float px = fmaf(M[0], cx, fmaf(M[1], cy, fmaf(M[2], cz, M[3])));
   const float py = fmaf(M[4], cx, fmaf(M[5], cy, fmaf(M[6], cz, M[7])));
   const float pz = fmaf(M[8], cx, fmaf(M[9], cy, fmaf(M[10], cz, M[11])));
+  if (p->frustum_mode == 1) {
+    /* VoxelHashing DepthCameraData::isInCameraFrustumApprox as remembered from the public sources (not in /root/reference): the block
+     * centre through cameraToKinectProj -- x, y to [-1, 1] over (W - 1), (H - 1), z to [0, 1] over the SENSOR depth range --, scaled by
+     * 0.95, inside the unit box.  Every operation individually rounded, true divisions. */
+    const float zn = ((pz - p->depth_min) / (p->depth_max - p->depth_min)) * 0.95f;
+    if (!(zn >= 0.0f && zn <= 1.0f) || !(pz > 0.0f)) return 0;
+    const float u = (px * p->fx) / pz + p->mx;
+    const float v = (py * p->fy) / pz + p->my;
+    const float wm1 = (float)(p->width - 1), hm1 = (float)(p->height - 1);
+    const float nx = ((2.0f * u - wm1) / wm1) * 0.95f;
+    const float ny = ((hm1 - 2.0f * v) / hm1) * 0.95f;
+    return nx >= -1.0f && nx <= 1.0f && ny >= -1.0f && ny <= 1.0f;
+  }
   if (!(pz > -f->radius)) return 0;
   if (!(pz < f->zfar + f->radius)) return 0;
   if (!(fmaf(f->xa[0], px, f->xc[0] * pz) >= -f->xr[0])) return 0;
@@ -315,13 +333,24 @@ static void alloc_frame(or_volume* v, const or_frame* f) {
   free(cand);
 }
 
+/* weight_mode 1: (uchar)max(weightSample * 1.5f * (1 - depthZeroOne), 1.0f), depthZeroOne over the sensor depth range; at most 255 */
+static int depth_weight(const or_params* p, float d) {
+  const float z01 = (d - p->depth_min) / (p->depth_max - p->depth_min);
+  const float wf = fmaxf(((float)p->weight_sample * 1.5f) * (1.0f - z01), 1.0f);
+  const int w = wf >= 255.0f ? 255 : (int)wf;
+  return w;
+}
+static uint8_t blend(const or_params* p, uint8_t a, uint8_t b) {
+  if (p->colour_round) return (uint8_t)(0.5f * (float)a + 0.5f * (float)b + 0.5f);   /* combineVoxel upstream: round half up */
+  return (uint8_t)((a + b) / 2);                                                     /* App. C: (v.color + c) / 2, integer division */
+}
+
 /* ---- spec 3.5: integrate / deintegrate one block ---- */
 static void fuse_block(or_volume* v, const or_frame* f, int32_t slot, const uint8_t* rgb, int sign) {
   const or_params* p = &v->p;
   const int32_t bx = v->coords[3 * slot], by = v->coords[3 * slot + 1], bz = v->coords[3 * slot + 2];
   or_voxel* vox = v->voxels + (size_t)slot * OR_BLOCK_VOXELS;
   const float* M = f->Ti;
-  const float wn = (float)p->weight_sample;
   for (int lz = 0; lz < 8; lz++) for (int ly = 0; ly < 8; ly++) {
     const float wy = (float)(8 * by + ly) * p->voxel_size;
     const float wz = (float)(8 * bz + lz) * p->voxel_size;
@@ -350,22 +379,21 @@ static void fuse_block(or_volume* v, const or_frame* f, int32_t slot, const uint
       if (sdf > t) sdf = t;
       or_voxel* q = &vox[lz * 64 + ly * 8 + lx];
       const float wo = (float)q->w;
+      const int wni = p->weight_mode == 1 ? depth_weight(p, d) : p->weight_sample;
+      const float wn = (float)wni;
       if (sign > 0) {
         q->sdf = fmaf(q->sdf, wo, sdf * wn) / (wo + wn);
         if (rgb) {
           const uint8_t* c = rgb + 3 * (size_t)(iy * p->width + ix);
-          if (q->w == 0) { q->r = c[0]; q->g = c[1]; q->b = c[2]; }
-          else {
-            q->r = (uint8_t)((q->r + c[0]) / 2);   /* App. C: (v.color + c) / 2 per channel, integer division */
-            q->g = (uint8_t)((q->g + c[1]) / 2);
-            q->b = (uint8_t)((q->b + c[2]) / 2);
-          }
+          const int first = p->colour_first ? (q->r == 0 && q->g == 0 && q->b == 0) : (q->w == 0);
+          if (first) { q->r = c[0]; q->g = c[1]; q->b = c[2]; }
+          else { q->r = blend(p, q->r, c[0]); q->g = blend(p, q->g, c[1]); q->b = blend(p, q->b, c[2]); }
         }
-        int w = (int)q->w + p->weight_sample;
+        int w = (int)q->w + wni;
         if (w > p->weight_max) w = p->weight_max;
         q->w = (uint8_t)w;
       } else {
-        const int w = (int)q->w - p->weight_sample;
+        const int w = (int)q->w - wni;
         if (w <= 0) { q->sdf = 0.0f; q->r = q->g = q->b = 0; q->w = 0; }
         else { q->sdf = fmaf(q->sdf, wo, -(sdf * wn)) / (wo - wn); q->w = (uint8_t)w; }
       }

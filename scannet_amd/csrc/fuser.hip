@@ -27,7 +27,10 @@
 
 namespace {
 
-// bounding sphere of the block against the four side planes and the z range of the frustum
+// bounding sphere of the block against the four side planes and the z range of the frustum (frustum_mode 0), or -- frustum_mode 1,
+// DESIGN 6b -- VoxelHashing's isSDFBlockInCameraFrustumApprox: the block centre projected, normalised device coordinates x 0.95 inside
+// [-1, 1]^2 x [0, 1] with z normalised by the SENSOR depth range.  Every operation individually rounded, true divisions: oracle/tsdf_oracle.c
+// block_in_frustum runs the same sequence.
 __device__ inline bool block_in_frustum(const ParamsK& P, const FrameK& F, int bx, int by, int bz) {
   const float cx = ((float)(8 * bx) + 3.5f) * P.voxel;
   const float cy = ((float)(8 * by) + 3.5f) * P.voxel;
@@ -35,6 +38,16 @@ __device__ inline bool block_in_frustum(const ParamsK& P, const FrameK& F, int b
   const float px = fmaf(F.Ti[0], cx, fmaf(F.Ti[1], cy, fmaf(F.Ti[2], cz, F.Ti[3])));
   const float py = fmaf(F.Ti[4], cx, fmaf(F.Ti[5], cy, fmaf(F.Ti[6], cz, F.Ti[7])));
   const float pz = fmaf(F.Ti[8], cx, fmaf(F.Ti[9], cy, fmaf(F.Ti[10], cz, F.Ti[11])));
+  if (P.frustum_mode == 1) {   // kernarg scalar: a uniform branch
+    const float zn = ((pz - P.dmin) / (P.dmax - P.dmin)) * 0.95f;
+    if (!(zn >= 0.0f && zn <= 1.0f) || !(pz > 0.0f)) return false;   // also every NaN
+    const float u = (px * P.fx) / pz + P.mx;
+    const float v = (py * P.fy) / pz + P.my;
+    const float wm1 = (float)(P.W - 1), hm1 = (float)(P.H - 1);
+    const float nx = ((2.0f * u - wm1) / wm1) * 0.95f;
+    const float ny = ((hm1 - 2.0f * v) / hm1) * 0.95f;
+    return nx >= -1.0f && nx <= 1.0f && ny >= -1.0f && ny <= 1.0f;
+  }
   bool in = pz > -F.radius;
   in = in && (pz < F.zfar + F.radius);
   in = in && (fmaf(F.xa[0], px, F.xc[0] * pz) >= -F.xr[0]);
@@ -545,6 +558,13 @@ __device__ inline int cvt_i32(float x) {  // v_cvt_i32_f32: truncates, saturates
   return r;
 }
 
+// weight_mode 1 (VoxelHashing): the weight of an observation falls with its depth; (uchar) of the float, at most 255
+__device__ inline int depth_weight(const ParamsK& P, float d) {
+  const float z01 = (d - P.dmin) / (P.dmax - P.dmin);
+  const float wf = fmaxf(((float)P.wsample * 1.5f) * (1.0f - z01), 1.0f);
+  return min(cvt_i32(wf), 255);   // saturating conversion: a masked lane's garbage depth cannot trap
+}
+
 // TAB: the weighted-mean division goes through the LDS reciprocal table (integrate with 1 <= weight_sample <= 256).
 // Rows [J0, J0 + NJ) of the tile (a row = the 64 x 2 voxels one 16 B load per lane covers).  NJ = 4 gives the most
 // independent work per issue slot, NJ = 2 called twice halves the live registers (single-frame, occupancy-bound variant).
@@ -589,19 +609,25 @@ __device__ inline void fuse_project(const ParamsK& P, const float* __restrict__ 
 
 // Phase B: the update of DESIGN.md 3.5 from the gathered depths (colours) into the tile registers.
 // WM (weight mode): 0 = any weight_sample / weight_max, 1 = weight_sample == 1, 2 = weight_sample == 1 and weight_max == 255 (the shipped
-// parameters after the uchar clamp): the weight byte then increments with saturation as ONE add-with-carry on the {rgb, weight} word.
+// parameters after the uchar clamp): the weight byte then increments with saturation as ONE add-with-carry on the {rgb, weight} word;
+// 3 = the observation's weight depends on its depth (sf_params::weight_mode 1), otherwise as 0.
 // dirty[j]: lane mask (a scalar register pair) of the lanes whose row j changed -- kept on the scalar unit across the frames of a batch.
 template <int SIGN, bool COLOR, bool TAB, int WM, int J0, int NJ>
 __device__ inline void fuse_update(const ParamsK& P, const v2f (&rcp_m)[NJ], const float (&d)[2 * NJ], const uint32_t (&c)[2 * NJ], const v2f (&pz)[NJ],
                                    const bool (&ok)[2 * NJ], uint4 (&v)[4], uint64_t (&dirty)[4]) {
-  constexpr bool WS1 = WM >= 1;
+  constexpr bool WS1 = WM == 1 || WM == 2;
   // ---- phase B1: which voxels does this frame update?  Then a wave-uniform early-out: 10-25 % of the (block, frame) pairs the frustum
   // test lets through update nothing (blocks behind the surface, beyond the integration distance, over invalid depth, in the sliver
   // between the image border and the conservative sphere test) -- everything below (weighted mean, weights, selects: ~40 % of the
   // instructions of a frame) is skipped for them.  Measured on the configs[1] stream with the CPU checker: tools/waste.py.
   const float wn = (float)P.wsample;
+  const uint32_t round_mask = P.colour_round ? 0x010101u : 0u;             // scalar registers
+  const uint32_t first_mask = P.colour_first ? 0x00FFFFFFu : 0xFF000000u;
+  constexpr bool wdep = WM == 3;   // depth-dependent observation weight (sf_params::weight_mode 1): its own instantiation, the generic path pays nothing for it
   const uint32_t maxd_bits = __float_as_uint(P.maxd);
   v2f q[NJ], sdfc[NJ];
+  v2f wnv[NJ];          // weight of this observation per voxel (a splat unless wdep)
+  int wni[2 * NJ];
   uint32_t ncw[2 * NJ];
   bool upd[2 * NJ];
   bool sat[2 * NJ];
@@ -618,7 +644,9 @@ __device__ inline void fuse_update(const ParamsK& P, const v2f (&rcp_m)[NJ], con
       sdf[hx] = min_f32(sdf[hx], t[hx]);
       sat[2 * j + hx] = false;
       any_upd = any_upd || upd[2 * j + hx];
+      wni[2 * j + hx] = wdep ? depth_weight(P, dk[hx]) : P.wsample;
     }
+    wnv[j] = wdep ? (v2f){(float)wni[2 * j], (float)wni[2 * j + 1]} : splat(wn);
     sdfc[j] = sdf;
   }
   if (!__any((int)any_upd)) return;
@@ -631,8 +659,8 @@ __device__ inline void fuse_update(const ParamsK& P, const v2f (&rcp_m)[NJ], con
     const v2f wo = {(float)(cwj[0] >> 24), (float)(cwj[1] >> 24)};
     const v2f old = {__uint_as_float(v[J0 + j].x), __uint_as_float(v[J0 + j].z)};
     if (SIGN > 0) {
-      const v2f n = pk_fma(old, wo, WS1 ? sdf : sdf * splat(wn));  // x * 1.0f == x bit for bit
-      const v2f m = wo + splat(wn);
+      const v2f n = pk_fma(old, wo, WS1 ? sdf : sdf * wnv[j]);  // x * 1.0f == x bit for bit
+      const v2f m = wo + wnv[j];
       if (TAB) {
         q[j] = quot_rn(n, m, rcp_m[j]);
         slow = slow || (fabsf(n.x) < 0x1p-100f) || (fabsf(n.y) < 0x1p-100f);
@@ -647,9 +675,14 @@ __device__ inline void fuse_update(const ParamsK& P, const v2f (&rcp_m)[NJ], con
         if (COLOR) {
           // (a + b) / 2 per channel (integer division), the three channels at once: (a & b) + ((a ^ b) >> 1) on each byte
           // (no carry crosses a byte: the sum is at most 255; the mask keeps a byte's low bit out of its neighbour's top bit)
+          // colour_round 1 (combineVoxel upstream): (uchar)(0.5f a + 0.5f b + 0.5f) = (a + b + 1) >> 1 = (a | b) - ((a ^ b) >> 1);
+          // colour_first 1: "first observation" is a black accumulated colour instead of a zero weight
+          // Both switches as wave-uniform MASKS, not branches (a branch doubled the scalar code of the colour kernels): the round-half-up average
+          // is the truncated one plus the low bit of a ^ b per channel, and "first" tests the weight byte or the colour bytes of the word.
           const uint32_t ck = c[2 * j + hx];
-          const uint32_t avg = (rgb & ck) + (((rgb ^ ck) & 0xFEFEFEu) >> 1);
-          rgb = w == 0 ? ck : avg;
+          const uint32_t x = rgb ^ ck;
+          const uint32_t avg = (rgb & ck) + ((x & 0xFEFEFEu) >> 1) + (x & round_mask);
+          rgb = (cw & first_mask) == 0u ? ck : avg;
         }
         if (WM == 2) {
           // weight byte + 1, saturating at 255: the add carries out of the word exactly when the weight was 255 -- then keep it
@@ -659,18 +692,18 @@ __device__ inline void fuse_update(const ParamsK& P, const v2f (&rcp_m)[NJ], con
           if (COLOR) ncw[2 * j + hx] = full ? base : inc;
           else { ncw[2 * j + hx] = inc; sat[2 * j + hx] = full; }   // without colour "keep it" is "do not touch the word": folded into the final select
         } else {
-          uint32_t nw = w + (uint32_t)P.wsample;
+          uint32_t nw = w + (uint32_t)wni[2 * j + hx];
           if (nw > (uint32_t)P.wmax) nw = (uint32_t)P.wmax;
           ncw[2 * j + hx] = rgb | (nw << 24);
         }
       }
     } else {
-      const v2f n = pk_fma(old, wo, -(sdf * splat(wn)));
-      const v2f m = wo - splat(wn);
+      const v2f n = pk_fma(old, wo, -(sdf * wnv[j]));
+      const v2f m = wo - wnv[j];
       q[j] = (v2f){n.x / m.x, n.y / m.y};  // discarded when the weight drops to <= 0 (then m <= 0)
 #pragma unroll
       for (int hx = 0; hx < 2; hx++) {
-        const int nw = (int)(cwj[hx] >> 24) - P.wsample;
+        const int nw = (int)(cwj[hx] >> 24) - wni[2 * j + hx];
         if (nw <= 0) { q[j][hx] = __uint_as_float(0u); ncw[2 * j + hx] = 0u; }
         else ncw[2 * j + hx] = (cwj[hx] & 0xFFFFFFu) | ((uint32_t)nw << 24);
       }
@@ -682,8 +715,8 @@ __device__ inline void fuse_update(const ParamsK& P, const v2f (&rcp_m)[NJ], con
     for (int j = 0; j < NJ; j++) {
       const v2f wo = {(float)(v[J0 + j].y >> 24), (float)(v[J0 + j].w >> 24)};
       const v2f old = {__uint_as_float(v[J0 + j].x), __uint_as_float(v[J0 + j].z)};
-      const v2f n = pk_fma(old, wo, sdfc[j] * splat(wn));
-      const v2f m = wo + splat(wn);
+      const v2f n = pk_fma(old, wo, sdfc[j] * wnv[j]);
+      const v2f m = wo + wnv[j];
       q[j] = (v2f){n.x / m.x, n.y / m.y};
     }
   }
@@ -719,7 +752,7 @@ __device__ inline void fuse_rows(const ParamsK& P, const float* __restrict__ Ti,
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
       // weight_sample == 1 in the shipped parameters (WM >= 1): a constant index offset folds into the LDS instruction's immediate
-      const uint32_t ws = WM >= 1 ? 1u : (uint32_t)P.wsample;
+      const uint32_t ws = (WM == 1 || WM == 2) ? 1u : (uint32_t)P.wsample;
       rcp_m[j] = (v2f){rtab[(v[J0 + j].y >> 24) + ws], rtab[(v[J0 + j].w >> 24) + ws]};
     }
   }
@@ -1121,6 +1154,9 @@ __global__ __launch_bounds__(256) void k_rehash(HashEntry* table, const uint64_t
       }
       at++;
       if (at == P.total_slots) at = 0;
+      // no slot within MAX_PROBES (the rebuild inserts in directory order, a key can land further from home than it was): the block stays in
+      // the directory but cannot be looked up -- counted, sf_fuser_garbage_collect reports SF_ERR_CAPACITY
+      if (probe == MAX_PROBES - 1) atomicAdd(&counters[C_ALLOC_FAIL], 1);
     }
   }
 }
@@ -1258,7 +1294,7 @@ bool frame_setup(const sf_params& p, const float* pose, FrameK& f) {
 // on the front stream would only get CUs by starving some of its waves (measured: 113 us overlapped vs 90 us alone, and no
 // more frames/s), so such a batch goes down ONE stream, pre-pass to integrate.
 static bool pipe_batch(const sf_fuser* f, int n, bool color, int sign) {
-  const bool tab_ok = f->p.weight_sample >= 1 && f->p.weight_sample <= RTAB - 256;
+  const bool tab_ok = f->p.weight_sample >= 1 && f->p.weight_sample <= RTAB - 256 && f->p.weight_mode == 0;
   return sign > 0 && n == 1 && !color && tab_ok && f->pipe_mode != 0;
 }
 // Whether the next frame's pre-pass / allocation / compaction should run on the front stream beside the persistent kernel.  Measured on
@@ -1301,7 +1337,8 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
   // One frame per launch without colour runs the persistent k_integrate_pipe, which fills every CU: kernels of the next frame
   // on the front stream would only get CUs by starving some of its waves (measured: 113 us overlapped vs 90 us alone, and
   // no more frames/s), so for such a frame everything goes down ONE stream.
-  const bool tab_ok = f->p.weight_sample >= 1 && f->p.weight_sample <= RTAB - 256;
+  const bool tab_ok = f->p.weight_sample >= 1 && f->p.weight_sample <= RTAB - 256 && f->p.weight_mode == 0;   // the table is indexed by weight + sample
+  const bool ws1 = f->p.weight_sample == 1 && f->p.weight_mode == 0;   // every observation weighs exactly 1
   const bool pipe = pipe_batch(f, n, col, sign);
   hipStream_t sa = sf_input_stream(f, n, col, sign);  // callers stage the batch's frames on this stream too
   if (f->overlap && sa != s) {
@@ -1367,16 +1404,18 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
     else hipLaunchKernelGGL((k_integrate_pipe<true, WMODE, false>), pg, dim3(256), 0, s, f->voxels, f->block_keys, f->compact2[sl],            \
                             f->depthf2[sl], f->counters, f->host_mirror, cc, f->pk, bt);                                                       \
   } while (0)
-    if (f->p.weight_sample == 1 && f->pk.wmax == 255) LAUNCH_PIPE(2);
-    else if (f->p.weight_sample == 1) LAUNCH_PIPE(1);
+    if (ws1 && f->pk.wmax == 255) LAUNCH_PIPE(2);
+    else if (ws1) LAUNCH_PIPE(1);
     else LAUNCH_PIPE(0);
 #undef LAUNCH_PIPE
   } else if (sign > 0) {
-    if (f->p.weight_sample == 1 && f->pk.wmax == 255) { if (col) LAUNCH_INT(1, true, true, 2); else LAUNCH_INT(1, false, true, 2); }  // the shipped setting
-    else if (f->p.weight_sample == 1) { if (col) LAUNCH_INT(1, true, true, 1); else LAUNCH_INT(1, false, true, 1); }
+    if (ws1 && f->pk.wmax == 255) { if (col) LAUNCH_INT(1, true, true, 2); else LAUNCH_INT(1, false, true, 2); }  // the shipped setting
+    else if (ws1) { if (col) LAUNCH_INT(1, true, true, 1); else LAUNCH_INT(1, false, true, 1); }
     else if (tab)                { if (col) LAUNCH_INT(1, true, true, 0); else LAUNCH_INT(1, false, true, 0); }
+    else if (f->p.weight_mode == 1) { if (col) LAUNCH_INT(1, true, false, 3); else LAUNCH_INT(1, false, false, 3); }
     else                         { if (col) LAUNCH_INT(1, true, false, 0); else LAUNCH_INT(1, false, false, 0); }
-  } else                         { if (col) LAUNCH_INT(-1, true, false, 0); else LAUNCH_INT(-1, false, false, 0); }
+  } else if (f->p.weight_mode == 1) { if (col) LAUNCH_INT(-1, true, false, 3); else LAUNCH_INT(-1, false, false, 3); }
+  else                           { if (col) LAUNCH_INT(-1, true, false, 0); else LAUNCH_INT(-1, false, false, 0); }
 #undef LAUNCH_INT
   if (f->profile) (void)hipEventRecord(e1, s);
   if (f->overlap && sa != s) (void)hipEventRecord(f->ev_fused[sl], s);
@@ -1420,6 +1459,10 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
   if ((p->integration_width > 0) != (p->integration_height > 0) || p->integration_width == 1 || p->integration_height == 1 ||
       (p->integration_width > 0 && (p->depth_width < 2 || p->depth_height < 2)))
     return sf::fail(SF_ERR_INVALID_ARG, "integration size %d x %d", p->integration_width, p->integration_height);
+  if ((p->frustum_mode | p->colour_round | p->colour_first | p->weight_mode) & ~1)
+    return sf::fail(SF_ERR_INVALID_ARG, "frustum_mode / colour_round / colour_first / weight_mode must be 0 or 1");
+  if (p->frustum_mode == 1 && !(p->depth_max > p->depth_min))
+    return sf::fail(SF_ERR_INVALID_ARG, "frustum_mode 1 normalises z by the sensor depth range: depth_max must exceed depth_min");
   if ((uint64_t)p->hash_num_buckets * p->hash_bucket_size > 0x7FFFFFFFull || p->num_sdf_blocks > 0x3FFFFFFFu)
     return sf::fail(SF_ERR_INVALID_ARG, "hash table / heap too large for 32-bit slot indices");
   int ndev = 0;
@@ -1472,6 +1515,7 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
   k.cW = p->color_width > 0 && p->color_height > 0 ? p->color_width : 0;
   k.cH = k.cW ? p->color_height : 0;
   k.cfx = p->cfx; k.cfy = p->cfy; k.cmx = p->cmx; k.cmy = p->cmy;
+  k.frustum_mode = p->frustum_mode; k.colour_round = p->colour_round; k.colour_first = p->colour_first; k.weight_mode = p->weight_mode;
   if (resample && k.cW == 0) {   // colour frames at the INPUT depth resolution: "their own resolution" as far as the integration camera is concerned
     k.cW = p->depth_width; k.cH = p->depth_height;
     k.cfx = p->fx; k.cfy = p->fy; k.cmx = p->mx; k.cmy = p->my;
@@ -1553,6 +1597,38 @@ SF_API void sf_fuser_destroy(sf_fuser* f) {
   if (f->host_mirror) (void)hipHostFree(f->host_mirror);
   if (f->stream) (void)hipStreamDestroy(f->stream);
   delete f;
+}
+
+// Back to the state sf_fuser_create leaves: empty table, full heap, zeroed tiles (only the slots ever handed out are touched: a 4 mm room is
+// ~0.5 GB of the 4.3 GB reserved), counters and frame numbering restarted; parameters, streams and tuning stay.  What the reference's tools do
+// between two scans is to exit and start again (Server/scan_processor.py:137-141 runs one process per scan); a long-lived caller -- the scan
+// queue of scannet_amd/shard.py, bench.py's repetitions -- keeps the 4+ GB allocation instead.
+SF_API int sf_fuser_reset(sf_fuser* f) {
+  if (!f) return sf::fail(SF_ERR_INVALID_ARG, "NULL fuser");
+  SF_HIP_CHECK(hipSetDevice(f->device));
+  SF_HIP_CHECK(sf_quiesce(f));
+  int32_t hw = 0;
+  SF_HIP_CHECK(hipMemcpy(&hw, &f->counters[C_HIGH_WATER], 4, hipMemcpyDeviceToHost));
+  const ParamsK& k = f->pk;
+  if (hw < 0 || (uint32_t)hw > k.num_blocks) hw = (int32_t)k.num_blocks;
+  SF_HIP_CHECK(hipMemsetAsync(f->table, 0xFF, (size_t)k.total_slots * sizeof(HashEntry), f->stream));
+  if (hw > 0) {
+    SF_HIP_CHECK(hipMemsetAsync(f->voxels, 0, (size_t)hw * 4096, f->stream));
+    SF_HIP_CHECK(hipMemsetAsync(f->block_flags, 0, (size_t)hw, f->stream));
+  }
+  SF_HIP_CHECK(hipMemsetAsync(f->counters, 0, C_COUNT * 4, f->stream));
+  hipLaunchKernelGGL(k_init_heap, dim3((k.num_blocks + 255) / 256), dim3(256), 0, f->stream, f->heap, f->block_keys, (int)k.num_blocks);
+  const int32_t free0 = (int32_t)k.num_blocks;
+  SF_HIP_CHECK(hipMemcpyAsync(&f->counters[C_HEAP_FREE], &free0, 4, hipMemcpyHostToDevice, f->stream));
+  SF_HIP_CHECK(sf_quiesce(f));
+  *f->host_mirror = 0;
+  f->frame_seq = 1;
+  f->slot = 0;
+  f->serial_tail = false;
+  f->pipe_beside = f->pipe_overlap == 1;
+  f->frames_integrated = f->frames_skipped = 0;
+  f->events_used = 0;
+  return SF_OK;
 }
 
 static int fuse_host(sf_fuser* f, const uint16_t* depth, const uint8_t* rgb, const float* pose, int sign) {
@@ -1647,23 +1723,34 @@ SF_API int sf_fuser_tune(sf_fuser* f, const char* key, int value) {
     // allocation / compaction of the NEXT pass while the rest runs integrate -- the short latency-bound kernels no longer queue behind (or
     // squeeze in between) the workgroups of the bandwidth-bound one.  0: both streams on every CU.
     const int ncu = f->num_cus;
+    if (value >= ncu) return sf::fail(SF_ERR_INVALID_ARG, "sf_fuser_tune: front_cus = %d on a device with %d CUs (the main stream needs at least one)", value, ncu);
     std::vector<uint32_t> front_mask((size_t)(ncu + 31) / 32, 0u), main_mask((size_t)(ncu + 31) / 32, 0u);
+    const int every = value > 0 ? ncu / value : 0;   // >= 1 because value < ncu
     for (int c = 0; c < ncu; c++) {
-      const bool to_front = value > 0 && (c % (ncu / value)) == 0 && (c / (ncu / value)) < value;
+      const bool to_front = value > 0 && (c % every) == 0 && (c / every) < value;
       (to_front ? front_mask : main_mask)[(size_t)c / 32] |= 1u << (c % 32);
+    }
+    // the new pair first: a failure leaves the fuser on its old streams instead of on none
+    hipStream_t ns = nullptr, nf = nullptr;
+    hipError_t e;
+    if (value == 0) {
+      int prio_lo = 0, prio_hi = 0;
+      e = hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+      if (e == hipSuccess) e = hipStreamCreateWithFlags(&ns, hipStreamNonBlocking);
+      if (e == hipSuccess) e = hipStreamCreateWithPriority(&nf, hipStreamNonBlocking, prio_hi);
+    } else {
+      e = hipExtStreamCreateWithCUMask(&ns, (uint32_t)main_mask.size(), main_mask.data());
+      if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&nf, (uint32_t)front_mask.size(), front_mask.data());
+    }
+    if (e != hipSuccess) {
+      if (ns) (void)hipStreamDestroy(ns);
+      if (nf) (void)hipStreamDestroy(nf);
+      return sf::fail(SF_ERR_DEVICE, "sf_fuser_tune: front_cus = %d: %s", value, hipGetErrorString(e));
     }
     (void)hipStreamDestroy(f->stream);
     (void)hipStreamDestroy(f->front);
-    f->stream = f->front = nullptr;
-    if (value == 0) {
-      int prio_lo = 0, prio_hi = 0;
-      SF_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-      SF_HIP_CHECK(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
-      SF_HIP_CHECK(hipStreamCreateWithPriority(&f->front, hipStreamNonBlocking, prio_hi));
-    } else {
-      SF_HIP_CHECK(hipExtStreamCreateWithCUMask(&f->stream, (uint32_t)main_mask.size(), main_mask.data()));
-      SF_HIP_CHECK(hipExtStreamCreateWithCUMask(&f->front, (uint32_t)front_mask.size(), front_mask.data()));
-    }
+    f->stream = ns;
+    f->front = nf;
     f->front_cus = value;
   }
   else if (k == "alloc_group" && in(1, MAX_BATCH)) f->alloc_group = value;
@@ -1800,13 +1887,17 @@ SF_API int sf_fuser_garbage_collect(sf_fuser* f, uint32_t* freed) {
   int32_t fr = 0;
   SF_HIP_CHECK(hipMemcpyAsync(&fr, &f->counters[C_GC_FREED], 4, hipMemcpyDeviceToHost, f->stream));
   SF_HIP_CHECK(sf_quiesce(f));
+  int32_t fail0 = 0, fail1 = 0;
   if (fr > 0) {   // leave no tombstone behind: rebuild the table from the directory
+    SF_HIP_CHECK(hipMemcpyAsync(&fail0, &f->counters[C_ALLOC_FAIL], 4, hipMemcpyDeviceToHost, f->stream));
     SF_HIP_CHECK(hipMemsetAsync(f->table, 0xFF, (size_t)f->pk.total_slots * sizeof(HashEntry), f->stream));
     SF_HIP_CHECK(hipMemsetAsync(&f->counters[C_SLOTS_USED], 0, 4, f->stream));
     hipLaunchKernelGGL(k_rehash, dim3(f->compact_grid), dim3(256), 0, f->stream, f->table, f->block_keys, f->block_entry, f->counters, f->pk);
+    SF_HIP_CHECK(hipMemcpyAsync(&fail1, &f->counters[C_ALLOC_FAIL], 4, hipMemcpyDeviceToHost, f->stream));
     SF_HIP_CHECK(sf_quiesce(f));
   }
   if (freed) *freed = (uint32_t)fr;
+  if (fail1 != fail0) return sf::fail(SF_ERR_CAPACITY, "garbage collection: %d surviving blocks found no hash slot within %d probes when the table was rebuilt", fail1 - fail0, MAX_PROBES);
   return SF_OK;
 }
 

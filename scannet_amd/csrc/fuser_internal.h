@@ -38,6 +38,8 @@ struct ParamsK {
   // input depth frames at inW x inH resampled (nearest) to W x H by the pre-pass; inW == 0: the frames are W x H already
   int inW, inH;
   float rsx, rsy;   // (inW - 1) / (W - 1), (inH - 1) / (H - 1)
+  // upstream-conformance switches (scanfuse.h sf_params; 0 everywhere = SURVEY App. C)
+  int frustum_mode, colour_round, colour_first, weight_mode;
 };
 
 __host__ __device__ inline bool slab_owns_coord(const ParamsK& P, int c) {

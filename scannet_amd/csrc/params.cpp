@@ -52,6 +52,7 @@ SF_API void sf_params_default(sf_params* p) {
   p->color_width = 0; p->color_height = 0;
   p->cfx = p->cfy = p->cmx = p->cmy = 0.0f;
   p->integration_width = p->integration_height = 0;   // integrate at the input resolution (BASELINE.json's 640x480)
+  p->frustum_mode = p->colour_round = p->colour_first = p->weight_mode = 0;   // SURVEY App. C throughout (scanfuse.h: upstream-conformance switches)
 }
 
 namespace {
@@ -151,6 +152,11 @@ SF_API int sf_params_load_file(const char* path, sf_params* p) {
   // zParametersScanNet.txt:20-21: the size the input depth is resampled to (the input size itself comes from the .sens file)
   v = p->integration_width;  if ((rc = geti("s_integrationWidth", &v)) != SF_OK) return rc; p->integration_width = (int32_t)v;
   v = p->integration_height; if ((rc = geti("s_integrationHeight", &v)) != SF_OK) return rc; p->integration_height = (int32_t)v;
+  // upstream-conformance switches (scanfuse.h): not keys of the upstream tools, which ignore names they do not know
+  v = p->frustum_mode; if ((rc = geti("s_scanfuseFrustumMode", &v)) != SF_OK) return rc; p->frustum_mode = (int32_t)v;
+  v = p->colour_round; if ((rc = geti("s_scanfuseColourRound", &v)) != SF_OK) return rc; p->colour_round = (int32_t)v;
+  v = p->colour_first; if ((rc = geti("s_scanfuseColourFirst", &v)) != SF_OK) return rc; p->colour_first = (int32_t)v;
+  v = p->weight_mode;  if ((rc = geti("s_scanfuseWeightMode", &v)) != SF_OK) return rc;  p->weight_mode = (int32_t)v;
   if (!(p->voxel_size > 0) || p->hash_num_buckets == 0 || p->num_sdf_blocks == 0)
     return sf::fail(SF_ERR_FORMAT, "%s: non-positive voxel size / hash size", path);
   return SF_OK;

@@ -94,7 +94,9 @@ bool unfilter_pass(const uint8_t* raw, size_t raw_len, size_t& used, uint32_t pw
 }
 
 // PNG in memory -> samples.  check_crc: verify the chunk CRCs (files of the annotation tools; the reference's stb reader does not).
-int png_decode(const uint8_t* file, size_t n, bool check_crc, PngImage& img, const char* name) {
+// expect_w / expect_h (0 = any size) and max_depth are enforced on the IHDR itself, before anything is allocated: a colour frame of a .sens is
+// untrusted input, and a 40-byte file may announce 2^30 pixels.
+int png_decode(const uint8_t* file, size_t n, bool check_crc, PngImage& img, const char* name, uint32_t expect_w = 0, uint32_t expect_h = 0, int max_depth = 16) {
   static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
   if (n < 33 || std::memcmp(file, sig, 8) != 0) return sf::fail(SF_ERR_FORMAT, "%s is not a PNG file", name);
   std::vector<uint8_t> idat;
@@ -112,6 +114,9 @@ int png_decode(const uint8_t* file, size_t n, bool check_crc, PngImage& img, con
       if (body[10] != 0 || body[11] != 0) return sf::fail(SF_ERR_FORMAT, "%s: unknown compression / filter method", name);
       if (body[12] > 1) return sf::fail(SF_ERR_FORMAT, "%s: unknown interlace method", name);
       img.interlaced = body[12] == 1;
+      if ((expect_w && img.w != expect_w) || (expect_h && img.h != expect_h))
+        return sf::fail(SF_ERR_FORMAT, "%s is %ux%u, header says %ux%u", name, img.w, img.h, expect_w, expect_h);
+      if (img.depth > max_depth) return sf::fail(SF_ERR_UNSUPPORTED, "%s: %d-bit samples (limit %d)", name, img.depth, max_depth);
       have_ihdr = true;
     } else if (!have_ihdr) return sf::fail(SF_ERR_FORMAT, "%s: first chunk is not IHDR", name);
     else if (std::memcmp(type, "PLTE", 4) == 0) {
@@ -143,6 +148,9 @@ int png_decode(const uint8_t* file, size_t n, bool check_crc, PngImage& img, con
     const uint32_t pw = img.interlaced ? (img.w - XO[p] + XS[p] - 1) / XS[p] : img.w, ph = img.interlaced ? (img.h - YO[p] + YS[p] - 1) / YS[p] : img.h;
     if (pw && ph) raw_len += (((size_t)pw * img.channels * d + 7) / 8 + 1) * ph;
   }
+  // deflate cannot expand by more than 1032 : 1 (a 258-byte match from two bits): an image the IDAT bytes cannot possibly fill is
+  // rejected before its buffer is allocated and zero-filled
+  if (raw_len > idat.size() * 1032 + 1024) return sf::fail(SF_ERR_FORMAT, "%s: %zu bytes of image data announced, %zu compressed bytes present", name, raw_len, idat.size());
   std::vector<uint8_t> raw(raw_len);
   uint64_t got = 0;
   if (sf_zlib_inflate(idat.data(), idat.size(), raw.data(), raw.size(), &got) != SF_OK) return sf::fail(SF_ERR_FORMAT, "%s: %s", name, sf_last_error());
@@ -167,10 +175,9 @@ int png_decode(const uint8_t* file, size_t n, bool check_crc, PngImage& img, con
 // grey of depth < 8 scaled to 0..255 (x 255 / 85 / 17), grey -> r = g = b, palette expanded, alpha dropped.
 int png_decode_rgb(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t expect_w, uint32_t expect_h) {
   PngImage img;
-  const int rc = png_decode(data, (size_t)n, false, img, "png colour frame");
+  // size and depth (the reference decoder reads 1/2/4/8-bit PNGs only, stb_image.h:4350) are checked on the IHDR, before any allocation
+  const int rc = png_decode(data, (size_t)n, false, img, "png colour frame", expect_w, expect_h, 8);
   if (rc != SF_OK) return rc;
-  if (img.depth == 16) return sf::fail(SF_ERR_UNSUPPORTED, "png colour frame: 16-bit samples (the reference decoder reads 1/2/4/8-bit PNGs only, stb_image.h:4350)");
-  if (img.w != expect_w || img.h != expect_h) return sf::fail(SF_ERR_FORMAT, "png colour frame is %ux%u, header says %ux%u", img.w, img.h, expect_w, expect_h);
   const size_t npx = (size_t)img.w * img.h;
   const uint8_t* s = img.samples.data();
   const int scale = img.ctype == 0 ? (img.depth == 1 ? 255 : img.depth == 2 ? 85 : img.depth == 4 ? 17 : 1) : 1;

@@ -135,6 +135,12 @@ class Fuser:
         """Frames fused per pass over the voxel tiles by integrate_batch_device / run (default 16; tune(batch=...))."""
         return int(_abi.lib().sf_fuser_batch_frames(self._h))
 
+    def reset(self):
+        """Empty volume again; parameters, streams and tuning stay (sf_fuser_reset)."""
+        L = _abi.lib()
+        L.sf_fuser_reset.argtypes = [C.c_void_p]
+        check(L.sf_fuser_reset(self._h))
+
     def garbage_collect(self):
         n = C.c_uint32(0)
         check(_abi.lib().sf_fuser_garbage_collect(self._h, C.byref(n)))

@@ -569,3 +569,235 @@ def test_gpu_mesh_matches_the_literal_marching_cubes():
     res = spec_literal_mc_check(coords[order], vox[order], dict(keys=keys, pos=xyz, col=rgba[:, :3], idx=tris), 0.01, gp.mc_thresh_factor)
     assert res["vertices"] > 20000, res
     print("literal marching cubes:", res)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# The regime the benchmark runs in: weights at the clamp (zParametersScanNet.txt:52-53: weight sample 1, weight max 99999999 -> 255 in the
+# uchar).  After 255 observations of a voxel every further frame goes through the saturation branch of fuse_update (add-with-carry on the
+# packed word for the shipped parameters, the explicit clamp otherwise) and the reciprocal table at m = 256.
+# ---------------------------------------------------------------------------------------------------------------------------------------
+class _DeviceFrames:
+    """u16 depth frames (and optionally rgb) uploaded once; integrate_batch_device over a range of them."""
+
+    def __init__(self, depth, rgb=None):
+        import ctypes as C
+        from scannet_amd import _abi
+        self.L, self.C, self._abi = _abi.lib(), C, _abi
+        self.depth = np.ascontiguousarray(depth, np.uint16)
+        self.rgb = None if rgb is None else np.ascontiguousarray(rgb, np.uint8)
+        self.d = C.c_void_p()
+        self.c = C.c_void_p()
+        _abi.check(self.L.sf_device_malloc(0, self.depth.nbytes, C.byref(self.d)))
+        _abi.check(self.L.sf_device_upload(self.d, self.depth.ctypes.data_as(C.c_void_p), self.depth.nbytes))
+        if self.rgb is not None:
+            _abi.check(self.L.sf_device_malloc(0, self.rgb.nbytes, C.byref(self.c)))
+            _abi.check(self.L.sf_device_upload(self.c, self.rgb.ctypes.data_as(C.c_void_p), self.rgb.nbytes))
+        self.dstride = self.depth[0].nbytes
+        self.cstride = 0 if self.rgb is None else self.rgb[0].nbytes
+
+    def fuse(self, fuser, poses, a, b):
+        fuser.integrate_batch_device(self.d.value + a * self.dstride, self.dstride, poses[a:b],
+                                     None if self.rgb is None else self.c.value + a * self.cstride, self.cstride)
+
+    def close(self):
+        self.L.sf_device_free(self.d)
+        if self.c:
+            self.L.sf_device_free(self.c)
+
+
+def _static_view_stream(W, H, n, wobble_every=0, seed=11, colour=False):
+    """n frames of ONE view of the box room (so every visible voxel is observed n times) with fresh sensor noise per frame; every
+    `wobble_every`-th frame looks from elsewhere (new blocks are born in the middle of passes, old ones drop out of the frustum)."""
+    rng = np.random.default_rng(seed)
+    depth = np.zeros((n, H, W), np.uint16)
+    poses = np.zeros((n, 16), np.float32)
+    rgb = rng.integers(0, 256, (n, H, W, 3), dtype=np.uint8) if colour else None
+    for i in range(n):
+        k = 40 if not (wobble_every and i % wobble_every == wobble_every - 1) else 40 + 3 * (i // wobble_every + 1)
+        pose = synth.trajectory_pose(k, 400)
+        depth[i] = synth.render_room_depth(pose, W, H, noise_frame=i)
+        poses[i] = pose.reshape(16)
+    if colour:
+        rgb[:, : H // 3] = 0   # a black band: sf_params::colour_first tells "no colour yet" from "black" differently
+    return depth, poses, rgb
+
+
+@pytest.mark.parametrize("schedule,colour", [("batch16", False), ("pipe", False), ("one_frame_kernel", False), ("batch16", True), ("one_frame_kernel", True)])
+def test_weights_at_the_clamp_match_the_oracle(oracle, schedule, colour):
+    """320 frames onto one 160x120 view: weights pass 255.  Compared bit for bit with the oracle below the clamp (130 frames), right at it (256)
+    and 64 frames beyond, through the 16-frame pass, the persistent one-frame kernel (k_integrate_pipe) and k_integrate at one frame per launch."""
+    from scannet_amd import fusion
+    W, H, N = 160, 120, 320
+    op, gp = _mk(oracle, W, H, voxel=0.01, num_sdf_blocks=1 << 15)
+    depth, poses, rgb = _static_view_stream(W, H, N, wobble_every=37, colour=colour)
+    tune = {"batch16": {}, "pipe": {"batch": 1}, "one_frame_kernel": {"batch": 1, "pipe": 0}}[schedule]
+    ovol = oracle.Volume(op, threads=8)
+    dev = _DeviceFrames(depth, rgb)
+    try:
+        with fusion.Fuser(gp, **tune) as f:
+            a = 0
+            for b in (130, 256, N):
+                for i in range(a, b):
+                    ovol.integrate(depth[i], poses[i].reshape(4, 4), rgb=None if rgb is None else rgb[i])
+                dev.fuse(f, poses, a, b)
+                _assert_same(ovol, f)
+                a = b
+            _, gv = f.export_blocks()
+            assert (gv["w"] == 255).mean() > 0.3, "the test is supposed to sit at the clamp"
+            assert f.stats()["alloc_failures"] == 0
+            # and back down from the clamp: 255 - 1, the mean un-weighted with the weight the voxel HOLDS (not the number of frames it saw)
+            for i in (N - 1, N - 2, 200):
+                ovol.deintegrate(depth[i], poses[i].reshape(4, 4), rgb=None if rgb is None else rgb[i])
+                assert f.deintegrate(depth[i], poses[i].reshape(4, 4), rgb=None if rgb is None else rgb[i])
+            _assert_same(ovol, f)
+    finally:
+        dev.close()
+
+
+@pytest.mark.parametrize("weight_max", [3, 7])
+@pytest.mark.parametrize("weight_sample", [1, 2, 5])
+def test_small_weight_limits_match_the_oracle(oracle, weight_max, weight_sample):
+    """weight_max in {3, 7} x weight_sample in {1, 2, 5}: the clamp of the generic weight path (weight + sample > max after one or two frames,
+    sample > max included), 16 frames per pass and one per launch, then deintegration from the clamped weight."""
+    from scannet_amd import fusion
+    W, H, N = 160, 120, 20
+    depth, poses, _ = _static_view_stream(W, H, N, wobble_every=7)
+    for tune in ({}, {"batch": 1}, {"batch": 1, "pipe": 0}):
+        op, gp = _mk(oracle, W, H, voxel=0.01, num_sdf_blocks=1 << 15, weight_max=weight_max, weight_sample=weight_sample)
+        ovol = oracle.Volume(op, threads=8)
+        dev = _DeviceFrames(depth)
+        try:
+            with fusion.Fuser(gp, **tune) as f:
+                for i in range(N):
+                    ovol.integrate(depth[i], poses[i].reshape(4, 4))
+                dev.fuse(f, poses, 0, N)
+                _assert_same(ovol, f)
+                _, gv = f.export_blocks()
+                assert gv["w"].max() == weight_max
+                for i in (N - 1, 3):
+                    ovol.deintegrate(depth[i], poses[i].reshape(4, 4))
+                    assert f.deintegrate(depth[i], poses[i].reshape(4, 4))
+                _assert_same(ovol, f)
+        finally:
+            dev.close()
+
+
+def test_weights_at_the_clamp_at_full_size(oracle):
+    """BASELINE configs[1] geometry (640x480, 4 mm, default parameters): 288 frames of one view through the 16-frame pass -- the kernel, the
+    frame size, the voxel size and the weight regime bench.py times -- bit for bit against the oracle."""
+    from scannet_amd import fusion
+    W, H, N = 640, 480, 288
+    op, gp = _mk(oracle, W, H, num_sdf_blocks=1 << 18)
+    rng = np.random.default_rng(5)
+    pose = synth.trajectory_pose(700, 5578)
+    base = synth.render_room_depth(pose, W, H).astype(np.int32)
+    depth = np.zeros((N, H, W), np.uint16)
+    for i in range(N):
+        depth[i] = np.where(base > 0, base + rng.integers(0, 8, base.shape), 0)   # 3 random LSBs per pixel and frame (SURVEY section 6 probe)
+    poses = np.tile(pose.reshape(1, 16), (N, 1)).astype(np.float32)
+    ovol = oracle.Volume(op, threads=16)
+    dev = _DeviceFrames(depth)
+    try:
+        with fusion.Fuser(gp) as f:
+            for i in range(N):
+                ovol.integrate(depth[i], pose)
+            dev.fuse(f, poses, 0, N)
+            _assert_same(ovol, f)
+            _, gv = f.export_blocks()
+            assert (gv["w"] == 255).mean() > 0.3
+    finally:
+        dev.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# upstream-conformance switches (sf_params::frustum_mode / colour_round / colour_first / weight_mode; DESIGN.md 6b): every mode in the
+# kernels bit for bit against the same mode of the oracle
+# ---------------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("switches", [dict(frustum_mode=1), dict(colour_round=1), dict(colour_first=1), dict(weight_mode=1, weight_sample=10),
+                                      dict(weight_mode=1), dict(frustum_mode=1, colour_round=1, colour_first=1, weight_mode=1, weight_sample=4)])
+def test_conformance_switches_match_the_oracle(oracle, switches):
+    from scannet_amd import fusion
+    W, H, N = 320, 240, 40
+    rng = np.random.default_rng(9)
+    depth = np.zeros((N, H, W), np.uint16)
+    poses = np.zeros((N, 16), np.float32)
+    rgb = rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)
+    rgb[:, :, : W // 4] = 0   # black band
+    for i in range(N):
+        pose = synth.trajectory_pose(5 * i, 1200)
+        depth[i] = synth.render_room_depth(pose, W, H, noise_frame=i)
+        poses[i] = pose.reshape(16)
+    for tune in ({}, {"batch": 1}):
+        op, gp = _mk(oracle, W, H, voxel=0.008, num_sdf_blocks=1 << 17, **switches)
+        ovol = oracle.Volume(op, threads=8)
+        dev = _DeviceFrames(depth, rgb)
+        try:
+            with fusion.Fuser(gp, **tune) as f:
+                for i in range(N):
+                    ovol.integrate(depth[i], poses[i].reshape(4, 4), rgb=rgb[i])
+                dev.fuse(f, poses, 0, N)
+                _assert_same(ovol, f)
+                for i in (N - 1, 10):
+                    ovol.deintegrate(depth[i], poses[i].reshape(4, 4), rgb=rgb[i])
+                    assert f.deintegrate(depth[i], poses[i].reshape(4, 4), rgb=rgb[i])
+                _assert_same(ovol, f)
+                assert f.stats()["alloc_failures"] == 0
+        finally:
+            dev.close()
+
+
+def test_block_centre_frustum_geometry_only_and_mesh(oracle):
+    """frustum_mode 1 without colour through the persistent one-frame kernel and the 16-frame pass, then the mesh: the block sets differ from the
+    default's at the image border only, and the canonical mesh of the switched volume is the oracle's."""
+    from scannet_amd import fusion
+    W, H, N = 320, 240, 24
+    depth = np.zeros((N, H, W), np.uint16)
+    poses = np.zeros((N, 16), np.float32)
+    for i in range(N):
+        pose = synth.trajectory_pose(9 * i, 1200)
+        depth[i] = synth.render_room_depth(pose, W, H, noise_frame=i)
+        poses[i] = pose.reshape(16)
+    counts = {}
+    for mode in (0, 1):
+        for tune in ({}, {"batch": 1}):
+            op, gp = _mk(oracle, W, H, voxel=0.008, num_sdf_blocks=1 << 17, frustum_mode=mode)
+            ovol = oracle.Volume(op, threads=8)
+            dev = _DeviceFrames(depth)
+            try:
+                with fusion.Fuser(gp, **tune) as f:
+                    for i in range(N):
+                        ovol.integrate(depth[i], poses[i].reshape(4, 4))
+                    dev.fuse(f, poses, 0, N)
+                    _assert_same(ovol, f)
+                    counts[mode] = f.stats()["blocks_allocated"]
+                    if mode == 1 and not tune:
+                        _assert_same_mesh(ovol, f)
+            finally:
+                dev.close()
+    assert 0.9 * counts[0] < counts[1] < counts[0]
+
+
+def test_reset_gives_an_empty_fuser_again(oracle):
+    """sf_fuser_reset: the second scan through a reset fuser equals the same scan through a fresh one (and the oracle)."""
+    from scannet_amd import fusion
+    W, H = 160, 120
+    op, gp = _mk(oracle, W, H, voxel=0.01, num_sdf_blocks=1 << 15)
+    da, pa, _ = _static_view_stream(W, H, 20, wobble_every=5, seed=1)
+    db, pb, _ = _static_view_stream(W, H, 24, wobble_every=3, seed=2)
+    pb[:, 3] += 0.5   # another place
+    ovol = oracle.Volume(op, threads=4)
+    for i in range(len(db)):
+        ovol.integrate(db[i], pb[i].reshape(4, 4))
+    with fusion.Fuser(gp) as f:
+        for i in range(len(da)):
+            f.integrate(da[i], pa[i].reshape(4, 4))
+        assert f.stats()["blocks_allocated"] > 0
+        f.reset()
+        st = f.stats()
+        assert st["blocks_allocated"] == 0 and st["hash_slots_used"] == 0 and st["frames_integrated"] == 0 and st["high_water"] == 0
+        dev = _DeviceFrames(db)
+        try:
+            dev.fuse(f, pb, 0, len(db))
+            _assert_same(ovol, f)
+        finally:
+            dev.close()

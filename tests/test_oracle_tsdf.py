@@ -301,3 +301,122 @@ def test_oracle_mesh_matches_the_literal_marching_cubes(oracle):
     coords, vox = vol.export()
     res = spec_literal_mc_check(coords, vox, vol.extract_mesh(), 0.02)
     assert res["vertices"] > 3000 and res["triangles"] > 5000, res
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# upstream-conformance switches (include/scanfuse.h sf_params::frustum_mode / colour_round / colour_first / weight_mode)
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def _small(oracle, **over):
+    p = oracle.default_params(160, 120)
+    p.fx = p.fy = 577.87 / 4
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+def test_colour_round_half_up_is_the_float_formula_upstream_writes():
+    """colour_round 1 is stated upstream as (uchar)(0.5f * c0 + 0.5f * c1 + 0.5f); the kernels compute (a + b + 1) >> 1 on packed bytes.  All
+    65 536 byte pairs: the float expression, the integer one and the packed-word one ((a & b) + ((a ^ b) >> 1) + ((a ^ b) & 1)) agree."""
+    a, b = np.meshgrid(np.arange(256, dtype=np.uint32), np.arange(256, dtype=np.uint32))
+    f = (np.float32(0.5) * a.astype(np.float32) + np.float32(0.5) * b.astype(np.float32) + np.float32(0.5)).astype(np.uint8)
+    assert np.array_equal(f, ((a + b + 1) >> 1).astype(np.uint8))
+    x = a ^ b
+    assert np.array_equal(f, ((a & b) + ((x & 0xFE) >> 1) + (x & 1)).astype(np.uint8))
+    assert np.array_equal(((a + b) // 2).astype(np.uint8), ((a & b) + ((x & 0xFE) >> 1)).astype(np.uint8))   # colour_round 0
+
+
+def test_colour_switches(oracle):
+    I = np.eye(4, dtype=np.float32)
+    d = synth.plane_frame(160, 120, 1500)
+    c0 = np.full((120, 160, 3), (10, 200, 31), np.uint8)
+    c1 = np.full((120, 160, 3), (21, 100, 30), np.uint8)
+    black = np.zeros((120, 160, 3), np.uint8)
+    vol = oracle.Volume(_small(oracle, colour_round=1))
+    vol.integrate(d, I, rgb=c0)
+    vol.integrate(d, I, rgb=c1)
+    _, v = vol.export()
+    m = v["w"] == 2
+    assert m.any() and (v["r"][m] == 16).all() and (v["g"][m] == 150).all() and (v["b"][m] == 31).all()   # (10 + 21 + 1) >> 1, (31 + 30 + 1) >> 1
+    # colour_first: a black accumulated colour is "no colour yet" upstream -- black, then c1: weight rule averages, colour rule copies
+    for first, want in ((0, (10, 50, 15)), (1, (21, 100, 30))):
+        vol = oracle.Volume(_small(oracle, colour_first=first))
+        vol.integrate(d, I, rgb=black)
+        vol.integrate(d, I, rgb=c1)
+        _, v = vol.export()
+        m = v["w"] == 2
+        assert m.any() and (v["r"][m] == want[0]).all() and (v["g"][m] == want[1]).all() and (v["b"][m] == want[2]).all(), first
+
+
+def test_depth_dependent_weight(oracle):
+    """weight_mode 1 (VoxelHashing): (uchar)max(ws * 1.5 * (1 - (d - dmin) / (dmax - dmin)), 1).  ws = 10 at d = 1.5 m: 15 * (1 - 1.4 / 5.9) =
+    11.44 -> 11; at 5 m (beyond the integration distance nothing is fused) -- and with the SHIPPED ws = 1 the rule gives 1 at every depth."""
+    I = np.eye(4, dtype=np.float32)
+    for ws, mm, want in ((10, 1500, 11), (10, 3900, 5), (1, 500, 1), (1, 3900, 1), (4, 200, 5)):
+        vol = oracle.Volume(_small(oracle, weight_mode=1, weight_sample=ws))
+        vol.integrate(synth.plane_frame(160, 120, mm), I)
+        _, v = vol.export()
+        z01 = (np.float32(mm) / np.float32(1000) - np.float32(0.1)) / (np.float32(6.0) - np.float32(0.1))
+        assert want == int(max(np.float32(ws) * np.float32(1.5) * (np.float32(1) - z01), np.float32(1)))
+        assert set(np.unique(v["w"])) == {0, want}, (ws, mm, np.unique(v["w"]))
+    # integrate then deintegrate with the same weights empties the volume
+    vol = oracle.Volume(_small(oracle, weight_mode=1, weight_sample=10))
+    a = synth.plane_frame(160, 120, 1500)
+    vol.integrate(a, I)
+    vol.deintegrate(a, I)
+    _, v = vol.export()
+    assert (v["w"] == 0).all() and (v["sdf"] == 0).all()
+
+
+def test_block_centre_frustum(oracle):
+    """frustum_mode 1: the allocated set is the sphere-mode set restricted to the blocks whose CENTRE projects inside 0.95 x NDC, and border
+    blocks the sphere test keeps are dropped -- checked against the float64 statement in oracle/spec_literal.py away from ties."""
+    from oracle import spec_literal
+    W, H = 160, 120
+    fx, fy, mx, my = synth.intrinsics(W, H)
+    pose = synth.trajectory_pose(7, 400)
+    d = synth.render_room_depth(pose, W, H, noise_frame=7)
+    sets = []
+    for mode in (0, 1):
+        p = oracle.default_params(W, H, voxel=0.01)
+        p.fx, p.fy, p.mx, p.my = fx, fy, mx, my
+        p.frustum_mode = mode
+        vol = oracle.Volume(p, threads=4)
+        n = vol.integrate(d, pose)
+        assert n == vol.num_blocks
+        sets.append(vol.export())
+    (c0, v0), (c1, v1) = sets
+    k = lambda c: {tuple(r) for r in c}
+    assert k(c1) < k(c0) and 0.9 * len(c0) < len(c1) < len(c0), (len(c0), len(c1))   # the rays stay inside the image: only the 2.5 % border ring goes
+    inside, near = spec_literal.centre_in_frustum(c0, np.linalg.inv(pose.astype(np.float64)), voxel=0.01, fx=fx, fy=fy, mx=mx, my=my, width=W, height=H,
+                                                  dmin=0.1, dmax=6.0)
+    want = {tuple(r) for r in c0[inside & ~near]}
+    maybe = {tuple(r) for r in c0[near]}
+    assert want <= k(c1) <= (want | maybe) and len(maybe) < 0.01 * len(c0)
+    # the voxels of a block both modes hold are the same voxels
+    idx0 = {tuple(r): i for i, r in enumerate(c0)}
+    sel = np.array([idx0[tuple(r)] for r in c1])
+    assert np.array_equal(v0[sel].view(np.uint8), v1.view(np.uint8))
+
+
+def test_switched_semantics_within_tolerance_of_the_literal_specification(oracle):
+    """The float64 literal evaluator with the same switches (block-centre frustum, depth-dependent weight at VoxelHashing's own ws = 10)."""
+    W, H = 160, 120
+    p = oracle.default_params(W, H, voxel=0.008)
+    fx, fy, mx, my = synth.intrinsics(W, H)
+    p.fx, p.fy, p.mx, p.my = fx, fy, mx, my
+    p.frustum_mode, p.weight_mode, p.weight_sample = 1, 1, 10
+    vol = oracle.Volume(p, threads=8)
+    frames, after = [], []
+    for i in (0, 1, 2, 150, 151, 300):
+        pose = synth.trajectory_pose(i, 1200)
+        d = synth.render_room_depth(pose, W, H, noise_frame=i)
+        vol.integrate(d, pose)
+        frames.append((d, pose))
+        after.append(vol.export()[0])
+    coords, vox = vol.export()
+    final, birth = _births(after)
+    assert np.array_equal(final, coords)
+    res = spec_literal_check(frames, coords, birth, vox, dict(voxel=0.008, fx=fx, fy=fy, mx=mx, my=my, width=W, height=H, frustum_mode=1, weight_mode=1,
+                                                             weight_sample=10), sample=6000)
+    assert res["max_abs_sdf_err_m"] < 2e-5
+    assert vox["w"].max() > 20   # several observations of weight > 1 each

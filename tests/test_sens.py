@@ -477,6 +477,20 @@ def test_png_colour_sub_byte_depths_follow_the_png_specification(tmp_path):
     sd.save(p)
     with pytest.raises(_abi.ScanfuseError):
         sens.SensorData(p).frames[0].decompress_color()
+    # a 60-byte frame that announces 30000 x 30000 RGBA: refused on the IHDR (size mismatch with the .sens header), before the 3.6 GB its
+    # rows would take are allocated -- and a frame of the RIGHT size whose IDAT cannot possibly hold it is refused before the buffer exists
+    import resource
+    tiny = _png_bytes(np.zeros((4, 4), np.uint8), 0, 8)
+    hostile = tiny[:16] + (30000).to_bytes(4, "big") + (30000).to_bytes(4, "big") + bytes([8, 6]) + tiny[26:]
+    for (w, h, blob, what) in ((4, 4, hostile, "header says"), (30000, 30000, hostile, "compressed bytes present")):
+        sd = sens.SensorData.create(w, h, 8, 8, np.eye(4), np.eye(4), color_compression=1, depth_compression=0)
+        sd.add_frame(np.zeros((8, 8), np.uint16), np.eye(4), color=blob)
+        p = str(tmp_path / "hostile.sens")
+        sd.save(p)
+        before = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+        with pytest.raises(_abi.ScanfuseError, match=what):
+            sens.SensorData(p).frames[0].decompress_color()
+        assert resource.getrusage(resource.RUSAGE_SELF).ru_maxrss - before < 200 * 1024   # KiB: nothing image-sized was touched
 
 
 def test_occipital_depth_frames_in_a_sens(oracle, tmp_path):
