@@ -56,27 +56,42 @@ CONFIGS = {
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------------
-# CPU baseline (rank 0, N = 1): the oracle port on a bounded sample; the reference's own SensReader decode beside ours
+# CPU baseline (rank 0, N = 1): the oracle port on a bounded sample at 1, 8 and all usable threads; the reference's own SensReader decode
+# beside ours; the parity of the GPU path with the oracle on exactly the frames the CPU leg fused
 # ---------------------------------------------------------------------------------------------------------------------------------------
-def cpu_baseline(depth_host, poses, voxel, budget_s=12.0, max_frames=2048):
-    """Oracle (our CPU port of the same spec, OpenMP over blocks) timed on a bounded sample of the same stream."""
+def cpu_baseline(depth_host, poses, voxel, frames=200):
+    """the CPU path = reference SensorData decode (compiled from /root/reference when this repo was built) + the oracle
+    (our CPU port of the same specification, OpenMP over blocks) on the first `frames` frames of the same stream, at 1, 8 and all the threads this
+    container may use.  Returns (dict for the JSON line, the oracle volume of the all-threads run for the parity leg)."""
     from oracle import oracle as orc
     from scannet_amd import _abi
-    threads = _abi.usable_cpus()   # the cgroup quota, not the 256 logical CPUs the container shows
-    vol = orc.Volume(orc.default_params(W, H, voxel), threads=threads)
-    t0 = time.perf_counter()
-    n = 0
-    for i in range(min(max_frames, len(depth_host))):
-        vol.integrate(depth_host[i], poses[i])
-        n += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    vol.close()
+    allt = _abi.usable_cpus()   # the cgroup quota, not the 256 logical CPUs the container shows
+    n = min(frames, len(depth_host))
     decode = reference_decode_ms(depth_host[:32], poses[:32])
-    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": threads, "kind": "port", "reference_decode": decode,
-            "sample": "first %d frames of the same stream, oracle/tsdf_oracle.c -O2 -fopenmp (%d threads = the CPUs this container may use, of %d visible), %.1f s"
-                      % (n, threads, os.cpu_count() or threads, dt)}
+    t_dec = (decode or {}).get("reference_sensreader")
+    by, keep = {}, None
+    for th in sorted({1, min(8, allt), allt}):
+        vol = orc.Volume(orc.default_params(W, H, voxel), threads=th)
+        t0 = time.perf_counter()
+        for i in range(n):
+            vol.integrate(depth_host[i], poses[i])
+        dt = time.perf_counter() - t0
+        e = {"frames_per_s_integrate": round(n / dt, 3), "seconds": round(dt, 2)}
+        if t_dec:   # the reference decodes one frame per call on the caller's thread; `th` threads decode `th` frames at once
+            e["frames_per_s_with_reference_decode"] = round(1.0 / (dt / n + t_dec * 1e-3 / th), 3)
+        by[str(th)] = e
+        if th == allt:
+            keep = vol
+        else:
+            vol.close()
+    best = by[str(allt)]
+    out = {"value": best.get("frames_per_s_with_reference_decode", best["frames_per_s_integrate"]), "unit": "frames/s", "cores": allt, "kind": "port",
+           "by_threads": by, "reference_decode": decode,
+           "cpu_model": _cpu_model(), "nproc_visible": os.cpu_count(),
+           "sample": "first %d frames of the same stream: reference SensorData depth decode (oracle/_ref/libref_sens.so, -O2, one frame per thread) + "
+                     "oracle/tsdf_oracle.c (-O2 -fopenmp, blocks over threads) at 1 / 8 / %d threads (= the CPUs this container may use, of %d visible); "
+                     "`value` is the all-threads figure" % (n, allt, os.cpu_count() or allt)}
+    return out, keep, n
 
 
 def reference_decode_ms(depth_host, poses):
@@ -117,10 +132,38 @@ def reference_decode_ms(depth_host, poses):
         return None
 
 
+
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
+def parity_leg(ovol, n, frames_dev, stride, poses, params, local_rank):
+    """The same n frames the CPU leg fused, through the HIP path of THIS run's build: block set and every voxel byte must be identical."""
+    import hashlib
+    from scannet_amd import fusion
+    oc, ov = ovol.export()
+    with fusion.Fuser(params, device=local_rank, **TUNE) as f:
+        f.integrate_batch_device(frames_dev.data_ptr(), stride, poses[:n])
+        gc, gv = f.export_blocks()
+        fails = f.stats()["alloc_failures"]
+    ho = hashlib.sha256(oc.tobytes() + ov.tobytes()).hexdigest()
+    hg = hashlib.sha256(gc.tobytes() + gv.tobytes()).hexdigest()
+    return {"frames": n, "blocks": int(len(gc)), "blocks_oracle": int(len(oc)), "sha256_equal": ho == hg, "sha256": hg[:16], "alloc_failures": fails,
+            "weight_max_seen": int(gv["w"].max()) if len(gc) else 0,
+            "what": "sha256 over (block coordinates sorted by x, y, z; 512 x 8-byte voxels per block) of oracle/tsdf_oracle.c and of the HIP path "
+                    "(16 frames per pass) after the first %d frames of this run's stream" % n}
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------------
 # PMC passes: this script re-run as a child under rocprofv3 --pmc (no trace domains), per-launch averages of the integrate kernel
 # ---------------------------------------------------------------------------------------------------------------------------------------
-def pmc_pass(counters, config, steps, warmup, single_frame, timeout_s=420):
+def pmc_pass(args, counters, config, steps, warmup, single_frame, timeout_s=420):
     """One rocprofv3 --pmc pass over the first `steps` timed frames of this same script.  Returns ({counter: average per integrate launch of
     the timed region}, the child's JSON line) or None."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
@@ -130,7 +173,7 @@ def pmc_pass(counters, config, steps, warmup, single_frame, timeout_s=420):
     try:
         env = dict(os.environ, TMPDIR="/tmp")
         cmd = [exe, "--pmc"] + list(counters) + ["-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--config", config, "--steps", str(steps),
-               "--warmup", str(warmup), "--no-cpu-baseline", "--no-profile", "--no-pmc", "--no-colour", "--teardown"] + (["--single-frame"] if single_frame else []) + \
+               "--warmup", str(warmup), "--child", "--no-profile", "--teardown", "--scene", str(args.scene), "--noise", str(args.noise)] + (["--single-frame"] if single_frame else []) + \
               sum((["--tune", "%s=%d" % kv] for kv in TUNE.items()), [])
         r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
         dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
@@ -162,13 +205,13 @@ def pmc_pass(counters, config, steps, warmup, single_frame, timeout_s=420):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def pmc_traffic(config, steps, warmup, single_frame):
+def pmc_traffic(args, config, steps, warmup, single_frame):
     """HBM-side traffic of the integrate kernel per launch: FETCH_SIZE and WRITE_SIZE in SEPARATE passes.  Corrections as
     MI355X_MICROARCH.md (HBM) prescribes and tools/pmc_calibrate.py confirmed for this kernel's 16 B/lane pattern
     (profiles/r01_b_alloc_bitmap_rocprofv3.txt): both counters are KiB per dispatch, FETCH_SIZE reports exactly half of the bytes read,
     WRITE_SIZE the bytes written.  Infinity-Cache hits are counted (fabric-side counters), so this is an upper bound on DRAM traffic."""
-    a = pmc_pass(["FETCH_SIZE"], config, steps, warmup, single_frame)
-    b = pmc_pass(["WRITE_SIZE"], config, steps, warmup, single_frame) if a else None
+    a = pmc_pass(args, ["FETCH_SIZE"], config, steps, warmup, single_frame)
+    b = pmc_pass(args, ["WRITE_SIZE"], config, steps, warmup, single_frame) if a else None
     if not a or not b:
         return None
     read_b, write_b = 2.0 * a[0]["FETCH_SIZE"] * 1024.0, b[0]["WRITE_SIZE"] * 1024.0
@@ -179,10 +222,10 @@ def pmc_traffic(config, steps, warmup, single_frame):
             "alg_bytes_same_launches": alg, "traffic_over_alg": round((read_b + write_b) / alg, 4) if alg else None}
 
 
-def pmc_valu(config, steps, warmup, single_frame):
+def pmc_valu(args, config, steps, warmup, single_frame):
     """VALU issue utilisation of the integrate kernel: SQ_ACTIVE_INST_VALU (quad-cycles a SIMD spends issuing VALU, summed over SIMDs)
     over the SIMD quad-cycles of the launch = 1024 SIMDs x (GRBM_GUI_ACTIVE / 8 XCDs) / 4 -- the method of profiles/r01_c."""
-    a = pmc_pass(["SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"], config, steps, warmup, single_frame)
+    a = pmc_pass(args, ["SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"], config, steps, warmup, single_frame)
     if not a:
         return None
     v, child = a
@@ -198,18 +241,68 @@ def pmc_valu(config, steps, warmup, single_frame):
 # ---------------------------------------------------------------------------------------------------------------------------------------
 # configs[1] / configs[2]: one resident stream per rank
 # ---------------------------------------------------------------------------------------------------------------------------------------
+def end_to_end(frames_dev, poses, n, params, local_rank, torch):
+    """SURVEY 8d "End-to-end frames/s": the first n frames of the run's stream written to a .sens in /tmp (zlib depth, this library's writer),
+    then sf_fuse_run: file -> decode pool -> pinned ring -> H2D -> fusion.  Wall time from the first byte decoded to the last kernel."""
+    from scannet_amd import fusion, sens, synth
+    d = tempfile.mkdtemp(prefix="sf_e2e_", dir="/tmp")
+    try:
+        path = os.path.join(d, "stream.sens")
+        host = frames_dev[:n].cpu().numpy().view(np.uint16)
+        K = synth.intrinsic_matrix(W, H)
+        sd = sens.SensorData.create(0, 0, W, H, K, K, depth_compression=1, sensor_name="StructureSensor")
+        t0 = time.perf_counter()
+        sd.add_depth_frames(host, poses[:n].reshape(-1, 4, 4))
+        sd.save(path)
+        sd.close()
+        t_write = time.perf_counter() - t0
+        size = os.path.getsize(path)
+        sd = sens.SensorData(path)
+        best = None
+        for _ in range(2):   # the second pass reads the file from the page cache, as the stage after `convert` does
+            with fusion.Fuser(params, device=local_rank, **TUNE) as f:
+                rs = f.run(sd)
+                st = f.stats()
+            if best is None or rs["seconds_total"] < best[0]["seconds_total"]:
+                best = (rs, st)
+        sd.close()
+        rs, st = best
+        return {"frames": int(rs["frames_total"]), "frames_per_s": round(rs["frames_total"] / rs["seconds_total"], 1), "seconds": round(rs["seconds_total"], 4),
+                "compressed_bytes_per_frame": round(size / n), "sens_bytes": size, "decode_threads": int(rs["decode_threads"]),
+                "decode_ms_per_frame_per_thread": round(1e3 * rs["seconds_decode_cpu"] / max(rs["frames_total"], 1), 3),
+                "blocks_live_end": st["blocks_allocated"], "alloc_failures": st["alloc_failures"], "write_s": round(t_write, 2),
+                "what": ".sens on disk (zlib depth, %d KB per frame) -> %d decode threads -> pinned ring -> H2D -> pre-pass / allocation / compaction / integrate, "
+                        "16 frames per pass; wall time of sf_fuse_run (first byte decoded -> last kernel complete), best of 2" % (size // n // 1024, rs["decode_threads"])}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def repeats_for(K):
+    """How often the K timed steps are repeated (fresh volume each time) so that the timed regions add up to ~1 s of GPU time at the ~30 us per
+    frame this path runs at -- a function of K alone, so every rank of a multi-GPU run takes the same number."""
+    return int(min(2000, max(3, -(-1.0 // (K * 30e-6)))))
+
+
 def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
-    from scannet_amd import _abi, fusion
+    from scannet_amd import _abi, fusion, synth
     cfg = CONFIGS[cfg_name]
     K = args.steps if args.steps is not None else cfg["steps"]
     Wm = args.warmup if args.warmup is not None else cfg["warmup"]
-    n_frames = K + Wm
+    child = args.child
+    # the roofline sample: the timed region itself when it is long enough to hold full 16-frame passes, else a fixed window of the same stream
+    # (frames 64..463) -- a 20-step run times two short launches, which says nothing about the kernel
+    if K >= 400 or child or cfg_name != "4mm":
+        roof_W, roof_K = Wm, min(K, args.pmc_steps)
+    else:
+        roof_W, roof_K = 64, 400
+    e2e_n = 0 if (child or world > 1 or args.no_e2e or cfg_name != "4mm") else args.e2e_frames
+    cpu_n = 0 if (child or world > 1 or args.no_cpu_baseline) else args.cpu_frames
+    ooc_n = 0 if (child or world > 1 or args.no_out_of_cache or cfg_name != "4mm" or args.no_profile) else 16 + 64
+    n_frames = max(K + Wm, roof_W + roof_K if not child else 0, e2e_n, cpu_n, ooc_n)
     first = (rank * 697) % TOTAL_FRAMES   # every rank walks the same room from a different starting frame (an independent scan per GPU)
     stride = W * H * 2
     frames = torch.empty((n_frames, H, W), dtype=torch.int16, device="cuda")
-    poses = np.zeros((n_frames, 16), np.float32)
-    L = _abi.lib()
-    _abi.check(L.sf_synth_room_device(C.c_void_p(frames.data_ptr()), stride, first, n_frames, TOTAL_FRAMES, W, H, 1, poses.ctypes.data_as(C.c_void_p)))
+    poses = synth.render_scan_device(frames.data_ptr(), stride, first, n_frames, TOTAL_FRAMES, W, H, noise=args.noise, scene=args.scene, seed=0)
     params = fusion.default_params(voxel_size=cfg["voxel_size"], hash_num_buckets=cfg["hash_num_buckets"], num_sdf_blocks=cfg["num_sdf_blocks"])
 
     colour_frames = [None]
@@ -227,9 +320,10 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
             colour_frames[0] = out
         return colour_frames[0]
 
-    def run(n_warm, n_timed, profile, single_frame=False, colour=False, extra_tune=None):
-        """Fuse frames [0, n_warm) untimed, then frames [n_warm, n_warm + n_timed) between two barrier+synchronize pairs."""
-        fuser = fusion.Fuser(params, device=local_rank, **dict(dict(TUNE, **({"batch": 1} if single_frame else {})), **(extra_tune or {})))
+    def run(n_warm, n_timed, profile, single_frame=False, colour=False, extra_tune=None, repeats=1, prm=None):
+        """`repeats` times on one fuser (sf_fuser_reset in between): fuse frames [0, n_warm) untimed, then frames [n_warm, n_warm + n_timed) between
+        two barrier+synchronize pairs.  Elapsed times per repeat (max over ranks), kernel events and counters summed over the repeats."""
+        fuser = fusion.Fuser(prm if prm is not None else params, device=local_rank, **dict(dict(TUNE, **({"batch": 1} if single_frame else {})), **(extra_tune or {})))
         rgb = colour_tensor(n_warm + n_timed) if colour else None
         cstride = W * H * 3
 
@@ -239,43 +333,58 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
             if world > 1:
                 dist.barrier()
 
-        fuser.integrate_batch_device(frames[:n_warm].data_ptr(), stride, poses[:n_warm], rgb.data_ptr() if colour else None, cstride)
-        sync_all()
-        st0 = fuser.stats()
-        if profile:
-            fuser.profile(True)
-        sync_all()
-        t0 = time.perf_counter()
-        fuser.integrate_batch_device(frames[n_warm:].data_ptr(), stride, poses[n_warm:n_warm + n_timed], rgb[n_warm:].data_ptr() if colour else None, cstride)
-        t_enq = time.perf_counter() - t0
-        sync_all()
-        elapsed = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            elapsed = float(tt.item())
-        st1 = fuser.stats()
-        kernel_ms, launches, _ = fuser.profile_read() if profile else (0.0, 0, 0)
-        fuser.profile(False)
+        times, t_enq_sum, kernel_ms, launches, blocks, tiles = [], 0.0, 0.0, 0, 0, 0
+        st1 = None
+        for rep in range(repeats):
+            if rep:
+                fuser.reset()
+            fuser.integrate_batch_device(frames[:n_warm].data_ptr(), stride, poses[:n_warm], rgb.data_ptr() if colour else None, cstride)
+            sync_all()
+            st0 = fuser.stats()
+            if profile:
+                fuser.profile(True)
+            sync_all()
+            t0 = time.perf_counter()
+            fuser.integrate_batch_device(frames[n_warm:].data_ptr(), stride, poses[n_warm:n_warm + n_timed], rgb[n_warm:].data_ptr() if colour else None, cstride)
+            t_enq_sum += time.perf_counter() - t0
+            sync_all()
+            elapsed = time.perf_counter() - t0
+            if world > 1:
+                tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                elapsed = float(tt.item())
+            times.append(elapsed)
+            st1 = fuser.stats()
+            if profile:
+                ms, ln, _ = fuser.profile_read()
+                kernel_ms += ms
+                launches += ln
+                fuser.profile(False)
+            blocks += st1["total_frame_blocks"] - st0["total_frame_blocks"]
+            tiles += st1["total_pass_tiles"] - st0["total_pass_tiles"]
         ceiling = None
         if single_frame and profile:
             # the last frame's tile traffic without the arithmetic: what this access pattern (scattered 4 KiB RMW) can reach
-            rmw_us, tiles = fuser.calib_tile_rmw(read_only=False, iters=20)
+            rmw_us, ntiles = fuser.calib_tile_rmw(read_only=False, iters=20)
             ro_us, _ = fuser.calib_tile_rmw(read_only=True, iters=20)
-            if tiles > 0:
-                ceiling = {"tiles": tiles, "rmw_copy_us": round(rmw_us, 2), "rmw_copy_GBs": round(tiles * 8192 / rmw_us / 1e3, 1),
-                           "read_only_us": round(ro_us, 2), "read_only_GBs": round(tiles * 4096 / ro_us / 1e3, 1)}
+            if ntiles > 0:
+                ceiling = {"tiles": ntiles, "rmw_copy_us": round(rmw_us, 2), "rmw_copy_GBs": round(ntiles * 8192 / rmw_us / 1e3, 1),
+                           "read_only_us": round(ro_us, 2), "read_only_GBs": round(ntiles * 4096 / ro_us / 1e3, 1)}
         batch = fuser.batch_frames
         fuser.close()
-        blocks = st1["total_frame_blocks"] - st0["total_frame_blocks"]
-        # B_frame = N_blk*(512*8 read + 512*8 write + 16) + W*H*2 + 64, summed over the frames
-        alg_bytes = blocks * (4096 + 4096 + 16) + n_timed * (W * H * (5 if colour else 2) + 64)
-        return {"elapsed": elapsed, "t_enq": t_enq, "kernel_ms": kernel_ms, "launches": launches, "blocks": blocks, "alg_bytes": alg_bytes,
+        # B_frame = N_blk*(512*8 read + 512*8 write + 16) + W*H*2 + 64, summed over the frames (and the repeats)
+        alg_bytes = blocks * (4096 + 4096 + 16) + repeats * n_timed * (W * H * (5 if colour else 2) + 64)
+        # what ONE pass over the tiles has to move whatever the number of frames it fuses: every tile of the pass's list read and written once
+        # plus the frames' depth images -- the memory roofline of the temporally blocked launch
+        batch_bytes = tiles * 8192 + repeats * n_timed * (W * H * (5 if colour else 2))
+        tsort = sorted(times)
+        return {"elapsed": tsort[len(tsort) // 2], "times": times, "t_enq": t_enq_sum / repeats, "kernel_ms": kernel_ms, "launches": launches, "blocks": blocks,
+                "alg_bytes": alg_bytes, "batch_bytes": batch_bytes, "tiles": tiles, "repeats": repeats,
                 "batch": batch, "n_launch": (n_timed + batch - 1) // batch, "st1": st1, "ceiling": ceiling}
 
     def per_launch(m, n_timed):
         return {"avg_kernel_us": round(m["kernel_ms"] * 1e3 / m["launches"], 2), "launches": m["launches"],
-                "frames_per_launch": round(n_timed / m["launches"], 2), "avg_frame_blocks_per_launch": round(m["blocks"] / m["launches"], 1),
+                "frames_per_launch": round(m["repeats"] * n_timed / m["launches"], 2), "avg_frame_blocks_per_launch": round(m["blocks"] / m["launches"], 1),
                 "alg_bytes_per_launch": round(m["alg_bytes"] / m["launches"])}
 
     def roofline_hbm(m, n_timed, kernel):
@@ -291,19 +400,25 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
         r["footprint_vs_infinity_cache"] = round(fp / MALL_BYTES, 2)
         r["footprint_note"] = ("the launch's tile set is %.1f x the 256 MiB Infinity Cache: %s" %
                                (fp / MALL_BYTES, "tiles come from HBM every launch" if fp > 4 * MALL_BYTES else
-                                "consecutive frames re-touch tiles that may still be on-die (FETCH_SIZE counts those hits): see --config 1mm for the out-of-cache figure"))
+                                "consecutive frames re-touch tiles that may still be on-die (FETCH_SIZE counts those hits): see roofline_out_of_cache"))
         return r
 
-    def roofline_valu(m, n_timed, kernel, valu, traffic):
-        """16 frames per launch: VALU-issue bound.  frac = measured VALU issue utilisation; hbm_frac from the counter traffic."""
+    def roofline_valu(m, n_timed, kernel, valu, traffic, sample):
+        """16 frames per launch: VALU-issue bound.  frac = measured VALU issue utilisation; hbm_frac from the counter traffic; hbm_alg_batch = the
+        bytes a 16-frame pass must move (its tiles once + its depth images) over the launch duration, against the 8 TB/s peak."""
         if not m["launches"]:
             return None
         t_s = m["kernel_ms"] * 1e-3 / m["launches"]
         alg_equiv = m["alg_bytes"] / m["launches"] / t_s / 1e9
+        batch_gbs = m["batch_bytes"] / m["launches"] / t_s / 1e9
         r = {"bound": "valu", "achieved": valu["valu_util"] if valu else None, "peak": 1.0, "unit": "fraction of SIMD VALU issue slots",
-             "frac": valu["valu_util"] if valu else None, "traffic": traffic["bytes"] if traffic else None, "kernel": kernel,
+             "frac": valu["valu_util"] if valu else None, "traffic": traffic["bytes"] if traffic else None, "kernel": kernel, "sample": sample,
              "hbm_frac": round(traffic["bytes"] / t_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
              "hbm_GBs": round(traffic["bytes"] / t_s / 1e9, 1) if traffic else None,
+             "hbm_alg_batch": {"bytes_per_launch": round(m["batch_bytes"] / m["launches"]), "tiles_per_launch": round(m["tiles"] / m["launches"], 1),
+                               "GBs": round(batch_gbs, 1), "frac": round(batch_gbs / HBM_PEAK_GBS, 4),
+                               "what": "(tiles of the pass x 8192 B + frames of the pass x %d B) / launch duration / 8 TB/s: the memory roofline of the temporally "
+                                       "blocked pass -- comparable across batch sizes, <= 1" % (W * H * 2)},
              "alg_equiv_GBs": round(alg_equiv, 1),
              "alg_equiv_note": "SURVEY 8d algorithmic bytes of frame-by-frame fusion over the launch duration: what the launch replaces, not bytes it moves "
                                "(temporal blocking keeps each tile in registers for all frames of the batch) -- not a roofline fraction"}
@@ -314,19 +429,24 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
             r["traffic_detail"] = traffic
         return r
 
-    m = run(Wm, K, not args.no_profile, single_frame=args.single_frame)
+    R = 1 if child else (args.repeats if args.repeats else repeats_for(K))
+    m = run(Wm, K, not args.no_profile, single_frame=args.single_frame, repeats=R)
     out = None
     if rank == 0:
-        pmc_on = world == 1 and not args.no_pmc and not args.no_profile
-        psteps = min(args.pmc_steps, K)
+        pmc_on = world == 1 and not args.no_pmc and not args.no_profile and not child
         if m["batch"] == 1:
-            roof = roofline_hbm(m, K, "k_integrate_pipe<true,true>")
+            roof = roofline_hbm(m, K, "k_integrate_pipe<true,2,*>")
             if roof is not None and m["ceiling"]:
                 roof["pattern_ceiling"] = dict(m["ceiling"], frac_of_ceiling=round(roof["achieved"] / m["ceiling"]["rmw_copy_GBs"], 4))
         else:
-            valu = pmc_valu(cfg_name, psteps, Wm, False) if pmc_on else None
-            traffic = pmc_traffic(cfg_name, psteps, Wm, False) if pmc_on else None
-            roof = roofline_valu(m, K, "k_integrate<1,false,true,true>", valu, traffic)
+            same = (roof_W, roof_K) == (Wm, K)
+            mr = m if same or child or args.no_profile else run(roof_W, roof_K, True)
+            valu = pmc_valu(args, cfg_name, roof_K, roof_W, False) if pmc_on else None
+            traffic = pmc_traffic(args, cfg_name, roof_K, roof_W, False) if pmc_on else None
+            roof = roofline_valu(mr, roof_K, "k_integrate<1,false,true,2>", valu, traffic,
+                                 "frames %d..%d of the stream (%s), HIP events around every integrate launch; counters from rocprofv3 --pmc passes over the same frames"
+                                 % (roof_W, roof_W + roof_K - 1, "the timed region" if same else "a fixed window: the timed region of this run is too short to hold full passes"))
+        ts = m["times"]
         out = {
             "metric": "RGB-D frames/sec integrated (640x480, %s voxel)" % ("4 mm" if cfg_name == "4mm" else "1 mm"),
             "value": round(world * K / m["elapsed"], 2), "unit": "frames/s",
@@ -335,57 +455,88 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
             "host_enqueue_ms_per_step": round(m["t_enq"] * 1e3 / max(K, 1), 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": cfg["label"] + ", frames %d..%d per rank, depth resident in HBM" % (Wm, n_frames - 1), "tune": dict(TUNE),
+            "repeats": {"n": len(ts), "timed_s_total": round(sum(ts), 4), "value_median": round(world * K / m["elapsed"], 2),
+                        "value_min": round(world * K / max(ts), 2), "value_max": round(world * K / min(ts), 2),
+                        "what": "the %d warm-up + %d timed steps repeated on an emptied volume (sf_fuser_reset) until the timed regions add up to ~1 s; "
+                                "`value` is the median repeat" % (Wm, K)},
+            "config": {"workload": cfg["label"] + ", frames %d..%d per rank, depth resident in HBM" % (Wm, K + Wm - 1), "tune": dict(TUNE),
+                       "scene": {0: "empty box room", 1: "box room furnished with 48 boxes (csrc/synth.hip clutter_boxes), sensor holes"}[args.scene],
+                       "noise": {0: "none", 1: "round-1 LCG ramp (3 LSBs)", 2: "3 LSBs hashed per pixel and frame"}[args.noise],
                        "sharding": "one independent scan per GPU, no collective on the data path",
                        "blocks_live_end": m["st1"]["blocks_allocated"], "alloc_failures": m["st1"]["alloc_failures"],
                        "frames_per_pass": m["batch"], "integrate_launches": m["n_launch"],
-                       "alg_bytes_per_launch": round(m["alg_bytes"] / max(m["n_launch"], 1))},
-            "roofline_inputs": {"block_frames_per_launch": round(m["blocks"] / max(m["n_launch"], 1), 1)},
+                       "alg_bytes_per_launch": round(m["alg_bytes"] / max(m["n_launch"] * m["repeats"], 1))},
+            "roofline_inputs": {"block_frames_per_launch": round(m["blocks"] / max(m["n_launch"] * m["repeats"], 1), 1)},
             "roofline": roof,
         }
-        if world == 1 and not args.no_profile and not args.single_frame and not args.no_single_frame and K > 1:
-            # the same update HBM-bound: one frame per launch (what sf_fuser_integrate does for a live stream)
-            ks = min(K, 1200)
-            m1 = run(Wm, ks, True, single_frame=True)
-            r1 = roofline_hbm(m1, ks, "k_integrate_pipe<true,true>: one frame per launch (batch = 1), persistent, software-pipelined (tiles and depth gathers "
-                                      "of later tiles in flight into LDS); the next frame's pre-pass / allocation / compaction on a second stream")
+        extras = world == 1 and not args.no_profile and not args.single_frame and not child
+        if extras and not args.no_single_frame:
+            # the same update HBM-bound: one frame per launch (what sf_fuser_integrate does for a live stream), on the roofline sample
+            ks = min(roof_K, 1200)
+            m1 = run(roof_W, ks, True, single_frame=True)
+            r1 = roofline_hbm(m1, ks, "k_integrate_pipe<true,2,*>: one frame per launch (batch = 1), persistent, software-pipelined (tiles and depth gathers "
+                                      "of later tiles in flight into LDS)")
             if r1 is not None:
                 r1["frames_per_s"] = round(ks / m1["elapsed"], 1)
                 r1["ms_per_frame"] = round(m1["elapsed"] * 1e3 / ks, 5)
+                r1["sample"] = "frames %d..%d" % (roof_W, roof_W + ks - 1)
                 if m1["ceiling"]:
                     r1["pattern_ceiling"] = dict(m1["ceiling"], frac_of_ceiling=round(r1["achieved"] / m1["ceiling"]["rmw_copy_GBs"], 4),
                                                  note="k_tile_rmw: the same tiles of the last timed frame read and written back unchanged, no arithmetic, same "
                                                       "launch geometry -- what scattered 4 KiB read-modify-write reaches on this HBM")
                 if pmc_on:
-                    t = pmc_traffic(cfg_name, min(psteps, ks), Wm, True)
+                    t = pmc_traffic(args, cfg_name, min(roof_K, ks), roof_W, True)
                     if t is not None:
                         r1["traffic"] = t["bytes"]
                         r1["traffic_detail"] = t
-                if "pipe_overlap" not in TUNE:
-                    # the kernel with the GPU to itself (the next frame's pre-pass / allocation / compaction serialised behind it): what the
-                    # KERNEL reaches; the schedule above is the one the fuser picks because it gives more frames/s when the tile set is large
-                    ma = run(Wm, ks, True, single_frame=True, extra_tune={"pipe_overlap": 0})   # the same frames as the pass above
+                out["roofline_single_frame"] = r1
+        if extras and ooc_n:
+            # BASELINE configs[2] bounded: the same first frames at 1 mm voxels (2^22 buckets, 2^25 blocks = 137 GB of tiles reserved), one frame per
+            # launch -- every launch's tile set is ~20 x the Infinity Cache, so this IS an HBM figure
+            c1 = CONFIGS["1mm"]
+            p1 = fusion.default_params(voxel_size=c1["voxel_size"], hash_num_buckets=c1["hash_num_buckets"], num_sdf_blocks=c1["num_sdf_blocks"])
+            try:
+                mo = run(16, 64, True, single_frame=True, prm=p1)
+                ro = roofline_hbm(mo, 64, "k_integrate_pipe<true,2,nt>: one frame per launch at 1 mm voxels, non-temporal tile traffic")
+                if ro is not None:
+                    ro["frames_per_s"] = round(64 / mo["elapsed"], 1)
+                    ro["sample"] = "frames 16..79 of the same stream at 1 mm voxels (BASELINE configs[2] geometry); `python bench.py --config 1mm` is the long form"
+                    if mo["ceiling"]:
+                        ro["pattern_ceiling"] = dict(mo["ceiling"], frac_of_ceiling=round(ro["achieved"] / mo["ceiling"]["rmw_copy_GBs"], 4))
+                    ma = run(16, 64, True, single_frame=True, prm=p1, extra_tune={"pipe_overlap": 0})
                     if ma["launches"]:
                         ach = ma["alg_bytes"] / (ma["kernel_ms"] * 1e-3) / 1e9
-                        r1["kernel_alone"] = {"tune": "pipe_overlap=0", "avg_kernel_us": round(ma["kernel_ms"] * 1e3 / ma["launches"], 2), "achieved": round(ach, 1),
-                                              "frac": round(ach / HBM_PEAK_GBS, 4), "frames_per_s": round(ks / ma["elapsed"], 1),
-                                              "frac_of_ceiling": round(ach / m1["ceiling"]["rmw_copy_GBs"], 4) if m1["ceiling"] else None}
-                out["roofline_single_frame"] = r1
-        if world == 1 and not args.no_profile and not args.single_frame and not args.no_colour and cfg_name == "4mm" and K > 1:
+                        ro["kernel_alone"] = {"tune": "pipe_overlap=0 (the next frame's pre-pass / allocation / compaction serialised behind the kernel)",
+                                              "avg_kernel_us": round(ma["kernel_ms"] * 1e3 / ma["launches"], 2), "achieved": round(ach, 1),
+                                              "frac": round(ach / HBM_PEAK_GBS, 4), "frames_per_s": round(64 / ma["elapsed"], 1),
+                                              "frac_of_ceiling": round(ach / mo["ceiling"]["rmw_copy_GBs"], 4) if mo["ceiling"] else None}
+                    # the 16-frame schedule on the same frames, for the frames/s of configs[2]
+                    mb = run(16, 64, True, prm=p1)
+                    ro["batched_frames_per_s"] = round(64 / mb["elapsed"], 1)
+                    out["roofline_out_of_cache"] = ro
+            except _abi.ScanfuseError as e:   # a smaller GPU than the 288 GB part cannot reserve the tiles
+                out["roofline_out_of_cache"] = {"error": str(e)}
+        if extras and not args.no_colour and cfg_name == "4mm":
             # the colour variant of the same pass (a colour frame per depth frame, resident in HBM): k_integrate<1, true, ...>
-            kc = min(K, 2000)
-            mc = run(Wm, kc, True, colour=True)
+            kc = min(roof_K, 2000)
+            mc = run(roof_W, kc, True, colour=True)
             if mc["launches"]:
                 t_s = mc["kernel_ms"] * 1e-3 / mc["launches"]
                 rc = {"bound": "valu", "frames_per_s": round(kc / mc["elapsed"], 1), "ms_per_frame": round(mc["elapsed"] * 1e3 / kc, 5),
                       "kernel": "k_integrate<1,true,true,2>", "alg_equiv_GBs": round(mc["alg_bytes"] / mc["launches"] / t_s / 1e9, 1),
+                      "sample": "frames %d..%d" % (roof_W, roof_W + kc - 1),
                       "note": "16 frames per launch with a colour gather and blend per voxel on top of the geometry update; VALU-issue bound like the geometry kernel "
-                              "(frac: see roofline.frac; no separate counter pass is run for it).  End to end from a .sens (tools/e2e_bench.py --color raw) the same path runs at 17-19 k frames/s"}
+                              "(frac: see roofline.frac; no separate counter pass is run for it)"}
                 rc.update(per_launch(mc, kc))
                 out["roofline_colour"] = rc
-        if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
-            ns = min(2048, n_frames)   # ~12 s of the port; the depth of the sample pulled back to the host
-            out["cpu_baseline"] = cpu_baseline(frames[:ns].cpu().numpy().view(np.uint16), poses[:ns].reshape(-1, 4, 4), cfg["voxel_size"])
+        if e2e_n:
+            out["end_to_end"] = end_to_end(frames, poses, e2e_n, params, local_rank, torch)
+        if cpu_n:   # rank 0 at N = 1 only
+            host = frames[:cpu_n].cpu().numpy().view(np.uint16)
+            base, ovol, n_cpu = cpu_baseline(host, poses[:cpu_n].reshape(-1, 4, 4), cfg["voxel_size"], frames=cpu_n)
+            out["cpu_baseline"] = base
+            out["parity"] = parity_leg(ovol, n_cpu, frames, stride, poses, params, local_rank)
+            ovol.close()
     return out
 
 
@@ -415,7 +566,7 @@ def run_scans(args, rank, local_rank, world, dist, torch):
         with fusion.Fuser(params, device=local_rank, **TUNE) as f:
             for a in range(0, n, chunk):
                 m = min(chunk, n - a)
-                poses = synth.render_scan_device(buf.data_ptr(), stride, a, m, n, W, H, room=room)
+                poses = synth.render_scan_device(buf.data_ptr(), stride, a, m, n, W, H, room=room, noise=args.noise, scene=args.scene, seed=args.first_scan + i)
                 f.integrate_batch_device(buf.data_ptr(), stride, poses)
                 f.sync()
             mesh = f.extract_mesh()
@@ -520,7 +671,8 @@ def run_partition(args, rank, local_rank, world, dist, torch):
     while a < n_frames:   # room by room
         room, inside, per = synth.corridor_room(a, total)
         m = min(per - inside, n_frames - a)
-        poses[a:a + m] = synth.render_scan_device(frames[a:].data_ptr(), stride, inside, m, per, W, H, origin=(room * synth.CORRIDOR_PITCH, 0.0, 0.0))
+        poses[a:a + m] = synth.render_scan_device(frames[a:].data_ptr(), stride, inside, m, per, W, H, origin=(room * synth.CORRIDOR_PITCH, 0.0, 0.0),
+                                                 noise=args.noise, scene=args.scene, seed=room)
         a += m
     blocks = 1 << 23 if world == 1 else max(1 << 20, (1 << 23) // world * 2)
     params = fusion.default_params(num_sdf_blocks=blocks, hash_num_buckets=max(1 << 19, blocks // 2))
@@ -596,6 +748,14 @@ def main():
     ap.add_argument("--no-single-frame", action="store_true", help="skip the secondary one-frame-per-launch roofline pass")
     ap.add_argument("--no-colour", action="store_true", help="skip the secondary colour-fusion pass")
     ap.add_argument("--teardown", action="store_true", help="leave through the interpreter's normal teardown (set for the runs under rocprofv3)")
+    ap.add_argument("--child", action="store_true", help="a counter pass of another bench.py: the K timed steps once, nothing else")
+    ap.add_argument("--repeats", type=int, default=0, help="how often the timed steps are repeated on an emptied volume (default: until ~1 s of timed GPU time)")
+    ap.add_argument("--scene", type=int, choices=[0, 1], default=1, help="synthetic scene: 0 = the empty box room of rounds 1-2, 1 = the furnished room (default)")
+    ap.add_argument("--noise", type=int, choices=[0, 1, 2], default=2, help="depth noise: 1 = the LCG ramp of rounds 1-2, 2 = three LSBs hashed per pixel and frame (default)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (.sens in /tmp -> sf_fuse_run)")
+    ap.add_argument("--e2e-frames", type=int, default=1024)
+    ap.add_argument("--cpu-frames", type=int, default=200, help="frames of the CPU-baseline / parity leg")
+    ap.add_argument("--no-out-of-cache", action="store_true", help="skip the bounded 1 mm (configs[2]) sub-measurement")
     ap.add_argument("--host-stage", choices=["full", "gpu-decimate", "gpu", "clean", "none"], default="full",
                     help="--config scans: what follows marching cubes -- full: clean + sequential quadric collapse x 2 + segment on host threads; gpu-decimate: the "
                          "same chain with the collapse on the GPU (sf_mesh_simplify_gpu); clean: clean + segment; none: nothing")

@@ -107,6 +107,8 @@ typedef struct sf_stats {
   uint64_t total_frame_blocks;   /* sum of N_blk over all frames since create / reset_counters   */
   uint32_t hash_slots_used;
   uint32_t high_water;           /* 1 + highest heap block index ever handed out                 */
+  uint64_t total_pass_tiles;     /* sum over the passes (of up to sf_fuser_batch_frames() frames) of the tiles the pass read and wrote:
+                                    what temporal blocking moves through HBM, against total_frame_blocks for frame-by-frame fusion */
 } sf_stats;
 
 int sf_device_count(int* count);
@@ -249,6 +251,10 @@ int sf_sens_frame_meta(const sf_sens* s, uint64_t frame, sf_sens_frame_meta_t* o
 int sf_sens_create(const sf_sens_info* header, sf_sens** out);
 int sf_sens_add_frame(sf_sens* s, const uint8_t* color, uint64_t color_bytes, const uint16_t* depth, const float pose[16],
                       uint64_t timestamp_color, uint64_t timestamp_depth);
+/* n depth-only frames (`frame_stride_bytes` apart; poses = n x 16 floats; depth time stamps timestamp0 + i * step) compressed on `threads`
+ * threads (0 = every CPU this process may use) and appended in order -- the result is the file n sf_sens_add_frame calls would write. */
+int sf_sens_add_depth_frames(sf_sens* s, const uint16_t* depth, uint64_t frame_stride_bytes, uint64_t n, const float* poses,
+                             uint64_t timestamp0_us, uint64_t timestamp_step_us, int threads);
 int sf_sens_set_pose(sf_sens* s, uint64_t frame, const float pose[16]);
 int sf_sens_save(const sf_sens* s, const char* path);
 

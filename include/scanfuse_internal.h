@@ -25,6 +25,8 @@ extern "C" {
  *   "nt"          -1/0/1 that kernel's tile loads and stores non-temporal: -1 = when the previous pass touched more than 512 MiB of tiles (default)
  *   "front_cus"   0..128 the second stream owns that many CUs (spread over the chip), the main stream the rest (hipExtStreamCreateWithCUMask); 0 = shared
  *   "alloc_group" 1..16  consecutive frames one allocation workgroup walks (default 16: the whole batch)
+ *   "alloc_ray"   0/1    the allocation kernel's occupancy bitmap in ray space (k_alloc_ray; default: whenever the voxel size lets the window hold a
+ *                        pixel tile's rays: >= 2.5 mm voxels with the shipped camera) or as a 32^3-block cube anchored at the first ray (k_alloc)
  *   "ramp"        0..16  frames of the FIRST pass of a sf_fuser_integrate_batch_device call (default 8; 0 = a full pass): nothing overlaps that
  *                        pass's pre-pass / allocation, so a short one starts the pipeline sooner
  * Synchronises the fuser.  SF_ERR_INVALID_ARG for an unknown key or a value out of range. */

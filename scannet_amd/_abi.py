@@ -33,6 +33,7 @@ class SfStats(C.Structure):
         ("last_frame_blocks", C.c_uint32), ("alloc_failures", C.c_uint32),
         ("total_frame_blocks", C.c_uint64),
         ("hash_slots_used", C.c_uint32), ("high_water", C.c_uint32),
+        ("total_pass_tiles", C.c_uint64),
     ]
 
 

@@ -445,6 +445,271 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_
 }
 
 // ---------------------------------------------------------------------------------------------------
+// K2r: the same allocation with the occupancy bitmap laid out in RAY SPACE (the default whenever the geometry fits, see alloc_ray in
+// sf_fuser_create).  A 16x16 pixel tile looks down a thin pencil of rays: a few blocks wide but as deep as the scene -- and where the tile
+// straddles a depth discontinuity (every furniture edge of a real room) its rays sit in two clusters metres apart.  The cube window of
+// k_alloc (32^3 blocks = 1 m at 4 mm voxels, anchored at the first ray) covers one cluster; the other fell through to an LDS hash set and,
+// when that filled, to one global-table probe PER DDA STEP: measured on the furnished room, 115 us -> 450 us (up to 1.2 ms) per batch.
+// Here the window follows the pencil: block (c_a, c_u, c_v) -- a = the axis the tile's centre ray mostly runs along, u, v the other two --
+// maps to   k  = +-(c_a - k0)                        slab index along the ray, 0 at the camera, RW_DEPTH = 256 slabs (8 m at 4 mm)
+//           du = c_u - (ou + ((su k + fu) >> 12))    lateral offset from the centre ray's block in slab k, RW_LAT = 16 wide
+// (dv likewise), bit = k * 256 + dv * 16 + du.  The map is a bijection onto the window for any integers k0, su, ou, ... -- how well the
+// centre line is placed only decides how many rays stay inside --, so it is fixed once per workgroup from the group's FIRST frame and the
+// "already queued by an earlier frame" bitmap stays valid across the frames of the group.  One slab = 256 bits = 8 words = one thread of the
+// workgroup: the scan is two 16-byte LDS reads per thread and frame, and only the ~10 threads whose slab is occupied do anything more.
+// Everything else (ray set-up, DDA, frustum test, queue, table probe, heap pop) is k_alloc's, statement for statement: the allocated SET
+// and every birth frame are the same (tests/test_gpu_tsdf.py runs both kernels against the oracle).
+// ---------------------------------------------------------------------------------------------------
+constexpr int RW_LAT_LOG2 = 4, RW_LAT = 1 << RW_LAT_LOG2, RW_DEPTH = 256;
+constexpr int RW_WORDS = RW_DEPTH * RW_LAT * RW_LAT / 32;   // 2048 words = 8 KiB per bitmap
+
+template <bool MULTI>
+__global__ __launch_bounds__(256) void k_alloc_ray(const float* __restrict__ depthf_all, HashEntry* table, int32_t* heap,
+                                                   uint64_t* block_keys, int32_t* block_entry, uint8_t* block_flags, int32_t* counters, ParamsK P,
+                                                   BatchFrames B, int group_frames) {
+  __shared__ uint4 s_frame4[RW_WORDS / 4];              // blocks the current frame's rays visit (slab-major)
+  __shared__ uint4 s_done4[MULTI ? RW_WORDS / 4 : 1];   // blocks an earlier frame of the group has already queued
+  __shared__ unsigned long long s_keys[ALLOC_SET];      // the same for blocks outside the window
+  __shared__ unsigned long long s_list[ALLOC_LIST];     // queue for phase 2
+  __shared__ uint8_t s_birth[ALLOC_LIST];               // ... and the frame (index in the batch) that queued the key
+  __shared__ int s_count;
+  uint32_t* const s_frame = reinterpret_cast<uint32_t*>(s_frame4);
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_count = 0;
+  const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+  const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+  const HashRefs h{table, heap, block_keys, block_entry, block_flags, counters};
+  for (int i = threadIdx.x; i < ALLOC_SET; i += 256) s_keys[i] = KEY_EMPTY;
+  for (int i = threadIdx.x; i < RW_WORDS / 4; i += 256) s_frame4[i] = make_uint4(0, 0, 0, 0);
+  if (MULTI)
+    for (int i = threadIdx.x; i < RW_WORDS / 4; i += 256) s_done4[i] = make_uint4(0, 0, 0, 0);
+  const size_t npx = (size_t)P.W * P.H;
+  const int j_begin = blockIdx.z * group_frames;
+  const int j_end = min(B.n, j_begin + group_frames);
+
+  auto direct = [&](uint64_t key, int bx, int by, int bz, uint32_t seq) {
+    HashEntry* e = hash_find_or_claim(h, P, key, bx, by, bz, seq);
+    if (e) {
+      atomicAdd(&counters[C_SLOTS_USED], 1);
+      give_block(h, e, key, atomicSub(&counters[C_HEAP_FREE], 1) - 1);
+    }
+  };
+
+  // ---- the window map, from the centre ray of the tile in the group's first frame (uniform: every thread computes the same numbers)
+  int w_axis, w_k0, w_sgn, w_su, w_ou, w_fu, w_sv, w_ov, w_fv;
+  {
+    const FrameK& F0 = B.f[min(j_begin, MAX_BATCH - 1)];
+    const float bs = 8.0f * P.voxel;
+    const float kxc = (((float)(blockIdx.x * 16) + 7.5f) - P.mx) / P.fx, kyc = (((float)(blockIdx.y * 16) + 7.5f) - P.my) / P.fy;
+    float dir[3], org[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      dir[r] = F0.T[4 * r] * kxc + F0.T[4 * r + 1] * kyc + F0.T[4 * r + 2];
+      org[r] = F0.T[4 * r + 3] / bs;   // camera centre in block units
+    }
+    const float ax = fabsf(dir[0]), ay = fabsf(dir[1]), az = fabsf(dir[2]);
+    w_axis = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+    const float da = w_axis == 0 ? dir[0] : (w_axis == 1 ? dir[1] : dir[2]);
+    const float oa = w_axis == 0 ? org[0] : (w_axis == 1 ? org[1] : org[2]);
+    const float du_ = w_axis == 0 ? dir[1] : (w_axis == 1 ? dir[2] : dir[0]);   // u = (a + 1) % 3, v = (a + 2) % 3
+    const float dv_ = w_axis == 0 ? dir[2] : (w_axis == 1 ? dir[0] : dir[1]);
+    const float ou_ = w_axis == 0 ? org[1] : (w_axis == 1 ? org[2] : org[0]);
+    const float ov_ = w_axis == 0 ? org[2] : (w_axis == 1 ? org[0] : org[1]);
+    w_sgn = da < 0.0f ? -1 : 1;
+    const int cb = (int)floorf(oa);
+    w_k0 = cb - w_sgn;                                 // slab 1 holds the camera, slab 0 is one block of margin behind it
+    const float inv = da != 0.0f ? 1.0f / da : 0.0f;
+    const float slu = du_ * inv * (float)w_sgn, slv = dv_ * inv * (float)w_sgn;   // lateral blocks per slab, |.| <= 1
+    // lateral position of the centre ray at the middle of slab 0 (block units), minus half the window
+    const float a0 = ((float)w_k0 + 0.5f) - oa;
+    const float iu = ou_ + du_ * inv * a0 - (float)(RW_LAT / 2), iv = ov_ + dv_ * inv * a0 - (float)(RW_LAT / 2);
+    const float fiu = floorf(iu), fiv = floorf(iv);
+    w_ou = (int)fiu; w_fu = (int)((iu - fiu) * 4096.0f);
+    w_ov = (int)fiv; w_fv = (int)((iv - fiv) * 4096.0f);
+    w_su = (int)rintf(slu * 4096.0f); w_sv = (int)rintf(slv * 4096.0f);
+    w_axis = __builtin_amdgcn_readfirstlane(w_axis); w_k0 = __builtin_amdgcn_readfirstlane(w_k0); w_sgn = __builtin_amdgcn_readfirstlane(w_sgn);
+    w_su = __builtin_amdgcn_readfirstlane(w_su); w_ou = __builtin_amdgcn_readfirstlane(w_ou); w_fu = __builtin_amdgcn_readfirstlane(w_fu);
+    w_sv = __builtin_amdgcn_readfirstlane(w_sv); w_ov = __builtin_amdgcn_readfirstlane(w_ov); w_fv = __builtin_amdgcn_readfirstlane(w_fv);
+  }
+  // block -> bit (0xFFFFFFFF outside the window)
+  auto win_bit = [&](int cx, int cy, int cz) -> uint32_t {
+    const int ca = w_axis == 0 ? cx : (w_axis == 1 ? cy : cz);
+    const int cu = w_axis == 0 ? cy : (w_axis == 1 ? cz : cx);
+    const int cv = w_axis == 0 ? cz : (w_axis == 1 ? cx : cy);
+    const int k = w_sgn > 0 ? ca - w_k0 : w_k0 - ca;
+    // (k is anything for a block far outside: the products wrap, harmlessly -- `in` only holds for 0 <= k < RW_DEPTH)
+    const uint32_t du = (uint32_t)(cu - w_ou - ((int)((uint32_t)w_su * (uint32_t)k + (uint32_t)w_fu) >> 12));
+    const uint32_t dv = (uint32_t)(cv - w_ov - ((int)((uint32_t)w_sv * (uint32_t)k + (uint32_t)w_fv) >> 12));
+    const bool in = (uint32_t)k < (uint32_t)RW_DEPTH && (du | dv) < (uint32_t)RW_LAT;
+    return in ? (((uint32_t)k << (2 * RW_LAT_LOG2)) | (dv << RW_LAT_LOG2) | du) : 0xFFFFFFFFu;
+  };
+
+  const bool in_image = x < P.W && y < P.H;
+  const float kx = ((float)x - P.mx) / P.fx, ky = ((float)y - P.my) / P.fy;  // the pixel's ray direction is the same for every frame
+  const float rvoxel = 1.0f / P.voxel;                                        // RN(1 / voxel) for world_to_block
+  float d_next = in_image && j_begin < j_end ? depthf_all[(size_t)j_begin * npx + (size_t)(y * P.W + x)] : -INFINITY;
+  __syncthreads();   // bitmaps zeroed
+  for (int j = j_begin; j < j_end; ++j) {
+    const FrameK& F = B.f[j];  // uniform index: scalar loads from the kernarg segment
+    const float d_cur = d_next;
+    d_next = in_image && j + 1 < j_end ? depthf_all[(size_t)(j + 1) * npx + (size_t)(y * P.W + x)] : -INFINITY;
+
+    // ---- ray set-up (k_alloc's, statement for statement)
+    bool active = false;
+    int a_cx = 0, a_cy = 0, a_cz = 0, a_sx = 0, a_sy = 0, a_sz = 0, a_ex = 0, a_ey = 0, a_ez = 0;
+    float a_tmx = INFINITY, a_tmy = INFINITY, a_tmz = INFINITY, a_tdx = INFINITY, a_tdy = INFINITY, a_tdz = INFINITY;
+    if (in_image) {
+      const float d = d_cur;
+      if (d != -INFINITY && d < P.maxd) {
+        const float t = fmaf(P.tscale, d, P.tbase);
+        const float lo = min_f32(P.maxd, d - t);
+        const float hi = min_f32(P.maxd, d + t);
+        if (lo < hi) {
+          float p0[3], p1[3];
+          {
+            const float ax = kx * lo, ay = ky * lo, az = lo;
+#pragma unroll
+            for (int r = 0; r < 3; r++) p0[r] = fmaf(F.T[4 * r], ax, fmaf(F.T[4 * r + 1], ay, fmaf(F.T[4 * r + 2], az, F.T[4 * r + 3])));
+          }
+          {
+            const float ax = kx * hi, ay = ky * hi, az = hi;
+#pragma unroll
+            for (int r = 0; r < 3; r++) p1[r] = fmaf(F.T[4 * r], ax, fmaf(F.T[4 * r + 1], ay, fmaf(F.T[4 * r + 2], az, F.T[4 * r + 3])));
+          }
+          const float bsize = 8.0f * P.voxel;
+          int cur[3], stp[3], bnd[3];
+          float tm[3], td[3];
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            const float dir = p1[c] - p0[c];
+            cur[c] = world_to_block(p0[c], P.voxel, rvoxel);
+            const int e = world_to_block(p1[c], P.voxel, rvoxel);
+            stp[c] = dir > 0.0f ? 1 : (dir < 0.0f ? -1 : 0);
+            bnd[c] = e + stp[c];
+            if (stp[c] == 0) { tm[c] = INFINITY; td[c] = INFINITY; }
+            else {
+              const int nb = cur[c] + (stp[c] > 0 ? 1 : 0);
+              const float plane = ((float)(8 * nb) - 0.5f) * P.voxel;
+              const float rdir = recip_rn(dir);   // one reciprocal for both quotients
+              tm[c] = div_rn(plane - p0[c], dir, rdir);
+              td[c] = div_rn((float)stp[c] * bsize, dir, rdir);
+            }
+          }
+          a_cx = cur[0]; a_cy = cur[1]; a_cz = cur[2];
+          a_sx = stp[0]; a_sy = stp[1]; a_sz = stp[2]; a_ex = bnd[0]; a_ey = bnd[1]; a_ez = bnd[2];
+          a_tmx = tm[0]; a_tmy = tm[1]; a_tmz = tm[2]; a_tdx = td[0]; a_tdy = td[1]; a_tdz = td[2];
+          active = true;
+        }
+      }
+    }
+
+    // ---- DDA: one LDS bit per visited block
+    if (active) {
+      uint64_t last_key = KEY_EMPTY;
+      for (int it = 0; it < MAX_DDA_ITERS; ++it) {
+        const uint32_t bit = win_bit(a_cx, a_cy, a_cz);
+        const bool inwin = bit != 0xFFFFFFFFu;
+        // lanes whose left neighbour (DPP row_shr:1) sets the same bit stay silent: 64 same-address ds_or serialise (see k_alloc)
+        const uint32_t left = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFEu, (int)bit, 0x111, 0xF, 0xF, false);
+        if (inwin) {
+          if (left != bit) atomicOr(&s_frame[bit >> 5], 1u << (bit & 31));
+        } else {
+          const uint64_t key = pack_key(a_cx, a_cy, a_cz);
+          if (key != last_key) {
+            last_key = key;
+            if (slab_owns(P, a_cx, a_cy, a_cz) && block_in_frustum(P, F, a_cx, a_cy, a_cz)) {
+              uint32_t sl = ((uint32_t)(key ^ (key >> 21) ^ (key >> 42)) * 2654435761u) >> 24;  // 8 bits
+              bool placed = false;
+              for (int pr = 0; pr < ALLOC_SET_PROBES; ++pr) {
+                const unsigned long long old = atomicCAS(&s_keys[sl], (unsigned long long)KEY_EMPTY, (unsigned long long)key);
+                if (old == key) { placed = true; break; }  // queued by an earlier step / ray / frame
+                if (old == KEY_EMPTY) {
+                  const int pos = atomicAdd(&s_count, 1);
+                  if (pos < ALLOC_LIST) { s_list[pos] = key; s_birth[pos] = (uint8_t)j; placed = true; }
+                  break;  // queue full: direct path below
+                }
+                sl = (sl + 1) & (ALLOC_SET - 1);
+              }
+              if (!placed) direct(key, a_cx, a_cy, a_cz, B.seq0 + (uint32_t)j);
+            }
+          }
+        }
+        bool done;
+        if (a_tmx < a_tmy && a_tmx < a_tmz) { a_cx += a_sx; done = (a_cx == a_ex); a_tmx += a_tdx; }
+        else if (a_tmz < a_tmy) { a_cz += a_sz; done = (a_cz == a_ez); a_tmz += a_tdz; }
+        else { a_cy += a_sy; done = (a_cy == a_ey); a_tmy += a_tdy; }
+        if (done) break;
+      }
+    }
+    __syncthreads();
+    // ---- scan: thread t owns slab t (8 words): blocks this frame visits that no earlier frame of the group queued -> frustum test -> queue
+    {
+      const int k = (int)threadIdx.x;
+      const uint4 f0 = s_frame4[2 * k], f1 = s_frame4[2 * k + 1];
+      if ((f0.x | f0.y | f0.z | f0.w | f1.x | f1.y | f1.z | f1.w) != 0u) {   // ~10 threads of the workgroup
+        uint32_t* const s_done = reinterpret_cast<uint32_t*>(s_done4);
+        const int ca = w_sgn > 0 ? w_k0 + k : w_k0 - k;
+        const int cu0 = w_ou + ((w_su * k + w_fu) >> 12), cv0 = w_ov + ((w_sv * k + w_fv) >> 12);
+#pragma unroll 1
+        for (int w = 0; w < 8; w++) {   // the words come from LDS again: a register array indexed by w would live in scratch
+          const uint32_t fw = s_frame[8 * k + w];
+          if (fw == 0u) continue;
+          s_frame[8 * k + w] = 0u;      // ready for the next frame (nobody else touches this slab before the next barrier)
+          const uint32_t dw = MULTI ? s_done[8 * k + w] : 0u;
+          uint32_t bits = fw & ~dw, queued = 0u;
+          while (bits) {
+            const int b = __ffs((int)bits) - 1;
+            bits &= bits - 1u;
+            const int idx = w * 32 + b;
+            const int cu = cu0 + (idx & (RW_LAT - 1)), cv = cv0 + (idx >> RW_LAT_LOG2);
+            const int bx = w_axis == 0 ? ca : (w_axis == 1 ? cv : cu);
+            const int by = w_axis == 0 ? cu : (w_axis == 1 ? ca : cv);
+            const int bz = w_axis == 0 ? cv : (w_axis == 1 ? cu : ca);
+            if (!slab_owns(P, bx, by, bz)) { queued |= 1u << b; continue; }  // another GPU's block: never ours, stop looking at it
+            if (!block_in_frustum(P, F, bx, by, bz)) continue;  // a later frame may still want it
+            queued |= 1u << b;
+            const int pos = atomicAdd(&s_count, 1);
+            if (pos < ALLOC_LIST) { s_list[pos] = pack_key(bx, by, bz); s_birth[pos] = (uint8_t)j; }
+            else direct(pack_key(bx, by, bz), bx, by, bz, B.seq0 + (uint32_t)j);
+          }
+          if (MULTI && queued) s_done[8 * k + w] = dw | queued;
+        }
+      }
+    }
+    __syncthreads();   // slabs re-zeroed before the next frame's rays set bits
+  }
+
+  // ---- phase 2: queued keys -> global hash, all lanes in parallel (k_alloc's)
+  const int n_unique = min(s_count, ALLOC_LIST);
+  for (int i0 = 0; i0 < n_unique; i0 += 256) {
+    const int i = i0 + threadIdx.x;
+    const uint64_t key = i < n_unique ? s_list[i] : KEY_EMPTY;
+    HashEntry* claimed = nullptr;
+    if (key != KEY_EMPTY) {
+      int bx, by, bz;
+      unpack_key(key, bx, by, bz);
+      claimed = hash_find_or_claim(h, P, key, bx, by, bz, B.seq0 + (uint32_t)s_birth[i]);
+    }
+    const uint64_t cm = __ballot(claimed != nullptr);
+    if (cm != 0ull) {
+      const int n = __popcll((unsigned long long)cm);
+      const int first = __ffsll((unsigned long long)cm) - 1;
+      int base = 0;
+      if (lane == first) {
+        base = atomicSub(&counters[C_HEAP_FREE], n);
+        atomicAdd(&counters[C_SLOTS_USED], n);
+      }
+      base = __shfl(base, first);
+      if (claimed != nullptr) {
+        const int rank = __popcll((unsigned long long)(cm & ((1ull << lane) - 1ull)));
+        give_block(h, claimed, key, base - 1 - rank);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // K3: compactify.  Scans the block directory (8 B per heap slot up to the high-water mark -- not the
 // 16 B x buckets x 10 hash table upstream scans) and appends the slots of the blocks that at least one
 // frame of the batch updates, together with the bit mask of those frames: bit j is set iff the block is in
@@ -508,7 +773,10 @@ __global__ __launch_bounds__(256) void k_compactify(const uint64_t* __restrict__
       if (total) {
         const unsigned long long add = (unsigned long long)(uint32_t)total | ((unsigned long long)(uint32_t)tlast << 32);
         s_base = (int)(uint32_t)atomicAdd(reinterpret_cast<unsigned long long*>(&counters[counter_id]), add);
-        if (!all_live) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[C_TOTAL_LO]), (unsigned long long)tpop);
+        if (!all_live) {
+          atomicAdd(reinterpret_cast<unsigned long long*>(&counters[C_TOTAL_LO]), (unsigned long long)tpop);
+          atomicAdd(reinterpret_cast<unsigned long long*>(&counters[C_TILES_LO]), (unsigned long long)total);
+        }
       }
     }
     __syncthreads();
@@ -1353,14 +1621,18 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
                      f->p.depth_min, f->p.depth_max, f->counters, cc, f->pk, f->ray_kx, f->ray_ky);
   if (sign > 0) {
     // WIN 64 (32 KiB bitmap) has no room for the second bitmap: one frame per workgroup there
-    const int gf = f->alloc_win64 ? 1 : std::min(f->alloc_group, n);
+    const int gf = (f->alloc_win64 && !f->alloc_ray) ? 1 : std::min(f->alloc_group, n);
     const dim3 ag((f->p.depth_width + 15) / 16, (f->p.depth_height + 15) / 16, (n + gf - 1) / gf);
 #define LAUNCH_ALLOC(WL, MU) \
   hipLaunchKernelGGL((k_alloc<WL, MU>), ag, dim3(256), 0, sa, f->depthf2[sl], f->table, f->heap, f->block_keys, f->block_entry, f->block_flags, f->counters, f->pk, bf, gf)
-    if (f->alloc_win64) LAUNCH_ALLOC(6, false);
+#define LAUNCH_ALLOC_RAY(MU) \
+  hipLaunchKernelGGL((k_alloc_ray<MU>), ag, dim3(256), 0, sa, f->depthf2[sl], f->table, f->heap, f->block_keys, f->block_entry, f->block_flags, f->counters, f->pk, bf, gf)
+    if (f->alloc_ray) { if (gf == 1) LAUNCH_ALLOC_RAY(false); else LAUNCH_ALLOC_RAY(true); }
+    else if (f->alloc_win64) LAUNCH_ALLOC(6, false);
     else if (gf == 1) LAUNCH_ALLOC(5, false);
     else LAUNCH_ALLOC(5, true);
 #undef LAUNCH_ALLOC
+#undef LAUNCH_ALLOC_RAY
   }
   hipLaunchKernelGGL(k_compactify, dim3(f->compact_grid), dim3(256), 0, sa, f->block_keys, f->block_entry, f->block_flags, f->table, f->compact2[sl],
                      f->cmask2[sl], f->counters, cc, 0, f->pk, bf);
@@ -1488,6 +1760,12 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
     // longest ray segment 2 * trunc(max distance) in blocks decides the LDS window size of k_alloc
     const float seg = 2.0f * (p->trunc_base + p->trunc_scale * p->max_integration_dist) / (8.0f * p->voxel_size);
     f->alloc_win64 = seg > 20.0f;
+    // the ray-space window (k_alloc_ray) holds the pencil of a 16x16 pixel tile when 16 blocks span its width plus a few blocks of camera
+    // motion inside a batch, and 256 slabs its depth: half a tile at the integration distance within 4 blocks, the longest ray within 250
+    const float bsz = 8.0f * p->voxel_size;
+    const float half_tile = 8.0f * p->max_integration_dist / std::min(p->fx, p->fy);
+    const float reach = (p->max_integration_dist + p->trunc_base + p->trunc_scale * p->max_integration_dist) * 1.25f;
+    f->alloc_ray = half_tile / bsz <= 4.0f && reach / bsz <= (float)(RW_DEPTH - 6);
   }
   ParamsK& k = f->pk;
   k.W = p->depth_width; k.H = p->depth_height; k.fx = p->fx; k.fy = p->fy; k.mx = p->mx; k.my = p->my;
@@ -1754,6 +2032,7 @@ SF_API int sf_fuser_tune(sf_fuser* f, const char* key, int value) {
     f->front_cus = value;
   }
   else if (k == "alloc_group" && in(1, MAX_BATCH)) f->alloc_group = value;
+  else if (k == "alloc_ray" && in(0, 1)) f->alloc_ray = value != 0;   // 1: the ray-space window whatever the geometry (rays outside it take the slow path), 0: the cube window
   else if (k == "ramp" && in(0, MAX_BATCH)) f->ramp = value;
   else return sf::fail(SF_ERR_INVALID_ARG, "sf_fuser_tune: unknown key or value out of range: %s = %d", key, value);
   return SF_OK;
@@ -1789,6 +2068,8 @@ SF_API int sf_fuser_stats(sf_fuser* f, sf_stats* out) {
   uint64_t tot;
   std::memcpy(&tot, &c[C_TOTAL_LO], 8);
   out->total_frame_blocks = tot;
+  std::memcpy(&tot, &c[C_TILES_LO], 8);
+  out->total_pass_tiles = tot;
   out->hash_slots_used = (uint32_t)c[C_SLOTS_USED];
   out->high_water = (uint32_t)c[C_HIGH_WATER];
   return SF_OK;

@@ -103,6 +103,7 @@ enum Counter {
   C_COMPACT_B = 18,  // second batch slot (batches alternate between two sets of per-batch buffers)
   C_EXPORT = 20,
   C_TOTAL_LO = 32,   // 64-bit sum of N_blk over all frames lives in counters[32..33] (own cache line)
+  C_TILES_LO = 34,   // 64-bit sum over the passes of the tiles each pass touched (the pass's list length): counters[34..35], same line
   C_COUNT = 48
 };
 
@@ -209,6 +210,7 @@ struct sf_fuser {
   int32_t* host_mirror = nullptr;  // pinned, device-visible: N_blk of the most recent integrate
   int num_cus = 256;
   bool alloc_win64 = false;  // 64^3-block LDS window when a ray segment spans more than ~20 blocks
+  bool alloc_ray = false;    // k_alloc_ray (occupancy bitmap in ray space: 16 x 16 blocks across the pixel tile's pencil of rays, 256 slabs along it) instead of the cube window
   bool xcd_walk = true;  // k_integrate: each XCD walks one contiguous eighth of the list (tune "xcd_walk" 0: plain grid-stride)
   int pipe_mode = 1;    // 1: colourless one-frame launches run k_integrate_pipe (tune "pipe" 0: k_integrate)
   int pipe_wgs = 3;     // persistent workgroups per CU of k_integrate_pipe (48 KiB of LDS each)

@@ -163,6 +163,17 @@ class SensorData:
         check(_abi.lib().sf_sens_add_frame(self._h, _ptr(c), 0 if c is None else c.size, _ptr(d), _ptr(pose), timestamp_color, timestamp_depth))
         self._refresh()
 
+    def add_depth_frames(self, depth, poses, timestamp0=0, timestamp_step=33333, threads=0):
+        """n depth-only frames [n, H, W] uint16 with poses [n, 4, 4], compressed on `threads` threads (0 = all this process may use)."""
+        d = np.ascontiguousarray(depth, np.uint16)
+        p = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
+        if d.ndim != 3 or d.shape[1] * d.shape[2] != self.depth_width * self.depth_height or len(p) != len(d):
+            raise ValueError("depth must be [n, H, W] at the file's depth size with one pose per frame")
+        L = _abi.lib()
+        L.sf_sens_add_depth_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int]
+        check(L.sf_sens_add_depth_frames(self._h, _ptr(d), d[0].nbytes, len(d), _ptr(p), int(timestamp0), int(timestamp_step), int(threads)))
+        self._refresh()
+
     def set_pose(self, frame, camera_to_world):
         pose = np.ascontiguousarray(camera_to_world, np.float32).reshape(16)
         check(_abi.lib().sf_sens_set_pose(self._h, frame, _ptr(pose)))

@@ -801,3 +801,59 @@ def test_reset_gives_an_empty_fuser_again(oracle):
             _assert_same(ovol, f)
         finally:
             dev.close()
+
+
+@pytest.mark.parametrize("alloc_ray", [1, 0])
+def test_allocation_kernels_on_a_furnished_scene(oracle, alloc_ray):
+    """Both allocation kernels (occupancy bitmap in ray space / as a cube anchored at the first ray) on the furnished room, where pixel tiles
+    straddle depth discontinuities, with frames that jump around inside a pass (the ray-space window is laid out from the pass's first frame: the
+    later ones fall outside it and take the slow path) -- the same block set and birth frames as the oracle, 16 frames per pass and one."""
+    from scannet_amd import fusion
+    W, H = 320, 240
+    boxes = synth.clutter_boxes()
+    idx = [0, 1, 2, 3, 400, 401, 4, 5, 800, 6, 7, 8, 1100, 9, 10, 11, 12, 13, 200, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34]
+    depth = np.zeros((len(idx), H, W), np.uint16)
+    poses = np.zeros((len(idx), 16), np.float32)
+    for k, i in enumerate(idx):
+        pose = synth.trajectory_pose(i, 1200)
+        depth[k] = synth.render_room_depth(pose, W, H, noise_frame=i, noise=2, boxes=boxes)
+        poses[k] = pose.reshape(16)
+    for tune in ({}, {"batch": 1}, {"alloc_group": 4}):
+        op, gp = _mk(oracle, W, H, voxel=0.008, num_sdf_blocks=1 << 17)
+        ovol = oracle.Volume(op, threads=8)
+        dev = _DeviceFrames(depth)
+        try:
+            with fusion.Fuser(gp, alloc_ray=alloc_ray, **tune) as f:
+                for k in range(len(idx)):
+                    ovol.integrate(depth[k], poses[k].reshape(4, 4))
+                dev.fuse(f, poses, 0, len(idx))
+                assert f.stats()["alloc_failures"] == 0
+                _assert_same(ovol, f)
+        finally:
+            dev.close()
+
+
+def test_ray_space_allocation_at_full_size_on_the_furnished_stream(oracle):
+    """640x480, 4 mm, the furnished bench stream with hashed noise and sensor holes: 48 frames through the default schedule, bit for bit."""
+    from scannet_amd import fusion
+    W, H, N = 640, 480, 48
+    boxes = synth.clutter_boxes()
+    depth = np.zeros((N, H, W), np.uint16)
+    poses = np.zeros((N, 16), np.float32)
+    for k in range(N):
+        i = 1000 + 3 * k
+        pose = synth.trajectory_pose(i, 5578)
+        depth[k] = synth.render_room_depth(pose, W, H, noise_frame=i, noise=2, boxes=boxes)
+        poses[k] = pose.reshape(16)
+    op, gp = _mk(oracle, W, H, num_sdf_blocks=1 << 18)
+    ovol = oracle.Volume(op, threads=16)
+    dev = _DeviceFrames(depth)
+    try:
+        with fusion.Fuser(gp) as f:
+            for k in range(N):
+                ovol.integrate(depth[k], poses[k].reshape(4, 4))
+            dev.fuse(f, poses, 0, N)
+            assert f.stats()["alloc_failures"] == 0
+            _assert_same(ovol, f)
+    finally:
+        dev.close()

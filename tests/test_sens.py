@@ -548,3 +548,26 @@ def test_jpeg_restart_intervals_against_pil(tmp_path):
         # not identity: libjpeg's IDCT differs, and at 4:2:2 so does its last chroma column (identity is against the reference, above)
         assert (diff.max(-1) > 4).mean() < 0.02 and diff.mean() < 0.6, (sub, blocks, diff.max())
 
+
+
+def test_bulk_depth_writer_writes_the_file_of_the_frame_by_frame_writer(tmp_path):
+    """sf_sens_add_depth_frames (threaded deflate) against n sf_sens_add_frame calls: byte-identical files, zlib and raw depth."""
+    W, H, N = 64, 48, 37
+    rng = np.random.default_rng(21)
+    depth = rng.integers(0, 5000, (N, H, W), dtype=np.uint16)
+    depth[3] = 0
+    poses = rng.normal(size=(N, 4, 4)).astype(np.float32)
+    K = synth.intrinsic_matrix(W, H)
+    for comp in (1, 0):
+        a = sens.SensorData.create(0, 0, W, H, K, K, depth_compression=comp)
+        for i in range(N):
+            a.add_frame(depth[i], poses[i], timestamp_depth=1000 + 33333 * i)
+        b = sens.SensorData.create(0, 0, W, H, K, K, depth_compression=comp)
+        b.add_depth_frames(depth[:20], poses[:20], timestamp0=1000, threads=5)
+        b.add_depth_frames(depth[20:], poses[20:], timestamp0=1000 + 33333 * 20, threads=0)
+        pa, pb = str(tmp_path / ("a%d.sens" % comp)), str(tmp_path / ("b%d.sens" % comp))
+        a.save(pa)
+        b.save(pb)
+        assert open(pa, "rb").read() == open(pb, "rb").read()
+        r = sens.SensorData(pb)
+        assert r.num_frames == N and np.array_equal(r.frames[36].decompress_depth(), depth[36])

@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--gpu-decimate", action="store_true", help="the decimate stage on the GPU (sf_mesh_simplify_gpu) instead of the sequential filter")
     ap.add_argument("--gpu-clean", action="store_true", help="the cleaning filters on the GPU (sf_mesh_clean_gpu: same output) instead of the host filters")
     ap.add_argument("--fuse-only", action="store_true", help="stop after the fusion stage")
+    ap.add_argument("--scene", type=int, default=synth.SCENE_DEFAULT, help="0 = empty box room, 1 = furnished (default)")
+    ap.add_argument("--noise", type=int, default=synth.NOISE_DEFAULT, help="1 = the LCG ramp of rounds 1-2, 2 = hashed per pixel (default)")
     ap.add_argument("--color-res", default="", help="WxH of the colour frames when it differs from the depth size (ScanNet: 1296x968)")
     a = ap.parse_args()
     W, H = 640, 480
@@ -44,7 +46,7 @@ def main():
     dptr = C.c_void_p()
     _abi.check(L.sf_device_malloc(0, nbytes, C.byref(dptr)))
     poses = np.zeros((a.frames, 16), np.float32)
-    _abi.check(L.sf_synth_room_device(dptr, W * H * 2, 0, a.frames, a.total, W, H, 1, poses.ctypes.data_as(C.c_void_p)))
+    poses = synth.render_scan_device(dptr.value, W * H * 2, 0, a.frames, a.total, W, H, noise=a.noise, scene=a.scene)
     depth = np.zeros((a.frames, H, W), np.uint16)
     _abi.check(L.sf_device_download(depth.ctypes.data_as(C.c_void_p), dptr, nbytes))
     L.sf_device_free(dptr)
@@ -62,7 +64,9 @@ def main():
         for k in range(8):   # eight distinct encoded frames, cycled (encoding thousands of frames would dominate the set-up)
             img = np.stack([(xx + 8 * k) % 256, (yy * 2) % 256, (128 + 100 * np.sin(xx / 30.0) * np.cos(yy / 20.0 + k))], -1).astype(np.uint8)
             blobs.append(calibrate.jpeg_encode(img, 90, True))
-    for i in range(a.frames):
+    if a.color == "none":
+        sd.add_depth_frames(depth, poses.reshape(-1, 4, 4))   # threaded deflate
+    for i in range(a.frames if a.color != "none" else 0):
         color = None
         if a.color == "raw":
             color = np.stack([(xx + i) % 256, (yy * 2) % 256, np.full_like(xx, (i * 3) % 256)], -1).astype(np.uint8)
@@ -72,7 +76,8 @@ def main():
     sd.save(path)
     sd.close()
     t_write = time.perf_counter() - t0
-    res = {"frames": a.frames, "sens_bytes": os.path.getsize(path), "write_s": round(t_write, 2), "voxel": a.voxel, "host_cores": os.cpu_count()}
+    res = {"frames": a.frames, "sens_bytes": os.path.getsize(path), "compressed_bytes_per_frame": os.path.getsize(path) // a.frames, "scene": a.scene, "noise": a.noise,
+           "write_s": round(t_write, 2), "voxel": a.voxel, "host_cores": os.cpu_count()}
 
     fx, fy, mx, my = synth.intrinsics(W, H)
     gp = fusion.default_params(depth_width=W, depth_height=H, fx=fx, fy=fy, mx=mx, my=my, voxel_size=a.voxel, num_sdf_blocks=a.blocks,
