@@ -698,7 +698,8 @@ def run_partition(args, rank, local_rank, world, dist, torch):
     t_fuse = time.perf_counter() - t0
     # the exchange step + meshing (reported beside the metric, not part of the K timed steps)
     t1 = time.perf_counter()
-    sent, got = partition.exchange_boundary(fuser) if world > 1 else (fuser.count_boundary(), 0)
+    sent, got = partition.exchange_boundary(fuser, mode=args.exchange) if world > 1 else (fuser.count_boundary(), 0)
+    bytes_in = partition.exchange_boundary.last_bytes if world > 1 else 0
     sync_all()
     t_exch = time.perf_counter() - t1
     t2 = time.perf_counter()
@@ -707,7 +708,8 @@ def run_partition(args, rank, local_rank, world, dist, torch):
     sync_all()
     t_mc = time.perf_counter() - t2
     st = fuser.stats()
-    vals = torch.tensor([t_fuse, t_exch, t_mc, float(st["blocks_allocated"]), float(sent), float(got), float(nf), float(st["alloc_failures"])], dtype=torch.float64, device="cuda")
+    vals = torch.tensor([t_fuse, t_exch, t_mc, float(st["blocks_allocated"]), float(sent), float(got), float(nf), float(st["alloc_failures"]), float(bytes_in)],
+                        dtype=torch.float64, device="cuda")
     if world > 1:
         mx = vals.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = vals.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
@@ -725,10 +727,14 @@ def run_partition(args, rank, local_rank, world, dist, torch):
         "config": {"workload": "configs[4]: one %d-frame walk through a corridor of %d box rooms (6x4x3 m, %.1f m pitch), 640x480, 4 mm voxels; every rank sees every frame"
                                % (total, synth.CORRIDOR_ROOMS, synth.CORRIDOR_PITCH),
                    "partition": ("stripes of %d block layers along x dealt round-robin" % args.stripe_blocks) if args.partition == "stripes" else "one contiguous slab along x per rank",
-                   "collective": "RCCL all-gather of the boundary block layers (device tensors) once, before marching cubes" if world > 1 else "none at N = 1",
+                   "collective": ({"neighbour": "RCCL send / recv of the boundary block layers (device tensors) to the ONE rank that needs them (ring shift over the "
+                                                "direct xGMI links), once, before marching cubes",
+                                   "all_gather": "RCCL all-gather of the boundary block layers (device tensors) once, before marching cubes"}[args.exchange]
+                                  if world > 1 else "none at N = 1"),
                    "blocks_per_rank_max": int(mx[3]), "blocks_per_rank_min": int(mn[3]), "blocks_total": int(sm[3]), "alloc_failures": int(sm[7])},
         "exchange": {"seconds": round(float(mx[1]), 4), "boundary_blocks_sent_total": int(sm[4]), "ghost_blocks_received_total": int(sm[5]),
-                     "bytes_all_gathered_per_rank": int(sm[4]) * 4108},
+                     "mode": args.exchange, "payload_bytes_received_per_rank_max": int(mx[8]), "payload_bytes_received_total": int(sm[8]),
+                     "all_gather_would_receive_per_rank": int(sm[4]) * 4108},
         "marching_cubes": {"seconds": round(float(mx[2]), 4), "faces_total": int(sm[6])},
         "roofline": None,
     }
@@ -764,6 +770,7 @@ def main():
     ap.add_argument("--scan-frames", type=int, default=50000, help="--config partition: length of the long scan")
     ap.add_argument("--partition", choices=["stripes", "slabs"], default="stripes")
     ap.add_argument("--stripe-blocks", type=int, default=16)
+    ap.add_argument("--exchange", choices=["neighbour", "all_gather"], default="neighbour", help="--config partition: how the boundary layers travel")
     ap.add_argument("--stripes-at-one", action="store_true", help="set the partition even at N = 1 (rank 0 of 1 owns everything)")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="sf_fuser_tune switches for every fuser of the run (A/B measurements)")
     args = ap.parse_args()

@@ -57,6 +57,13 @@ int sf_synth_scene_device(void* d_depth, uint64_t frame_stride_bytes, uint64_t f
                           float* poses_out);
 int sf_synth_clutter_boxes(const double room_m[3], uint32_t seed, float* lo_out /* 48 x 3 */, float* hi_out /* 48 x 3 */, int* n_out);
 
+/* Decimation known-answer probe (tests/test_simplify_known_answers.py): of mesh `in` as the quadric edge collapse sees it before the first
+ * collapse -- the summed quadric of the edge's end points {a00 a01 a02 a11 a12 a22, b0 b1 b2, c} (error(x) = x'Ax + b'x + c), the position
+ * the collapsed vertex would take, the priority of the collapse, and ScaleFactor = 1e8 / diag^6.  Any output may be NULL. */
+struct sf_mesh;
+int sf_simplify_probe_edge(const struct sf_mesh* in, const sf_simplify_params* p, uint32_t v0, uint32_t v1, double quadric10[10], float position[3],
+                           float* priority, double* scale_factor);
+
 /* Device self-test: the hand-expanded correctly rounded divisions of the integrate and allocation kernels against the hardware's IEEE
  * division -- all 2^23 mantissas x 9 exponents for 1/x, 511 integer divisors x 2^21 numerators for n/m, 2^28 general operand pairs
  * (incl. near-exact and near-half-way quotients) for a/b.  All three counts must be 0 (tests/test_gpu_tsdf.py). */

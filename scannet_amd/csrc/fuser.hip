@@ -1841,9 +1841,18 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
   SF_ALLOC(f->counters, C_COUNT * 4);
   SF_ALLOC(f->ray_kx, (size_t)k.W * 4);
   SF_ALLOC(f->ray_ky, (size_t)k.H * 4);
-  SF_ALLOC(f->staging_depth, f->in_px * 2);
-  SF_ALLOC(f->staging_rgb, (k.cW ? (size_t)k.cW * k.cH : npx) * 3);
+  const size_t rgb_bytes = (k.cW ? (size_t)k.cW * k.cH : npx) * 3;
+  for (int q = 0; q < sf_fuser::HOST_RING; q++) {
+    SF_ALLOC(f->staging_depth[q], f->in_px * 2);
+    SF_ALLOC(f->staging_rgb[q], rgb_bytes);
+  }
 #undef SF_ALLOC
+  for (int q = 0; q < sf_fuser::HOST_RING; q++) {
+    SF_CREATE_CHECK(hipHostMalloc(&f->pinned_depth[q], f->in_px * 2, hipHostMallocDefault));
+    SF_CREATE_CHECK(hipHostMalloc(&f->pinned_rgb[q], rgb_bytes, hipHostMallocDefault));
+    SF_CREATE_CHECK(hipEventCreateWithFlags(&f->ev_h2d[q], hipEventDisableTiming));
+    SF_CREATE_CHECK(hipEventCreateWithFlags(&f->ev_consumed[q], hipEventDisableTiming));
+  }
   SF_CREATE_CHECK(hipHostMalloc((void**)&f->host_mirror, 64, hipHostMallocMapped));
   *f->host_mirror = 0;
   SF_CREATE_CHECK(hipMemsetAsync(f->table, 0xFF, (size_t)k.total_slots * sizeof(HashEntry), f->stream));
@@ -1871,7 +1880,13 @@ SF_API void sf_fuser_destroy(sf_fuser* f) {
   for (int q = 0; q < 2; q++) { if (f->ev_compact[q]) (void)hipEventDestroy(f->ev_compact[q]); if (f->ev_fused[q]) (void)hipEventDestroy(f->ev_fused[q]); }
   if (f->ev_input) (void)hipEventDestroy(f->ev_input);
   if (f->front) { (void)hipStreamSynchronize(f->front); (void)hipStreamDestroy(f->front); }
-  (void)hipFree(f->staging_depth); (void)hipFree(f->staging_rgb);
+  for (int q = 0; q < sf_fuser::HOST_RING; q++) {
+    (void)hipFree(f->staging_depth[q]); (void)hipFree(f->staging_rgb[q]);
+    if (f->pinned_depth[q]) (void)hipHostFree(f->pinned_depth[q]);
+    if (f->pinned_rgb[q]) (void)hipHostFree(f->pinned_rgb[q]);
+    if (f->ev_h2d[q]) (void)hipEventDestroy(f->ev_h2d[q]);
+    if (f->ev_consumed[q]) (void)hipEventDestroy(f->ev_consumed[q]);
+  }
   if (f->host_mirror) (void)hipHostFree(f->host_mirror);
   if (f->stream) (void)hipStreamDestroy(f->stream);
   delete f;
@@ -1914,16 +1929,27 @@ static int fuse_host(sf_fuser* f, const uint16_t* depth, const uint8_t* rgb, con
   if (pose[0] == -INFINITY) { f->frames_skipped++; return sf::fail(SF_ERR_SKIPPED, "frame skipped: camToWorld is -inf (tracking lost)"); }
   SF_HIP_CHECK(hipSetDevice(f->device));
   const size_t npx = (size_t)f->pk.W * f->pk.H;
-  // the staging buffer is reused: wait for the previous frame's kernels before overwriting it
-  SF_HIP_CHECK(sf_quiesce(f));
+  const size_t rgb_bytes = (f->pk.cW ? (size_t)f->pk.cW * f->pk.cH : npx) * 3;
+  // The caller's buffers are ordinary (pageable) memory and are its own again the moment this call returns -- a live stream decodes the next
+  // frame into the same buffer, a binding may free it.  So the frame is copied into a page-locked slot of the ring HERE, on the caller's
+  // thread (614 KB: ~50 us), and everything behind that -- H2D, pre-pass, allocation, compaction, integrate -- is queued and left running.
+  // Round 2 drained both streams and waited for the H2D in every call: the GPU idled while the host copied and the host idled while the GPU
+  // fused (one frame per launch: 7.8 k frames/s with resident frames, less through this entry point).
+  const int q = f->host_slot;
+  f->host_slot = (q + 1) % sf_fuser::HOST_RING;
+  if (f->host_frames >= (uint64_t)sf_fuser::HOST_RING) SF_HIP_CHECK(hipEventSynchronize(f->ev_h2d[q]));   // the copy of HOST_RING frames ago has read the slot
+  std::memcpy(f->pinned_depth[q], depth, f->in_px * 2);
+  if (rgb) std::memcpy(f->pinned_rgb[q], rgb, rgb_bytes);
   hipStream_t in_stream = sf_input_stream(f, 1, rgb != nullptr, sign);  // the stream the pre-pass reads the frame on
-  SF_HIP_CHECK(hipMemcpyAsync(f->staging_depth, depth, f->in_px * 2, hipMemcpyHostToDevice, in_stream));
-  if (rgb) SF_HIP_CHECK(hipMemcpyAsync(f->staging_rgb, rgb, (f->pk.cW ? (size_t)f->pk.cW * f->pk.cH : npx) * 3, hipMemcpyHostToDevice, in_stream));
-  // The caller's buffers are ordinary (pageable) memory and are its own again the moment this call returns -- a live stream decodes the
-  // next frame into the same buffer, a binding may free it: the copies must have READ them by then (the runtime may pin pageable pages in
-  // place and let the DMA run on), so wait for the copies; only the kernels run asynchronously.
-  SF_HIP_CHECK(hipStreamSynchronize(in_stream));
-  return run_frame(f, f->staging_depth, rgb ? f->staging_rgb : nullptr, pose, sign);
+  if (f->host_frames >= (uint64_t)sf_fuser::HOST_RING) SF_HIP_CHECK(hipStreamWaitEvent(in_stream, f->ev_consumed[q], 0));   // the kernels that read the device copy
+  SF_HIP_CHECK(hipMemcpyAsync(f->staging_depth[q], f->pinned_depth[q], f->in_px * 2, hipMemcpyHostToDevice, in_stream));
+  if (rgb) SF_HIP_CHECK(hipMemcpyAsync(f->staging_rgb[q], f->pinned_rgb[q], rgb_bytes, hipMemcpyHostToDevice, in_stream));
+  SF_HIP_CHECK(hipEventRecord(f->ev_h2d[q], in_stream));
+  const int rc = run_frame(f, f->staging_depth[q], rgb ? f->staging_rgb[q] : nullptr, pose, sign);
+  // the frame's pre-pass (the only reader of the device copy) precedes its integrate launch in stream order: an event behind that launch covers it
+  SF_HIP_CHECK(hipEventRecord(f->ev_consumed[q], f->stream));
+  f->host_frames++;
+  return rc;
 }
 
 SF_API int sf_fuser_integrate(sf_fuser* f, const uint16_t* depth, const uint8_t* rgb, const float pose[16]) {

@@ -205,8 +205,19 @@ struct sf_fuser {
   int32_t* counters = nullptr;
   float* ray_kx = nullptr;   // (x - mx) / fx per column, (y - my) / fy per row of the integration image (colour look-up of the pre-pass)
   float* ray_ky = nullptr;
-  void* staging_depth = nullptr;  // device copies of host-supplied frames
-  void* staging_rgb = nullptr;
+  // host-buffer entry points (sf_fuser_integrate / deintegrate: a live stream hands one pageable frame per call): a ring of HOST_RING slots,
+  // each a page-locked host copy + a device copy of one frame.  The call copies the caller's frame into the page-locked slot (so the caller's
+  // buffer is free when the call returns), queues the H2D and the frame's kernels, and returns; a slot is reused HOST_RING frames later, behind
+  // the events below -- no stream is drained per frame.
+  static constexpr int HOST_RING = 3;
+  void* staging_depth[HOST_RING] = {nullptr, nullptr, nullptr};  // device copies of host-supplied frames
+  void* staging_rgb[HOST_RING] = {nullptr, nullptr, nullptr};
+  void* pinned_depth[HOST_RING] = {nullptr, nullptr, nullptr};   // page-locked host copies
+  void* pinned_rgb[HOST_RING] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_h2d[HOST_RING] = {nullptr, nullptr, nullptr};       // the slot's H2D copy has read the page-locked buffer
+  hipEvent_t ev_consumed[HOST_RING] = {nullptr, nullptr, nullptr};  // the kernels that read the slot's device copy are queued behind this
+  int host_slot = 0;
+  uint64_t host_frames = 0;
   int32_t* host_mirror = nullptr;  // pinned, device-visible: N_blk of the most recent integrate
   int num_cus = 256;
   bool alloc_win64 = false;  // 64^3-block LDS window when a ray segment spans more than ~20 blocks

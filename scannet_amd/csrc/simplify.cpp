@@ -566,6 +566,28 @@ SF_API void sf_simplify_default_params(sf_simplify_params* p) {
   p->auto_clean = 1;            // :14
 }
 
+// scanfuse_internal.h: the quadric, the optimal position and the priority the filter assigns to the collapse v0 -> v1 of `in` BEFORE any
+// collapse has happened -- what tests/test_simplify_known_answers.py checks against values derived by hand.
+SF_API int sf_simplify_probe_edge(const sf_mesh* in, const sf_simplify_params* p, uint32_t v0, uint32_t v1, double quadric10[10], float position[3],
+                                  float* priority, double* scale_factor) {
+  if (!in || !p) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  Simplifier S(*p);
+  const int rc = S.init(in);
+  if (rc != SF_OK) return rc;
+  if (v0 >= S.nv() || v1 >= S.nv() || v0 == v1) return sf::fail(SF_ERR_INVALID_ARG, "sf_simplify_probe_edge: vertices %u, %u of %zu", v0, v1, S.nv());
+  Quadric q = S.Q[v0];
+  q.add(S.Q[v1]);
+  if (quadric10) {
+    for (int i = 0; i < 6; i++) quadric10[i] = q.a[i];
+    for (int i = 0; i < 3; i++) quadric10[6 + i] = q.b[i];
+    quadric10[9] = q.c;
+  }
+  if (position) S.optimal(v0, v1, q, position);
+  if (priority) *priority = S.priority(v0, v1);
+  if (scale_factor) *scale_factor = S.scale;
+  return SF_OK;
+}
+
 SF_API int sf_mesh_simplify(const sf_mesh* in, const sf_simplify_params* p, sf_mesh** out, sf_simplify_stats* stats) {
   if (!in || !p || !out) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
   if (p->preserve_boundary || p->preserve_normal || p->preserve_topology || p->quality_weight)

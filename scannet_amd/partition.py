@@ -89,11 +89,43 @@ def _all_gather_ragged(arr, group=None):
     return [o[:c] for c, o in zip(counts, outs)]
 
 
-def exchange_boundary(fuser, rank=None, group=None, gather=None):
-    """Before meshing: export this rank's boundary layers, all-gather, import what this rank needs as ghosts.
-    With a process group on the nccl backend everything stays in HBM (device export -> RCCL all-gather -> device import with the
-    ownership filter in the kernel).  `gather(coords, voxels) -> (list, list)` replaces torch.distributed in single-process tests
-    (numpy).  Returns (blocks sent, ghost blocks received)."""
+def _ring_shift(c, v, group=None):
+    """Every rank sends (c, v) to its LEFT neighbour and receives its RIGHT neighbour's: the whole exchange of the stripe / slab partition.
+    The lowest layer of a stripe of rank r sits right above the highest layer of a stripe of rank r - 1 (stripes are dealt round-robin,
+    slabs in rank order), so rank r's boundary blocks are wanted by rank (r - 1) mod N and by nobody else.  torch.distributed point-to-point
+    (batch_isend_irecv: ncclSend / ncclRecv in one group under the nccl backend -- on a node whose GPUs are fully connected by xGMI each pair
+    of neighbours has its own link, so the N transfers run at link speed side by side instead of every rank receiving everything)."""
+    import torch
+    import torch.distributed as dist
+    world, me = dist.get_world_size(group), dist.get_rank(group)
+    peer = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+    left, right = peer((me - 1) % world), peer((me + 1) % world)
+    dev = c.device
+    n_out = torch.tensor([c.shape[0]], dtype=torch.int64, device=dev)
+    n_in = torch.zeros(1, dtype=torch.int64, device=dev)
+    for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, n_out, left, group), dist.P2POp(dist.irecv, n_in, right, group)]):
+        req.wait()
+    nr = int(n_in.item())
+    rc = torch.empty((nr, 3), dtype=c.dtype, device=dev)
+    rv = torch.empty((nr, 4096), dtype=v.dtype, device=dev)
+    ops = []
+    if c.shape[0]:
+        ops += [dist.P2POp(dist.isend, c.contiguous(), left, group), dist.P2POp(dist.isend, v.contiguous(), left, group)]
+    if nr:
+        ops += [dist.P2POp(dist.irecv, rc, right, group), dist.P2POp(dist.irecv, rv, right, group)]
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return rc, rv
+
+
+def exchange_boundary(fuser, rank=None, group=None, gather=None, mode="neighbour"):
+    """Before meshing: export this rank's boundary layers, hand them to the rank that needs them, import what arrives as ghosts.
+    mode "neighbour" (default): one send to the left neighbour, one receive from the right one (`_ring_shift`); "all_gather": every rank
+    receives every rank's layers and keeps what it wants (the round-2 form; the north star's wording).  With a process group on the nccl
+    backend everything stays in HBM (device export -> RCCL -> device import with the ownership filter in the kernel).
+    `gather(coords, voxels) -> (list, list)` replaces torch.distributed in single-process tests (numpy).
+    Returns (blocks sent, ghost blocks received); `exchange_boundary.last_bytes` = payload bytes this rank received."""
     if gather is not None:
         c, v = fuser.export_boundary()
         all_c, all_v = gather(c, v)
@@ -109,19 +141,40 @@ def exchange_boundary(fuser, rank=None, group=None, gather=None):
             v = torch.empty((max(n, 1), 4096), dtype=torch.uint8, device=dev)
             n = fuser.export_boundary(c, v) if n else 0
             c, v = c[:n], v[:n]
-        else:   # gloo: host tensors (CPU tests)
+        else:   # gloo: host tensors (CPU tests; two processes sharing one GPU)
             cn, vn = fuser.export_boundary()
             c, v = torch.from_numpy(cn), torch.from_numpy(np.ascontiguousarray(vn).view(np.uint8).reshape(len(cn), 4096))
+        if mode == "neighbour":
+            got = 0
+            if dist.get_world_size(group) > 1:
+                rc, rv = _ring_shift(c, v, group)
+                if dev.type == "cuda":
+                    # the import kernel runs on the fuser's own stream: what RCCL queued on torch's stream must have landed first
+                    torch.cuda.current_stream().synchronize()
+                elif len(rc):
+                    rc, rv = rc.numpy(), rv.numpy()
+                got = fuser.import_ghosts(rc, rv) if len(rc) else 0
+                exchange_boundary.last_bytes = int(len(rc)) * 4108
+            else:
+                exchange_boundary.last_bytes = 0
+            return int(len(c)), got
         all_c = _all_gather_ragged(c, group)
         all_v = _all_gather_ragged(v, group)
+        if dev.type == "cuda":
+            torch.cuda.current_stream().synchronize()   # order RCCL's output before the import on the fuser's stream
     got = 0
+    exchange_boundary.last_bytes = 0
     for r, (cc, vv) in enumerate(zip(all_c, all_v)):
         if r == me or len(cc) == 0:
             continue
         if not isinstance(cc, np.ndarray) and cc.device.type == "cpu":
             cc, vv = cc.numpy(), vv.numpy()
+        exchange_boundary.last_bytes += int(len(cc)) * 4108
         got += fuser.import_ghosts(cc, vv)
     return int(len(c)), got
+
+
+exchange_boundary.last_bytes = 0
 
 
 def exchange_boundary_layers(fuser, planes, rank, group=None, gather=None):

@@ -202,20 +202,25 @@ def _worker_exchange(rank, world, port, out_dir):
                     n += 1
             return n
 
-    f = FakeFuser()
-    sent, got = partition.exchange_boundary(f)
-    mine = f._layers()
-    want = sorted(x + 1 for x in mine if x + 1 < 20 and partition.owner_of(x + 1, origin, thick, world) != rank)
-    assert sent == f.count_boundary() and sorted(f.ghosts) == want and got == len(want), (rank, sorted(f.ghosts), want)
+    for mode in ("neighbour", "all_gather"):   # the ring shift to the one rank that needs the layers, and the all-gather of round 2
+        f = FakeFuser()
+        sent, got = partition.exchange_boundary(f, mode=mode)
+        mine = f._layers()
+        want = sorted(x + 1 for x in mine if x + 1 < 20 and partition.owner_of(x + 1, origin, thick, world) != rank)
+        assert sent == f.count_boundary() and sorted(f.ghosts) == want and got == len(want), (mode, rank, sorted(f.ghosts), want)
+        if mode == "neighbour":   # exactly what this rank keeps arrived, nothing else
+            assert partition.exchange_boundary.last_bytes == 4108 * len(want)
     np.save(os.path.join(out_dir, "x%d.npy" % rank), np.array([sent, got]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_stripe_boundary_exchange_two_ranks(tmp_path):
-    """partition.exchange_boundary (the all-gather of every rank's boundary layers + the ownership filter on import) at world size 2."""
+@pytest.mark.parametrize("world", [2, 3])
+def test_stripe_boundary_exchange_two_ranks(tmp_path, world):
+    """partition.exchange_boundary at world size 2 and 3: the ring shift (every boundary layer goes to the left neighbour and nowhere else) and
+    the all-gather + ownership filter give every rank exactly the layers above its own."""
     port = _free_port()
-    mp.spawn(_worker_exchange, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker_exchange, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     a, b = np.load(str(tmp_path / "x0.npy")), np.load(str(tmp_path / "x1.npy"))
     assert a[0] > 0 and b[0] > 0 and a[1] > 0 and b[1] > 0
 
