@@ -489,6 +489,20 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
                     if t is not None:
                         r1["traffic"] = t["bytes"]
                         r1["traffic_detail"] = t
+                # the entry point a live stream calls: one pageable host frame per call (sf_fuser_integrate), through the page-locked ring
+                nh = min(ks, 400)
+                host = frames[roof_W:roof_W + nh].cpu().numpy().view(np.uint16)
+                with fusion.Fuser(params, device=local_rank, **TUNE) as fh:
+                    fh.integrate_batch_device(frames[:roof_W].data_ptr(), stride, poses[:roof_W])
+                    fh.sync()
+                    t0 = time.perf_counter()
+                    for i in range(nh):
+                        fh.integrate(host[i], poses[roof_W + i])
+                    fh.sync()
+                    dt = time.perf_counter() - t0
+                r1["live_stream_host_buffers"] = {"frames_per_s": round(nh / dt, 1), "frames": nh,
+                                                  "what": "sf_fuser_integrate per frame from pageable host memory (copy into a page-locked ring slot, H2D, "
+                                                          "pre-pass, allocation, compaction, integrate queued; no stream drained per frame), PCIe included"}
                 out["roofline_single_frame"] = r1
         if extras and ooc_n:
             # BASELINE configs[2] bounded: the same first frames at 1 mm voxels (2^22 buckets, 2^25 blocks = 137 GB of tiles reserved), one frame per

@@ -490,7 +490,8 @@ def test_png_colour_sub_byte_depths_follow_the_png_specification(tmp_path):
         before = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
         with pytest.raises(_abi.ScanfuseError, match=what):
             sens.SensorData(p).frames[0].decompress_color()
-        assert resource.getrusage(resource.RUSAGE_SELF).ru_maxrss - before < 200 * 1024   # KiB: nothing image-sized was touched
+        if not os.environ.get("SCANFUSE_LIBRARY"):   # (the sanitizer build keeps shadow memory and quarantines: its RSS says nothing)
+            assert resource.getrusage(resource.RUSAGE_SELF).ru_maxrss - before < 200 * 1024   # KiB: nothing image-sized was touched
 
 
 def test_occipital_depth_frames_in_a_sens(oracle, tmp_path):
