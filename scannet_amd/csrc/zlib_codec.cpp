@@ -149,6 +149,25 @@ const FixedTables& fixed_tables() {
 int inflate_block(BitReader& br, const Huffman& lit, const Huffman& dist, uint8_t* out, uint64_t cap, uint64_t& pos) {
   for (;;) {
     br.refill();
+    // Runs of literals (noisy depth is mostly literals: ~450 k symbols per 640x480 frame): a first-level entry is a literal iff
+    // 1 <= entry < 256 << 4, it takes at most FAST_BITS = 11 of the >= 56 bits just loaded, so five of them need no refill and -- with 8 bytes
+    // of room left -- no bounds check each.  The first entry that is not a short literal falls through to the general path below.
+    if (pos + 8 <= cap) {
+      uint32_t e = lit.fast[br.buf & ((1u << FAST_BITS) - 1)];
+      int run = 0;
+      while ((uint16_t)(e - 1u) < 0x0FFFu && run < 5) {
+        out[pos++] = (uint8_t)(e >> 4);
+        br.buf >>= (e & 15);
+        br.cnt -= (int)(e & 15);
+        run++;
+        e = lit.fast[br.buf & ((1u << FAST_BITS) - 1)];
+      }
+      if (run == 5) {                          // the reservoir may be down to one bit: top up first
+        if (br.overrun > 8) return sf::fail(SF_ERR_FORMAT, "inflate: truncated stream");
+        continue;
+      }
+      if (run && br.cnt < 48) br.refill();     // a length / distance pair needs up to 15 + 5 + 15 + 13 bits
+    }
     int sym = decode_sym(br, lit);
     if (sym < 0) return sf::fail(SF_ERR_FORMAT, "inflate: bad literal/length code");
     if (sym < 256) {
@@ -185,6 +204,12 @@ int inflate_block(BitReader& br, const Huffman& lit, const Huffman& dist, uint8_
       for (uint32_t i = 0; i < len; i += 8) std::memcpy(dst + i, src + i, 8);
     } else if (d == 1) {
       std::memset(dst, src[0], len);
+    } else if ((d == 2 || d == 4) && pos + 8 <= cap) {
+      // the pixel to the left / two to the left (u16 data): the period divides 8, so one 8-byte pattern serves every chunk
+      uint64_t pat;
+      if (d == 2) { uint16_t h; std::memcpy(&h, src, 2); pat = 0x0001000100010001ull * h; }
+      else { uint32_t w; std::memcpy(&w, src, 4); pat = 0x0000000100000001ull * w; }
+      for (uint32_t i = 0; i < len; i += 8) std::memcpy(dst + i, &pat, 8);
     } else {
       for (uint32_t i = 0; i < len; i++) dst[i] = src[i];
     }
