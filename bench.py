@@ -430,7 +430,9 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
         return r
 
     R = 1 if child else (args.repeats if args.repeats else repeats_for(K))
-    m = run(Wm, K, not args.no_profile, single_frame=args.single_frame, repeats=R)
+    # the timed region runs WITHOUT the HIP events around every integrate launch (they cost ~2 % of the frames/s: profiles/r03_small_experiments.txt);
+    # kernel durations come from the roofline sample below, fused again with the events on.  --single-frame keeps them: its line is the roofline.
+    m = run(Wm, K, args.single_frame and not args.no_profile, single_frame=args.single_frame, repeats=R)
     out = None
     if rank == 0:
         pmc_on = world == 1 and not args.no_pmc and not args.no_profile and not child
@@ -440,12 +442,14 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
                 roof["pattern_ceiling"] = dict(m["ceiling"], frac_of_ceiling=round(roof["achieved"] / m["ceiling"]["rmw_copy_GBs"], 4))
         else:
             same = (roof_W, roof_K) == (Wm, K)
-            mr = m if same or child or args.no_profile else run(roof_W, roof_K, True)
+            mr = m if child or args.no_profile else run(roof_W, roof_K, True)
             valu = pmc_valu(args, cfg_name, roof_K, roof_W, False) if pmc_on else None
             traffic = pmc_traffic(args, cfg_name, roof_K, roof_W, False) if pmc_on else None
             roof = roofline_valu(mr, roof_K, "k_integrate<1,false,true,2>", valu, traffic,
                                  "frames %d..%d of the stream (%s), HIP events around every integrate launch; counters from rocprofv3 --pmc passes over the same frames"
-                                 % (roof_W, roof_W + roof_K - 1, "the timed region" if same else "a fixed window: the timed region of this run is too short to hold full passes"))
+                                 % (roof_W, roof_W + roof_K - 1, "the timed region, fused again with events on" if same else
+                                    ("the first frames of the timed region, fused again with events on" if roof_W == Wm else
+                                     "a fixed window: the timed region of this run is too short to hold full passes")))
         ts = m["times"]
         out = {
             "metric": "RGB-D frames/sec integrated (640x480, %s voxel)" % ("4 mm" if cfg_name == "4mm" else "1 mm"),

@@ -466,7 +466,8 @@ constexpr int RW_WORDS = RW_DEPTH * RW_LAT * RW_LAT / 32;   // 2048 words = 8 Ki
 template <bool MULTI>
 __global__ __launch_bounds__(256) void k_alloc_ray(const float* __restrict__ depthf_all, HashEntry* table, int32_t* heap,
                                                    uint64_t* block_keys, int32_t* block_entry, uint8_t* block_flags, int32_t* counters, ParamsK P,
-                                                   BatchFrames B, int group_frames) {
+                                                   BatchFrames B, int group_frames, int ablate) {
+  // ablate (tune "alloc_ablate", measurements only -- the volume is wrong with any bit set): 1 no LDS atomics, 2 no scan, 4 no DDA walk, 8 no barriers
   __shared__ uint4 s_frame4[RW_WORDS / 4];              // blocks the current frame's rays visit (slab-major)
   __shared__ uint4 s_done4[MULTI ? RW_WORDS / 4 : 1];   // blocks an earlier frame of the group has already queued
   __shared__ unsigned long long s_keys[ALLOC_SET];      // the same for blocks outside the window
@@ -496,55 +497,66 @@ __global__ __launch_bounds__(256) void k_alloc_ray(const float* __restrict__ dep
     }
   };
 
-  // ---- the window map, from the centre ray of the tile in the group's first frame (uniform: every thread computes the same numbers)
-  int w_axis, w_k0, w_sgn, w_su, w_ou, w_fu, w_sv, w_ov, w_fv;
-  {
-    const FrameK& F0 = B.f[min(j_begin, MAX_BATCH - 1)];
-    const float bs = 8.0f * P.voxel;
-    const float kxc = (((float)(blockIdx.x * 16) + 7.5f) - P.mx) / P.fx, kyc = (((float)(blockIdx.y * 16) + 7.5f) - P.my) / P.fy;
-    float dir[3], org[3];
+  // ---- the window map (uniform: every thread computes the same numbers), laid along the MEAN of the tile's centre rays in frames ja and jb --
+  // the first and the last frame it will serve: a camera that turns during the pass sweeps the pencil sideways (0.2 degrees per frame in the
+  // bench walk's corners = 7 blocks at 4 m over 16 frames), and rays that leave the window take the slow path (an LDS hash set, then one
+  // global-table probe per step: the workgroups of such tiles ran 3x longer than the rest and set the kernel's duration)
+  int w_axis = 0, w_k0 = 0, w_sgn = 1, w_su = 0, w_ou = 0, w_fu = 0, w_sv = 0, w_ov = 0, w_fv = 0;
+  const float bs = 8.0f * P.voxel;
+  const float kxc = (((float)(blockIdx.x * 16) + 7.5f) - P.mx) / P.fx, kyc = (((float)(blockIdx.y * 16) + 7.5f) - P.my) / P.fy;
+  auto centre_ray = [&](int j, float (&dir)[3], float (&org)[3]) {
+    const FrameK& Fj = B.f[min(max(j, 0), MAX_BATCH - 1)];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-      dir[r] = F0.T[4 * r] * kxc + F0.T[4 * r + 1] * kyc + F0.T[4 * r + 2];
-      org[r] = F0.T[4 * r + 3] / bs;   // camera centre in block units
+      dir[r] = Fj.T[4 * r] * kxc + Fj.T[4 * r + 1] * kyc + Fj.T[4 * r + 2];   // camera-space z component 1: dir * z = the point at depth z
+      org[r] = Fj.T[4 * r + 3] / bs;                                         // camera centre in block units
     }
+  };
+  auto anchor = [&](int ja, int jb) {
+    float da_[3], oa_[3], db_[3], ob_[3], dir[3], org[3];
+    centre_ray(ja, da_, oa_);
+    centre_ray(jb, db_, ob_);
+#pragma unroll
+    for (int r = 0; r < 3; r++) { dir[r] = 0.5f * (da_[r] + db_[r]); org[r] = 0.5f * (oa_[r] + ob_[r]); }
     const float ax = fabsf(dir[0]), ay = fabsf(dir[1]), az = fabsf(dir[2]);
-    w_axis = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
-    const float da = w_axis == 0 ? dir[0] : (w_axis == 1 ? dir[1] : dir[2]);
-    const float oa = w_axis == 0 ? org[0] : (w_axis == 1 ? org[1] : org[2]);
-    const float du_ = w_axis == 0 ? dir[1] : (w_axis == 1 ? dir[2] : dir[0]);   // u = (a + 1) % 3, v = (a + 2) % 3
-    const float dv_ = w_axis == 0 ? dir[2] : (w_axis == 1 ? dir[0] : dir[1]);
-    const float ou_ = w_axis == 0 ? org[1] : (w_axis == 1 ? org[2] : org[0]);
-    const float ov_ = w_axis == 0 ? org[2] : (w_axis == 1 ? org[0] : org[1]);
-    w_sgn = da < 0.0f ? -1 : 1;
+    int axis = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+    const float da = axis == 0 ? dir[0] : (axis == 1 ? dir[1] : dir[2]);
+    const float oa = axis == 0 ? org[0] : (axis == 1 ? org[1] : org[2]);
+    const float du_ = axis == 0 ? dir[1] : (axis == 1 ? dir[2] : dir[0]);   // u = (a + 1) % 3, v = (a + 2) % 3
+    const float dv_ = axis == 0 ? dir[2] : (axis == 1 ? dir[0] : dir[1]);
+    const float ou_ = axis == 0 ? org[1] : (axis == 1 ? org[2] : org[0]);
+    const float ov_ = axis == 0 ? org[2] : (axis == 1 ? org[0] : org[1]);
+    int sgn = da < 0.0f ? -1 : 1;
     const int cb = (int)floorf(oa);
-    w_k0 = cb - w_sgn;                                 // slab 1 holds the camera, slab 0 is one block of margin behind it
+    int k0 = cb - sgn;                                 // slab 1 holds the camera, slab 0 is one block of margin behind it
     const float inv = da != 0.0f ? 1.0f / da : 0.0f;
-    const float slu = du_ * inv * (float)w_sgn, slv = dv_ * inv * (float)w_sgn;   // lateral blocks per slab, |.| <= 1
-    // lateral position of the centre ray at the middle of slab 0 (block units), minus half the window
-    const float a0 = ((float)w_k0 + 0.5f) - oa;
+    const float slu = du_ * inv * (float)sgn, slv = dv_ * inv * (float)sgn;   // lateral blocks per slab, |.| <= 1
+    // lateral position of the centre line at the middle of slab 0 (block units), minus half the window
+    const float a0 = ((float)k0 + 0.5f) - oa;
     const float iu = ou_ + du_ * inv * a0 - (float)(RW_LAT / 2), iv = ov_ + dv_ * inv * a0 - (float)(RW_LAT / 2);
     const float fiu = floorf(iu), fiv = floorf(iv);
-    w_ou = (int)fiu; w_fu = (int)((iu - fiu) * 4096.0f);
-    w_ov = (int)fiv; w_fv = (int)((iv - fiv) * 4096.0f);
-    w_su = (int)rintf(slu * 4096.0f); w_sv = (int)rintf(slv * 4096.0f);
-    w_axis = __builtin_amdgcn_readfirstlane(w_axis); w_k0 = __builtin_amdgcn_readfirstlane(w_k0); w_sgn = __builtin_amdgcn_readfirstlane(w_sgn);
-    w_su = __builtin_amdgcn_readfirstlane(w_su); w_ou = __builtin_amdgcn_readfirstlane(w_ou); w_fu = __builtin_amdgcn_readfirstlane(w_fu);
-    w_sv = __builtin_amdgcn_readfirstlane(w_sv); w_ov = __builtin_amdgcn_readfirstlane(w_ov); w_fv = __builtin_amdgcn_readfirstlane(w_fv);
-  }
-  // block -> bit (0xFFFFFFFF outside the window)
-  auto win_bit = [&](int cx, int cy, int cz) -> uint32_t {
-    const int ca = w_axis == 0 ? cx : (w_axis == 1 ? cy : cz);
-    const int cu = w_axis == 0 ? cy : (w_axis == 1 ? cz : cx);
-    const int cv = w_axis == 0 ? cz : (w_axis == 1 ? cx : cy);
-    const int k = w_sgn > 0 ? ca - w_k0 : w_k0 - ca;
-    // (k is anything for a block far outside: the products wrap, harmlessly -- `in` only holds for 0 <= k < RW_DEPTH)
-    const uint32_t du = (uint32_t)(cu - w_ou - ((int)((uint32_t)w_su * (uint32_t)k + (uint32_t)w_fu) >> 12));
-    const uint32_t dv = (uint32_t)(cv - w_ov - ((int)((uint32_t)w_sv * (uint32_t)k + (uint32_t)w_fv) >> 12));
-    const bool in = (uint32_t)k < (uint32_t)RW_DEPTH && (du | dv) < (uint32_t)RW_LAT;
-    return in ? (((uint32_t)k << (2 * RW_LAT_LOG2)) | (dv << RW_LAT_LOG2) | du) : 0xFFFFFFFFu;
+    w_axis = __builtin_amdgcn_readfirstlane(axis); w_k0 = __builtin_amdgcn_readfirstlane(k0); w_sgn = __builtin_amdgcn_readfirstlane(sgn);
+    w_su = __builtin_amdgcn_readfirstlane((int)rintf(slu * 4096.0f)); w_ou = __builtin_amdgcn_readfirstlane((int)fiu);
+    w_fu = __builtin_amdgcn_readfirstlane((int)((iu - fiu) * 4096.0f));
+    w_sv = __builtin_amdgcn_readfirstlane((int)rintf(slv * 4096.0f)); w_ov = __builtin_amdgcn_readfirstlane((int)fiv);
+    w_fv = __builtin_amdgcn_readfirstlane((int)((iv - fiv) * 4096.0f));
   };
-
+  // How many consecutive frames one map can serve: the tile's centre point at the integration distance moves D blocks between the group's
+  // first and last frame; anchored on the mean, a map holds a sweep of ~9 blocks (window +-8, half a tile's width and the block rounding
+  // off).  A faster camera gets a fresh map -- and a cleared "already queued" bitmap, which only costs repeated look-ups -- every n_map frames.
+  int n_map = max(1, j_end - j_begin);
+  if (MULTI && j_end - j_begin > 1) {
+    float d0[3], o0[3], d1[3], o1[3];
+    centre_ray(j_begin, d0, o0);
+    centre_ray(j_end - 1, d1, o1);
+    const float far = P.maxd / bs;
+    float D = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 3; r++) D = fmaxf(D, fabsf((o1[r] + d1[r] * far) - (o0[r] + d0[r] * far)));
+    if (D > 9.0f) n_map = max(1, (int)((float)(j_end - j_begin) * 9.0f / D));
+    n_map = __builtin_amdgcn_readfirstlane(n_map);
+  }
+  int next_map = j_begin;
   const bool in_image = x < P.W && y < P.H;
   const float kx = ((float)x - P.mx) / P.fx, ky = ((float)y - P.my) / P.fy;  // the pixel's ray direction is the same for every frame
   const float rvoxel = 1.0f / P.voxel;                                        // RN(1 / voxel) for world_to_block
@@ -554,6 +566,12 @@ __global__ __launch_bounds__(256) void k_alloc_ray(const float* __restrict__ dep
     const FrameK& F = B.f[j];  // uniform index: scalar loads from the kernarg segment
     const float d_cur = d_next;
     d_next = in_image && j + 1 < j_end ? depthf_all[(size_t)(j + 1) * npx + (size_t)(y * P.W + x)] : -INFINITY;
+    if (j == next_map) {   // uniform
+      anchor(j, min(j + n_map, j_end) - 1);
+      next_map = j + n_map;
+      if (MULTI && j != j_begin)   // the queued-blocks bitmap was laid out by the old map (read again only behind the next barrier)
+        for (int i = threadIdx.x; i < RW_WORDS / 4; i += 256) s_done4[i] = make_uint4(0, 0, 0, 0);
+    }
 
     // ---- ray set-up (k_alloc's, statement for statement)
     bool active = false;
@@ -604,50 +622,112 @@ __global__ __launch_bounds__(256) void k_alloc_ray(const float* __restrict__ dep
       }
     }
 
-    // ---- DDA: one LDS bit per visited block
-    if (active) {
-      uint64_t last_key = KEY_EMPTY;
+    // ---- DDA: one LDS bit per visited block.  The walk runs in WINDOW coordinates: slab k along the pencil and the lateral block
+    // coordinates relative to the window origin (ru, rv), so that a step costs an add on one of them instead of the whole map -- and the
+    // three-way branch of the reference walk is evaluated as three lane masks (the same comparisons in the same order: x if strictly
+    // smallest, else z if smaller than y, else y), so no lane waits for the branches the others take.
+    if (active && !(ablate & 4)) {
+      // (a, u, v) = (w_axis, w_axis + 1, w_axis + 2) mod 3: uniform permutation of the ray's block coordinates, steps and bounds
+      const int c_a = w_axis == 0 ? a_cx : (w_axis == 1 ? a_cy : a_cz), c_u = w_axis == 0 ? a_cy : (w_axis == 1 ? a_cz : a_cx), c_v = w_axis == 0 ? a_cz : (w_axis == 1 ? a_cx : a_cy);
+      const int s_a = w_axis == 0 ? a_sx : (w_axis == 1 ? a_sy : a_sz), s_u = w_axis == 0 ? a_sy : (w_axis == 1 ? a_sz : a_sx), s_v = w_axis == 0 ? a_sz : (w_axis == 1 ? a_sx : a_sy);
+      const int e_a = w_axis == 0 ? a_ex : (w_axis == 1 ? a_ey : a_ez), e_u = w_axis == 0 ? a_ey : (w_axis == 1 ? a_ez : a_ex), e_v = w_axis == 0 ? a_ez : (w_axis == 1 ? a_ex : a_ey);
+      int k = w_sgn > 0 ? c_a - w_k0 : w_k0 - c_a;
+      const int k_end = w_sgn > 0 ? e_a - w_k0 : w_k0 - e_a;
+      const int dk = w_sgn > 0 ? s_a : -s_a;
+      int ru = c_u - w_ou, rv = c_v - w_ov;
+      const int ru_end = e_u - w_ou, rv_end = e_v - w_ov;
+      // the hot walk only sets bits; a ray that leaves the window (rare: the map follows the camera) is walked AGAIN below for the blocks outside
+      const int k_first = k, ru_first = ru, rv_first = rv;
+      const float tmx0 = a_tmx, tmy0 = a_tmy, tmz0 = a_tmz;
+      bool left_window = false;
       for (int it = 0; it < MAX_DDA_ITERS; ++it) {
-        const uint32_t bit = win_bit(a_cx, a_cy, a_cz);
-        const bool inwin = bit != 0xFFFFFFFFu;
+        // (a slab index far outside the window only has to fail the range test: the 24-bit product may be anything there)
+        const uint32_t du = (uint32_t)(ru - ((__mul24(w_su, k) + w_fu) >> 12));
+        const uint32_t dv = (uint32_t)(rv - ((__mul24(w_sv, k) + w_fv) >> 12));
+        const bool inwin = (uint32_t)k < (uint32_t)RW_DEPTH && (du | dv) < (uint32_t)RW_LAT;
+        const uint32_t bit = inwin ? (((uint32_t)k << (2 * RW_LAT_LOG2)) | (dv << RW_LAT_LOG2) | du) : 0xFFFFFFFFu;
         // lanes whose left neighbour (DPP row_shr:1) sets the same bit stay silent: 64 same-address ds_or serialise (see k_alloc)
         const uint32_t left = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFEu, (int)bit, 0x111, 0xF, 0xF, false);
-        if (inwin) {
-          if (left != bit) atomicOr(&s_frame[bit >> 5], 1u << (bit & 31));
-        } else {
-          const uint64_t key = pack_key(a_cx, a_cy, a_cz);
-          if (key != last_key) {
-            last_key = key;
-            if (slab_owns(P, a_cx, a_cy, a_cz) && block_in_frustum(P, F, a_cx, a_cy, a_cz)) {
-              uint32_t sl = ((uint32_t)(key ^ (key >> 21) ^ (key >> 42)) * 2654435761u) >> 24;  // 8 bits
-              bool placed = false;
-              for (int pr = 0; pr < ALLOC_SET_PROBES; ++pr) {
-                const unsigned long long old = atomicCAS(&s_keys[sl], (unsigned long long)KEY_EMPTY, (unsigned long long)key);
-                if (old == key) { placed = true; break; }  // queued by an earlier step / ray / frame
-                if (old == KEY_EMPTY) {
-                  const int pos = atomicAdd(&s_count, 1);
-                  if (pos < ALLOC_LIST) { s_list[pos] = key; s_birth[pos] = (uint8_t)j; placed = true; }
-                  break;  // queue full: direct path below
-                }
-                sl = (sl + 1) & (ALLOC_SET - 1);
-              }
-              if (!placed) direct(key, a_cx, a_cy, a_cz, B.seq0 + (uint32_t)j);
-            }
-          }
-        }
-        bool done;
-        if (a_tmx < a_tmy && a_tmx < a_tmz) { a_cx += a_sx; done = (a_cx == a_ex); a_tmx += a_tdx; }
-        else if (a_tmz < a_tmy) { a_cz += a_sz; done = (a_cz == a_ez); a_tmz += a_tdz; }
-        else { a_cy += a_sy; done = (a_cy == a_ey); a_tmy += a_tdy; }
+        if (inwin && left != bit && !(ablate & 1)) atomicOr(&s_frame[bit >> 5], 1u << (bit & 31));
+        left_window = left_window || !inwin;
+        const bool go_x = a_tmx < a_tmy && a_tmx < a_tmz;
+        const bool go_z = !go_x && a_tmz < a_tmy;
+        const bool go_y = !go_x && !go_z;
+        a_tmx += go_x ? a_tdx : 0.0f;   // x + 0 = x: the axes not taken keep their value bit for bit
+        a_tmy += go_y ? a_tdy : 0.0f;
+        a_tmz += go_z ? a_tdz : 0.0f;
+        const bool go_a = w_axis == 0 ? go_x : (w_axis == 1 ? go_y : go_z);
+        const bool go_u = w_axis == 0 ? go_y : (w_axis == 1 ? go_z : go_x);
+        k += go_a ? dk : 0;
+        ru += go_u ? s_u : 0;
+        rv += (!go_a && !go_u) ? s_v : 0;
+        const bool done = go_a ? k == k_end : (go_u ? ru == ru_end : rv == rv_end);
         if (done) break;
       }
+      if (left_window) {   // the same walk once more, this time for the blocks OUTSIDE the window: LDS hash set, then the global table
+        k = k_first; ru = ru_first; rv = rv_first;
+        a_tmx = tmx0; a_tmy = tmy0; a_tmz = tmz0;
+        uint64_t last_key = KEY_EMPTY;
+        for (int it = 0; it < MAX_DDA_ITERS; ++it) {
+          const uint32_t du = (uint32_t)(ru - ((__mul24(w_su, k) + w_fu) >> 12));
+          const uint32_t dv = (uint32_t)(rv - ((__mul24(w_sv, k) + w_fv) >> 12));
+          const bool inwin = (uint32_t)k < (uint32_t)RW_DEPTH && (du | dv) < (uint32_t)RW_LAT;
+          if (!inwin) {
+            const int ca = w_sgn > 0 ? w_k0 + k : w_k0 - k, cu = ru + w_ou, cv = rv + w_ov;
+            const int cx = w_axis == 0 ? ca : (w_axis == 1 ? cv : cu), cy = w_axis == 0 ? cu : (w_axis == 1 ? ca : cv), cz = w_axis == 0 ? cv : (w_axis == 1 ? cu : ca);
+            const uint64_t key = pack_key(cx, cy, cz);
+            if (key != last_key) {
+              last_key = key;
+              if (slab_owns(P, cx, cy, cz) && block_in_frustum(P, F, cx, cy, cz)) {
+                uint32_t sl = ((uint32_t)(key ^ (key >> 21) ^ (key >> 42)) * 2654435761u) >> 24;  // 8 bits
+                bool placed = false;
+                for (int pr = 0; pr < ALLOC_SET_PROBES; ++pr) {
+                  const unsigned long long old = atomicCAS(&s_keys[sl], (unsigned long long)KEY_EMPTY, (unsigned long long)key);
+                  if (old == key) { placed = true; break; }  // queued by an earlier step / ray / frame
+                  if (old == KEY_EMPTY) {
+                    const int pos = atomicAdd(&s_count, 1);
+                    if (pos < ALLOC_LIST) { s_list[pos] = key; s_birth[pos] = (uint8_t)j; placed = true; }
+                    break;  // queue full: direct path below
+                  }
+                  sl = (sl + 1) & (ALLOC_SET - 1);
+                }
+                if (!placed) direct(key, cx, cy, cz, B.seq0 + (uint32_t)j);
+              }
+            }
+          }
+          const bool go_x = a_tmx < a_tmy && a_tmx < a_tmz;
+          const bool go_z = !go_x && a_tmz < a_tmy;
+          const bool go_y = !go_x && !go_z;
+          a_tmx += go_x ? a_tdx : 0.0f;
+          a_tmy += go_y ? a_tdy : 0.0f;
+          a_tmz += go_z ? a_tdz : 0.0f;
+          const bool go_a = w_axis == 0 ? go_x : (w_axis == 1 ? go_y : go_z);
+          const bool go_u = w_axis == 0 ? go_y : (w_axis == 1 ? go_z : go_x);
+          k += go_a ? dk : 0;
+          ru += go_u ? s_u : 0;
+          rv += (!go_a && !go_u) ? s_v : 0;
+          const bool done = go_a ? k == k_end : (go_u ? ru == ru_end : rv == rv_end);
+          if (done) break;
+        }
+      }
     }
-    __syncthreads();
+    if (!(ablate & 8)) __syncthreads();
     // ---- scan: thread t owns slab t (8 words): blocks this frame visits that no earlier frame of the group queued -> frustum test -> queue
-    {
+    if (!(ablate & 2)) {
       const int k = (int)threadIdx.x;
       const uint4 f0 = s_frame4[2 * k], f1 = s_frame4[2 * k + 1];
-      if ((f0.x | f0.y | f0.z | f0.w | f1.x | f1.y | f1.z | f1.w) != 0u) {   // ~10 threads of the workgroup
+      bool occupied = (f0.x | f0.y | f0.z | f0.w | f1.x | f1.y | f1.z | f1.w) != 0u;   // ~10 threads of the workgroup
+      if (MULTI && occupied) {
+        // the usual case inside a pass: everything this frame visits in the slab was queued by an earlier frame -- two more reads say so, and
+        // the slab is cleared for the next frame without walking its words
+        const uint4 d0 = s_done4[2 * k], d1 = s_done4[2 * k + 1];
+        if (((f0.x & ~d0.x) | (f0.y & ~d0.y) | (f0.z & ~d0.z) | (f0.w & ~d0.w) | (f1.x & ~d1.x) | (f1.y & ~d1.y) | (f1.z & ~d1.z) | (f1.w & ~d1.w)) == 0u) {
+          s_frame4[2 * k] = make_uint4(0, 0, 0, 0);
+          s_frame4[2 * k + 1] = make_uint4(0, 0, 0, 0);
+          occupied = false;
+        }
+      }
+      if (occupied) {
         uint32_t* const s_done = reinterpret_cast<uint32_t*>(s_done4);
         const int ca = w_sgn > 0 ? w_k0 + k : w_k0 - k;
         const int cu0 = w_ou + ((w_su * k + w_fu) >> 12), cv0 = w_ov + ((w_sv * k + w_fv) >> 12);
@@ -677,7 +757,7 @@ __global__ __launch_bounds__(256) void k_alloc_ray(const float* __restrict__ dep
         }
       }
     }
-    __syncthreads();   // slabs re-zeroed before the next frame's rays set bits
+    if (!(ablate & 8)) __syncthreads();   // slabs re-zeroed before the next frame's rays set bits
   }
 
   // ---- phase 2: queued keys -> global hash, all lanes in parallel (k_alloc's)
@@ -1625,8 +1705,12 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
     const dim3 ag((f->p.depth_width + 15) / 16, (f->p.depth_height + 15) / 16, (n + gf - 1) / gf);
 #define LAUNCH_ALLOC(WL, MU) \
   hipLaunchKernelGGL((k_alloc<WL, MU>), ag, dim3(256), 0, sa, f->depthf2[sl], f->table, f->heap, f->block_keys, f->block_entry, f->block_flags, f->counters, f->pk, bf, gf)
+    // alloc_wgs > 0: at most that many allocation workgroups per CU, by asking for LDS the kernel does not use (160 KiB per CU).  The kernel
+    // is latency-bound (barriers, LDS atomics: 35 % VALU utilisation) and, unthrottled, parks 4-5 waves of 72 VGPRs on every SIMD for ~200 us of
+    // each pass -- registers the integrate kernel next to it needs for ITS waves (timeline: profiles/r03_timeline_*.txt)
+    const unsigned alloc_pad = (f->alloc_wgs > 0 && n > 1) ? (unsigned)std::max(0, (160 * 1024) / (f->alloc_wgs + 1) + 1024 - 23048) : 0u;
 #define LAUNCH_ALLOC_RAY(MU) \
-  hipLaunchKernelGGL((k_alloc_ray<MU>), ag, dim3(256), 0, sa, f->depthf2[sl], f->table, f->heap, f->block_keys, f->block_entry, f->block_flags, f->counters, f->pk, bf, gf)
+  hipLaunchKernelGGL((k_alloc_ray<MU>), ag, dim3(256), alloc_pad, sa, f->depthf2[sl], f->table, f->heap, f->block_keys, f->block_entry, f->block_flags, f->counters, f->pk, bf, gf, f->alloc_ablate)
     if (f->alloc_ray) { if (gf == 1) LAUNCH_ALLOC_RAY(false); else LAUNCH_ALLOC_RAY(true); }
     else if (f->alloc_win64) LAUNCH_ALLOC(6, false);
     else if (gf == 1) LAUNCH_ALLOC(5, false);
@@ -2058,6 +2142,16 @@ SF_API int sf_fuser_tune(sf_fuser* f, const char* key, int value) {
     f->front_cus = value;
   }
   else if (k == "alloc_group" && in(1, MAX_BATCH)) f->alloc_group = value;
+  else if (k == "alloc_wgs" && in(0, 8)) f->alloc_wgs = value;
+  else if (k == "alloc_ablate" && in(0, 15)) f->alloc_ablate = value;
+  else if (k == "front_prio" && in(0, 1)) {   // 1: the front stream at the device's highest priority (default), 0: at the default priority
+    int prio_lo = 0, prio_hi = 0;
+    SF_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    hipStream_t nf = nullptr;
+    SF_HIP_CHECK(hipStreamCreateWithPriority(&nf, hipStreamNonBlocking, value ? prio_hi : prio_lo));
+    (void)hipStreamDestroy(f->front);
+    f->front = nf;
+  }
   else if (k == "alloc_ray" && in(0, 1)) f->alloc_ray = value != 0;   // 1: the ray-space window whatever the geometry (rays outside it take the slow path), 0: the cube window
   else if (k == "ramp" && in(0, MAX_BATCH)) f->ramp = value;
   else return sf::fail(SF_ERR_INVALID_ARG, "sf_fuser_tune: unknown key or value out of range: %s = %d", key, value);

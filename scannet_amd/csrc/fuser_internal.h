@@ -221,6 +221,8 @@ struct sf_fuser {
   int32_t* host_mirror = nullptr;  // pinned, device-visible: N_blk of the most recent integrate
   int num_cus = 256;
   bool alloc_win64 = false;  // 64^3-block LDS window when a ray segment spans more than ~20 blocks
+  int alloc_ablate = 0;      // measurement only (tune "alloc_ablate"): parts of k_alloc_ray switched off, the volume is WRONG with any bit set
+  int alloc_wgs = 0;         // > 0: allocation workgroups per CU capped (LDS padding) so that the integrate kernel beside them keeps its waves (tune "alloc_wgs")
   bool alloc_ray = false;    // k_alloc_ray (occupancy bitmap in ray space: 16 x 16 blocks across the pixel tile's pencil of rays, 256 slabs along it) instead of the cube window
   bool xcd_walk = true;  // k_integrate: each XCD walks one contiguous eighth of the list (tune "xcd_walk" 0: plain grid-stride)
   int pipe_mode = 1;    // 1: colourless one-frame launches run k_integrate_pipe (tune "pipe" 0: k_integrate)
