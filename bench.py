@@ -16,7 +16,7 @@
                          to the ranks, boundary layers all-gathered over RCCL before marching cubes; one step = one frame (strong scaling).
 
 `roofline` describes the dominant kernel of the timed region and every `frac` is a fraction of a hardware peak (<= 1):
-  * 16 frames per launch (the default schedule) is VALU-issue bound: bound = "valu", frac = SQ_ACTIVE_INST_VALU over the SIMD issue
+  * 32 frames per launch (the default schedule) is VALU-issue bound: bound = "valu", frac = SQ_ACTIVE_INST_VALU over the SIMD issue
     slots of the launch (separate rocprofv3 --pmc pass), hbm_frac = counter traffic / time / 8 TB/s, alg_equiv_GBs = what the launch
     would have moved without temporal blocking (SURVEY 8d algorithmic bytes / time: NOT a roofline fraction).
   * `roofline_single_frame` (one frame per launch, what a live stream gets) is HBM bound: achieved = algorithmic bytes / time.
@@ -157,7 +157,7 @@ def parity_leg(ovol, n, frames_dev, stride, poses, params, local_rank):
     return {"frames": n, "blocks": int(len(gc)), "blocks_oracle": int(len(oc)), "sha256_equal": ho == hg, "sha256": hg[:16], "alloc_failures": fails,
             "weight_max_seen": int(gv["w"].max()) if len(gc) else 0,
             "what": "sha256 over (block coordinates sorted by x, y, z; 512 x 8-byte voxels per block) of oracle/tsdf_oracle.c and of the HIP path "
-                    "(16 frames per pass) after the first %d frames of this run's stream" % n}
+                    "(the default schedule: 32 frames per pass) after the first %d frames of this run's stream" % n}
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------------
@@ -272,7 +272,7 @@ def end_to_end(frames_dev, poses, n, params, local_rank, torch):
                 "decode_ms_per_frame_per_thread": round(1e3 * rs["seconds_decode_cpu"] / max(rs["frames_total"], 1), 3),
                 "blocks_live_end": st["blocks_allocated"], "alloc_failures": st["alloc_failures"], "write_s": round(t_write, 2),
                 "what": ".sens on disk (zlib depth, %d KB per frame) -> %d decode threads -> pinned ring -> H2D -> pre-pass / allocation / compaction / integrate, "
-                        "16 frames per pass; wall time of sf_fuse_run (first byte decoded -> last kernel complete), best of 2" % (size // n // 1024, rs["decode_threads"])}
+                        "32 frames per pass; wall time of sf_fuse_run (first byte decoded -> last kernel complete), best of 2" % (size // n // 1024, rs["decode_threads"])}
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
@@ -404,8 +404,8 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
         return r
 
     def roofline_valu(m, n_timed, kernel, valu, traffic, sample):
-        """16 frames per launch: VALU-issue bound.  frac = measured VALU issue utilisation; hbm_frac from the counter traffic; hbm_alg_batch = the
-        bytes a 16-frame pass must move (its tiles once + its depth images) over the launch duration, against the 8 TB/s peak."""
+        """Many frames per launch (32 by default): VALU-issue bound.  frac = measured VALU issue utilisation; hbm_frac from the counter traffic; hbm_alg_batch = the
+        bytes one pass must move (its tiles once + its depth images) over the launch duration, against the 8 TB/s peak."""
         if not m["launches"]:
             return None
         t_s = m["kernel_ms"] * 1e-3 / m["launches"]
@@ -543,7 +543,7 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
                 rc = {"bound": "valu", "frames_per_s": round(kc / mc["elapsed"], 1), "ms_per_frame": round(mc["elapsed"] * 1e3 / kc, 5),
                       "kernel": "k_integrate<1,true,true,2>", "alg_equiv_GBs": round(mc["alg_bytes"] / mc["launches"] / t_s / 1e9, 1),
                       "sample": "frames %d..%d" % (roof_W, roof_W + kc - 1),
-                      "note": "16 frames per launch with a colour gather and blend per voxel on top of the geometry update; VALU-issue bound like the geometry kernel "
+                      "note": "32 frames per launch with a colour gather and blend per voxel on top of the geometry update; VALU-issue bound like the geometry kernel "
                               "(frac: see roofline.frac; no separate counter pass is run for it)"}
                 rc.update(per_launch(mc, kc))
                 out["roofline_colour"] = rc
@@ -668,7 +668,7 @@ def run_scans(args, rank, local_rank, world, dist, torch):
         "host_stage_parts_s_mean_rank0": {k: round(float(np.mean([r.get(k, 0.0) for _, r in done])), 3)
                                           for k in ("clean_s", "decimate_s", "clean_lores_s", "segment_s", "decimate_rounds", "faces")} if host_s else None,
         "roofline": None,
-        "note": "per scan: frames rendered into HBM in chunks of %d (input generation, counted as GPU-busy), fused 16 frames per pass, marching cubes; the host "
+        "note": "per scan: frames rendered into HBM in chunks of %d (input generation, counted as GPU-busy), fused 32 frames per pass, marching cubes; the host "
                 "stage runs on threads while the GPU takes the next scan.  With the full host stage the CPUs, not the GPU, set scans/min" % chunk,
     }
 

@@ -39,8 +39,8 @@ struct BatchSlot {
   bool used[2] = {false, false};
   std::atomic<int> decoded{0};    // frames of the current generation the pool has finished with
   std::atomic<int> failed{0};
-  uint8_t coef_mode[16] = {0};    // per frame: 1 = the pinned colour payload holds JPEG coefficients (GPU reconstructs), 0 = RGB
-  uint32_t pay_used[16] = {0};    // bytes of that payload
+  uint8_t coef_mode[MAX_BATCH] = {0};    // per frame: 1 = the pinned colour payload holds JPEG coefficients (GPU reconstructs), 0 = RGB
+  uint32_t pay_used[MAX_BATCH] = {0};    // bytes of that payload
 };
 
 }  // namespace
@@ -302,10 +302,12 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
         int nj = 0;
         for (int q = jfirst; q < j; q++)
           if (valid[q] && rgbf[q] && bs.coef_mode[q]) { pp_[nj] = d_pay(sl, q); rr_[nj] = d_rgb(sl, q); pl_[nj] = d_planes(sl, q); nj++; }
-        if (nj > 0) {
-          const int rcj = jpeg_gpu_reconstruct(in_stream, nj, pp_, rr_, pl_, pay_blocks, s->info.color_width, s->info.color_height);
-          if (rcj != SF_OK) { result = rcj; err = sf_last_error(); break; }
+        bool jpeg_failed = false;
+        for (int q0 = 0; q0 < nj; q0 += 16) {   // jpeg_gpu.hip reconstructs at most 16 frames per launch
+          const int rcj = jpeg_gpu_reconstruct(in_stream, std::min(16, nj - q0), pp_ + q0, rr_ + q0, pl_ + q0, pay_blocks, s->info.color_width, s->info.color_height);
+          if (rcj != SF_OK) { result = rcj; err = sf_last_error(); jpeg_failed = true; break; }
         }
+        if (jpeg_failed) break;
       }
       const int rc = sf_fuser_run_batch(f, dd, rgb ? dr : nullptr, pp, m);
       if (rc != SF_OK) { result = rc; err = sf_last_error(); break; }

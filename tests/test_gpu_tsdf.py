@@ -71,14 +71,15 @@ def test_room_stream_bit_exact(oracle):
 
 
 def test_batched_pass_equals_frame_by_frame(oracle):
-    """Temporal blocking: sf_fuser_integrate_batch_device fuses up to 16 frames per pass over the tiles.  The result must
+    """Temporal blocking: sf_fuser_integrate_batch_device fuses up to 32 frames per pass over the tiles.  The result must
     be the frame-by-frame result bit for bit: blocks born in the middle of a batch (large pose jumps) only receive the
     frames from their birth on, skipped poses leave gaps, the final batch is partial."""
     from scannet_amd import fusion
     W, H = 320, 240
     op, gp = _mk(oracle, W, H, voxel=0.008, num_sdf_blocks=1 << 17)
     ovol = oracle.Volume(op, threads=8)
-    idx = [0, 1, 2, 300, 301, 3, 600, 601, 900, 4, 5, 1100, 302, 303, 6, 7, 8, 602, 9, 901, 902, 10, 11]  # 23 frames: 16 + 7
+    idx = [0, 1, 2, 300, 301, 3, 600, 601, 900, 4, 5, 1100, 302, 303, 6, 7, 8, 602, 9, 901, 902, 10, 11,
+           12, 13, 304, 305, 14, 603, 604, 15, 16, 903, 17, 18, 1101, 19, 306, 20, 21, 605, 22, 23, 904, 24, 25, 26]  # 47 frames: passes of 8 (ramp), 32 and 7
     depth = np.zeros((len(idx), H, W), np.uint16)
     poses = np.zeros((len(idx), 16), np.float32)
     last = None
@@ -98,10 +99,10 @@ def test_batched_pass_equals_frame_by_frame(oracle):
     try:
         _abi.check(L.sf_device_upload(dptr, depth.ctypes.data_as(C.c_void_p), depth.nbytes))
         with fusion.Fuser(gp) as f:
-            assert f.batch_frames == 16
+            assert f.batch_frames == 32
             f.integrate_batch_device(dptr.value, W * H * 2, poses)
             st = f.stats()
-            assert st["frames_integrated"] == 21 and st["frames_skipped"] == 2
+            assert st["frames_integrated"] == len(idx) - 2 and st["frames_skipped"] == 2
             assert st["last_frame_blocks"] == last
             _assert_same(ovol, f)
     finally:
@@ -622,15 +623,16 @@ def _static_view_stream(W, H, n, wobble_every=0, seed=11, colour=False):
     return depth, poses, rgb
 
 
-@pytest.mark.parametrize("schedule,colour", [("batch16", False), ("pipe", False), ("one_frame_kernel", False), ("batch16", True), ("one_frame_kernel", True)])
+@pytest.mark.parametrize("schedule,colour", [("batch32", False), ("batch16", False), ("pipe", False), ("one_frame_kernel", False), ("batch32", True), ("batch16", True),
+                                             ("one_frame_kernel", True)])
 def test_weights_at_the_clamp_match_the_oracle(oracle, schedule, colour):
     """320 frames onto one 160x120 view: weights pass 255.  Compared bit for bit with the oracle below the clamp (130 frames), right at it (256)
-    and 64 frames beyond, through the 16-frame pass, the persistent one-frame kernel (k_integrate_pipe) and k_integrate at one frame per launch."""
+    and 64 frames beyond, through the 32- and the 16-frame pass, the persistent one-frame kernel (k_integrate_pipe) and k_integrate at one frame per launch."""
     from scannet_amd import fusion
     W, H, N = 160, 120, 320
     op, gp = _mk(oracle, W, H, voxel=0.01, num_sdf_blocks=1 << 15)
     depth, poses, rgb = _static_view_stream(W, H, N, wobble_every=37, colour=colour)
-    tune = {"batch16": {}, "pipe": {"batch": 1}, "one_frame_kernel": {"batch": 1, "pipe": 0}}[schedule]
+    tune = {"batch32": {}, "batch16": {"batch": 16}, "pipe": {"batch": 1}, "one_frame_kernel": {"batch": 1, "pipe": 0}}[schedule]
     ovol = oracle.Volume(op, threads=8)
     dev = _DeviceFrames(depth, rgb)
     try:
