@@ -70,25 +70,32 @@ def cpu_baseline(depth_host, poses, voxel, frames=200):
     decode = reference_decode_ms(depth_host[:32], poses[:32])
     t_dec = (decode or {}).get("reference_sensreader")
     by, keep = {}, None
+    n_all = n
     for th in sorted({1, min(8, allt), allt}):
         vol = orc.Volume(orc.default_params(W, H, voxel), threads=th)
+        budget = 30.0 if th == 1 else 12.0   # seconds: the 4 mm stream finishes its 200 frames inside these, 1 mm voxels (0.25 s per frame on 16 threads) do not
         t0 = time.perf_counter()
+        done = 0
         for i in range(n):
             vol.integrate(depth_host[i], poses[i])
+            done += 1
+            if time.perf_counter() - t0 > budget:
+                break
         dt = time.perf_counter() - t0
-        e = {"frames_per_s_integrate": round(n / dt, 3), "seconds": round(dt, 2)}
+        e = {"frames": done, "frames_per_s_integrate": round(done / dt, 3), "seconds": round(dt, 2)}
         if t_dec:   # the reference decodes one frame per call on the caller's thread; `th` threads decode `th` frames at once
-            e["frames_per_s_with_reference_decode"] = round(1.0 / (dt / n + t_dec * 1e-3 / th), 3)
+            e["frames_per_s_with_reference_decode"] = round(1.0 / (dt / done + t_dec * 1e-3 / th), 3)
         by[str(th)] = e
         if th == allt:
-            keep = vol
+            keep, n_all = vol, done
         else:
             vol.close()
+    n = n_all
     best = by[str(allt)]
     out = {"value": best.get("frames_per_s_with_reference_decode", best["frames_per_s_integrate"]), "unit": "frames/s", "cores": allt, "kind": "port",
            "by_threads": by, "reference_decode": decode,
            "cpu_model": _cpu_model(), "nproc_visible": os.cpu_count(),
-           "sample": "first %d frames of the same stream: reference SensorData depth decode (oracle/_ref/libref_sens.so, -O2, one frame per thread) + "
+           "sample": "first %d frames of the same stream (fewer where a leg ran into its time budget: by_threads.*.frames): reference SensorData depth decode (oracle/_ref/libref_sens.so, -O2, one frame per thread) + "
                      "oracle/tsdf_oracle.c (-O2 -fopenmp, blocks over threads) at 1 / 8 / %d threads (= the CPUs this container may use, of %d visible); "
                      "`value` is the all-threads figure" % (n, allt, os.cpu_count() or allt)}
     return out, keep, n
@@ -277,10 +284,12 @@ def end_to_end(frames_dev, poses, n, params, local_rank, torch):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def repeats_for(K):
-    """How often the K timed steps are repeated (fresh volume each time) so that the timed regions add up to ~1 s of GPU time at the ~30 us per
-    frame this path runs at -- a function of K alone, so every rank of a multi-GPU run takes the same number."""
-    return int(min(2000, max(3, -(-1.0 // (K * 30e-6)))))
+def repeats_for(K, cfg_name="4mm"):
+    """How often the K timed steps are repeated (fresh volume each time) so that the timed regions add up to ~1 s of GPU time at the rate this
+    path runs at (~30 us per frame at 4 mm, ~1 ms at 1 mm) -- a function of K and the configuration alone, so every rank of a multi-GPU run takes
+    the same number."""
+    per_frame = 30e-6 if cfg_name == "4mm" else 1e-3
+    return int(min(2000, max(3, -(-1.0 // (K * per_frame)))))
 
 
 def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
@@ -429,7 +438,7 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
             r["traffic_detail"] = traffic
         return r
 
-    R = 1 if child else (args.repeats if args.repeats else repeats_for(K))
+    R = 1 if child else (args.repeats if args.repeats else repeats_for(K, cfg_name))
     # the timed region runs WITHOUT the HIP events around every integrate launch (they cost ~2 % of the frames/s: profiles/r03_small_experiments.txt);
     # kernel durations come from the roofline sample below, fused again with the events on.  --single-frame keeps them: its line is the roofline.
     m = run(Wm, K, args.single_frame and not args.no_profile, single_frame=args.single_frame, repeats=R)
