@@ -44,18 +44,21 @@ __global__ __launch_bounds__(256) void k_synth_room(uint16_t* __restrict__ out, 
   const double cx = ((double)x - mx) / fx, cy = ((double)y - my) / fy;
   const double room[3] = {rx, ry, rz};
   double t = INFINITY;
-  double dir[3];
+  double dir[3], inv[3];
   int axis = 0;   // axis of the surface hit (its normal): for the grazing-angle holes of scene 1
 #pragma unroll
   for (int a = 0; a < 3; a++) {
     const double d = fr.R[3 * a] * cx + fr.R[3 * a + 1] * cy + fr.R[3 * a + 2];
     dir[a] = d;
+    inv[a] = 1.0 / d;   // one division per axis: the 48 boxes below multiply (144 fp64 divisions per pixel made the generator slower than the fusion)
     double ta = INFINITY;
     if (d > 0) ta = (room[a] - fr.o[a]) / d;
     else if (d < 0) ta = (0.0 - fr.o[a]) / d;
     if (ta < t) { t = ta; axis = a; }
   }
-  // boxes: slab test from outside; the entry face gives the normal
+  // boxes: slab test from outside; the entry face gives the normal.  Which box is hit is decided with the reciprocals; the depth of the hit is
+  // then taken with the division the host renderer uses, so the two agree to the bit but for rays that graze an edge.
+  int hit_box = -1;
   for (int b = 0; b < boxes.n; b++) {
     double tn = 0.0, tf = INFINITY;
     int an = 0;
@@ -64,12 +67,16 @@ __global__ __launch_bounds__(256) void k_synth_room(uint16_t* __restrict__ out, 
     for (int a = 0; a < 3; a++) {
       const double lo = boxes.lo[b][a], hi = boxes.hi[b][a];
       if (dir[a] == 0.0) { miss = miss || fr.o[a] < lo || fr.o[a] > hi; continue; }
-      double t0 = (lo - fr.o[a]) / dir[a], t1 = (hi - fr.o[a]) / dir[a];
+      double t0 = (lo - fr.o[a]) * inv[a], t1 = (hi - fr.o[a]) * inv[a];
       if (t0 > t1) { const double q = t0; t0 = t1; t1 = q; }
       if (t0 > tn) { tn = t0; an = a; }
       tf = fmin(tf, t1);
     }
-    if (!miss && tn < tf && tn > 0.0 && tn < t) { t = tn; axis = an; }
+    if (!miss && tn < tf && tn > 0.0 && tn < t) { t = tn; axis = an; hit_box = b; }
+  }
+  if (hit_box >= 0) {
+    const double face = dir[axis] > 0.0 ? (double)boxes.lo[hit_box][axis] : (double)boxes.hi[hit_box][axis];
+    t = (face - fr.o[axis]) / dir[axis];
   }
   double mm = rint(t * 1000.0);
   long long v = (mm < 65535.0) ? (long long)mm : 0;  // also catches inf / nan
