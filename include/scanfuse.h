@@ -82,6 +82,11 @@ typedef struct sf_params {
    *                 1: VoxelHashing: (uchar)max(weightSample * 1.5f * (1 - (d - depthMin) / (depthMax - depthMin)), 1.0f).  With the shipped
    *                    weightSample = 1 (zParametersScanNet.txt:52) both give 1 for every depth. */
   int32_t frustum_mode, colour_round, colour_first, weight_mode;
+  /*   weight_wrap   0: the 8-bit weight saturates at min(s_SDFIntegrationWeightMax, 255) (SURVEY App. C decision).
+   *                 1: upstream stores min(weightMax, w0 + w1) into its `uchar weight` -- with the shipped weightMax = 99999999
+   *                    (zParametersScanNet.txt:53) the 256th observation of a voxel WRAPS its weight to 0 and the running mean starts again.
+   *                    weight_max is then taken as given (not clamped to 255) and the stored weight is the sum modulo 256. */
+  int32_t weight_wrap;
 } sf_params;
 
 /* SURVEY 8d camera + zParametersScanNet.txt values with BASELINE.json's 4 mm / 2^19-bucket overrides */

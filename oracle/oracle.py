@@ -32,6 +32,7 @@ class OrParams(C.Structure):
         ("weight_sample", C.c_int32), ("weight_max", C.c_int32),
         ("mc_thresh_factor", C.c_float),
         ("frustum_mode", C.c_int32), ("colour_round", C.c_int32), ("colour_first", C.c_int32), ("weight_mode", C.c_int32),
+        ("weight_wrap", C.c_int32),
     ]
 
 

@@ -47,12 +47,13 @@ def centre_in_frustum(coords, Ti, *, voxel, fx, fy, mx, my, width, height, dmin,
 
 
 def evaluate(frames, coords, birth, *, voxel, fx, fy, mx, my, width, height, trunc_base=0.06, trunc_scale=0.02, max_dist=4.0, weight_sample=1,
-             weight_max=255, depth_shift=1000.0, dmin=0.1, dmax=6.0, eps_px=None, eps_m=2e-5, frustum_mode=0, weight_mode=0):
+             weight_max=255, depth_shift=1000.0, dmin=0.1, dmax=6.0, eps_px=None, eps_m=2e-5, frustum_mode=0, weight_mode=0, weight_wrap=0):
     """frames: [(depth u16 [H,W], camToWorld 4x4)], in order.  coords: int [n,3] block coordinates.  birth: int [n] index of the first frame
     at which block i exists (allocation is a separate rule; the caller takes it from the implementation under test).
     frustum_mode 0: every existing block is visited (the sphere test of App. C is conservative: it never keeps a voxel that projects into the
     image from being visited, so it is not evaluated here).  frustum_mode 1: only blocks whose centre passes `centre_in_frustum` for the frame.
     weight_mode 1: an observation weighs (uchar)max(weight_sample * 1.5 * (1 - (d - dmin) / (dmax - dmin)), 1) (VoxelHashing).
+    weight_wrap 1: the stored weight is min(weight_max, w + w_new) modulo 256 (upstream's uchar; no clamp at 255).
     Returns (sdf float64 [n,512], weight int [n,512], tie bool [n,512])."""
     if eps_px is None:
         eps_px = 1e-6 * max(width, height)   # ~8 ulp of a pixel coordinate at the far edge of the image: what a few fp32 roundings can move it
@@ -69,7 +70,7 @@ def evaluate(frames, coords, birth, *, voxel, fx, fy, mx, my, width, height, tru
     sdf_acc = np.zeros((n, 512), np.float64)
     w_acc = np.zeros((n, 512), np.int64)
     tie = np.zeros((n, 512), bool)
-    wmax = min(int(weight_max), 255)
+    wmax = int(weight_max) if weight_wrap else min(int(weight_max), 255)
     wn = float(weight_sample)
     birth = np.asarray(birth, np.int64)
     for k, (depth, pose) in enumerate(frames):
@@ -121,6 +122,7 @@ def evaluate(frames, coords, birth, *, voxel, fx, fy, mx, my, width, height, tru
             wk = np.full(dd.shape, wn)
         new_s = (so * wo + s * wk) / (wo + wk)
         sdf_acc[live] = np.where(upd, new_s, so)
-        w_acc[live] = np.where(upd, np.minimum(wmax, wo + wk.astype(np.int64)), wo)
+        w_new = np.minimum(wmax, wo + wk.astype(np.int64))
+        w_acc[live] = np.where(upd, w_new % 256 if weight_wrap else w_new, wo)
         tie[live] |= t_here
     return sdf_acc, w_acc, tie

@@ -56,6 +56,7 @@ typedef struct {
   int32_t colour_round;         /* 1: (uchar)(0.5f a + 0.5f b + 0.5f) */
   int32_t colour_first;         /* 1: a black accumulated colour, not a zero weight, marks the first observation */
   int32_t weight_mode;          /* 1: depth-dependent observation weight (VoxelHashing) */
+  int32_t weight_wrap;          /* 1: weight_max as given, the sum stored modulo 256 (upstream's uchar with weightMax = 99999999) */
 } or_params;
 
 typedef struct {
@@ -142,7 +143,7 @@ static int32_t block_insert(or_volume* v, int32_t x, int32_t y, int32_t z) {
 or_volume* or_create(const or_params* p, int threads) {
   or_volume* v = (or_volume*)calloc(1, sizeof(or_volume));
   v->p = *p;
-  if (v->p.weight_max > 255) v->p.weight_max = 255; /* uchar weight: saturate (SURVEY App. C decision) */
+  if (v->p.weight_max > 255 && !v->p.weight_wrap) v->p.weight_max = 255; /* uchar weight: saturate (SURVEY App. C decision) */
   v->map_cap = 1u << 16;
   v->keys = (uint64_t*)malloc(v->map_cap * sizeof(uint64_t));
   v->vals = (int32_t*)malloc(v->map_cap * sizeof(int32_t));

@@ -23,6 +23,7 @@ class SfParams(C.Structure):
         ("cfx", C.c_float), ("cfy", C.c_float), ("cmx", C.c_float), ("cmy", C.c_float),
         ("integration_width", C.c_int32), ("integration_height", C.c_int32),
         ("frustum_mode", C.c_int32), ("colour_round", C.c_int32), ("colour_first", C.c_int32), ("weight_mode", C.c_int32),
+        ("weight_wrap", C.c_int32),
     ]
 
 

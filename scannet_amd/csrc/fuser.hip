@@ -1815,8 +1815,8 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
   if ((p->integration_width > 0) != (p->integration_height > 0) || p->integration_width == 1 || p->integration_height == 1 ||
       (p->integration_width > 0 && (p->depth_width < 2 || p->depth_height < 2)))
     return sf::fail(SF_ERR_INVALID_ARG, "integration size %d x %d", p->integration_width, p->integration_height);
-  if ((p->frustum_mode | p->colour_round | p->colour_first | p->weight_mode) & ~1)
-    return sf::fail(SF_ERR_INVALID_ARG, "frustum_mode / colour_round / colour_first / weight_mode must be 0 or 1");
+  if ((p->frustum_mode | p->colour_round | p->colour_first | p->weight_mode | p->weight_wrap) & ~1)
+    return sf::fail(SF_ERR_INVALID_ARG, "frustum_mode / colour_round / colour_first / weight_mode / weight_wrap must be 0 or 1");
   if (p->frustum_mode == 1 && !(p->depth_max > p->depth_min))
     return sf::fail(SF_ERR_INVALID_ARG, "frustum_mode 1 normalises z by the sensor depth range: depth_max must exceed depth_min");
   if ((uint64_t)p->hash_num_buckets * p->hash_bucket_size > 0x7FFFFFFFull || p->num_sdf_blocks > 0x3FFFFFFFu)
@@ -1837,7 +1837,8 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
     }                                                                                                       \
   } while (0)
   f->p = *p;
-  if (f->p.weight_max > 255) f->p.weight_max = 255;  // uchar weight saturates (SURVEY App. C decision)
+  if (f->p.weight_max > 255 && !f->p.weight_wrap) f->p.weight_max = 255;  // uchar weight saturates (SURVEY App. C decision)
+  if (f->p.weight_max > 0x00FFFFFF) f->p.weight_max = 0x00FFFFFF;   // weight_wrap: "no limit" for an 8-bit sum; the clamp compare stays exact in 32 bits
   if (f->p.weight_max < 1) f->p.weight_max = 1;
   f->device = device;
   {

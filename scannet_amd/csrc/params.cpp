@@ -52,7 +52,7 @@ SF_API void sf_params_default(sf_params* p) {
   p->color_width = 0; p->color_height = 0;
   p->cfx = p->cfy = p->cmx = p->cmy = 0.0f;
   p->integration_width = p->integration_height = 0;   // integrate at the input resolution (BASELINE.json's 640x480)
-  p->frustum_mode = p->colour_round = p->colour_first = p->weight_mode = 0;   // SURVEY App. C throughout (scanfuse.h: upstream-conformance switches)
+  p->frustum_mode = p->colour_round = p->colour_first = p->weight_mode = p->weight_wrap = 0;   // SURVEY App. C throughout (scanfuse.h: upstream-conformance switches)
 }
 
 namespace {
@@ -144,7 +144,7 @@ SF_API int sf_params_load_file(const char* path, sf_params* p) {
 #undef GETF
   int64_t v;
   v = p->weight_sample; if ((rc = geti("s_SDFIntegrationWeightSample", &v)) != SF_OK) return rc; p->weight_sample = (int32_t)v;
-  v = p->weight_max;    if ((rc = geti("s_SDFIntegrationWeightMax", &v)) != SF_OK) return rc;    p->weight_max = (int32_t)(v > 255 ? 255 : v);
+  v = p->weight_max;    if ((rc = geti("s_SDFIntegrationWeightMax", &v)) != SF_OK) return rc;    p->weight_max = (int32_t)(v > 0x7FFFFFFF ? 0x7FFFFFFF : v);   // sf_fuser_create clamps to 255 unless weight_wrap
   v = p->hash_num_buckets; if ((rc = geti("s_hashNumBuckets", &v)) != SF_OK) return rc; p->hash_num_buckets = (uint32_t)v;
   v = p->num_sdf_blocks;   if ((rc = geti("s_hashNumSDFBlocks", &v)) != SF_OK) return rc; p->num_sdf_blocks = (uint32_t)v;
   v = p->mc_max_triangles; if ((rc = geti("s_marchingCubesMaxNumTriangles", &v)) != SF_OK) return rc; p->mc_max_triangles = (uint32_t)v;
@@ -157,6 +157,7 @@ SF_API int sf_params_load_file(const char* path, sf_params* p) {
   v = p->colour_round; if ((rc = geti("s_scanfuseColourRound", &v)) != SF_OK) return rc; p->colour_round = (int32_t)v;
   v = p->colour_first; if ((rc = geti("s_scanfuseColourFirst", &v)) != SF_OK) return rc; p->colour_first = (int32_t)v;
   v = p->weight_mode;  if ((rc = geti("s_scanfuseWeightMode", &v)) != SF_OK) return rc;  p->weight_mode = (int32_t)v;
+  v = p->weight_wrap;  if ((rc = geti("s_scanfuseWeightWrap", &v)) != SF_OK) return rc;  p->weight_wrap = (int32_t)v;
   if (!(p->voxel_size > 0) || p->hash_num_buckets == 0 || p->num_sdf_blocks == 0)
     return sf::fail(SF_ERR_FORMAT, "%s: non-positive voxel size / hash size", path);
   return SF_OK;

@@ -716,7 +716,8 @@ def test_weights_at_the_clamp_at_full_size(oracle):
 # kernels bit for bit against the same mode of the oracle
 # ---------------------------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("switches", [dict(frustum_mode=1), dict(colour_round=1), dict(colour_first=1), dict(weight_mode=1, weight_sample=10),
-                                      dict(weight_mode=1), dict(frustum_mode=1, colour_round=1, colour_first=1, weight_mode=1, weight_sample=4)])
+                                      dict(weight_mode=1), dict(frustum_mode=1, colour_round=1, colour_first=1, weight_mode=1, weight_sample=4),
+                                      dict(weight_wrap=1, weight_max=99999999, weight_sample=40), dict(weight_wrap=1, weight_max=300, weight_sample=90, weight_mode=1)])
 def test_conformance_switches_match_the_oracle(oracle, switches):
     from scannet_amd import fusion
     W, H, N = 320, 240, 40
@@ -859,3 +860,25 @@ def test_ray_space_allocation_at_full_size_on_the_furnished_stream(oracle):
             _assert_same(ovol, f)
     finally:
         dev.close()
+
+
+def test_weight_wrap_over_a_long_stream(oracle):
+    """sf_params::weight_wrap 1 with the shipped weight limit (99999999): 300 frames of one view, the weights pass 255 and start again at 0 --
+    the kernels (32 frames per pass and one per launch) against the oracle, bit for bit."""
+    from scannet_amd import fusion
+    W, H, N = 160, 120, 300
+    depth, poses, _ = _static_view_stream(W, H, N, wobble_every=41)
+    for tune in ({}, {"batch": 1}):
+        op, gp = _mk(oracle, W, H, voxel=0.01, num_sdf_blocks=1 << 15, weight_wrap=1, weight_max=99999999)
+        ovol = oracle.Volume(op, threads=8)
+        dev = _DeviceFrames(depth)
+        try:
+            with fusion.Fuser(gp, **tune) as f:
+                for i in range(N):
+                    ovol.integrate(depth[i], poses[i].reshape(4, 4))
+                dev.fuse(f, poses, 0, N)
+                _assert_same(ovol, f)
+                _, gv = f.export_blocks()
+                assert 30 <= gv["w"].max() <= 255 and (gv["w"] == (N - 256)).mean() > 0.2   # wrapped: a voxel seen by every frame holds N - 256
+        finally:
+            dev.close()

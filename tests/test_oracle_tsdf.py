@@ -420,3 +420,31 @@ def test_switched_semantics_within_tolerance_of_the_literal_specification(oracle
                                                              weight_sample=10), sample=6000)
     assert res["max_abs_sdf_err_m"] < 2e-5
     assert vox["w"].max() > 20   # several observations of weight > 1 each
+
+
+def test_weight_wrap(oracle):
+    """weight_wrap 1 (upstream's `uchar weight` with the shipped s_SDFIntegrationWeightMax = 99999999): the 256th observation wraps the weight
+    to 0 and the mean restarts -- 256 observations of a plane at 1500 mm, then 44 of one at 1510 mm: the weight reads 44 and the sdf is the mean
+    of the last 44 observations only (the first 256 are forgotten); the saturating default keeps 255 and the long memory."""
+    I = np.eye(4, dtype=np.float32)
+    a, b = synth.plane_frame(160, 120, 1500), synth.plane_frame(160, 120, 1510)
+    vol = oracle.Volume(_small(oracle, weight_wrap=1, weight_max=99999999))
+    sat = oracle.Volume(_small(oracle, weight_max=99999999))
+    for i in range(300):
+        d = a if i < 256 else b
+        vol.integrate(d, I)
+        sat.integrate(d, I)
+    _, v = vol.export()
+    _, s = sat.export()
+    assert v["w"].max() == 44 and s["w"].max() == 255
+    # voxels observed by all 300 frames: the wrapped volume holds exactly plane b's values (as if fused 44 times from empty), the saturated one does not
+    ref = oracle.Volume(_small(oracle))
+    for i in range(44):
+        ref.integrate(b, I)
+    rc, rv = ref.export()
+    vc, _ = vol.export()
+    idx = {tuple(c): i for i, c in enumerate(vc)}
+    sel = np.array([idx[tuple(c)] for c in rc])
+    full = (rv["w"] == 44) & (v["w"][sel] == 44)
+    assert full.sum() > 10000
+    assert np.abs(v["sdf"][sel][full] - rv["sdf"][full]).max() < 1e-6
