@@ -442,6 +442,8 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
     # the timed region runs WITHOUT the HIP events around every integrate launch (they cost ~2 % of the frames/s: profiles/r03_small_experiments.txt);
     # kernel durations come from the roofline sample below, fused again with the events on.  --single-frame keeps them: its line is the roofline.
     m = run(Wm, K, args.single_frame and not args.no_profile, single_frame=args.single_frame, repeats=R)
+    # the roofline window, on EVERY rank (run() holds barriers and an all-reduce when N > 1: a pass only rank 0 entered would hang the job)
+    mr = m if (child or args.no_profile or m["batch"] == 1) else run(roof_W, roof_K, True)
     out = None
     if rank == 0:
         pmc_on = world == 1 and not args.no_pmc and not args.no_profile and not child
@@ -451,7 +453,6 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
                 roof["pattern_ceiling"] = dict(m["ceiling"], frac_of_ceiling=round(roof["achieved"] / m["ceiling"]["rmw_copy_GBs"], 4))
         else:
             same = (roof_W, roof_K) == (Wm, K)
-            mr = m if child or args.no_profile else run(roof_W, roof_K, True)
             valu = pmc_valu(args, cfg_name, roof_K, roof_W, False) if pmc_on else None
             traffic = pmc_traffic(args, cfg_name, roof_K, roof_W, False) if pmc_on else None
             roof = roofline_valu(mr, roof_K, "k_integrate<1,false,true,2>", valu, traffic,
@@ -800,6 +801,8 @@ def main():
     ap.add_argument("--exchange", choices=["neighbour", "all_gather"], default="neighbour", help="--config partition: how the boundary layers travel")
     ap.add_argument("--stripes-at-one", action="store_true", help="set the partition even at N = 1 (rank 0 of 1 owns everything)")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="sf_fuser_tune switches for every fuser of the run (A/B measurements)")
+    ap.add_argument("--share-gpu", action="store_true", help="testing aid: every rank on GPU 0 over the gloo backend (RCCL refuses two ranks on one device) -- "
+                                                             "exercises the N > 1 control flow (barriers, max over ranks) on a one-GPU box; the rates mean nothing")
     args = ap.parse_args()
     if args.pmc_steps is None:
         args.pmc_steps = 400 if args.config == "4mm" else 64
@@ -814,9 +817,14 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.share_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     if args.config in CONFIGS:
         out = run_stream(args, args.config, rank, local_rank, world, dist, torch)

@@ -509,3 +509,25 @@ def test_real_fusers_in_separate_processes_exchange_and_merge(tmp_path, world, m
     xyz, rgba, tris, keys = partition.merge_slab_meshes([(p["xyz"], p["rgba"], p["tris"], p["keys"], p["fk"]) for p in parts])
     assert np.array_equal(keys, ref[3]) and np.array_equal(xyz.view(np.uint32), ref[0].view(np.uint32))
     assert np.array_equal(rgba, ref[1]) and np.array_equal(tris, ref[2])
+
+
+def test_bench_with_two_ranks_sharing_one_gpu():
+    """bench.py's N > 1 control flow (one process per rank, barriers, max over ranks, the roofline window on every rank, the partition's ring
+    shift) on a one-GPU box: `--share-gpu` puts both ranks on GPU 0 over gloo.  A pass that only rank 0 enters hangs the job -- that regression
+    is what this guards; the rates mean nothing."""
+    import socket
+    import sys
+    common = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1"]
+    for extra in (["--steps", "20", "--warmup", "5", "--repeats", "3"], ["--config", "partition", "--scan-frames", "600"]):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        r = subprocess.run(common + ["--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu"] + extra,
+                           capture_output=True, text=True, cwd=ROOT, timeout=400)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-1500:]          # rank 0 prints ONE line
+        j = json.loads(lines[0])
+        assert j["n_gpus"] == 2 and j["value"] > 0 and j["unit"] == "frames/s"
+        if "partition" in extra:
+            assert j["exchange"]["mode"] == "neighbour" and j["exchange"]["boundary_blocks_sent_total"] == j["exchange"]["ghost_blocks_received_total"] > 0
+        else:
+            assert j["repeats"]["n"] == 3 and j["roofline"]["launches"] > 0
