@@ -27,6 +27,7 @@ extern "C" {
  *   "alloc_group" 1..16  consecutive frames one allocation workgroup walks (default 16: the whole batch)
  *   "alloc_ray"   0/1    the allocation kernel's occupancy bitmap in ray space (k_alloc_ray; default: whenever the voxel size lets the window hold a
  *                        pixel tile's rays: >= 2.5 mm voxels with the shipped camera) or as a 32^3-block cube anchored at the first ray (k_alloc)
+ *   "prepass_fuse" 0/1   one colourless frame per pass: the allocation kernel converts the depth itself (default 1), no separate pre-pass launch
  *   "ramp"        0..16  frames of the FIRST pass of a sf_fuser_integrate_batch_device call (default 8; 0 = a full pass): nothing overlaps that
  *                        pass's pre-pass / allocation, so a short one starts the pipeline sooner
  * Synchronises the fuser.  SF_ERR_INVALID_ARG for an unknown key or a value out of range. */

@@ -466,8 +466,12 @@ constexpr int RW_WORDS = RW_DEPTH * RW_LAT * RW_LAT / 32;   // 2048 words = 8 Ki
 template <bool MULTI>
 __global__ __launch_bounds__(256) void k_alloc_ray(const float* __restrict__ depthf_all, HashEntry* table, int32_t* heap,
                                                    uint64_t* block_keys, int32_t* block_entry, uint8_t* block_flags, int32_t* counters, ParamsK P,
-                                                   BatchFrames B, int group_frames, int ablate) {
+                                                   BatchFrames B, int group_frames, int ablate, const uint16_t* __restrict__ fuse_depth16,
+                                                   float* depthf_out, int compact_counter) {
   // ablate (tune "alloc_ablate", measurements only -- the volume is wrong with any bit set): 1 no LDS atomics, 2 no scan, 4 no DDA walk, 8 no barriers
+  // fuse_depth16 != nullptr (one frame per pass, no colour, no resampling: a live stream): the kernel is ALSO the depth pre-pass -- every lane
+  // converts its own pixel (k_prepass's arithmetic), stores it for the integrate kernel's gathers and walks it; one launch and one
+  // dependency hop less in a chain of four that is the whole frame time
   __shared__ uint4 s_frame4[RW_WORDS / 4];              // blocks the current frame's rays visit (slab-major)
   __shared__ uint4 s_done4[MULTI ? RW_WORDS / 4 : 1];   // blocks an earlier frame of the group has already queued
   __shared__ unsigned long long s_keys[ALLOC_SET];      // the same for blocks outside the window
@@ -560,7 +564,20 @@ __global__ __launch_bounds__(256) void k_alloc_ray(const float* __restrict__ dep
   const bool in_image = x < P.W && y < P.H;
   const float kx = ((float)x - P.mx) / P.fx, ky = ((float)y - P.my) / P.fy;  // the pixel's ray direction is the same for every frame
   const float rvoxel = 1.0f / P.voxel;                                        // RN(1 / voxel) for world_to_block
-  float d_next = in_image && j_begin < j_end ? depthf_all[(size_t)j_begin * npx + (size_t)(y * P.W + x)] : -INFINITY;
+  float d_next;
+  if (fuse_depth16 != nullptr) {   // uniform
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicExch(reinterpret_cast<unsigned long long*>(&counters[compact_counter]), 0ull);
+    d_next = -INFINITY;
+    if (in_image) {
+      const uint16_t u = fuse_depth16[(size_t)(y * P.W + x)];
+      float v = (float)u / P.depth_shift;
+      if (u == 0 || v < P.dmin || v > P.dmax) v = -INFINITY;
+      depthf_out[(size_t)(y * P.W + x)] = v;
+      d_next = v;
+    }
+  } else {
+    d_next = in_image && j_begin < j_end ? depthf_all[(size_t)j_begin * npx + (size_t)(y * P.W + x)] : -INFINITY;
+  }
   __syncthreads();   // bitmaps zeroed
   for (int j = j_begin; j < j_end; ++j) {
     const FrameK& F = B.f[j];  // uniform index: scalar loads from the kernarg segment
@@ -1697,8 +1714,11 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
     }
     (void)hipStreamWaitEvent(sa, f->ev_fused[sl], 0);
   }
-  hipLaunchKernelGGL(k_prepass, dim3((npx / 8 + 255) / 256 + 1, n), dim3(256), 0, sa, in, f->depthf2[sl], f->color2[sl], npx, f->p.depth_shift,
-                     f->p.depth_min, f->p.depth_max, f->counters, cc, f->pk, f->ray_kx, f->ray_ky);
+  // one colourless frame at the integration size through the ray-space allocation kernel: that kernel converts the depth itself
+  const bool fuse_pre = f->prepass_fuse && f->alloc_ray && n == 1 && sign > 0 && !col && f->pk.inW == 0;
+  if (!fuse_pre)
+    hipLaunchKernelGGL(k_prepass, dim3((npx / 8 + 255) / 256 + 1, n), dim3(256), 0, sa, in, f->depthf2[sl], f->color2[sl], npx, f->p.depth_shift,
+                       f->p.depth_min, f->p.depth_max, f->counters, cc, f->pk, f->ray_kx, f->ray_ky);
   if (sign > 0) {
     // WIN 64 (32 KiB bitmap) has no room for the second bitmap: one frame per workgroup there
     const int gf = (f->alloc_win64 && !f->alloc_ray) ? 1 : std::min(f->alloc_group, n);
@@ -1710,7 +1730,8 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
     // each pass -- registers the integrate kernel next to it needs for ITS waves (timeline: profiles/r03_timeline_*.txt)
     const unsigned alloc_pad = (f->alloc_wgs > 0 && n > 1) ? (unsigned)std::max(0, (160 * 1024) / (f->alloc_wgs + 1) + 1024 - 23048) : 0u;
 #define LAUNCH_ALLOC_RAY(MU) \
-  hipLaunchKernelGGL((k_alloc_ray<MU>), ag, dim3(256), alloc_pad, sa, f->depthf2[sl], f->table, f->heap, f->block_keys, f->block_entry, f->block_flags, f->counters, f->pk, bf, gf, f->alloc_ablate)
+  hipLaunchKernelGGL((k_alloc_ray<MU>), ag, dim3(256), alloc_pad, sa, f->depthf2[sl], f->table, f->heap, f->block_keys, f->block_entry, f->block_flags, f->counters, f->pk, bf, gf, f->alloc_ablate, \
+                     fuse_pre ? in.depth[0] : (const uint16_t*)nullptr, f->depthf2[sl], cc)
     if (f->alloc_ray) { if (gf == 1) LAUNCH_ALLOC_RAY(false); else LAUNCH_ALLOC_RAY(true); }
     else if (f->alloc_win64) LAUNCH_ALLOC(6, false);
     else if (gf == 1) LAUNCH_ALLOC(5, false);
@@ -2144,6 +2165,7 @@ SF_API int sf_fuser_tune(sf_fuser* f, const char* key, int value) {
   }
   else if (k == "alloc_group" && in(1, MAX_BATCH)) f->alloc_group = value;
   else if (k == "alloc_wgs" && in(0, 8)) f->alloc_wgs = value;
+  else if (k == "prepass_fuse" && in(0, 1)) f->prepass_fuse = value != 0;
   else if (k == "alloc_ablate" && in(0, 15)) f->alloc_ablate = value;
   else if (k == "front_prio" && in(0, 1)) {   // 1: the front stream at the device's highest priority (default), 0: at the default priority
     int prio_lo = 0, prio_hi = 0;

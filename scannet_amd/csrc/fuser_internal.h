@@ -222,6 +222,7 @@ struct sf_fuser {
   int32_t* host_mirror = nullptr;  // pinned, device-visible: N_blk of the most recent integrate
   int num_cus = 256;
   bool alloc_win64 = false;  // 64^3-block LDS window when a ray segment spans more than ~20 blocks
+  bool prepass_fuse = true;  // one colourless frame per pass: k_alloc_ray converts the depth itself, no k_prepass launch (tune "prepass_fuse")
   int alloc_ablate = 0;      // measurement only (tune "alloc_ablate"): parts of k_alloc_ray switched off, the volume is WRONG with any bit set
   int alloc_wgs = 0;         // > 0: allocation workgroups per CU capped (LDS padding) so that the integrate kernel beside them keeps its waves (tune "alloc_wgs")
   bool alloc_ray = false;    // k_alloc_ray (occupancy bitmap in ray space: 16 x 16 blocks across the pixel tile's pencil of rays, 256 slabs along it) instead of the cube window
