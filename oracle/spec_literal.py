@@ -47,13 +47,16 @@ def centre_in_frustum(coords, Ti, *, voxel, fx, fy, mx, my, width, height, dmin,
 
 
 def evaluate(frames, coords, birth, *, voxel, fx, fy, mx, my, width, height, trunc_base=0.06, trunc_scale=0.02, max_dist=4.0, weight_sample=1,
-             weight_max=255, depth_shift=1000.0, dmin=0.1, dmax=6.0, eps_px=None, eps_m=2e-5, frustum_mode=0, weight_mode=0, weight_wrap=0):
+             weight_max=255, depth_shift=1000.0, dmin=0.1, dmax=6.0, eps_px=None, eps_m=2e-5, frustum_mode=0, weight_mode=0, weight_wrap=0, colour_round=0, colour_first=0, return_colour=False):
     """frames: [(depth u16 [H,W], camToWorld 4x4)], in order.  coords: int [n,3] block coordinates.  birth: int [n] index of the first frame
     at which block i exists (allocation is a separate rule; the caller takes it from the implementation under test).
     frustum_mode 0: every existing block is visited (the sphere test of App. C is conservative: it never keeps a voxel that projects into the
     image from being visited, so it is not evaluated here).  frustum_mode 1: only blocks whose centre passes `centre_in_frustum` for the frame.
     weight_mode 1: an observation weighs (uchar)max(weight_sample * 1.5 * (1 - (d - dmin) / (dmax - dmin)), 1) (VoxelHashing).
     weight_wrap 1: the stored weight is min(weight_max, w + w_new) modulo 256 (upstream's uchar; no clamp at 255).
+    A frame may carry a third element, rgb uint8 [H,W,3]: the colour rule of App. C is then evaluated too (first observation copies -- by weight 0, or
+    by a black accumulated colour with colour_first 1 --, later ones average per channel, truncating or, with colour_round 1, rounding half up) and
+    `return_colour=True` appends the colours (int [n,512,3]) to the result.
     Returns (sdf float64 [n,512], weight int [n,512], tie bool [n,512])."""
     if eps_px is None:
         eps_px = 1e-6 * max(width, height)   # ~8 ulp of a pixel coordinate at the far edge of the image: what a few fp32 roundings can move it
@@ -69,11 +72,14 @@ def evaluate(frames, coords, birth, *, voxel, fx, fy, mx, my, width, height, tru
     Z = np.broadcast_to(gz, (n, 8, 8, 8)).reshape(n, 512)
     sdf_acc = np.zeros((n, 512), np.float64)
     w_acc = np.zeros((n, 512), np.int64)
+    col_acc = np.zeros((n, 512, 3), np.int64)
     tie = np.zeros((n, 512), bool)
     wmax = int(weight_max) if weight_wrap else min(int(weight_max), 255)
     wn = float(weight_sample)
     birth = np.asarray(birth, np.int64)
-    for k, (depth, pose) in enumerate(frames):
+    for k, frame in enumerate(frames):
+        depth, pose = frame[0], frame[1]
+        rgb = frame[2] if len(frame) > 2 else None
         pose = np.asarray(pose, np.float64).reshape(4, 4)
         if not np.isfinite(pose).all():
             continue   # tracking lost: the frame is skipped
@@ -120,9 +126,16 @@ def evaluate(frames, coords, birth, *, voxel, fx, fy, mx, my, width, height, tru
             t_here |= valid & (raw_w > 1.0) & (np.abs(raw_w - np.rint(raw_w)) < 1e-5)
         else:
             wk = np.full(dd.shape, wn)
+        if rgb is not None:
+            c_new = np.asarray(rgb, np.int64)[iy, ix]                  # [m, 512, 3]
+            c_old = col_acc[live]
+            first = (c_old.sum(-1) == 0) if colour_first else (wo == 0)
+            avg = (c_old + c_new + (1 if colour_round else 0)) // 2
+            c_upd = np.where(first[..., None], c_new, avg)
+            col_acc[live] = np.where(upd[..., None], c_upd, c_old)
         new_s = (so * wo + s * wk) / (wo + wk)
         sdf_acc[live] = np.where(upd, new_s, so)
         w_new = np.minimum(wmax, wo + wk.astype(np.int64))
         w_acc[live] = np.where(upd, w_new % 256 if weight_wrap else w_new, wo)
         tie[live] |= t_here
-    return sdf_acc, w_acc, tie
+    return (sdf_acc, w_acc, tie, col_acc) if return_colour else (sdf_acc, w_acc, tie)

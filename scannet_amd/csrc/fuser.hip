@@ -1978,7 +1978,8 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
 SF_API void sf_fuser_destroy(sf_fuser* f) {
   if (!f) return;
   (void)hipSetDevice(f->device);
-  if (f->stream) (void)hipStreamSynchronize(f->stream);
+  if (f->front) (void)hipStreamSynchronize(f->front);   // both streams drained before ANYTHING they read or write goes (the host-frame ring's
+  if (f->stream) (void)hipStreamSynchronize(f->stream); // page-locked slots are read by copies queued on either of them)
   for (auto& e : f->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   (void)hipFree(f->table); (void)hipFree(f->heap); (void)hipFree(f->block_keys); (void)hipFree(f->block_entry); (void)hipFree(f->block_flags); (void)hipFree(f->voxels);
   for (int q = 0; q < 2; q++) { (void)hipFree(f->depthf2[q]); (void)hipFree(f->color2[q]); (void)hipFree(f->compact2[q]); (void)hipFree(f->cmask2[q]); }

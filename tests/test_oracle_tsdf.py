@@ -448,3 +448,37 @@ def test_weight_wrap(oracle):
     full = (rv["w"] == 44) & (v["w"][sel] == 44)
     assert full.sum() > 10000
     assert np.abs(v["sdf"][sel][full] - rv["sdf"][full]).max() < 1e-6
+
+
+@pytest.mark.parametrize("colour_round,colour_first", [(0, 0), (1, 0), (0, 1), (1, 1)])
+def test_colour_rule_against_the_literal_evaluation(oracle, colour_round, colour_first):
+    """The colour half of the voxel update against the literal evaluator (integers: no tolerance), in all four switch positions, on frames with
+    random colours and a black band; voxels whose geometry sits on a decision boundary (the evaluator's `tie`) are left out."""
+    from oracle import spec_literal
+    W, H = 160, 120
+    p = oracle.default_params(W, H, voxel=0.01)
+    fx, fy, mx, my = synth.intrinsics(W, H)
+    p.fx, p.fy, p.mx, p.my = fx, fy, mx, my
+    p.colour_round, p.colour_first = colour_round, colour_first
+    vol = oracle.Volume(p, threads=8)
+    rng = np.random.default_rng(17)
+    frames, after = [], []
+    for i in (0, 1, 2, 3, 40, 41, 42, 2):
+        pose = synth.trajectory_pose(i, 400)
+        d = synth.render_room_depth(pose, W, H, noise_frame=i)
+        rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        rgb[:, : W // 3] = 0
+        vol.integrate(d, pose, rgb=rgb)
+        frames.append((d, pose, rgb))
+        after.append(vol.export()[0])
+    coords, vox = vol.export()
+    final, birth = _births(after)
+    assert np.array_equal(final, coords)
+    pick = np.sort(np.random.default_rng(1).choice(len(coords), 4000, replace=False))
+    sdf, w, tie, col = spec_literal.evaluate(frames, coords[pick], birth[pick], voxel=0.01, fx=fx, fy=fy, mx=mx, my=my, width=W, height=H,
+                                             colour_round=colour_round, colour_first=colour_first, return_colour=True)
+    ok = ~tie & (w > 0)
+    assert ok.sum() > 100000 and np.array_equal(w[ok], vox["w"][pick][ok])
+    got = np.stack([vox["r"][pick], vox["g"][pick], vox["b"][pick]], -1).astype(np.int64)
+    assert np.array_equal(got[ok], col[ok])
+    assert (w[ok] >= 3).sum() > 10000          # several blends per voxel, so the rounding direction matters
