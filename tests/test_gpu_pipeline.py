@@ -531,3 +531,42 @@ def test_bench_with_two_ranks_sharing_one_gpu():
             assert j["exchange"]["mode"] == "neighbour" and j["exchange"]["boundary_blocks_sent_total"] == j["exchange"]["ghost_blocks_received_total"] > 0
         else:
             assert j["repeats"]["n"] == 3 and j["roofline"]["launches"] > 0
+
+
+def test_match_upstream_tool_finds_the_switches_a_mesh_was_fused_with(tmp_path):
+    """tools/match_upstream.py (DESIGN 6b): a `_vh.ply` fused with a known switch combination is handed in as "the reference binary's output";
+    the tool fuses the same .sens under every combination and must rank the right one first with nothing unmatched."""
+    import sys
+    from scannet_amd import fusion, sens
+    W, H, N = 160, 120, 24
+    K = synth.intrinsic_matrix(W, H)
+    sd = sens.SensorData.create(W, H, W, H, K, K, color_compression=0, depth_compression=1, sensor_name="StructureSensor")
+    rng = np.random.default_rng(4)
+    for i in range(N):
+        pose = synth.trajectory_pose(11 * i, 1200)
+        rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        rgb[:, : W // 3] = 0
+        sd.add_frame(synth.render_room_depth(pose, W, H, noise_frame=i), pose, color=rgb, timestamp_depth=i)
+    path = str(tmp_path / "scan.sens")
+    sd.save(path)
+    params = str(tmp_path / "p.txt")
+    open(params, "w").write("s_SDFVoxelSize = 0.02f;\ns_hashNumSDFBlocks = 32768;\ns_hashNumBuckets = 16384;\ns_SDFIntegrationWeightMax = 99999999;\n")
+    truth = dict(frustum_mode=1, colour_round=1, colour_first=0, weight_mode=0, weight_wrap=0)
+    p = fusion.load_params(params)
+    fx, fy, mx, my = synth.intrinsics(W, H)
+    p.depth_width, p.depth_height, p.fx, p.fy, p.mx, p.my = W, H, fx, fy, mx, my
+    for k, v in truth.items():
+        setattr(p, k, v)
+    with fusion.Fuser(p) as f:
+        f.run(sens.SensorData(path))
+        f.extract_mesh().write_ply(str(tmp_path / "ref_vh.ply"))
+    out = str(tmp_path / "rank.json")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "match_upstream.py"), path, str(tmp_path / "ref_vh.ply"), "--params", params,
+                        "--fix", "weight_mode=0", "--fix", "weight_wrap=0", "--json", out], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    rank = json.load(open(out))
+    assert len(rank) == 8
+    assert rank[0]["switches"] == truth and rank[0]["score"]["unmatched"] == 0.0 and rank[0]["score"]["mean_m"] == 0.0 and rank[0]["score"]["colour"] == 0.0
+    # the other frustum rule and the other rounding are visibly worse
+    assert rank[-1]["score"]["unmatched"] > 0 or rank[-1]["score"]["colour"] > 0
+    assert "s_scanfuseFrustumMode = 1;" in r.stdout and "s_scanfuseColourRound = 1;" in r.stdout
