@@ -882,3 +882,35 @@ def test_weight_wrap_over_a_long_stream(oracle):
                 assert 30 <= gv["w"].max() <= 255 and (gv["w"] == (N - 256)).mean() > 0.2   # wrapped: a voxel seen by every frame holds N - 256
         finally:
             dev.close()
+
+
+def test_host_entry_point_has_read_the_buffers_when_it_returns(oracle):
+    """sf_fuser_integrate takes pageable buffers that are the caller's again the moment it returns (a live stream decodes the next frame into the
+    same memory).  One depth and one colour buffer are overwritten right after every call -- with garbage, then with the next frame --, 40 calls in
+    a row without a sync: the page-locked ring (3 slots) must have taken its copy each time, and wraps around a dozen times."""
+    from scannet_amd import fusion
+    W, H, N = 160, 120, 40
+    op, gp = _mk(oracle, W, H, voxel=0.01, num_sdf_blocks=1 << 15)
+    depth, poses, rgb = _static_view_stream(W, H, N, wobble_every=6, colour=True)
+    ovol = oracle.Volume(op, threads=8)
+    dbuf = np.zeros((H, W), np.uint16)
+    cbuf = np.zeros((H, W, 3), np.uint8)
+    with fusion.Fuser(gp) as f:
+        for i in range(N):
+            use_colour = i % 3 != 0        # the ring serves colour and geometry-only frames alike
+            dbuf[:] = depth[i]
+            cbuf[:] = rgb[i]
+            ovol.integrate(depth[i], poses[i].reshape(4, 4), rgb=rgb[i] if use_colour else None)
+            assert f.integrate(dbuf, poses[i].reshape(4, 4), rgb=cbuf if use_colour else None)
+            dbuf[:] = 0xFFFF               # the caller scribbles over its buffers at once
+            cbuf[:] = 0x55
+        _assert_same(ovol, f)
+        # deintegrate through the same entry point
+        for i in (N - 1, N - 2):
+            dbuf[:] = depth[i]
+            cbuf[:] = rgb[i]
+            c = i % 3 != 0
+            ovol.deintegrate(depth[i], poses[i].reshape(4, 4), rgb=rgb[i] if c else None)
+            assert f.deintegrate(dbuf, poses[i].reshape(4, 4), rgb=cbuf if c else None)
+            dbuf[:] = 1
+        _assert_same(ovol, f)
