@@ -126,8 +126,36 @@ const uint8_t LEN_EXTRA[31] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3
 const uint16_t DIST_BASE[32] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577, 0, 0};
 const uint8_t DIST_EXTRA[32] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13, 0, 0};
 
+// Packed first-level tables: everything the inner loop needs about a symbol in ONE load (the generic tables above give a symbol number that
+// has to be looked up again for its base value and extra-bit count -- two more dependent loads per match, and a deflated depth frame is ~100 k
+// short matches).  Entry for the next FAST_BITS bits of the stream:
+//   literal / length table   bits 0..3 code length | 4..6 extra bits of a length | 8..16 literal byte or base length | 29 end of block, 30 length, 31 literal
+//   distance table           bits 0..3 code length | 4..7 extra bits | 8..23 base distance
+// 0 = the code is longer than FAST_BITS (or not a valid symbol): the generic path decodes it.
+constexpr uint32_t PK_LIT = 1u << 31, PK_LEN = 1u << 30, PK_EOB = 1u << 29;
+struct PackedTables { uint32_t lit[1 << FAST_BITS], dist[1 << FAST_BITS]; };
+
+void build_packed(PackedTables& pk, const Huffman& lit, const Huffman& dist) {
+  for (uint32_t i = 0; i < (1u << FAST_BITS); i++) {
+    const uint32_t e = lit.fast[i];
+    uint32_t v = 0;
+    if (e) {
+      const uint32_t sym = e >> 4, len = e & 15;
+      if (sym < 256) v = PK_LIT | (sym << 8) | len;
+      else if (sym == 256) v = PK_EOB | len;
+      else if (sym - 257 < 29) v = PK_LEN | ((uint32_t)LEN_BASE[sym - 257] << 8) | ((uint32_t)LEN_EXTRA[sym - 257] << 4) | len;
+    }
+    pk.lit[i] = v;
+    const uint32_t d = dist.fast[i];
+    uint32_t w = 0;
+    if (d && (d >> 4) < 30) w = ((uint32_t)DIST_BASE[d >> 4] << 8) | ((uint32_t)DIST_EXTRA[d >> 4] << 4) | (d & 15);
+    pk.dist[i] = w;
+  }
+}
+
 struct FixedTables {
   Huffman lit, dist;
+  PackedTables pk;
   FixedTables() {
     uint8_t l[288];
     for (int i = 0; i < 144; i++) l[i] = 8;
@@ -138,6 +166,7 @@ struct FixedTables {
     uint8_t d[32];
     for (int i = 0; i < 32; i++) d[i] = 5;
     build_huffman(dist, d, 32);
+    build_packed(pk, lit, dist);
   }
 };
 
@@ -146,27 +175,66 @@ const FixedTables& fixed_tables() {
   return t;
 }
 
-int inflate_block(BitReader& br, const Huffman& lit, const Huffman& dist, uint8_t* out, uint64_t cap, uint64_t& pos) {
+// the copy of a match (shared by the packed and the generic path); pos + len <= cap has been checked
+static inline void copy_match(uint8_t* out, uint64_t cap, uint64_t& pos, uint32_t len, uint32_t d) {
+  uint8_t* dst = out + pos;
+  const uint8_t* src = dst - d;
+  pos += len;
+  if (d >= 8 && pos + 8 <= cap) {
+    // 8-byte chunks; may write up to 7 bytes past `len`, which the cap check allows for
+    for (uint32_t i = 0; i < len; i += 8) std::memcpy(dst + i, src + i, 8);
+  } else if (d == 1) {
+    std::memset(dst, src[0], len);
+  } else if ((d == 2 || d == 4) && pos + 8 <= cap) {
+    // the pixel to the left / two to the left (u16 data): the period divides 8, so one 8-byte pattern serves every chunk
+    uint64_t pat;
+    if (d == 2) { uint16_t h; std::memcpy(&h, src, 2); pat = 0x0001000100010001ull * h; }
+    else { uint32_t w; std::memcpy(&w, src, 4); pat = 0x0000000100000001ull * w; }
+    for (uint32_t i = 0; i < len; i += 8) std::memcpy(dst + i, &pat, 8);
+  } else {
+    for (uint32_t i = 0; i < len; i++) dst[i] = src[i];
+  }
+}
+
+int inflate_block(BitReader& br, const Huffman& lit, const Huffman& dist, const PackedTables& pk, uint8_t* out, uint64_t cap, uint64_t& pos) {
+  constexpr uint32_t FMASK = (1u << FAST_BITS) - 1;
   for (;;) {
     br.refill();
-    // Runs of literals (noisy depth is mostly literals: ~450 k symbols per 640x480 frame): a first-level entry is a literal iff
-    // 1 <= entry < 256 << 4, it takes at most FAST_BITS = 11 of the >= 56 bits just loaded, so five of them need no refill and -- with 8 bytes
-    // of room left -- no bounds check each.  The first entry that is not a short literal falls through to the general path below.
+    // ---- the packed path: with 8 bytes of room left, literals run without bounds checks (five codes of <= FAST_BITS = 11 bits fit the >= 56 bits
+    // just loaded), and a length / distance pair whose two codes are short is decoded from two table loads: 11 + 5 + 11 + 13 = 40 bits
     if (pos + 8 <= cap) {
-      uint32_t e = lit.fast[br.buf & ((1u << FAST_BITS) - 1)];
+      uint32_t e = pk.lit[br.buf & FMASK];
       int run = 0;
-      while ((uint16_t)(e - 1u) < 0x0FFFu && run < 5) {
-        out[pos++] = (uint8_t)(e >> 4);
+      while ((e & PK_LIT) && run < 5) {
+        out[pos++] = (uint8_t)(e >> 8);
         br.buf >>= (e & 15);
         br.cnt -= (int)(e & 15);
         run++;
-        e = lit.fast[br.buf & ((1u << FAST_BITS) - 1)];
+        e = pk.lit[br.buf & FMASK];
       }
       if (run == 5) {                          // the reservoir may be down to one bit: top up first
         if (br.overrun > 8) return sf::fail(SF_ERR_FORMAT, "inflate: truncated stream");
         continue;
       }
-      if (run && br.cnt < 48) br.refill();     // a length / distance pair needs up to 15 + 5 + 15 + 13 bits
+      if (run && br.cnt < 48) br.refill();     // the low bits of the reservoir, hence `e`, stay what they were
+      if (e & PK_LEN) {
+        const uint32_t dd = pk.dist[(br.buf >> ((e & 15) + ((e >> 4) & 7))) & FMASK];
+        if (dd) {
+          const uint32_t lb = e & 15, lx = (e >> 4) & 7;
+          br.buf >>= lb;
+          const uint32_t len = ((e >> 8) & 0x1FF) + (uint32_t)(br.buf & ((1u << lx) - 1));
+          const uint32_t db = dd & 15, dx = (dd >> 4) & 15;
+          br.buf >>= lx + db;
+          const uint32_t d = (dd >> 8) + (uint32_t)(br.buf & ((1u << dx) - 1));
+          br.buf >>= dx;
+          br.cnt -= (int)(lb + lx + db + dx);
+          if (d > pos) return sf::fail(SF_ERR_FORMAT, "inflate: distance %u before start of output", d);
+          if (pos + len > cap) return sf::fail(SF_ERR_BOUNDS, "inflate: output exceeds %llu bytes", (unsigned long long)cap);
+          copy_match(out, cap, pos, len, d);
+          if (br.overrun > 8) return sf::fail(SF_ERR_FORMAT, "inflate: truncated stream");
+          continue;
+        }
+      }
     }
     int sym = decode_sym(br, lit);
     if (sym < 0) return sf::fail(SF_ERR_FORMAT, "inflate: bad literal/length code");
@@ -196,23 +264,7 @@ int inflate_block(BitReader& br, const Huffman& lit, const Huffman& dist, uint8_
     const uint32_t d = DIST_BASE[ds] + br.take(DIST_EXTRA[ds]);
     if (d > pos) return sf::fail(SF_ERR_FORMAT, "inflate: distance %u before start of output", d);
     if (pos + len > cap) return sf::fail(SF_ERR_BOUNDS, "inflate: output exceeds %llu bytes", (unsigned long long)cap);
-    uint8_t* dst = out + pos;
-    const uint8_t* src = dst - d;
-    pos += len;
-    if (d >= 8 && pos + 8 <= cap) {
-      // 8-byte chunks; may write up to 7 bytes past `len`, which the cap check above allows for
-      for (uint32_t i = 0; i < len; i += 8) std::memcpy(dst + i, src + i, 8);
-    } else if (d == 1) {
-      std::memset(dst, src[0], len);
-    } else if ((d == 2 || d == 4) && pos + 8 <= cap) {
-      // the pixel to the left / two to the left (u16 data): the period divides 8, so one 8-byte pattern serves every chunk
-      uint64_t pat;
-      if (d == 2) { uint16_t h; std::memcpy(&h, src, 2); pat = 0x0001000100010001ull * h; }
-      else { uint32_t w; std::memcpy(&w, src, 4); pat = 0x0000000100000001ull * w; }
-      for (uint32_t i = 0; i < len; i += 8) std::memcpy(dst + i, &pat, 8);
-    } else {
-      for (uint32_t i = 0; i < len; i++) dst[i] = src[i];
-    }
+    copy_match(out, cap, pos, len, d);
     if (br.overrun > 8) return sf::fail(SF_ERR_FORMAT, "inflate: truncated stream");
   }
 }
@@ -241,7 +293,7 @@ int inflate_raw(const uint8_t* src, uint64_t n, uint8_t* out, uint64_t cap, uint
       br.cnt = 0;
     } else if (type == 1) {
       const FixedTables& ft = fixed_tables();
-      const int rc = inflate_block(br, ft.lit, ft.dist, out, cap, pos);
+      const int rc = inflate_block(br, ft.lit, ft.dist, ft.pk, out, cap, pos);
       if (rc != SF_OK) return rc;
     } else if (type == 2) {
       br.refill();
@@ -275,8 +327,10 @@ int inflate_raw(const uint8_t* src, uint64_t n, uint8_t* out, uint64_t cap, uint
         }
       }
       static thread_local Huffman lit, dist;
+      static thread_local PackedTables pk;
       if (!build_huffman(lit, lens, hlit) || !build_huffman(dist, lens + hlit, hdist)) return sf::fail(SF_ERR_FORMAT, "inflate: over-subscribed Huffman code");
-      const int rc = inflate_block(br, lit, dist, out, cap, pos);
+      build_packed(pk, lit, dist);
+      const int rc = inflate_block(br, lit, dist, pk, out, cap, pos);
       if (rc != SF_OK) return rc;
     } else {
       return sf::fail(SF_ERR_FORMAT, "inflate: reserved block type");
