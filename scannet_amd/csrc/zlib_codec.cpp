@@ -199,6 +199,60 @@ static inline void copy_match(uint8_t* out, uint64_t cap, uint64_t& pos, uint32_
 int inflate_block(BitReader& br, const Huffman& lit, const Huffman& dist, const PackedTables& pk, uint8_t* out, uint64_t cap, uint64_t& pos) {
   constexpr uint32_t FMASK = (1u << FAST_BITS) - 1;
   for (;;) {
+    // ---- the tight loop: a deflated depth frame is ~110 k matches of ~5 bytes and ~30 k literals.  While the output has room for the longest
+    // match plus the chunked copy's overshoot and the input has 8 bytes left (the refill is then one unaligned load), a symbol costs two table
+    // loads and a copy -- no per-symbol bounds checks, no tail handling.  Anything else (end of block, a code longer than FAST_BITS, the last
+    // bytes of either buffer) leaves the loop for the careful body below, which handles one symbol and comes back.
+    while (pos + 274 <= cap && br.end - br.p >= 8) {
+      {
+        uint64_t w;
+        std::memcpy(&w, br.p, 8);
+        br.buf |= w << br.cnt;
+        br.p += (63 - br.cnt) >> 3;
+        br.cnt |= 56;
+      }
+      uint32_t e = pk.lit[br.buf & FMASK];
+      if (e & PK_LIT) {                       // one or two literals (<= 22 bits), then round again -- or a match right behind ONE literal (11 + 40 bits)
+        out[pos++] = (uint8_t)(e >> 8);
+        br.buf >>= (e & 15);
+        br.cnt -= (int)(e & 15);
+        e = pk.lit[br.buf & FMASK];
+        if (e & PK_LIT) {
+          out[pos++] = (uint8_t)(e >> 8);
+          br.buf >>= (e & 15);
+          br.cnt -= (int)(e & 15);
+          continue;
+        }
+      }
+      if (!(e & PK_LEN)) break;
+      const uint32_t lb = e & 15, lx = (e >> 4) & 7;
+      const uint32_t dd = pk.dist[(br.buf >> (lb + lx)) & FMASK];
+      if (!dd) break;
+      br.buf >>= lb;
+      const uint32_t len = ((e >> 8) & 0x1FF) + (uint32_t)(br.buf & ((1u << lx) - 1));
+      const uint32_t db = dd & 15, dx = (dd >> 4) & 15;
+      br.buf >>= lx + db;
+      const uint32_t d = (dd >> 8) + (uint32_t)(br.buf & ((1u << dx) - 1));
+      br.buf >>= dx;
+      br.cnt -= (int)(lb + lx + db + dx);
+      if (d > pos) return sf::fail(SF_ERR_FORMAT, "inflate: distance %u before start of output", d);
+      uint8_t* dst = out + pos;
+      const uint8_t* src = dst - d;
+      pos += len;
+      if (d >= 8) {
+        std::memcpy(dst, src, 8);
+        for (uint32_t i = 8; i < len; i += 8) std::memcpy(dst + i, src + i, 8);
+      } else if (d == 1) {
+        std::memset(dst, src[0], len);
+      } else if (d == 2 || d == 4) {
+        uint64_t pat;
+        if (d == 2) { uint16_t h; std::memcpy(&h, src, 2); pat = 0x0001000100010001ull * h; }
+        else { uint32_t w; std::memcpy(&w, src, 4); pat = 0x0000000100000001ull * w; }
+        for (uint32_t i = 0; i < len; i += 8) std::memcpy(dst + i, &pat, 8);
+      } else {
+        for (uint32_t i = 0; i < len; i++) dst[i] = src[i];
+      }
+    }
     br.refill();
     // ---- the packed path: with 8 bytes of room left, literals run without bounds checks (five codes of <= FAST_BITS = 11 bits fit the >= 56 bits
     // just loaded), and a length / distance pair whose two codes are short is decoded from two table loads: 11 + 5 + 11 + 13 = 40 bits
