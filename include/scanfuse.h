@@ -139,7 +139,7 @@ int sf_fuser_integrate_batch_device(sf_fuser* f, const void* d_depth, uint64_t f
  * gives a colour resolution), `rgb_stride_bytes` apart. */
 int sf_fuser_integrate_batch_device_rgb(sf_fuser* f, const void* d_depth, uint64_t frame_stride_bytes, const void* d_rgb, uint64_t rgb_stride_bytes,
                                         const float* poses, uint64_t n);
-int sf_fuser_batch_frames(const sf_fuser* f);   /* 16 */
+int sf_fuser_batch_frames(const sf_fuser* f);   /* 32 */
 
 /* Empty volume again (table, heap, tiles, counters, frame numbering); parameters, streams and tuning stay.  The reference's tools are
  * one process per scan (Server/scan_processor.py:137-141); a caller that fuses scan after scan keeps its allocation this way. */

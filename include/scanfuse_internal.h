@@ -15,7 +15,7 @@ extern "C" {
 #endif
 
 /* Scheduling switches of a fuser (results are bit-identical under all of them; tests/test_gpu_tsdf.py runs the matrix):
- *   "batch"       1..16  frames fused per pass over the voxel tiles (default 16; 1 = what sf_fuser_integrate gives a live stream)
+ *   "batch"       1..32  frames fused per pass over the voxel tiles (default 32: the frame mask of a block is one word; 1 = what sf_fuser_integrate gives a live stream)
  *   "overlap"     0/1    pre-pass / allocation / compaction of the next batch on a second stream (default 1)
  *   "xcd_walk"    0/1    each XCD walks one contiguous eighth of the block list (default 1)
  *   "pipe"        0/1    colourless one-frame passes run the software-pipelined persistent kernel (default 1)
@@ -24,11 +24,11 @@ extern "C" {
  *                        pass touched more than 512 MiB of tiles (default), 0 never, 1 always
  *   "nt"          -1/0/1 that kernel's tile loads and stores non-temporal: -1 = when the previous pass touched more than 512 MiB of tiles (default)
  *   "front_cus"   0..128 the second stream owns that many CUs (spread over the chip), the main stream the rest (hipExtStreamCreateWithCUMask); 0 = shared
- *   "alloc_group" 1..16  consecutive frames one allocation workgroup walks (default 16: the whole batch)
+ *   "alloc_group" 1..32  consecutive frames one allocation workgroup walks (default 16: half of a 32-frame pass)
  *   "alloc_ray"   0/1    the allocation kernel's occupancy bitmap in ray space (k_alloc_ray; default: whenever the voxel size lets the window hold a
  *                        pixel tile's rays: >= 2.5 mm voxels with the shipped camera) or as a 32^3-block cube anchored at the first ray (k_alloc)
  *   "prepass_fuse" 0/1   one colourless frame per pass: the allocation kernel converts the depth itself (default 1), no separate pre-pass launch
- *   "ramp"        0..16  frames of the FIRST pass of a sf_fuser_integrate_batch_device call (default 8; 0 = a full pass): nothing overlaps that
+ *   "ramp"        0..32  frames of the FIRST pass of a sf_fuser_integrate_batch_device call (default 8; 0 = a full pass): nothing overlaps that
  *                        pass's pre-pass / allocation, so a short one starts the pipeline sooner
  * Synchronises the fuser.  SF_ERR_INVALID_ARG for an unknown key or a value out of range. */
 int sf_fuser_tune(sf_fuser* f, const char* key, int value);
