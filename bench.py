@@ -585,6 +585,7 @@ def run_scans(args, rank, local_rank, world, dist, torch):
     buf = torch.empty((chunk, H, W), dtype=torch.int16, device="cuda")
     params = fusion.default_params()
     gpu_busy = [0.0]
+    render_busy = [0.0]   # of which: rendering the synthetic input (sf_synth_scene_device synchronises) -- benchmark scaffolding, not the path
     frames_done = [0]
     outdir = tempfile.mkdtemp(prefix="sf_scans_r%d_" % rank, dir="/tmp")
 
@@ -594,7 +595,9 @@ def run_scans(args, rank, local_rank, world, dist, torch):
         with fusion.Fuser(params, device=local_rank, **TUNE) as f:
             for a in range(0, n, chunk):
                 m = min(chunk, n - a)
+                tr = time.perf_counter()
                 poses = synth.render_scan_device(buf.data_ptr(), stride, a, m, n, W, H, room=room, noise=args.noise, scene=args.scene, seed=args.first_scan + i)
+                render_busy[0] += time.perf_counter() - tr
                 f.integrate_batch_device(buf.data_ptr(), stride, poses)
                 f.sync()
             mesh = f.extract_mesh()
@@ -634,7 +637,7 @@ def run_scans(args, rank, local_rank, world, dist, torch):
     workers = max(1, _abi.usable_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))))
     for w in range(Wm):   # untimed: pages in the library, the kernels and the host stage
         host_stage(0, gpu_stage(0)) if args.host_stage != "none" else gpu_stage(0)
-    gpu_busy[0], frames_done[0] = 0.0, 0
+    gpu_busy[0], frames_done[0], render_busy[0] = 0.0, 0, 0.0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -674,6 +677,9 @@ def run_scans(args, rank, local_rank, world, dist, torch):
                                   "clean": "clean.mlx + Segmentator per scan on a pool of %d host threads per rank" % workers, "none": "none (fusion + marching cubes only)"}[args.host_stage],
                    "frames_total": int(frames_sum)},
         "gpu_busy_s_sum": round(busy_sum, 3), "gpu_idle_pct": round(100.0 * (1.0 - busy_sum / (elapsed * world)), 1),
+        "input_render_s_rank0": round(render_busy[0], 3),
+        "input_render_note": "seconds of rank 0's GPU-busy time spent RENDERING the synthetic scans (csrc/synth.hip: benchmark input, counted in the rate because it "
+                             "occupies the same GPU; a real rebuild reads .sens files instead)",
         "host_stage_s_mean_rank0": round(float(np.mean(host_s)), 3) if host_s else None,
         "host_stage_parts_s_mean_rank0": {k: round(float(np.mean([r.get(k, 0.0) for _, r in done])), 3)
                                           for k in ("clean_s", "decimate_s", "clean_lores_s", "segment_s", "decimate_rounds", "faces")} if host_s else None,
