@@ -417,19 +417,19 @@ def test_hand_expanded_divisions_on_device():
     assert (a.value, b.value, c.value) == (0, 0, 0)
 
 
-@pytest.mark.parametrize("case", [0, 1, 2])
+@pytest.mark.parametrize("case", [0, 1, 2, 3, 4, 5])
 def test_gpu_matches_committed_digests(case):
     """The HIP path against tests/golden/tsdf_golden.json (digests of the oracle's voxels and canonical mesh, generated by
     tests/golden/make_tsdf_golden.py) -- no oracle call on the GPU box for this one."""
     from scannet_amd import fusion
     from tests.test_oracle_tsdf import _golden
     mod, gold = _golden()
-    name, size, voxel, idx, colour, deint = mod.SCENARIOS[case]
+    name, size, voxel, idx, colour, deint, opts = mod.SCENARIOS[case]
 
     class Adapter:
-        def __init__(self, W, H, vx):
+        def __init__(self, W, H, vx, **switches):
             fx, fy, mx, my = synth.intrinsics(W, H)
-            self.f = fusion.Fuser(fusion.default_params(depth_width=W, depth_height=H, voxel_size=vx, fx=fx, fy=fy, mx=mx, my=my, num_sdf_blocks=1 << 16))
+            self.f = fusion.Fuser(fusion.default_params(depth_width=W, depth_height=H, voxel_size=vx, fx=fx, fy=fy, mx=mx, my=my, num_sdf_blocks=1 << 16, **switches))
 
         def integrate(self, d, pose, rgb=None):
             self.f.integrate(d, pose, rgb=rgb)
@@ -444,7 +444,7 @@ def test_gpu_matches_committed_digests(case):
             xyz, rgba, tris, keys = self.f.extract_mesh().arrays(keys=True)
             return xyz, np.ascontiguousarray(rgba[:, :3]), tris.astype(np.int32), keys
 
-    got = mod.run(Adapter, name, size, voxel, idx, colour, deint)
+    got = mod.run(Adapter, name, size, voxel, idx, colour, deint, opts)
     assert got == gold[name]
 
 

@@ -184,15 +184,17 @@ def _golden():
     return mod, json.load(open(os.path.join(here, "tsdf_golden.json")))
 
 
-@pytest.mark.parametrize("case", [0, 1, 2])
+@pytest.mark.parametrize("case", [0, 1, 2, 3, 4, 5])
 def test_oracle_matches_committed_digests(oracle, case):
     """tests/golden/tsdf_golden.json freezes the oracle's output (voxels + canonical mesh) on small seeded scenarios."""
     mod, gold = _golden()
-    name, size, voxel, idx, colour, deint = mod.SCENARIOS[case]
+    name, size, voxel, idx, colour, deint, opts = mod.SCENARIOS[case]
 
-    def factory(W, H, vx):
+    def factory(W, H, vx, **switches):
         p = oracle.default_params(W, H, vx)
         p.fx, p.fy, p.mx, p.my = synth.intrinsics(W, H)
+        for k, v in switches.items():
+            setattr(p, k, v)
         vol = oracle.Volume(p, threads=4)
         raw = vol.extract_mesh
 
@@ -202,7 +204,7 @@ def test_oracle_matches_committed_digests(oracle, case):
         vol.extract_mesh = extract
         return vol
 
-    assert mod.run(factory, name, size, voxel, idx, colour, deint) == gold[name]
+    assert mod.run(factory, name, size, voxel, idx, colour, deint, opts) == gold[name]
 
 
 def _births(volume_after_each_frame_coords):
