@@ -33,6 +33,10 @@ extern "C" {
  * Synchronises the fuser.  SF_ERR_INVALID_ARG for an unknown key or a value out of range. */
 int sf_fuser_tune(sf_fuser* f, const char* key, int value);
 
+/* How many blocks the allocation kernels took to the global hash table one by one because a workgroup's LDS queue / hash set was full (the slow
+ * path k_alloc_ray exists to avoid; the volume is the same either way).  tests/test_gpu_tsdf.py asserts 0 on the bench walk's corners. */
+int sf_fuser_alloc_direct_count(sf_fuser* f, uint64_t* out);
+
 /* Kernel timing with HIP events on the fuser's stream: when enabled, every integrate launch is bracketed
  * by an event pair; sf_fuser_profile_read sums and clears them (synchronises). */
 int sf_fuser_profile_enable(sf_fuser* f, int on);

@@ -12,7 +12,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the TSDF / Segmentator arithmetic is specified operation by operation;
 # only explicit fmaf() may fuse.  HIP's default correctly-rounded fp32 divide / sqrt is relied upon.
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden", "-Wall", "-Wno-unused-result",
-          "-I" + os.path.join(ROOT, "include")]
+          "-I" + os.path.join(ROOT, "include")] + os.environ.get("SCANFUSE_BUILD_FLAGS", "").split()   # e.g. -DSF_MEASURE_ABLATE for tools/gpu/r03_ablate.sh
 
 
 def sources():

@@ -269,6 +269,7 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_
 
   // a block the workgroup cannot queue (queue full: pathological tile) goes straight to the global table
   auto direct = [&](uint64_t key, int bx, int by, int bz, uint32_t seq) {
+    atomicAdd(&counters[C_ALLOC_DIRECT], 1);   // sf_fuser_alloc_direct_count: the tests assert that the bench walk never comes here
     HashEntry* e = hash_find_or_claim(h, P, key, bx, by, bz, seq);
     if (e) {
       atomicAdd(&counters[C_SLOTS_USED], 1);
@@ -494,6 +495,7 @@ __global__ __launch_bounds__(256) void k_alloc_ray(const float* __restrict__ dep
   const int j_end = min(B.n, j_begin + group_frames);
 
   auto direct = [&](uint64_t key, int bx, int by, int bz, uint32_t seq) {
+    atomicAdd(&counters[C_ALLOC_DIRECT], 1);   // sf_fuser_alloc_direct_count: the tests assert that the bench walk never comes here
     HashEntry* e = hash_find_or_claim(h, P, key, bx, by, bz, seq);
     if (e) {
       atomicAdd(&counters[C_SLOTS_USED], 1);
@@ -923,6 +925,13 @@ __device__ inline int cvt_i32(float x) {  // v_cvt_i32_f32: truncates, saturates
   return r;
 }
 
+// a + b saturating at 2^32 - 1: v_add_u32 with the VOP3 clamp bit (b in a scalar register: VOP3 takes no literal on gfx9)
+__device__ inline uint32_t add_sat_u32(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_add_u32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "s"(b));
+  return r;
+}
+
 // weight_mode 1 (VoxelHashing): the weight of an observation falls with its depth; (uchar) of the float, at most 255
 __device__ inline int depth_weight(const ParamsK& P, float d) {
   const float z01 = (d - P.dmin) / (P.dmax - P.dmin);
@@ -977,7 +986,11 @@ __device__ inline void fuse_project(const ParamsK& P, const float* __restrict__ 
 // parameters after the uchar clamp): the weight byte then increments with saturation as ONE add-with-carry on the {rgb, weight} word;
 // 3 = the observation's weight depends on its depth (sf_params::weight_mode 1), otherwise as 0.
 // dirty[j]: lane mask (a scalar register pair) of the lanes whose row j changed -- kept on the scalar unit across the frames of a batch.
-template <int SIGN, bool COLOR, bool TAB, int WM, int J0, int NJ>
+// ROWS: dirty[] holds one lane mask per row (one frame per launch: the HBM-bound schedule writes back only the rows some lane changed); without
+// it dirty[0] is a wave-uniform "some frame touched this tile" flag and the caller writes the whole tile back -- a ballot of an i1 that is not
+// itself a compare costs a v_cndmask + v_cmp per row (8 of the 241 VALU instructions of a lane's frame), and a pass of 32 frames is VALU-bound
+// with HBM at 8 % of its peak.
+template <int SIGN, bool COLOR, bool TAB, int WM, int J0, int NJ, bool ROWS = true>
 __device__ inline void fuse_update(const ParamsK& P, const v2f (&rcp_m)[NJ], const float (&d)[2 * NJ], const uint32_t (&c)[2 * NJ], const v2f (&pz)[NJ],
                                    const bool (&ok)[2 * NJ], uint4 (&v)[4], uint64_t (&dirty)[4]) {
   constexpr bool WS1 = WM == 1 || WM == 2;
@@ -1036,30 +1049,33 @@ __device__ inline void fuse_update(const ParamsK& P, const v2f (&rcp_m)[NJ], con
       for (int hx = 0; hx < 2; hx++) {
         const uint32_t cw = cwj[hx];
         const uint32_t w = cw >> 24;
-        uint32_t rgb = cw & 0xFFFFFFu;
+        uint32_t rgb = cw;   // bytes 0..2 = the accumulated colour (byte 3, the weight, is masked out where the word is assembled)
         if (COLOR) {
-          // (a + b) / 2 per channel (integer division), the three channels at once: (a & b) + ((a ^ b) >> 1) on each byte
-          // (no carry crosses a byte: the sum is at most 255; the mask keeps a byte's low bit out of its neighbour's top bit)
-          // colour_round 1 (combineVoxel upstream): (uchar)(0.5f a + 0.5f b + 0.5f) = (a + b + 1) >> 1 = (a | b) - ((a ^ b) >> 1);
-          // colour_first 1: "first observation" is a black accumulated colour instead of a zero weight
-          // Both switches as wave-uniform MASKS, not branches (a branch doubled the scalar code of the colour kernels): the round-half-up average
-          // is the truncated one plus the low bit of a ^ b per channel, and "first" tests the weight byte or the colour bytes of the word.
+          // (a + b) / 2 per channel (integer division) is ONE instruction on this ISA: v_lerp_u8 D = per byte (S0 + S1 + S2[bit 0 of the
+          // byte]) >> 1 -- the sum is formed in 9 bits, nothing crosses a byte.  colour_round 1 (combineVoxel upstream, DESIGN 6b:
+          // (uchar)(0.5f a + 0.5f b + 0.5f) = (a + b + 1) >> 1) is the same instruction with bit 0 of every colour byte of S2 set.  The weight byte
+          // of the result is garbage and never used.  colour_first 1: "first observation" is a black accumulated colour instead of a zero weight --
+          // a wave-uniform mask on the word, not a branch.  (Round 3 spent 12 VALU instructions per voxel on this blend: xor / and / shift / add3.)
           const uint32_t ck = c[2 * j + hx];
-          const uint32_t x = rgb ^ ck;
-          const uint32_t avg = (rgb & ck) + ((x & 0xFEFEFEu) >> 1) + (x & round_mask);
+          const uint32_t avg = __builtin_amdgcn_lerp(cw, ck, round_mask);
           rgb = (cw & first_mask) == 0u ? ck : avg;
         }
         if (WM == 2) {
-          // weight byte + 1, saturating at 255: the add carries out of the word exactly when the weight was 255 -- then keep it
-          const uint32_t base = COLOR ? (rgb | (cw & 0xFF000000u)) : cw;
-          uint32_t inc;
-          const bool full = __builtin_add_overflow(base, 0x01000000u, &inc);
-          if (COLOR) ncw[2 * j + hx] = full ? base : inc;
-          else { ncw[2 * j + hx] = inc; sat[2 * j + hx] = full; }   // without colour "keep it" is "do not touch the word": folded into the final select
+          if (COLOR) {
+            // weight byte + 1 saturating at 255: an unsigned add with the clamp bit on the whole word saturates to 0xFFFFFFFF exactly when the
+            // weight was 255; only byte 3 of the sum is kept
+            ncw[2 * j + hx] = (rgb & 0x00FFFFFFu) | (add_sat_u32(cw, 0x01000000u) & 0xFF000000u);
+          } else {
+            // without colour "keep the word at 255" is "do not touch the word": the carry of the add folds into the final select
+            uint32_t inc;
+            const bool full = __builtin_add_overflow(cw, 0x01000000u, &inc);
+            ncw[2 * j + hx] = inc;
+            sat[2 * j + hx] = full;
+          }
         } else {
           uint32_t nw = w + (uint32_t)wni[2 * j + hx];
           if (nw > (uint32_t)P.wmax) nw = (uint32_t)P.wmax;
-          ncw[2 * j + hx] = rgb | (nw << 24);
+          ncw[2 * j + hx] = (rgb & 0x00FFFFFFu) | (nw << 24);
         }
       }
     } else {
@@ -1091,8 +1107,9 @@ __device__ inline void fuse_update(const ParamsK& P, const v2f (&rcp_m)[NJ], con
     v[J0 + j].y = (upd[2 * j] && !sat[2 * j]) ? ncw[2 * j] : v[J0 + j].y;
     v[J0 + j].z = upd[2 * j + 1] ? __float_as_uint(q[j].y) : v[J0 + j].z;
     v[J0 + j].w = (upd[2 * j + 1] && !sat[2 * j + 1]) ? ncw[2 * j + 1] : v[J0 + j].w;
-    dirty[J0 + j] |= __ballot(upd[2 * j] || upd[2 * j + 1]);
+    if (ROWS) dirty[J0 + j] |= __ballot(upd[2 * j] || upd[2 * j + 1]);
   }
+  if (!ROWS) dirty[0] = ~0ull;   // reached only when some lane of the wave updates a voxel (the early-out above)
 }
 
 
@@ -1103,7 +1120,7 @@ __device__ inline __amdgpu_buffer_rsrc_t image_rsrc(const void* base, uint32_t b
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);   // raw buffer, dword data format (gfx9)
 }
 
-template <int SIGN, bool COLOR, bool TAB, int WM, int J0, int NJ>
+template <int SIGN, bool COLOR, bool TAB, int WM, int J0, int NJ, bool ROWS>
 __device__ inline void fuse_rows(const ParamsK& P, const float* __restrict__ Ti, const float* __restrict__ depthf,
                                  const uint32_t* __restrict__ color, const float* rtab, v2f wx, float wy, const float (&wz)[4],
                                  uint4 (&v)[4], uint64_t (&dirty)[4]) {
@@ -1132,12 +1149,12 @@ __device__ inline void fuse_rows(const ParamsK& P, const float* __restrict__ Ti,
 #pragma unroll
     for (int k = 0; k < 2 * NJ; k++) c[k] = __builtin_amdgcn_raw_buffer_load_b32(rc, pix[k] << 2, 0, 0);
   }
-  fuse_update<SIGN, COLOR, TAB, WM, J0, NJ>(P, rcp_m, d, c, pz, ok, v, dirty);
+  fuse_update<SIGN, COLOR, TAB, WM, J0, NJ, ROWS>(P, rcp_m, d, c, pz, ok, v, dirty);
 }
 
 // 4 waves per SIMD (<= 128 VGPRs).  Tried for the one-frame-per-launch case: 5 waves / 96 VGPRs with the tile in two
 // half passes -- the spills cost more than the occupancy buys (183 us vs 112 us per launch).
-template <int SIGN, bool COLOR, bool TAB, int WM>
+template <int SIGN, bool COLOR, bool TAB, int WM, bool ROWS>
 __global__ __launch_bounds__(256, 4) void k_integrate(uint4* __restrict__ voxels, const uint64_t* __restrict__ block_keys,
                                                    const int32_t* __restrict__ compact, const uint32_t* __restrict__ cmask,
                                                    const float* __restrict__ depthf_all, const uint32_t* __restrict__ color_all,
@@ -1193,11 +1210,16 @@ __global__ __launch_bounds__(256, 4) void k_integrate(uint4* __restrict__ voxels
       const float* Ti = B.Ti[q];
       const float* __restrict__ depthf = depthf_all + (size_t)q * npx;
       const uint32_t* __restrict__ color = color_all + (size_t)q * npx;
-      fuse_rows<SIGN, COLOR, TAB, WM, 0, 4>(P, Ti, depthf, color, s_rtab, wx, wy, wz, v, dirty);
+      fuse_rows<SIGN, COLOR, TAB, WM, 0, 4, ROWS>(P, Ti, depthf, color, s_rtab, wx, wy, wz, v, dirty);
     }
+    if (ROWS) {
 #pragma unroll
-    for (int j = 0; j < 4; j++)
-      if ((dirty[j] >> lane) & 1ull) vb[j * 64 + lane] = v[j];
+      for (int j = 0; j < 4; j++)
+        if ((dirty[j] >> lane) & 1ull) vb[j * 64 + lane] = v[j];
+    } else if (dirty[0] != 0ull) {   // wave-uniform: some frame of the pass changed a voxel of this tile -- the whole tile goes back, four 1 KiB stores
+#pragma unroll
+      for (int j = 0; j < 4; j++) vb[j * 64 + lane] = v[j];
+    }
   }
 }
 
@@ -1765,9 +1787,15 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
     f->events_used++;
     (void)hipEventRecord(e0, s);
   }
-#define LAUNCH_INT(SG, CL, TB, W1)                                                                                                        \
-  hipLaunchKernelGGL((k_integrate<SG, CL, TB, W1>), dim3(grid), dim3(256), 0, s, f->voxels, f->block_keys, f->compact2[sl], f->cmask2[sl], \
+#define LAUNCH_INT_R(SG, CL, TB, W1, RW)                                                                                                       \
+  hipLaunchKernelGGL((k_integrate<SG, CL, TB, W1, RW>), dim3(grid), dim3(256), 0, s, f->voxels, f->block_keys, f->compact2[sl], f->cmask2[sl], \
                      f->depthf2[sl], f->color2[sl], f->counters, f->host_mirror, cc, f->xcd_walk ? 1 : 0, f->pk, bt)
+  // per-row write-back masks for one frame per launch (HBM-bound) and for deintegration; a pass of several frames (VALU-bound) writes touched tiles whole
+#define LAUNCH_INT(SG, CL, TB, W1)                                    \
+  do {                                                                \
+    if (SG < 0 || n == 1) LAUNCH_INT_R(SG, CL, TB, W1, true);         \
+    else LAUNCH_INT_R(1, CL, TB, W1, false);                          \
+  } while (0)
   const bool tab = tab_ok;  // the LDS reciprocal table covers weight + sample < 512
   // one frame per launch without colour: the software-pipelined kernel (SF_PIPE=0: always k_integrate)
   if (pipe) {
@@ -1794,6 +1822,7 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
   } else if (f->p.weight_mode == 1) { if (col) LAUNCH_INT(-1, true, false, 3); else LAUNCH_INT(-1, false, false, 3); }
   else                           { if (col) LAUNCH_INT(-1, true, false, 0); else LAUNCH_INT(-1, false, false, 0); }
 #undef LAUNCH_INT
+#undef LAUNCH_INT_R
   if (f->profile) (void)hipEventRecord(e1, s);
   if (f->overlap && sa != s) (void)hipEventRecord(f->ev_fused[sl], s);
   if (f->overlap && sa == s) f->serial_tail = true;  // no cross-stream traffic at all while single-stream batches follow each other
@@ -2167,8 +2196,15 @@ SF_API int sf_fuser_tune(sf_fuser* f, const char* key, int value) {
   else if (k == "alloc_group" && in(1, MAX_BATCH)) f->alloc_group = value;
   else if (k == "alloc_wgs" && in(0, 8)) f->alloc_wgs = value;
   else if (k == "prepass_fuse" && in(0, 1)) f->prepass_fuse = value != 0;
-  else if (k == "alloc_ablate" && in(0, 15)) f->alloc_ablate = value;
+#ifdef SF_MEASURE_ABLATE
+  else if (k == "alloc_ablate" && in(0, 15)) f->alloc_ablate = value;   // parts of k_alloc_ray switched off: the volume is WRONG with any bit set
+#else
+  else if (k == "alloc_ablate")
+    return sf::fail(SF_ERR_INVALID_ARG, "sf_fuser_tune: alloc_ablate switches parts of the allocation off (the volume is wrong under it): only in a library built with -DSF_MEASURE_ABLATE");
+#endif
   else if (k == "front_prio" && in(0, 1)) {   // 1: the front stream at the device's highest priority (default), 0: at the default priority
+    if (f->front_cus > 0)
+      return sf::fail(SF_ERR_INVALID_ARG, "sf_fuser_tune: front_prio would replace the CU-masked front stream (front_cus = %d) by an unmasked one; set front_cus 0 first", f->front_cus);
     int prio_lo = 0, prio_hi = 0;
     SF_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     hipStream_t nf = nullptr;
@@ -2216,6 +2252,16 @@ SF_API int sf_fuser_stats(sf_fuser* f, sf_stats* out) {
   out->total_pass_tiles = tot;
   out->hash_slots_used = (uint32_t)c[C_SLOTS_USED];
   out->high_water = (uint32_t)c[C_HIGH_WATER];
+  return SF_OK;
+}
+
+SF_API int sf_fuser_alloc_direct_count(sf_fuser* f, uint64_t* out) {
+  if (!f || !out) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  SF_HIP_CHECK(hipSetDevice(f->device));
+  SF_HIP_CHECK(sf_quiesce(f));
+  int32_t c = 0;
+  SF_HIP_CHECK(hipMemcpy(&c, &f->counters[C_ALLOC_DIRECT], 4, hipMemcpyDeviceToHost));
+  *out = (uint64_t)(uint32_t)c;
   return SF_OK;
 }
 

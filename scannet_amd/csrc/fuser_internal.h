@@ -89,6 +89,12 @@ struct BatchFrames {  // k_alloc, k_compactify
 struct BatchTi {  // k_integrate: world -> camera rows 0..2 of every frame of the batch
   float Ti[MAX_BATCH][12];
 };
+// Kernel-argument segments: HIP's portability note names 4 KB (CUDA's limit); the AMD runtime sizes the kernarg segment from the kernel's own
+// metadata, and k_alloc_ray / k_compactify take BatchFrames (4 872 B) + ParamsK + pointers = ~5.2 KB by value on gfx950 under ROCm 7.2 (every
+// -m gpu test launches them).  The bound below is what this code relies on having been tested; a toolchain with a smaller limit fails the launch
+// loudly (hipErrorInvalidValue -> SF_ERR_DEVICE), it does not truncate.
+static_assert(sizeof(BatchFrames) == 8 + MAX_BATCH * sizeof(FrameK) && sizeof(BatchFrames) + 512 <= 6144, "BatchFrames kernarg grew: re-test the launch or move FrameK to a device buffer");
+static_assert(sizeof(BatchIn) <= 512 && sizeof(BatchTi) <= 1536, "kernarg structs");
 
 enum Counter {
   C_HEAP_FREE = 0,
@@ -98,6 +104,7 @@ enum Counter {
   C_LAST_BLOCKS = 5,
   C_GC_FREED = 7,
   C_IMPORTED = 8,
+  C_ALLOC_DIRECT = 9,   // blocks an allocation workgroup could not queue in LDS and took to the global table one by one (the slow path)
   // 64-bit compaction counters (8-byte aligned, own cache line): low word = entries in the compact list,
   // high word = blocks the LAST frame of the batch updates
   C_COMPACT = 16,

@@ -226,39 +226,60 @@ SF_API int sf_sens_add_depth_frames(sf_sens* s, const uint16_t* depth, uint64_t 
   const uint64_t raw = (uint64_t)s->info.depth_width * s->info.depth_height * 2;
   if (frame_stride_bytes < raw) return sf::fail(SF_ERR_INVALID_ARG, "frame stride smaller than a frame");
   if (n == 0) return SF_OK;
-  std::vector<SensFrame> made((size_t)n);
-  std::atomic<uint64_t> next{0};
-  std::atomic<int> failed{0};
-  const int nt = (int)std::min<uint64_t>(n, (uint64_t)(threads > 0 ? threads : sf::usable_cpus()));
-  auto work = [&]() {
-    for (;;) {
-      const uint64_t i = next.fetch_add(1);
-      if (i >= n || failed.load()) return;
-      SensFrame& f = made[(size_t)i];
-      std::memcpy(f.pose, poses + 16 * i, 64);
-      f.ts_color = 0;
-      f.ts_depth = timestamp0_us + i * timestamp_step_us;
-      const uint16_t* src = (const uint16_t*)((const uint8_t*)depth + i * frame_stride_bytes);
-      uint64_t dbytes = raw;
-      if (s->info.depth_compression == 0) {
-        f.owned.assign((const uint8_t*)src, (const uint8_t*)src + raw);
-      } else {
-        f.owned.resize(sf_zlib_deflate_bound(raw));
-        if (sf_zlib_deflate(src, raw, f.owned.data(), f.owned.size(), &dbytes) != SF_OK) { failed.store(1); return; }
-        f.owned.resize(dbytes);
-        f.owned.shrink_to_fit();
+  // no exception may cross the C ABI (std::thread's constructor and every allocation below can throw), and the frames are compressed in
+  // CHUNKS: only a chunk's worth of deflate-bound-sized buffers is ever alive beside the frames already shrunk to their compressed size
+  try {
+    const int nt = (int)std::min<uint64_t>(n, (uint64_t)(threads > 0 ? threads : sf::usable_cpus()));
+    const uint64_t chunk = std::max<uint64_t>(64, 8 * (uint64_t)nt);
+    s->frames.reserve(s->frames.size() + (size_t)n);
+    for (uint64_t c0 = 0; c0 < n; c0 += chunk) {
+      const uint64_t cn = std::min(chunk, n - c0);
+      std::vector<SensFrame> made((size_t)cn);
+      std::atomic<uint64_t> next{0};
+      std::atomic<int> failed{0};
+      auto work = [&]() {
+        try {
+          for (;;) {
+            const uint64_t k = next.fetch_add(1);
+            if (k >= cn || failed.load()) return;
+            const uint64_t i = c0 + k;
+            SensFrame& f = made[(size_t)k];
+            std::memcpy(f.pose, poses + 16 * i, 64);
+            f.ts_color = 0;
+            f.ts_depth = timestamp0_us + i * timestamp_step_us;
+            const uint16_t* src = (const uint16_t*)((const uint8_t*)depth + i * frame_stride_bytes);
+            uint64_t dbytes = raw;
+            if (s->info.depth_compression == 0) {
+              f.owned.assign((const uint8_t*)src, (const uint8_t*)src + raw);
+            } else {
+              f.owned.resize(sf_zlib_deflate_bound(raw));
+              if (sf_zlib_deflate(src, raw, f.owned.data(), f.owned.size(), &dbytes) != SF_OK) { failed.store(1); return; }
+              f.owned.resize(dbytes);
+              f.owned.shrink_to_fit();
+            }
+            f.color_bytes = 0;
+            f.depth_bytes = dbytes;
+          }
+        } catch (...) {
+          failed.store(2);   // bad_alloc on a worker: reported below, never thrown across the thread boundary
+        }
+      };
+      std::vector<std::thread> pool;
+      const int ct = (int)std::min<uint64_t>(cn, (uint64_t)nt);
+      try {
+        for (int t = 1; t < ct; t++) pool.emplace_back(work);
+      } catch (...) {
+        // could not start another thread: the ones that run (and this one) finish the chunk
       }
-      f.color_bytes = 0;
-      f.depth_bytes = dbytes;
+      work();
+      for (auto& t : pool) t.join();
+      if (failed.load() == 1) return sf::fail(SF_ERR_FORMAT, "sf_sens_add_depth_frames: deflate failed");
+      if (failed.load()) return sf::fail(SF_ERR_IO, "sf_sens_add_depth_frames: out of memory");
+      for (auto& f : made) s->frames.push_back(std::move(f));
     }
-  };
-  std::vector<std::thread> pool;
-  for (int t = 1; t < nt; t++) pool.emplace_back(work);
-  work();
-  for (auto& t : pool) t.join();
-  if (failed.load()) return sf::fail(SF_ERR_FORMAT, "sf_sens_add_depth_frames: deflate failed");
-  s->frames.reserve(s->frames.size() + (size_t)n);
-  for (auto& f : made) s->frames.push_back(std::move(f));
+  } catch (const std::exception& e) {
+    return sf::fail(SF_ERR_IO, "sf_sens_add_depth_frames: %s", e.what());
+  }
   for (SensFrame& q : s->frames)
     if (!q.owned.empty()) { q.color = q.owned.data(); q.depth = q.owned.data() + q.color_bytes; }
   return SF_OK;

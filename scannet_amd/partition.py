@@ -28,7 +28,13 @@ STRIPE_BLOCKS = 16
 def slab_planes(x_lo_block, x_hi_block, world):
     """world + 1 block planes splitting [x_lo_block, x_hi_block) evenly; the outer slabs are open-ended."""
     edges = [int(round(x_lo_block + (x_hi_block - x_lo_block) * r / world)) for r in range(world + 1)]
-    edges[0], edges[-1] = -(1 << 20) + 1, (1 << 20) - 1   # 21-bit block coordinates
+    edges[0] = -(1 << 20) + 1   # 21-bit block coordinates
+    for r in range(1, world + 1):
+        # strictly increasing whatever the extent: an extent narrower than `world` layers used to give equal planes, i.e. an EMPTY slab -- and the
+        # ring shift of exchange_boundary hands rank r's lowest layer to rank r - 1 only: with an empty slab in between, the rank that needed
+        # the layer never saw it (a silent seam in the merged mesh; ADVICE round 3)
+        edges[r] = max(edges[r], edges[r - 1] + 1)
+    edges[-1] = max(edges[-1], (1 << 20) - 1)
     return edges
 
 

@@ -171,7 +171,7 @@ class SensorData:
             raise ValueError("depth must be [n, H, W] at the file's depth size with one pose per frame")
         L = _abi.lib()
         L.sf_sens_add_depth_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int]
-        check(L.sf_sens_add_depth_frames(self._h, _ptr(d), d[0].nbytes, len(d), _ptr(p), int(timestamp0), int(timestamp_step), int(threads)))
+        check(L.sf_sens_add_depth_frames(self._h, _ptr(d), self.depth_width * self.depth_height * 2, len(d), _ptr(p), int(timestamp0), int(timestamp_step), int(threads)))
         self._refresh()
 
     def set_pose(self, frame, camera_to_world):

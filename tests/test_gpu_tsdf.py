@@ -914,3 +914,111 @@ def test_host_entry_point_has_read_the_buffers_when_it_returns(oracle):
             assert f.deintegrate(dbuf, poses[i].reshape(4, 4), rgb=cbuf if c else None)
             dbuf[:] = 1
         _assert_same(ovol, f)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# RGB-D at the benchmark's size: the metric is "RGB-D frames/s at 640x480 / 4 mm" -- the colour kernel
+# k_integrate<1, true, true, 2, *> at exactly that geometry, with colour at depth resolution and at ScanNet's real 1296x968 with its own
+# intrinsics (sensorData.h:600-616; the vertex colours meshlabserver keeps with -m vc, scan_processor.py:143), through every schedule
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def _baseline_walk_on_device(n, first, W=640, H=480):
+    """n frames of the configs[1] walk (furnished room, hashed noise: bench.py's default input) rendered by the device renderer; returns
+    (device pointer, host copy [n, H, W] u16, poses [n, 16])."""
+    import ctypes as C
+    from scannet_amd import _abi
+    L = _abi.lib()
+    dptr = C.c_void_p()
+    nbytes = n * W * H * 2
+    _abi.check(L.sf_device_malloc(0, nbytes, C.byref(dptr)))
+    poses = synth.render_scan_device(dptr.value, W * H * 2, first, n, 5578, W, H, noise=2, scene=1, seed=0)
+    host = np.zeros((n, H, W), np.uint16)
+    _abi.check(L.sf_device_download(host.ctypes.data_as(C.c_void_p), dptr, nbytes))
+    return dptr, host, poses
+
+
+def _texture_frames(n, H, W, seed):
+    """A colour frame per depth frame: per-pixel hashed bytes over a gradient that moves with the frame, a black band (the colour_first rule
+    tells black from unobserved) and saturated patches (255 + 255 must not carry into the neighbouring channel)."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:H, 0:W]
+    base = np.stack([xx * 255 // W, yy * 255 // H, xx + yy], -1).astype(np.uint8)   # uint8 arithmetic below wraps modulo 256
+    out = np.zeros((n, H, W, 3), np.uint8)
+    for i in range(n):
+        out[i] = base + np.array([5 * i, 3 * i, 7 * i], np.uint8) + rng.integers(0, 32, (H, W, 3), dtype=np.uint8)
+        out[i, : H // 8] = 0
+        out[i, H // 2 : H // 2 + H // 16, : W // 3] = 255
+    return out
+
+
+@pytest.mark.parametrize("colour_size", ["depth", "1296x968"])
+def test_rgbd_baseline_walk_matches_the_oracle(oracle, colour_size):
+    """64 frames of the configs[1] walk round a corner of the furnished room, 640x480 depth / 4 mm voxels / shipped parameters, a colour frame per
+    depth frame -- at depth resolution and at 1296x968 with the colour camera's own intrinsics -- through the 32-frame pass (first pass 8: the
+    ramp), the 16-frame pass and one frame per launch: block set, sdf, rgb and weight bit for bit against oracle.Volume."""
+    import ctypes as C
+    from scannet_amd import _abi, fusion
+    W, H, N = 640, 480, 64
+    op, gp = _mk(oracle, W, H, num_sdf_blocks=1 << 18)
+    dptr, depth, poses = _baseline_walk_on_device(N, 1368)
+    L = _abi.lib()
+    cptr = C.c_void_p()
+    try:
+        if colour_size == "depth":
+            rgb = _texture_frames(N, H, W, seed=21)
+            small = rgb
+        else:
+            CW, CH = 1296, 968
+            cfx, cfy, cmx, cmy = np.float32(1170.19), np.float32(1170.19), np.float32(647.75), np.float32(483.75)   # a ScanNet colour camera
+            gp.color_width, gp.color_height, gp.cfx, gp.cfy, gp.cmx, gp.cmy = CW, CH, cfx, cfy, cmx, cmy
+            rgb = _texture_frames(N, CH, CW, seed=22)
+            # the pre-pass's look-up restated in numpy: colour pixel under the depth pixel's ray, nearest, black outside (fmaf = one rounding)
+            xs, ys = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32))
+            u = (((xs - np.float32(gp.mx)) / np.float32(gp.fx)).astype(np.float64) * np.float64(cfx) + np.float64(cmx)).astype(np.float32) + np.float32(0.5)
+            v = (((ys - np.float32(gp.my)) / np.float32(gp.fy)).astype(np.float64) * np.float64(cfy) + np.float64(cmy)).astype(np.float32) + np.float32(0.5)
+            ok = (u >= 0) & (u < CW) & (v >= 0) & (v < CH)
+            iu, iv = np.where(ok, u, 0).astype(np.int64), np.where(ok, v, 0).astype(np.int64)
+            assert 0.5 < ok.mean() <= 1.0
+            small = np.where(ok[None, ..., None], rgb[:, iv, iu], 0).astype(np.uint8)
+        ovol = oracle.Volume(op, threads=16)
+        last = 0
+        for i in range(N):
+            last = ovol.integrate(depth[i], poses[i].reshape(4, 4), rgb=small[i])
+        _abi.check(L.sf_device_malloc(0, rgb.nbytes, C.byref(cptr)))
+        _abi.check(L.sf_device_upload(cptr, rgb.ctypes.data_as(C.c_void_p), rgb.nbytes))
+        for tune in ({}, {"batch": 16}, {"batch": 1}):
+            with fusion.Fuser(gp, **tune) as f:
+                f.integrate_batch_device(dptr.value, W * H * 2, poses, cptr.value, rgb[0].nbytes)
+                st = f.stats()
+                assert st["alloc_failures"] == 0 and st["frames_integrated"] == N and st["last_frame_blocks"] == last
+                _assert_same(ovol, f)
+                _, gv = f.export_blocks()
+                seen = gv["w"] > 0
+                assert seen.mean() > 0.2 and (gv["r"][seen] > 0).mean() > 0.5, "colour did not reach the voxels"
+        ovol.close()
+    finally:
+        L.sf_device_free(dptr)
+        if cptr:
+            L.sf_device_free(cptr)
+
+
+def test_bench_walk_corner_stays_on_the_allocation_fast_path():
+    """when k_alloc_ray re-anchors its window inside a group (a fast-turning tile) the blocks already queued are queued again; the
+    duplicates must not fill the workgroup's LDS queue, or its blocks go to the global table one probe at a time -- the slow path the kernel was
+    written to avoid.  96 frames round a corner of the bench walk (the fastest turn of the stream) at full size: the direct path is never taken."""
+    import ctypes as C
+    from scannet_amd import _abi, fusion
+    W, H, N = 640, 480, 96
+    gp = fusion.default_params(depth_width=W, depth_height=H, num_sdf_blocks=1 << 18)
+    dptr, _, poses = _baseline_walk_on_device(N, 1340)
+    L = _abi.lib()
+    L.sf_fuser_alloc_direct_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    try:
+        for tune in ({}, {"batch": 16}, {"alloc_group": 32}):
+            with fusion.Fuser(gp, **tune) as f:
+                f.integrate_batch_device(dptr.value, W * H * 2, poses)
+                n = C.c_uint64(123)
+                _abi.check(L.sf_fuser_alloc_direct_count(f._h, C.byref(n)))
+                assert n.value == 0, "%d blocks took the one-by-one path under %r" % (n.value, tune)
+                assert f.stats()["alloc_failures"] == 0
+    finally:
+        L.sf_device_free(dptr)

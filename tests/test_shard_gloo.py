@@ -252,3 +252,21 @@ def test_slab_planes_and_mesh_merge():
     xyz, rgba, tris, keys = partition.merge_slab_meshes([a, b])
     assert keys.tolist() == [10, 20, 30, 40] and tris.tolist() == [[0, 1, 2], [1, 3, 2]]
     assert xyz.tolist() == [[0, 0, 0], [1, 0, 0], [1, 1, 0], [2, 0, 0]] and rgba[:, 0].tolist() == [1, 1, 1, 2]
+
+
+def test_slab_planes_never_leave_an_empty_slab():
+    """an extent narrower than `world` layers gave equal planes (an empty slab); the ring shift of exchange_boundary sends a rank's
+    lowest layer to rank - 1 only, so the rank below an empty slab never received the layer it needed.  Planes are strictly increasing now, and
+    with them the neighbour rule delivers every layer that is wanted (simulated here layer by layer for world 3 over a 2-layer extent)."""
+    from scannet_amd import partition
+    for lo, hi, world in ((0, 2, 3), (5, 5, 4), (-3, -1, 8), (0, 100, 3)):
+        p = partition.slab_planes(lo, hi, world)
+        assert len(p) == world + 1 and all(p[r] < p[r + 1] for r in range(world)), p
+        assert p[0] < -(1 << 19) and p[-1] >= (1 << 20) - 1
+        owner = lambda c: next(r for r in range(world) if p[r] <= c < p[r + 1])   # noqa: E731
+        layers = range(lo - 2, hi + 3)   # layers that hold blocks
+        for c in layers:
+            # layer c is a boundary layer of its owner iff the layer below belongs to somebody else; that somebody must be owner - 1,
+            # the only rank the ring shift sends to
+            if owner(c) != owner(c - 1):
+                assert owner(c - 1) == owner(c) - 1, (p, c)
