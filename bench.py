@@ -1,13 +1,16 @@
 #!/usr/bin/env python3
 """bench.py -- RGB-D frames/s integrated on MI355X + the roofline of the integrate kernel.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 4mm|1mm|scans|partition]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 4mm|1mm|scans|partition]      (N > 1 without a launcher: bench.py re-executes itself
+                                                                                               under torch.distributed.run with N ranks, or refuses)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 --config (BASELINE.json `configs`; the default is the one the metric is quoted on):
-  4mm        configs[1]  scene0000_00-scale synthetic stream (5 578 frames, 640x480, 4 mm voxels, 2^19 hash buckets).  One step = one depth
-                         frame through the whole per-frame hot path (pre-pass, block allocation, frustum compaction, TSDF integrate); the
-                         stream is rendered into HBM before the timed region; with N > 1 every rank fuses its own scan (weak scaling).
+  4mm        configs[1]  scene0000_00-scale synthetic stream (5 578 frames, 640x480, 4 mm voxels, 2^19 hash buckets).  One step = one RGB-D
+                         frame -- a 640x480 u16 depth image AND a 640x480 RGB image -- through the whole per-frame hot path (pre-pass, block
+                         allocation, frustum compaction, TSDF + colour integrate); both streams are resident in HBM before the timed region;
+                         with N > 1 every rank fuses its own scan (weak scaling).  --depth-only times the geometry-only path (rounds 1-3's
+                         headline; reported beside the metric as value_depth_only in every default line).
   1mm        configs[2]  the same stream at 1 mm voxels / 2^22 buckets / 2^25 SDF blocks (137 GB of tiles): ~1.4 M tiles = 5.9 GB touched
                          per frame, far beyond the 256 MiB Infinity Cache -- the out-of-cache HBM roofline of the one-frame kernel.
   scans      configs[3]  independent scans (room size +-20 %, 300..6000 frames) popped longest-first from one queue by all ranks, no
@@ -59,7 +62,7 @@ CONFIGS = {
 # CPU baseline (rank 0, N = 1): the oracle port on a bounded sample at 1, 8 and all usable threads; the reference's own SensReader decode
 # beside ours; the parity of the GPU path with the oracle on exactly the frames the CPU leg fused
 # ---------------------------------------------------------------------------------------------------------------------------------------
-def cpu_baseline(depth_host, poses, voxel, frames=200):
+def cpu_baseline(depth_host, poses, voxel, frames=200, rgb_host=None):
     """the CPU path = reference SensorData decode (compiled from /root/reference when this repo was built) + the oracle
     (our CPU port of the same specification, OpenMP over blocks) on the first `frames` frames of the same stream, at 1, 8 and all the threads this
     container may use.  Returns (dict for the JSON line, the oracle volume of the all-threads run for the parity leg)."""
@@ -77,7 +80,7 @@ def cpu_baseline(depth_host, poses, voxel, frames=200):
         t0 = time.perf_counter()
         done = 0
         for i in range(n):
-            vol.integrate(depth_host[i], poses[i])
+            vol.integrate(depth_host[i], poses[i], rgb=None if rgb_host is None else rgb_host[i])
             done += 1
             if time.perf_counter() - t0 > budget:
                 break
@@ -95,9 +98,10 @@ def cpu_baseline(depth_host, poses, voxel, frames=200):
     out = {"value": best.get("frames_per_s_with_reference_decode", best["frames_per_s_integrate"]), "unit": "frames/s", "cores": allt, "kind": "port",
            "by_threads": by, "reference_decode": decode,
            "cpu_model": _cpu_model(), "nproc_visible": os.cpu_count(),
-           "sample": "first %d frames of the same stream (fewer where a leg ran into its time budget: by_threads.*.frames): reference SensorData depth decode (oracle/_ref/libref_sens.so, -O2, one frame per thread) + "
+           "colour": rgb_host is not None,
+           "sample": "first %d %s frames of the same stream (fewer where a leg ran into its time budget: by_threads.*.frames): reference SensorData depth decode (oracle/_ref/libref_sens.so, -O2, one frame per thread) + "
                      "oracle/tsdf_oracle.c (-O2 -fopenmp, blocks over threads) at 1 / 8 / %d threads (= the CPUs this container may use, of %d visible); "
-                     "`value` is the all-threads figure" % (n, allt, os.cpu_count() or allt)}
+                     "`value` is the all-threads figure" % (n, "RGB-D (depth + resident raw colour)" if rgb_host is not None else "depth-only", allt, os.cpu_count() or allt)}
     return out, keep, n
 
 
@@ -150,27 +154,29 @@ def _cpu_model():
     return None
 
 
-def parity_leg(ovol, n, frames_dev, stride, poses, params, local_rank):
-    """The same n frames the CPU leg fused, through the HIP path of THIS run's build: block set and every voxel byte must be identical."""
+def parity_leg(ovol, n, frames_dev, stride, poses, params, local_rank, rgb_dev=None):
+    """The same n frames the CPU leg fused, through the HIP path of THIS run's build: block set and every voxel byte (sdf, r, g, b, weight) must
+    be identical."""
     import hashlib
     from scannet_amd import fusion
     oc, ov = ovol.export()
     with fusion.Fuser(params, device=local_rank, **TUNE) as f:
-        f.integrate_batch_device(frames_dev.data_ptr(), stride, poses[:n])
+        f.integrate_batch_device(frames_dev.data_ptr(), stride, poses[:n], None if rgb_dev is None else rgb_dev.data_ptr(), W * H * 3)
         gc, gv = f.export_blocks()
         fails = f.stats()["alloc_failures"]
     ho = hashlib.sha256(oc.tobytes() + ov.tobytes()).hexdigest()
     hg = hashlib.sha256(gc.tobytes() + gv.tobytes()).hexdigest()
     return {"frames": n, "blocks": int(len(gc)), "blocks_oracle": int(len(oc)), "sha256_equal": ho == hg, "sha256": hg[:16], "alloc_failures": fails,
-            "weight_max_seen": int(gv["w"].max()) if len(gc) else 0,
-            "what": "sha256 over (block coordinates sorted by x, y, z; 512 x 8-byte voxels per block) of oracle/tsdf_oracle.c and of the HIP path "
-                    "(the default schedule: 32 frames per pass) after the first %d frames of this run's stream" % n}
+            "weight_max_seen": int(gv["w"].max()) if len(gc) else 0, "colour": rgb_dev is not None,
+            "coloured_voxels": int(((gv["r"] | gv["g"] | gv["b"]) > 0).sum()) if len(gc) else 0,
+            "what": "sha256 over (block coordinates sorted by x, y, z; 512 x 8-byte voxels {f32 sdf, u8 r, g, b, weight} per block) of oracle/tsdf_oracle.c and of the HIP path "
+                    "(the default schedule: 32 frames per pass) after the first %d %s frames of this run's stream" % (n, "RGB-D" if rgb_dev is not None else "depth-only")}
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------------
 # PMC passes: this script re-run as a child under rocprofv3 --pmc (no trace domains), per-launch averages of the integrate kernel
 # ---------------------------------------------------------------------------------------------------------------------------------------
-def pmc_pass(args, counters, config, steps, warmup, single_frame, timeout_s=420):
+def pmc_pass(args, counters, config, steps, warmup, single_frame, depth_only, timeout_s=420):
     """One rocprofv3 --pmc pass over the first `steps` timed frames of this same script.  Returns ({counter: average per integrate launch of
     the timed region}, the child's JSON line) or None."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
@@ -181,6 +187,7 @@ def pmc_pass(args, counters, config, steps, warmup, single_frame, timeout_s=420)
         env = dict(os.environ, TMPDIR="/tmp")
         cmd = [exe, "--pmc"] + list(counters) + ["-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--config", config, "--steps", str(steps),
                "--warmup", str(warmup), "--child", "--no-profile", "--teardown", "--scene", str(args.scene), "--noise", str(args.noise)] + (["--single-frame"] if single_frame else []) + \
+              (["--depth-only"] if depth_only else []) + \
               sum((["--tune", "%s=%d" % kv] for kv in TUNE.items()), [])
         r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
         dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
@@ -195,7 +202,7 @@ def pmc_pass(args, counters, config, steps, warmup, single_frame, timeout_s=420)
         launches = child["config"]["integrate_launches"]
         # one frame per launch runs the software-pipelined k_integrate_pipe, batches run k_integrate; the integrate launches of the timed
         # region are the LAST `launches` dispatches of the kernel (warm-up comes first)
-        pat = "%k_integrate_pipe%" if single_frame else "%k_integrate<1, false%"
+        pat = "%k_integrate_pipe%" if (single_frame and depth_only) else ("%k_integrate<1, false%" if depth_only else "%k_integrate<1, true%")
         db = sqlite3.connect(dbs[0])
         out = {}
         for c in counters:
@@ -212,13 +219,13 @@ def pmc_pass(args, counters, config, steps, warmup, single_frame, timeout_s=420)
         shutil.rmtree(d, ignore_errors=True)
 
 
-def pmc_traffic(args, config, steps, warmup, single_frame):
+def pmc_traffic(args, config, steps, warmup, single_frame, depth_only):
     """HBM-side traffic of the integrate kernel per launch: FETCH_SIZE and WRITE_SIZE in SEPARATE passes.  Corrections as
     MI355X_MICROARCH.md (HBM) prescribes and tools/pmc_calibrate.py confirmed for this kernel's 16 B/lane pattern
     (profiles/r01_b_alloc_bitmap_rocprofv3.txt): both counters are KiB per dispatch, FETCH_SIZE reports exactly half of the bytes read,
     WRITE_SIZE the bytes written.  Infinity-Cache hits are counted (fabric-side counters), so this is an upper bound on DRAM traffic."""
-    a = pmc_pass(args, ["FETCH_SIZE"], config, steps, warmup, single_frame)
-    b = pmc_pass(args, ["WRITE_SIZE"], config, steps, warmup, single_frame) if a else None
+    a = pmc_pass(args, ["FETCH_SIZE"], config, steps, warmup, single_frame, depth_only)
+    b = pmc_pass(args, ["WRITE_SIZE"], config, steps, warmup, single_frame, depth_only) if a else None
     if not a or not b:
         return None
     read_b, write_b = 2.0 * a[0]["FETCH_SIZE"] * 1024.0, b[0]["WRITE_SIZE"] * 1024.0
@@ -229,10 +236,10 @@ def pmc_traffic(args, config, steps, warmup, single_frame):
             "alg_bytes_same_launches": alg, "traffic_over_alg": round((read_b + write_b) / alg, 4) if alg else None}
 
 
-def pmc_valu(args, config, steps, warmup, single_frame):
+def pmc_valu(args, config, steps, warmup, single_frame, depth_only):
     """VALU issue utilisation of the integrate kernel: SQ_ACTIVE_INST_VALU (quad-cycles a SIMD spends issuing VALU, summed over SIMDs)
     over the SIMD quad-cycles of the launch = 1024 SIMDs x (GRBM_GUI_ACTIVE / 8 XCDs) / 4 -- the method of profiles/r01_c."""
-    a = pmc_pass(args, ["SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"], config, steps, warmup, single_frame)
+    a = pmc_pass(args, ["SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"], config, steps, warmup, single_frame, depth_only)
     if not a:
         return None
     v, child = a
@@ -248,18 +255,38 @@ def pmc_valu(args, config, steps, warmup, single_frame):
 # ---------------------------------------------------------------------------------------------------------------------------------------
 # configs[1] / configs[2]: one resident stream per rank
 # ---------------------------------------------------------------------------------------------------------------------------------------
-def end_to_end(frames_dev, poses, n, params, local_rank, torch):
+def end_to_end(frames_dev, poses, n, params, local_rank, torch, colour=None):
     """SURVEY 8d "End-to-end frames/s": the first n frames of the run's stream written to a .sens in /tmp (zlib depth, this library's writer),
-    then sf_fuse_run: file -> decode pool -> pinned ring -> H2D -> fusion.  Wall time from the first byte decoded to the last kernel."""
+    then sf_fuse_run: file -> decode pool -> pinned ring -> H2D -> fusion.  Wall time from the first byte decoded to the last kernel.
+    colour = "jpeg1296": every frame also carries a baseline-JPEG colour image at ScanNet's real 1296x968 with its own intrinsics
+    (sensorData.h:600-616: Huffman decode on the host threads, IDCT / upsampling / YCbCr->RGB on the GPU, then the colour pre-pass samples it
+    under each depth pixel's ray) -- eight distinct encoded images cycled, so the set-up does not encode thousands of frames."""
     from scannet_amd import fusion, sens, synth
     d = tempfile.mkdtemp(prefix="sf_e2e_", dir="/tmp")
     try:
         path = os.path.join(d, "stream.sens")
         host = frames_dev[:n].cpu().numpy().view(np.uint16)
         K = synth.intrinsic_matrix(W, H)
-        sd = sens.SensorData.create(0, 0, W, H, K, K, depth_compression=1, sensor_name="StructureSensor")
         t0 = time.perf_counter()
-        sd.add_depth_frames(host, poses[:n].reshape(-1, 4, 4))
+        prm = params
+        if colour == "jpeg1296":
+            from scannet_amd import calibrate
+            cw, ch = 1296, 968
+            KC = synth.intrinsic_matrix(cw, ch)
+            yy, xx = np.mgrid[0:ch, 0:cw]
+            blobs = []
+            for k in range(8):
+                img = np.stack([(xx // 3 + 31 * k) % 256, (yy // 2 + 17 * k) % 256, (128 + 100 * np.sin(xx / 30.0) * np.cos(yy / 20.0 + k))], -1).astype(np.uint8)
+                blobs.append(calibrate.jpeg_encode(img, 90, True))
+            sd = sens.SensorData.create(cw, ch, W, H, KC, K, color_compression=2, depth_compression=1, sensor_name="StructureSensor")
+            for i in range(n):
+                sd.add_frame(host[i], poses[i].reshape(4, 4), color=blobs[i % 8], timestamp_depth=33333 * i)
+            prm = type(params).from_buffer_copy(params)
+            prm.color_width, prm.color_height = cw, ch
+            prm.cfx, prm.cfy, prm.cmx, prm.cmy = synth.intrinsics(cw, ch)
+        else:
+            sd = sens.SensorData.create(0, 0, W, H, K, K, depth_compression=1, sensor_name="StructureSensor")
+            sd.add_depth_frames(host, poses[:n].reshape(-1, 4, 4))
         sd.save(path)
         sd.close()
         t_write = time.perf_counter() - t0
@@ -267,7 +294,7 @@ def end_to_end(frames_dev, poses, n, params, local_rank, torch):
         sd = sens.SensorData(path)
         best = None
         for _ in range(2):   # the second pass reads the file from the page cache, as the stage after `convert` does
-            with fusion.Fuser(params, device=local_rank, **TUNE) as f:
+            with fusion.Fuser(prm, device=local_rank, **TUNE) as f:
                 rs = f.run(sd)
                 st = f.stats()
             if best is None or rs["seconds_total"] < best[0]["seconds_total"]:
@@ -277,9 +304,11 @@ def end_to_end(frames_dev, poses, n, params, local_rank, torch):
         return {"frames": int(rs["frames_total"]), "frames_per_s": round(rs["frames_total"] / rs["seconds_total"], 1), "seconds": round(rs["seconds_total"], 4),
                 "compressed_bytes_per_frame": round(size / n), "sens_bytes": size, "decode_threads": int(rs["decode_threads"]),
                 "decode_ms_per_frame_per_thread": round(1e3 * rs["seconds_decode_cpu"] / max(rs["frames_total"], 1), 3),
+                "colour_fused": int(rs["color_fused"]),
                 "blocks_live_end": st["blocks_allocated"], "alloc_failures": st["alloc_failures"], "write_s": round(t_write, 2),
-                "what": ".sens on disk (zlib depth, %d KB per frame) -> %d decode threads -> pinned ring -> H2D -> pre-pass / allocation / compaction / integrate, "
-                        "32 frames per pass; wall time of sf_fuse_run (first byte decoded -> last kernel complete), best of 2" % (size // n // 1024, rs["decode_threads"])}
+                "what": ".sens on disk (zlib depth%s, %d KB per frame) -> %d decode threads -> pinned ring -> H2D -> pre-pass / allocation / compaction / integrate, "
+                        "32 frames per pass; wall time of sf_fuse_run (first byte decoded -> last kernel complete), best of 2"
+                        % (" + baseline-JPEG colour at 1296x968 with its own intrinsics" if colour == "jpeg1296" else "", size // n // 1024, rs["decode_threads"])}
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
@@ -304,6 +333,7 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
         roof_W, roof_K = Wm, min(K, args.pmc_steps)
     else:
         roof_W, roof_K = 64, 400
+    rgbd = not args.depth_only   # the metric's own configuration: a colour frame per depth frame
     e2e_n = 0 if (child or world > 1 or args.no_e2e or cfg_name != "4mm") else args.e2e_frames
     cpu_n = 0 if (child or world > 1 or args.no_cpu_baseline) else args.cpu_frames
     ooc_n = 0 if (child or world > 1 or args.no_out_of_cache or cfg_name != "4mm" or args.no_profile) else 16 + 64
@@ -317,21 +347,28 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
     colour_frames = [None]
 
     def colour_tensor(n):
-        """A synthetic RGB frame per depth frame, resident in HBM: smooth gradients that move with the frame index (uint8 [n, H, W, 3])."""
+        """A synthetic RGB frame per depth frame, resident in HBM (uint8 [n, H, W, 3], 921 600 B per frame): gradients that move with the frame
+        index under a per-pixel texture, a black band at the top (colour_first tells black from unobserved) and a saturated patch."""
         if colour_frames[0] is None or colour_frames[0].shape[0] < n:
-            yy = torch.arange(H, device="cuda").view(1, H, 1)
-            xx = torch.arange(W, device="cuda").view(1, 1, W)
-            k = torch.arange(n, device="cuda").view(n, 1, 1)
+            yy = torch.arange(H, device="cuda", dtype=torch.int32).view(1, H, 1)
+            xx = torch.arange(W, device="cuda", dtype=torch.int32).view(1, 1, W)
+            tex = ((xx * 7919 + yy * 104729) >> 3) & 31
             out = torch.empty((n, H, W, 3), dtype=torch.uint8, device="cuda")
-            out[..., 0] = (xx * 255 // W + k) % 256
-            out[..., 1] = (yy * 255 // H + 3 * k) % 256
-            out[..., 2] = (xx + yy + 7 * k) % 256
+            for a in range(0, n, 256):   # chunks: the int32 temporaries of 5 578 frames at once would be tens of GB
+                b = min(n, a + 256)
+                k = torch.arange(a, b, device="cuda", dtype=torch.int32).view(-1, 1, 1) + first
+                out[a:b, ..., 0] = ((xx * 255 // W + 5 * k + tex) % 256).to(torch.uint8)
+                out[a:b, ..., 1] = ((yy * 255 // H + 3 * k + tex) % 256).to(torch.uint8)
+                out[a:b, ..., 2] = ((xx + yy + 7 * k + tex) % 256).to(torch.uint8)
+            out[:, : H // 8] = 0
+            out[:, H // 2: H // 2 + H // 16, : W // 3] = 255
             colour_frames[0] = out
         return colour_frames[0]
 
-    def run(n_warm, n_timed, profile, single_frame=False, colour=False, extra_tune=None, repeats=1, prm=None):
+    def run(n_warm, n_timed, profile, single_frame=False, colour=None, extra_tune=None, repeats=1, prm=None):
         """`repeats` times on one fuser (sf_fuser_reset in between): fuse frames [0, n_warm) untimed, then frames [n_warm, n_warm + n_timed) between
         two barrier+synchronize pairs.  Elapsed times per repeat (max over ranks), kernel events and counters summed over the repeats."""
+        colour = rgbd if colour is None else colour
         fuser = fusion.Fuser(prm if prm is not None else params, device=local_rank, **dict(dict(TUNE, **({"batch": 1} if single_frame else {})), **(extra_tune or {})))
         rgb = colour_tensor(n_warm + n_timed) if colour else None
         cstride = W * H * 3
@@ -342,7 +379,7 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
             if world > 1:
                 dist.barrier()
 
-        times, t_enq_sum, kernel_ms, launches, blocks, tiles = [], 0.0, 0.0, 0, 0, 0
+        times, own_times, t_enq_sum, kernel_ms, launches, blocks, tiles = [], [], 0.0, 0.0, 0, 0, 0
         st1 = None
         for rep in range(repeats):
             if rep:
@@ -358,6 +395,7 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
             t_enq_sum += time.perf_counter() - t0
             sync_all()
             elapsed = time.perf_counter() - t0
+            own_times.append(elapsed)
             if world > 1:
                 tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -387,9 +425,9 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
         # plus the frames' depth images -- the memory roofline of the temporally blocked launch
         batch_bytes = tiles * 8192 + repeats * n_timed * (W * H * (5 if colour else 2))
         tsort = sorted(times)
-        return {"elapsed": tsort[len(tsort) // 2], "times": times, "t_enq": t_enq_sum / repeats, "kernel_ms": kernel_ms, "launches": launches, "blocks": blocks,
+        return {"elapsed": tsort[len(tsort) // 2], "times": times, "own_times": own_times, "t_enq": t_enq_sum / repeats, "kernel_ms": kernel_ms, "launches": launches, "blocks": blocks,
                 "alg_bytes": alg_bytes, "batch_bytes": batch_bytes, "tiles": tiles, "repeats": repeats,
-                "batch": batch, "n_launch": (n_timed + batch - 1) // batch, "st1": st1, "ceiling": ceiling}
+                "batch": batch, "n_launch": (n_timed + batch - 1) // batch, "st1": st1, "ceiling": ceiling, "colour": colour}
 
     def per_launch(m, n_timed):
         return {"avg_kernel_us": round(m["kernel_ms"] * 1e3 / m["launches"], 2), "launches": m["launches"],
@@ -439,28 +477,37 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
         return r
 
     R = 1 if child else (args.repeats if args.repeats else repeats_for(K, cfg_name))
+    kname = "k_integrate<1,true,true,2,false>" if rgbd else "k_integrate<1,false,true,2,false>"
     # the timed region runs WITHOUT the HIP events around every integrate launch (they cost ~2 % of the frames/s: profiles/r03_small_experiments.txt);
     # kernel durations come from the roofline sample below, fused again with the events on.  --single-frame keeps them: its line is the roofline.
     m = run(Wm, K, args.single_frame and not args.no_profile, single_frame=args.single_frame, repeats=R)
     # the roofline window, on EVERY rank (run() holds barriers and an all-reduce when N > 1: a pass only rank 0 entered would hang the job)
     mr = m if (child or args.no_profile or m["batch"] == 1) else run(roof_W, roof_K, True)
+    # every rank's own rate, gathered (N > 1): the driver computes scaling efficiency from `value`, a reader sees the spread here
+    per_rank = None
+    if world > 1:
+        mine = torch.tensor([K / min(m["own_times"])], dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [round(float(t.item()), 1) for t in allr]
     out = None
     if rank == 0:
         pmc_on = world == 1 and not args.no_pmc and not args.no_profile and not child
         if m["batch"] == 1:
-            roof = roofline_hbm(m, K, "k_integrate_pipe<true,2,*>")
+            roof = roofline_hbm(m, K, "k_integrate_pipe<true,2,*>" if not rgbd else "k_integrate<1,true,true,2,true> (one frame per launch)")
             if roof is not None and m["ceiling"]:
                 roof["pattern_ceiling"] = dict(m["ceiling"], frac_of_ceiling=round(roof["achieved"] / m["ceiling"]["rmw_copy_GBs"], 4))
         else:
             same = (roof_W, roof_K) == (Wm, K)
-            valu = pmc_valu(args, cfg_name, roof_K, roof_W, False) if pmc_on else None
-            traffic = pmc_traffic(args, cfg_name, roof_K, roof_W, False) if pmc_on else None
-            roof = roofline_valu(mr, roof_K, "k_integrate<1,false,true,2>", valu, traffic,
+            valu = pmc_valu(args, cfg_name, roof_K, roof_W, False, not rgbd) if pmc_on else None
+            traffic = pmc_traffic(args, cfg_name, roof_K, roof_W, False, not rgbd) if pmc_on else None
+            roof = roofline_valu(mr, roof_K, kname, valu, traffic,
                                  "frames %d..%d of the stream (%s), HIP events around every integrate launch; counters from rocprofv3 --pmc passes over the same frames"
                                  % (roof_W, roof_W + roof_K - 1, "the timed region, fused again with events on" if same else
                                     ("the first frames of the timed region, fused again with events on" if roof_W == Wm else
                                      "a fixed window: the timed region of this run is too short to hold full passes")))
         ts = m["times"]
+        px_bytes = 5 if rgbd else 2
         out = {
             "metric": "RGB-D frames/sec integrated (640x480, %s voxel)" % ("4 mm" if cfg_name == "4mm" else "1 mm"),
             "value": round(world * K / m["elapsed"], 2), "unit": "frames/s",
@@ -469,26 +516,47 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
             "host_enqueue_ms_per_step": round(m["t_enq"] * 1e3 / max(K, 1), 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "rccl_ranks": world if (world > 1 and dist.get_backend() == "nccl") else (0 if world > 1 else 1),
+            "process_group": (dist.get_backend() if world > 1 else "none (one process)"),
+            "per_rank_frames_per_s": per_rank,
             "repeats": {"n": len(ts), "timed_s_total": round(sum(ts), 4), "value_median": round(world * K / m["elapsed"], 2),
                         "value_min": round(world * K / max(ts), 2), "value_max": round(world * K / min(ts), 2),
                         "what": "the %d warm-up + %d timed steps repeated on an emptied volume (sf_fuser_reset) until the timed regions add up to ~1 s; "
                                 "`value` is the median repeat" % (Wm, K)},
-            "config": {"workload": cfg["label"] + ", frames %d..%d per rank, depth resident in HBM" % (Wm, K + Wm - 1), "tune": dict(TUNE),
+            "config": {"workload": cfg["label"] + ", frames %d..%d per rank, %s resident in HBM" % (Wm, K + Wm - 1, "depth AND colour (a 640x480 RGB8 frame per depth frame, 921 600 B)" if rgbd else "depth (geometry only: --depth-only)"),
+                       "rgbd": rgbd, "tune": dict(TUNE),
                        "scene": {0: "empty box room", 1: "box room furnished with 48 boxes (csrc/synth.hip clutter_boxes), sensor holes"}[args.scene],
                        "noise": {0: "none", 1: "round-1 LCG ramp (3 LSBs)", 2: "3 LSBs hashed per pixel and frame"}[args.noise],
                        "sharding": "one independent scan per GPU, no collective on the data path",
                        "blocks_live_end": m["st1"]["blocks_allocated"], "alloc_failures": m["st1"]["alloc_failures"],
                        "frames_per_pass": m["batch"], "integrate_launches": m["n_launch"],
                        "alg_bytes_per_launch": round(m["alg_bytes"] / max(m["n_launch"] * m["repeats"], 1))},
-            "roofline_inputs": {"block_frames_per_launch": round(m["blocks"] / max(m["n_launch"] * m["repeats"], 1), 1)},
+            "roofline_inputs": {"block_frames_per_launch": round(m["blocks"] / max(m["n_launch"] * m["repeats"], 1), 1), "input_bytes_per_pixel": px_bytes},
             "roofline": roof,
         }
+        if rgbd:
+            out["value_rgbd"] = out["value"]
+        else:
+            out["value_depth_only"] = out["value"]
         extras = world == 1 and not args.no_profile and not args.single_frame and not child
+        if extras and rgbd and not args.no_depth_only and cfg_name == "4mm":
+            # the geometry-only pass over the same frames (the headline of rounds 1-3): rate with the same repeats, kernel duration and VALU counters
+            md = run(Wm, K, False, colour=False, repeats=R)
+            out["value_depth_only"] = round(K / md["elapsed"], 2)
+            mdr = run(roof_W, roof_K, True, colour=False)
+            vd = pmc_valu(args, cfg_name, roof_K, roof_W, False, True) if pmc_on else None
+            rd = roofline_valu(mdr, roof_K, "k_integrate<1,false,true,2,false>", vd, None,
+                               "frames %d..%d of the stream without the colour frames, HIP events around every integrate launch" % (roof_W, roof_W + roof_K - 1))
+            if rd is not None:
+                rd["frames_per_s"] = out["value_depth_only"]
+                rd["colour_pass_over_depth_pass"] = round(mr["kernel_ms"] / mr["launches"] / (mdr["kernel_ms"] / mdr["launches"]), 4) if (mr["launches"] and mdr["launches"]) else None
+                out["roofline_depth_only"] = rd
         if extras and not args.no_single_frame:
-            # the same update HBM-bound: one frame per launch (what sf_fuser_integrate does for a live stream), on the roofline sample
+            # the same update HBM-bound: one frame per launch (what sf_fuser_integrate does for a live stream), on the roofline sample; geometry only --
+            # the colourless one-frame pass runs the software-pipelined kernel, whose bytes are SURVEY 8d's formula
             ks = min(roof_K, 1200)
-            m1 = run(roof_W, ks, True, single_frame=True)
-            r1 = roofline_hbm(m1, ks, "k_integrate_pipe<true,2,*>: one frame per launch (batch = 1), persistent, software-pipelined (tiles and depth gathers "
+            m1 = run(roof_W, ks, True, single_frame=True, colour=False)
+            r1 = roofline_hbm(m1, ks, "k_integrate_pipe<true,2,*>: one DEPTH frame per launch (batch = 1), persistent, software-pipelined (tiles and depth gathers "
                                       "of later tiles in flight into LDS)")
             if r1 is not None:
                 r1["frames_per_s"] = round(ks / m1["elapsed"], 1)
@@ -499,10 +567,16 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
                                                  note="k_tile_rmw: the same tiles of the last timed frame read and written back unchanged, no arithmetic, same "
                                                       "launch geometry -- what scattered 4 KiB read-modify-write reaches on this HBM")
                 if pmc_on:
-                    t = pmc_traffic(args, cfg_name, min(roof_K, ks), roof_W, True)
+                    t = pmc_traffic(args, cfg_name, min(roof_K, ks), roof_W, True, True)
                     if t is not None:
                         r1["traffic"] = t["bytes"]
                         r1["traffic_detail"] = t
+                if rgbd:
+                    m1c = run(roof_W, min(ks, 400), True, single_frame=True, colour=True)
+                    if m1c["launches"]:
+                        r1["rgbd_one_frame_per_launch"] = {"frames_per_s": round(min(ks, 400) / m1c["elapsed"], 1), "avg_kernel_us": round(m1c["kernel_ms"] * 1e3 / m1c["launches"], 2),
+                                                           "kernel": "k_integrate<1,true,true,2,true>",
+                                                           "hbm_frac_alg": round(m1c["alg_bytes"] / (m1c["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                 # the entry point a live stream calls: one pageable host frame per call (sf_fuser_integrate), through the page-locked ring
                 nh = min(ks, 400)
                 host = frames[roof_W:roof_W + nh].cpu().numpy().view(np.uint16)
@@ -515,7 +589,7 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
                     fh.sync()
                     dt = time.perf_counter() - t0
                 r1["live_stream_host_buffers"] = {"frames_per_s": round(nh / dt, 1), "frames": nh,
-                                                  "what": "sf_fuser_integrate per frame from pageable host memory (copy into a page-locked ring slot, H2D, "
+                                                  "what": "sf_fuser_integrate per depth frame from pageable host memory (copy into a page-locked ring slot, H2D, "
                                                           "pre-pass, allocation, compaction, integrate queued; no stream drained per frame), PCIe included"}
                 out["roofline_single_frame"] = r1
         if extras and ooc_n:
@@ -524,47 +598,53 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
             c1 = CONFIGS["1mm"]
             p1 = fusion.default_params(voxel_size=c1["voxel_size"], hash_num_buckets=c1["hash_num_buckets"], num_sdf_blocks=c1["num_sdf_blocks"])
             try:
-                mo = run(16, 64, True, single_frame=True, prm=p1)
-                ro = roofline_hbm(mo, 64, "k_integrate_pipe<true,2,nt>: one frame per launch at 1 mm voxels, non-temporal tile traffic")
+                mo = run(16, 64, True, single_frame=True, prm=p1, colour=False)
+                ro = roofline_hbm(mo, 64, "k_integrate_pipe<true,2,nt>: one depth frame per launch at 1 mm voxels, non-temporal tile traffic")
                 if ro is not None:
                     ro["frames_per_s"] = round(64 / mo["elapsed"], 1)
                     ro["sample"] = "frames 16..79 of the same stream at 1 mm voxels (BASELINE configs[2] geometry); `python bench.py --config 1mm` is the long form"
                     if mo["ceiling"]:
                         ro["pattern_ceiling"] = dict(mo["ceiling"], frac_of_ceiling=round(ro["achieved"] / mo["ceiling"]["rmw_copy_GBs"], 4))
-                    ma = run(16, 64, True, single_frame=True, prm=p1, extra_tune={"pipe_overlap": 0})
+                    ma = run(16, 64, True, single_frame=True, prm=p1, extra_tune={"pipe_overlap": 0}, colour=False)
                     if ma["launches"]:
                         ach = ma["alg_bytes"] / (ma["kernel_ms"] * 1e-3) / 1e9
                         ro["kernel_alone"] = {"tune": "pipe_overlap=0 (the next frame's pre-pass / allocation / compaction serialised behind the kernel)",
                                               "avg_kernel_us": round(ma["kernel_ms"] * 1e3 / ma["launches"], 2), "achieved": round(ach, 1),
                                               "frac": round(ach / HBM_PEAK_GBS, 4), "frames_per_s": round(64 / ma["elapsed"], 1),
                                               "frac_of_ceiling": round(ach / mo["ceiling"]["rmw_copy_GBs"], 4) if mo["ceiling"] else None}
-                    # the 16-frame schedule on the same frames, for the frames/s of configs[2]
-                    mb = run(16, 64, True, prm=p1)
+                    # the 32-frame schedule on the same frames, for the frames/s of configs[2]
+                    mb = run(16, 64, True, prm=p1, colour=False)
                     ro["batched_frames_per_s"] = round(64 / mb["elapsed"], 1)
                     out["roofline_out_of_cache"] = ro
+                    # the numbers themselves inside `roofline` (the driver's record keeps that object, of the extra ones only the key names)
+                    if roof is not None:
+                        roof["hbm_out_of_cache"] = {"frac": ro["frac"], "achieved_GBs": ro["achieved"], "frac_of_rmw_ceiling": (ro.get("pattern_ceiling") or {}).get("frac_of_ceiling"),
+                                                    "kernel_alone_frac": (ro.get("kernel_alone") or {}).get("frac"), "footprint_vs_infinity_cache": ro["footprint_vs_infinity_cache"],
+                                                    "what": "k_integrate_pipe, one depth frame per launch at 1 mm voxels (BASELINE configs[2] geometry): SURVEY 8d algorithmic bytes / launch "
+                                                            "duration / 8 TB/s in the shipped schedule; details under roofline_out_of_cache"}
             except _abi.ScanfuseError as e:   # a smaller GPU than the 288 GB part cannot reserve the tiles
                 out["roofline_out_of_cache"] = {"error": str(e)}
-        if extras and not args.no_colour and cfg_name == "4mm":
-            # the colour variant of the same pass (a colour frame per depth frame, resident in HBM): k_integrate<1, true, ...>
-            kc = min(roof_K, 2000)
-            mc = run(roof_W, kc, True, colour=True)
-            if mc["launches"]:
-                t_s = mc["kernel_ms"] * 1e-3 / mc["launches"]
-                rc = {"bound": "valu", "frames_per_s": round(kc / mc["elapsed"], 1), "ms_per_frame": round(mc["elapsed"] * 1e3 / kc, 5),
-                      "kernel": "k_integrate<1,true,true,2>", "alg_equiv_GBs": round(mc["alg_bytes"] / mc["launches"] / t_s / 1e9, 1),
-                      "sample": "frames %d..%d" % (roof_W, roof_W + kc - 1),
-                      "note": "32 frames per launch with a colour gather and blend per voxel on top of the geometry update; VALU-issue bound like the geometry kernel "
-                              "(frac: see roofline.frac; no separate counter pass is run for it)"}
-                rc.update(per_launch(mc, kc))
-                out["roofline_colour"] = rc
         if e2e_n:
             out["end_to_end"] = end_to_end(frames, poses, e2e_n, params, local_rank, torch)
+            if rgbd and not args.no_e2e_rgbd:
+                out["end_to_end_rgbd"] = end_to_end(frames, poses, max(64, e2e_n // 2), params, local_rank, torch, colour="jpeg1296")
         if cpu_n:   # rank 0 at N = 1 only
             host = frames[:cpu_n].cpu().numpy().view(np.uint16)
-            base, ovol, n_cpu = cpu_baseline(host, poses[:cpu_n].reshape(-1, 4, 4), cfg["voxel_size"], frames=cpu_n)
+            rgb_dev = colour_tensor(max(cpu_n, 1)) if rgbd else None
+            rgb_host = rgb_dev[:cpu_n].cpu().numpy() if rgbd else None
+            base, ovol, n_cpu = cpu_baseline(host, poses[:cpu_n].reshape(-1, 4, 4), cfg["voxel_size"], frames=cpu_n, rgb_host=rgb_host)
             out["cpu_baseline"] = base
-            out["parity"] = parity_leg(ovol, n_cpu, frames, stride, poses, params, local_rank)
+            out["parity"] = parity_leg(ovol, n_cpu, frames, stride, poses, params, local_rank, rgb_dev=rgb_dev)
             ovol.close()
+            if rgbd:
+                out["parity_colour"] = out["parity"]
+                # and the geometry-only path of the same build against the oracle's geometry-only volume (all threads, not timed)
+                from oracle import oracle as orc
+                vol = orc.Volume(orc.default_params(W, H, cfg["voxel_size"]), threads=_abi.usable_cpus())
+                for i in range(n_cpu):
+                    vol.integrate(host[i], poses[i].reshape(4, 4))
+                out["parity_depth_only"] = parity_leg(vol, n_cpu, frames, stride, poses, params, local_rank)
+                vol.close()
     return out
 
 
@@ -751,9 +831,14 @@ def run_partition(args, rank, local_rank, world, dist, torch):
     else:
         mx = sm = mn = vals
     fuser.close()
+    prefix = None
+    if world > 1 and not args.no_prefix_check:
+        prefix = partition_prefix_check(args, frames, stride, poses, params, rank, local_rank, world, dist)
     if rank != 0:
         return None
     t_fuse = float(mx[0])
+    if world > 1 and args.exchange == "neighbour" and int(sm[4]) != int(sm[5]):
+        raise SystemExit("bench.py: %d boundary blocks sent but %d ghost blocks received: the ring shift lost or duplicated layers" % (int(sm[4]), int(sm[5])))
     return {
         "metric": "RGB-D frames/sec integrated (640x480, 4 mm voxel), one scan partitioned over the GPUs",
         "value": round(K / t_fuse, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(t_fuse * 1e3 / K, 5),
@@ -770,8 +855,53 @@ def run_partition(args, rank, local_rank, world, dist, torch):
                      "mode": args.exchange, "payload_bytes_received_per_rank_max": int(mx[8]), "payload_bytes_received_total": int(sm[8]),
                      "all_gather_would_receive_per_rank": int(sm[4]) * 4108},
         "marching_cubes": {"seconds": round(float(mx[2]), 4), "faces_total": int(sm[6])},
+        "rccl_ranks": world if (world > 1 and dist.get_backend() == "nccl") else (0 if world > 1 else 1),
+        "process_group": (dist.get_backend() if world > 1 else "none (one process)"),
+        "per_rank_blocks": None if world == 1 else {"max": int(mx[3]), "min": int(mn[3])},
+        "prefix_check": prefix,
         "roofline": None,
     }
+
+
+def partition_prefix_check(args, frames, stride, poses, params, rank, local_rank, world, dist, n=96):
+    """The N-rank path against ONE fuser on a bounded prefix: every rank fuses the first n frames with its stripes, the boundary layers travel, every
+    rank meshes its own blocks, rank 0 merges the meshes by key -- and fuses the same n frames alone, without a partition.  The two canonical
+    meshes (vertices in edge-key order, triangles in cube-key order) must be byte-identical."""
+    import hashlib
+    from scannet_amd import fusion, partition
+    n = min(n, len(poses))
+    with fusion.Fuser(params, device=local_rank, **TUNE) as f:
+        if args.partition == "stripes":
+            f.set_stripes(0, 0, args.stripe_blocks, world, rank)
+        else:
+            from scannet_amd import synth
+            planes = partition.slab_planes(0, int(np.ceil(synth.CORRIDOR_ROOMS * synth.CORRIDOR_PITCH / (8 * params.voxel_size))), world)
+            f.set_slab(0, planes[rank], planes[rank + 1])
+        f.integrate_batch_device(frames.data_ptr(), stride, poses[:n])
+        f.sync()
+        sent, got = partition.exchange_boundary(f, mode=args.exchange)
+        m = f.extract_mesh()
+        xyz, rgba, tris, keys = m.arrays(keys=True)
+        part = (xyz, rgba, tris, keys, m.face_keys())
+    parts = [None] * world
+    dist.all_gather_object(parts, part)
+    counts = [None] * world
+    dist.all_gather_object(counts, (int(sent), int(got)))
+    if rank != 0:
+        return None
+
+    def sha(xyz, rgba, tris):
+        return hashlib.sha256(np.ascontiguousarray(xyz).tobytes() + np.ascontiguousarray(rgba).tobytes() + np.ascontiguousarray(tris).tobytes()).hexdigest()
+
+    mx_, mr_, mt_, _ = partition.merge_slab_meshes(parts)
+    with fusion.Fuser(params, device=local_rank, **TUNE) as f:
+        f.integrate_batch_device(frames.data_ptr(), stride, poses[:n])
+        ox, orgba, ot, _ = f.extract_mesh().arrays(keys=True)
+    h_n, h_1 = sha(mx_, mr_, mt_), sha(ox, orgba, ot)
+    return {"frames": n, "faces": int(len(ot)), "merged_mesh_sha256": h_n[:16], "one_fuser_mesh_sha256": h_1[:16], "sha256_equal": h_n == h_1,
+            "boundary_blocks_sent": sum(c[0] for c in counts), "ghost_blocks_received": sum(c[1] for c in counts),
+            "what": "first %d frames: %d ranks with their stripes -> boundary exchange (%s) -> marching cubes per rank -> merge by key, against one fuser "
+                    "without a partition on rank 0: canonical vertex / colour / triangle arrays hashed" % (n, world, args.exchange)}
 
 
 def main():
@@ -786,7 +916,11 @@ def main():
     ap.add_argument("--pmc-steps", type=int, default=None)
     ap.add_argument("--single-frame", action="store_true", help="one frame per launch (batch = 1) for the main measurement")
     ap.add_argument("--no-single-frame", action="store_true", help="skip the secondary one-frame-per-launch roofline pass")
-    ap.add_argument("--no-colour", action="store_true", help="skip the secondary colour-fusion pass")
+    ap.add_argument("--depth-only", action="store_true", help="time the geometry-only path (no colour frames): the headline of rounds 1-3")
+    ap.add_argument("--no-depth-only", action="store_true", help="skip the secondary geometry-only pass (value_depth_only, roofline_depth_only)")
+    ap.add_argument("--no-colour", action="store_true", help="accepted for old command lines; the colour path is the default measurement now (see --depth-only)")
+    ap.add_argument("--no-e2e-rgbd", action="store_true", help="skip the end-to-end leg with 1296x968 JPEG colour")
+    ap.add_argument("--no-prefix-check", action="store_true", help="--config partition: skip the merged-mesh check of a bounded prefix against one fuser")
     ap.add_argument("--teardown", action="store_true", help="leave through the interpreter's normal teardown (set for the runs under rocprofv3)")
     ap.add_argument("--child", action="store_true", help="a counter pass of another bench.py: the K timed steps once, nothing else")
     ap.add_argument("--repeats", type=int, default=0, help="how often the timed steps are repeated on an emptied volume (default: until ~1 s of timed GPU time)")
@@ -796,9 +930,10 @@ def main():
     ap.add_argument("--e2e-frames", type=int, default=1024)
     ap.add_argument("--cpu-frames", type=int, default=200, help="frames of the CPU-baseline / parity leg")
     ap.add_argument("--no-out-of-cache", action="store_true", help="skip the bounded 1 mm (configs[2]) sub-measurement")
-    ap.add_argument("--host-stage", choices=["full", "gpu-decimate", "gpu", "clean", "none"], default="full",
-                    help="--config scans: what follows marching cubes -- full: clean + sequential quadric collapse x 2 + segment on host threads; gpu-decimate: the "
-                         "same chain with the collapse on the GPU (sf_mesh_simplify_gpu); clean: clean + segment; none: nothing")
+    ap.add_argument("--host-stage", choices=["full", "gpu-decimate", "gpu", "clean", "none"], default="gpu",
+                    help="--config scans: what follows marching cubes -- gpu (default): clean.mlx, quadric collapse x 2 and cleanLoRes on the GPU + segment on host "
+                         "threads; full: clean + SEQUENTIAL quadric collapse x 2 + segment on host threads (GPU idle 86 %%); gpu-decimate: the host chain with only "
+                         "the collapse on the GPU (sf_mesh_simplify_gpu); clean: clean + segment; none: nothing")
     ap.add_argument("--first-scan", type=int, default=0)
     ap.add_argument("--max-scan-frames", type=int, default=0)
     ap.add_argument("--scan-frames", type=int, default=50000, help="--config partition: length of the long scan")
@@ -814,15 +949,37 @@ def main():
         args.pmc_steps = 400 if args.config == "4mm" else 64
     TUNE.update({kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.tune})
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-
     import torch
     import torch.distributed as dist
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # a bare `python bench.py --gpus N`: become the launcher -- one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1
+        # (--gpus was parsed and never read; a bare invocation measured ONE GPU and said so only in n_gpus)
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus and not args.share_gpu:
+            raise SystemExit("bench.py --gpus %d: this node shows %d GPU(s); refusing to measure fewer ranks than asked for "
+                             "(--share-gpu runs N ranks on GPU 0 over gloo to exercise the control flow)" % (args.gpus, ndev))
+        import socket
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): refusing to report a rate for a different number of GPUs"
+                         % (args.gpus, world))
+    if not args.share_gpu and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: %d ranks on a node with %d GPU(s) (--share-gpu puts them all on GPU 0 over gloo)" % (world, torch.cuda.device_count()))
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -831,6 +988,8 @@ def main():
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: process group of %d ranks for --gpus %d" % (dist.get_world_size(), args.gpus))
 
     if args.config in CONFIGS:
         out = run_stream(args, args.config, rank, local_rank, world, dist, torch)

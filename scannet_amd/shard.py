@@ -142,14 +142,17 @@ def main(argv=None):
     import torch
     import torch.distributed as dist
     argv = sys.argv[1:] if argv is None else argv
-    # python -m scannet_amd.shard scans.txt [--gpu-decimate] [--host-clean]
-    #   the cleaning filters run on the rank's GPU (sf_mesh_clean_gpu: output identical to the host filters) unless --host-clean;
-    #   --gpu-decimate also runs the quadric collapse there (sf_mesh_simplify_gpu: different triangles, same guarantees)
+    # python -m scannet_amd.shard scans.txt [--host-decimate] [--host-clean]
+    #   everything behind marching cubes runs on the rank's GPU by default: the cleaning filters (sf_mesh_clean_gpu: output identical to the host
+    #   filters) and the quadric collapse (sf_mesh_simplify_gpu: rounds of independent collapses -- different triangles from the sequential filter,
+    #   the same guarantees and tests; neither is pinned to MeshLab).  The sequential collapse is 19 of a scan's 22 s of host time and left the GPU
+    #   idle 86 % of a rebuild (21.8 against 100 scans/min per GPU, profiles/r03_bench_scans_*.json): --host-decimate / --host-clean select the
+    #   host filters.  (--gpu-decimate: the default since round 4, accepted for old command lines.)
     flags = {a for a in argv if a.startswith("--")}
     argv = [a for a in argv if not a.startswith("--")]
-    unknown = flags - {"--gpu-decimate", "--host-clean"}
+    unknown = flags - {"--gpu-decimate", "--host-clean", "--host-decimate"}
     if unknown or len(argv) != 1:
-        raise SystemExit("usage: python -m scannet_amd.shard scans.txt [--gpu-decimate] [--host-clean]" + ("  (unknown: %s)" % " ".join(sorted(unknown)) if unknown else ""))
+        raise SystemExit("usage: python -m scannet_amd.shard scans.txt [--host-decimate] [--host-clean]" + ("  (unknown: %s)" % " ".join(sorted(unknown)) if unknown else ""))
     scans = [ln.strip() for ln in open(argv[0]) if ln.strip()]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -163,7 +166,7 @@ def main(argv=None):
     def host(path, x):
         mesh, info = x
         info.update(finish_scan(mesh, path, gpu_clean=None if "--host-clean" in flags else local_rank,
-                                gpu_decimate=local_rank if "--gpu-decimate" in flags else None))
+                                gpu_decimate=None if "--host-decimate" in flags else local_rank))
         return info
     res = run_pipelined(scans, costs, lambda s: fuse_scan(s, device=local_rank), host, workers)
     for i, r in res:

@@ -28,7 +28,7 @@ def test_bench_help_names_the_configs():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert r.returncode == 0
     for word in ("--config", "4mm", "1mm", "scans", "partition", "--gpus", "--steps", "--warmup", "--host-stage", "--repeats", "--scene", "--noise",
-                 "--exchange", "--share-gpu", "--no-e2e", "--cpu-frames"):
+                 "--exchange", "--share-gpu", "--no-e2e", "--cpu-frames", "--depth-only", "--no-e2e-rgbd", "--no-prefix-check"):
         assert word in r.stdout, word
 
 

@@ -512,25 +512,42 @@ def test_real_fusers_in_separate_processes_exchange_and_merge(tmp_path, world, m
 
 
 def test_bench_with_two_ranks_sharing_one_gpu():
-    """bench.py's N > 1 control flow (one process per rank, barriers, max over ranks, the roofline window on every rank, the partition's ring
-    shift) on a one-GPU box: `--share-gpu` puts both ranks on GPU 0 over gloo.  A pass that only rank 0 enters hangs the job -- that regression
-    is what this guards; the rates mean nothing."""
-    import socket
+    """A BARE `python bench.py --gpus 2 ...` (no launcher in the command: bench.py re-executes itself under torch.distributed.run) runs two ranks:
+    one process per rank, barriers, max over ranks, the roofline window on every rank, the partition's ring shift and the merged-mesh check --
+    on a one-GPU box `--share-gpu` puts both ranks on GPU 0 over gloo.  A pass that only rank 0 enters hangs the job; a --gpus that is parsed and
+    never read measures one GPU (round 3).  The rates mean nothing here."""
     import sys
-    common = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1"]
-    for extra in (["--steps", "20", "--warmup", "5", "--repeats", "3"], ["--config", "partition", "--scan-frames", "600"]):
-        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-        r = subprocess.run(common + ["--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu"] + extra,
-                           capture_output=True, text=True, cwd=ROOT, timeout=400)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    for extra in (["--steps", "64", "--warmup", "5", "--repeats", "3", "--no-pmc"], ["--config", "partition", "--scan-frames", "600"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu"] + extra,
+                           capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
         assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         assert len(lines) == 1, r.stdout[-1500:]          # rank 0 prints ONE line
         j = json.loads(lines[0])
-        assert j["n_gpus"] == 2 and j["value"] > 0 and j["unit"] == "frames/s"
+        assert j["n_gpus"] == 2 and j["value"] > 0 and j["unit"] == "frames/s" and j["process_group"] == "gloo"
         if "partition" in extra:
             assert j["exchange"]["mode"] == "neighbour" and j["exchange"]["boundary_blocks_sent_total"] == j["exchange"]["ghost_blocks_received_total"] > 0
+            pc = j["prefix_check"]
+            assert pc["sha256_equal"] and pc["faces"] > 10000 and pc["boundary_blocks_sent"] == pc["ghost_blocks_received"] > 0
         else:
             assert j["repeats"]["n"] == 3 and j["roofline"]["launches"] > 0
+            assert len(j["per_rank_frames_per_s"]) == 2 and min(j["per_rank_frames_per_s"]) > 0
+            assert j["config"]["rgbd"] is True and j["value_rgbd"] == j["value"]
+
+
+def test_bench_refuses_more_ranks_than_gpus_and_a_mismatched_launcher():
+    """`--gpus N` on a node with fewer GPUs refuses (unless --share-gpu); a launcher that started a different number of ranks than --gpus names is
+    refused too -- no line with the wrong n_gpus can come out."""
+    import sys
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "4", "--warmup", "1"], capture_output=True, text=True, cwd=ROOT, timeout=300, env=env)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout) and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"], capture_output=True, text=True, cwd=ROOT, timeout=300,
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout) and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
 def test_match_upstream_tool_finds_the_switches_a_mesh_was_fused_with(tmp_path):
