@@ -944,7 +944,7 @@ def _texture_frames(n, H, W, seed):
     base = np.stack([xx * 255 // W, yy * 255 // H, xx + yy], -1).astype(np.uint8)   # uint8 arithmetic below wraps modulo 256
     out = np.zeros((n, H, W, 3), np.uint8)
     for i in range(n):
-        out[i] = base + np.array([5 * i, 3 * i, 7 * i], np.uint8) + rng.integers(0, 32, (H, W, 3), dtype=np.uint8)
+        out[i] = base + (np.array([5 * i, 3 * i, 7 * i]) % 256).astype(np.uint8) + rng.integers(0, 32, (H, W, 3), dtype=np.uint8)
         out[i, : H // 8] = 0
         out[i, H // 2 : H // 2 + H // 16, : W // 3] = 255
     return out
