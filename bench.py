@@ -627,7 +627,7 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
         if e2e_n:
             out["end_to_end"] = end_to_end(frames, poses, e2e_n, params, local_rank, torch)
             if rgbd and not args.no_e2e_rgbd:
-                out["end_to_end_rgbd"] = end_to_end(frames, poses, max(64, e2e_n // 2), params, local_rank, torch, colour="jpeg1296")
+                out["end_to_end_rgbd"] = end_to_end(frames, poses, e2e_n, params, local_rank, torch, colour="jpeg1296")
         if cpu_n:   # rank 0 at N = 1 only
             host = frames[:cpu_n].cpu().numpy().view(np.uint16)
             rgb_dev = colour_tensor(max(cpu_n, 1)) if rgbd else None

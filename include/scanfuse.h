@@ -95,6 +95,13 @@ void sf_params_default(sf_params* p);
  * present override *p (call sf_params_default first).  Replaces GlobalAppState::readMembers upstream;
  * in-tree format examples: Alignment/src/globalAppState.h:8-41. */
 int sf_params_load_file(const char* path, sf_params* p);
+/* The five upstream-conformance switches at once: which = 1 "VoxelHashing" (DepthSensing.exe, the binary the `improve` stage runs,
+ * Server/scan_processor.py:34-35,138): frustum_mode = colour_round = colour_first = weight_mode = weight_wrap = 1; which = 2 "BundleFusion"
+ * (FriedLiver.exe, the `recons` stage, :27-29,126): the same with weight_mode = 0 (that code base computes the depth-dependent weight and then
+ * forces it to 1); which = 0: SURVEY App. C (all 0, the default).  The upstream behaviour is AS REMEMBERED -- neither code base is in the
+ * reference tree -- which is why it is a preset a maintainer can confirm with one mesh (INTEGRATION.md "Conformance packet"),
+ * not the default.  Also a parameter-file key: s_scanfuseUpstream = 0 | 1 | 2 (applied before the five individual keys, which override it). */
+int sf_params_upstream_preset(sf_params* p, int which);
 
 /* ------------------------------------------------------------------------------------------------
  * Voxel-hash TSDF fuser.  Replaces the scene-representation calls of the external DepthSensing.exe /

@@ -43,6 +43,11 @@ int sf_fuser_alloc_direct_count(sf_fuser* f, uint64_t* out);
 int sf_zlib_inflate_pair(const void* src_a, uint64_t n_a, void* dst_a, uint64_t cap_a, uint64_t* len_a, int* rc_a,
                          const void* src_b, uint64_t n_b, void* dst_b, uint64_t cap_b, uint64_t* len_b, int* rc_b);
 
+/* Phases of the most recent sf_fuser_extract_mesh, milliseconds: [0] whole call, [1] live-block list, [2] count pass (k_mc), [3] scan + emit pass,
+ * [4] vertex sort (radix sort of the 3T edge keys), [5] heads + scan + weld, [6] triangle sort + gather, [7] downloads (device side), [8] host: output
+ * arrays allocated + downloads awaited; then [9] live blocks, [10] triangles, [11] welded vertices.  n <= 12 values are written. */
+int sf_fuser_mc_timing(const sf_fuser* f, double* out, int n);
+
 /* Kernel timing with HIP events on the fuser's stream: when enabled, every integrate launch is bracketed
  * by an event pair; sf_fuser_profile_read sums and clears them (synchronises). */
 int sf_fuser_profile_enable(sf_fuser* f, int on);

@@ -175,6 +175,31 @@ def ref_sens_available():
     return os.path.exists(os.path.join(_HERE, "_ref", "libref_sens.so"))
 
 
+def ref_unproject_available():
+    return os.path.exists(os.path.join(_HERE, "_ref", "libref_unproject.so"))
+
+
+def ref_unproject(K, depth_m):
+    """The reference's own unprojection (filter.cu:74-91 on the float4x4 of cuda_SimpleMatrixUtil.h, compiled from /root/reference into
+    oracle/_ref/libref_unproject.so): K 4x4 intrinsics, depth_m [H, W] float32 metres (-inf invalid) -> camera-space points [H, W, 3]."""
+    L = C.CDLL(os.path.join(_HERE, "_ref", "libref_unproject.so"))
+    L.ref_unproject.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p]
+    K = np.ascontiguousarray(K, np.float32).reshape(16)
+    d = np.ascontiguousarray(depth_m, np.float32)
+    out = np.zeros(d.shape + (3,), np.float32)
+    L.ref_unproject(_ptr(K), d.shape[1], d.shape[0], _ptr(d), _ptr(out))
+    return out
+
+
+def ref_intrinsics_inverse(K):
+    L = C.CDLL(os.path.join(_HERE, "_ref", "libref_unproject.so"))
+    L.ref_intrinsics_inverse.argtypes = [C.c_void_p, C.c_void_p]
+    K = np.ascontiguousarray(K, np.float32).reshape(16)
+    out = np.zeros(16, np.float32)
+    L.ref_intrinsics_inverse(_ptr(K), _ptr(out))
+    return out.reshape(4, 4)
+
+
 def ref_segmentator_path(o0=False):
     p = os.path.join(_HERE, "_ref", "segmentator_ref_O0" if o0 else "segmentator_ref")
     return p if os.path.exists(p) else None

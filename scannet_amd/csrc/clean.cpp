@@ -86,7 +86,7 @@ uint32_t uf_find(std::vector<uint32_t>& p, uint32_t x) {
 }
 
 // filter 1: returns for every vertex the index of the vertex it is merged into (itself for survivors)
-int merge_close(const std::vector<float>& pos, float radius, std::vector<uint32_t>& target) {
+int merge_close(const sf::mesh_vec<float>& pos, float radius, std::vector<uint32_t>& target) {
   const bool timing = std::getenv("SF_CLEAN_TIMING") != nullptr;
   auto t_last = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {

@@ -2030,6 +2030,7 @@ SF_API void sf_fuser_destroy(sf_fuser* f) {
     if (f->ev_consumed[q]) (void)hipEventDestroy(f->ev_consumed[q]);
   }
   if (f->host_mirror) (void)hipHostFree(f->host_mirror);
+  for (int q = 0; q < 2; q++) { if (f->mc_bounce[q]) (void)hipHostFree(f->mc_bounce[q]); if (f->mc_bounce_ev[q]) (void)hipEventDestroy(f->mc_bounce_ev[q]); }
   if (f->stream) (void)hipStreamDestroy(f->stream);
   delete f;
 }

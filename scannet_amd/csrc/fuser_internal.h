@@ -245,6 +245,9 @@ struct sf_fuser {
   int compact_grid = 1024;  // 1024 directory entries per workgroup, grid-stride beyond
   uint64_t frames_integrated = 0, frames_skipped = 0;
   bool profile = false;
+  void* mc_bounce[2] = {nullptr, nullptr};            // page-locked bounce buffers of the mesh download (mc.hip), allocated on first use
+  hipEvent_t mc_bounce_ev[2] = {nullptr, nullptr};
+  double mc_timing[12] = {0};   // phases of the most recent sf_fuser_extract_mesh (mc.hip; sf_fuser_mc_timing)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   size_t events_used = 0;
 };

@@ -16,9 +16,13 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstring>
+#include <algorithm>
 #include <memory>
+#include <thread>
+#include <vector>
 
 #include <rocprim/rocprim.hpp>
 
@@ -211,17 +215,95 @@ McTables host_tables() {
     if (e_ != hipSuccess) return sf::fail(SF_ERR_DEVICE, "%s failed: %s (mc.hip:%d)", #call, hipGetErrorString(e_), __LINE__); \
   } while (0)
 
+
+// Device -> host for the mesh arrays (a scan-sized mesh is ~250 MB going into freshly allocated, never touched memory): the runtime's own path for
+// pageable destinations stages through a small pinned buffer on ONE thread -- copy and first-touch page faults serialised, ~6 GB/s.  Here: two
+// 16 MiB page-locked bounce buffers owned by the fuser; chunk i + 1 travels over the link while a small team of threads copies chunk i out,
+// each thread faulting its own pages.
+struct DlSeg { void* dst; const void* src; size_t bytes; };
+constexpr size_t DL_CHUNK = 16u << 20;
+
+void team_copy(uint8_t* dst, const uint8_t* src, size_t n) {
+  const int nt = n < (2u << 20) ? 1 : std::max(1, std::min(4, sf::usable_cpus()));
+  if (nt == 1) { std::memcpy(dst, src, n); return; }
+  std::vector<std::thread> team;
+  const size_t per = ((n / (size_t)nt) + 4095) & ~(size_t)4095;
+  for (int t = 1; t < nt; t++) {
+    const size_t a = std::min(n, per * (size_t)t), b = std::min(n, per * (size_t)(t + 1));
+    if (b > a) team.emplace_back([=] { std::memcpy(dst + a, src + a, b - a); });
+  }
+  std::memcpy(dst, src, std::min(n, per));
+  for (std::thread& t : team) t.join();
+}
+
+int download_segments(sf_fuser* f, hipStream_t s, const DlSeg* segs, int nseg) {
+  for (int q = 0; q < 2; q++) {
+    if (!f->mc_bounce[q]) MC_CHECK(hipHostMalloc(&f->mc_bounce[q], DL_CHUNK, hipHostMallocDefault));
+    if (!f->mc_bounce_ev[q]) MC_CHECK(hipEventCreateWithFlags(&f->mc_bounce_ev[q], hipEventDisableTiming));
+  }
+  struct Pending { uint8_t* dst; size_t n; bool live; } pend[2] = {{nullptr, 0, false}, {nullptr, 0, false}};
+  int slot = 0;
+  auto drain = [&](int q) -> int {
+    if (!pend[q].live) return SF_OK;
+    MC_CHECK(hipEventSynchronize(f->mc_bounce_ev[q]));
+    team_copy(pend[q].dst, (const uint8_t*)f->mc_bounce[q], pend[q].n);
+    pend[q].live = false;
+    return SF_OK;
+  };
+  for (int i = 0; i < nseg; i++) {
+    for (size_t off = 0; off < segs[i].bytes; off += DL_CHUNK) {
+      const size_t n = std::min(DL_CHUNK, segs[i].bytes - off);
+      int rc = drain(slot);   // the bounce buffer is free once its previous chunk has been copied out
+      if (rc != SF_OK) return rc;
+      MC_CHECK(hipMemcpyAsync(f->mc_bounce[slot], (const uint8_t*)segs[i].src + off, n, hipMemcpyDeviceToHost, s));
+      MC_CHECK(hipEventRecord(f->mc_bounce_ev[slot], s));
+      pend[slot] = {(uint8_t*)segs[i].dst + off, n, true};
+      slot ^= 1;
+      rc = drain(slot);       // while that one travels, copy the other out
+      if (rc != SF_OK) return rc;
+    }
+  }
+  int rc = drain(0);
+  if (rc != SF_OK) return rc;
+  return drain(1);
+}
+
 }  // namespace
+
+// phase clock of the most recent extraction (scanfuse_internal.h sf_fuser_mc_timing): host wall clock between the points where the host
+// waits for the stream anyway, HIP events for the phases in between
+namespace {
+struct McClock {
+  hipEvent_t ev[8] = {nullptr};
+  int n = 0;
+  hipStream_t s;
+  explicit McClock(hipStream_t st) : s(st) {}
+  ~McClock() { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); }
+  void mark() { if (n < 8 && hipEventCreate(&ev[n]) == hipSuccess) { (void)hipEventRecord(ev[n], s); n++; } }
+  double ms(int a, int b) const { float t = 0; return (a < n && b < n && hipEventElapsedTime(&t, ev[a], ev[b]) == hipSuccess) ? (double)t : -1.0; }
+};
+double wall_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+
+SF_API int sf_fuser_mc_timing(const sf_fuser* f, double* out, int n) {
+  if (!f || !out || n < 0) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  for (int i = 0; i < n; i++) out[i] = i < 12 ? f->mc_timing[i] : 0.0;
+  return SF_OK;
+}
 
 SF_API int sf_fuser_extract_mesh(sf_fuser* f, sf_mesh** out) {
   if (!f || !out) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
   MC_CHECK(hipSetDevice(f->device));
+  const double t_begin = wall_ms();
+  for (double& v : f->mc_timing) v = 0.0;
   int32_t n_live = 0;
   int rc = sf_compact_live(f, &n_live, 0);  // ghost copies of a neighbour slab's blocks are read as neighbours, never meshed
   if (rc != SF_OK) return rc;
   std::unique_ptr<sf_mesh> m(new sf_mesh());
   if (n_live == 0) { *out = m.release(); return SF_OK; }
   hipStream_t s = f->stream;
+  McClock clk(s);
+  const double t_compact = wall_ms();
   const float thresh = f->p.mc_thresh_factor * f->p.voxel_size;
   const McTables ht = host_tables();
   DevBuf d_tab, d_cnt, d_off, d_tmp;
@@ -231,8 +313,10 @@ SF_API int sf_fuser_extract_mesh(sf_fuser* f, sf_mesh** out) {
   MC_CHECK(d_off.alloc((size_t)(n_live + 1) * 4));
   MC_CHECK(hipMemsetAsync(d_cnt.p, 0, (size_t)(n_live + 1) * 4, s));
   const int grid = n_live < f->num_cus * 8 ? n_live : f->num_cus * 8;
+  clk.mark();   // 0
   hipLaunchKernelGGL(k_mc, dim3(grid), dim3(512), 0, s, f->voxels, f->table, f->block_keys, f->compact, n_live, d_tab.as<McTables>(), f->pk,
                      thresh, 0, d_cnt.as<uint32_t>(), (const uint32_t*)nullptr, (uint64_t*)nullptr, (uint64_t*)nullptr, (float*)nullptr, (uint32_t*)nullptr);
+  clk.mark();   // 1: count pass done
   size_t tmp_bytes = 0;
   MC_CHECK(rocprim::exclusive_scan(nullptr, tmp_bytes, d_cnt.as<uint32_t>(), d_off.as<uint32_t>(), 0u, (size_t)(n_live + 1), rocprim::plus<uint32_t>(), s));
   MC_CHECK(d_tmp.alloc(tmp_bytes));
@@ -243,6 +327,7 @@ SF_API int sf_fuser_extract_mesh(sf_fuser* f, sf_mesh** out) {
   if (T == 0) { *out = m.release(); return SF_OK; }
   if ((uint64_t)T * 3 > 0xFFFFFFF0ull) { return sf::fail(SF_ERR_CAPACITY, "mesh too large: %u triangles", T); }
   const uint32_t NV = 3 * T;
+  const double t_counted = wall_ms();
   DevBuf d_tkey, d_vkey, d_vpos, d_vcol;
   MC_CHECK(d_tkey.alloc((size_t)T * 8));
   MC_CHECK(d_vkey.alloc((size_t)NV * 8));
@@ -251,6 +336,7 @@ SF_API int sf_fuser_extract_mesh(sf_fuser* f, sf_mesh** out) {
   hipLaunchKernelGGL(k_mc, dim3(grid), dim3(512), 0, s, f->voxels, f->table, f->block_keys, f->compact, n_live, d_tab.as<McTables>(), f->pk,
                      thresh, 1, d_cnt.as<uint32_t>(), d_off.as<uint32_t>(), d_tkey.as<uint64_t>(), d_vkey.as<uint64_t>(), d_vpos.as<float>(),
                      d_vcol.as<uint32_t>());
+  clk.mark();   // 2: emit pass queued behind this
   // ---- weld: sort edge keys, flag heads, scan, scatter
   DevBuf d_vkey_s, d_src, d_src_s, d_flag, d_excl, d_tmp2;
   MC_CHECK(d_vkey_s.alloc((size_t)NV * 8));
@@ -261,6 +347,7 @@ SF_API int sf_fuser_extract_mesh(sf_fuser* f, sf_mesh** out) {
   MC_CHECK(rocprim::radix_sort_pairs(nullptr, sort_bytes, d_vkey.as<uint64_t>(), d_vkey_s.as<uint64_t>(), d_src.as<uint32_t>(), d_src_s.as<uint32_t>(), (size_t)NV, 0, 64, s));
   MC_CHECK(d_tmp2.alloc(sort_bytes));
   MC_CHECK(rocprim::radix_sort_pairs(d_tmp2.p, sort_bytes, d_vkey.as<uint64_t>(), d_vkey_s.as<uint64_t>(), d_src.as<uint32_t>(), d_src_s.as<uint32_t>(), (size_t)NV, 0, 64, s));
+  clk.mark();   // 3: vertex sort
   MC_CHECK(d_flag.alloc((size_t)(NV + 1) * 4));
   MC_CHECK(d_excl.alloc((size_t)(NV + 1) * 4));
   MC_CHECK(hipMemsetAsync(d_flag.p, 0, (size_t)(NV + 1) * 4, s));
@@ -281,6 +368,7 @@ SF_API int sf_fuser_extract_mesh(sf_fuser* f, sf_mesh** out) {
   hipLaunchKernelGGL(k_weld, dim3((NV + 255) / 256), dim3(256), 0, s, d_vkey_s.as<uint64_t>(), d_src_s.as<uint32_t>(), d_flag.as<uint32_t>(),
                      d_excl.as<uint32_t>(), NV, d_vpos.as<float>(), d_vcol.as<uint32_t>(), d_vid.as<uint32_t>(), d_opos.as<float>(),
                      d_ocol.as<uint32_t>(), d_okey.as<uint64_t>());
+  clk.mark();   // 4: heads, scan, weld
   // ---- canonical triangle order: sort by (cube key, table order)
   DevBuf d_tkey_s, d_tsrc, d_tsrc_s, d_tmp4, d_oidx;
   MC_CHECK(d_tkey_s.alloc((size_t)T * 8));
@@ -293,19 +381,30 @@ SF_API int sf_fuser_extract_mesh(sf_fuser* f, sf_mesh** out) {
   MC_CHECK(rocprim::radix_sort_pairs(d_tmp4.p, tsort_bytes, d_tkey.as<uint64_t>(), d_tkey_s.as<uint64_t>(), d_tsrc.as<uint32_t>(), d_tsrc_s.as<uint32_t>(), (size_t)T, 0, 64, s));
   MC_CHECK(d_oidx.alloc((size_t)T * 12));
   hipLaunchKernelGGL(k_gather_tris, dim3((T + 255) / 256), dim3(256), 0, s, d_tsrc_s.as<uint32_t>(), d_vid.as<uint32_t>(), T, d_oidx.as<uint32_t>());
+  clk.mark();   // 5: triangle sort + gather
   // ---- download
+  const double t_queued = wall_ms();
   m->pos.resize((size_t)NU * 3);
   m->col.resize((size_t)NU * 4);
   m->keys.resize(NU);
   m->tri.resize((size_t)T * 3);
   m->tkeys.resize(T);
-  MC_CHECK(hipMemcpyAsync(m->tkeys.data(), d_tkey_s.p, (size_t)T * 8, hipMemcpyDeviceToHost, s));
-  MC_CHECK(hipMemcpyAsync(m->pos.data(), d_opos.p, (size_t)NU * 12, hipMemcpyDeviceToHost, s));
-  MC_CHECK(hipMemcpyAsync(m->col.data(), d_ocol.p, (size_t)NU * 4, hipMemcpyDeviceToHost, s));
-  MC_CHECK(hipMemcpyAsync(m->keys.data(), d_okey.p, (size_t)NU * 8, hipMemcpyDeviceToHost, s));
-  MC_CHECK(hipMemcpyAsync(m->tri.data(), d_oidx.p, (size_t)T * 12, hipMemcpyDeviceToHost, s));
+  {
+    const DlSeg segs[5] = {{m->tkeys.data(), d_tkey_s.p, (size_t)T * 8}, {m->pos.data(), d_opos.p, (size_t)NU * 12}, {m->col.data(), d_ocol.p, (size_t)NU * 4},
+                           {m->keys.data(), d_okey.p, (size_t)NU * 8}, {m->tri.data(), d_oidx.p, (size_t)T * 12}};
+    rc = download_segments(f, s, segs, 5);
+    if (rc != SF_OK) return rc;
+  }
+  clk.mark();   // 6: downloads
   MC_CHECK(hipStreamSynchronize(s));
   MC_CHECK(hipGetLastError());
+  const double t_end = wall_ms();
+  // [0] whole call  [1] live-block list  [2] count pass  [3] emit pass  [4] vertex sort  [5] heads + scan + weld  [6] triangle sort + gather
+  // [7] downloads (device time)  [8] host: output arrays allocated and zero-filled + waiting for the downloads  [9] live blocks  [10] triangles  [11] vertices
+  double* tm = f->mc_timing;
+  tm[0] = t_end - t_begin; tm[1] = t_compact - t_begin; tm[2] = clk.ms(0, 1); tm[3] = clk.ms(1, 2); tm[4] = clk.ms(2, 3); tm[5] = clk.ms(3, 4);
+  tm[6] = clk.ms(4, 5); tm[7] = clk.ms(5, 6); tm[8] = t_end - t_queued; tm[9] = (double)n_live; tm[10] = (double)T; tm[11] = (double)NU;
+  (void)t_counted;
   *out = m.release();
   return SF_OK;
 }

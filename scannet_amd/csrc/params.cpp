@@ -28,6 +28,15 @@ std::string& last_error_ref() {
 }  // namespace sf
 
 SF_API const char* sf_last_error(void) { return sf::last_error_ref().c_str(); }
+SF_API int sf_params_upstream_preset(sf_params* p, int which) {
+  if (!p) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  if (which < 0 || which > 2) return sf::fail(SF_ERR_INVALID_ARG, "upstream preset %d (0 = SURVEY App. C, 1 = VoxelHashing / DepthSensing.exe, 2 = BundleFusion / FriedLiver.exe)", which);
+  const int on = which != 0;
+  p->frustum_mode = p->colour_round = p->colour_first = p->weight_wrap = on;
+  p->weight_mode = which == 1;
+  return SF_OK;
+}
+
 SF_API const char* sf_version(void) { return "scanfuse 0.1 (gfx950)"; }
 
 SF_API void sf_params_default(sf_params* p) {
@@ -153,6 +162,8 @@ SF_API int sf_params_load_file(const char* path, sf_params* p) {
   v = p->integration_width;  if ((rc = geti("s_integrationWidth", &v)) != SF_OK) return rc; p->integration_width = (int32_t)v;
   v = p->integration_height; if ((rc = geti("s_integrationHeight", &v)) != SF_OK) return rc; p->integration_height = (int32_t)v;
   // upstream-conformance switches (scanfuse.h): not keys of the upstream tools, which ignore names they do not know
+  v = -1; if ((rc = geti("s_scanfuseUpstream", &v)) != SF_OK) return rc;
+  if (v >= 0 && (rc = sf_params_upstream_preset(p, (int)v)) != SF_OK) return rc;
   v = p->frustum_mode; if ((rc = geti("s_scanfuseFrustumMode", &v)) != SF_OK) return rc; p->frustum_mode = (int32_t)v;
   v = p->colour_round; if ((rc = geti("s_scanfuseColourRound", &v)) != SF_OK) return rc; p->colour_round = (int32_t)v;
   v = p->colour_first; if ((rc = geti("s_scanfuseColourFirst", &v)) != SF_OK) return rc; p->colour_first = (int32_t)v;

@@ -168,13 +168,13 @@ int read_ply(const char* path, sf_mesh* m) {
     if (is_vertex && ix >= 0 && iy >= 0 && iz >= 0) {
       for (int q : {ix, iy, iz})
         if (TYPE_SIZE[el.props[q].type] != 4) return sf::fail(SF_ERR_FORMAT, "%s: destination vector is wrongly typed to hold this property (x/y/z must be 4-byte floats)", path);
-      m->pos.resize(el.size * 3);
+      m->pos.assign(el.size * 3, 0.0f);   // (mesh arrays do not zero-fill on resize: mesh.h)
       const bool has_col = ir >= 0 && ig >= 0 && ib >= 0 && TYPE_SIZE[el.props[ir].type] == 1 && TYPE_SIZE[el.props[ig].type] == 1 && TYPE_SIZE[el.props[ib].type] == 1;
       if (has_col) m->col.assign(el.size * 4, 255);
     }
     if (is_face && il >= 0 && TYPE_SIZE[el.props[il].type] != 4)
       return sf::fail(SF_ERR_FORMAT, "%s: destination vector is wrongly typed to hold this property (face indices must be 4-byte integers)", path);
-    if (is_face && il >= 0) m->tri.resize(el.size * 3);
+    if (is_face && il >= 0) m->tri.assign(el.size * 3, 0u);
     const bool want_v = is_vertex && !m->pos.empty();
     const bool want_f = is_face && il >= 0;
     const bool has_col = want_v && !m->col.empty();

@@ -18,6 +18,7 @@
 #include <fstream>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <unordered_set>
 #include <vector>
 
@@ -27,107 +28,150 @@ int mesh_read_any(const char* path, sf_mesh* m, bool* obj_multi);  // ply.cpp
 
 namespace {
 
-struct GraphEdge {
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Layout.  The graph has one edge per face corner; edge 3f + c of face (i, j, k) joins  c = 0: i-j,  c = 1: i-k,  c = 2: k-j  (the order
+// segmentator.cpp:199-204 pushes them in).  Nothing but the weight has to travel through the sort: a key is {weight, edge number} = 8 bytes
+// and the end points are read back from the face array -- std::sort's permutation is a function of the comparison results alone (the
+// comparator looks at the weight only, :67-69), so sorting 8-byte keys gives the permutation the reference gets for its 12-byte records, ties
+// and NaNs included, with a third less memory moved.  Vertex normals are three separate float arrays (the face loop touches them at random:
+// one cache line per component and vertex instead of a 12-byte struct straddling lines).
+// What is sequential by definition stays sequential: the running mean of the face normals (its value depends on the order of a vertex's
+// faces) and the sweep.  What is independent per element runs on all the cores the process may use: the edge weights and the label look-up.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+struct WeightKey {
   float w;
-  int a, b;
+  uint32_t edge;
 };
-inline bool operator<(const GraphEdge& l, const GraphEdge& r) { return l.w < r.w; }
+inline bool operator<(const WeightKey& l, const WeightKey& r) { return l.w < r.w; }
 
-struct Node {
-  int rank, parent, size;
-};
+inline void edge_ends(const uint32_t* tri, uint32_t e, uint32_t& u, uint32_t& v) {
+  const uint32_t* t = tri + 3 * (size_t)(e / 3u);
+  const uint32_t c = e % 3u;
+  u = c == 2u ? t[2] : t[0];
+  v = c == 1u ? t[2] : t[1];
+}
 
-struct Forest {
-  std::vector<Node> n;
-  explicit Forest(int count) : n((size_t)count) {
-    for (int i = 0; i < count; i++) n[i] = Node{0, i, 1};
+// disjoint sets over the vertices: union by rank exactly as segmentator.cpp:43-54 (x under y on a tie, y's rank grows) -- which root survives
+// a join decides the label that comes out -- but the look-up is free to shorten paths as it likes (the reference re-points only the node it
+// started from, :36-42): a root is a root.  Path halving here.
+struct VertexSets {
+  std::vector<uint32_t> up, members;
+  std::vector<uint8_t> rank;   // <= log2(vertices)
+  explicit VertexSets(size_t n) : up(n), members(n, 1u), rank(n, 0) {
+    for (size_t i = 0; i < n; i++) up[i] = (uint32_t)i;
   }
-  int find(int x) {
-    int r = x;
-    while (r != n[r].parent) r = n[r].parent;
-    n[x].parent = r;  // only the start node is re-pointed (segmentator.cpp:36-42)
-    return r;
+  uint32_t root(uint32_t x) {
+    while (up[x] != x) {
+      up[x] = up[up[x]];
+      x = up[x];
+    }
+    return x;
   }
-  void join(int x, int y) {
-    if (n[x].rank > n[y].rank) {
-      n[y].parent = x;
-      n[x].size += n[y].size;
+  uint32_t root_readonly(uint32_t x) const {
+    while (up[x] != x) x = up[x];
+    return x;
+  }
+  void unite(uint32_t x, uint32_t y) {   // both roots
+    if (rank[x] > rank[y]) {
+      up[y] = x;
+      members[x] += members[y];
     } else {
-      n[x].parent = y;
-      n[y].size += n[x].size;
-      if (n[x].rank == n[y].rank) n[y].rank++;
+      up[x] = y;
+      members[y] += members[x];
+      if (rank[x] == rank[y]) rank[y]++;
     }
   }
 };
 
-struct V3 {
-  float x, y, z;
-};
-inline V3 sub(const V3& a, const V3& b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
-inline V3 unit_cross(const V3& u, const V3& v) {
-  V3 c{u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x};
-  const float len = sqrtf(c.x * c.x + c.y * c.y + c.z * c.z);
-  c.x /= len; c.y /= len; c.z /= len;
-  return c;
-}
-inline V3 blend(const V3& a, const V3& b, float t) {
-  const float s = 1.0f - t;
-  return V3{t * b.x + s * a.x, t * b.y + s * a.y, t * b.z + s * a.z};
+// fn(begin, end) over [0, n) on up to 8 of the CPUs this process may use
+template <class Fn>
+void in_parallel(size_t n, size_t grain, Fn fn) {
+  const size_t want = std::min<size_t>((size_t)std::max(1, std::min(8, sf::usable_cpus())), (n + grain - 1) / std::max<size_t>(grain, 1));
+  if (want <= 1) { fn((size_t)0, n); return; }
+  const size_t per = (n + want - 1) / want;
+  std::vector<std::thread> team;
+  for (size_t t = 1; t < want; t++) {
+    const size_t lo = std::min(n, per * t), hi = std::min(n, per * (t + 1));
+    if (hi > lo) team.emplace_back([=] { fn(lo, hi); });
+  }
+  fn((size_t)0, std::min(n, per));
+  for (std::thread& th : team) th.join();
 }
 
 void segment_core(const float* xyz, size_t nv, const uint32_t* tri, size_t nf, float kthr, int min_verts, int32_t* out) {
-  std::vector<V3> points(nv, V3{0, 0, 0}), normals(nv, V3{0, 0, 0});
-  std::vector<int> counts(nv, 0);
-  const size_t ne = nf * 3;
-  std::vector<GraphEdge> edges(ne);
+  // ---- vertex normals: running mean of the unit face normals in face order (:185-208).  Per face: the unit normal (cross product divided
+  // by its length: a zero-area face gives NaN, :107-112), then for each corner n <- t * fn + (1 - t) * n with t = 1 / (faces seen so far + 1)
+  // (:113-116; the counts move only after all three corners, :205-207 -- a face that names a vertex twice blends it twice with the same t).
+  std::vector<float> nx(nv, 0.0f), ny(nv, 0.0f), nz(nv, 0.0f);
+  std::vector<uint32_t> seen(nv, 0u);
   for (size_t f = 0; f < nf; f++) {
-    const uint32_t i1 = tri[3 * f], i2 = tri[3 * f + 1], i3 = tri[3 * f + 2];
-    const V3 p1{xyz[3 * (size_t)i1], xyz[3 * (size_t)i1 + 1], xyz[3 * (size_t)i1 + 2]};
-    const V3 p2{xyz[3 * (size_t)i2], xyz[3 * (size_t)i2 + 1], xyz[3 * (size_t)i2 + 2]};
-    const V3 p3{xyz[3 * (size_t)i3], xyz[3 * (size_t)i3 + 1], xyz[3 * (size_t)i3 + 2]};
-    points[i1] = p1; points[i2] = p2; points[i3] = p3;
-    edges[3 * f].a = (int)i1;     edges[3 * f].b = (int)i2;
-    edges[3 * f + 1].a = (int)i1; edges[3 * f + 1].b = (int)i3;
-    edges[3 * f + 2].a = (int)i3; edges[3 * f + 2].b = (int)i2;
-    const V3 fn = unit_cross(sub(p2, p1), sub(p3, p1));
-    normals[i1] = blend(normals[i1], fn, 1.0f / (counts[i1] + 1.0f));
-    normals[i2] = blend(normals[i2], fn, 1.0f / (counts[i2] + 1.0f));
-    normals[i3] = blend(normals[i3], fn, 1.0f / (counts[i3] + 1.0f));
-    counts[i1]++; counts[i2]++; counts[i3]++;
+    const uint32_t* t = tri + 3 * f;
+    const float* A = xyz + 3 * (size_t)t[0];
+    const float* B = xyz + 3 * (size_t)t[1];
+    const float* Cc = xyz + 3 * (size_t)t[2];
+    const float ux = B[0] - A[0], uy = B[1] - A[1], uz = B[2] - A[2];
+    const float vx = Cc[0] - A[0], vy = Cc[1] - A[1], vz = Cc[2] - A[2];
+    float fx = uy * vz - uz * vy, fy = uz * vx - ux * vz, fz = ux * vy - uy * vx;
+    const float flen = sqrtf(fx * fx + fy * fy + fz * fz);
+    fx /= flen; fy /= flen; fz /= flen;
+    for (int c = 0; c < 3; c++) {
+      const uint32_t v = t[c];
+      const float wnew = 1.0f / ((float)seen[v] + 1.0f), wold = 1.0f - wnew;
+      nx[v] = wnew * fx + wold * nx[v];
+      ny[v] = wnew * fy + wold * ny[v];
+      nz[v] = wnew * fz + wold * nz[v];
+    }
+    seen[t[0]]++; seen[t[1]]++; seen[t[2]]++;
   }
-  for (size_t e = 0; e < ne; e++) {
-    const V3& n1 = normals[edges[e].a];
-    const V3& n2 = normals[edges[e].b];
-    const V3& p1 = points[edges[e].a];
-    const V3& p2 = points[edges[e].b];
-    float dx = p2.x - p1.x, dy = p2.y - p1.y, dz = p2.z - p1.z;
-    const float dd = sqrtf(dx * dx + dy * dy + dz * dz);
-    dx /= dd; dy /= dd; dz /= dd;
-    const float dot = n1.x * n2.x + n1.y * n2.y + n1.z * n2.z;
-    const float dot2 = n2.x * dx + n2.y * dy + n2.z * dz;
-    float ww = 1.0f - dot;
-    if (dot2 > 0) ww = ww * ww;
-    edges[e].w = ww;
-  }
-  std::sort(edges.begin(), edges.end());
-  Forest u((int)nv);
+  // ---- edge weights (:211-229): 1 - n_u . n_v, squared where the edge is convex (n_v leans along u -> v).  Independent per edge.
+  const size_t ne = nf * 3;
+  std::vector<WeightKey> keys(ne);
+  in_parallel(ne, 1 << 16, [&](size_t lo, size_t hi) {
+    for (size_t e = lo; e < hi; e++) {
+      uint32_t u, v;
+      edge_ends(tri, (uint32_t)e, u, v);
+      const float* P = xyz + 3 * (size_t)u;
+      const float* Q = xyz + 3 * (size_t)v;
+      float ex = Q[0] - P[0], ey = Q[1] - P[1], ez = Q[2] - P[2];
+      const float elen = sqrtf(ex * ex + ey * ey + ez * ez);
+      ex /= elen; ey /= elen; ez /= elen;
+      const float across = nx[u] * nx[v] + ny[u] * ny[v] + nz[u] * nz[v];
+      const float along = nx[v] * ex + ny[v] * ey + nz[v] * ez;
+      float w = 1.0f - across;
+      if (along > 0) w = w * w;
+      keys[e] = WeightKey{w, (uint32_t)e};
+    }
+  });
+  // ---- the reference's sort call on the reference's comparator (:74); see "Layout" for why the keys may be smaller than its records
+  std::sort(keys.begin(), keys.end());
+  // ---- sweep (:76-90): join two components when the edge is no heavier than either component's threshold; the survivor's threshold becomes
+  // the edge weight + k / its size
+  VertexSets sets(nv);
   {
-    std::vector<float> thr(nv, kthr);
-    for (size_t e = 0; e < ne; e++) {
-      int a = u.find(edges[e].a);
-      const int b = u.find(edges[e].b);
-      if (a != b && edges[e].w <= thr[a] && edges[e].w <= thr[b]) {
-        u.join(a, b);
-        a = u.find(a);
-        thr[a] = edges[e].w + (kthr / u.n[a].size);
+    std::vector<float> limit(nv, kthr);
+    for (size_t q = 0; q < ne; q++) {
+      uint32_t u, v;
+      edge_ends(tri, keys[q].edge, u, v);
+      const uint32_t ru = sets.root(u), rv = sets.root(v);
+      const float w = keys[q].w;
+      if (ru != rv && w <= limit[ru] && w <= limit[rv]) {
+        sets.unite(ru, rv);
+        const uint32_t r = sets.up[ru] == ru ? ru : rv;   // whichever of the two is still a root
+        limit[r] = w + (kthr / (float)sets.members[r]);
       }
     }
   }
-  for (size_t e = 0; e < ne; e++) {
-    const int a = u.find(edges[e].a), b = u.find(edges[e].b);
-    if (a != b && (u.n[a].size < min_verts || u.n[b].size < min_verts)) u.join(a, b);
+  // ---- components smaller than segMinVerts are joined across any edge, in sorted-edge order (:237-243)
+  for (size_t q = 0; q < ne; q++) {
+    uint32_t u, v;
+    edge_ends(tri, keys[q].edge, u, v);
+    const uint32_t ru = sets.root(u), rv = sets.root(v);
+    if (ru != rv && ((int)sets.members[ru] < min_verts || (int)sets.members[rv] < min_verts)) sets.unite(ru, rv);
   }
-  for (size_t q = 0; q < nv; q++) out[q] = u.find((int)q);
+  // ---- label of a vertex = its root (:246-250)
+  in_parallel(nv, 1 << 16, [&](size_t lo, size_t hi) {
+    for (size_t q = lo; q < hi; q++) out[q] = (int32_t)sets.root_readonly((uint32_t)q);
+  });
 }
 
 }  // namespace

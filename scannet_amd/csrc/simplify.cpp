@@ -264,8 +264,8 @@ struct Simplifier {
   }
 
   int init(const sf_mesh* in) {
-    pos = in->pos;
-    tri = in->tri;
+    pos.assign(in->pos.begin(), in->pos.end());
+    tri.assign(in->tri.begin(), in->tri.end());
     const size_t n_v = nv(), n_f = tri.size() / 3;
     for (uint32_t v : tri)
       if (v >= n_v) return sf::fail(SF_ERR_FORMAT, "face references vertex %u of %zu", v, n_v);

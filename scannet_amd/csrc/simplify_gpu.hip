@@ -325,8 +325,8 @@ SF_API int sf_mesh_simplify_gpu(const sf_mesh* in, const sf_simplify_params* p, 
   std::memset(&st, 0, sizeof(st));
   st.vertices_in = V;
   st.faces_in = F;
-  std::vector<float> pos = in->pos;
-  std::vector<uint32_t> tri = in->tri;
+  std::vector<float> pos(in->pos.begin(), in->pos.end());
+  std::vector<uint32_t> tri(in->tri.begin(), in->tri.end());
   std::vector<uint8_t> alive_h(F, 1), vdel_h(V, 0);
   uint64_t nalive = 0;
   for (uint32_t v : tri)

@@ -17,15 +17,29 @@ static int die(const char* what) {
   return 1;
 }
 
-int main(int argc, const char** argv) {
+int main(int argc, const char** argv_in) {
+  // --upstream[=voxelhashing|bundlefusion]: the upstream-conformance preset (scanfuse.h sf_params_upstream_preset; default: SURVEY App. C).  Not an
+  // argument of the tool this replaces -- the pipeline's command line (scan_processor.py:138) stays valid -- and it may stand anywhere.
+  const char* argv[8];
+  int upstream = 0, n = 0;
+  for (int i = 0; i < argc; i++) {
+    if (!std::strcmp(argv_in[i], "--upstream") || !std::strcmp(argv_in[i], "--upstream=voxelhashing")) upstream = 1;
+    else if (!std::strcmp(argv_in[i], "--upstream=bundlefusion")) upstream = 2;
+    else if (n < 8) argv[n++] = argv_in[i];
+  }
+  argc = n;
   if (argc < 4) {
-    std::printf("Usage: depthsensing <zParameters.txt> <zParametersTracking.txt> <scan.sens> [out.ply]\n");
+    std::printf("Usage: depthsensing [--upstream[=voxelhashing|bundlefusion]] <zParameters.txt> <zParametersTracking.txt> <scan.sens> [out.ply]\n");
     return 255;
   }
   const char* sens_path = argv[3];
   sf_params p;
   sf_params_default(&p);
-  if (sf_params_load_file(argv[1], &p) != SF_OK) return die("parameter file");
+  if (upstream && sf_params_upstream_preset(&p, upstream) != SF_OK) return die("preset");
+  if (sf_params_load_file(argv[1], &p) != SF_OK) return die("parameter file");   // s_scanfuse* keys of the file override the preset
+  if (p.frustum_mode | p.colour_round | p.colour_first | p.weight_mode | p.weight_wrap)
+    std::printf("Upstream-conformance switches: frustum_mode %d, colour_round %d, colour_first %d, weight_mode %d, weight_wrap %d\n", p.frustum_mode, p.colour_round,
+                p.colour_first, p.weight_mode, p.weight_wrap);
   // the second parameter file holds tracking settings only; it must exist (the reference tool reads it) but nothing in it concerns fusion
   if (FILE* fp = std::fopen(argv[2], "r")) std::fclose(fp);
   else { std::fprintf(stderr, "could not open parameter file %s\n", argv[2]); return 1; }

@@ -240,6 +240,17 @@ class Fuser:
         check(L.sf_fuser_import_ghosts(self._h, _ptr(coords), _ptr(voxels), cnt, 1 if on_dev else 0, C.byref(got)))
         return got.value
 
+    def mc_timing(self):
+        """Phases of the most recent extract_mesh() in ms (scanfuse_internal.h sf_fuser_mc_timing) + block / triangle / vertex counts."""
+        L = _abi.lib()
+        L.sf_fuser_mc_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
+        t = (C.c_double * 12)()
+        check(L.sf_fuser_mc_timing(self._h, t, 12))
+        names = ("total", "live_list", "count_pass", "scan_emit_pass", "vertex_sort", "heads_scan_weld", "triangle_sort_gather", "downloads_device", "host_alloc_and_wait")
+        out = {k: round(t[i], 3) for i, k in enumerate(names)}
+        out.update(blocks=int(t[9]), triangles=int(t[10]), vertices=int(t[11]))
+        return out
+
     def extract_mesh(self):
         """Marching cubes over all live blocks -> segmentator.Mesh (vertices in edge-key order, deterministic)."""
         from .segmentator import Mesh

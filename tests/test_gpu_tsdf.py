@@ -1022,3 +1022,22 @@ def test_bench_walk_corner_stays_on_the_allocation_fast_path():
                 assert f.stats()["alloc_failures"] == 0
     finally:
         L.sf_device_free(dptr)
+
+
+def test_conformance_packet_digests():
+    """conformance/digests.json (tools/conformance_packet.py: the oracle's volume and mesh digests on the packet's 300-frame scan under all 32
+    combinations of the upstream-conformance switches): the HIP path reproduces every entry through the C ABI -- after the 40-frame walk and after
+    the dwell that takes the 8-bit weights through 255 (saturation or wrap)."""
+    import importlib.util
+    import json
+    import os
+    from scannet_amd import fusion
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("conformance_packet", os.path.join(root, "tools", "conformance_packet.py"))
+    cp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cp)
+    want = json.load(open(os.path.join(root, "conformance", "digests.json")))["combinations"]
+    fr = cp.frames("full")
+    for sw in cp.combos():
+        got = cp.run_gpu(fusion, fr, sw)
+        assert got == want[cp.name_of(sw)], cp.name_of(sw)

@@ -5,10 +5,14 @@ unpinned"), so the oracle is pinned by analytic known answers on the reference's
 depth/depthShift (sensorData.h:968-977), K^-1 unprojection without y flip (sensorData.h:1568-1579),
 -inf poses skipped (sensorData.h:382) and the zParametersScanNet.txt:34-35,47-53 constants.
 """
+import os
+
 import numpy as np
 import pytest
 
 from scannet_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def f32(x):
@@ -484,3 +488,59 @@ def test_colour_rule_against_the_literal_evaluation(oracle, colour_round, colour
     got = np.stack([vox["r"][pick], vox["g"][pick], vox["b"][pick]], -1).astype(np.int64)
     assert np.array_equal(got[ok], col[ok])
     assert (w[ok] >= 3).sum() > 10000          # several blends per voxel, so the rounding direction matters
+
+
+def test_reference_unprojection_form_against_the_ray_slope_form(oracle):
+    """SURVEY 8a row a6 pinned to IN-TREE code: the reference unprojects a depth pixel as K^-1 . (x d, y d, d) (filter.cu:74-91 on the float4x4
+    class of cuda_SimpleMatrixUtil.h -- compiled from /root/reference into oracle/_ref/libref_unproject.so); the fusion kernels and
+    oracle/tsdf_oracle.c use the ray-slope form ((x - mx) / fx) d, ((y - my) / fy) d, d (one division per column / row, tabulated).  Same
+    convention (pixel centres at integers, no y flip, z = the depth itself), and over EVERY pixel of a 640x480 image and the sensor's depth range
+    the two differ by rounding only: bounded here far inside the 1e-4 m of the north star."""
+    if not oracle.ref_unproject_available():
+        pytest.skip("oracle/_ref/libref_unproject.so not built (needs /root/reference)")
+    W, H = 640, 480
+    fx, fy, mx, my = (np.float32(v) for v in synth.intrinsics(W, H))
+    K = np.array([[fx, 0, mx, 0], [0, fy, my, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32)
+    inv = oracle.ref_intrinsics_inverse(K)
+    assert inv[2].tolist() == [0, 0, 1, 0] and inv[3].tolist() == [0, 0, 0, 1] and inv[0, 1] == 0 and inv[1, 0] == 0
+    assert abs(float(inv[0, 0]) * float(fx) - 1) < 1e-6 and abs(float(inv[0, 2]) + float(mx) / float(fx)) < 1e-6
+    xs, ys = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32))
+    kx, ky = (xs - mx) / fx, (ys - my) / fy          # csrc/fuser.hip k_ray_tables / k_alloc: true float32 divisions
+    worst, worst_rel = 0.0, 0.0
+    rng = np.random.default_rng(4)
+    depths = [0.1, 0.25, 0.5, 1.0, 1.5, 2.0, 3.0, 3.999, 4.0, 5.0, 6.0] + list(rng.uniform(0.1, 6.0, 9))
+    for dval in depths:
+        d = np.full((H, W), np.float32(dval), np.float32)
+        d[0, 0] = -np.inf
+        ref = oracle.ref_unproject(K, d)
+        ours = np.stack([kx * d, ky * d, d], -1).astype(np.float32)
+        assert np.all(np.isneginf(ref[0, 0])), "an invalid pixel stays invalid (filter.cu:83)"
+        assert np.array_equal(ref[..., 2][1:], d[1:]), "camera-space z is the depth itself"
+        diff = np.abs(ref[1:].astype(np.float64) - ours[1:].astype(np.float64))
+        worst = max(worst, float(diff.max()))
+        worst_rel = max(worst_rel, float((diff[..., :2] / np.float64(dval)).max()))
+    # conventions: +x to the right of the principal point, +y BELOW it (no flip), both forms
+    d = np.full((H, W), np.float32(2.0), np.float32)
+    ref = oracle.ref_unproject(K, d)
+    assert ref[300, 500, 0] > 0 and ref[300, 500, 1] > 0 and ref[100, 100, 0] < 0 and ref[100, 100, 1] < 0
+    assert worst < 2e-6 and worst_rel < 5e-7, (worst, worst_rel)   # metres; measured 7.2e-7 m, 1.9e-7 of the depth
+    print("a6: max |K^-1 form - ray-slope form| = %.3g m, %.3g of the depth" % (worst, worst_rel))
+
+
+def test_conformance_packet_is_reproducible(oracle):
+    """conformance/digests.json (tools/conformance_packet.py; INTEGRATION.md "Conformance packet"): the packet's input is closed-form, so its
+    first frames and the oracle's volume / mesh after the 40-frame walk come out again, here for the two presets (SURVEY App. C = 00000, the
+    VoxelHashing preset = 11111); all 32 combinations on all 300 frames are reproduced by the HIP path in tests/test_gpu_tsdf.py."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("conformance_packet", os.path.join(ROOT, "tools", "conformance_packet.py"))
+    cp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cp)
+    want = json.load(open(os.path.join(ROOT, "conformance", "digests.json")))
+    assert want["switch_order"] == list(cp.SWITCHES) and len(want["combinations"]) == 32
+    assert len({v["full"]["mesh_sha256"] for v in want["combinations"].values()}) == 32, "every switch must be observable on the packet's scan"
+    fr = cp.frames("walk")
+    for name in ("00000", "11111"):
+        sw = dict(zip(cp.SWITCHES, (int(c) for c in name)))
+        got = cp.run_oracle(oracle, fr, sw, threads=8)
+        assert got["walk"] == want["combinations"][name]["walk"], name

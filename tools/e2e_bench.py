@@ -103,6 +103,10 @@ def main():
         t0 = time.perf_counter()
         mesh = f.extract_mesh()
         res["marching_cubes_s"] = round(time.perf_counter() - t0, 3)
+        t0 = time.perf_counter()
+        mesh = f.extract_mesh()   # once more: the first call pays for the kernels' code objects and the pinned staging
+        res["marching_cubes_second_call_s"] = round(time.perf_counter() - t0, 3)
+        res["marching_cubes_phases_ms"] = f.mc_timing()
     nv, nf = mesh.counts()
     res["mesh"] = {"vertices": nv, "faces": nf}
     ply = os.path.join(a.dir, "scene_e2e_vh.ply")
