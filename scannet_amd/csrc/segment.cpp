@@ -31,12 +31,14 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------------------------------------
 // Layout.  The graph has one edge per face corner; edge 3f + c of face (i, j, k) joins  c = 0: i-j,  c = 1: i-k,  c = 2: k-j  (the order
 // segmentator.cpp:199-204 pushes them in).  Nothing but the weight has to travel through the sort: a key is {weight, edge number} = 8 bytes
-// and the end points are read back from the face array -- std::sort's permutation is a function of the comparison results alone (the
-// comparator looks at the weight only, :67-69), so sorting 8-byte keys gives the permutation the reference gets for its 12-byte records, ties
-// and NaNs included, with a third less memory moved.  Vertex normals are three separate float arrays (the face loop touches them at random:
-// one cache line per component and vertex instead of a 12-byte struct straddling lines).
+// -- std::sort's permutation is a function of the comparison results alone (the comparator looks at the weight only, :67-69), so sorting
+// 8-byte keys gives the permutation the reference gets for its 12-byte records, ties and NaNs included, with a third less memory moved -- and
+// the end points are gathered behind the sort, by all cores, into an array the two sweeps then read front to back.
+// Everything touched at random is packed so that one access is one cache line: a vertex's running normal and face count (16 bytes), a set's
+// size / threshold / rank (12 bytes, read at roots only); the parent links, which the root walk chases, are an array of their own.
 // What is sequential by definition stays sequential: the running mean of the face normals (its value depends on the order of a vertex's
-// faces) and the sweep.  What is independent per element runs on all the cores the process may use: the edge weights and the label look-up.
+// faces), the sort (ties must fall as libstdc++'s introsort lets them: which vertex ends up as a set's root -- its label -- depends on it)
+// and the sweeps.  What is independent per element runs on the cores the process may use: edge weights, end-point gather, label look-up.
 // ---------------------------------------------------------------------------------------------------------------------------------------
 struct WeightKey {
   float w;
@@ -44,20 +46,32 @@ struct WeightKey {
 };
 inline bool operator<(const WeightKey& l, const WeightKey& r) { return l.w < r.w; }
 
-inline void edge_ends(const uint32_t* tri, uint32_t e, uint32_t& u, uint32_t& v) {
+struct EdgeEnds {
+  uint32_t u, v;
+};
+inline EdgeEnds edge_ends(const uint32_t* tri, uint32_t e) {
   const uint32_t* t = tri + 3 * (size_t)(e / 3u);
   const uint32_t c = e % 3u;
-  u = c == 2u ? t[2] : t[0];
-  v = c == 1u ? t[2] : t[1];
+  return EdgeEnds{c == 2u ? t[2] : t[0], c == 1u ? t[2] : t[1]};
 }
+
+struct VertexNormal {
+  float x, y, z;
+  uint32_t faces;   // incident faces blended in so far
+};
 
 // disjoint sets over the vertices: union by rank exactly as segmentator.cpp:43-54 (x under y on a tie, y's rank grows) -- which root survives
 // a join decides the label that comes out -- but the look-up is free to shorten paths as it likes (the reference re-points only the node it
 // started from, :36-42): a root is a root.  Path halving here.
+struct SetInfo {
+  uint32_t members;
+  float limit;      // the sweep's merge threshold of the set (:82-88), kept beside the size it is computed from
+  uint32_t rank;
+};
 struct VertexSets {
-  std::vector<uint32_t> up, members;
-  std::vector<uint8_t> rank;   // <= log2(vertices)
-  explicit VertexSets(size_t n) : up(n), members(n, 1u), rank(n, 0) {
+  std::vector<uint32_t> up;
+  std::vector<SetInfo> info;   // valid at roots
+  VertexSets(size_t n, float limit0) : up(n), info(n, SetInfo{1u, limit0, 0u}) {
     for (size_t i = 0; i < n; i++) up[i] = (uint32_t)i;
   }
   uint32_t root(uint32_t x) {
@@ -71,15 +85,16 @@ struct VertexSets {
     while (up[x] != x) x = up[x];
     return x;
   }
-  void unite(uint32_t x, uint32_t y) {   // both roots
-    if (rank[x] > rank[y]) {
+  uint32_t unite(uint32_t x, uint32_t y) {   // both roots; returns the surviving root
+    if (info[x].rank > info[y].rank) {
       up[y] = x;
-      members[x] += members[y];
-    } else {
-      up[x] = y;
-      members[y] += members[x];
-      if (rank[x] == rank[y]) rank[y]++;
+      info[x].members += info[y].members;
+      return x;
     }
+    up[x] = y;
+    info[y].members += info[x].members;
+    if (info[x].rank == info[y].rank) info[y].rank++;
+    return y;
   }
 };
 
@@ -102,8 +117,7 @@ void segment_core(const float* xyz, size_t nv, const uint32_t* tri, size_t nf, f
   // ---- vertex normals: running mean of the unit face normals in face order (:185-208).  Per face: the unit normal (cross product divided
   // by its length: a zero-area face gives NaN, :107-112), then for each corner n <- t * fn + (1 - t) * n with t = 1 / (faces seen so far + 1)
   // (:113-116; the counts move only after all three corners, :205-207 -- a face that names a vertex twice blends it twice with the same t).
-  std::vector<float> nx(nv, 0.0f), ny(nv, 0.0f), nz(nv, 0.0f);
-  std::vector<uint32_t> seen(nv, 0u);
+  std::vector<VertexNormal> vn(nv, VertexNormal{0.0f, 0.0f, 0.0f, 0u});
   for (size_t f = 0; f < nf; f++) {
     const uint32_t* t = tri + 3 * f;
     const float* A = xyz + 3 * (size_t)t[0];
@@ -115,28 +129,28 @@ void segment_core(const float* xyz, size_t nv, const uint32_t* tri, size_t nf, f
     const float flen = sqrtf(fx * fx + fy * fy + fz * fz);
     fx /= flen; fy /= flen; fz /= flen;
     for (int c = 0; c < 3; c++) {
-      const uint32_t v = t[c];
-      const float wnew = 1.0f / ((float)seen[v] + 1.0f), wold = 1.0f - wnew;
-      nx[v] = wnew * fx + wold * nx[v];
-      ny[v] = wnew * fy + wold * ny[v];
-      nz[v] = wnew * fz + wold * nz[v];
+      VertexNormal& n = vn[t[c]];
+      const float wnew = 1.0f / ((float)n.faces + 1.0f), wold = 1.0f - wnew;
+      n.x = wnew * fx + wold * n.x;
+      n.y = wnew * fy + wold * n.y;
+      n.z = wnew * fz + wold * n.z;
     }
-    seen[t[0]]++; seen[t[1]]++; seen[t[2]]++;
+    vn[t[0]].faces++; vn[t[1]].faces++; vn[t[2]].faces++;
   }
   // ---- edge weights (:211-229): 1 - n_u . n_v, squared where the edge is convex (n_v leans along u -> v).  Independent per edge.
   const size_t ne = nf * 3;
   std::vector<WeightKey> keys(ne);
   in_parallel(ne, 1 << 16, [&](size_t lo, size_t hi) {
     for (size_t e = lo; e < hi; e++) {
-      uint32_t u, v;
-      edge_ends(tri, (uint32_t)e, u, v);
-      const float* P = xyz + 3 * (size_t)u;
-      const float* Q = xyz + 3 * (size_t)v;
+      const EdgeEnds ends = edge_ends(tri, (uint32_t)e);
+      const float* P = xyz + 3 * (size_t)ends.u;
+      const float* Q = xyz + 3 * (size_t)ends.v;
+      const VertexNormal &nu = vn[ends.u], &nw = vn[ends.v];
       float ex = Q[0] - P[0], ey = Q[1] - P[1], ez = Q[2] - P[2];
       const float elen = sqrtf(ex * ex + ey * ey + ez * ez);
       ex /= elen; ey /= elen; ez /= elen;
-      const float across = nx[u] * nx[v] + ny[u] * ny[v] + nz[u] * nz[v];
-      const float along = nx[v] * ex + ny[v] * ey + nz[v] * ez;
+      const float across = nu.x * nw.x + nu.y * nw.y + nu.z * nw.z;
+      const float along = nw.x * ex + nw.y * ey + nw.z * ez;
       float w = 1.0f - across;
       if (along > 0) w = w * w;
       keys[e] = WeightKey{w, (uint32_t)e};
@@ -144,29 +158,37 @@ void segment_core(const float* xyz, size_t nv, const uint32_t* tri, size_t nf, f
   });
   // ---- the reference's sort call on the reference's comparator (:74); see "Layout" for why the keys may be smaller than its records
   std::sort(keys.begin(), keys.end());
-  // ---- sweep (:76-90): join two components when the edge is no heavier than either component's threshold; the survivor's threshold becomes
-  // the edge weight + k / its size
-  VertexSets sets(nv);
-  {
-    std::vector<float> limit(nv, kthr);
-    for (size_t q = 0; q < ne; q++) {
-      uint32_t u, v;
-      edge_ends(tri, keys[q].edge, u, v);
-      const uint32_t ru = sets.root(u), rv = sets.root(v);
-      const float w = keys[q].w;
-      if (ru != rv && w <= limit[ru] && w <= limit[rv]) {
-        sets.unite(ru, rv);
-        const uint32_t r = sets.up[ru] == ru ? ru : rv;   // whichever of the two is still a root
-        limit[r] = w + (kthr / (float)sets.members[r]);
-      }
+  std::vector<EdgeEnds> sorted_ends(ne);
+  in_parallel(ne, 1 << 16, [&](size_t lo, size_t hi) {
+    for (size_t q = lo; q < hi; q++) sorted_ends[q] = edge_ends(tri, keys[q].edge);
+  });
+  // ---- sweep (:76-90): join two sets when the edge is no heavier than either set's threshold; the survivor's threshold becomes the edge
+  // weight + k / its size
+  VertexSets sets(nv, kthr);
+  for (size_t q = 0; q < ne; q++) {
+    const uint32_t ru = sets.root(sorted_ends[q].u), rv = sets.root(sorted_ends[q].v);
+    if (ru == rv) continue;
+    const float w = keys[q].w;
+    if (w <= sets.info[ru].limit && w <= sets.info[rv].limit) {
+      const uint32_t r = sets.unite(ru, rv);
+      sets.info[r].limit = w + (kthr / (float)sets.info[r].members);
     }
   }
-  // ---- components smaller than segMinVerts are joined across any edge, in sorted-edge order (:237-243)
+  // ---- sets smaller than segMinVerts are joined across any edge, in sorted-edge order (:237-243).  Every vertex is pointed at its root first
+  // (in parallel: the links only get shorter), so the look-ups of this pass are one read unless one of its own joins intervenes.
+  in_parallel(nv, 1 << 16, [&](size_t lo, size_t hi) {
+    for (size_t q = lo; q < hi; q++) {
+      // roots are never written here; a non-root's link only ever moves to a node further up its own root path, so a concurrent walker that
+      // reads either value arrives at the same root (relaxed atomic accesses: the links are shared between the threads of this loop)
+      uint32_t x = (uint32_t)q, p = __atomic_load_n(&sets.up[x], __ATOMIC_RELAXED);
+      if (p == x) continue;
+      for (uint32_t pp; (pp = __atomic_load_n(&sets.up[p], __ATOMIC_RELAXED)) != p; p = pp) {}
+      __atomic_store_n(&sets.up[q], p, __ATOMIC_RELAXED);
+    }
+  });
   for (size_t q = 0; q < ne; q++) {
-    uint32_t u, v;
-    edge_ends(tri, keys[q].edge, u, v);
-    const uint32_t ru = sets.root(u), rv = sets.root(v);
-    if (ru != rv && ((int)sets.members[ru] < min_verts || (int)sets.members[rv] < min_verts)) sets.unite(ru, rv);
+    const uint32_t ru = sets.root(sorted_ends[q].u), rv = sets.root(sorted_ends[q].v);
+    if (ru != rv && ((int)sets.info[ru].members < min_verts || (int)sets.info[rv].members < min_verts)) sets.unite(ru, rv);
   }
   // ---- label of a vertex = its root (:246-250)
   in_parallel(nv, 1 << 16, [&](size_t lo, size_t hi) {
