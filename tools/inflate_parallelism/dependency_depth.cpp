@@ -1,9 +1,13 @@
+// dependency_depth.cpp -- what bounds a parallel LZ77 resolution of a deflated depth frame: the depth of the match -> match dependency chains
+// (a match whose source bytes were written by another match has to wait for it), the mix of literals / matches / distances, and how quickly a
+// decoder started at an arbitrary bit falls in step with the true token boundaries (the fixed Huffman code is self-synchronising).
+// A STUDY (tools/inflate_parallelism/README.md), not product code.     dependency_depth <file.z>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
 #include <algorithm>
-#include "/root/repo/scannet_amd/csrc/inflate_lanes.h"
+#include "inflate_lanes.h"
 int main(int argc, char** argv) {
   FILE* f = fopen(argv[1], "rb"); fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
   std::vector<uint8_t> src(n); fread(src.data(), 1, n, f); fclose(f);

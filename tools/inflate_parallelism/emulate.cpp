@@ -1,11 +1,13 @@
-// inflate_emu.cpp -- the chunk-parallel inflate of inflate_lanes.h run on the HOST, lane by lane in lock step.  Test infrastructure for the algorithm
-// (scanfuse_internal.h: sf_inflate_lanes_emulate): the CPU suite runs it against zlib and the reference's stb inflater on the streams the writers
-// produce, on corrupted streams and on the adversarial cases (long runs, far matches, tiny frames); the device kernel (inflate_gpu.hip) executes the
-// same lane programs, so what is left to the GPU tests is the memory model.  The product path never calls this.
+// emulate.cpp -- the chunk-parallel inflate of inflate_lanes.h run on the HOST, lane by lane in lock step: how many stage-A rounds the chunk starts
+// need to settle, and how many turns stage C takes when 1 024 lanes write their chunks concurrently and a match has to wait for its source bytes.
+// A STUDY (tools/inflate_parallelism/README.md), not product code: the output is checked against the input's zlib inflate by run.py.
+//   emulate <file.z> <expected bytes> [out.bin]
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
-#include "common.h"
+#include <cstdio>
+
 #include "inflate_lanes.h"
 
 namespace {
@@ -25,14 +27,14 @@ struct HostMem {
 
 }  // namespace
 
-// stats_out (nullable, 4 words): chunks, stage-A rounds, stage-A chunk scans, stage-C turns
-SF_API int sf_inflate_lanes_emulate(const void* src_, uint64_t n, void* dst, uint64_t dst_cap, uint64_t* out_len, uint32_t* stats_out) {
-  if (!src_ || !dst || !out_len) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+static int fail(const char* what) { std::fprintf(stderr, "emulate: %s\n", what); return 1; }
+
+static int emulate(const void* src_, uint64_t n, void* dst, uint64_t dst_cap, uint64_t* out_len, uint32_t* stats_out) {
   const uint8_t* src = (const uint8_t*)src_;
   *out_len = 0;
-  if (n < 8 || (src[0] & 0x0F) != 8 || ((src[0] << 8 | src[1]) % 31) != 0 || (src[1] & 0x20)) return sf::fail(SF_ERR_FORMAT, "not a zlib stream");
-  if ((src[2] & 7) != 3) return sf::fail(SF_ERR_UNSUPPORTED, "not one final fixed-Huffman block (the host inflater's business)");
-  if (n - 2 > (1ull << 28)) return sf::fail(SF_ERR_UNSUPPORTED, "stream too long for 32-bit bit positions");
+  if (n < 8 || (src[0] & 0x0F) != 8 || ((src[0] << 8 | src[1]) % 31) != 0 || (src[1] & 0x20)) return fail("not a zlib stream");
+  if ((src[2] & 7) != 3) return fail("not one final fixed-Huffman block");
+  if (n - 2 > (1ull << 28)) return fail("stream too long");
   const uint32_t nbytes = (uint32_t)(n - 2);
   std::vector<uint32_t> words((nbytes + 3) / 4 + 2, 0u);
   std::memcpy(words.data(), src + 2, nbytes);
@@ -55,19 +57,20 @@ SF_API int sf_inflate_lanes_emulate(const void* src_, uint64_t n, void* dst, uin
       }
     bool any = false;
     for (uint32_t c = 0; c < C; c++) {
-      const uint32_t ns = c == 0 ? 3u : (((flag[c - 1] & IL_FLAG_EOB) || end[c - 1] == IL_NONE) ? IL_NONE : end[c - 1]);
+      const uint32_t ns = c == 0 ? 3u : end[c - 1];
       dirty[c] = ns != start[c];
       start[c] = ns;
       any = any || dirty[c];
     }
+    if (std::getenv("IL_TRACE")) { unsigned nd = 0; for (uint32_t c = 0; c < C; c++) nd += dirty[c]; std::fprintf(stderr, "round %u: %u chunks restart\n", rounds, nd); }
     if (!any) break;
-    if (rounds > C + 2) return sf::fail(SF_ERR_FORMAT, "chunk starts did not converge");   // cannot happen (induction over the chunks)
+    if (rounds > C + 2) return fail("chunk starts did not converge");   // cannot happen (induction over the chunks)
   }
   // the true token path is known: validate it
   int32_t status = IL_ST_OK;
   bool eob = false;
   for (uint32_t c = 0; c < C && status == IL_ST_OK; c++) {
-    if (start[c] == IL_NONE) continue;
+    if (eob) { start[c] = IL_NONE; outb[c] = 0; continue; }   // behind the end of the block: the trailer, not tokens
     if (flag[c] & IL_FLAG_ERR) status = IL_ST_BAD_CODE;
     else if (flag[c] & IL_FLAG_EOB) eob = true;
   }
@@ -90,11 +93,32 @@ SF_API int sf_inflate_lanes_emulate(const void* src_, uint64_t n, void* dst, uin
       }
       turns++;
       if (all || status != IL_ST_OK) break;
-      if (turns > 4u * (off[C] + 64u)) return sf::fail(SF_ERR_FORMAT, "stage C made no progress (deadlock)");   // cannot happen
+      if (turns > 4u * (off[C] + 64u)) return fail("stage C made no progress (deadlock)");   // cannot happen
     }
   }
   if (stats_out) { stats_out[0] = C; stats_out[1] = rounds; stats_out[2] = scans; stats_out[3] = turns; }
-  if (status != IL_ST_OK) return sf::fail(SF_ERR_FORMAT, "chunk-parallel inflate: status %d", status);
+  if (status != IL_ST_OK) { std::fprintf(stderr, "emulate: status %d\n", status); return 1; }
   *out_len = off[C];
-  return SF_OK;
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 3) return fail("usage: emulate <file.z> <expected bytes> [out.bin]");
+  FILE* f = std::fopen(argv[1], "rb");
+  if (!f) return fail("cannot open input");
+  std::fseek(f, 0, SEEK_END);
+  const long n = std::ftell(f);
+  std::fseek(f, 0, SEEK_SET);
+  std::vector<uint8_t> src((size_t)n);
+  if (std::fread(src.data(), 1, (size_t)n, f) != (size_t)n) return fail("short read");
+  std::fclose(f);
+  const uint64_t want = std::strtoull(argv[2], nullptr, 10);
+  std::vector<uint8_t> out(want + 64);
+  uint64_t got = 0;
+  uint32_t st[4] = {0, 0, 0, 0};
+  if (emulate(src.data(), (uint64_t)n, out.data(), want, &got, st)) return 1;
+  std::printf("chunks %u | stage A: %u rounds, %.2f scans per chunk | stage C (lanes write in token order, wait for their source bytes): %u turns | %llu bytes\n", st[0], st[1],
+              (double)st[2] / st[0], st[3], (unsigned long long)got);
+  if (argc > 3) { FILE* o = std::fopen(argv[3], "wb"); if (o) { std::fwrite(out.data(), 1, got, o); std::fclose(o); } }
+  return got == want ? 0 : 1;
 }

@@ -128,19 +128,24 @@ IL_HD ILToken il_token(const ILStream& s, ILBits& b) {
   return t;
 }
 
-// stage A: the tokens that START in [start, limit): where the first token behind them starts, how many bytes they produce
+// stage A: the tokens that START in [start, limit): where the first token behind them starts, how many bytes they produce.
+// Nothing stops the scan before the limit: a lane that started at a wrong bit must reach the end of its chunk (and resynchronise on the way) even
+// if it meets an invalid code or what looks like an end-of-block code -- the flags only count if this turns out to be the true token path, and
+// then: bytes are counted up to the first end-of-block code, and invalid codes behind it (the Adler-32 trailer read as tokens) are no error.
 IL_HD void il_scan_chunk(const ILStream& s, uint32_t start, uint32_t limit, uint32_t& end, uint32_t& out_bytes, uint32_t& flag) {
   ILBits b;
   il_bits_init(s, b, start);
   uint32_t out = 0, fl = IL_FLAG_OK;
   while (b.pos < limit) {
     const ILToken t = il_token(s, b);
-    if (b.pos > s.nbits) { fl |= IL_FLAG_ERR | IL_FLAG_EOB; break; }   // ran off the end: nothing follows
-    // an invalid code does not stop the scan: a lane that started at a wrong bit must still reach the end of its chunk (and resynchronise on the
-    // way) -- the flag only counts if this turns out to be the true token path
-    if (t.kind == 3u) { fl |= IL_FLAG_ERR; continue; }
-    if (t.kind == 2u) { fl |= IL_FLAG_EOB; break; }
-    out += t.kind == 0u ? 1u : t.value;
+    if (b.pos > s.nbits) {   // ran off the end of the stream
+      if (!(fl & IL_FLAG_EOB)) fl |= IL_FLAG_ERR;
+      break;
+    }
+    if (fl & IL_FLAG_EOB) continue;   // behind the end of the block: only the position matters
+    if (t.kind == 3u) fl |= IL_FLAG_ERR;
+    else if (t.kind == 2u) fl |= IL_FLAG_EOB;
+    else out += t.kind == 0u ? 1u : t.value;
   }
   end = b.pos;
   out_bytes = out;
