@@ -202,7 +202,7 @@ def pmc_pass(args, counters, config, steps, warmup, single_frame, depth_only, ti
         launches = child["config"]["integrate_launches"]
         # one frame per launch runs the software-pipelined k_integrate_pipe, batches run k_integrate; the integrate launches of the timed
         # region are the LAST `launches` dispatches of the kernel (warm-up comes first)
-        pat = "%k_integrate_pipe%" if (single_frame and depth_only) else ("%k_integrate<1, false%" if depth_only else "%k_integrate<1, true%")
+        pat = "%k_integrate_pipe%" if (single_frame and depth_only) else ("%k_integrate<1, 0,%" if depth_only else "%k_integrate<1, 2,%")   # <SIGN, COLOR (0 none, 2 colour), ...>
         db = sqlite3.connect(dbs[0])
         out = {}
         for c in counters:
@@ -477,7 +477,7 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
         return r
 
     R = 1 if child else (args.repeats if args.repeats else repeats_for(K, cfg_name))
-    kname = "k_integrate<1,true,true,2,false>" if rgbd else "k_integrate<1,false,true,2,false>"
+    kname = "k_integrate<1,2,true,2,false>" if rgbd else "k_integrate<1,0,true,2,false>"
     # the timed region runs WITHOUT the HIP events around every integrate launch (they cost ~2 % of the frames/s: profiles/r03_small_experiments.txt);
     # kernel durations come from the roofline sample below, fused again with the events on.  --single-frame keeps them: its line is the roofline.
     m = run(Wm, K, args.single_frame and not args.no_profile, single_frame=args.single_frame, repeats=R)
@@ -494,7 +494,7 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
     if rank == 0:
         pmc_on = world == 1 and not args.no_pmc and not args.no_profile and not child
         if m["batch"] == 1:
-            roof = roofline_hbm(m, K, "k_integrate_pipe<true,2,*>" if not rgbd else "k_integrate<1,true,true,2,true> (one frame per launch)")
+            roof = roofline_hbm(m, K, "k_integrate_pipe<true,2,*>" if not rgbd else "k_integrate<1,2,true,2,true> (one frame per launch)")
             if roof is not None and m["ceiling"]:
                 roof["pattern_ceiling"] = dict(m["ceiling"], frac_of_ceiling=round(roof["achieved"] / m["ceiling"]["rmw_copy_GBs"], 4))
         else:
@@ -545,7 +545,7 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
             out["value_depth_only"] = round(K / md["elapsed"], 2)
             mdr = run(roof_W, roof_K, True, colour=False)
             vd = pmc_valu(args, cfg_name, roof_K, roof_W, False, True) if pmc_on else None
-            rd = roofline_valu(mdr, roof_K, "k_integrate<1,false,true,2,false>", vd, None,
+            rd = roofline_valu(mdr, roof_K, "k_integrate<1,0,true,2,false>", vd, None,
                                "frames %d..%d of the stream without the colour frames, HIP events around every integrate launch" % (roof_W, roof_W + roof_K - 1))
             if rd is not None:
                 rd["frames_per_s"] = out["value_depth_only"]
@@ -575,7 +575,7 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
                     m1c = run(roof_W, min(ks, 400), True, single_frame=True, colour=True)
                     if m1c["launches"]:
                         r1["rgbd_one_frame_per_launch"] = {"frames_per_s": round(min(ks, 400) / m1c["elapsed"], 1), "avg_kernel_us": round(m1c["kernel_ms"] * 1e3 / m1c["launches"], 2),
-                                                           "kernel": "k_integrate<1,true,true,2,true>",
+                                                           "kernel": "k_integrate<1,2,true,2,true>",
                                                            "hbm_frac_alg": round(m1c["alg_bytes"] / (m1c["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                 # the entry point a live stream calls: one pageable host frame per call (sf_fuser_integrate), through the page-locked ring
                 nh = min(ks, 400)

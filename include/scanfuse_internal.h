@@ -37,12 +37,6 @@ int sf_fuser_tune(sf_fuser* f, const char* key, int value);
  * path k_alloc_ray exists to avoid; the volume is the same either way).  tests/test_gpu_tsdf.py asserts 0 on the bench walk's corners. */
 int sf_fuser_alloc_direct_count(sf_fuser* f, uint64_t* out);
 
-/* Two zlib streams inflated side by side on the calling thread (csrc/zlib_codec.cpp: the tokens of two independent fixed-Huffman blocks
- * advance alternately so that the core overlaps the two dependent chains); what the frame pipeline's decode threads call with two depth
- * frames at a time.  *len_x / *rc_x are what sf_zlib_inflate gives for stream x alone; returns the first non-zero of the two. */
-int sf_zlib_inflate_pair(const void* src_a, uint64_t n_a, void* dst_a, uint64_t cap_a, uint64_t* len_a, int* rc_a,
-                         const void* src_b, uint64_t n_b, void* dst_b, uint64_t cap_b, uint64_t* len_b, int* rc_b);
-
 /* Phases of the most recent sf_fuser_extract_mesh, milliseconds: [0] whole call, [1] live-block list, [2] count pass (k_mc), [3] scan + emit pass,
  * [4] vertex sort (radix sort of the 3T edge keys), [5] heads + scan + weld, [6] triangle sort + gather, [7] downloads (device side), [8] host: output
  * arrays allocated + downloads awaited; then [9] live blocks, [10] triangles, [11] welded vertices.  n <= 12 values are written. */

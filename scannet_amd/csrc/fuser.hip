@@ -992,11 +992,12 @@ __device__ inline void fuse_project(const ParamsK& P, const float* __restrict__ 
 // parameters after the uchar clamp): the weight byte then increments with saturation as ONE add-with-carry on the {rgb, weight} word;
 // 3 = the observation's weight depends on its depth (sf_params::weight_mode 1), otherwise as 0.
 // dirty[j]: lane mask (a scalar register pair) of the lanes whose row j changed -- kept on the scalar unit across the frames of a batch.
+// COLOR: 0 = geometry only, 1 = colour (every switch a wave-uniform mask), 2 = colour with colour_first == 0 compiled in.
 // ROWS: dirty[] holds one lane mask per row (one frame per launch: the HBM-bound schedule writes back only the rows some lane changed); without
 // it dirty[0] is a wave-uniform "some frame touched this tile" flag and the caller writes the whole tile back -- a ballot of an i1 that is not
 // itself a compare costs a v_cndmask + v_cmp per row (8 of the 241 VALU instructions of a lane's frame), and a pass of 32 frames is VALU-bound
 // with HBM at 8 % of its peak.
-template <int SIGN, bool COLOR, bool TAB, int WM, int J0, int NJ, bool ROWS = true>
+template <int SIGN, int COLOR, bool TAB, int WM, int J0, int NJ, bool ROWS = true>
 __device__ inline void fuse_update(const ParamsK& P, const v2f (&rcp_m)[NJ], const float (&d)[2 * NJ], const uint32_t (&c)[2 * NJ], const v2f (&pz)[NJ],
                                    const bool (&ok)[2 * NJ], uint4 (&v)[4], uint64_t (&dirty)[4]) {
   constexpr bool WS1 = WM == 1 || WM == 2;
@@ -1064,7 +1065,10 @@ __device__ inline void fuse_update(const ParamsK& P, const v2f (&rcp_m)[NJ], con
           // a wave-uniform mask on the word, not a branch.  (Round 3 spent 12 VALU instructions per voxel on this blend: xor / and / shift / add3.)
           const uint32_t ck = c[2 * j + hx];
           const uint32_t avg = __builtin_amdgcn_lerp(cw, ck, round_mask);
-          rgb = (cw & first_mask) == 0u ? ck : avg;
+          // COLOR 2 (colour_first == 0, the shipped semantics): "no observation yet" = the weight byte is zero = the word is below 2^24 -- one compare
+          // against a literal instead of a mask and a compare
+          const bool first = COLOR == 2 ? cw < 0x01000000u : (cw & first_mask) == 0u;
+          rgb = first ? ck : avg;
         }
         if (WM == 2) {
           if (COLOR) {
@@ -1126,7 +1130,7 @@ __device__ inline __amdgpu_buffer_rsrc_t image_rsrc(const void* base, uint32_t b
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);   // raw buffer, dword data format (gfx9)
 }
 
-template <int SIGN, bool COLOR, bool TAB, int WM, int J0, int NJ, bool ROWS>
+template <int SIGN, int COLOR, bool TAB, int WM, int J0, int NJ, bool ROWS>
 __device__ inline void fuse_rows(const ParamsK& P, const float* __restrict__ Ti, const float* __restrict__ depthf,
                                  const uint32_t* __restrict__ color, const float* rtab, v2f wx, float wy, const float (&wz)[4],
                                  uint4 (&v)[4], uint64_t (&dirty)[4]) {
@@ -1160,7 +1164,7 @@ __device__ inline void fuse_rows(const ParamsK& P, const float* __restrict__ Ti,
 
 // 4 waves per SIMD (<= 128 VGPRs).  Tried for the one-frame-per-launch case: 5 waves / 96 VGPRs with the tile in two
 // half passes -- the spills cost more than the occupancy buys (183 us vs 112 us per launch).
-template <int SIGN, bool COLOR, bool TAB, int WM, bool ROWS>
+template <int SIGN, int COLOR, bool TAB, int WM, bool ROWS>
 __global__ __launch_bounds__(256, 4) void k_integrate(uint4* __restrict__ voxels, const uint64_t* __restrict__ block_keys,
                                                    const int32_t* __restrict__ compact, const uint32_t* __restrict__ cmask,
                                                    const float* __restrict__ depthf_all, const uint32_t* __restrict__ color_all,
@@ -1409,7 +1413,7 @@ __global__ __launch_bounds__(256, 3) void k_integrate_pipe(uint4* __restrict__ v
     for (int k = 0; k < 8; k++) ok[k] = (okmask >> k) & 1u;
     uint32_t cdummy[8];
     uint64_t dirty[4] = {0ull, 0ull, 0ull, 0ull};
-    fuse_update<1, false, TAB, WM, 0, 4>(P, rcp_m, d, cdummy, pz, ok, v, dirty);  // consumes d: the gather slot is free again
+    fuse_update<1, 0, TAB, WM, 0, 4>(P, rcp_m, d, cdummy, pz, ok, v, dirty);  // consumes d: the gather slot is free again
     uint4* vb = voxels + (size_t)slot * 256;
 #pragma unroll
     for (int j = 0; j < 4; j++)
@@ -1820,13 +1824,17 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
     else LAUNCH_PIPE(0);
 #undef LAUNCH_PIPE
   } else if (sign > 0) {
-    if (ws1 && f->pk.wmax == 255) { if (col) LAUNCH_INT(1, true, true, 2); else LAUNCH_INT(1, false, true, 2); }  // the shipped setting
-    else if (ws1) { if (col) LAUNCH_INT(1, true, true, 1); else LAUNCH_INT(1, false, true, 1); }
-    else if (tab)                { if (col) LAUNCH_INT(1, true, true, 0); else LAUNCH_INT(1, false, true, 0); }
-    else if (f->p.weight_mode == 1) { if (col) LAUNCH_INT(1, true, false, 3); else LAUNCH_INT(1, false, false, 3); }
-    else                         { if (col) LAUNCH_INT(1, true, false, 0); else LAUNCH_INT(1, false, false, 0); }
-  } else if (f->p.weight_mode == 1) { if (col) LAUNCH_INT(-1, true, false, 3); else LAUNCH_INT(-1, false, false, 3); }
-  else                           { if (col) LAUNCH_INT(-1, true, false, 0); else LAUNCH_INT(-1, false, false, 0); }
+    if (ws1 && f->pk.wmax == 255) {   // the shipped setting
+      if (col && !f->p.colour_first) LAUNCH_INT(1, 2, true, 2);
+      else if (col) LAUNCH_INT(1, 1, true, 2);
+      else LAUNCH_INT(1, 0, true, 2);
+    }
+    else if (ws1) { if (col) LAUNCH_INT(1, 1, true, 1); else LAUNCH_INT(1, 0, true, 1); }
+    else if (tab)                { if (col) LAUNCH_INT(1, 1, true, 0); else LAUNCH_INT(1, 0, true, 0); }
+    else if (f->p.weight_mode == 1) { if (col) LAUNCH_INT(1, 1, false, 3); else LAUNCH_INT(1, 0, false, 3); }
+    else                         { if (col) LAUNCH_INT(1, 1, false, 0); else LAUNCH_INT(1, 0, false, 0); }
+  } else if (f->p.weight_mode == 1) { if (col) LAUNCH_INT(-1, 1, false, 3); else LAUNCH_INT(-1, 0, false, 3); }
+  else                           { if (col) LAUNCH_INT(-1, 1, false, 0); else LAUNCH_INT(-1, 0, false, 0); }
 #undef LAUNCH_INT
 #undef LAUNCH_INT_R
   if (f->profile) (void)hipEventRecord(e1, s);

@@ -162,56 +162,40 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   std::string pool_err;
   int pool_rc = SF_OK;
   auto nap = [] { std::this_thread::sleep_for(std::chrono::microseconds(20)); };
-  // The pool takes frames in PAIRS: two zlib depth frames are inflated side by side on one thread (sens_decode_depth_pair: the tokens of the two
-  // independent streams advance alternately, so the core overlaps two dependent chains instead of waiting out one); colour, if any, per frame.
   auto worker = [&]() {
     for (;;) {
-      const uint64_t k0 = next.fetch_add(2);
-      if (k0 >= total || abort.load(std::memory_order_relaxed)) return;
-      const int nk = k0 + 1 < total ? 2 : 1;
-      int sl[2], jj[2];
-      for (int q = 0; q < nk; q++) {
-        const uint64_t k = k0 + (uint64_t)q, g = k / (uint64_t)B;
-        jj[q] = (int)(k % (uint64_t)B);
-        sl[q] = (int)(g % (uint64_t)NB);
-        while (g >= landed.load(std::memory_order_acquire) + (uint64_t)NB) {  // batch g - NB still owns the pinned buffers
-          if (abort.load(std::memory_order_relaxed)) return;
-          nap();
-        }
+      const uint64_t k = next.fetch_add(1);
+      if (k >= total || abort.load(std::memory_order_relaxed)) return;
+      const uint64_t g = k / (uint64_t)B;
+      const int j = (int)(k % (uint64_t)B), sl = (int)(g % (uint64_t)NB);
+      while (g >= landed.load(std::memory_order_acquire) + (uint64_t)NB) {  // batch g - NB still owns the pinned buffers
+        if (abort.load(std::memory_order_relaxed)) return;
+        nap();
       }
+      const uint64_t frame = first + k;
       const auto t0 = std::chrono::steady_clock::now();
-      int rc[2] = {SF_OK, SF_OK};
-      bool valid[2] = {false, false};
-      for (int q = 0; q < nk; q++) valid[q] = s->frames[first + k0 + (uint64_t)q].pose[0] != -INFINITY;
-      if (nk == 2 && valid[0] && valid[1]) {
-        (void)sens_decode_depth_pair(s, first + k0, h_depth(sl[0], jj[0]), &rc[0], first + k0 + 1, h_depth(sl[1], jj[1]), &rc[1]);
-      } else {
-        for (int q = 0; q < nk; q++)
-          if (valid[q]) rc[q] = sens_decode_depth(s, first + k0 + (uint64_t)q, h_depth(sl[q], jj[q]));
-      }
-      for (int q = 0; q < nk; q++) {
-        const uint64_t frame = first + k0 + (uint64_t)q;
-        if (valid[q] && rc[q] == SF_OK && use_rgb && s->frames[frame].color_bytes) {
+      int rc = SF_OK;
+      if (s->frames[frame].pose[0] != -INFINITY) {
+        rc = sens_decode_depth(s, frame, h_depth(sl, j));
+        if (rc == SF_OK && use_rgb && s->frames[frame].color_bytes) {
           bool coef = false;
           if (gpu_jpeg) {
-            uint8_t* pay = h_pay(sl[q], jj[q]);
+            uint8_t* pay = h_pay(sl, j);
             coef = jpeg_decode_coef(s->frames[frame].color, s->frames[frame].color_bytes, s->info.color_width, s->info.color_height, pay, pay_b) == SF_OK &&
                    reinterpret_cast<const SfJpegLayout*>(pay)->nblocks == pay_blocks;
-            if (coef) ring[(size_t)sl[q]].pay_used[jj[q]] = (uint32_t)sf_jpeg_payload_bytes(*reinterpret_cast<const SfJpegLayout*>(pay));
+            if (coef) ring[(size_t)sl].pay_used[j] = (uint32_t)sf_jpeg_payload_bytes(*reinterpret_cast<const SfJpegLayout*>(pay));
           }
-          ring[(size_t)sl[q]].coef_mode[jj[q]] = coef ? 1 : 0;
-          if (!coef) rc[q] = sf_sens_decode_color(s, frame, h_rgb(sl[q], jj[q]));   // raw colour, or a JPEG the GPU path does not take (errors surface here)
+          ring[(size_t)sl].coef_mode[j] = coef ? 1 : 0;
+          if (!coef) rc = sf_sens_decode_color(s, frame, h_rgb(sl, j));   // raw colour, or a JPEG the GPU path does not take (errors surface here)
         }
       }
       decode_ns.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
-      for (int q = 0; q < nk; q++) {
-        if (rc[q] != SF_OK) {
-          std::lock_guard<std::mutex> lk(err_mu);
-          if (pool_rc == SF_OK) { pool_rc = rc[q]; pool_err = sf_last_error(); }
-          ring[(size_t)sl[q]].failed.fetch_add(1);
-        }
-        ring[(size_t)sl[q]].decoded.fetch_add(1, std::memory_order_release);
+      if (rc != SF_OK) {
+        std::lock_guard<std::mutex> lk(err_mu);
+        if (pool_rc == SF_OK) { pool_rc = rc; pool_err = sf_last_error(); }
+        ring[(size_t)sl].failed.fetch_add(1);
       }
+      ring[(size_t)sl].decoded.fetch_add(1, std::memory_order_release);
     }
   };
   std::vector<std::thread> pool;

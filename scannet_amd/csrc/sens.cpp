@@ -159,26 +159,6 @@ int sens_decode_depth(const sf_sens* s, uint64_t i, uint16_t* dst) {
   }
 }
 
-// two frames on the calling thread, side by side when both are zlib depth (sf_zlib_inflate_pair: the two token chains overlap in the core);
-// rc0 / rc1 and the thread's last error are what sens_decode_depth gives for each frame alone
-int sens_decode_depth_pair(const sf_sens* s, uint64_t i0, uint16_t* dst0, int* rc0, uint64_t i1, uint16_t* dst1, int* rc1) {
-  const bool both = s->info.depth_compression == 1 && i0 < s->frames.size() && i1 < s->frames.size() && s->frames[i0].depth && s->frames[i0].depth_bytes &&
-                    s->frames[i1].depth && s->frames[i1].depth_bytes;
-  if (!both) {
-    *rc0 = sens_decode_depth(s, i0, dst0);
-    *rc1 = sens_decode_depth(s, i1, dst1);
-    return *rc0 != SF_OK ? *rc0 : *rc1;
-  }
-  const uint64_t want = (uint64_t)s->info.depth_width * s->info.depth_height * 2;
-  const SensFrame &f0 = s->frames[i0], &f1 = s->frames[i1];
-  uint64_t g0 = 0, g1 = 0;
-  (void)sf_zlib_inflate_pair(f0.depth, f0.depth_bytes, dst0, want, &g0, rc0, f1.depth, f1.depth_bytes, dst1, want, &g1, rc1);
-  // (when both fail the thread's error text is the second frame's; the caller reports the first failing frame's code)
-  if (*rc1 == SF_OK && g1 != want) *rc1 = sf::fail(SF_ERR_FORMAT, "depth frame %llu inflates to %llu bytes, expected %llu", (unsigned long long)i1, (unsigned long long)g1, (unsigned long long)want);
-  if (*rc0 == SF_OK && g0 != want) *rc0 = sf::fail(SF_ERR_FORMAT, "depth frame %llu inflates to %llu bytes, expected %llu", (unsigned long long)i0, (unsigned long long)g0, (unsigned long long)want);
-  return *rc0 != SF_OK ? *rc0 : *rc1;
-}
-
 SF_API int sf_sens_decode_depth(const sf_sens* s, uint64_t frame, uint16_t* dst) {
   if (!s || !dst) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
   return sens_decode_depth(s, frame, dst);

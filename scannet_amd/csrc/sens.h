@@ -27,5 +27,3 @@ struct sf_sens {
 
 // inflate / copy frame `i`'s depth into dst (W*H u16); thread-safe (no shared mutable state)
 int sens_decode_depth(const sf_sens* s, uint64_t i, uint16_t* dst);
-// frames i0 and i1 side by side on the calling thread (zlib depth: the two inflate chains interleaved); *rc0 / *rc1 per frame
-int sens_decode_depth_pair(const sf_sens* s, uint64_t i0, uint16_t* dst0, int* rc0, uint64_t i1, uint16_t* dst1, int* rc1);

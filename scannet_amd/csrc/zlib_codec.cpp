@@ -323,87 +323,6 @@ int inflate_block(BitReader& br, const Huffman& lit, const Huffman& dist, const 
   }
 }
 
-// Two fixed-Huffman blocks side by side.  One block is a dependent chain per token -- refill, table load, (table load,) shifts, copy: ~15 cycles
-// of latency for ~50 instructions, a third of what the core could issue -- and the frames of a .sens are independent streams, so the frame
-// pipeline hands its decode threads TWO frames at a time and this loop advances them alternately: the out-of-order core overlaps the two
-// chains.  The body is inflate_block's tight loop, token for token (same tables, same copies), so each output is byte-identical to a single
-// decode; whatever the tight loop does not take (end of block, the last bytes of either buffer, a bad code) ends the pairing and each stream
-// is finished by inflate_block from where it stands.
-struct PairLane {
-  BitReader br;
-  uint8_t* out;
-  uint64_t cap, pos;
-};
-// one tight-loop step (inflate_block's, token for token); 0 = done, go on; 1 = not for the tight loop; < 0 = error.
-// (Tried and measured slower, 0.65-0.94x: the same step without a branch on literal / match -- the literal store and the first eight bytes of a
-// copy always executed, the kind selecting lengths and bit counts through conditional moves: the extra distance-table load per literal and one
-// refill per token instead of one per two literals cost more than the mispredictions.)
-static inline int pair_step(PairLane& L, const PackedTables& pk) {
-  constexpr uint32_t FMASK = (1u << FAST_BITS) - 1;
-  BitReader& br = L.br;
-  {
-    uint64_t w;
-    std::memcpy(&w, br.p, 8);
-    br.buf |= w << br.cnt;
-    br.p += (63 - br.cnt) >> 3;
-    br.cnt |= 56;
-  }
-  uint32_t e = pk.lit[br.buf & FMASK];
-  if (e & PK_LIT) {
-    L.out[L.pos++] = (uint8_t)(e >> 8);
-    br.buf >>= (e & 15);
-    br.cnt -= (int)(e & 15);
-    e = pk.lit[br.buf & FMASK];
-    if (e & PK_LIT) {
-      L.out[L.pos++] = (uint8_t)(e >> 8);
-      br.buf >>= (e & 15);
-      br.cnt -= (int)(e & 15);
-      return 0;
-    }
-  }
-  if (!(e & PK_LEN)) return 1;
-  const uint32_t lb = e & 15, lx = (e >> 4) & 7;
-  const uint32_t dd = pk.dist[(br.buf >> (lb + lx)) & FMASK];
-  if (!dd) return 1;
-  br.buf >>= lb;
-  const uint32_t len = ((e >> 8) & 0x1FF) + (uint32_t)(br.buf & ((1u << lx) - 1));
-  const uint32_t db = dd & 15, dx = (dd >> 4) & 15;
-  br.buf >>= lx + db;
-  const uint32_t d = (dd >> 8) + (uint32_t)(br.buf & ((1u << dx) - 1));
-  br.buf >>= dx;
-  br.cnt -= (int)(lb + lx + db + dx);
-  if (d > L.pos) return sf::fail(SF_ERR_FORMAT, "inflate: distance %u before start of output", d);
-  uint8_t* dst = L.out + L.pos;
-  const uint8_t* src = dst - d;
-  L.pos += len;
-  if (d >= 8) {
-    std::memcpy(dst, src, 8);
-    for (uint32_t i = 8; i < len; i += 8) std::memcpy(dst + i, src + i, 8);
-  } else if (d == 1) {
-    std::memset(dst, src[0], len);
-  } else if (d == 2 || d == 4) {
-    uint64_t pat;
-    if (d == 2) { uint16_t h; std::memcpy(&h, src, 2); pat = 0x0001000100010001ull * h; }
-    else { uint32_t w; std::memcpy(&w, src, 4); pat = 0x0000000100000001ull * w; }
-    for (uint32_t i = 0; i < len; i += 8) std::memcpy(dst + i, &pat, 8);
-  } else {
-    for (uint32_t i = 0; i < len; i++) dst[i] = src[i];
-  }
-  return 0;
-}
-
-// a zlib stream that is ONE final fixed-Huffman block (what the reference's stb writer and this library's writer emit): reader behind the block header
-static bool open_fixed_final(const uint8_t* src, uint64_t n, BitReader& br) {
-  if (n < 8) return false;
-  const uint32_t cmf = src[0], flg = src[1];
-  if ((cmf * 256 + flg) % 31 != 0 || (flg & 32) || (cmf & 15) != 8) return false;
-  if ((src[2] & 7) != 3) return false;   // BFINAL = 1, BTYPE = 01
-  br = BitReader{src + 2, src + n};
-  br.refill();
-  br.drop(3);
-  return true;
-}
-
 int inflate_raw(const uint8_t* src, uint64_t n, uint8_t* out, uint64_t cap, uint64_t* out_len) {
   BitReader br{src, src + n};
   uint64_t pos = 0;
@@ -639,32 +558,4 @@ SF_API int sf_zlib_inflate(const void* src_, uint64_t n, void* dst, uint64_t dst
   if (flg & 32) return sf::fail(SF_ERR_FORMAT, "zlib: preset dictionary not allowed");
   if ((cmf & 15) != 8) return sf::fail(SF_ERR_FORMAT, "zlib: compression method is not DEFLATE");
   return inflate_raw(src + 2, n - 2, (uint8_t*)dst, dst_cap, out_len);
-}
-
-// scanfuse_internal.h: two streams at once (the frame pipeline's decode threads take frames in pairs).  Each output and each status is what
-// sf_zlib_inflate gives for that stream alone; streams that are not one final fixed-Huffman block are simply decoded one after the other.
-SF_API int sf_zlib_inflate_pair(const void* src_a, uint64_t n_a, void* dst_a, uint64_t cap_a, uint64_t* len_a, int* rc_a,
-                                const void* src_b, uint64_t n_b, void* dst_b, uint64_t cap_b, uint64_t* len_b, int* rc_b) {
-  if (!src_a || !src_b || !dst_a || !dst_b || !len_a || !len_b || !rc_a || !rc_b) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
-  PairLane A{{}, (uint8_t*)dst_a, cap_a, 0}, B{{}, (uint8_t*)dst_b, cap_b, 0};
-  if (!open_fixed_final((const uint8_t*)src_a, n_a, A.br) || !open_fixed_final((const uint8_t*)src_b, n_b, B.br)) {
-    *rc_a = sf_zlib_inflate(src_a, n_a, dst_a, cap_a, len_a);
-    *rc_b = sf_zlib_inflate(src_b, n_b, dst_b, cap_b, len_b);
-    return (*rc_a != SF_OK) ? *rc_a : *rc_b;
-  }
-  const FixedTables& ft = fixed_tables();
-  int ra = 0, rb = 0;
-  while (A.pos + 274 <= A.cap && A.br.end - A.br.p >= 8 && B.pos + 274 <= B.cap && B.br.end - B.br.p >= 8) {
-    ra = pair_step(A, ft.pk);
-    rb = pair_step(B, ft.pk);
-    if (ra | rb) break;
-  }
-  // each stream on its own from where it stands (a step that returned 1 consumed nothing but a refill and, at most, one literal it also wrote)
-  *rc_a = ra < 0 ? ra : inflate_block(A.br, ft.lit, ft.dist, ft.pk, A.out, A.cap, A.pos);
-  if (*rc_a == SF_OK && A.br.overrun > 8) *rc_a = sf::fail(SF_ERR_FORMAT, "inflate: truncated stream");
-  *len_a = A.pos;
-  *rc_b = rb < 0 ? rb : inflate_block(B.br, ft.lit, ft.dist, ft.pk, B.out, B.cap, B.pos);
-  if (*rc_b == SF_OK && B.br.overrun > 8) *rc_b = sf::fail(SF_ERR_FORMAT, "inflate: truncated stream");
-  *len_b = B.pos;
-  return (*rc_a != SF_OK) ? *rc_a : *rc_b;
 }

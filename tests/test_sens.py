@@ -572,49 +572,3 @@ def test_bulk_depth_writer_writes_the_file_of_the_frame_by_frame_writer(tmp_path
         assert open(pa, "rb").read() == open(pb, "rb").read()
         r = sens.SensorData(pb)
         assert r.num_frames == N and np.array_equal(r.frames[36].decompress_depth(), depth[36])
-
-
-def test_inflate_pair_gives_what_two_single_inflates_give():
-    """sf_zlib_inflate_pair (the frame pipeline's decode threads inflate two depth frames side by side): each output, length and status is the
-    single decode's -- for two fixed-Huffman streams of equal and of very different length (the pairing ends when the first one does), for a
-    dynamic-Huffman or stored stream on either side (no pairing at all), and when one of the two is truncated or corrupt."""
-    L = _abi.lib()
-    L.sf_zlib_inflate_pair.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_int)] * 2
-    rng = np.random.default_rng(5)
-
-    def depth_like(n, noise):
-        d = (1800 + 300 * np.sin(np.arange(n) / 211.0)).astype(np.uint16) + rng.integers(0, noise, n, dtype=np.uint16)
-        return d.tobytes()
-
-    raws = [depth_like(307200, 8), depth_like(307200, 8), depth_like(307200, 2), depth_like(5000, 8), b"", b"xyz" * 5, bytes(70000)]
-    fixed = [sens.zlib_deflate(r) for r in raws]                    # one final fixed-Huffman block, as the reference's stb writer emits
-    assert all((b[2] & 7) == 3 for b in fixed)
-    others = [zlib.compress(raws[0], 6), zlib.compress(raws[3], 0), zlib.compress(raws[2], 9)]   # dynamic, stored, dynamic
-    streams = [(b, r) for b, r in zip(fixed, raws)] + [(others[0], raws[0]), (others[1], raws[3]), (others[2], raws[2])]
-    bad = [(fixed[0][:len(fixed[0]) // 2], None), (fixed[0][:2] + bytes([fixed[0][2] ^ 0xFF]) + fixed[0][3:], None), (b"\x78", None)]
-
-    def run(a, b):
-        oa, ob = np.zeros(len(a[1] or b"") + 700000, np.uint8), np.zeros(len(b[1] or b"") + 700000, np.uint8)
-        na, nb, ra, rb = C.c_uint64(0), C.c_uint64(0), C.c_int(9), C.c_int(9)
-        sa, sb = np.frombuffer(a[0], np.uint8), np.frombuffer(b[0], np.uint8)
-        rc = L.sf_zlib_inflate_pair(sa.ctypes.data, len(a[0]), oa.ctypes.data, len(a[1]) if a[1] is not None else 614400, C.byref(na), C.byref(ra),
-                                    sb.ctypes.data, len(b[0]), ob.ctypes.data, len(b[1]) if b[1] is not None else 614400, C.byref(nb), C.byref(rb))
-        return rc, (ra.value, oa[:na.value].tobytes()), (rb.value, ob[:nb.value].tobytes())
-
-    for a in streams:
-        for b in streams:
-            rc, (ra, oa), (rb, ob) = run(a, b)
-            assert rc == 0 and ra == 0 and rb == 0 and oa == a[1] and ob == b[1]
-    for x in bad:
-        for good in (streams[0], streams[7]):
-            for pair in ((x, good), (good, x)):
-                rc, ra, rb = run(*pair)
-                r_bad, r_good = (ra, rb) if pair[0] is x else (rb, ra)
-                assert rc != 0 and r_bad[0] != 0 and r_good == (0, good[1])      # the good stream is not affected by its neighbour
-    # capacity one byte short on one side: that side reports it, the other is complete
-    sa, sb = streams[0], streams[1]
-    oa, ob = np.zeros(700000, np.uint8), np.zeros(700000, np.uint8)
-    na, nb, ra, rb = C.c_uint64(0), C.c_uint64(0), C.c_int(0), C.c_int(0)
-    rc = L.sf_zlib_inflate_pair(np.frombuffer(sa[0], np.uint8).ctypes.data, len(sa[0]), oa.ctypes.data, len(sa[1]) - 1, C.byref(na), C.byref(ra),
-                                np.frombuffer(sb[0], np.uint8).ctypes.data, len(sb[0]), ob.ctypes.data, len(sb[1]), C.byref(nb), C.byref(rb))
-    assert rc == -7 and ra.value == -7 and rb.value == 0 and ob[:nb.value].tobytes() == sb[1]   # -7 = SF_ERR_BOUNDS
