@@ -211,12 +211,33 @@ def pmc_pass(args, counters, config, steps, warmup, single_frame, depth_only, ti
                 db.close()
                 return None
             out[c] = sum(rows[-launches:]) / launches
+        # the kernels in FRONT of the integrate launch (one launch each per pass): the same counters from the same pass, and their duration under
+        # the profiler (kernels serialised: what each takes alone)
+        front = {}
+        for key, fp in FRONT_KERNELS.items():
+            e = {}
+            for c in counters:
+                rows = [v for (v,) in db.execute("select value from counters_collection where counter_name = ? and kernel_name like ? order by dispatch_id", (c, fp))]
+                if len(rows) >= launches:
+                    e[c] = sum(rows[-launches:]) / launches
+            try:
+                dur = [t for (t,) in db.execute("select end - start from kernels where name like ? order by start", (fp,))]
+                if len(dur) >= launches:
+                    e["avg_us_alone"] = round(sum(dur[-launches:]) / launches / 1e3, 2)
+            except sqlite3.Error:
+                pass
+            if e:
+                front[key] = e
         db.close()
+        out["_front"] = front
         return out, child
     except Exception:
         return None
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+FRONT_KERNELS = {"k_alloc_ray": "%k_alloc_ray%", "k_compactify": "%k_compactify%", "k_prepass": "%k_prepass%"}
 
 
 def pmc_traffic(args, config, steps, warmup, single_frame, depth_only):
@@ -230,7 +251,14 @@ def pmc_traffic(args, config, steps, warmup, single_frame, depth_only):
         return None
     read_b, write_b = 2.0 * a[0]["FETCH_SIZE"] * 1024.0, b[0]["WRITE_SIZE"] * 1024.0
     alg = a[1]["config"].get("alg_bytes_per_launch")
-    return {"bytes": round(read_b + write_b), "read_bytes": round(read_b), "write_bytes": round(write_b),
+    front = {}
+    for k in FRONT_KERNELS:
+        fa, fb = a[0].get("_front", {}).get(k, {}), b[0].get("_front", {}).get(k, {})
+        if "FETCH_SIZE" in fa and "WRITE_SIZE" in fb:
+            front[k] = {"read_bytes": round(2.0 * fa["FETCH_SIZE"] * 1024.0), "write_bytes": round(fb["WRITE_SIZE"] * 1024.0), "avg_us_alone": fa.get("avg_us_alone")}
+            if fa.get("avg_us_alone"):
+                front[k]["hbm_frac_alone"] = round((front[k]["read_bytes"] + front[k]["write_bytes"]) / (fa["avg_us_alone"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+    return {"bytes": round(read_b + write_b), "read_bytes": round(read_b), "write_bytes": round(write_b), "front_chain": front,
             "sample": "integrate launches of frames %d..%d, rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; FETCH_SIZE x2 "
                       "(gfx950 128-B requests tallied at 64 B), WRITE_SIZE x1, KiB -> bytes; Infinity-Cache hits are counted" % (warmup, warmup + steps - 1),
             "alg_bytes_same_launches": alg, "traffic_over_alg": round((read_b + write_b) / alg, 4) if alg else None}
@@ -245,7 +273,13 @@ def pmc_valu(args, config, steps, warmup, single_frame, depth_only):
     v, child = a
     slots = NUM_SIMDS * (v["GRBM_GUI_ACTIVE"] / 8.0) / 4.0
     blk = child["roofline_inputs"]["block_frames_per_launch"] if "roofline_inputs" in child else None
-    return {"valu_util": round(v["SQ_ACTIVE_INST_VALU"] / slots, 4) if slots else None, "active_inst_valu": round(v["SQ_ACTIVE_INST_VALU"]),
+    front = {}
+    for k, e in v.get("_front", {}).items():
+        if all(c in e for c in ("SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE")) and e["GRBM_GUI_ACTIVE"] > 0:
+            front[k] = {"valu_util_alone": round(e["SQ_ACTIVE_INST_VALU"] / (NUM_SIMDS * (e["GRBM_GUI_ACTIVE"] / 8.0) / 4.0), 4), "insts_valu": round(e["SQ_INSTS_VALU"]),
+                        "avg_us_alone": e.get("avg_us_alone"), "valu_insts_share_of_the_pass": round(e["SQ_INSTS_VALU"] / (e["SQ_INSTS_VALU"] + v["SQ_INSTS_VALU"]), 4)}
+    return {"front_chain": front,
+            "valu_util": round(v["SQ_ACTIVE_INST_VALU"] / slots, 4) if slots else None, "active_inst_valu": round(v["SQ_ACTIVE_INST_VALU"]),
             "insts_valu": round(v["SQ_INSTS_VALU"]), "gui_active_clocks_per_xcd": round(v["GRBM_GUI_ACTIVE"] / 8.0),
             "valu_insts_per_voxel_frame": round(v["SQ_INSTS_VALU"] * 64.0 / (blk * 512.0), 2) if blk else None,
             "sample": "rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE (own pass, kernels serialised by the profiler), integrate launches of frames %d..%d"
@@ -293,15 +327,34 @@ def end_to_end(frames_dev, poses, n, params, local_rank, torch, colour=None):
         size = os.path.getsize(path)
         sd = sens.SensorData(path)
         best = None
+        mc = None
         for _ in range(2):   # the second pass reads the file from the page cache, as the stage after `convert` does
             with fusion.Fuser(prm, device=local_rank, **TUNE) as f:
                 rs = f.run(sd)
                 st = f.stats()
+                if colour is None:   # what follows the fusion in the `improve` stage: marching cubes over the fused volume (second call: warm)
+                    del_mesh = f.extract_mesh()
+                    del del_mesh
+                    del_mesh = f.extract_mesh()
+                    del del_mesh
+                    mc = f.mc_timing()
             if best is None or rs["seconds_total"] < best[0]["seconds_total"]:
                 best = (rs, st)
         sd.close()
         rs, st = best
-        return {"frames": int(rs["frames_total"]), "frames_per_s": round(rs["frames_total"] / rs["seconds_total"], 1), "seconds": round(rs["seconds_total"], 4),
+        if mc is not None and mc["blocks"]:
+            tile_b = mc["blocks"] * 729 * 8          # the 9^3 tile {sdf, rgbw} staged per block (8^3 own voxels + the +1 halo from 7 neighbours), per pass
+            soup_b = mc["triangles"] * (8 + 3 * (8 + 12 + 4))
+            out_b = mc["vertices"] * (12 + 4 + 8) + mc["triangles"] * (12 + 8)
+            mc["count_pass_GBs"] = round(tile_b / (mc["count_pass"] * 1e-3) / 1e9, 1) if mc["count_pass"] > 0 else None
+            mc["count_pass_hbm_frac"] = round(tile_b / (mc["count_pass"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if mc["count_pass"] > 0 else None
+            mc["emit_pass_GBs"] = round((tile_b + soup_b) / (mc["scan_emit_pass"] * 1e-3) / 1e9, 1) if mc["scan_emit_pass"] > 0 else None
+            mc["download_bytes"] = out_b
+            mc["download_GBs"] = round(out_b / (mc["downloads_device"] * 1e-3) / 1e9, 1) if mc["downloads_device"] > 0 else None
+            mc["what"] = ("sf_fuser_extract_mesh over the %d live blocks of the fused prefix, second call, milliseconds per phase (HIP events; host_alloc_and_wait: wall clock): two passes of "
+                          "k_mc staging a 9^3 tile per block (count, emit), rocPRIM radix sorts of the 3T edge keys and the T cube keys, weld, download of %.0f MB through two page-locked "
+                          "bounce buffers with a copy team" % (mc["blocks"], out_b / 1e6))
+        return {"marching_cubes": mc, "frames": int(rs["frames_total"]), "frames_per_s": round(rs["frames_total"] / rs["seconds_total"], 1), "seconds": round(rs["seconds_total"], 4),
                 "compressed_bytes_per_frame": round(size / n), "sens_bytes": size, "decode_threads": int(rs["decode_threads"]),
                 "decode_ms_per_frame_per_thread": round(1e3 * rs["seconds_decode_cpu"] / max(rs["frames_total"], 1), 3),
                 "colour_fused": int(rs["color_fused"]),
@@ -474,6 +527,14 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
             r["valu_detail"] = valu
         if traffic:
             r["traffic_detail"] = traffic
+        # the kernels in front of the integrate launch (allocation, compaction, pre-pass; one launch each per pass): VALU and HBM figures from the
+        # same counter passes -- each measured ALONE (the profiler serialises kernels); in the shipped schedule they run beside the previous integrate
+        fc = {}
+        for src in (valu, traffic):
+            for k, e in ((src or {}).get("front_chain") or {}).items():
+                fc.setdefault(k, {}).update(e)
+        if fc:
+            r["front_chain"] = fc
         return r
 
     R = 1 if child else (args.repeats if args.repeats else repeats_for(K, cfg_name))
