@@ -30,6 +30,7 @@ extern "C" {
  *   "prepass_fuse" 0/1   one colourless frame per pass: the allocation kernel converts the depth itself (default 1), no separate pre-pass launch
  *   "ramp"        0..32  frames of the FIRST pass of a sf_fuser_integrate_batch_device call (default 8; 0 = a full pass): nothing overlaps that
  *                        pass's pre-pass / allocation, so a short one starts the pipeline sooner
+ *   "ramp_geo"    0/1    the passes behind the first one double (ramp, 2 ramp, 4 ramp, ... batch) instead of jumping to the batch size (default 1)
  * Synchronises the fuser.  SF_ERR_INVALID_ARG for an unknown key or a value out of range. */
 int sf_fuser_tune(sf_fuser* f, const char* key, int value);
 

@@ -2127,7 +2127,7 @@ static int integrate_batch_device(sf_fuser* f, const void* d_depth, uint64_t fra
   const void* dr[MAX_BATCH];
   const float* pp[MAX_BATCH];
   int m = 0;
-  bool first_pass = true;
+  int pass = 0;
   for (uint64_t i = 0; i <= n; i++) {
     if (i < n) {
       if (poses[16 * i] == -INFINITY) { f->frames_skipped++; continue; }  // tracking lost: skip (sensorData.h:382)
@@ -2137,13 +2137,18 @@ static int integrate_batch_device(sf_fuser* f, const void* d_depth, uint64_t fra
       m++;
     }
     // the first pass of a call has nothing to hide its pre-pass / allocation / compaction behind: a short one (f->ramp frames) gets the
-    // integrate stream busy sooner and the full-size passes after it overlap as usual (same voxels under any batching)
-    const int want = (first_pass && f->ramp > 0 && f->ramp < f->batch && n > (uint64_t)f->ramp) ? f->ramp : f->batch;
+    // integrate stream busy sooner, and (ramp_geo) the passes behind it double -- ramp, 2 ramp, 4 ramp ... up to the batch size -- so that the
+    // front chain of pass k + 1 still fits under the integrate launch of pass k (same voxels under any batching)
+    int want = f->batch;
+    if (f->ramp > 0 && f->ramp < f->batch && n > (uint64_t)f->ramp) {
+      if (pass == 0) want = f->ramp;
+      else if (f->ramp_geo && pass < 6) want = std::min(f->batch, f->ramp << pass);
+    }
     if (m == want || (i == n && m > 0)) {
       const int rc = run_batch(f, dd, d_rgb ? dr : nullptr, pp, m, +1);
       if (rc != SF_OK) return rc;
       m = 0;
-      first_pass = false;
+      pass++;
     }
   }
   return SF_OK;
@@ -2229,6 +2234,7 @@ SF_API int sf_fuser_tune(sf_fuser* f, const char* key, int value) {
   }
   else if (k == "alloc_ray" && in(0, 1)) f->alloc_ray = value != 0;   // 1: the ray-space window whatever the geometry (rays outside it take the slow path), 0: the cube window
   else if (k == "ramp" && in(0, MAX_BATCH)) f->ramp = value;
+  else if (k == "ramp_geo" && in(0, 1)) f->ramp_geo = value != 0;
   else return sf::fail(SF_ERR_INVALID_ARG, "sf_fuser_tune: unknown key or value out of range: %s = %d", key, value);
   return SF_OK;
 }

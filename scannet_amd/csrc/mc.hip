@@ -19,6 +19,8 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <sys/mman.h>
+
 #include <algorithm>
 #include <memory>
 #include <thread>
@@ -237,6 +239,12 @@ void team_copy(uint8_t* dst, const uint8_t* src, size_t n) {
 }
 
 int download_segments(sf_fuser* f, hipStream_t s, const DlSeg* segs, int nseg) {
+  // the destinations are fresh anonymous memory: with 4 KiB pages the copy team spends its time in page faults (8 threads: 10 GB/s, less than half
+  // of what the link delivers); ask for transparent huge pages on the 2 MiB-aligned inside of every large array -- 512x fewer faults
+  for (int i = 0; i < nseg; i++) {
+    const uintptr_t a = ((uintptr_t)segs[i].dst + (2u << 20) - 1) & ~(uintptr_t)((2u << 20) - 1), b = ((uintptr_t)segs[i].dst + segs[i].bytes) & ~(uintptr_t)((2u << 20) - 1);
+    if (b > a) (void)madvise((void*)a, (size_t)(b - a), MADV_HUGEPAGE);   // advisory: a kernel without THP just says no
+  }
   for (int q = 0; q < 2; q++) {
     if (!f->mc_bounce[q]) MC_CHECK(hipHostMalloc(&f->mc_bounce[q], DL_CHUNK, hipHostMallocDefault));
     if (!f->mc_bounce_ev[q]) MC_CHECK(hipEventCreateWithFlags(&f->mc_bounce_ev[q], hipEventDisableTiming));
