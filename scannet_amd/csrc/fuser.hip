@@ -467,6 +467,58 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_
 constexpr int RW_LAT_LOG2 = 4, RW_LAT = 1 << RW_LAT_LOG2, RW_DEPTH = 256;
 constexpr int RW_WORDS = RW_DEPTH * RW_LAT * RW_LAT / 32;   // 2048 words = 8 KiB per bitmap
 
+// One ray's walk over the blocks of [d - t, d + t] in WINDOW coordinates, for the window axis AXIS (compile time): slab k along the pencil and
+// the lateral block coordinates relative to the window origin (ru, rv), so that a step costs an add on one of them instead of the whole map.
+// The three-way branch of the reference walk is evaluated as lane masks -- the same comparisons in the same order: x if strictly smallest, else
+// z if smaller than y, else y -- so no lane waits for the branches the others take.  This walk only sets bits; it returns true when the ray left
+// the window (rare: the map follows the camera), and the caller walks such a ray AGAIN for the blocks outside.
+struct RayWalk {
+  int cx, cy, cz, sx, sy, sz, ex, ey, ez;      // first block, step and one-past-the-last block per axis
+  float tmx, tmy, tmz, tdx, tdy, tdz;          // parameter of the next block face / per block, per axis
+};
+struct WindowMap {
+  int k0, sgn, su, ou, fu, sv, ov, fv;
+};
+template <int AXIS>
+__device__ inline bool ray_walk_bits(const RayWalk& r, const WindowMap& w, uint32_t* s_frame, bool no_atomics) {
+  // (a, u, v) = (AXIS, AXIS + 1, AXIS + 2) mod 3
+  const int c_a = AXIS == 0 ? r.cx : (AXIS == 1 ? r.cy : r.cz), c_u = AXIS == 0 ? r.cy : (AXIS == 1 ? r.cz : r.cx), c_v = AXIS == 0 ? r.cz : (AXIS == 1 ? r.cx : r.cy);
+  const int s_a = AXIS == 0 ? r.sx : (AXIS == 1 ? r.sy : r.sz), s_u = AXIS == 0 ? r.sy : (AXIS == 1 ? r.sz : r.sx), s_v = AXIS == 0 ? r.sz : (AXIS == 1 ? r.sx : r.sy);
+  const int e_a = AXIS == 0 ? r.ex : (AXIS == 1 ? r.ey : r.ez), e_u = AXIS == 0 ? r.ey : (AXIS == 1 ? r.ez : r.ex), e_v = AXIS == 0 ? r.ez : (AXIS == 1 ? r.ex : r.ey);
+  int k = w.sgn > 0 ? c_a - w.k0 : w.k0 - c_a;
+  const int k_end = w.sgn > 0 ? e_a - w.k0 : w.k0 - e_a;
+  const int dk = w.sgn > 0 ? s_a : -s_a;
+  int ru = c_u - w.ou, rv = c_v - w.ov;
+  const int ru_end = e_u - w.ou, rv_end = e_v - w.ov;
+  float tmx = r.tmx, tmy = r.tmy, tmz = r.tmz;
+  bool left_window = false;
+  for (int it = 0; it < MAX_DDA_ITERS; ++it) {
+    // (a slab index far outside the window only has to fail the range test: the 24-bit product may be anything there)
+    const uint32_t du = (uint32_t)(ru - ((__mul24(w.su, k) + w.fu) >> 12));
+    const uint32_t dv = (uint32_t)(rv - ((__mul24(w.sv, k) + w.fv) >> 12));
+    const bool inwin = (uint32_t)k < (uint32_t)RW_DEPTH && (du | dv) < (uint32_t)RW_LAT;
+    const uint32_t bit = inwin ? (((uint32_t)k << (2 * RW_LAT_LOG2)) | (dv << RW_LAT_LOG2) | du) : 0xFFFFFFFFu;
+    // lanes whose left neighbour (DPP row_shr:1) sets the same bit stay silent: 64 same-address ds_or serialise (see k_alloc)
+    const uint32_t left = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFEu, (int)bit, 0x111, 0xF, 0xF, false);
+    if (inwin && left != bit && !no_atomics) atomicOr(&s_frame[bit >> 5], 1u << (bit & 31));
+    left_window = left_window || !inwin;
+    const bool go_x = tmx < tmy && tmx < tmz;
+    const bool go_z = !go_x && tmz < tmy;
+    const bool go_y = !go_x && !go_z;
+    tmx += go_x ? r.tdx : 0.0f;   // x + 0 = x: the axes not taken keep their value bit for bit
+    tmy += go_y ? r.tdy : 0.0f;
+    tmz += go_z ? r.tdz : 0.0f;
+    const bool go_a = AXIS == 0 ? go_x : (AXIS == 1 ? go_y : go_z);
+    const bool go_u = AXIS == 0 ? go_y : (AXIS == 1 ? go_z : go_x);
+    k += go_a ? dk : 0;
+    ru += go_u ? s_u : 0;
+    rv += (!go_a && !go_u) ? s_v : 0;
+    const bool done = go_a ? k == k_end : (go_u ? ru == ru_end : rv == rv_end);
+    if (done) break;
+  }
+  return left_window;
+}
+
 template <bool MULTI>
 __global__ __launch_bounds__(256) void k_alloc_ray(const float* __restrict__ depthf_all, HashEntry* table, int32_t* heap,
                                                    uint64_t* block_keys, int32_t* block_entry, uint8_t* block_flags, int32_t* counters, ParamsK P,
@@ -650,47 +702,27 @@ __global__ __launch_bounds__(256) void k_alloc_ray(const float* __restrict__ dep
     // three-way branch of the reference walk is evaluated as three lane masks (the same comparisons in the same order: x if strictly
     // smallest, else z if smaller than y, else y), so no lane waits for the branches the others take.
     if (active && !(ablate & 4)) {
-      // (a, u, v) = (w_axis, w_axis + 1, w_axis + 2) mod 3: uniform permutation of the ray's block coordinates, steps and bounds
-      const int c_a = w_axis == 0 ? a_cx : (w_axis == 1 ? a_cy : a_cz), c_u = w_axis == 0 ? a_cy : (w_axis == 1 ? a_cz : a_cx), c_v = w_axis == 0 ? a_cz : (w_axis == 1 ? a_cx : a_cy);
-      const int s_a = w_axis == 0 ? a_sx : (w_axis == 1 ? a_sy : a_sz), s_u = w_axis == 0 ? a_sy : (w_axis == 1 ? a_sz : a_sx), s_v = w_axis == 0 ? a_sz : (w_axis == 1 ? a_sx : a_sy);
-      const int e_a = w_axis == 0 ? a_ex : (w_axis == 1 ? a_ey : a_ez), e_u = w_axis == 0 ? a_ey : (w_axis == 1 ? a_ez : a_ex), e_v = w_axis == 0 ? a_ez : (w_axis == 1 ? a_ex : a_ey);
-      int k = w_sgn > 0 ? c_a - w_k0 : w_k0 - c_a;
-      const int k_end = w_sgn > 0 ? e_a - w_k0 : w_k0 - e_a;
-      const int dk = w_sgn > 0 ? s_a : -s_a;
-      int ru = c_u - w_ou, rv = c_v - w_ov;
-      const int ru_end = e_u - w_ou, rv_end = e_v - w_ov;
-      // the hot walk only sets bits; a ray that leaves the window (rare: the map follows the camera) is walked AGAIN below for the blocks outside
-      const int k_first = k, ru_first = ru, rv_first = rv;
-      const float tmx0 = a_tmx, tmy0 = a_tmy, tmz0 = a_tmz;
-      bool left_window = false;
-      for (int it = 0; it < MAX_DDA_ITERS; ++it) {
-        // (a slab index far outside the window only has to fail the range test: the 24-bit product may be anything there)
-        const uint32_t du = (uint32_t)(ru - ((__mul24(w_su, k) + w_fu) >> 12));
-        const uint32_t dv = (uint32_t)(rv - ((__mul24(w_sv, k) + w_fv) >> 12));
-        const bool inwin = (uint32_t)k < (uint32_t)RW_DEPTH && (du | dv) < (uint32_t)RW_LAT;
-        const uint32_t bit = inwin ? (((uint32_t)k << (2 * RW_LAT_LOG2)) | (dv << RW_LAT_LOG2) | du) : 0xFFFFFFFFu;
-        // lanes whose left neighbour (DPP row_shr:1) sets the same bit stay silent: 64 same-address ds_or serialise (see k_alloc)
-        const uint32_t left = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFEu, (int)bit, 0x111, 0xF, 0xF, false);
-        if (inwin && left != bit && !(ablate & 1)) atomicOr(&s_frame[bit >> 5], 1u << (bit & 31));
-        left_window = left_window || !inwin;
-        const bool go_x = a_tmx < a_tmy && a_tmx < a_tmz;
-        const bool go_z = !go_x && a_tmz < a_tmy;
-        const bool go_y = !go_x && !go_z;
-        a_tmx += go_x ? a_tdx : 0.0f;   // x + 0 = x: the axes not taken keep their value bit for bit
-        a_tmy += go_y ? a_tdy : 0.0f;
-        a_tmz += go_z ? a_tdz : 0.0f;
-        const bool go_a = w_axis == 0 ? go_x : (w_axis == 1 ? go_y : go_z);
-        const bool go_u = w_axis == 0 ? go_y : (w_axis == 1 ? go_z : go_x);
-        k += go_a ? dk : 0;
-        ru += go_u ? s_u : 0;
-        rv += (!go_a && !go_u) ? s_v : 0;
-        const bool done = go_a ? k == k_end : (go_u ? ru == ru_end : rv == rv_end);
-        if (done) break;
-      }
-      if (left_window) {   // the same walk once more, this time for the blocks OUTSIDE the window: LDS hash set, then the global table
-        k = k_first; ru = ru_first; rv = rv_first;
-        a_tmx = tmx0; a_tmy = tmy0; a_tmz = tmz0;
+      // The axis the window runs along is the same for every lane of the workgroup (a scalar): the hot walk is compiled THREE times, once per
+      // axis, and chosen by a scalar branch -- inside each copy "the window axis" is a compile-time name for one of x / y / z, so a step's
+      // "which coordinate moves" is the very lane mask its comparison produced.  (With w_axis as a run-time select on the three masks the
+      // compiler materialised them into registers and picked among them with vector selects: 11 of the 48 vector instructions of a step.)
+      const RayWalk rw{a_cx, a_cy, a_cz, a_sx, a_sy, a_sz, a_ex, a_ey, a_ez, a_tmx, a_tmy, a_tmz, a_tdx, a_tdy, a_tdz};
+      const WindowMap wm{w_k0, w_sgn, w_su, w_ou, w_fu, w_sv, w_ov, w_fv};
+      bool left_window;
+      if (w_axis == 0) left_window = ray_walk_bits<0>(rw, wm, s_frame, (ablate & 1) != 0);
+      else if (w_axis == 1) left_window = ray_walk_bits<1>(rw, wm, s_frame, (ablate & 1) != 0);
+      else left_window = ray_walk_bits<2>(rw, wm, s_frame, (ablate & 1) != 0);
+      if (left_window) {   // the same walk once more (one copy, the axis a run-time value), this time for the blocks OUTSIDE the window: LDS hash set, then the global table
+        const int c_a = w_axis == 0 ? a_cx : (w_axis == 1 ? a_cy : a_cz), c_u = w_axis == 0 ? a_cy : (w_axis == 1 ? a_cz : a_cx), c_v = w_axis == 0 ? a_cz : (w_axis == 1 ? a_cx : a_cy);
+        const int s_a = w_axis == 0 ? a_sx : (w_axis == 1 ? a_sy : a_sz), s_u = w_axis == 0 ? a_sy : (w_axis == 1 ? a_sz : a_sx), s_v = w_axis == 0 ? a_sz : (w_axis == 1 ? a_sx : a_sy);
+        const int e_a = w_axis == 0 ? a_ex : (w_axis == 1 ? a_ey : a_ez), e_u = w_axis == 0 ? a_ey : (w_axis == 1 ? a_ez : a_ex), e_v = w_axis == 0 ? a_ez : (w_axis == 1 ? a_ex : a_ey);
+        int k = w_sgn > 0 ? c_a - w_k0 : w_k0 - c_a;
+        const int k_end = w_sgn > 0 ? e_a - w_k0 : w_k0 - e_a;
+        const int dk = w_sgn > 0 ? s_a : -s_a;
+        int ru = c_u - w_ou, rv = c_v - w_ov;
+        const int ru_end = e_u - w_ou, rv_end = e_v - w_ov;
         uint64_t last_key = KEY_EMPTY;
+#pragma unroll 1
         for (int it = 0; it < MAX_DDA_ITERS; ++it) {
           const uint32_t du = (uint32_t)(ru - ((__mul24(w_su, k) + w_fu) >> 12));
           const uint32_t dv = (uint32_t)(rv - ((__mul24(w_sv, k) + w_fv) >> 12));
@@ -704,6 +736,7 @@ __global__ __launch_bounds__(256) void k_alloc_ray(const float* __restrict__ dep
               if (slab_owns(P, cx, cy, cz) && block_in_frustum(P, F, cx, cy, cz)) {
                 uint32_t sl = ((uint32_t)(key ^ (key >> 21) ^ (key >> 42)) * 2654435761u) >> 24;  // 8 bits
                 bool placed = false;
+#pragma unroll 1
                 for (int pr = 0; pr < ALLOC_SET_PROBES; ++pr) {
                   const unsigned long long old = atomicCAS(&s_keys[sl], (unsigned long long)KEY_EMPTY, (unsigned long long)key);
                   if (old == key) { placed = true; break; }  // queued by an earlier step / ray / frame

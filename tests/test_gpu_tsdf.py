@@ -79,7 +79,7 @@ def test_batched_pass_equals_frame_by_frame(oracle):
     op, gp = _mk(oracle, W, H, voxel=0.008, num_sdf_blocks=1 << 17)
     ovol = oracle.Volume(op, threads=8)
     idx = [0, 1, 2, 300, 301, 3, 600, 601, 900, 4, 5, 1100, 302, 303, 6, 7, 8, 602, 9, 901, 902, 10, 11,
-           12, 13, 304, 305, 14, 603, 604, 15, 16, 903, 17, 18, 1101, 19, 306, 20, 21, 605, 22, 23, 904, 24, 25, 26]  # 47 frames: passes of 8 (ramp), 32 and 7
+           12, 13, 304, 305, 14, 603, 604, 15, 16, 903, 17, 18, 1101, 19, 306, 20, 21, 605, 22, 23, 904, 24, 25, 26]  # 47 frames: passes of 8 (ramp), 16 and 23
     depth = np.zeros((len(idx), H, W), np.uint16)
     poses = np.zeros((len(idx), 16), np.float32)
     last = None
