@@ -43,6 +43,11 @@ int sf_fuser_alloc_direct_count(sf_fuser* f, uint64_t* out);
  * arrays allocated + downloads awaited; then [9] live blocks, [10] triangles, [11] welded vertices.  n <= 12 values are written. */
 int sf_fuser_mc_timing(const sf_fuser* f, double* out, int n);
 
+/* One baseline-JPEG picture through the whole DEVICE path of the frame pipeline: headers parsed and the byte stuffing removed on the host, entropy
+ * decoding (csrc/jpeg_huff_gpu.hip) and reconstruction (csrc/jpeg_gpu.hip) on GPU `device`; the bytes are sf_jpeg_decode's.  SF_ERR_UNSUPPORTED
+ * for what the device's entropy decoder leaves to the host (restart intervals, sampling factors above 2), SF_ERR_FORMAT for a corrupt stream. */
+int sf_jpeg_decode_gpu_huffman(const uint8_t* data, uint64_t bytes, uint32_t width, uint32_t height, int device, uint8_t* dst_rgb);
+
 /* Kernel timing with HIP events on the fuser's stream: when enabled, every integrate launch is bracketed
  * by an event pair; sf_fuser_profile_read sums and clears them (synchronises). */
 int sf_fuser_profile_enable(sf_fuser* f, int on);

@@ -59,16 +59,21 @@ def jpeg_encode(rgb, quality=90, subsample=True):
     return out[:n.value].tobytes()
 
 
-def jpeg_decode(blob, width, height, device=None):
-    """Baseline JPEG -> [H, W, 3] uint8: on the host (device=None: what sf_sens_decode_color runs), or entropy decoding on the host and
-    reconstruction on GPU `device` (the split sf_fuse_run uses) -- the same bytes either way."""
+def jpeg_decode(blob, width, height, device=None, device_huffman=False):
+    """Baseline JPEG -> [H, W, 3] uint8: on the host (device=None: what sf_sens_decode_color runs); entropy decoding on the host and
+    reconstruction on GPU `device`; or (device_huffman) entropy decoding on the GPU too -- what sf_fuse_run does with a colour frame, the host
+    only parses the headers.  The same bytes every way; device_huffman raises ScanfuseError (unsupported) for restart intervals, which
+    sf_fuse_run entropy-decodes on the host."""
     L = _lib()
     b = np.frombuffer(blob, np.uint8)
     out = np.empty((height, width, 3), np.uint8)
     L.sf_jpeg_decode.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
     L.sf_jpeg_decode_gpu.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+    L.sf_jpeg_decode_gpu_huffman.argtypes = L.sf_jpeg_decode_gpu.argtypes
     if device is None:
         check(L.sf_jpeg_decode(b.ctypes.data, b.size, width, height, out.ctypes.data))
+    elif device_huffman:
+        check(L.sf_jpeg_decode_gpu_huffman(b.ctypes.data, b.size, width, height, int(device), out.ctypes.data))
     else:
         check(L.sf_jpeg_decode_gpu(b.ctypes.data, b.size, width, height, int(device), out.ctypes.data))
     return out

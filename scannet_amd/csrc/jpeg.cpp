@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "common.h"
+#include "jpeg_huff.h"
 #include "jpeg_idct.h"
 
 namespace {
@@ -190,7 +191,8 @@ void idct_block(int* blk, bool dc_only, uint8_t* out, int stride) {
 // dst != nullptr: decode to RGB.  dst == nullptr: entropy-decode only -- the layout goes to *L, block table and non-zero quantised
 // coefficients behind it (payload: SfJpegLayout, table, entries; the GPU reconstructs: jpeg_gpu.hip); SF_ERR_UNSUPPORTED when the layout is
 // one the GPU path does not take or the payload does not fit payload_capacity bytes.
-static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t expect_w, uint32_t expect_h, uint8_t* payload, uint64_t payload_capacity) {
+static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t expect_w, uint32_t expect_h, uint8_t* payload, uint64_t payload_capacity,
+                       bool prepare_only = false) {
   SfJpegLayout* L = reinterpret_cast<SfJpegLayout*>(payload);
   uint32_t* table = nullptr;
   uint32_t* entries = nullptr;
@@ -303,6 +305,50 @@ static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t e
       for (int z = 0; z < 64; z++) L->q[i][z] = qt[comp[i].tq][z];
     }
     L->nblocks = nb;
+    if (prepare_only) {
+      // jpeg_prepare_huff: nothing is decoded here -- the layout, the Huffman tables per component, the shape of an MCU and the entropy-coded
+      // segment with its byte stuffing removed go to the device, which decodes it (jpeg_huff.h / jpeg_huff_gpu.hip)
+      if (restart) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: restart intervals take the host entropy decoder");
+      if (sizeof(SfJpegLayout) + sizeof(SfJpegHuffDesc) + 16 > payload_capacity) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: payload too small");
+      SfJpegHuffDesc* D = reinterpret_cast<SfJpegHuffDesc*>(payload + sizeof(SfJpegLayout));
+      std::memset(D, 0, sizeof(*D));
+      D->total_blocks = nb;
+      D->mcux = (uint32_t)mcux;
+      int bpm = 0;
+      for (int i = 0; i < ncomp; i++)
+        for (int by = 0; by < comp[i].v; by++)
+          for (int bx = 0; bx < comp[i].h; bx++) {
+            if (bpm >= JH_MAX_MCU_BLOCKS) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: more than 10 blocks per MCU");
+            D->comp_of[bpm] = (uint8_t)i; D->bx_of[bpm] = (uint8_t)bx; D->by_of[bpm] = (uint8_t)by;
+            bpm++;
+          }
+      D->blocks_per_mcu = (uint32_t)bpm;
+      if ((uint32_t)(mcux * mcuy * bpm) != nb) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: block count does not match the MCU grid");
+      auto put = [](SfJpegHuffTable& t, const HuffDC_AC& h) {
+        std::memcpy(t.look, h.look, sizeof(t.look));
+        for (int l = 0; l < 18; l++) t.maxcode[l] = h.maxcode[l];
+        for (int l = 0; l < 17; l++) { t.mincode[l] = h.mincode[l]; t.valptr[l] = h.valptr[l]; }
+        std::memcpy(t.vals, h.vals, 256);
+      };
+      for (int i = 0; i < ncomp; i++) { put(D->dc[i], hdc[comp[i].td]); put(D->ac[i], hac[comp[i].ta]); }
+      uint8_t* ecs = payload + sizeof(SfJpegLayout) + sizeof(SfJpegHuffDesc);
+      const uint64_t cap = payload_capacity - sizeof(SfJpegLayout) - sizeof(SfJpegHuffDesc);
+      uint64_t w = 0;
+      for (uint64_t i = pos; i < n; i++) {
+        const uint8_t b = data[i];
+        if (b == 0xFF) {
+          if (i + 1 < n && data[i + 1] == 0x00) i++;   // stuffed zero
+          else break;                                   // a marker ends the segment (EOI; RSTn cannot occur: no restart interval)
+        }
+        if (w + 16 > cap) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: the entropy-coded segment does not fit the payload");
+        ecs[w++] = b;
+      }
+      D->ecs_bytes = (uint32_t)w;
+      while (w & 3) ecs[w++] = 0;
+      for (int i = 0; i < 8; i++) ecs[w++] = 0;
+      D->ecs_words = (uint32_t)(w / 4);
+      return SF_OK;
+    }
     if (sizeof(SfJpegLayout) + 4ull * nb > payload_capacity) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: the block table does not fit the payload");
     table = reinterpret_cast<uint32_t*>(payload + sizeof(SfJpegLayout));
     entries = table + nb;
@@ -468,6 +514,13 @@ int jpeg_decode_rgb(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t expe
 int jpeg_decode_coef(const uint8_t* data, uint64_t n, uint32_t expect_w, uint32_t expect_h, uint8_t* payload, uint64_t payload_capacity) {
   if (!payload) return sf::fail(SF_ERR_INVALID_ARG, "jpeg_decode_coef: NULL argument");
   return decode_impl(data, n, nullptr, expect_w, expect_h, payload, payload_capacity);
+}
+
+// nothing decoded: SfJpegLayout + SfJpegHuffDesc + the unstuffed entropy-coded segment, for the device's entropy decoder (jpeg_huff_gpu.hip).
+// SF_ERR_UNSUPPORTED for what that decoder leaves to the host (restart intervals, sampling factors above 2, a segment larger than the payload).
+int jpeg_prepare_huff(const uint8_t* data, uint64_t n, uint32_t expect_w, uint32_t expect_h, uint8_t* payload, uint64_t payload_capacity) {
+  if (!payload) return sf::fail(SF_ERR_INVALID_ARG, "jpeg_prepare_huff: NULL argument");
+  return decode_impl(data, n, nullptr, expect_w, expect_h, payload, payload_capacity, true);
 }
 
 // Baseline JPEG -> RGB on the host (what sf_sens_decode_color does for a TYPE_JPEG frame)

@@ -19,11 +19,15 @@
 #include <vector>
 
 #include "fuser_internal.h"
+#include "jpeg_huff.h"
 #include "jpeg_idct.h"
 #include "sens.h"
 
 int sf_fuser_run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb, const float* const* poses, int n);  // fuser.hip
 int jpeg_decode_coef(const uint8_t* data, uint64_t n, uint32_t expect_w, uint32_t expect_h, uint8_t* payload, uint64_t payload_capacity);  // jpeg.cpp
+int jpeg_prepare_huff(const uint8_t* data, uint64_t n, uint32_t expect_w, uint32_t expect_h, uint8_t* payload, uint64_t payload_capacity);  // jpeg.cpp
+int jpeg_gpu_huffman(hipStream_t stream, int n, const uint8_t* const* d_prepared, uint8_t* const* d_payload, const uint32_t* max_entries, const int32_t* tags,
+                     int32_t* d_status);  // jpeg_huff_gpu.hip
 int jpeg_gpu_reconstruct(hipStream_t stream, int n, const uint8_t* const* d_payload, uint8_t* const* d_rgb, uint8_t* const* d_planes, uint32_t max_blocks,
                          uint32_t max_width, uint32_t max_height);  // jpeg_gpu.hip
 
@@ -39,7 +43,9 @@ struct BatchSlot {
   bool used[2] = {false, false};
   std::atomic<int> decoded{0};    // frames of the current generation the pool has finished with
   std::atomic<int> failed{0};
-  uint8_t coef_mode[MAX_BATCH] = {0};    // per frame: 1 = the pinned colour payload holds JPEG coefficients (GPU reconstructs), 0 = RGB
+  // per frame, what the pinned colour area holds: 0 = RGB; 1 = JPEG coefficients (the host entropy-decoded, the GPU reconstructs);
+  // 2 = the entropy-coded segment, prepared (the GPU decodes AND reconstructs)
+  uint8_t coef_mode[MAX_BATCH] = {0};
   uint32_t pay_used[MAX_BATCH] = {0};    // bytes of that payload
 };
 
@@ -95,6 +101,10 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   // JPEG colour: the host threads only entropy-decode; the coefficients travel in place of the pixels and the GPU reconstructs
   // (jpeg_gpu.hip).  The payload is sized from the first colour frame's layout (a scan's frames share it); a frame that does not fit,
   // or has a layout the GPU path does not take, is decoded on the host as before.  SF_JPEG_HOST=1: always decode on the host.
+  // SF_JPEG_GPU_HUFFMAN=1: a host thread only parses the headers and strips the byte stuffing (jpeg_prepare_huff), the entropy-coded
+  // segment travels and the GPU entropy-decodes too (jpeg_huff_gpu.hip; frames with restart intervals stay with the host threads).  Same
+  // bytes; measured SLOWER with 16 host threads (6.1 k against 7.5 k frames/s at 1296x968: 1.25 ms per 16 pictures on 16 CUs) -- it is
+  // for hosts with few cores, and opt-in until the kernel is spread over more CUs.
   size_t pay_b = 0, planes_b = 0;
   uint32_t pay_blocks = 0;
   if (jpeg_colour && std::getenv("SF_JPEG_HOST") == nullptr) {
@@ -114,6 +124,9 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
     }
   }
   const bool gpu_jpeg = pay_b != 0;
+  const bool gpu_huffman = gpu_jpeg && std::getenv("SF_JPEG_GPU_HUFFMAN") != nullptr;
+  const uint32_t pay_entries = gpu_jpeg ? (uint32_t)((pay_b - sizeof(SfJpegLayout) - 4 * (size_t)pay_blocks) / 4) : 0u;
+  int32_t* d_jstatus = nullptr;   // 2 ints per ring slot and frame, written by the device's entropy decoder only when a picture fails
   const size_t slot_depth = (depth_b * B + 255) & ~(size_t)255, slot_planes = planes_b * B;
   // pinned slot: depth, then per frame ONE colour area that holds either pixels or coefficients (col_b = the larger of the two);
   // device slot: depth, pixels, coefficients, planes scratch
@@ -135,6 +148,7 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
     }
     if (h_pool) (void)hipHostFree(h_pool);
     if (d_pool) (void)hipFree(d_pool);
+    if (d_jstatus) (void)hipFree(d_jstatus);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (copy_stream2) (void)hipStreamDestroy(copy_stream2);
   };
@@ -147,6 +161,10 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   RUN_CHECK(hipStreamCreateWithFlags(&copy_stream2, hipStreamNonBlocking));
   RUN_CHECK(hipHostMalloc((void**)&h_pool, (size_t)NB * slot_b, hipHostMallocDefault));
   RUN_CHECK(hipMalloc((void**)&d_pool, (size_t)NB * dslot_b));
+  if (gpu_huffman) {
+    RUN_CHECK(hipMalloc((void**)&d_jstatus, (size_t)NB * B * 8));
+    RUN_CHECK(hipMemset(d_jstatus, 0, (size_t)NB * B * 8));
+  }
   for (BatchSlot& sl : ring) {
     RUN_CHECK(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
     RUN_CHECK(hipEventCreateWithFlags(&sl.copied_rgb, hipEventDisableTiming));
@@ -178,14 +196,22 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
       if (s->frames[frame].pose[0] != -INFINITY) {
         rc = sens_decode_depth(s, frame, h_depth(sl, j));
         if (rc == SF_OK && use_rgb && s->frames[frame].color_bytes) {
-          bool coef = false;
+          int coef = 0;
           if (gpu_jpeg) {
             uint8_t* pay = h_pay(sl, j);
-            coef = jpeg_decode_coef(s->frames[frame].color, s->frames[frame].color_bytes, s->info.color_width, s->info.color_height, pay, pay_b) == SF_OK &&
-                   reinterpret_cast<const SfJpegLayout*>(pay)->nblocks == pay_blocks;
-            if (coef) ring[(size_t)sl].pay_used[j] = (uint32_t)sf_jpeg_payload_bytes(*reinterpret_cast<const SfJpegLayout*>(pay));
+            const SensFrame& fr = s->frames[frame];
+            if (gpu_huffman && jpeg_prepare_huff(fr.color, fr.color_bytes, s->info.color_width, s->info.color_height, pay, col_b) == SF_OK &&
+                reinterpret_cast<const SfJpegLayout*>(pay)->nblocks == pay_blocks) {
+              coef = 2;
+              ring[(size_t)sl].pay_used[j] = (uint32_t)(sizeof(SfJpegLayout) + sizeof(SfJpegHuffDesc) +
+                                                        4 * (size_t)reinterpret_cast<const SfJpegHuffDesc*>(pay + sizeof(SfJpegLayout))->ecs_words);
+            } else if (jpeg_decode_coef(fr.color, fr.color_bytes, s->info.color_width, s->info.color_height, pay, pay_b) == SF_OK &&
+                       reinterpret_cast<const SfJpegLayout*>(pay)->nblocks == pay_blocks) {
+              coef = 1;
+              ring[(size_t)sl].pay_used[j] = (uint32_t)sf_jpeg_payload_bytes(*reinterpret_cast<const SfJpegLayout*>(pay));
+            }
           }
-          ring[(size_t)sl].coef_mode[j] = coef ? 1 : 0;
+          ring[(size_t)sl].coef_mode[j] = (uint8_t)coef;
           if (!coef) rc = sf_sens_decode_color(s, frame, h_rgb(sl, j));   // raw colour, or a JPEG the GPU path does not take (errors surface here)
         }
       }
@@ -265,9 +291,10 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
       any_rgb = true;
       j = j1;
     }
-    for (int j = 0, k = 0; j < cnt && e == hipSuccess; j++) {   // coefficients: what each entropy-decoded frame really holds, alternating streams
+    for (int j = 0, k = 0; j < cnt && e == hipSuccess; j++) {   // coefficients / entropy-coded segments: what each frame really holds, alternating streams
       if (!rgbf[j] || !bs.coef_mode[j]) continue;
-      e = hipMemcpyAsync(d_pay(sl, j), h_pay(sl, j), bs.pay_used[j], hipMemcpyHostToDevice, (k++ & 1) ? cs_depth : cs_rgb);
+      // a prepared segment lands where the pixels will be written: it is dead once k_jpeg_huff has turned it into the coefficient payload
+      e = hipMemcpyAsync(bs.coef_mode[j] == 2 ? d_rgb(sl, j) : d_pay(sl, j), h_pay(sl, j), bs.pay_used[j], hipMemcpyHostToDevice, (k++ & 1) ? cs_depth : cs_rgb);
       any_rgb = true;
     }
     if (e == hipSuccess && any_rgb) {   // `copied` on the depth stream stands for both parts
@@ -303,7 +330,27 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
         for (int q = jfirst; q < j; q++)
           if (valid[q] && rgbf[q] && bs.coef_mode[q]) { pp_[nj] = d_pay(sl, q); rr_[nj] = d_rgb(sl, q); pl_[nj] = d_planes(sl, q); nj++; }
         bool jpeg_failed = false;
-        for (int q0 = 0; q0 < nj; q0 += 16) {   // jpeg_gpu.hip reconstructs at most 16 frames per launch
+        {   // entropy decoding of the frames that travelled as segments: one 1024-lane workgroup per picture, 16 pictures per launch
+          const uint8_t* seg[16];
+          uint8_t* out[16];
+          uint32_t cap[16];
+          int32_t tag[16];
+          int nh = 0, slot0 = 0;
+          auto flush = [&]() {
+            if (nh == 0 || jpeg_failed) return;
+            const int rch = jpeg_gpu_huffman(in_stream, nh, seg, out, cap, tag, d_jstatus + 2 * ((size_t)sl * B + (size_t)slot0));
+            if (rch != SF_OK) { result = rch; err = sf_last_error(); jpeg_failed = true; }
+            nh = 0;
+          };
+          for (int q = jfirst; q < j; q++) {
+            if (!(valid[q] && rgbf[q] && bs.coef_mode[q] == 2)) continue;
+            if (nh == 0) slot0 = q;
+            seg[nh] = d_rgb(sl, q); out[nh] = d_pay(sl, q); cap[nh] = pay_entries; tag[nh] = (int32_t)(first + g * (uint64_t)B + (uint64_t)q);
+            if (++nh == 16) flush();
+          }
+          flush();
+        }
+        for (int q0 = 0; q0 < nj && !jpeg_failed; q0 += 16) {   // jpeg_gpu.hip reconstructs at most 16 frames per launch
           const int rcj = jpeg_gpu_reconstruct(in_stream, std::min(16, nj - q0), pp_ + q0, rr_ + q0, pl_ + q0, pay_blocks, s->info.color_width, s->info.color_height);
           if (rcj != SF_OK) { result = rcj; err = sf_last_error(); jpeg_failed = true; break; }
         }
@@ -336,6 +383,16 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
                  t_wait_ready, t_api, t_flush, now_s() - t_loop_end, NB, B);
   (void)hipStreamSynchronize(copy_stream);
   (void)hipStreamSynchronize(copy_stream2);
+  if (result == SF_OK && qe == hipSuccess && d_jstatus) {   // a colour frame the device's entropy decoder gave up on fails the run, as it would on the host
+    std::vector<int32_t> st((size_t)NB * B * 2);
+    if (hipMemcpy(st.data(), d_jstatus, st.size() * 4, hipMemcpyDeviceToHost) == hipSuccess)
+      for (size_t i = 0; i < st.size(); i += 2)
+        if (st[i] != 0) {
+          result = SF_ERR_FORMAT;
+          err = "jpeg: colour frame " + std::to_string(st[i + 1]) + ": corrupt or truncated entropy-coded segment (device status " + std::to_string(st[i]) + ")";
+          break;
+        }
+  }
   cleanup();
   if (result != SF_OK) return sf::fail(result, "%s", err.c_str());
   if (qe != hipSuccess) return sf::fail(SF_ERR_DEVICE, "device error while fusing: %s", hipGetErrorString(qe));

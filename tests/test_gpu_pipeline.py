@@ -313,6 +313,59 @@ def test_jpeg_gpu_reconstruction_equals_the_host_decoder():
         calibrate.jpeg_decode(b"\xff\xd8 not a jpeg", 8, 8, device=0)
 
 
+def test_jpeg_gpu_entropy_decoding_equals_the_host_decoder():
+    """sf_jpeg_decode_gpu_huffman -- headers on the host, Huffman decoding by 1024 lanes per picture (csrc/jpeg_huff_gpu.hip: speculative chunk
+    states iterated to their fixed point, prefix sums, a second decode that writes) and reconstruction on the GPU: what sf_fuse_run does with a
+    colour frame -- returns the host decoder's bytes.  4:4:4 / 4:2:2 / 4:2:0 / 4:4:0 / grey, optimised (per-picture) Huffman tables, sizes
+    that are not multiples of the MCU, one-MCU and one-chunk pictures, q 30 (short chunks, many rounds) to q 100 (every coefficient coded),
+    noise (long codes), ScanNet's 1296x968.  Restart intervals are refused (sf_fuse_run decodes those on the host); corrupt streams fail."""
+    import io
+    from PIL import Image
+    from scannet_amd import calibrate
+    from scannet_amd._abi import ScanfuseError
+    from tests import jpeg_tools
+    rng = np.random.default_rng(11)
+    cases = 0
+    for (W, H) in ((136, 104), (133, 99), (64, 48), (17, 9), (1, 1), (8, 8), (1296, 968)):
+        img = _smooth_image(W, H, cases)
+        noisy = np.clip(img.astype(np.int32) + rng.integers(-40, 41, img.shape), 0, 255).astype(np.uint8)
+        blobs = []
+        for sub in (0, 1, 2):
+            for q, opt, pic in ((88, False, img), (30, True, img), (100, False, noisy), (95, True, noisy)):
+                if W > 1000 and (q == 100 or sub == 0):
+                    continue
+                buf = io.BytesIO()
+                Image.fromarray(pic).save(buf, format="JPEG", quality=q, subsampling=sub, optimize=opt)
+                blobs.append(buf.getvalue())
+        buf = io.BytesIO()
+        Image.fromarray(noisy[..., 0]).save(buf, format="JPEG", quality=80)          # one component
+        blobs.append(buf.getvalue())
+        blobs.append(calibrate.jpeg_encode(img, 92, True))
+        blobs.append(calibrate.jpeg_encode(noisy, 75, False))
+        if W < 1000:
+            blobs.append(jpeg_tools.encode(noisy, ((1, 2), (1, 1), (1, 1)), qstep=3))          # 4:4:0
+            blobs.append(jpeg_tools.encode(img, ((1, 1), (2, 2), (2, 2)), qstep=5))            # chroma finer than luma
+        for b in blobs:
+            host = calibrate.jpeg_decode(b, W, H)
+            gpu = calibrate.jpeg_decode(b, W, H, device=0, device_huffman=True)
+            assert np.array_equal(host, gpu), "%dx%d case %d: %d bytes differ" % (W, H, cases, (host != gpu).sum())
+            cases += 1
+    assert cases == 6 * 17 + 9
+    W, H = 136, 104
+    img = _smooth_image(W, H, 2)
+    buf = io.BytesIO()
+    Image.fromarray(img).save(buf, format="JPEG", quality=85, subsampling=2, restart_marker_blocks=3)   # DRI / RSTn: the host's
+    with pytest.raises(ScanfuseError) as ei:
+        calibrate.jpeg_decode(buf.getvalue(), W, H, device=0, device_huffman=True)
+    assert "restart" in str(ei.value)
+    good = calibrate.jpeg_encode(img, 90, True)
+    cut = good[: len(good) * 2 // 3] + b"\xff\xd9"                   # the segment ends before the picture does
+    with pytest.raises(ScanfuseError):
+        calibrate.jpeg_decode(cut, W, H, device=0, device_huffman=True)
+    with pytest.raises(ScanfuseError):
+        calibrate.jpeg_decode(b"\xff\xd8 not a jpeg", 8, 8, device=0, device_huffman=True)
+
+
 def test_jpeg_gpu_reconstruction_identical_to_the_reference_decoder(oracle, tmp_path):
     """The GPU reconstruction against the REFERENCE's decoder itself (SensorData::decompressColorAlloc -> stb_image, compiled from the
     reference's sources into oracle/_ref/libref_sens.so, which travels with the snapshot): integer work, identical bytes.  4:4:4 / 4:2:2
@@ -357,9 +410,10 @@ def test_jpeg_gpu_reconstruction_identical_to_the_reference_decoder(oracle, tmp_
     assert n == 27
 
 
-@pytest.mark.parametrize("kind", ["raw", "jpeg", "jpeg_host"])
+@pytest.mark.parametrize("kind", ["raw", "jpeg", "jpeg_gpu_huffman", "jpeg_host"])
 def test_fuse_run_with_colour_matches_frame_by_frame(tmp_path, kind, monkeypatch):
-    """Colour at its own resolution through the threaded pipeline (raw; JPEG with the GPU reconstruction; JPEG decoded on the host):
+    """Colour at its own resolution through the threaded pipeline (raw; JPEG entropy-decoded by the host threads and reconstructed on the
+    GPU; JPEG entropy-decoded on the GPU too (SF_JPEG_GPU_HUFFMAN); JPEG decoded on the host):
     the same voxels, colours included, as integrating the host-decoded frames one by one.  One frame has no pose, one no colour."""
     from scannet_amd import calibrate, fusion, sens
     W, H, CW, CH = 160, 120, 324, 242
@@ -386,6 +440,8 @@ def test_fuse_run_with_colour_matches_frame_by_frame(tmp_path, kind, monkeypatch
     gp.color_width, gp.color_height, gp.cfx, gp.cfy, gp.cmx, gp.cmy = CW, CH, 340.3, 338.1, 160.2, 119.7
     if kind == "jpeg_host":
         monkeypatch.setenv("SF_JPEG_HOST", "1")
+    if kind == "jpeg_gpu_huffman":
+        monkeypatch.setenv("SF_JPEG_GPU_HUFFMAN", "1")
     s = sens.SensorData(p)
     with fusion.Fuser(gp) as a, fusion.Fuser(gp) as b:
         rs = a.run(s, decode_threads=5)

@@ -17,7 +17,7 @@ def main():
     qcol = "queue_id" if "queue_id" in cols else ("queue" if "queue" in cols else None)
     rows = list(db.execute("select %s, start, end%s from kernels order by start" % (name, (", " + qcol) if qcol else "")))
     short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:34]
-    integ = [i for i, r in enumerate(rows) if "k_integrate<1, false" in r[0]]
+    integ = [i for i, r in enumerate(rows) if "k_integrate<1," in r[0]]
     if first is None:
         first = integ[len(integ) // 2] - 4 if integ else 0
     t0 = rows[first][1]
@@ -29,7 +29,7 @@ def main():
     d = [(rows[i][2] - rows[i][1]) / 1e3 for i in integ]
     if g:
         g2 = sorted(g)
-        print("\nk_integrate<1,false,..>: %d launches, duration mean %.1f us; gap to the next launch: median %.1f us, mean %.1f us, p90 %.1f us"
+        print("\nk_integrate<1,..>: %d launches, duration mean %.1f us; gap to the next launch: median %.1f us, mean %.1f us, p90 %.1f us"
               % (len(d), sum(d) / len(d), g2[len(g2) // 2], sum(g) / len(g), g2[int(len(g2) * 0.9)]))
 
 

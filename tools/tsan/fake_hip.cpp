@@ -93,4 +93,6 @@ hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = std::malloc(n); re
 hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
 hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n); return *p ? hipSuccess : 1; }
 hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind) { std::memcpy(dst, src, bytes); return hipSuccess; }
+hipError_t hipMemset(void* dst, int value, size_t bytes) { std::memset(dst, value, bytes); return hipSuccess; }
 void fake_stream_enqueue(hipStream_t s, void (*fn)(void*), void* arg) { s->push([fn, arg] { fn(arg); }); }

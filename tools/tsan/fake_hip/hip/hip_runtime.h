@@ -38,6 +38,8 @@ hipError_t hipHostMalloc(void**, size_t, unsigned);
 hipError_t hipHostFree(void*);
 hipError_t hipMalloc(void**, size_t);
 hipError_t hipFree(void*);
+hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind);
+hipError_t hipMemset(void* dst, int value, size_t bytes);
 
 // for the stubs of the device side (tools/tsan/harness.cpp): run `fn(arg)` on the stream, in order
 void fake_stream_enqueue(hipStream_t, void (*fn)(void*), void* arg);

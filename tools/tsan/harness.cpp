@@ -45,6 +45,7 @@ int sf_fuser_run_batch(sf_fuser* f, const void* const* d_depth, const void* cons
   if (s != f->stream) { hipEventRecord(f->ev_compact[0], s); hipStreamWaitEvent(f->stream, f->ev_compact[0], 0); }
   return SF_OK;
 }
+int jpeg_gpu_huffman(hipStream_t, int, const uint8_t* const*, uint8_t* const*, const uint32_t*, const int32_t*, int32_t*) { return SF_OK; }
 int jpeg_gpu_reconstruct(hipStream_t, int, const uint8_t* const*, uint8_t* const*, uint8_t* const*, uint32_t, uint32_t, uint32_t) { return SF_OK; }   // raw colour in this harness
 
 int main(int argc, char** argv) {
