@@ -43,6 +43,13 @@ int sf_fuser_alloc_direct_count(sf_fuser* f, uint64_t* out);
  * arrays allocated + downloads awaited; then [9] live blocks, [10] triangles, [11] welded vertices.  n <= 12 values are written. */
 int sf_fuser_mc_timing(const sf_fuser* f, double* out, int n);
 
+/* One zlib stream through the DEVICE inflate of the frame pipeline (csrc/inflate_gpu.hip): the bytes are sf_zlib_inflate's.  SF_ERR_UNSUPPORTED
+ * for streams the device leaves to the host inflater (anything but ONE final fixed-Huffman block -- what the reference's writer and this
+ * library's emit; expect_bytes not a multiple of 4), SF_ERR_FORMAT for corrupt streams and streams that inflate to another size. */
+int sf_zlib_inflate_gpu(const void* src, uint64_t src_bytes, uint64_t expect_bytes, int device, void* dst);
+/* The two kernels of that path timed apart (HIP events) on `count` <= 32 resident streams: microseconds per launch (tools/gpu/inflate_bench.py). */
+int sf_zlib_inflate_gpu_bench(const void* const* srcs, const uint64_t* src_bytes, int count, uint64_t expect_bytes, int device, int repeats, double* us_tokens, double* us_copy);
+
 /* One baseline-JPEG picture through the whole DEVICE path of the frame pipeline: headers parsed and the byte stuffing removed on the host, entropy
  * decoding (csrc/jpeg_huff_gpu.hip) and reconstruction (csrc/jpeg_gpu.hip) on GPU `device`; the bytes are sf_jpeg_decode's.  SF_ERR_UNSUPPORTED
  * for what the device's entropy decoder leaves to the host (restart intervals, sampling factors above 2), SF_ERR_FORMAT for a corrupt stream. */

@@ -25,6 +25,9 @@
 
 int sf_fuser_run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb, const float* const* poses, int n);  // fuser.hip
 int jpeg_decode_coef(const uint8_t* data, uint64_t n, uint32_t expect_w, uint32_t expect_h, uint8_t* payload, uint64_t payload_capacity);  // jpeg.cpp
+bool inflate_gpu_takes(const uint8_t* z, uint64_t n);  // inflate_gpu.hip
+int inflate_gpu_batch(hipStream_t stream, int n, const uint32_t* const* d_words, const uint32_t* nbytes, uint8_t* const* d_out, uint16_t* const* d_plan, uint32_t expect,
+                      const int32_t* tags, int32_t* d_status);  // inflate_gpu.hip
 int jpeg_prepare_huff(const uint8_t* data, uint64_t n, uint32_t expect_w, uint32_t expect_h, uint8_t* payload, uint64_t payload_capacity);  // jpeg.cpp
 int jpeg_gpu_huffman(hipStream_t stream, int n, const uint8_t* const* d_prepared, uint8_t* const* d_payload, const uint32_t* max_entries, const int32_t* tags,
                      int32_t* d_status);  // jpeg_huff_gpu.hip
@@ -37,6 +40,7 @@ namespace {
 struct BatchSlot {
   hipEvent_t copied = nullptr;    // H2D of this batch finished (its pinned buffers may be refilled)
   hipEvent_t copied_rgb = nullptr;  // the colour part of it, on the other copy stream
+  hipEvent_t inflated = nullptr;    // the frames that travelled compressed are pixels now (recorded on the inflate stream)
   // pre-pass of this batch finished (its device buffers may be overwritten): one event per input stream a sub-batch of the slot ran on --
   // the fuser orders its two streams among themselves, but the ring does not lean on that
   hipEvent_t consumed[2] = {nullptr, nullptr};
@@ -47,6 +51,10 @@ struct BatchSlot {
   // 2 = the entropy-coded segment, prepared (the GPU decodes AND reconstructs)
   uint8_t coef_mode[MAX_BATCH] = {0};
   uint32_t pay_used[MAX_BATCH] = {0};    // bytes of that payload
+  // per frame, what the pinned depth area holds: 0 = pixels (raw, or inflated / decoded by a host thread); 1 = the zlib stream from its third
+  // byte on (the GPU inflates: inflate_gpu.hip)
+  uint8_t depth_mode[MAX_BATCH] = {0};
+  uint32_t comp_used[MAX_BATCH] = {0};   // bytes of that stream
 };
 
 }  // namespace
@@ -81,6 +89,10 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   // default pool size: inflating a depth frame takes ~0.13 ms, so 32 threads outrun the GPU (measured: 16 threads 28 k frames/s,
   // 64 threads 26 k); baseline-JPEG colour costs milliseconds per frame and takes up to 64 (128 measured slower: 5.0 k vs 8.1 k frames/s)
   const bool jpeg_colour = use_rgb && s->info.color_compression == 2;
+  // zlib depth (the reference's writer: one final fixed-Huffman block per frame) is inflated on the GPU: a host thread only copies the compressed
+  // frame into the pinned ring; streams the device does not take (dynamic / stored / several blocks, longer than the pixels) are inflated by
+  // the host threads as before.  SF_INFLATE_HOST=1: always inflate on the host.
+  const bool gpu_inflate = s->info.depth_compression == 1 && (npx * 2) % 4 == 0 && std::getenv("SF_INFLATE_HOST") == nullptr;
   const int hw = sf::usable_cpus();
   int nthreads = decode_threads > 0 ? decode_threads : std::min(hw, jpeg_colour ? 64 : 32);
   if (nthreads < 1) nthreads = 1;
@@ -91,9 +103,13 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   // enough batch slots for every decode thread to be busy while two batches sit between copy and pre-pass
   // 3 slots (one decoding, one in flight, one being read by the pre-pass) are enough: 4, 6 and 10 measured no faster (tools/gpu/h2d_bw.hip:
   // the link moves 57 GB/s from pinned memory on two streams; a colour run is bound by the fusion kernels and ~15 ms of set-up)
-  const int NB = (int)std::max<uint64_t>(1, std::min<uint64_t>(std::max<uint64_t>(3, ((uint64_t)nthreads + B - 1) / B + 2), std::max<uint64_t>(nbatches, 1)));
+  constexpr int NZ = 3;   // inflate streams: consecutive batches are inflated side by side (a batch takes longer to inflate than to fuse)
+  const int NB = (int)std::max<uint64_t>(1, std::min<uint64_t>(std::max<uint64_t>(gpu_inflate ? 3 + NZ : 3, ((uint64_t)nthreads + B - 1) / B + 2), std::max<uint64_t>(nbatches, 1)));
   std::vector<BatchSlot> ring((size_t)NB);
   hipStream_t copy_stream = nullptr, copy_stream2 = nullptr;   // two streams = two SDMA engines: one alone moves ~20 GB/s
+  hipStream_t inflate_stream[NZ] = {nullptr, nullptr, nullptr};   // batch g is inflated on stream g % NZ, beside the pre-pass / allocation / integration of the batches before it
+  uint8_t* d_plan[NZ] = {nullptr, nullptr, nullptr};              // scratch of the inflate kernels (one u16 per output byte), one per stream
+  int32_t* d_zstatus = nullptr;                                // 2 ints per ring slot and frame, written by the device's inflate only when a frame fails
   // ONE pinned host allocation and ONE device allocation for the whole ring
   uint8_t* h_pool = nullptr;
   uint8_t* d_pool = nullptr;
@@ -132,7 +148,9 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   // device slot: depth, pixels, coefficients, planes scratch
   const size_t col_b = std::max(rgb_b, pay_b), slot_col = (col_b * B + 255) & ~(size_t)255;
   const size_t slot_b = slot_depth + slot_col;
-  const size_t dslot_b = slot_depth + slot_col + (gpu_jpeg ? slot_col : 0) + slot_planes;   // every colour area strides by col_b: runs copy as one piece
+  // a compressed frame on the device: 64-byte aligned with 256 readable bytes behind it (the lanes of k_inflate_tokens fetch 64 bytes at a time, two fetches ahead)
+  const size_t comp_stride = gpu_inflate ? (depth_b + 256 + 63) & ~(size_t)63 : 0, slot_comp = (comp_stride * B + 255) & ~(size_t)255;
+  const size_t dslot_b = slot_depth + slot_col + (gpu_jpeg ? slot_col : 0) + slot_planes + slot_comp;   // every colour area strides by col_b: runs copy as one piece
   auto h_depth = [&](int sl, int j) { return (uint16_t*)(h_pool + (size_t)sl * slot_b + (size_t)j * depth_b); };
   auto d_depth = [&](int sl, int j) { return d_pool + (size_t)sl * dslot_b + (size_t)j * depth_b; };
   auto h_rgb = [&](int sl, int j) { return h_pool + (size_t)sl * slot_b + slot_depth + (size_t)j * col_b; };
@@ -140,15 +158,20 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   auto h_pay = h_rgb;
   auto d_pay = [&](int sl, int j) { return d_pool + (size_t)sl * dslot_b + slot_depth + slot_col + (size_t)j * col_b; };
   auto d_planes = [&](int sl, int j) { return d_pool + (size_t)sl * dslot_b + slot_depth + 2 * slot_col + (size_t)j * planes_b; };
+  auto d_comp = [&](int sl, int j) { return d_pool + (size_t)(sl + 1) * dslot_b - slot_comp + (size_t)j * comp_stride; };   // the compressed frames, behind everything else of the slot
   auto cleanup = [&]() {
     for (BatchSlot& sl : ring) {
       if (sl.copied) (void)hipEventDestroy(sl.copied);
       if (sl.copied_rgb) (void)hipEventDestroy(sl.copied_rgb);
+      if (sl.inflated) (void)hipEventDestroy(sl.inflated);
       for (hipEvent_t ev : sl.consumed) if (ev) (void)hipEventDestroy(ev);
     }
     if (h_pool) (void)hipHostFree(h_pool);
     if (d_pool) (void)hipFree(d_pool);
     if (d_jstatus) (void)hipFree(d_jstatus);
+    for (uint8_t* q : d_plan) if (q) (void)hipFree(q);
+    if (d_zstatus) (void)hipFree(d_zstatus);
+    for (hipStream_t q : inflate_stream) if (q) (void)hipStreamDestroy(q);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (copy_stream2) (void)hipStreamDestroy(copy_stream2);
   };
@@ -161,6 +184,14 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   RUN_CHECK(hipStreamCreateWithFlags(&copy_stream2, hipStreamNonBlocking));
   RUN_CHECK(hipHostMalloc((void**)&h_pool, (size_t)NB * slot_b, hipHostMallocDefault));
   RUN_CHECK(hipMalloc((void**)&d_pool, (size_t)NB * dslot_b));
+  if (gpu_inflate) {
+    for (int q = 0; q < NZ; q++) {
+      RUN_CHECK(hipStreamCreateWithFlags(&inflate_stream[q], hipStreamNonBlocking));
+      RUN_CHECK(hipMalloc((void**)&d_plan[q], 2 * depth_b * (size_t)B));
+    }
+    RUN_CHECK(hipMalloc((void**)&d_zstatus, (size_t)NB * B * 8));
+    RUN_CHECK(hipMemset(d_zstatus, 0, (size_t)NB * B * 8));
+  }
   if (gpu_huffman) {
     RUN_CHECK(hipMalloc((void**)&d_jstatus, (size_t)NB * B * 8));
     RUN_CHECK(hipMemset(d_jstatus, 0, (size_t)NB * B * 8));
@@ -168,6 +199,7 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   for (BatchSlot& sl : ring) {
     RUN_CHECK(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
     RUN_CHECK(hipEventCreateWithFlags(&sl.copied_rgb, hipEventDisableTiming));
+    RUN_CHECK(hipEventCreateWithFlags(&sl.inflated, hipEventDisableTiming));
     RUN_CHECK(hipEventCreateWithFlags(&sl.consumed[0], hipEventDisableTiming));
     RUN_CHECK(hipEventCreateWithFlags(&sl.consumed[1], hipEventDisableTiming));
   }
@@ -194,7 +226,18 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
       const auto t0 = std::chrono::steady_clock::now();
       int rc = SF_OK;
       if (s->frames[frame].pose[0] != -INFINITY) {
-        rc = sens_decode_depth(s, frame, h_depth(sl, j));
+        const SensFrame& fd = s->frames[frame];
+        if (gpu_inflate && fd.depth && fd.depth_bytes - 2 <= depth_b && inflate_gpu_takes(fd.depth, fd.depth_bytes)) {
+          uint8_t* dst = reinterpret_cast<uint8_t*>(h_depth(sl, j));
+          const size_t nb = (size_t)fd.depth_bytes - 2;
+          std::memcpy(dst, fd.depth + 2, nb);
+          for (size_t q = nb; q & 3; q++) dst[q] = 0;   // the device reads whole words (depth_b is a multiple of 4: there is room)
+          ring[(size_t)sl].depth_mode[j] = 1;
+          ring[(size_t)sl].comp_used[j] = (uint32_t)nb;
+        } else {
+          ring[(size_t)sl].depth_mode[j] = 0;
+          rc = sens_decode_depth(s, frame, h_depth(sl, j));
+        }
         if (rc == SF_OK && use_rgb && s->frames[frame].color_bytes) {
           int coef = 0;
           if (gpu_jpeg) {
@@ -273,12 +316,18 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
       rgbf[j] = valid[j] && use_rgb && s->frames[frame].color_bytes != 0;
       if (!valid[j]) { n_skip++; f->frames_skipped++; }
     }
-    for (int j = 0; j < cnt && e == hipSuccess;) {
-      if (!valid[j]) { j++; continue; }
+    bool any_comp = false;
+    for (int j = 0; j < cnt && e == hipSuccess;) {   // pixels: runs of frames a host thread decoded
+      if (!valid[j] || bs.depth_mode[j]) { j++; continue; }
       int j1 = j;
-      while (j1 < cnt && valid[j1]) j1++;
+      while (j1 < cnt && valid[j1] && !bs.depth_mode[j1]) j1++;
       e = hipMemcpyAsync(d_depth(sl, j), h_depth(sl, j), (size_t)(j1 - j) * depth_b, hipMemcpyHostToDevice, cs_depth);
       j = j1;
+    }
+    for (int j = 0; j < cnt && e == hipSuccess; j++) {   // compressed frames: what each really holds
+      if (!valid[j] || !bs.depth_mode[j]) continue;
+      e = hipMemcpyAsync(d_comp(sl, j), h_depth(sl, j), ((size_t)bs.comp_used[j] + 3) & ~(size_t)3, hipMemcpyHostToDevice, cs_depth);
+      any_comp = true;
     }
     bool any_rgb = false;
     for (int j = 0; j < cnt && e == hipSuccess;) {   // pixels: runs of frames decoded on the host
@@ -304,6 +353,34 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
     if (e == hipSuccess) e = hipEventRecord(bs.copied, cs_depth);
     if (e != hipSuccess) { result = SF_ERR_DEVICE; err = std::string("copy pipeline: ") + hipGetErrorString(e); break; }
     issued.store(g + 1, std::memory_order_release);
+    if (any_comp) {   // inflate on its own stream: 1024 lanes per frame tokenise, one wave per frame copies (inflate_gpu.hip)
+      hipStream_t zs = inflate_stream[g % NZ];
+      uint8_t* zplan = d_plan[g % NZ];
+      e = hipStreamWaitEvent(zs, bs.copied, 0);
+      const uint32_t* zw[32];
+      uint32_t zn[32];
+      uint8_t* zo[32];
+      uint16_t* zb[32];
+      int32_t zt[32];
+      int nz = 0, slot0 = 0;
+      auto flush = [&]() {
+        if (nz == 0 || e != hipSuccess || result != SF_OK) return;
+        const int rcz = inflate_gpu_batch(zs, nz, zw, zn, zo, zb, (uint32_t)depth_b, zt, d_zstatus + 2 * ((size_t)sl * B + (size_t)slot0));
+        if (rcz != SF_OK) { result = rcz; err = sf_last_error(); }
+        nz = 0;
+      };
+      for (int j = 0; j < cnt; j++) {
+        if (!valid[j] || !bs.depth_mode[j]) continue;
+        if (nz == 0) slot0 = j;
+        zw[nz] = reinterpret_cast<const uint32_t*>(d_comp(sl, j)); zn[nz] = bs.comp_used[j]; zo[nz] = d_depth(sl, j);
+        zb[nz] = reinterpret_cast<uint16_t*>(zplan + 2 * depth_b * (size_t)j); zt[nz] = (int32_t)(first + g * (uint64_t)B + (uint64_t)j);
+        if (++nz == 32) flush();
+      }
+      flush();
+      if (e == hipSuccess) e = hipEventRecord(bs.inflated, zs);
+      if (e != hipSuccess) { result = SF_ERR_DEVICE; err = std::string("inflate pipeline: ") + hipGetErrorString(e); }
+      if (result != SF_OK) break;
+    }
     if (timing) t_api += now_s() - t1;
     // ---- kernels: the valid frames in order, a sub-batch is all-colour or all-geometry
     const double t2 = timing ? now_s() : 0;
@@ -321,7 +398,9 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
         j++;
       }
       hipStream_t in_stream = sf_input_stream(f, m, rgb, +1);  // the stream this sub-batch's pre-pass runs on
-      if (hipStreamWaitEvent(in_stream, bs.copied, 0) != hipSuccess) { result = SF_ERR_DEVICE; err = "hipStreamWaitEvent failed"; break; }
+      if (hipStreamWaitEvent(in_stream, bs.copied, 0) != hipSuccess || (any_comp && hipStreamWaitEvent(in_stream, bs.inflated, 0) != hipSuccess)) {
+        result = SF_ERR_DEVICE; err = "hipStreamWaitEvent failed"; break;
+      }
       if (rgb && gpu_jpeg) {   // IDCT + upsampling + colour conversion of this sub-batch's entropy-decoded frames, ahead of its pre-pass
         const uint8_t* pp_[MAX_BATCH];
         uint8_t* rr_[MAX_BATCH];
@@ -383,6 +462,17 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
                  t_wait_ready, t_api, t_flush, now_s() - t_loop_end, NB, B);
   (void)hipStreamSynchronize(copy_stream);
   (void)hipStreamSynchronize(copy_stream2);
+  for (hipStream_t q : inflate_stream) if (q) (void)hipStreamSynchronize(q);
+  if (result == SF_OK && qe == hipSuccess && d_zstatus) {   // a depth frame the device's inflate gave up on fails the run, as it would on the host
+    std::vector<int32_t> st((size_t)NB * B * 2);
+    if (hipMemcpy(st.data(), d_zstatus, st.size() * 4, hipMemcpyDeviceToHost) == hipSuccess)
+      for (size_t i = 0; i < st.size(); i += 2)
+        if (st[i] != 0) {
+          result = SF_ERR_FORMAT;
+          err = "inflate: depth frame " + std::to_string(st[i + 1]) + ": corrupt stream, or it does not inflate to the frame's size (device status " + std::to_string(st[i]) + ")";
+          break;
+        }
+  }
   if (result == SF_OK && qe == hipSuccess && d_jstatus) {   // a colour frame the device's entropy decoder gave up on fails the run, as it would on the host
     std::vector<int32_t> st((size_t)NB * B * 2);
     if (hipMemcpy(st.data(), d_jstatus, st.size() * 4, hipMemcpyDeviceToHost) == hipSuccess)

@@ -38,10 +38,17 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-def zlib_inflate(data, out_bytes):
-    """Inflate a zlib stream into a bytes object of at most out_bytes (no Adler-32 check, like the reference)."""
+def zlib_inflate(data, out_bytes, device=None):
+    """Inflate a zlib stream into a bytes object of at most out_bytes (no Adler-32 check, like the reference).  device=k: on GPU k, the way
+    sf_fuse_run inflates depth frames (csrc/inflate_gpu.hip) -- the stream must be ONE final fixed-Huffman block (what the reference's writer and
+    this library's emit) that inflates to exactly out_bytes, a multiple of 4; ScanfuseError (unsupported) otherwise."""
     src = np.frombuffer(data, np.uint8)
     dst = np.empty(out_bytes, np.uint8)
+    if device is not None:
+        L = _abi.lib()
+        L.sf_zlib_inflate_gpu.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
+        check(L.sf_zlib_inflate_gpu(_ptr(src), len(src), out_bytes, int(device), _ptr(dst)))
+        return dst.tobytes()
     n = C.c_uint64(0)
     check(_abi.lib().sf_zlib_inflate(_ptr(src), len(src), _ptr(dst), out_bytes, C.byref(n)))
     return dst[:n.value].tobytes()

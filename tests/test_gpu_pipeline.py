@@ -55,6 +55,69 @@ def test_fuse_run_matches_frame_by_frame(oracle, tmp_path):
                 d2.run(sd)
 
 
+def _recompress_depth_frames(path, which, how):
+    """Rewrite a .sens (v4 layout, sensorData.h:1250-1290 / :580-598) with the depth blobs of the frames in `which` replaced by how(raw bytes)."""
+    import struct
+    import zlib
+    b = open(path, "rb").read()
+    o = 4
+    (n,) = struct.unpack_from("<Q", b, o)
+    o += 8 + n + 4 * 64 + 4 + 4
+    cw, ch, dw, dh = struct.unpack_from("<IIII", b, o)
+    o += 16 + 4
+    (nf,) = struct.unpack_from("<Q", b, o)
+    o += 8
+    out = bytearray(b[:o])
+    for i in range(nf):
+        head = b[o:o + 64 + 16]
+        cs, ds = struct.unpack_from("<QQ", b, o + 80)
+        col = b[o + 96:o + 96 + cs]
+        dep = b[o + 96 + cs:o + 96 + cs + ds]
+        o += 96 + cs + ds
+        if i in which:
+            dep = how(zlib.decompress(dep))
+        out += head + struct.pack("<QQ", cs, len(dep)) + col + dep
+    out += b[o:]
+    open(path, "wb").write(bytes(out))
+
+
+@pytest.mark.parametrize("where", ["gpu", "host"])
+def test_fuse_run_inflates_depth_on_the_gpu_or_on_the_host(tmp_path, where, monkeypatch):
+    """sf_fuse_run sends zlib depth frames to the GPU compressed (the writer's one fixed-Huffman block: csrc/inflate_gpu.hip) and inflates what
+    the device does not take on the host threads -- here every fifth frame is recompressed by python's zlib (dynamic blocks) and one is stored
+    (level 0) -- or everything on the host (SF_INFLATE_HOST): the same voxels as integrating the decoded frames one by one.  A frame whose stream
+    inflates to the wrong size fails the run on either path."""
+    import zlib
+    from scannet_amd import fusion, sens
+    from tests import deflate_tools as dt
+    W, H = 320, 240
+    p = str(tmp_path / "scene.sens")
+    frames = _write_sens(p, 70, W, H, 1200, invalid=(9,))
+    _recompress_depth_frames(p, set(range(0, 70, 5)) - {35}, lambda raw: zlib.compress(raw, 6))
+    _recompress_depth_frames(p, {35}, lambda raw: zlib.compress(raw, 0))
+    if where == "host":
+        monkeypatch.setenv("SF_INFLATE_HOST", "1")
+    fx, fy, mx, my = synth.intrinsics(W, H)
+    gp = fusion.default_params(depth_width=W, depth_height=H, fx=fx, fy=fy, mx=mx, my=my, voxel_size=0.008, num_sdf_blocks=1 << 17)
+    sd = sens.SensorData(p)
+    with fusion.Fuser(gp) as a, fusion.Fuser(gp) as b:
+        st = a.run(sd, decode_threads=3)
+        assert (st["frames_total"], st["frames_integrated"], st["frames_skipped"]) == (70, 69, 1)
+        for d, pose in frames:
+            b.integrate(d, pose)
+        ca, va = a.export_blocks()
+        cb, vb = b.export_blocks()
+        assert np.array_equal(ca, cb) and np.array_equal(va.view(np.uint8), vb.view(np.uint8))
+    short = str(tmp_path / "short.sens")
+    _write_sens(short, 12, W, H, 1200)
+    short_tokens = list(range(250)) * 4 + [(258, 1000)] * 591 + [(118, 1000)]                # one fixed block that inflates to four bytes less than a frame
+    assert len(dt.apply_tokens(short_tokens)) == W * H * 2 - 4
+    _recompress_depth_frames(short, {7}, lambda raw: dt.zlib_stream(short_tokens))
+    with fusion.Fuser(gp) as c:
+        with pytest.raises(Exception, match="inflate"):
+            c.run(sens.SensorData(short), decode_threads=2)
+
+
 def test_drop_in_executables(tmp_path):
     """`depthsensing p1 p2 scan.sens` -> scan_vh.ply, then `segmentator scan_vh.ply` -> scan_vh.0.010000.segs.json;
     stderr stays empty (Server/util.py:42-44 logs stderr as an error)."""
@@ -311,6 +374,44 @@ def test_jpeg_gpu_reconstruction_equals_the_host_decoder():
         assert np.array_equal(calibrate.jpeg_decode(b, W, H), calibrate.jpeg_decode(b, W, H, device=0))
     with pytest.raises(Exception):
         calibrate.jpeg_decode(b"\xff\xd8 not a jpeg", 8, 8, device=0)
+
+
+def test_gpu_inflate_equals_zlib():
+    """sf_zlib_inflate_gpu -- the depth frames' inflate as sf_fuse_run does it (csrc/inflate_gpu.hip: 1024 lanes tokenise a frame from guessed
+    chunk starts iterated to their fixed point, ONE wave copies in 256-byte groups with the window in LDS) -- returns zlib's bytes: the streams of
+    this library's writer and of the reference's (one final fixed-Huffman block) on depth frames, noise, constants; token lists no match finder
+    would produce (runs that copy themselves, chains of short near matches, the longest distance, distances around the group size); corrupt
+    streams fail with the host inflater's verdict; dynamic / multi-block streams are refused (the pipeline inflates those on the host)."""
+    import zlib
+    from scannet_amd import sens
+    from scannet_amd._abi import ScanfuseError
+    from tests import deflate_tools as dt
+    from tests.test_inflate_lanes import token_cases
+    rng = np.random.default_rng(0)
+    frames = [synth.render_room_depth(synth.trajectory_pose(37 * k, 1200), 640, 480, noise_frame=k).tobytes() for k in range(4)]
+    frames += [bytes(614400), rng.integers(0, 65536, 307200, dtype=np.uint16).tobytes(), (np.arange(76800, dtype=np.uint16) // 7).tobytes(), b"\x01\x02\x03\x04" * 25, b"abcd"]
+    for raw in frames:
+        z = sens.zlib_deflate(raw)
+        assert zlib.decompress(z) == raw
+        assert sens.zlib_inflate(z, len(raw), device=0) == raw
+    for name, tokens in token_cases().items():
+        want = dt.apply_tokens(tokens)
+        pad = (-len(want)) % 4
+        z = dt.zlib_stream(tokens + [0] * pad)
+        assert sens.zlib_inflate(z, len(want) + pad, device=0) == want + bytes(pad), name
+    lits = [int(v) for v in rng.integers(0, 256, 4000)]
+    for bad, word in ((dt.zlib_stream(lits, end=False), "code"),      # "no end-of-block code", or the trailer read as tokens holds "an invalid code" first (dt.zlib_stream(lits[:2000] + [("sym", 286)] + lits[2000:]), "invalid code"),
+                      (dt.zlib_stream(lits[:2000] + [("sym", 257), ("dist", 30)] + lits[2000:]), "invalid code"),
+                      (dt.zlib_stream(lits[:10] + [(5, 11)] + lits[10:3995]), "in front of the output"), (dt.zlib_stream(lits + [1, 2, 3, 4]), "expected size")):
+        with pytest.raises(ScanfuseError) as ei:
+            sens.zlib_inflate(bad, 4000, device=0)
+        assert word in str(ei.value), (word, str(ei.value))
+        with pytest.raises(ScanfuseError):
+            sens.zlib_inflate(bad, 4000)                     # the host inflater agrees
+    for foreign in (zlib.compress(bytes(lits), 6), dt.zlib_stream(lits, header=(0, 1))):
+        with pytest.raises(ScanfuseError) as ei:
+            sens.zlib_inflate(foreign, 4000, device=0)
+        assert "sf_zlib_inflate" in str(ei.value)
 
 
 def test_jpeg_gpu_entropy_decoding_equals_the_host_decoder():

@@ -1,0 +1,101 @@
+"""The lane programs of the device's inflate (scannet_amd/csrc/inflate_lanes.h) on the HOST: tools/inflate_parallelism/emulate_gpu.cpp runs the
+token kernel's 1024 lanes and the copy kernel's 64 lanes in lock step and writes what the device would; this file checks it against zlib.  The
+GPU runs the same header (tests/test_gpu_pipeline.py checks the bytes on the device)."""
+import os
+import re
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from tests import deflate_tools as dt
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def emulate(tmp_path_factory):
+    d = tmp_path_factory.mktemp("inflate_lanes")
+    exe = str(d / "emulate_gpu")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "scannet_amd", "csrc"), os.path.join(ROOT, "tools", "inflate_parallelism", "emulate_gpu.cpp"), "-o", exe],
+                   check=True)
+
+    def run(stream, expect):
+        p, o = str(d / "s.z"), str(d / "s.out")
+        open(p, "wb").write(stream)
+        if os.path.exists(o):
+            os.remove(o)
+        r = subprocess.run([exe, p, str(expect), o], capture_output=True, text=True)
+        return r.returncode, r.stdout, (open(o, "rb").read() if r.returncode == 0 else None)
+    return run
+
+
+def token_cases():
+    """name -> token list: what a match finder would not give us on demand"""
+    rng = np.random.default_rng(3)
+    cases = {}
+    cases["run of one byte"] = [7] + [(258, 1)] * 40 + [(3, 1), 9, 9, 9]                           # every match repeats the byte in front of it
+    cases["run of a pair, odd lengths"] = [1, 2] + [(int(l), 2) for l in rng.integers(3, 259, 300)]
+    t = [int(v) for v in rng.integers(0, 256, 8)]
+    for i in range(4000):                                                                           # chains of short near matches: each copies what the last one wrote
+        t.append((int(rng.integers(3, 7)), int(rng.integers(1, 9))))
+        if i % 5 == 0:
+            t.append(int(rng.integers(0, 256)))
+    cases["chains of short near matches"] = t
+    t = [int(v) for v in rng.integers(0, 256, 32768)]
+    t += [(258, 32768)] * 100 + [(3, 32768), (258, 32767), (17, 24577), (258, 1)]
+    cases["the longest distance"] = t
+    t = [int(v) for v in rng.integers(0, 256, 1300)]
+    for i in range(6000):                                                                           # distances around the group size and its multiples
+        t.append((int(rng.integers(3, 40)), int(rng.choice([255, 256, 257, 511, 512, 513, 1279, 1280, 1281, 4, 3]))))
+    cases["distances around 256"] = t
+    cases["literals only"] = [int(v) for v in rng.integers(0, 256, 5000)]
+    cases["tiny"] = [5, 6, 7, (9, 3)]
+    return cases
+
+
+def test_token_streams_inflate_as_zlib_says(emulate):
+    for name, tokens in token_cases().items():
+        want = dt.apply_tokens(tokens)
+        pad = (-len(want)) % 4
+        tokens = tokens + [0] * pad                       # the device inflates to multiples of 4 bytes (depth frames are)
+        want += bytes(pad)
+        z = dt.zlib_stream(tokens)
+        assert zlib.decompress(z) == want, name           # the helper against zlib
+        rc, text, got = emulate(z, len(want))
+        assert rc == 0, (name, text)
+        assert got == want, name
+
+
+def test_depth_frames_through_this_library_writer(emulate):
+    """The streams the pipeline meets: this library's writer (one fixed block, as stb's) on depth-like frames, noise, constants."""
+    from scannet_amd import sens, synth
+    rng = np.random.default_rng(0)
+    frames = [synth.render_room_depth(synth.trajectory_pose(37, 1200), 320, 240, noise_frame=3).tobytes(), bytes(153600),
+              rng.integers(0, 65536, 76800, dtype=np.uint16).tobytes(), (np.arange(76800, dtype=np.uint16) // 7).tobytes(), b"\x01\x02\x03\x04" * 25]
+    seen = []
+    for raw in frames:
+        z = sens.zlib_deflate(raw)
+        assert zlib.decompress(z) == raw
+        rc, text, got = emulate(z, len(raw))
+        assert rc == 0 and got == raw, text
+        m = re.search(r"chunks (\d+) \| tokens: (\d+) rounds", text)
+        seen.append((int(m.group(1)), int(m.group(2))))
+    assert max(c for c, _ in seen) > 100 and all(r <= 6 for _, r in seen), seen
+
+
+def test_corrupt_and_foreign_streams(emulate):
+    rng = np.random.default_rng(1)
+    lits = [int(v) for v in rng.integers(0, 256, 4000)]
+    ok = dt.zlib_stream(lits)
+    assert emulate(ok, 4000)[0] == 0
+    assert emulate(ok, 4004)[1].strip() == "status -4"                                         # another size than expected
+    assert emulate(dt.zlib_stream(lits, end=False), 4000)[1].strip() == "status -3"            # no end-of-block code
+    assert emulate(dt.zlib_stream(lits[:2000] + [("sym", 286)] + lits[2000:]), 4000)[1].strip() == "status -2"     # a length symbol that does not exist
+    assert emulate(dt.zlib_stream(lits[:2000] + [("sym", 257), ("dist", 30)] + lits[2000:]), 4000)[1].strip() == "status -2"   # a distance code that does not exist
+    assert emulate(dt.zlib_stream(lits[:10] + [(5, 11)] + lits[10:3995]), 4000)[1].strip() == "status -5"          # a match that reaches in front of the output
+    assert emulate(zlib.compress(bytes(lits), 6), 4000)[0] == 2                                # a dynamic block: the host inflater's
+    assert emulate(dt.zlib_stream(lits, header=(0, 1)), 4000)[0] == 2                          # not the final block
+    junk = dt.zlib_stream(lits)[:-4] + bytes(rng.integers(0, 256, 600, dtype=np.uint8))        # whatever follows the end-of-block code is not decoded
+    assert emulate(junk, 4000)[0] == 0

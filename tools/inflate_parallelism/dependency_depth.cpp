@@ -12,10 +12,7 @@ int main(int argc, char** argv) {
   FILE* f = fopen(argv[1], "rb"); fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
   std::vector<uint8_t> src(n); fread(src.data(), 1, n, f); fclose(f);
   uint32_t nbytes = n - 2; std::vector<uint32_t> words((nbytes + 3) / 4 + 2, 0u); memcpy(words.data(), src.data() + 2, nbytes);
-  std::vector<uint32_t> lit(512), dist(32);
-  for (uint32_t i = 0; i < 512; i++) lit[i] = il_lit_entry(i);
-  for (uint32_t i = 0; i < 32; i++) dist[i] = il_dist_entry(i);
-  ILStream s{words.data(), (uint32_t)words.size(), nbytes * 8u, lit.data(), dist.data()};
+  ILStream s{words.data(), (uint32_t)words.size(), nbytes * 8u};
   ILBits b; il_bits_init(s, b, 3);
   std::vector<uint16_t> depth; depth.reserve(700000);
   long nlit = 0, nmatch = 0, mbytes = 0; std::vector<long> hist(4096, 0), lenh(300, 0), disth(20, 0);

@@ -38,10 +38,7 @@ static int emulate(const void* src_, uint64_t n, void* dst, uint64_t dst_cap, ui
   const uint32_t nbytes = (uint32_t)(n - 2);
   std::vector<uint32_t> words((nbytes + 3) / 4 + 2, 0u);
   std::memcpy(words.data(), src + 2, nbytes);
-  std::vector<uint32_t> lit(512), dist(32);
-  for (uint32_t i = 0; i < 512; i++) lit[i] = il_lit_entry(i);
-  for (uint32_t i = 0; i < 32; i++) dist[i] = il_dist_entry(i);
-  ILStream s{words.data(), (uint32_t)words.size(), nbytes * 8u, lit.data(), dist.data()};
+  ILStream s{words.data(), (uint32_t)words.size(), nbytes * 8u};
   uint32_t C, B;
   il_geometry(s.nbits, C, B);
   std::vector<uint32_t> start(C), end(C, 0), outb(C, 0), flag(C, IL_FLAG_OK);

@@ -45,6 +45,8 @@ int sf_fuser_run_batch(sf_fuser* f, const void* const* d_depth, const void* cons
   if (s != f->stream) { hipEventRecord(f->ev_compact[0], s); hipStreamWaitEvent(f->stream, f->ev_compact[0], 0); }
   return SF_OK;
 }
+bool inflate_gpu_takes(const uint8_t*, uint64_t) { return false; }   // the fake device has no kernels: the host threads inflate
+int inflate_gpu_batch(hipStream_t, int, const uint32_t* const*, const uint32_t*, uint8_t* const*, uint16_t* const*, uint32_t, const int32_t*, int32_t*) { return SF_OK; }
 int jpeg_gpu_huffman(hipStream_t, int, const uint8_t* const*, uint8_t* const*, const uint32_t*, const int32_t*, int32_t*) { return SF_OK; }
 int jpeg_gpu_reconstruct(hipStream_t, int, const uint8_t* const*, uint8_t* const*, uint8_t* const*, uint32_t, uint32_t, uint32_t) { return SF_OK; }   // raw colour in this harness
 
