@@ -34,6 +34,12 @@ int jpeg_gpu_huffman(hipStream_t stream, int n, const uint8_t* const* d_prepared
 int jpeg_gpu_reconstruct(hipStream_t stream, int n, const uint8_t* const* d_payload, uint8_t* const* d_rgb, uint8_t* const* d_planes, uint32_t max_blocks,
                          uint32_t max_width, uint32_t max_height);  // jpeg_gpu.hip
 
+// The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and kernels of streams that share a queue
+// run one after the other.  sf_fuse_run drives seven streams (the fuser's two, two for copies, three for the inflate kernels); on four queues
+// every third batch's inflate sat in the integrate pass's queue (29 k -> 20 k frames/s in the loop).  The variable is read at the first HIP call
+// of the process; one the user exported wins.
+__attribute__((constructor)) static void sf_ask_for_hardware_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "12", 0); }
+
 namespace {
 
 // One ring slot = one batch of B frames: contiguous pinned host buffers, contiguous device buffers, two events.
@@ -51,10 +57,6 @@ struct BatchSlot {
   // 2 = the entropy-coded segment, prepared (the GPU decodes AND reconstructs)
   uint8_t coef_mode[MAX_BATCH] = {0};
   uint32_t pay_used[MAX_BATCH] = {0};    // bytes of that payload
-  // per frame, what the pinned depth area holds: 0 = pixels (raw, or inflated / decoded by a host thread); 1 = the zlib stream from its third
-  // byte on (the GPU inflates: inflate_gpu.hip)
-  uint8_t depth_mode[MAX_BATCH] = {0};
-  uint32_t comp_used[MAX_BATCH] = {0};   // bytes of that stream
 };
 
 }  // namespace
@@ -143,13 +145,33 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   const bool gpu_huffman = gpu_jpeg && std::getenv("SF_JPEG_GPU_HUFFMAN") != nullptr;
   const uint32_t pay_entries = gpu_jpeg ? (uint32_t)((pay_b - sizeof(SfJpegLayout) - 4 * (size_t)pay_blocks) / 4) : 0u;
   int32_t* d_jstatus = nullptr;   // 2 ints per ring slot and frame, written by the device's entropy decoder only when a picture fails
-  const size_t slot_depth = (depth_b * B + 255) & ~(size_t)255, slot_planes = planes_b * B;
+  // GPU inflate: the depth part of a pinned slot is PACKED -- per frame either the zlib stream from its third byte on (the device inflates it)
+  // or, for a stream the device does not take, the pixels a host thread decoded; 64-byte aligned segments whose offsets are known before
+  // anybody decodes (the sizes are in the file's frame table), so that the batch crosses PCIe in ONE copy (32 copies of ~330 KB cost the
+  // enqueueing thread 0.6 ms per batch).  Otherwise: depth_b per frame.
+  const size_t seg_px = (depth_b + 63) & ~(size_t)63;
+  std::vector<uint8_t> zmode(gpu_inflate ? total : 0);      // per frame of the run: 1 = travels compressed
+  std::vector<uint32_t> zoff(gpu_inflate ? total : 0);      // its segment's offset in the slot
+  std::vector<uint32_t> zbytes(gpu_inflate ? nbatches : 0); // per batch: bytes to copy
+  if (gpu_inflate)
+    for (uint64_t g = 0; g < nbatches; g++) {
+      size_t at = 0;
+      for (uint64_t k = g * (uint64_t)B; k < std::min<uint64_t>(total, (g + 1) * (uint64_t)B); k++) {
+        const SensFrame& fd = s->frames[first + k];
+        zoff[k] = (uint32_t)at;
+        if (fd.pose[0] == -INFINITY) continue;
+        zmode[k] = fd.depth && fd.depth_bytes - 2 <= depth_b && inflate_gpu_takes(fd.depth, fd.depth_bytes) ? 1 : 0;
+        at += zmode[k] ? ((size_t)fd.depth_bytes - 2 + 63) & ~(size_t)63 : seg_px;
+      }
+      zbytes[g] = (uint32_t)at;
+    }
+  const size_t slot_depth = ((gpu_inflate ? seg_px : depth_b) * B + 255) & ~(size_t)255, slot_planes = planes_b * B;
   // pinned slot: depth, then per frame ONE colour area that holds either pixels or coefficients (col_b = the larger of the two);
   // device slot: depth, pixels, coefficients, planes scratch
   const size_t col_b = std::max(rgb_b, pay_b), slot_col = (col_b * B + 255) & ~(size_t)255;
   const size_t slot_b = slot_depth + slot_col;
-  // a compressed frame on the device: 64-byte aligned with 256 readable bytes behind it (the lanes of k_inflate_tokens fetch 64 bytes at a time, two fetches ahead)
-  const size_t comp_stride = gpu_inflate ? (depth_b + 256 + 63) & ~(size_t)63 : 0, slot_comp = (comp_stride * B + 255) & ~(size_t)255;
+  // the packed depth part on the device, with 256 readable bytes behind it (the lanes of k_inflate_tokens fetch 64 bytes at a time, two fetches ahead)
+  const size_t slot_comp = gpu_inflate ? slot_depth + 256 : 0;
   const size_t dslot_b = slot_depth + slot_col + (gpu_jpeg ? slot_col : 0) + slot_planes + slot_comp;   // every colour area strides by col_b: runs copy as one piece
   auto h_depth = [&](int sl, int j) { return (uint16_t*)(h_pool + (size_t)sl * slot_b + (size_t)j * depth_b); };
   auto d_depth = [&](int sl, int j) { return d_pool + (size_t)sl * dslot_b + (size_t)j * depth_b; };
@@ -158,7 +180,8 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   auto h_pay = h_rgb;
   auto d_pay = [&](int sl, int j) { return d_pool + (size_t)sl * dslot_b + slot_depth + slot_col + (size_t)j * col_b; };
   auto d_planes = [&](int sl, int j) { return d_pool + (size_t)sl * dslot_b + slot_depth + 2 * slot_col + (size_t)j * planes_b; };
-  auto d_comp = [&](int sl, int j) { return d_pool + (size_t)(sl + 1) * dslot_b - slot_comp + (size_t)j * comp_stride; };   // the compressed frames, behind everything else of the slot
+  auto h_stage = [&](int sl) { return h_pool + (size_t)sl * slot_b; };                             // the packed depth part (GPU inflate)
+  auto d_stage = [&](int sl) { return d_pool + (size_t)(sl + 1) * dslot_b - slot_comp; };            // ... on the device, behind everything else of the slot
   auto cleanup = [&]() {
     for (BatchSlot& sl : ring) {
       if (sl.copied) (void)hipEventDestroy(sl.copied);
@@ -227,15 +250,14 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
       int rc = SF_OK;
       if (s->frames[frame].pose[0] != -INFINITY) {
         const SensFrame& fd = s->frames[frame];
-        if (gpu_inflate && fd.depth && fd.depth_bytes - 2 <= depth_b && inflate_gpu_takes(fd.depth, fd.depth_bytes)) {
-          uint8_t* dst = reinterpret_cast<uint8_t*>(h_depth(sl, j));
+        if (gpu_inflate && zmode[k]) {
+          uint8_t* dst = h_stage(sl) + zoff[k];
           const size_t nb = (size_t)fd.depth_bytes - 2;
           std::memcpy(dst, fd.depth + 2, nb);
-          for (size_t q = nb; q & 3; q++) dst[q] = 0;   // the device reads whole words (depth_b is a multiple of 4: there is room)
-          ring[(size_t)sl].depth_mode[j] = 1;
-          ring[(size_t)sl].comp_used[j] = (uint32_t)nb;
+          for (size_t q = nb; q & 63; q++) dst[q] = 0;   // the device reads whole words; the segment is whole 64 bytes
+        } else if (gpu_inflate) {
+          rc = sens_decode_depth(s, frame, reinterpret_cast<uint16_t*>(h_stage(sl) + zoff[k]));
         } else {
-          ring[(size_t)sl].depth_mode[j] = 0;
           rc = sens_decode_depth(s, frame, h_depth(sl, j));
         }
         if (rc == SF_OK && use_rgb && s->frames[frame].color_bytes) {
@@ -317,17 +339,18 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
       if (!valid[j]) { n_skip++; f->frames_skipped++; }
     }
     bool any_comp = false;
-    for (int j = 0; j < cnt && e == hipSuccess;) {   // pixels: runs of frames a host thread decoded
-      if (!valid[j] || bs.depth_mode[j]) { j++; continue; }
-      int j1 = j;
-      while (j1 < cnt && valid[j1] && !bs.depth_mode[j1]) j1++;
-      e = hipMemcpyAsync(d_depth(sl, j), h_depth(sl, j), (size_t)(j1 - j) * depth_b, hipMemcpyHostToDevice, cs_depth);
-      j = j1;
-    }
-    for (int j = 0; j < cnt && e == hipSuccess; j++) {   // compressed frames: what each really holds
-      if (!valid[j] || !bs.depth_mode[j]) continue;
-      e = hipMemcpyAsync(d_comp(sl, j), h_depth(sl, j), ((size_t)bs.comp_used[j] + 3) & ~(size_t)3, hipMemcpyHostToDevice, cs_depth);
-      any_comp = true;
+    const uint64_t k0 = g * (uint64_t)B;   // index of the batch's first frame in the run
+    if (gpu_inflate) {   // the packed depth part in one piece
+      if (zbytes[g]) e = hipMemcpyAsync(d_stage(sl), h_stage(sl), zbytes[g], hipMemcpyHostToDevice, cs_depth);
+      for (int j = 0; j < cnt; j++) any_comp = any_comp || (valid[j] && zmode[k0 + (uint64_t)j]);
+    } else {
+      for (int j = 0; j < cnt && e == hipSuccess;) {   // one copy per run of consecutive valid frames
+        if (!valid[j]) { j++; continue; }
+        int j1 = j;
+        while (j1 < cnt && valid[j1]) j1++;
+        e = hipMemcpyAsync(d_depth(sl, j), h_depth(sl, j), (size_t)(j1 - j) * depth_b, hipMemcpyHostToDevice, cs_depth);
+        j = j1;
+      }
     }
     bool any_rgb = false;
     for (int j = 0; j < cnt && e == hipSuccess;) {   // pixels: runs of frames decoded on the host
@@ -370,9 +393,10 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
         nz = 0;
       };
       for (int j = 0; j < cnt; j++) {
-        if (!valid[j] || !bs.depth_mode[j]) continue;
+        if (!valid[j] || !zmode[k0 + (uint64_t)j]) continue;
         if (nz == 0) slot0 = j;
-        zw[nz] = reinterpret_cast<const uint32_t*>(d_comp(sl, j)); zn[nz] = bs.comp_used[j]; zo[nz] = d_depth(sl, j);
+        zw[nz] = reinterpret_cast<const uint32_t*>(d_stage(sl) + zoff[k0 + (uint64_t)j]);
+        zn[nz] = (uint32_t)(s->frames[first + k0 + (uint64_t)j].depth_bytes - 2); zo[nz] = d_depth(sl, j);
         zb[nz] = reinterpret_cast<uint16_t*>(zplan + 2 * depth_b * (size_t)j); zt[nz] = (int32_t)(first + g * (uint64_t)B + (uint64_t)j);
         if (++nz == 32) flush();
       }
@@ -394,7 +418,10 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
       const bool rgb = rgbf[j];
       const int jfirst = j;
       while (j < cnt && m < B && (!valid[j] || rgbf[j] == rgb)) {
-        if (valid[j]) { dd[m] = d_depth(sl, j); dr[m] = rgb ? d_rgb(sl, j) : nullptr; pp[m] = s->frames[first + g * (uint64_t)B + (uint64_t)j].pose; m++; }
+        if (valid[j]) {
+          // pixels: inflated on the device into the slot's frame area, or (a stream the device does not take) as the host thread decoded them
+          dd[m] = (gpu_inflate && !zmode[k0 + (uint64_t)j]) ? d_stage(sl) + zoff[k0 + (uint64_t)j] : d_depth(sl, j);
+          dr[m] = rgb ? d_rgb(sl, j) : nullptr; pp[m] = s->frames[first + g * (uint64_t)B + (uint64_t)j].pose; m++; }
         j++;
       }
       hipStream_t in_stream = sf_input_stream(f, m, rgb, +1);  // the stream this sub-batch's pre-pass runs on
