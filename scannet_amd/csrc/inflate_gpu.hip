@@ -58,7 +58,11 @@ __device__ inline uint32_t block_exscan(uint32_t v, uint32_t* s_wave, uint32_t& 
 struct LaneWindow {
   uint32_t* slot;
   uint32_t nbits;
+  const uint32_t* lit_;
+  const uint32_t* dist_;
   __device__ uint32_t word(uint32_t w) const { return slot[w & 31u]; }
+  __device__ uint32_t lit(uint32_t i) const { return lit_[i]; }
+  __device__ uint32_t dist(uint32_t i) const { return dist_[i]; }
 };
 __device__ inline void slot_put(uint32_t* slot, uint32_t seg, const uint4& a, const uint4& b, const uint4& c, const uint4& d) {
   uint32_t* p = slot + ((seg & 1u) << 4);
@@ -115,34 +119,52 @@ struct PlanSink {
 };
 
 __global__ __launch_bounds__(IG_LANES) void k_inflate_tokens(InflateBatch B) {
-  __shared__ uint32_t s_end[IG_LANES], s_wave[IG_LANES / 64];
+  __shared__ uint32_t s_lit[512], s_dist[32], s_end[IG_LANES], s_res[IG_LANES], s_start[IG_LANES], s_list[IG_LANES], s_wave[IG_LANES / 64];
   __shared__ uint32_t s_slots[IG_LANES * 33];
   const int f = blockIdx.x;
   if (B.out[f] == nullptr) return;
+  for (uint32_t i = threadIdx.x; i < 512u; i += IG_LANES) s_lit[i] = il_lit_entry(i);
+  if (threadIdx.x < 32u) s_dist[threadIdx.x] = il_dist_entry(threadIdx.x);
+  __syncthreads();
   const uint32_t nbytes = B.nbytes[f];
   const uint4* __restrict__ mem = reinterpret_cast<const uint4*>(B.words[f]);
   uint32_t* slot = s_slots + 33u * threadIdx.x;
-  LaneWindow S{slot, nbytes * 8u};
+  LaneWindow S{slot, nbytes * 8u, s_lit, s_dist};
   uint32_t C, Bc;
   il_geometry(S.nbits, C, Bc);
   const uint32_t c = threadIdx.x;
   const bool mine = c < C;
   const uint32_t limit = (c + 1 == C) ? S.nbits : (c + 1) * Bc;
-  // ---- stage A: the chunk starts to their fixed point (bit 3: behind BFINAL and BTYPE)
+  // ---- stage A: the chunk starts to their fixed point (bit 3: behind BFINAL and BTYPE).  Rounds 0 and 1 every lane scans its own chunk (the
+  // guessed start is almost never a token boundary: round 1 rescans ~94 %); from round 2 on ~1 % of the chunks restart, and those are dealt to
+  // the first lanes -- left where they are, a dozen chunks kept most of the 16 waves busy for another whole pass.
   uint32_t start = c == 0 ? 3u : c * Bc, end = 0, outb = 0, flag = IL_FLAG_OK;
   bool dirty = mine;
   for (uint32_t round = 0; round < C + 2u; round++) {
+    uint32_t cc = c;   // the chunk this lane scans in this round
+    bool work = dirty;
+    uint32_t my_start = start;
+    if (round >= 2u) {
+      uint32_t ndirty;
+      const uint32_t at = block_exscan(dirty ? 1u : 0u, s_wave, ndirty);
+      if (dirty) { s_list[at] = c; s_start[c] = start; }
+      __syncthreads();
+      work = threadIdx.x < ndirty;
+      if (work) { cc = s_list[threadIdx.x]; my_start = s_start[cc]; }
+    }
+    const uint32_t my_limit = (cc + 1 == C) ? S.nbits : (cc + 1) * Bc;
     ILScan sc;
-    lane_pass(mem, slot, start, dirty, [&]() { il_scan_begin(S, sc, start); },
+    lane_pass(mem, slot, my_start, work, [&]() { il_scan_begin(S, sc, my_start); },
               [&](uint32_t until) {
-                il_scan_run(S, sc, until < limit ? until : limit);
-                return sc.off_end || sc.b.pos >= limit;
+                il_scan_run(S, sc, until < my_limit ? until : my_limit);
+                return sc.off_end || sc.b.pos >= my_limit;
               });
-    if (dirty) {
-      end = sc.b.pos; outb = sc.out; flag = sc.fl;
-      s_end[c] = end;
+    if (work) {
+      s_end[cc] = sc.b.pos;
+      s_res[cc] = (sc.out << 2) | sc.fl;
     }
     __syncthreads();
+    if (dirty) { end = s_end[c]; outb = s_res[c] >> 2; flag = s_res[c] & 3u; }
     bool changed = false;
     if (mine && c > 0) {
       const uint32_t ns = s_end[c - 1];

@@ -47,9 +47,41 @@ enum : int32_t {
   IL_ST_BAD_DISTANCE = -5  // a match reaches in front of the output
 };
 
+// lit/len table, indexed by the next 9 stream bits (bit 0 = the first bit = the MSB of the code, RFC 1951 3.1.1):
+//   bits 0..3 code length | bits 4..5 kind (0 literal, 1 length, 2 end of block, 3 invalid) | bits 6..9 extra bits | bits 16..31 literal / length base
+IL_HD uint32_t il_lit_entry(uint32_t i) {
+  uint32_t rev = 0;
+  for (int b = 0; b < 9; b++) rev |= ((i >> b) & 1u) << (8 - b);
+  const uint32_t top7 = rev >> 2, top8 = rev >> 1;
+  uint32_t sym, nb;
+  if (top7 <= 0x17u) { sym = 256u + top7; nb = 7; }
+  else if (top8 >= 0x30u && top8 <= 0xBFu) { sym = top8 - 0x30u; nb = 8; }
+  else if (top8 >= 0xC0u && top8 <= 0xC7u) { sym = 280u + (top8 - 0xC0u); nb = 8; }
+  else { sym = 144u + (rev - 0x190u); nb = 9; }
+  if (sym < 256u) return nb | (0u << 4) | (sym << 16);
+  if (sym == 256u) return nb | (2u << 4);
+  if (sym > 285u) return nb | (3u << 4);
+  const uint32_t L = sym - 257u;
+  uint32_t base, ex;
+  if (L < 8u) { base = 3u + L; ex = 0; }
+  else if (L == 28u) { base = 258u; ex = 0; }
+  else { ex = (L >> 2) - 1u; base = 3u + ((4u + (L & 3u)) << ex); }
+  return nb | (1u << 4) | (ex << 6) | (base << 16);
+}
+// distance table, indexed by the next 5 stream bits: bits 0..3 extra bits | bit 4 invalid | bits 16..31 base
+IL_HD uint32_t il_dist_entry(uint32_t i) {
+  uint32_t code = 0;
+  for (int b = 0; b < 5; b++) code |= ((i >> b) & 1u) << (4 - b);
+  if (code >= 30u) return 1u << 4;
+  if (code < 4u) return (code + 1u) << 16;
+  const uint32_t ex = (code >> 1) - 1u;
+  return ex | ((1u + ((2u + (code & 1u)) << ex)) << 16);
+}
+
 // The block as the lanes see it -- a type S with
 //   uint32_t word(uint32_t i)     the deflate data as 32-bit words (the zlib stream from its third byte on; words behind the data read as anything:
 //                                 a token that ends behind nbits is an error whatever it decodes to)
+//   uint32_t lit(uint32_t i), dist(uint32_t i)    the two tables above
 //   uint32_t nbits                bits of deflate data incl. the Adler-32 trailer
 // The host reads a plain array (ILStream); the device keeps 128 bytes of every lane's chunk in LDS (inflate_gpu.hip: LaneWindow).
 struct ILStream {
@@ -57,6 +89,8 @@ struct ILStream {
   uint32_t nwords;
   uint32_t nbits;
   uint32_t word(uint32_t w) const { return w < nwords ? words[w] : 0u; }
+  uint32_t lit(uint32_t i) const { return il_lit_entry(i); }     // the host emulation computes the entries; the device holds them in LDS
+  uint32_t dist(uint32_t i) const { return il_dist_entry(i); }
 };
 
 struct ILBits {
@@ -87,44 +121,24 @@ struct ILToken {
   uint32_t value;  // literal byte / match length
   uint32_t dist;
 };
-IL_HD uint32_t il_rev32(uint32_t x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return __builtin_bitreverse32(x);
-#else
-  x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
-  x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
-  x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
-  x = ((x >> 8) & 0x00FF00FFu) | ((x & 0x00FF00FFu) << 8);
-  return (x >> 16) | (x << 16);
-#endif
-}
-// one token at the reader's position (consumed).  The code is FIXED (RFC 1951 3.2.6), so it is decoded by arithmetic -- no table, no branch on
-// the kind (the lanes of a wave hold literals and matches side by side; two dependent LDS look-ups per token were what a wave waited for).
-// Huffman codes are packed most significant bit first: the reversed word holds the code in its top bits.
-//   7 bits 0000000-0010111 -> 256-279 | 8 bits 00110000-10111111 -> 0-143 | 8 bits 11000000-11000111 -> 280-287 | 9 bits 110010000-111111111 -> 144-255
+// one token at the reader's position (consumed).  No branch on the kind: the lanes of a wave hold literals and matches side by side.  (The
+// code is fixed and could be decoded by arithmetic instead of the two look-ups; measured: 15 % slower -- the kernel is bound by the number of
+// instructions it issues, not by the look-ups' latency.)
 template <class S>
 IL_HD ILToken il_token(S& s, ILBits& b) {
   il_refill(s, b);
-  const uint32_t lo = (uint32_t)b.buf, r = il_rev32(lo);
-  const uint32_t c7 = r >> 25, c8 = r >> 24, c9 = r >> 23;
-  const bool is7 = c7 < 24u, is8 = c8 < 0xC8u;
-  const uint32_t sym = is7 ? 256u + c7 : (c8 < 0xC0u ? c8 - 0x30u : (is8 ? 280u + (c8 - 0xC0u) : 144u + (c9 - 0x190u)));
-  const uint32_t nb = is7 ? 7u : (is8 ? 8u : 9u);
-  const bool match = sym > 256u && sym <= 285u;
-  // lengths (3.2.5): symbols 257-264 are 3-10, then four symbols per extra bit, 285 is 258
-  const uint32_t L = sym - 257u;
-  const uint32_t ex = (match && L >= 8u && L != 28u) ? (L >> 2) - 1u : 0u;
-  const uint32_t lbase = L < 8u ? 3u + L : (L == 28u ? 258u : 3u + ((4u + (L & 3u)) << ex));
+  const uint32_t lo = (uint32_t)b.buf;
+  const uint32_t e = s.lit(lo & 511u);
+  const uint32_t nb = e & 15u, kind = (e >> 4) & 3u, ex = (e >> 6) & 15u;   // ex = 0 unless a length
   const uint32_t at = nb + ex;                                              // <= 13
   const uint32_t rest = (uint32_t)(b.buf >> at);                            // what follows the length: 5 distance bits + <= 13 extra
-  // distances: codes 0-3 are 1-4, then two codes per extra bit; 30 and 31 do not exist
-  const uint32_t dc = il_rev32(rest) >> 27;
-  const uint32_t dex = dc < 4u ? 0u : (dc >> 1) - 1u;
-  const uint32_t dbase = dc < 4u ? dc + 1u : 1u + ((2u + (dc & 1u)) << dex);
+  const uint32_t d = s.dist(rest & 31u);
+  const uint32_t dex = d & 15u;
+  const bool match = kind == 1u;
   ILToken t;
-  t.value = match ? lbase + ((lo >> nb) & ((1u << ex) - 1u)) : sym;
-  t.dist = match ? dbase + ((rest >> 5) & ((1u << dex) - 1u)) : 0u;
-  t.kind = sym < 256u ? 0u : (sym == 256u ? 2u : ((match && dc < 30u) ? 1u : 3u));
+  t.value = (e >> 16) + ((lo >> nb) & ((1u << ex) - 1u));
+  t.dist = match ? (d >> 16) + ((rest >> 5) & ((1u << dex) - 1u)) : 0u;
+  t.kind = (match && (d & 16u)) ? 3u : kind;
   il_consume(b, match ? at + 5u + dex : nb);
   return t;
 }

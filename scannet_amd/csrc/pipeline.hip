@@ -42,10 +42,41 @@ __attribute__((constructor)) static void sf_ask_for_hardware_queues() { (void)se
 
 namespace {
 
+// What sf_fuse_run sets up and does not need fresh: five streams (a hardware queue each: ~5 ms to create, and the runtime creates them one
+// after the other whatever the threads do) and the pinned pool (~6 ms per 100 MB).  Kept per device for the life of the process and handed
+// to one run at a time -- a dataset rebuild fuses 1513 scans in a process; a run that finds the set taken makes its own.
+struct RunResources {
+  int device = -1;
+  bool taken = false;
+  hipStream_t copy[2] = {nullptr, nullptr}, inflate[3] = {nullptr, nullptr, nullptr};
+  uint8_t* h_pool = nullptr;
+  size_t h_bytes = 0;
+};
+std::mutex g_res_mu;
+std::vector<RunResources*> g_res;   // never freed: the streams and the pool die with the process
+RunResources* acquire_resources(int device) {
+  std::lock_guard<std::mutex> lk(g_res_mu);
+  for (RunResources* r : g_res)
+    if (r->device == device && !r->taken) { r->taken = true; return r; }
+  for (RunResources* r : g_res)
+    if (r->device == device) return nullptr;   // taken: the caller works with resources of its own
+  RunResources* r = new RunResources;
+  r->device = device;
+  r->taken = true;
+  g_res.push_back(r);
+  return r;
+}
+void release_resources(RunResources* r) {
+  if (!r) return;
+  std::lock_guard<std::mutex> lk(g_res_mu);
+  r->taken = false;
+}
+
 // One ring slot = one batch of B frames: contiguous pinned host buffers, contiguous device buffers, two events.
 struct BatchSlot {
   hipEvent_t copied = nullptr;    // H2D of this batch finished (its pinned buffers may be refilled)
   hipEvent_t copied_rgb = nullptr;  // the colour part of it, on the other copy stream
+  hipEvent_t copied_rgb2 = nullptr; // ... its second half, when that has a stream of its own
   hipEvent_t inflated = nullptr;    // the frames that travelled compressed are pixels now (recorded on the inflate stream)
   // pre-pass of this batch finished (its device buffers may be overwritten): one event per input stream a sub-batch of the slot ran on --
   // the fuser orders its two streams among themselves, but the ring does not lean on that
@@ -79,7 +110,7 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   SF_HIP_CHECK(hipSetDevice(f->device));
   const auto t_start = std::chrono::steady_clock::now();
   const bool timing = std::getenv("SF_RUN_TIMING") != nullptr;
-  double t_wait_ready = 0, t_api = 0, t_flush = 0;
+  double t_wait_ready = 0, t_api = 0, t_flush = 0, t_launch_z = 0, t_memcpy = 0;
   auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const size_t npx = f->in_px;   // of an input frame (the pre-pass resamples to the integration size when the two differ)
   // colour is fused when its frames match what the fuser was created for: depth resolution, or the colour resolution
@@ -108,13 +139,16 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   constexpr int NZ = 3;   // inflate streams: consecutive batches are inflated side by side (a batch takes longer to inflate than to fuse)
   const int NB = (int)std::max<uint64_t>(1, std::min<uint64_t>(std::max<uint64_t>(gpu_inflate ? 3 + NZ : 3, ((uint64_t)nthreads + B - 1) / B + 2), std::max<uint64_t>(nbatches, 1)));
   std::vector<BatchSlot> ring((size_t)NB);
-  hipStream_t copy_stream = nullptr, copy_stream2 = nullptr;   // two streams = two SDMA engines: one alone moves ~20 GB/s
+  // two streams = two SDMA engines: one alone moves ~20 GB/s.  With the GPU inflate the batch's copies ride on its inflate stream (and the next
+  // one): copy, tokens, copies-kernel of batch g, then the copy of batch g + 3 -- a stream costs ~5 ms to create
+  hipStream_t copy_stream = nullptr, copy_stream2 = nullptr;
   hipStream_t inflate_stream[NZ] = {nullptr, nullptr, nullptr};   // batch g is inflated on stream g % NZ, beside the pre-pass / allocation / integration of the batches before it
   uint8_t* d_plan[NZ] = {nullptr, nullptr, nullptr};              // scratch of the inflate kernels (one u16 per output byte), one per stream
   int32_t* d_zstatus = nullptr;                                // 2 ints per ring slot and frame, written by the device's inflate only when a frame fails
   // ONE pinned host allocation and ONE device allocation for the whole ring
   uint8_t* h_pool = nullptr;
   uint8_t* d_pool = nullptr;
+  RunResources* res = acquire_resources(f->device);   // nullptr: another run of this process holds the device's set
   const size_t depth_b = npx * 2, rgb_b = use_rgb ? cpx * 3 : 0;
   // JPEG colour: the host threads only entropy-decode; the coefficients travel in place of the pixels and the GPU reconstructs
   // (jpeg_gpu.hip).  The payload is sized from the first colour frame's layout (a scan's frames share it); a frame that does not fit,
@@ -165,69 +199,95 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
       }
       zbytes[g] = (uint32_t)at;
     }
-  const size_t slot_depth = ((gpu_inflate ? seg_px : depth_b) * B + 255) & ~(size_t)255, slot_planes = planes_b * B;
+  size_t packed_max = 0;   // the largest batch's packed depth part: what a slot must hold (compressed frames: about half of the pixels)
+  for (uint32_t z : zbytes) packed_max = std::max<size_t>(packed_max, z);
+  const size_t slot_depth = ((gpu_inflate ? packed_max : depth_b * B) + 255) & ~(size_t)255, slot_planes = planes_b * B;
+  const size_t dslot_depth = gpu_inflate ? (depth_b * B + 255) & ~(size_t)255 : slot_depth;   // on the device: the frames as pixels (where the inflate kernels write)
   // pinned slot: depth, then per frame ONE colour area that holds either pixels or coefficients (col_b = the larger of the two);
   // device slot: depth, pixels, coefficients, planes scratch
   const size_t col_b = std::max(rgb_b, pay_b), slot_col = (col_b * B + 255) & ~(size_t)255;
   const size_t slot_b = slot_depth + slot_col;
   // the packed depth part on the device, with 256 readable bytes behind it (the lanes of k_inflate_tokens fetch 64 bytes at a time, two fetches ahead)
   const size_t slot_comp = gpu_inflate ? slot_depth + 256 : 0;
-  const size_t dslot_b = slot_depth + slot_col + (gpu_jpeg ? slot_col : 0) + slot_planes + slot_comp;   // every colour area strides by col_b: runs copy as one piece
+  const size_t dslot_b = dslot_depth + slot_col + (gpu_jpeg ? slot_col : 0) + slot_planes + slot_comp;   // every colour area strides by col_b: runs copy as one piece
   auto h_depth = [&](int sl, int j) { return (uint16_t*)(h_pool + (size_t)sl * slot_b + (size_t)j * depth_b); };
   auto d_depth = [&](int sl, int j) { return d_pool + (size_t)sl * dslot_b + (size_t)j * depth_b; };
   auto h_rgb = [&](int sl, int j) { return h_pool + (size_t)sl * slot_b + slot_depth + (size_t)j * col_b; };
-  auto d_rgb = [&](int sl, int j) { return d_pool + (size_t)sl * dslot_b + slot_depth + (size_t)j * col_b; };
+  auto d_rgb = [&](int sl, int j) { return d_pool + (size_t)sl * dslot_b + dslot_depth + (size_t)j * col_b; };
   auto h_pay = h_rgb;
-  auto d_pay = [&](int sl, int j) { return d_pool + (size_t)sl * dslot_b + slot_depth + slot_col + (size_t)j * col_b; };
-  auto d_planes = [&](int sl, int j) { return d_pool + (size_t)sl * dslot_b + slot_depth + 2 * slot_col + (size_t)j * planes_b; };
+  auto d_pay = [&](int sl, int j) { return d_pool + (size_t)sl * dslot_b + dslot_depth + slot_col + (size_t)j * col_b; };
+  auto d_planes = [&](int sl, int j) { return d_pool + (size_t)sl * dslot_b + dslot_depth + 2 * slot_col + (size_t)j * planes_b; };
   auto h_stage = [&](int sl) { return h_pool + (size_t)sl * slot_b; };                             // the packed depth part (GPU inflate)
   auto d_stage = [&](int sl) { return d_pool + (size_t)(sl + 1) * dslot_b - slot_comp; };            // ... on the device, behind everything else of the slot
   auto cleanup = [&]() {
     for (BatchSlot& sl : ring) {
       if (sl.copied) (void)hipEventDestroy(sl.copied);
       if (sl.copied_rgb) (void)hipEventDestroy(sl.copied_rgb);
+      if (sl.copied_rgb2) (void)hipEventDestroy(sl.copied_rgb2);
       if (sl.inflated) (void)hipEventDestroy(sl.inflated);
       for (hipEvent_t ev : sl.consumed) if (ev) (void)hipEventDestroy(ev);
     }
-    if (h_pool) (void)hipHostFree(h_pool);
+    if (h_pool && !(res && res->h_pool == h_pool)) (void)hipHostFree(h_pool);
     if (d_pool) (void)hipFree(d_pool);
     if (d_jstatus) (void)hipFree(d_jstatus);
     for (uint8_t* q : d_plan) if (q) (void)hipFree(q);
     if (d_zstatus) (void)hipFree(d_zstatus);
-    for (hipStream_t q : inflate_stream) if (q) (void)hipStreamDestroy(q);
-    if (copy_stream) (void)hipStreamDestroy(copy_stream);
-    if (copy_stream2) (void)hipStreamDestroy(copy_stream2);
+    if (!res) for (hipStream_t q : inflate_stream) if (q) (void)hipStreamDestroy(q);
+    if (!res && copy_stream) (void)hipStreamDestroy(copy_stream);
+    if (!res && copy_stream2) (void)hipStreamDestroy(copy_stream2);
+    release_resources(res);
   };
-#define RUN_CHECK(call)                                                                                   \
-  do {                                                                                                    \
-    hipError_t e_ = (call);                                                                               \
-    if (e_ != hipSuccess) { cleanup(); return sf::fail(SF_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_)); } \
-  } while (0)
-  RUN_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
-  RUN_CHECK(hipStreamCreateWithFlags(&copy_stream2, hipStreamNonBlocking));
-  RUN_CHECK(hipHostMalloc((void**)&h_pool, (size_t)NB * slot_b, hipHostMallocDefault));
-  RUN_CHECK(hipMalloc((void**)&d_pool, (size_t)NB * dslot_b));
-  if (gpu_inflate) {
-    for (int q = 0; q < NZ; q++) {
-      RUN_CHECK(hipStreamCreateWithFlags(&inflate_stream[q], hipStreamNonBlocking));
-      RUN_CHECK(hipMalloc((void**)&d_plan[q], 2 * depth_b * (size_t)B));
+  // Set-up.  Streams and the pinned pool come from the process-wide set when it is free (the first run on a device creates them: 23 ms for a
+  // depth-only run, 55 ms with colour, of a scan that is fused in 0.25 s; creating the streams on threads of their own did not help, the
+  // runtime makes its hardware queues one after the other).
+  const double ts0 = timing ? now_s() : 0;
+  {
+    hipError_t e_ = hipSuccess;
+    auto want_stream = [&](hipStream_t* cached, hipStream_t* out) {
+      if (e_ != hipSuccess) return;
+      if (cached && *cached) { *out = *cached; return; }
+      e_ = hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+      if (e_ == hipSuccess && cached) *cached = *out;
+    };
+    if (!gpu_inflate || use_rgb) {   // with the GPU inflate: for the colour part only (behind the inflate kernels of an earlier batch it arrived late)
+      want_stream(res ? &res->copy[0] : nullptr, &copy_stream);
+      want_stream(res ? &res->copy[1] : nullptr, &copy_stream2);
     }
-    RUN_CHECK(hipMalloc((void**)&d_zstatus, (size_t)NB * B * 8));
-    RUN_CHECK(hipMemset(d_zstatus, 0, (size_t)NB * B * 8));
-  }
-  if (gpu_huffman) {
-    RUN_CHECK(hipMalloc((void**)&d_jstatus, (size_t)NB * B * 8));
-    RUN_CHECK(hipMemset(d_jstatus, 0, (size_t)NB * B * 8));
-  }
-  for (BatchSlot& sl : ring) {
-    RUN_CHECK(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
-    RUN_CHECK(hipEventCreateWithFlags(&sl.copied_rgb, hipEventDisableTiming));
-    RUN_CHECK(hipEventCreateWithFlags(&sl.inflated, hipEventDisableTiming));
-    RUN_CHECK(hipEventCreateWithFlags(&sl.consumed[0], hipEventDisableTiming));
-    RUN_CHECK(hipEventCreateWithFlags(&sl.consumed[1], hipEventDisableTiming));
+    if (gpu_inflate)
+      for (int q = 0; q < NZ; q++) want_stream(res ? &res->inflate[q] : nullptr, &inflate_stream[q]);
+    const size_t h_need = (size_t)NB * slot_b;
+    if (e_ == hipSuccess && res && res->h_bytes >= h_need) {
+      h_pool = res->h_pool;
+    } else if (e_ == hipSuccess) {
+      if (res && res->h_pool) { (void)hipHostFree(res->h_pool); res->h_pool = nullptr; res->h_bytes = 0; }
+      e_ = hipHostMalloc((void**)&h_pool, h_need, hipHostMallocDefault);
+      if (e_ == hipSuccess && res) { res->h_pool = h_pool; res->h_bytes = h_need; }
+    }
+    if (e_ == hipSuccess) e_ = hipMalloc((void**)&d_pool, (size_t)NB * dslot_b);
+    if (gpu_inflate) {
+      for (int q = 0; q < NZ && e_ == hipSuccess; q++) e_ = hipMalloc((void**)&d_plan[q], 2 * depth_b * (size_t)B);
+      if (e_ == hipSuccess) e_ = hipMalloc((void**)&d_zstatus, (size_t)NB * B * 8);
+      if (e_ == hipSuccess) e_ = hipMemset(d_zstatus, 0, (size_t)NB * B * 8);
+    }
+    if (gpu_huffman) {
+      if (e_ == hipSuccess) e_ = hipMalloc((void**)&d_jstatus, (size_t)NB * B * 8);
+      if (e_ == hipSuccess) e_ = hipMemset(d_jstatus, 0, (size_t)NB * B * 8);
+    }
+    for (BatchSlot& sl : ring) {
+      if (e_ == hipSuccess) e_ = hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming);
+      if (e_ == hipSuccess) e_ = hipEventCreateWithFlags(&sl.copied_rgb, hipEventDisableTiming);
+      if (e_ == hipSuccess) e_ = hipEventCreateWithFlags(&sl.copied_rgb2, hipEventDisableTiming);
+      if (e_ == hipSuccess) e_ = hipEventCreateWithFlags(&sl.inflated, hipEventDisableTiming);
+      if (e_ == hipSuccess) e_ = hipEventCreateWithFlags(&sl.consumed[0], hipEventDisableTiming);
+      if (e_ == hipSuccess) e_ = hipEventCreateWithFlags(&sl.consumed[1], hipEventDisableTiming);
+    }
+    if (e_ != hipSuccess) { cleanup(); return sf::fail(SF_ERR_DEVICE, "sf_fuse_run set-up (streams, pinned and device pools) failed: %s", hipGetErrorString(e_)); }
   }
 
   const double t_setup_end = timing ? now_s() : 0;
+  if (timing)
+    std::fprintf(stderr, "sf_fuse_run set-up: frame table + layout %.1f ms; streams, pinned pool, device pool, events %.1f ms\n",
+                 (ts0 - std::chrono::duration<double>(t_start.time_since_epoch()).count()) * 1e3, (t_setup_end - ts0) * 1e3);
   std::atomic<uint64_t> next{0}, landed{0}, issued{0};  // frame counter of the pool; batches whose copies completed / were queued
   std::atomic<bool> abort{false};
   std::atomic<uint64_t> decode_ns{0};
@@ -326,10 +386,17 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
     hipError_t e = hipSuccess;
     // depth on one copy stream, colour on the other, batches alternating between them: two transfers are in flight at any time
     hipStream_t cs_depth = (g & 1) ? copy_stream2 : copy_stream, cs_rgb = (g & 1) ? copy_stream : copy_stream2;
+    hipStream_t cs_rgb2 = cs_depth;   // the colour part is the larger one: its second half follows the depth on the other stream
+    if (gpu_inflate) {                // ... or: depth in front of its stream's inflate kernels, the colour halves on the two copy streams
+      cs_depth = inflate_stream[g % NZ];
+      cs_rgb = use_rgb ? copy_stream : cs_depth;
+      cs_rgb2 = use_rgb ? copy_stream2 : cs_depth;
+    }
     for (int q = 0; q < 2 && e == hipSuccess; q++)
       if (bs.used[q]) {  // device buffers still read by this slot's previous pre-pass?
         e = hipStreamWaitEvent(cs_depth, bs.consumed[q], 0);
         if (e == hipSuccess) e = hipStreamWaitEvent(cs_rgb, bs.consumed[q], 0);
+        if (e == hipSuccess && cs_rgb2 != cs_depth && cs_rgb2 != cs_rgb) e = hipStreamWaitEvent(cs_rgb2, bs.consumed[q], 0);
       }
     bool valid[MAX_BATCH], rgbf[MAX_BATCH];
     for (int j = 0; j < cnt; j++) {
@@ -341,7 +408,9 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
     bool any_comp = false;
     const uint64_t k0 = g * (uint64_t)B;   // index of the batch's first frame in the run
     if (gpu_inflate) {   // the packed depth part in one piece
+      const double tm = timing ? now_s() : 0;
       if (zbytes[g]) e = hipMemcpyAsync(d_stage(sl), h_stage(sl), zbytes[g], hipMemcpyHostToDevice, cs_depth);
+      if (timing) t_memcpy += now_s() - tm;
       for (int j = 0; j < cnt; j++) any_comp = any_comp || (valid[j] && zmode[k0 + (uint64_t)j]);
     } else {
       for (int j = 0; j < cnt && e == hipSuccess;) {   // one copy per run of consecutive valid frames
@@ -357,26 +426,30 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
       if (!rgbf[j] || bs.coef_mode[j]) { j++; continue; }
       int j1 = j;
       while (j1 < cnt && rgbf[j1] && !bs.coef_mode[j1]) j1++;
-      const int jm = j + (j1 - j + 1) / 2;   // the colour part is the larger one: its second half follows the depth on the other stream
+      const int jm = j + (j1 - j + 1) / 2;
       e = hipMemcpyAsync(d_rgb(sl, j), h_rgb(sl, j), (size_t)(jm - j) * col_b, hipMemcpyHostToDevice, cs_rgb);
-      if (e == hipSuccess && j1 > jm) e = hipMemcpyAsync(d_rgb(sl, jm), h_rgb(sl, jm), (size_t)(j1 - jm) * col_b, hipMemcpyHostToDevice, cs_depth);
+      if (e == hipSuccess && j1 > jm) e = hipMemcpyAsync(d_rgb(sl, jm), h_rgb(sl, jm), (size_t)(j1 - jm) * col_b, hipMemcpyHostToDevice, cs_rgb2);
       any_rgb = true;
       j = j1;
     }
     for (int j = 0, k = 0; j < cnt && e == hipSuccess; j++) {   // coefficients / entropy-coded segments: what each frame really holds, alternating streams
       if (!rgbf[j] || !bs.coef_mode[j]) continue;
       // a prepared segment lands where the pixels will be written: it is dead once k_jpeg_huff has turned it into the coefficient payload
-      e = hipMemcpyAsync(bs.coef_mode[j] == 2 ? d_rgb(sl, j) : d_pay(sl, j), h_pay(sl, j), bs.pay_used[j], hipMemcpyHostToDevice, (k++ & 1) ? cs_depth : cs_rgb);
+      e = hipMemcpyAsync(bs.coef_mode[j] == 2 ? d_rgb(sl, j) : d_pay(sl, j), h_pay(sl, j), bs.pay_used[j], hipMemcpyHostToDevice, (k++ & 1) ? cs_rgb2 : cs_rgb);
       any_rgb = true;
     }
     if (e == hipSuccess && any_rgb) {   // `copied` on the depth stream stands for both parts
       e = hipEventRecord(bs.copied_rgb, cs_rgb);
       if (e == hipSuccess) e = hipStreamWaitEvent(cs_depth, bs.copied_rgb, 0);
+      if (e == hipSuccess && cs_rgb2 != cs_depth && cs_rgb2 != cs_rgb) {
+        e = hipEventRecord(bs.copied_rgb2, cs_rgb2);
+        if (e == hipSuccess) e = hipStreamWaitEvent(cs_depth, bs.copied_rgb2, 0);
+      }
     }
     if (e == hipSuccess) e = hipEventRecord(bs.copied, cs_depth);
     if (e != hipSuccess) { result = SF_ERR_DEVICE; err = std::string("copy pipeline: ") + hipGetErrorString(e); break; }
     issued.store(g + 1, std::memory_order_release);
-    if (any_comp) {   // inflate on its own stream: 1024 lanes per frame tokenise, one wave per frame copies (inflate_gpu.hip)
+    if (any_comp) {   // inflate behind the batch's copy: 1024 lanes per frame tokenise, a 256-lane workgroup per frame makes the copies (inflate_gpu.hip)
       hipStream_t zs = inflate_stream[g % NZ];
       uint8_t* zplan = d_plan[g % NZ];
       e = hipStreamWaitEvent(zs, bs.copied, 0);
@@ -388,7 +461,9 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
       int nz = 0, slot0 = 0;
       auto flush = [&]() {
         if (nz == 0 || e != hipSuccess || result != SF_OK) return;
+        const double tz = timing ? now_s() : 0;
         const int rcz = inflate_gpu_batch(zs, nz, zw, zn, zo, zb, (uint32_t)depth_b, zt, d_zstatus + 2 * ((size_t)sl * B + (size_t)slot0));
+        if (timing) t_launch_z += now_s() - tz;
         if (rcz != SF_OK) { result = rcz; err = sf_last_error(); }
         nz = 0;
       };
@@ -484,11 +559,11 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   const hipError_t qe = sf_quiesce(f);
   if (timing)
     std::fprintf(stderr, "sf_fuse_run: setup %.3f s (streams, %.0f MB pinned, %.0f MB device), loop %.3f s (wait for decoded batches %.3f, copy enqueue %.3f, kernels enqueue %.3f), "
-                         "join+drain %.3f s, %d batch slots x %d frames\n",
+                         "join+drain %.3f s, %d batch slots x %d frames; inside copy enqueue: packed depth memcpy calls %.3f s, inflate launches %.3f s\n",
                  t_setup_end - std::chrono::duration<double>(t_start.time_since_epoch()).count(), (double)NB * slot_b / 1e6, (double)NB * dslot_b / 1e6, t_loop_end - t_setup_end,
-                 t_wait_ready, t_api, t_flush, now_s() - t_loop_end, NB, B);
-  (void)hipStreamSynchronize(copy_stream);
-  (void)hipStreamSynchronize(copy_stream2);
+                 t_wait_ready, t_api, t_flush, now_s() - t_loop_end, NB, B, t_memcpy, t_launch_z);
+  if (copy_stream) (void)hipStreamSynchronize(copy_stream);
+  if (copy_stream2) (void)hipStreamSynchronize(copy_stream2);
   for (hipStream_t q : inflate_stream) if (q) (void)hipStreamSynchronize(q);
   if (result == SF_OK && qe == hipSuccess && d_zstatus) {   // a depth frame the device's inflate gave up on fails the run, as it would on the host
     std::vector<int32_t> st((size_t)NB * B * 2);

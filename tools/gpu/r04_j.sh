@@ -8,10 +8,14 @@ cd $R
 tail -4 $O/pytest.log
 for t in 16 4; do
 ( SF_RUN_TIMING=1 timeout 600 python tools/e2e_bench.py --frames 5578 --fuse-only --threads $t --out $O/e2e_t$t.json ) > $O/e2e_t$t.log 2>&1
-grep "sf_fuse_run" $O/e2e_t$t.log | tail -1 | cut -c1-220
+grep "sf_fuse_run" $O/e2e_t$t.log | tail -2 | cut -c1-220
 python -c "
 import json; print($t, json.load(open('gpurun_out/r04j/e2e_t$t.json'))['fuse']['frames_per_s_end_to_end'])"
 done
-( SF_INFLATE_HOST=1 timeout 600 python tools/e2e_bench.py --frames 5578 --fuse-only --out $O/e2e_host.json ) > $O/e2e_host.log 2>&1
-python -c "
-import json; print('host inflate', json.load(open('gpurun_out/r04j/e2e_host.json'))['fuse']['frames_per_s_end_to_end'])"
+( timeout 600 python tools/e2e_bench.py --frames 3000 --color raw --fuse-only --out $O/e2e_colour_raw.json ) > $O/e2e_colour_raw.log 2>&1
+( timeout 600 python tools/e2e_bench.py --frames 2000 --color jpeg --color-res 1296x968 --fuse-only --out $O/e2e_colour_jpeg_1296.json ) > $O/e2e_colour_jpeg_1296.log 2>&1
+python - <<'PY'
+import json
+for n in ("e2e_colour_raw", "e2e_colour_jpeg_1296"):
+    print(n, json.load(open("gpurun_out/r04j/%s.json" % n))["fuse"])
+PY
