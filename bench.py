@@ -41,6 +41,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# before anything initialises HIP (torch.cuda does, long before libscanfuse.so is loaded): sf_fuse_run drives seven streams, the runtime's
+# default of four hardware queues puts some of them in one queue (scannet_amd/__init__.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 
 TOTAL_FRAMES = 5578
 W, H = 640, 480
@@ -328,10 +331,13 @@ def end_to_end(frames_dev, poses, n, params, local_rank, torch, colour=None):
         sd = sens.SensorData(path)
         best = None
         mc = None
-        for _ in range(2):   # the second pass reads the file from the page cache, as the stage after `convert` does
+        runs = []
+        threads = min(4, os.cpu_count() or 4)   # the depth frames are inflated on the GPU: a host thread copies 330 KB per frame
+        for _ in range(2):   # the second pass reads the file from the page cache, as the stage after `convert` does, and finds the process's streams and pinned pool made
             with fusion.Fuser(prm, device=local_rank, **TUNE) as f:
-                rs = f.run(sd)
+                rs = f.run(sd, decode_threads=threads if colour is None else 0)
                 st = f.stats()
+                runs.append(round(rs["frames_total"] / rs["seconds_total"], 1))
                 if colour is None:   # what follows the fusion in the `improve` stage: marching cubes over the fused volume (second call: warm)
                     del_mesh = f.extract_mesh()
                     del del_mesh
@@ -340,6 +346,16 @@ def end_to_end(frames_dev, poses, n, params, local_rank, torch, colour=None):
                     mc = f.mc_timing()
             if best is None or rs["seconds_total"] < best[0]["seconds_total"]:
                 best = (rs, st)
+        host_inflate = None
+        if colour is None:   # rounds 1-3: every host thread this process may use inflates (SF_INFLATE_HOST)
+            os.environ["SF_INFLATE_HOST"] = "1"
+            try:
+                with fusion.Fuser(prm, device=local_rank, **TUNE) as f:
+                    rh = f.run(sd)
+                    host_inflate = {"frames_per_s": round(rh["frames_total"] / rh["seconds_total"], 1), "decode_threads": int(rh["decode_threads"]),
+                                    "decode_ms_per_frame_per_thread": round(1e3 * rh["seconds_decode_cpu"] / max(rh["frames_total"], 1), 3)}
+            finally:
+                del os.environ["SF_INFLATE_HOST"]
         sd.close()
         rs, st = best
         if mc is not None and mc["blocks"]:
@@ -357,11 +373,13 @@ def end_to_end(frames_dev, poses, n, params, local_rank, torch, colour=None):
         return {"marching_cubes": mc, "frames": int(rs["frames_total"]), "frames_per_s": round(rs["frames_total"] / rs["seconds_total"], 1), "seconds": round(rs["seconds_total"], 4),
                 "compressed_bytes_per_frame": round(size / n), "sens_bytes": size, "decode_threads": int(rs["decode_threads"]),
                 "decode_ms_per_frame_per_thread": round(1e3 * rs["seconds_decode_cpu"] / max(rs["frames_total"], 1), 3),
-                "colour_fused": int(rs["color_fused"]),
+                "colour_fused": int(rs["color_fused"]), "frames_per_s_first_and_second_run": runs, "depth_inflate": "gpu (csrc/inflate_gpu.hip)", "host_inflate": host_inflate,
                 "blocks_live_end": st["blocks_allocated"], "alloc_failures": st["alloc_failures"], "write_s": round(t_write, 2),
-                "what": ".sens on disk (zlib depth%s, %d KB per frame) -> %d decode threads -> pinned ring -> H2D -> pre-pass / allocation / compaction / integrate, "
-                        "32 frames per pass; wall time of sf_fuse_run (first byte decoded -> last kernel complete), best of 2"
-                        % (" + baseline-JPEG colour at 1296x968 with its own intrinsics" if colour == "jpeg1296" else "", size // n // 1024, rs["decode_threads"])}
+                "what": ".sens on disk (zlib depth%s, %d KB per frame) -> %d host threads copy the compressed depth frames%s into the pinned ring -> H2D -> inflate on the GPU -> pre-pass / "
+                        "allocation / compaction / integrate, 32 frames per pass; wall time of sf_fuse_run (first byte read -> last kernel complete), best of 2 (the first run of a "
+                        "process also creates the run's five streams and its pinned pool: frames_per_s_first_and_second_run); host_inflate: the same file with the host threads inflating"
+                        % (" + baseline-JPEG colour at 1296x968 with its own intrinsics" if colour == "jpeg1296" else "", size // n // 1024, rs["decode_threads"],
+                           " and Huffman-decode the colour frames (IDCT / upsampling / RGB on the GPU)" if colour == "jpeg1296" else "")}
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
@@ -688,7 +706,7 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
         if e2e_n:
             out["end_to_end"] = end_to_end(frames, poses, e2e_n, params, local_rank, torch)
             if rgbd and not args.no_e2e_rgbd:
-                out["end_to_end_rgbd"] = end_to_end(frames, poses, e2e_n, params, local_rank, torch, colour="jpeg1296")
+                out["end_to_end_rgbd"] = end_to_end(frames, poses, min(e2e_n, args.e2e_rgbd_frames), params, local_rank, torch, colour="jpeg1296")
         if cpu_n:   # rank 0 at N = 1 only
             host = frames[:cpu_n].cpu().numpy().view(np.uint16)
             rgb_dev = colour_tensor(max(cpu_n, 1)) if rgbd else None
@@ -988,7 +1006,8 @@ def main():
     ap.add_argument("--scene", type=int, choices=[0, 1], default=1, help="synthetic scene: 0 = the empty box room of rounds 1-2, 1 = the furnished room (default)")
     ap.add_argument("--noise", type=int, choices=[0, 1, 2], default=2, help="depth noise: 1 = the LCG ramp of rounds 1-2, 2 = three LSBs hashed per pixel and frame (default)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (.sens in /tmp -> sf_fuse_run)")
-    ap.add_argument("--e2e-frames", type=int, default=1024)
+    ap.add_argument("--e2e-frames", type=int, default=5578, help="frames of the end-to-end leg (.sens in /tmp -> sf_fuse_run): the whole scene0000_00-scale scan by default")
+    ap.add_argument("--e2e-rgbd-frames", type=int, default=1024, help="frames of its RGB-D variant (1296x968 JPEG colour: encoding and writing the file is what takes the time)")
     ap.add_argument("--cpu-frames", type=int, default=200, help="frames of the CPU-baseline / parity leg")
     ap.add_argument("--no-out-of-cache", action="store_true", help="skip the bounded 1 mm (configs[2]) sub-measurement")
     ap.add_argument("--host-stage", choices=["full", "gpu-decimate", "gpu", "clean", "none"], default="gpu",
