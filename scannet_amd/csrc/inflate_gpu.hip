@@ -28,6 +28,7 @@ struct InflateBatch {
   int32_t tag[IG_BATCH];             // what the caller wants to read back with a failure (a frame number)
   uint32_t expect;                   // bytes every frame must inflate to (a multiple of 4)
   int32_t* status;                   // written ONLY on failure: status[2 * slot] = IL_ST_* < 0, status[2 * slot + 1] = tag
+  uint32_t skip;                     // measurement (sf_zlib_inflate_gpu_bench): 1 = no stage C, 2 = no stage A either; 0 in the product
 };
 
 // exclusive prefix sum of one value per lane over the 1024 lanes of the workgroup; also the total
@@ -111,6 +112,23 @@ struct PlanSink {
     }
     o++;
   }
+  __device__ void put_run(uint16_t v, uint32_t n) {   // n times the same entry, without a loop over the entries (matches are ~4 bytes long: an
+                                                      // entry-by-entry head and tail cost more than the decoding)
+    while (n != 0u && o < head_end) { put(v); n--; }   // the chunk's first entries only
+    if (n == 0u) return;
+    const uint64_t four = (uint64_t)v * 0x0001000100010001ull;
+    const uint32_t k = o & 3u, room = 4u - k, take = n < room ? n : room;
+    const uint64_t part = take == 4u ? four : (four & ((1ull << (16u * take)) - 1ull));
+    acc = k == 0u ? part : acc | (part << (16u * k));
+    o += take;
+    n -= take;
+    if ((o & 3u) == 0u) *reinterpret_cast<uint64_t*>(plan + (o - 4u)) = acc;
+    for (; n >= 4u; n -= 4u, o += 4u) *reinterpret_cast<uint64_t*>(plan + o) = four;
+    if (n != 0u) {
+      acc = four & ((1ull << (16u * n)) - 1ull);
+      o += n;
+    }
+  }
   __device__ void flush() {   // the entries of an unfinished packet
     const uint32_t k = o & 3u;
     if (o >= head_end)
@@ -135,26 +153,28 @@ __global__ __launch_bounds__(IG_LANES) void k_inflate_tokens(InflateBatch B) {
   const uint32_t c = threadIdx.x;
   const bool mine = c < C;
   const uint32_t limit = (c + 1 == C) ? S.nbits : (c + 1) * Bc;
-  // ---- stage A: the chunk starts to their fixed point (bit 3: behind BFINAL and BTYPE).  Rounds 0 and 1 every lane scans its own chunk (the
-  // guessed start is almost never a token boundary: round 1 rescans ~94 %); from round 2 on ~1 % of the chunks restart, and those are dealt to
-  // the first lanes -- left where they are, a dozen chunks kept most of the 16 waves busy for another whole pass.
-  uint32_t start = c == 0 ? 3u : c * Bc, end = 0, outb = 0, flag = IL_FLAG_OK;
-  bool dirty = mine;
-  for (uint32_t round = 0; round < C + 2u; round++) {
+  // ---- stage A: the chunk starts to their fixed point (bit 3: behind BFINAL and BTYPE).  Round 0: every lane scans its own chunk from
+  // IL_LEAD_BITS in front of it and counts from the first token that starts inside (il_guess_start): ~99 % of the lanes are on the true path by
+  // then, the boundary they enter their chunk at IS the left neighbour's stop.  The chunks whose start turns out different rescan from the
+  // neighbour's stop; those few are dealt to the first lanes -- left where they are, a dozen chunks kept most of the 16 waves busy for another
+  // whole pass.
+  uint32_t start = 3u, end = 0, outb = 0, flag = IL_FLAG_OK;
+  bool dirty = mine && B.skip < 2u;
+  for (uint32_t round = 0; round < C + 2u && B.skip < 2u; round++) {
     uint32_t cc = c;   // the chunk this lane scans in this round
     bool work = dirty;
-    uint32_t my_start = start;
-    if (round >= 2u) {
+    uint32_t my_start = il_guess_start(c, Bc), my_own = c == 0 ? 3u : c * Bc;
+    if (round >= 1u) {
       uint32_t ndirty;
       const uint32_t at = block_exscan(dirty ? 1u : 0u, s_wave, ndirty);
       if (dirty) { s_list[at] = c; s_start[c] = start; }
       __syncthreads();
       work = threadIdx.x < ndirty;
-      if (work) { cc = s_list[threadIdx.x]; my_start = s_start[cc]; }
+      if (work) { cc = s_list[threadIdx.x]; my_start = my_own = s_start[cc]; }
     }
     const uint32_t my_limit = (cc + 1 == C) ? S.nbits : (cc + 1) * Bc;
     ILScan sc;
-    lane_pass(mem, slot, my_start, work, [&]() { il_scan_begin(S, sc, my_start); },
+    lane_pass(mem, slot, my_start, work, [&]() { il_scan_begin(S, sc, my_start, my_own); },
               [&](uint32_t until) {
                 il_scan_run(S, sc, until < my_limit ? until : my_limit);
                 return sc.off_end || sc.b.pos >= my_limit;
@@ -163,6 +183,7 @@ __global__ __launch_bounds__(IG_LANES) void k_inflate_tokens(InflateBatch B) {
       s_end[cc] = sc.b.pos;
       s_res[cc] = (sc.out << 2) | sc.fl;
     }
+    if (round == 0u && dirty) start = il_scan_first(sc);   // where the chunk's own tokens begin on the guessed path
     __syncthreads();
     if (dirty) { end = s_end[c]; outb = s_res[c] >> 2; flag = s_res[c] & 3u; }
     bool changed = false;
@@ -185,7 +206,7 @@ __global__ __launch_bounds__(IG_LANES) void k_inflate_tokens(InflateBatch B) {
   else if (total != B.expect) status = IL_ST_SIZE;
   // ---- stage C: the plan -- per output byte, a literal or how far back its source lies
   {
-    const bool writes = status == IL_ST_OK && live && outb != 0u;
+    const bool writes = status == IL_ST_OK && live && outb != 0u && B.skip == 0u;
     PlanSink P{B.plan[f], o, (o + 3u) & ~3u, 0ull};
     ILWrite w;
     w.status = IL_ST_OK;
@@ -318,7 +339,7 @@ int inflate_gpu_batch(hipStream_t stream, int n, const uint32_t* const* d_words,
 
 // scanfuse_internal.h: the two kernels timed apart (HIP events) on `count` <= 32 resident streams, `repeats` times: microseconds per launch of
 // k_inflate_tokens and of k_inflate_copy, for tools/gpu/inflate_bench.py.  The output is not returned (the parity tests check it).
-SF_API int sf_zlib_inflate_gpu_bench(const void* const* srcs, const uint64_t* src_bytes, int count, uint64_t expect_bytes, int device, int repeats, double* us_tokens, double* us_copy) {
+SF_API int sf_zlib_inflate_gpu_bench(const void* const* srcs, const uint64_t* src_bytes, int count, uint64_t expect_bytes, int device, int repeats, int skip, double* us_tokens, double* us_copy) {
   if (!srcs || !src_bytes || count < 1 || count > IG_BATCH || repeats < 1 || !us_tokens || !us_copy || (expect_bytes & 3u)) return sf::fail(SF_ERR_INVALID_ARG, "sf_zlib_inflate_gpu_bench: bad argument");
   SF_HIP_CHECK(hipSetDevice(device));
   InflateBatch b;
@@ -344,6 +365,7 @@ SF_API int sf_zlib_inflate_gpu_bench(const void* const* srcs, const uint64_t* sr
   if (e == hipSuccess) { owned.push_back(d_status); e = hipMemset(d_status, 0, 8 * IG_BATCH); }
   b.expect = (uint32_t)expect_bytes;
   b.status = d_status;
+  b.skip = (uint32_t)skip;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   for (int i = 0; i < 3 && e == hipSuccess; i++) e = hipEventCreate(&ev[i]);
   double t_tok = 0, t_cp = 0;
@@ -364,7 +386,7 @@ SF_API int sf_zlib_inflate_gpu_bench(const void* const* srcs, const uint64_t* sr
   for (hipEvent_t x : ev) if (x) (void)hipEventDestroy(x);
   release();
   if (e != hipSuccess) return sf::fail(SF_ERR_DEVICE, "sf_zlib_inflate_gpu_bench: %s", hipGetErrorString(e));
-  for (int i = 0; i < count; i++) if (st[2 * i] != 0) return sf::fail(SF_ERR_FORMAT, "stream %d: device status %d", i, st[2 * i]);
+  for (int i = 0; i < count && skip == 0; i++) if (st[2 * i] != 0) return sf::fail(SF_ERR_FORMAT, "stream %d: device status %d", i, st[2 * i]);
   *us_tokens = t_tok / repeats;
   *us_copy = t_cp / repeats;
   return SF_OK;

@@ -9,8 +9,9 @@
 //
 // Two kernels per batch of frames:
 //   TOKENS  one 1024-lane workgroup per frame, the stream cut into C <= 1024 chunks of >= 2400 bits:
-//     stage A  lane c decodes chunk c from where lane c - 1 stopped in the previous round (round 0: the chunk's first bit) and records where it
-//              stops and how many bytes its tokens produce; lanes whose start did not change do nothing.  With a FIXED code a decoder started at
+//     stage A  lane c decodes chunk c from where lane c - 1 stopped in the previous round (round 0: from 1024 bits in front of the chunk, counting
+//              from the first token that starts inside it) and records where it stops and how many bytes its tokens produce; lanes whose
+//              start did not change do nothing.  With a FIXED code a decoder started at
 //              an arbitrary bit falls in step with the true tokens after ~20 tokens, lane 0 starts from the truth: the fixed point is the true
 //              tokenisation (measured: 2-3 rounds, 1.95 scans per chunk; tools/inflate_parallelism/README.md).
 //     stage B  exclusive prefix sum of the chunks' output sizes.
@@ -151,34 +152,48 @@ IL_HD ILToken il_token(S& s, ILBits& b) {
 struct ILScan {
   ILBits b;
   uint32_t out, fl;
-  bool off_end;   // ran off the end of the stream
+  bool off_end;      // ran off the end of the stream
+  uint32_t own;      // tokens that start in front of this bit are decoded (to fall in step) but belong to the chunk before: not counted
+  uint32_t first;    // where the first counted token starts (IL_NONE: none yet)
 };
 template <class S>
-IL_HD void il_scan_begin(S& s, ILScan& sc, uint32_t start) {
+IL_HD void il_scan_begin(S& s, ILScan& sc, uint32_t start, uint32_t own) {
   il_bits_init(s, sc.b, start);
   sc.out = 0;
   sc.fl = IL_FLAG_OK;
   sc.off_end = false;
+  sc.own = own;
+  sc.first = IL_NONE;
 }
 template <class S>
 IL_HD void il_scan_run(S& s, ILScan& sc, uint32_t until) {   // the tokens that start in front of bit `until`
   while (!sc.off_end && sc.b.pos < until) {
+    const uint32_t at = sc.b.pos;
     const ILToken t = il_token(s, sc.b);
+    const bool counted = at >= sc.own;
+    sc.first = (counted && sc.first == IL_NONE) ? at : sc.first;
     if (sc.b.pos > s.nbits) {
       if (!(sc.fl & IL_FLAG_EOB)) sc.fl |= IL_FLAG_ERR;
       sc.off_end = true;
       break;
     }
-    const bool live = !(sc.fl & IL_FLAG_EOB);   // behind the end of the block only the position matters
+    const bool live = counted && !(sc.fl & IL_FLAG_EOB);   // behind the end of the block only the position matters
     sc.out += live ? (t.kind == 0u ? 1u : (t.kind == 1u ? t.value : 0u)) : 0u;
     sc.fl |= live ? (t.kind == 3u ? IL_FLAG_ERR : (t.kind == 2u ? IL_FLAG_EOB : 0u)) : 0u;
   }
 }
+IL_HD uint32_t il_scan_first(const ILScan& sc) { return sc.first == IL_NONE ? sc.b.pos : sc.first; }   // where the chunk's own tokens begin on this path
+// Round 0 does not know where chunk c's first token starts.  It starts IL_LEAD_BITS in front of the chunk: a decoder started at an arbitrary bit
+// is in step with the true tokens after ~20 of them (tools/inflate_parallelism/README.md), so most lanes reach their chunk on the true path and
+// the boundary they cross it at is the left neighbour's stop -- no second scan.  The others rescan from the neighbour's stop, as before.
+constexpr uint32_t IL_LEAD_BITS = 1024;
+IL_HD uint32_t il_guess_start(uint32_t c, uint32_t B) { return (c == 0u || c * B < IL_LEAD_BITS + 3u) ? 3u : c * B - IL_LEAD_BITS; }
 template <class S>
-IL_HD void il_scan_chunk(S& s, uint32_t start, uint32_t limit, uint32_t& end, uint32_t& out_bytes, uint32_t& flag) {
+IL_HD void il_scan_chunk(S& s, uint32_t start, uint32_t own, uint32_t limit, uint32_t& first, uint32_t& end, uint32_t& out_bytes, uint32_t& flag) {
   ILScan sc;
-  il_scan_begin(s, sc, start);
+  il_scan_begin(s, sc, start, own);
   il_scan_run(s, sc, limit);
+  first = il_scan_first(sc);
   end = sc.b.pos;
   out_bytes = sc.out;
   flag = sc.fl;
@@ -194,7 +209,7 @@ IL_HD void il_geometry(uint32_t nbits, uint32_t& C, uint32_t& B) {
 }
 
 // stage C: the chunk's tokens once more, written as the plan from offset o on (o_end: what stage A counted for the chunk) through a sink P with
-// P.put(uint16_t) (consecutive offsets) -- the device packs four entries into one 8-byte store.  Returns IL_ST_OK or why the frame is corrupt.
+// P.put(uint16_t) and P.put_run(uint16_t, n) (consecutive offsets) -- the device packs four entries into one 8-byte store.  Returns IL_ST_OK or why the frame is corrupt.
 constexpr uint16_t IL_PLAN_COPY = 0x8000u;
 struct ILWrite {
   ILBits b;
@@ -216,11 +231,17 @@ IL_HD void il_write_run(S& s, ILWrite& w, uint32_t o_end, uint32_t until, P& pla
       w.o++;
     } else if (t.kind == 1u) {
       if (t.dist > w.o) { w.status = IL_ST_BAD_DISTANCE; break; }
-      uint32_t far = t.dist - 1u, within = 0;                             // far <= 32 767: beyond d itself only when d < 258 (then <= 514)
       const uint32_t n = t.value < o_end - w.o ? t.value : o_end - w.o;   // stage A counted whole tokens: n == t.value on the true path
-      for (uint32_t i = 0; i < n; i++) {
-        plan.put((uint16_t)(IL_PLAN_COPY | far));
-        if (++within == t.dist) { within = 0; far += t.dist; }
+      if (t.dist >= n) {
+        // the usual match (a depth row copies the row above it): every byte is the same distance from its source -- one value, n times
+        // (entry by entry, the lanes of a wave waited for the longest match among them: the writing pass took 0.8 of the kernel's 1.1 ms)
+        plan.put_run((uint16_t)(IL_PLAN_COPY | (t.dist - 1u)), n);
+      } else {
+        uint32_t far = t.dist - 1u, within = 0;                           // a run that repeats itself: far <= 514
+        for (uint32_t i = 0; i < n; i++) {
+          plan.put((uint16_t)(IL_PLAN_COPY | far));
+          if (++within == t.dist) { within = 0; far += t.dist; }
+        }
       }
       w.o += n;
     } else {

@@ -27,13 +27,17 @@ def main():
         d = synth.render_room_depth(synth.trajectory_pose(i, 5578), 640, 480, noise_frame=i, noise=2, boxes=boxes)
         blobs.append(np.frombuffer(sens.zlib_deflate(d.tobytes()), np.uint8))
     L = _abi.lib()
-    L.sf_zlib_inflate_gpu_bench.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_int, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.sf_zlib_inflate_gpu_bench.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     ptrs = (C.c_void_p * len(blobs))(*[b.ctypes.data for b in blobs])
     sizes = (C.c_uint64 * len(blobs))(*[b.size for b in blobs])
     t, c = C.c_double(0), C.c_double(0)
-    _abi.check(L.sf_zlib_inflate_gpu_bench(ptrs, sizes, len(blobs), 614400, 0, a.repeats, C.byref(t), C.byref(c)))
+    parts = {}
+    for skip, name in ((1, "us_tokens_without_the_writing_pass"), (2, "us_tokens_without_scans_and_writing_pass")):
+        _abi.check(L.sf_zlib_inflate_gpu_bench(ptrs, sizes, len(blobs), 614400, 0, a.repeats, skip, C.byref(t), C.byref(c)))
+        parts[name] = round(t.value, 1)
+    _abi.check(L.sf_zlib_inflate_gpu_bench(ptrs, sizes, len(blobs), 614400, 0, a.repeats, 0, C.byref(t), C.byref(c)))
     comp = sum(b.size for b in blobs)
-    print(json.dumps({"frames": len(blobs), "compressed_bytes_per_frame": comp // len(blobs), "us_tokens": round(t.value, 1), "us_copy": round(c.value, 1),
+    print(json.dumps({"frames": len(blobs), "compressed_bytes_per_frame": comp // len(blobs), "us_tokens": round(t.value, 1), **parts, "us_copy": round(c.value, 1),
                       "frames_per_s_if_serial": round(len(blobs) / ((t.value + c.value) * 1e-6)), "frames_per_s_if_overlapped": round(len(blobs) / (max(t.value, c.value) * 1e-6)),
                       "compressed_GBs_tokens": round(comp / (t.value * 1e-6) / 1e9, 2), "output_GBs_copy": round(len(blobs) * 614400 / (c.value * 1e-6) / 1e9, 2)}))
 

@@ -50,7 +50,7 @@ static int emulate(const void* src_, uint64_t n, void* dst, uint64_t dst_cap, ui
     for (uint32_t c = 0; c < C; c++)
       if (dirty[c]) {
         if (start[c] == IL_NONE) { end[c] = IL_NONE; outb[c] = 0; flag[c] = IL_FLAG_EOB; }
-        else { il_scan_chunk(s, start[c], (c + 1 == C) ? s.nbits : (c + 1) * B, end[c], outb[c], flag[c]); scans++; }
+        else { uint32_t first_; il_scan_chunk(s, start[c], start[c], (c + 1 == C) ? s.nbits : (c + 1) * B, first_, end[c], outb[c], flag[c]); scans++; }
       }
     bool any = false;
     for (uint32_t c = 0; c < C; c++) {

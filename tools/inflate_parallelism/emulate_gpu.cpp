@@ -46,15 +46,20 @@ int main(int argc, char** argv) {
   // ---- k_inflate_tokens
   std::vector<uint32_t> start(C), end(C, 0), outb(C, 0), flag(C, IL_FLAG_OK);
   std::vector<char> dirty(C, 1);
-  for (uint32_t c = 0; c < C; c++) start[c] = c == 0 ? 3u : c * B;
-  uint32_t rounds = 0, scans = 0;
+  uint32_t rounds = 0, scans = 0, rescans_round1 = 0;
   for (;;) {
     rounds++;
     for (uint32_t c = 0; c < C; c++)
-      if (dirty[c]) { il_scan_chunk(S, start[c], (c + 1 == C) ? S.nbits : (c + 1) * B, end[c], outb[c], flag[c]); scans++; }
+      if (dirty[c]) {
+        const uint32_t limit = (c + 1 == C) ? S.nbits : (c + 1) * B;
+        if (rounds == 1) il_scan_chunk(S, il_guess_start(c, B), c == 0 ? 3u : c * B, limit, start[c], end[c], outb[c], flag[c]);   // start[c]: where the chunk's own tokens begin on the guessed path
+        else { uint32_t first; il_scan_chunk(S, start[c], start[c], limit, first, end[c], outb[c], flag[c]); }
+        scans++;
+      }
     bool any = false;
     for (uint32_t c = C; c-- > 1;) { dirty[c] = end[c - 1] != start[c]; start[c] = end[c - 1]; any = any || dirty[c]; }
     dirty[0] = 0;
+    if (rounds == 1) for (uint32_t c = 0; c < C; c++) rescans_round1 += dirty[c];
     if (!any || rounds > C + 2) break;
   }
   int32_t status = IL_ST_OK;
@@ -74,7 +79,7 @@ int main(int argc, char** argv) {
   else if (total != expect) status = IL_ST_SIZE;
   std::vector<uint8_t> out((size_t)expect + IL_GROUP, 0xEE);
   std::vector<uint16_t> plan((size_t)expect + IL_GROUP, 0xEEEE);
-  struct Sink { uint16_t* p; void put(uint16_t v) { *p++ = v; } };
+  struct Sink { uint16_t* p; void put(uint16_t v) { *p++ = v; } void put_run(uint16_t v, uint32_t n) { while (n--) *p++ = v; } };
   for (uint32_t c = 0; c < C && status == IL_ST_OK; c++)
     if (live[c] && outb[c]) { Sink P{plan.data() + off[c]}; status = il_write_chunk(S, start[c], off[c], off[c] + outb[c], P); }
   // ---- k_inflate_copy
@@ -116,7 +121,7 @@ int main(int argc, char** argv) {
     if (bad) status = IL_ST_BAD_DISTANCE;
   }
   if (status != IL_ST_OK) { std::printf("status %d\n", status); return 3; }
-  std::printf("chunks %u | tokens: %u rounds, %.2f scans per chunk | copies: %u groups, %.2f pointer-jumping rounds per group (max %u) | %u bytes\n", C, rounds, (double)scans / C, steps,
+  std::printf("chunks %u | tokens: %u rounds, %.2f scans per chunk, %u chunks rescanned after round 0 | copies: %u groups, %.2f pointer-jumping rounds per group (max %u) | %u bytes\n", C, rounds, (double)scans / C, rescans_round1, steps,
               (double)jump_rounds / steps, max_rounds, expect);
   if (argc > 3) { FILE* o = std::fopen(argv[3], "wb"); if (o) { std::fwrite(out.data(), 1, expect, o); std::fclose(o); } }
   return 0;
