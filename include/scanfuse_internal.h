@@ -47,7 +47,7 @@ int sf_fuser_mc_timing(const sf_fuser* f, double* out, int n);
  * for streams the device leaves to the host inflater (anything but ONE final fixed-Huffman block -- what the reference's writer and this
  * library's emit; expect_bytes not a multiple of 4), SF_ERR_FORMAT for corrupt streams and streams that inflate to another size. */
 int sf_zlib_inflate_gpu(const void* src, uint64_t src_bytes, uint64_t expect_bytes, int device, void* dst);
-/* The two kernels of that path timed apart (HIP events) on `count` <= 32 resident streams: microseconds per launch (tools/gpu/inflate_bench.py); skip: 1 = the token kernel without its writing pass, 2 = without its scans either (what is left is set-up, prefix sums and launch). */
+/* The two kernels of that path timed apart (HIP events) on `count` <= 32 resident streams: microseconds per launch (tools/gpu/inflate_bench.py); skip (a -DSF_MEASURE_ABLATE build only, SF_ERR_UNSUPPORTED otherwise): 1 = the token kernel without its writing pass, 2 = without its scans either. */
 int sf_zlib_inflate_gpu_bench(const void* const* srcs, const uint64_t* src_bytes, int count, uint64_t expect_bytes, int device, int repeats, int skip, double* us_tokens, double* us_copy);
 
 /* One baseline-JPEG picture through the whole DEVICE path of the frame pipeline: headers parsed and the byte stuffing removed on the host, entropy

@@ -28,7 +28,7 @@ struct InflateBatch {
   int32_t tag[IG_BATCH];             // what the caller wants to read back with a failure (a frame number)
   uint32_t expect;                   // bytes every frame must inflate to (a multiple of 4)
   int32_t* status;                   // written ONLY on failure: status[2 * slot] = IL_ST_* < 0, status[2 * slot + 1] = tag
-  uint32_t skip;                     // measurement (sf_zlib_inflate_gpu_bench): 1 = no stage C, 2 = no stage A either; 0 in the product
+  uint32_t skip;                     // read only in a -DSF_MEASURE_ABLATE build (sf_zlib_inflate_gpu_bench): 1 = no stage C, 2 = no stage A either
 };
 
 // exclusive prefix sum of one value per lane over the 1024 lanes of the workgroup; also the total
@@ -159,8 +159,13 @@ __global__ __launch_bounds__(IG_LANES) void k_inflate_tokens(InflateBatch B) {
   // neighbour's stop; those few are dealt to the first lanes -- left where they are, a dozen chunks kept most of the 16 waves busy for another
   // whole pass.
   uint32_t start = 3u, end = 0, outb = 0, flag = IL_FLAG_OK;
-  bool dirty = mine && B.skip < 2u;
-  for (uint32_t round = 0; round < C + 2u && B.skip < 2u; round++) {
+#ifdef SF_MEASURE_ABLATE
+  const uint32_t skip = B.skip;
+#else
+  constexpr uint32_t skip = 0u;
+#endif
+  bool dirty = mine && skip < 2u;
+  for (uint32_t round = 0; round < C + 2u && skip < 2u; round++) {
     uint32_t cc = c;   // the chunk this lane scans in this round
     bool work = dirty;
     uint32_t my_start = il_guess_start(c, Bc), my_own = c == 0 ? 3u : c * Bc;
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(IG_LANES) void k_inflate_tokens(InflateBatch B) {
   else if (total != B.expect) status = IL_ST_SIZE;
   // ---- stage C: the plan -- per output byte, a literal or how far back its source lies
   {
-    const bool writes = status == IL_ST_OK && live && outb != 0u && B.skip == 0u;
+    const bool writes = status == IL_ST_OK && live && outb != 0u && skip == 0u;
     PlanSink P{B.plan[f], o, (o + 3u) & ~3u, 0ull};
     ILWrite w;
     w.status = IL_ST_OK;
@@ -341,6 +346,9 @@ int inflate_gpu_batch(hipStream_t stream, int n, const uint32_t* const* d_words,
 // k_inflate_tokens and of k_inflate_copy, for tools/gpu/inflate_bench.py.  The output is not returned (the parity tests check it).
 SF_API int sf_zlib_inflate_gpu_bench(const void* const* srcs, const uint64_t* src_bytes, int count, uint64_t expect_bytes, int device, int repeats, int skip, double* us_tokens, double* us_copy) {
   if (!srcs || !src_bytes || count < 1 || count > IG_BATCH || repeats < 1 || !us_tokens || !us_copy || (expect_bytes & 3u)) return sf::fail(SF_ERR_INVALID_ARG, "sf_zlib_inflate_gpu_bench: bad argument");
+#ifndef SF_MEASURE_ABLATE
+  if (skip != 0) return sf::fail(SF_ERR_UNSUPPORTED, "sf_zlib_inflate_gpu_bench: the stage switches exist in a -DSF_MEASURE_ABLATE build only (SCANFUSE_BUILD_FLAGS)");
+#endif
   SF_HIP_CHECK(hipSetDevice(device));
   InflateBatch b;
   std::memset(&b, 0, sizeof(b));

@@ -52,6 +52,21 @@ def token_cases():
     cases["distances around 256"] = t
     cases["literals only"] = [int(v) for v in rng.integers(0, 256, 5000)]
     cases["tiny"] = [5, 6, 7, (9, 3)]
+    for k in range(12):                                                                             # random mixes: every length, distances of every size class, literal runs
+        r = np.random.default_rng(100 + k)
+        t = [int(v) for v in r.integers(0, 256, int(r.integers(1, 400)))]
+        produced = len(t)
+        for _ in range(int(r.integers(200, 9000))):
+            if r.random() < (0.1, 0.5, 0.9)[k % 3]:
+                t.append(int(r.integers(0, 256)))
+                produced += 1
+            else:
+                length = int(r.integers(3, 259)) if r.random() < 0.3 else int(r.integers(3, 12))
+                top = min(produced, 32768)
+                dist = int(r.integers(1, top + 1)) if r.random() < 0.5 else int(min(top, 2 ** int(r.integers(0, 16)) + int(r.integers(0, 3))))
+                t.append((length, max(1, dist)))
+                produced += length
+        cases["random mix %d" % k] = t
     return cases
 
 

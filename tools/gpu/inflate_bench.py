@@ -33,8 +33,9 @@ def main():
     t, c = C.c_double(0), C.c_double(0)
     parts = {}
     for skip, name in ((1, "us_tokens_without_the_writing_pass"), (2, "us_tokens_without_scans_and_writing_pass")):
-        _abi.check(L.sf_zlib_inflate_gpu_bench(ptrs, sizes, len(blobs), 614400, 0, a.repeats, skip, C.byref(t), C.byref(c)))
-        parts[name] = round(t.value, 1)
+        # the stage switches are compiled only with SCANFUSE_BUILD_FLAGS=-DSF_MEASURE_ABLATE (python -c 'from scannet_amd import build; build.build(force=True)')
+        if L.sf_zlib_inflate_gpu_bench(ptrs, sizes, len(blobs), 614400, 0, a.repeats, skip, C.byref(t), C.byref(c)) == 0:
+            parts[name] = round(t.value, 1)
     _abi.check(L.sf_zlib_inflate_gpu_bench(ptrs, sizes, len(blobs), 614400, 0, a.repeats, 0, C.byref(t), C.byref(c)))
     comp = sum(b.size for b in blobs)
     print(json.dumps({"frames": len(blobs), "compressed_bytes_per_frame": comp // len(blobs), "us_tokens": round(t.value, 1), **parts, "us_copy": round(c.value, 1),
