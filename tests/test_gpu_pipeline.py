@@ -412,6 +412,35 @@ def test_gpu_inflate_equals_zlib():
         with pytest.raises(ScanfuseError) as ei:
             sens.zlib_inflate(foreign, 4000, device=0)
         assert "sf_zlib_inflate" in str(ei.value)
+    # mutated streams: the device's verdict is the host inflater's -- the same bytes, or both refuse (and nothing faults)
+    raw = synth.render_room_depth(synth.trajectory_pose(11, 1200), 320, 240, noise_frame=5).tobytes()
+    z = bytearray(sens.zlib_deflate(raw))
+    agree = [0, 0]
+    for k in range(120):
+        m = bytearray(z)
+        if k % 4 == 0:
+            i = int(rng.integers(2, len(m) - 4)); m[i] ^= 1 << int(rng.integers(0, 8))
+        elif k % 4 == 1:
+            i = int(rng.integers(2, len(m) - 4)); m[i] = int(rng.integers(0, 256))
+        elif k % 4 == 2:
+            m = m[: int(rng.integers(8, len(m)))]
+        else:
+            i = int(rng.integers(2, len(m) - 40)); m[i:i + 8] = bytes(rng.integers(0, 256, 8, dtype=np.uint8))
+        m = bytes(m)
+        try:
+            host = sens.zlib_inflate(m, len(raw))
+            host = host if len(host) == len(raw) else None
+        except ScanfuseError:
+            host = None
+        try:
+            dev = sens.zlib_inflate(m, len(raw), device=0)
+        except ScanfuseError as e:
+            if "goes to sf_zlib_inflate" in str(e):
+                continue            # no longer one final fixed block: the pipeline hands it to the host inflater
+            dev = None
+        assert (dev is None) == (host is None) and dev == host, k
+        agree[dev is None] += 1
+    assert agree[0] >= 3 and agree[1] >= 40, agree
 
 
 def test_jpeg_gpu_entropy_decoding_equals_the_host_decoder():

@@ -114,3 +114,43 @@ def test_corrupt_and_foreign_streams(emulate):
     assert emulate(dt.zlib_stream(lits, header=(0, 1)), 4000)[0] == 2                          # not the final block
     junk = dt.zlib_stream(lits)[:-4] + bytes(rng.integers(0, 256, 600, dtype=np.uint8))        # whatever follows the end-of-block code is not decoded
     assert emulate(junk, 4000)[0] == 0
+
+
+def test_mutated_streams_get_the_host_inflater_verdict(emulate):
+    """Bit flips, byte pokes and truncations of a depth frame's stream: whatever the device's lane programs make of it is what the host inflater
+    (sf_zlib_inflate, itself fuzzed against zlib: tools/fuzz_codecs.py) makes of it -- the same bytes, or both refuse.  A stream that stops being
+    'one final fixed block' is the host's by construction (exit code 2)."""
+    from scannet_amd import sens, synth
+    from scannet_amd._abi import ScanfuseError
+    raw = synth.render_room_depth(synth.trajectory_pose(11, 1200), 320, 240, noise_frame=5).tobytes()
+    z = bytearray(sens.zlib_deflate(raw))
+    rng = np.random.default_rng(42)
+    agree_ok = agree_bad = foreign = 0
+    for k in range(160):
+        m = bytearray(z)
+        kind = k % 4
+        if kind == 0:
+            i = int(rng.integers(2, len(m) - 4)); m[i] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:
+            i = int(rng.integers(2, len(m) - 4)); m[i] = int(rng.integers(0, 256))
+        elif kind == 2:
+            m = m[: int(rng.integers(8, len(m)))]
+        else:
+            i = int(rng.integers(2, len(m) - 40)); m[i:i + 8] = bytes(rng.integers(0, 256, 8, dtype=np.uint8))
+        m = bytes(m)
+        try:
+            host = sens.zlib_inflate(m, len(raw))
+            host_ok = len(host) == len(raw)
+        except ScanfuseError:
+            host, host_ok = None, False
+        rc, text, got = emulate(m, len(raw))
+        if rc == 2:
+            foreign += 1
+            continue
+        assert (rc == 0) == host_ok, (k, kind, rc, text, host_ok)
+        if rc == 0:
+            assert got == host, (k, kind)
+            agree_ok += 1
+        else:
+            agree_bad += 1
+    assert agree_ok >= 5 and agree_bad >= 60, (agree_ok, agree_bad, foreign)
