@@ -257,7 +257,7 @@ IL_HD int32_t il_write_chunk(S& s, uint32_t start, uint32_t o, uint32_t o_end, P
   return w.status;
 }
 
-// ------------------------------------------------------------------------------------------------ the copy stage, one group of 256 bytes
+// ------------------------------------------------------------------------------------------------ the copy stage, one group of IL_GROUP bytes
 // Lane l of IL_GROUP / 4 owns bytes 4 l .. 4 l + 3 of the group at output offset `pos`.  M is the workgroup's shared memory:
 //   uint8_t  ring(uint32_t i)                     the byte at output offset i (i in [pos - 32 768, pos))
 //   uint16_t& gref(uint32_t j), uint8_t& gval(j)  per byte of the group: 0xFFFF + its value once known, else the group index of its source

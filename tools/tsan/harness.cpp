@@ -1,7 +1,7 @@
 // TEST INFRASTRUCTURE: ThreadSanitizer run of sf_fuse_run (scannet_amd/csrc/pipeline.hip) against the asynchronous fake HIP runtime.
 // The device side is stubbed: a "pass" (sf_fuser_run_batch) is an operation on the fuser's input stream that reads every byte of the
-// device buffers it was handed (checksum), optionally on a second stream pair like the real fuser; the JPEG reconstruction reads its
-// payloads and writes the RGB buffers.  The checksum over all frames must equal the one computed directly from the decoded file: the
+// device buffers it was handed (checksum), optionally on a second stream pair like the real fuser; the device's inflate is an operation on its
+// stream that inflates with the host inflater (two frames in three travel compressed).  The checksum over all frames must equal the one computed directly from the decoded file: the
 // pipeline delivered every frame, intact, in order -- and TSan saw no race on the way.
 #include <hip/hip_runtime.h>
 
@@ -45,8 +45,37 @@ int sf_fuser_run_batch(sf_fuser* f, const void* const* d_depth, const void* cons
   if (s != f->stream) { hipEventRecord(f->ev_compact[0], s); hipStreamWaitEvent(f->stream, f->ev_compact[0], 0); }
   return SF_OK;
 }
-bool inflate_gpu_takes(const uint8_t*, uint64_t) { return false; }   // the fake device has no kernels: the host threads inflate
-int inflate_gpu_batch(hipStream_t, int, const uint32_t* const*, const uint32_t*, uint8_t* const*, uint16_t* const*, uint32_t, const int32_t*, int32_t*) { return SF_OK; }
+// The device's inflate, faked: an operation on the stream it is launched on that inflates every frame of the launch with the host inflater from the
+// "device" copy of the compressed bytes into the frame buffer the pre-pass will read, and scribbles over the launch's plan scratch (shared by the
+// launches of one stream: a second stream using it at the same time is a race TSan sees).  Two frames in three travel compressed, the third is
+// inflated by a host thread -- both kinds in every batch, as a file with foreign streams gives.
+bool inflate_gpu_takes(const uint8_t* z, uint64_t n) {
+  return n >= 8 && (z[0] & 0x0F) == 8 && ((z[0] << 8 | z[1]) % 31) == 0 && !(z[1] & 0x20) && (z[2] & 7) == 3 && (z[n - 1] + z[n - 2]) % 3 != 0;
+}
+struct FakeInflate { std::vector<const uint32_t*> words; std::vector<uint32_t> nbytes; std::vector<uint8_t*> out; std::vector<uint16_t*> plan; uint32_t expect; int32_t* status; };
+static std::atomic<uint64_t> g_inflated{0};
+static void run_inflate(void* a) {
+  FakeInflate* p = (FakeInflate*)a;
+  g_inflated.fetch_add(p->out.size());
+  for (size_t i = 0; i < p->out.size(); i++) {
+    std::vector<uint8_t> z(2 + (size_t)p->nbytes[i]);
+    z[0] = 0x78; z[1] = 0x01;
+    std::memcpy(z.data() + 2, p->words[i], p->nbytes[i]);
+    std::memset(p->plan[i], (int)i, 2 * (size_t)p->expect);
+    uint64_t got = 0;
+    if (sf_zlib_inflate(z.data(), z.size(), p->out[i], p->expect, &got) != SF_OK || got != p->expect) p->status[2 * i] = -4;
+  }
+  delete p;
+}
+int inflate_gpu_batch(hipStream_t stream, int n, const uint32_t* const* d_words, const uint32_t* nbytes, uint8_t* const* d_out, uint16_t* const* d_plan, uint32_t expect, const int32_t*,
+                      int32_t* d_status) {
+  FakeInflate* p = new FakeInflate();
+  for (int i = 0; i < n; i++) { p->words.push_back(d_words[i]); p->nbytes.push_back(nbytes[i]); p->out.push_back(d_out[i]); p->plan.push_back(d_plan[i]); }
+  p->expect = expect;
+  p->status = d_status;
+  fake_stream_enqueue(stream, run_inflate, p);
+  return SF_OK;
+}
 int jpeg_gpu_huffman(hipStream_t, int, const uint8_t* const*, uint8_t* const*, const uint32_t*, const int32_t*, int32_t*) { return SF_OK; }
 int jpeg_gpu_reconstruct(hipStream_t, int, const uint8_t* const*, uint8_t* const*, uint8_t* const*, uint32_t, uint32_t, uint32_t) { return SF_OK; }   // raw colour in this harness
 
@@ -90,11 +119,14 @@ int main(int argc, char** argv) {
     hipStreamCreateWithFlags(&f.stream, 0); hipStreamCreateWithFlags(&f.front, 0);
     hipEventCreateWithFlags(&f.ev_compact[0], 0);
     g_sum = 0;
+    g_inflated = 0;
     sf_run_stats st;
     const int rc = sf_fuse_run(&f, s, 0, 0, threads, &st);
     if (rc != SF_OK) { std::fprintf(stderr, "sf_fuse_run: %s\n", sf_last_error()); rc_all = 6; }
     const bool ok = g_sum.load() == want && st.frames_integrated == seq;
-    std::printf("batch %2d: %llu frames fused, %llu skipped, checksum %s\n", batch, (unsigned long long)st.frames_integrated, (unsigned long long)st.frames_skipped, ok ? "ok" : "MISMATCH");
+    std::printf("batch %2d: %llu frames fused (%llu of them inflated by the fake device), %llu skipped, checksum %s\n", batch, (unsigned long long)st.frames_integrated,
+                (unsigned long long)g_inflated.load(), (unsigned long long)st.frames_skipped, ok ? "ok" : "MISMATCH");
+    if (g_inflated.load() == 0 || g_inflated.load() == st.frames_integrated) rc_all = 8;   // both kinds of frames must have been there
     if (!ok) rc_all = 7;
     hipStreamDestroy(f.front); hipStreamDestroy(f.stream); hipEventDestroy(f.ev_compact[0]);
     f.stream = f.front = nullptr;
