@@ -185,9 +185,14 @@ int sf_fuser_export_boundary(sf_fuser* f, int32_t* coords, void* voxels, uint64_
 int sf_fuser_import_ghosts(sf_fuser* f, const int32_t* coords, const void* voxels, uint64_t n, int src_on_device, uint64_t* imported);
 
 /* Fuse frames [first, last) of an opened .sens file (last = 0: to the end): a pool of `decode_threads` (0 = one
- * per core) inflates depth frames into pinned buffers in frame order, copies and kernels are queued as frames
- * become ready.  Replaces the frame loop around RGBDFrameCacheRead (sensorData.h:1717-1831).  The fuser must have
- * been created for the file's depth resolution.  Colour is fused when it is stored at depth resolution. */
+ * per core, at most 32 / 64) fills pinned buffers in frame order -- zlib depth frames as the reference's writer
+ * stores them (one fixed-Huffman block, stb_image_write.h:733-736) are copied COMPRESSED and inflated on the GPU
+ * (4 threads keep up); any other depth stream and JPEG / PNG colour are decoded by the pool (JPEG: entropy decoding
+ * only, the rest on the GPU) --, copies and kernels are queued as frames become ready.  Replaces the frame loop around
+ * RGBDFrameCacheRead (sensorData.h:1717-1831) and, inside it, decompressDepthAlloc / decompressColorAlloc
+ * (sensorData.h:600-616, 693-709).  The fuser must have been created for the file's depth resolution.  Colour is fused
+ * when it is stored at depth resolution or at the colour resolution given in sf_params.  Streams and the page-locked
+ * pool are kept for the next call of the process. */
 typedef struct sf_run_stats {
   uint64_t frames_total, frames_integrated, frames_skipped;
   uint32_t decode_threads, color_fused;
