@@ -347,6 +347,24 @@ def end_to_end(frames_dev, poses, n, params, local_rank, torch, colour=None):
             if best is None or rs["seconds_total"] < best[0]["seconds_total"]:
                 best = (rs, st)
         host_inflate = None
+        kernels = None
+        if colour is None:   # the two inflate kernels alone: 32 frames of this file per launch, HIP events around each (scanfuse_internal.h)
+            try:
+                from scannet_amd import _abi
+                L = _abi.lib()
+                L.sf_zlib_inflate_gpu_bench.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+                blobs = [np.frombuffer(sens.zlib_deflate(host[i * max(1, n // 32)].tobytes()), np.uint8) for i in range(min(32, n))]   # the file's streams: the same writer
+                ptrs = (C.c_void_p * len(blobs))(*[b.ctypes.data for b in blobs])
+                sizes = (C.c_uint64 * len(blobs))(*[b.size for b in blobs])
+                tt, tc = C.c_double(0), C.c_double(0)
+                if L.sf_zlib_inflate_gpu_bench(ptrs, sizes, len(blobs), W * H * 2, local_rank, 10, 0, C.byref(tt), C.byref(tc)) == 0:
+                    comp = sum(b.size for b in blobs)
+                    kernels = {"frames_per_launch": len(blobs), "k_inflate_tokens_us": round(tt.value, 1), "k_inflate_copy_us": round(tc.value, 1),
+                               "compressed_GBs_tokens": round(comp / (tt.value * 1e-6) / 1e9, 2), "output_GBs_copy": round(len(blobs) * W * H * 2 / (tc.value * 1e-6) / 1e9, 2),
+                               "what": "csrc/inflate_gpu.hip alone on 32 frames of this file, resident: 1024 lanes per frame tokenise (speculative chunk starts, prefix sums, the per-byte plan), "
+                                       "a 256-lane workgroup per frame makes the copies in 1024-byte groups with the window in LDS; counters: profiles/r04_pmc_inflate_kernels.txt"}
+            except Exception as ex:   # the leg is a measurement beside the metric: never take the line down
+                kernels = {"error": str(ex)[:200]}
         if colour is None:   # rounds 1-3: every host thread this process may use inflates (SF_INFLATE_HOST)
             os.environ["SF_INFLATE_HOST"] = "1"
             try:
@@ -373,7 +391,7 @@ def end_to_end(frames_dev, poses, n, params, local_rank, torch, colour=None):
         return {"marching_cubes": mc, "frames": int(rs["frames_total"]), "frames_per_s": round(rs["frames_total"] / rs["seconds_total"], 1), "seconds": round(rs["seconds_total"], 4),
                 "compressed_bytes_per_frame": round(size / n), "sens_bytes": size, "decode_threads": int(rs["decode_threads"]),
                 "decode_ms_per_frame_per_thread": round(1e3 * rs["seconds_decode_cpu"] / max(rs["frames_total"], 1), 3),
-                "colour_fused": int(rs["color_fused"]), "frames_per_s_first_and_second_run": runs, "depth_inflate": "gpu (csrc/inflate_gpu.hip)", "host_inflate": host_inflate,
+                "colour_fused": int(rs["color_fused"]), "frames_per_s_first_and_second_run": runs, "depth_inflate": "gpu (csrc/inflate_gpu.hip)", "inflate_kernels": kernels, "host_inflate": host_inflate,
                 "blocks_live_end": st["blocks_allocated"], "alloc_failures": st["alloc_failures"], "write_s": round(t_write, 2),
                 "what": ".sens on disk (zlib depth%s, %d KB per frame) -> %d host threads copy the compressed depth frames%s into the pinned ring -> H2D -> inflate on the GPU -> pre-pass / "
                         "allocation / compaction / integrate, 32 frames per pass; wall time of sf_fuse_run (first byte read -> last kernel complete), best of 2 (the first run of a "
