@@ -292,50 +292,93 @@ def pmc_valu(args, config, steps, warmup, single_frame, depth_only):
 # ---------------------------------------------------------------------------------------------------------------------------------------
 # configs[1] / configs[2]: one resident stream per rank
 # ---------------------------------------------------------------------------------------------------------------------------------------
+def textured_pictures(cw, ch, count=8, amp=3.0):
+    """Synthetic colour pictures with the entropy of real ones: a smooth scene under two octaves of sensor-like noise.  At quality 90, 4:2:0, a 1296x968
+    picture compresses to ~190-205 KB -- ScanNet's own range is 50-250 KB (sensorData.h:600-616; SURVEY 8a row a3 probed 204 KB); the smooth
+    pictures of round 4 came to 77-110 KB, and Huffman decoding costs per entropy-coded byte."""
+    yy, xx = np.mgrid[0:ch, 0:cw]
+    out = []
+    for k in range(count):
+        rng = np.random.default_rng(k)
+        base = np.stack([(xx // 3 + 31 * k) % 256, (yy // 2 + 17 * k) % 256, (128 + 100 * np.sin(xx / 30.0) * np.cos(yy / 20.0 + k))], -1)
+        coarse = rng.normal(0, amp, (ch // 2 + 1, cw // 2 + 1, 3)).repeat(2, 0).repeat(2, 1)[:ch, :cw]
+        out.append(np.clip(base + coarse + rng.normal(0, amp / 2, (ch, cw, 3)), 0, 255).astype(np.uint8))
+    return out
+
+
 def end_to_end(frames_dev, poses, n, params, local_rank, torch, colour=None):
-    """SURVEY 8d "End-to-end frames/s": the first n frames of the run's stream written to a .sens in /tmp (zlib depth, this library's writer),
-    then sf_fuse_run: file -> decode pool -> pinned ring -> H2D -> fusion.  Wall time from the first byte decoded to the last kernel.
-    colour = "jpeg1296": every frame also carries a baseline-JPEG colour image at ScanNet's real 1296x968 with its own intrinsics
-    (sensorData.h:600-616: Huffman decode on the host threads, IDCT / upsampling / YCbCr->RGB on the GPU, then the colour pre-pass samples it
-    under each depth pixel's ray) -- eight distinct encoded images cycled, so the set-up does not encode thousands of frames."""
+    """SURVEY 8d "End-to-end frames/s": the first n frames of the run's stream in a .sens in /tmp, then sf_fuse_run: file -> host threads -> pinned
+    ring -> H2D -> inflate on the GPU -> fusion.  Wall time from the first byte read to the last kernel.  The file is written by the REFERENCE
+    writer when oracle/_ref/libref_sens.so is there (SensorData::createFrame per frame: stb deflate at quality 8, sensorData.h:659-670 ->
+    stb_image_write.h:721-823 -- the bytes real ScanNet files hold; outside the timed region, as every write is); the same frames through this
+    library's writer are timed beside it (`other_writer`).  `frames_per_s` is the FIRST run of the file in this process (one process per scan is the
+    pipeline's contract, Server/scan_processor.py:138); the second run is in `frames_per_s_first_and_second_run`.
+    colour = "jpeg1296": every frame also carries a baseline-JPEG colour picture at ScanNet's real 1296x968 with its own intrinsics, ~200 KB each
+    (textured_pictures; eight distinct ones cycled): entropy decoding on the host threads or the GPU, IDCT / upsampling / YCbCr->RGB on the GPU,
+    then the colour pre-pass samples it under each depth pixel's ray.  The reference cannot encode JPEG off Windows (sensorData.h:576-593), so that
+    container is assembled by this library from the reference writer's depth blobs and this library's JPEG encoder."""
     from scannet_amd import fusion, sens, synth
     d = tempfile.mkdtemp(prefix="sf_e2e_", dir="/tmp")
     try:
-        path = os.path.join(d, "stream.sens")
         host = frames_dev[:n].cpu().numpy().view(np.uint16)
         K = synth.intrinsic_matrix(W, H)
-        t0 = time.perf_counter()
+        P44 = poses[:n].reshape(-1, 4, 4)
+        orc = None
+        try:
+            from oracle import oracle as _orc   # the reference WRITER only (input preparation, outside every timed region)
+            if _orc.ref_sens_available() and hasattr(_orc.ref_sens(), "ref_sens_add_frames_mt"):
+                orc = _orc
+        except Exception:
+            orc = None
+        files = []   # (writer, path, seconds to write)
         prm = params
         if colour == "jpeg1296":
             from scannet_amd import calibrate
             cw, ch = 1296, 968
             KC = synth.intrinsic_matrix(cw, ch)
-            yy, xx = np.mgrid[0:ch, 0:cw]
-            blobs = []
-            for k in range(8):
-                img = np.stack([(xx // 3 + 31 * k) % 256, (yy // 2 + 17 * k) % 256, (128 + 100 * np.sin(xx / 30.0) * np.cos(yy / 20.0 + k))], -1).astype(np.uint8)
-                blobs.append(calibrate.jpeg_encode(img, 90, True))
+            blobs = [calibrate.jpeg_encode(img, 90, True) for img in textured_pictures(cw, ch)]
+            t0 = time.perf_counter()
+            zd = orc.ref_write_sens(None, host, P44, K, want_blobs=True) if orc else None
             sd = sens.SensorData.create(cw, ch, W, H, KC, K, color_compression=2, depth_compression=1, sensor_name="StructureSensor")
             for i in range(n):
-                sd.add_frame(host[i], poses[i].reshape(4, 4), color=blobs[i % 8], timestamp_depth=33333 * i)
+                if zd is not None:
+                    sd.add_frame_blobs(zd[i], P44[i], color_blob=blobs[i % 8], timestamp_depth=33333 * i)
+                else:
+                    sd.add_frame(host[i], P44[i], color=blobs[i % 8], timestamp_depth=33333 * i)
+            path = os.path.join(d, "rgbd.sens")
+            sd.save(path)
+            sd.close()
+            del zd
+            files.append(("depth: reference (stb); colour: this library's baseline-JPEG encoder" if orc else "this library", path, time.perf_counter() - t0))
             prm = type(params).from_buffer_copy(params)
             prm.color_width, prm.color_height = cw, ch
             prm.cfx, prm.cfy, prm.cmx, prm.cmy = synth.intrinsics(cw, ch)
+            jpeg_bytes = round(sum(len(b) for b in blobs) / len(blobs))
         else:
+            jpeg_bytes = None
+            if orc:
+                t0 = time.perf_counter()
+                path = os.path.join(d, "reference_writer.sens")
+                orc.ref_write_sens(path, host, P44, K)
+                files.append(("reference (stb)", path, time.perf_counter() - t0))
+            t0 = time.perf_counter()
             sd = sens.SensorData.create(0, 0, W, H, K, K, depth_compression=1, sensor_name="StructureSensor")
-            sd.add_depth_frames(host, poses[:n].reshape(-1, 4, 4))
-        sd.save(path)
-        sd.close()
-        t_write = time.perf_counter() - t0
+            sd.add_depth_frames(host, P44)
+            path = os.path.join(d, "this_library.sens")
+            sd.save(path)
+            sd.close()
+            files.append(("this library", path, time.perf_counter() - t0))
+        writer, path, t_write = files[0]
         size = os.path.getsize(path)
         sd = sens.SensorData(path)
         best = None
+        first_run = None
         mc = None
         runs = []
-        threads = min(4, os.cpu_count() or 4)   # the depth frames are inflated on the GPU: a host thread copies 330 KB per frame
+        threads = min(4, os.cpu_count() or 4)   # the depth frames are inflated on the GPU: a host thread copies 330-370 KB per frame
         for _ in range(2):   # the second pass reads the file from the page cache, as the stage after `convert` does, and finds the process's streams and pinned pool made
             with fusion.Fuser(prm, device=local_rank, **TUNE) as f:
-                rs = f.run(sd, decode_threads=threads if colour is None else 0)
+                rs = f.run(sd, decode_threads=threads if colour is None else 0)   # JPEG colour: every host thread entropy-decodes (0 = all the process may use)
                 st = f.stats()
                 runs.append(round(rs["frames_total"] / rs["seconds_total"], 1))
                 if colour is None:   # what follows the fusion in the `improve` stage: marching cubes over the fused volume (second call: warm)
@@ -344,8 +387,19 @@ def end_to_end(frames_dev, poses, n, params, local_rank, torch, colour=None):
                     del_mesh = f.extract_mesh()
                     del del_mesh
                     mc = f.mc_timing()
+            if first_run is None:
+                first_run = (rs, st)
             if best is None or rs["seconds_total"] < best[0]["seconds_total"]:
                 best = (rs, st)
+        other = None
+        if len(files) > 1:   # the same frames through the other writer's streams
+            w2, p2, tw2 = files[1]
+            sd2 = sens.SensorData(p2)
+            with fusion.Fuser(prm, device=local_rank, **TUNE) as f:
+                r2 = f.run(sd2, decode_threads=threads if colour is None else 0)
+                other = {"writer": w2, "frames_per_s": round(r2["frames_total"] / r2["seconds_total"], 1), "compressed_bytes_per_frame": round(os.path.getsize(p2) / n),
+                         "depth_inflated_on_device": int(r2.get("depth_inflated_on_device", -1)), "write_s": round(tw2, 2), "run": "third of the process"}
+            sd2.close()
         host_inflate = None
         kernels = None
         if colour is None:   # the two inflate kernels alone: 32 frames of this file per launch, HIP events around each (scanfuse_internal.h)
@@ -353,7 +407,8 @@ def end_to_end(frames_dev, poses, n, params, local_rank, torch, colour=None):
                 from scannet_amd import _abi
                 L = _abi.lib()
                 L.sf_zlib_inflate_gpu_bench.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
-                blobs = [np.frombuffer(sens.zlib_deflate(host[i * max(1, n // 32)].tobytes()), np.uint8) for i in range(min(32, n))]   # the file's streams: the same writer
+                fr = sd.frames
+                blobs = [np.frombuffer(fr[i * max(1, n // 32)].depth_compressed, np.uint8) for i in range(min(32, n))]   # the file's own streams, as its writer made them
                 ptrs = (C.c_void_p * len(blobs))(*[b.ctypes.data for b in blobs])
                 sizes = (C.c_uint64 * len(blobs))(*[b.size for b in blobs])
                 tt, tc = C.c_double(0), C.c_double(0)
@@ -362,7 +417,8 @@ def end_to_end(frames_dev, poses, n, params, local_rank, torch, colour=None):
                     kernels = {"frames_per_launch": len(blobs), "k_inflate_tokens_us": round(tt.value, 1), "k_inflate_copy_us": round(tc.value, 1),
                                "compressed_GBs_tokens": round(comp / (tt.value * 1e-6) / 1e9, 2), "output_GBs_copy": round(len(blobs) * W * H * 2 / (tc.value * 1e-6) / 1e9, 2),
                                "what": "csrc/inflate_gpu.hip alone on 32 frames of this file, resident: 1024 lanes per frame tokenise (speculative chunk starts, prefix sums, the per-byte plan), "
-                                       "a 256-lane workgroup per frame makes the copies in 1024-byte groups with the window in LDS; counters: profiles/r04_pmc_inflate_kernels.txt"}
+                                       "a 256-lane workgroup per frame makes the copies in 1024-byte groups with the window in LDS; counters: profiles/r04_pmc_inflate_kernels.txt",
+                               "streams_of": writer}
             except Exception as ex:   # the leg is a measurement beside the metric: never take the line down
                 kernels = {"error": str(ex)[:200]}
         if colour is None:   # rounds 1-3: every host thread this process may use inflates (SF_INFLATE_HOST)
@@ -388,16 +444,22 @@ def end_to_end(frames_dev, poses, n, params, local_rank, torch, colour=None):
             mc["what"] = ("sf_fuser_extract_mesh over the %d live blocks of the fused prefix, second call, milliseconds per phase (HIP events; host_alloc_and_wait: wall clock): two passes of "
                           "k_mc staging a 9^3 tile per block (count, emit), rocPRIM radix sorts of the 3T edge keys and the T cube keys, weld, download of %.0f MB through two page-locked "
                           "bounce buffers with a copy team" % (mc["blocks"], out_b / 1e6))
-        return {"marching_cubes": mc, "frames": int(rs["frames_total"]), "frames_per_s": round(rs["frames_total"] / rs["seconds_total"], 1), "seconds": round(rs["seconds_total"], 4),
-                "compressed_bytes_per_frame": round(size / n), "sens_bytes": size, "decode_threads": int(rs["decode_threads"]),
+        r1 = first_run[0]
+        return {"marching_cubes": mc, "frames": int(r1["frames_total"]), "frames_per_s": round(r1["frames_total"] / r1["seconds_total"], 1), "seconds": round(r1["seconds_total"], 4),
+                "frames_per_s_best": round(rs["frames_total"] / rs["seconds_total"], 1), "writer": writer, "other_writer": other,
+                "compressed_bytes_per_frame": round(size / n), "jpeg_bytes_per_picture": jpeg_bytes, "sens_bytes": size, "decode_threads": int(rs["decode_threads"]),
                 "decode_ms_per_frame_per_thread": round(1e3 * rs["seconds_decode_cpu"] / max(rs["frames_total"], 1), 3),
-                "colour_fused": int(rs["color_fused"]), "frames_per_s_first_and_second_run": runs, "depth_inflate": "gpu (csrc/inflate_gpu.hip)", "inflate_kernels": kernels, "host_inflate": host_inflate,
+                "colour_fused": int(rs["color_fused"]), "frames_per_s_first_and_second_run": runs,
+                "depth_inflated_on_device": int(rs.get("depth_inflated_on_device", -1)), "depth_inflated_on_host": int(rs.get("depth_inflated_on_host", -1)),
+                "jpeg_entropy_on_device": int(rs.get("jpeg_entropy_on_device", -1)), "jpeg_entropy_on_host": int(rs.get("jpeg_entropy_on_host", -1)),
+                "depth_inflate": "gpu (csrc/inflate_gpu.hip)", "inflate_kernels": kernels, "host_inflate": host_inflate,
                 "blocks_live_end": st["blocks_allocated"], "alloc_failures": st["alloc_failures"], "write_s": round(t_write, 2),
-                "what": ".sens on disk (zlib depth%s, %d KB per frame) -> %d host threads copy the compressed depth frames%s into the pinned ring -> H2D -> inflate on the GPU -> pre-pass / "
-                        "allocation / compaction / integrate, 32 frames per pass; wall time of sf_fuse_run (first byte read -> last kernel complete), best of 2 (the first run of a "
-                        "process also creates the run's five streams and its pinned pool: frames_per_s_first_and_second_run); host_inflate: the same file with the host threads inflating"
-                        % (" + baseline-JPEG colour at 1296x968 with its own intrinsics" if colour == "jpeg1296" else "", size // n // 1024, rs["decode_threads"],
-                           " and Huffman-decode the colour frames (IDCT / upsampling / RGB on the GPU)" if colour == "jpeg1296" else "")}
+                "what": ".sens on disk written by: %s (zlib depth%s, %d KB per frame) -> %d host threads copy the compressed depth frames%s into the pinned ring -> H2D -> inflate on the GPU -> "
+                        "pre-pass / allocation / compaction / integrate, 32 frames per pass; wall time of sf_fuse_run (first byte read -> last kernel complete); frames_per_s = the FIRST run "
+                        "of the file in this process (it creates the run's streams and its pinned pool), frames_per_s_best = the better of two; other_writer: the same frames as this "
+                        "library's writer compresses them; host_inflate: the same file with the host threads inflating"
+                        % (writer, " + baseline-JPEG colour at 1296x968 with its own intrinsics, %d KB per picture" % (jpeg_bytes // 1024) if colour == "jpeg1296" else "", size // n // 1024,
+                           rs["decode_threads"], " and Huffman-decode the colour frames (IDCT / upsampling / RGB on the GPU)" if colour == "jpeg1296" else "")}
     finally:
         shutil.rmtree(d, ignore_errors=True)
 

@@ -192,7 +192,11 @@ int sf_fuser_import_ghosts(sf_fuser* f, const int32_t* coords, const void* voxel
  * RGBDFrameCacheRead (sensorData.h:1717-1831) and, inside it, decompressDepthAlloc / decompressColorAlloc
  * (sensorData.h:600-616, 693-709).  The fuser must have been created for the file's depth resolution.  Colour is fused
  * when it is stored at depth resolution or at the colour resolution given in sf_params.  Streams and the page-locked
- * pool are kept for the next call of the process. */
+ * pool are kept for the next call of the process.  The library never touches the process
+ * environment: the run wants a hardware queue per stream (HIP's GPU_MAX_HW_QUEUES, default 4, the application's to
+ * export before its first HIP call); on fewer it still returns SF_OK and leaves a "note: ..." text in sf_last_error().
+ * A depth frame whose stream is corrupt fails the run with SF_ERR_FORMAT; when the device inflated it, the frame was
+ * fused as "no measurement" (zero depth) before the failure reached the host -- never with another frame's pixels. */
 typedef struct sf_run_stats {
   uint64_t frames_total, frames_integrated, frames_skipped;
   uint32_t decode_threads, color_fused;
@@ -262,6 +266,9 @@ int sf_sens_decode_depth(const sf_sens* s, uint64_t frame, uint16_t* dst);
 int sf_sens_decode_color(const sf_sens* s, uint64_t frame, uint8_t* dst_rgb);
 int sf_sens_pose(const sf_sens* s, uint64_t frame, float out16[16], int* valid);
 int sf_sens_frame_meta(const sf_sens* s, uint64_t frame, sf_sens_frame_meta_t* out);
+/* RGBDFrame::getColorCompressed / getDepthCompressed (sensorData.h:418-429): the frame's compressed blobs where they lie (any out pointer may be
+ * NULL); valid until sf_sens_close or, for a file under construction, until the next frame is added. */
+int sf_sens_frame_blobs(const sf_sens* s, uint64_t frame, const uint8_t** color, uint64_t* color_bytes, const uint8_t** depth, uint64_t* depth_bytes);
 /* Writer.  `header` supplies everything but num_frames / num_imu.  color = W*H*3 RGB bytes for TYPE_RAW, an
  * already encoded blob for TYPE_JPEG / TYPE_PNG, or NULL / 0 for no colour; depth = W*H u16, compressed as
  * header->depth_compression says (0 raw, 1 zlib). */
@@ -272,6 +279,10 @@ int sf_sens_add_frame(sf_sens* s, const uint8_t* color, uint64_t color_bytes, co
  * threads (0 = every CPU this process may use) and appended in order -- the result is the file n sf_sens_add_frame calls would write. */
 int sf_sens_add_depth_frames(sf_sens* s, const uint16_t* depth, uint64_t frame_stride_bytes, uint64_t n, const float* poses,
                              uint64_t timestamp0_us, uint64_t timestamp_step_us, int threads);
+/* A frame whose colour and depth blobs are already in the container's compression types -- stored as given (what RGBDFrame::loadFromFile
+ * keeps per frame, sensorData.h:743-754): transcoding, merging files, depth streams another writer compressed. */
+int sf_sens_add_frame_blobs(sf_sens* s, const uint8_t* color, uint64_t color_bytes, const uint8_t* depth, uint64_t depth_bytes,
+                            const float pose[16], uint64_t timestamp_color, uint64_t timestamp_depth);
 int sf_sens_set_pose(sf_sens* s, uint64_t frame, const float pose[16]);
 int sf_sens_save(const sf_sens* s, const char* path);
 

@@ -50,6 +50,10 @@ int sf_zlib_inflate_gpu(const void* src, uint64_t src_bytes, uint64_t expect_byt
 /* The two kernels of that path timed apart (HIP events) on `count` <= 32 resident streams: microseconds per launch (tools/gpu/inflate_bench.py); skip (a -DSF_MEASURE_ABLATE build only, SF_ERR_UNSUPPORTED otherwise): 1 = the token kernel without its writing pass, 2 = without its scans either. */
 int sf_zlib_inflate_gpu_bench(const void* const* srcs, const uint64_t* src_bytes, int count, uint64_t expect_bytes, int device, int repeats, int skip, double* us_tokens, double* us_copy);
 
+/* Where the frames of the calling thread's last sf_fuse_run were decoded: out[0] zlib depth frames inflated on the device, out[1] by the host threads
+ * (streams the device does not take, or SF_INFLATE_HOST), out[2] JPEG colour frames entropy-decoded on the device, out[3] by the host threads. */
+int sf_fuse_run_device_counts(uint64_t out[4]);
+
 /* One baseline-JPEG picture through the whole DEVICE path of the frame pipeline: headers parsed and the byte stuffing removed on the host, entropy
  * decoding (csrc/jpeg_huff_gpu.hip) and reconstruction (csrc/jpeg_gpu.hip) on GPU `device`; the bytes are sf_jpeg_decode's.  SF_ERR_UNSUPPORTED
  * for what the device's entropy decoder leaves to the host (restart intervals, sampling factors above 2), SF_ERR_FORMAT for a corrupt stream. */

@@ -221,8 +221,46 @@ def ref_sens():
         L.ref_sens_create.argtypes = [C.c_uint32] * 4 + [C.c_void_p, C.c_void_p, C.c_float, C.c_char_p]
         L.ref_sens_add_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
         L.ref_sens_save.argtypes = [C.c_void_p, C.c_char_p]
+        if hasattr(L, "ref_sens_add_frames_mt"):
+            L.ref_sens_add_frames_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int]
+            L.ref_sens_depth_blob.restype = C.c_void_p
+            L.ref_sens_depth_blob.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         _ref = L
     return _ref
+
+
+def ref_write_sens(path, depth, poses, intrinsic_depth, rgb=None, intrinsic_color=None, threads=0, depth_shift=1000.0, name=b"StructureSensor",
+                   timestamp_step=33333, want_blobs=False):
+    """A .sens written by the REFERENCE writer: SensorData::initDefault + createFrame per frame (stb deflate, quality 8: sensorData.h:659-670 ->
+    stb_image_write.h:721-823) + saveToFile, through oracle/_ref/libref_sens.so.  depth [n, H, W] uint16, poses [n, 4, 4]; rgb None (a file
+    without colour: colour size 0 x 0, TYPE_RAW) or [n, Hc, Wc, 3] uint8 stored raw -- the reference cannot encode JPEG off Windows
+    (sensorData.h:576-593).  Frames are compressed on `threads` threads (0 = all this process may use).  Returns the depth blobs when asked."""
+    import numpy as np
+    R = ref_sens()
+    d = np.ascontiguousarray(depth, np.uint16)
+    n, H, W = d.shape
+    p = np.ascontiguousarray(poses, np.float32).reshape(n, 16)
+    Kd = np.ascontiguousarray(intrinsic_depth, np.float32)
+    Kc = Kd if intrinsic_color is None else np.ascontiguousarray(intrinsic_color, np.float32)
+    c = None if rgb is None else np.ascontiguousarray(rgb, np.uint8)
+    cw, ch = (0, 0) if c is None else (c.shape[2], c.shape[1])
+    h = R.ref_sens_create(cw, ch, W, H, Kc.ctypes.data_as(C.c_void_p), Kd.ctypes.data_as(C.c_void_p), float(depth_shift), name)
+    try:
+        nt = threads if threads > 0 else len(os.sched_getaffinity(0))
+        if R.ref_sens_add_frames_mt(h, None if c is None else c.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), n, p.ctypes.data_as(C.c_void_p), 0, int(timestamp_step), nt) != 0:
+            raise RuntimeError("reference writer failed")
+        blobs = None
+        if want_blobs:
+            blobs = []
+            for i in range(n):
+                nb = C.c_uint64(0)
+                q = R.ref_sens_depth_blob(h, i, C.byref(nb))
+                blobs.append(C.string_at(q, nb.value))
+        if path is not None and R.ref_sens_save(h, os.fsencode(path)) != 0:
+            raise RuntimeError("reference saveToFile failed: %s" % path)
+        return blobs
+    finally:
+        R.ref_sens_close(h)
 
 
 # ---------------------------------------------------------------- calibrate stage (oracle/calib_oracle.c)

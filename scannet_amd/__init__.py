@@ -4,12 +4,9 @@ Host-side Python mirror of the reference interfaces for this path (SensReader, t
 Segmentator) over the C ABI of libscanfuse.so (include/scanfuse.h).  The compute path is hand-written HIP
 for gfx950; importing a compute entry point without the built library raises (no CPU fallback).
 """
-import os as _os
+# Importing this package changes nothing in the process: the HIP runtime's GPU_MAX_HW_QUEUES (hardware queues per process, default 4; sf_fuse_run
+# drives up to seven streams and wants 12) is the APPLICATION's to export before its first HIP call -- bench.py, tools/e2e_bench.py and the bin/
+# tools do it in their own main(); sf_fuse_run leaves a note in sf_last_error() when it ran on fewer queues than streams (INTEGRATION.md section 4).
+RECOMMENDED_ENV = {"GPU_MAX_HW_QUEUES": "12"}
 
-# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels of streams that share one run
-# one after the other: with the fuser's two streams, two copy streams and three inflate streams an inflate batch sat in the integrate pass's
-# queue (sf_fuse_run 29 k -> 20 k frames/s in its loop).  Read at the first HIP call; a value the user exported wins.  libscanfuse.so does the
-# same when it is loaded (csrc/pipeline.hip), for callers that are not Python.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
-
-__all__ = ["synth"]
+__all__ = ["synth", "RECOMMENDED_ENV"]

@@ -139,6 +139,8 @@ struct PlanSink {
 __global__ __launch_bounds__(IG_LANES) void k_inflate_tokens(InflateBatch B) {
   __shared__ uint32_t s_lit[512], s_dist[32], s_end[IG_LANES], s_res[IG_LANES], s_start[IG_LANES], s_list[IG_LANES], s_wave[IG_LANES / 64];
   __shared__ uint32_t s_slots[IG_LANES * 33];
+  // 154 KB of static LDS: this kernel needs gfx950's 160 KB per workgroup (the library is built for gfx950 alone; a 64 KB part would need 512 lanes)
+  static_assert(sizeof(uint32_t) * (512 + 32 + 4 * IG_LANES + IG_LANES / 64 + IG_LANES * 33) <= 160 * 1024, "k_inflate_tokens: LDS budget of gfx950");
   const int f = blockIdx.x;
   if (B.out[f] == nullptr) return;
   for (uint32_t i = threadIdx.x; i < 512u; i += IG_LANES) s_lit[i] = il_lit_entry(i);
@@ -262,9 +264,13 @@ __global__ __launch_bounds__(IG_COPY_LANES) void k_inflate_copy(InflateBatch B) 
   __shared__ uint8_t s_gval[IL_GROUP];
   __shared__ uint32_t s_flag[2];
   const int f = blockIdx.x;
-  if (B.out[f] == nullptr || B.status[2 * f] != 0) return;   // a frame k_inflate_tokens gave up on stays as it is
+  if (B.out[f] == nullptr) return;
   const uint32_t lane = threadIdx.x, total = B.expect;
   uint32_t* __restrict__ out32 = reinterpret_cast<uint32_t*>(B.out[f]);
+  if (B.status[2 * f] != 0) {   // a frame k_inflate_tokens gave up on: depth 0 = "no measurement" everywhere, so that nothing of whatever the slot held
+    for (uint32_t i = lane; i < total / 4u; i += IG_COPY_LANES) out32[i] = 0u;   // before is fused under this frame's pose while the failure travels to the host
+    return;
+  }
   const uint64_t* __restrict__ plan64 = reinterpret_cast<const uint64_t*>(B.plan[f]);
   const GroupMem M{reinterpret_cast<uint8_t*>(s_ring), s_gref, s_gval};
   if (lane < 2u) s_flag[lane] = 0u;
@@ -308,9 +314,12 @@ __global__ __launch_bounds__(IG_COPY_LANES) void k_inflate_copy(InflateBatch B) 
 #pragma unroll
     for (uint32_t i = 0; i < IG_BLOCK; i++) cur[i] = nxt[i];
   }
-  if (bad) {
-    B.status[2 * f] = IL_ST_BAD_DISTANCE;
-    B.status[2 * f + 1] = B.tag[f];
+  if (__syncthreads_or((int)bad)) {   // a match that reaches in front of the output: the frame is void (see above)
+    for (uint32_t i = lane; i < total / 4u; i += IG_COPY_LANES) out32[i] = 0u;
+    if (bad) {
+      B.status[2 * f] = IL_ST_BAD_DISTANCE;
+      B.status[2 * f + 1] = B.tag[f];
+    }
   }
 }
 
@@ -318,8 +327,13 @@ __global__ __launch_bounds__(IG_COPY_LANES) void k_inflate_copy(InflateBatch B) 
 
 // Is this zlib stream one the device inflates (deflate, no preset dictionary, ONE final block with the fixed code)?  The host threads of the
 // frame pipeline ask before they decide where a depth frame is inflated.
+// Size bound: the kernels count output bytes in 32 bits.  The densest token is a 258-byte match in 13 bits (8-bit length code 285 + 5-bit
+// distance code, no extra bits): a stream of n bytes inflates to at most n * 8 / 13 * 258 < 159 n bytes, so below 2^24 bytes of deflate data no
+// count -- per chunk, prefix sum or total -- can wrap (2^24 * 159 = 2.7e9 < 2^32).  A depth frame's stream is bounded by its pixels anyway.
+constexpr uint64_t IG_MAX_STREAM_BYTES = 1ull << 24;
+static_assert(IG_MAX_STREAM_BYTES * 8 / 13 * 258 < (1ull << 32), "32-bit output counts of the inflate kernels");
 bool inflate_gpu_takes(const uint8_t* z, uint64_t n) {
-  return n >= 8 && (z[0] & 0x0F) == 8 && ((z[0] << 8 | z[1]) % 31) == 0 && !(z[1] & 0x20) && (z[2] & 7) == 3 && n - 2 < (1ull << 28);
+  return n >= 8 && (z[0] & 0x0F) == 8 && ((z[0] << 8 | z[1]) % 31) == 0 && !(z[1] & 0x20) && (z[2] & 7) == 3 && n - 2 < IG_MAX_STREAM_BYTES;
 }
 
 // Inflate up to 32 frames on `stream`: d_words[i] = the zlib stream from its third byte on (nbytes[i] bytes, 64-byte aligned, with 256 readable
@@ -330,6 +344,8 @@ int inflate_gpu_batch(hipStream_t stream, int n, const uint32_t* const* d_words,
   if (n < 1 || n > IG_BATCH || (expect & 3u) || !d_status) return sf::fail(SF_ERR_INVALID_ARG, "inflate_gpu_batch: %d frames of %u bytes", n, expect);
   InflateBatch b;
   std::memset(&b, 0, sizeof(b));
+  for (int i = 0; i < n; i++)
+    if (nbytes[i] >= IG_MAX_STREAM_BYTES) return sf::fail(SF_ERR_INVALID_ARG, "inflate_gpu_batch: stream %d has %u bytes (the device takes < 2^24: 32-bit output counts)", i, nbytes[i]);
   for (int i = 0; i < n; i++) {
     b.words[i] = d_words[i]; b.nbytes[i] = nbytes[i]; b.out[i] = d_out[i]; b.plan[i] = d_plan[i];
     b.tag[i] = tags ? tags[i] : i;

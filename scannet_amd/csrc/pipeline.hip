@@ -35,12 +35,22 @@ int jpeg_gpu_reconstruct(hipStream_t stream, int n, const uint8_t* const* d_payl
                          uint32_t max_width, uint32_t max_height);  // jpeg_gpu.hip
 
 // The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and kernels of streams that share a queue
-// run one after the other.  sf_fuse_run drives seven streams (the fuser's two, two for copies, three for the inflate kernels); on four queues
-// every third batch's inflate sat in the integrate pass's queue (29 k -> 20 k frames/s in the loop).  The variable is read at the first HIP call
-// of the process; one the user exported wins.
-__attribute__((constructor)) static void sf_ask_for_hardware_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "12", 0); }
+// run one after the other.  sf_fuse_run drives up to seven streams (the fuser's two, two for colour copies, three for the inflate kernels); on four
+// queues every third batch's inflate sat in the integrate pass's queue (29 k -> 20 k frames/s in the loop).  The variable belongs to the PROCESS
+// (it is read at its first HIP call): the library does not touch the environment -- the bin/ tools and bench.py export GPU_MAX_HW_QUEUES=12 in
+// their own main() before the first HIP call, and a run that finds fewer queues than it has streams says so through
+// sf_last_error() while returning SF_OK (sf_fuse_run_note).
 
 namespace {
+
+thread_local uint64_t t_run_counts[4] = {0, 0, 0, 0};   // of this thread's last sf_fuse_run: depth frames inflated on the device / by the host threads, colour
+                                                        // frames entropy-decoded on the device / by the host threads (sf_fuse_run_device_counts)
+
+int hardware_queues_of_the_process() {   // what the runtime was (or will be) told; its default is 4
+  const char* v = std::getenv("GPU_MAX_HW_QUEUES");
+  const int n = v ? std::atoi(v) : 0;
+  return n > 0 ? n : 4;
+}
 
 // What sf_fuse_run sets up and does not need fresh: five streams (a hardware queue each: ~5 ms to create, and the runtime creates them one
 // after the other whatever the threads do) and the pinned pool (~6 ms per 100 MB).  Kept per device for the life of the process and handed
@@ -366,6 +376,7 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   int result = SF_OK;
   std::string err;
   uint64_t n_int = 0, n_skip = 0;
+  uint64_t n_dev_z = 0, n_host_z = 0, n_dev_j = 0, n_host_j = 0;
   for (uint64_t g = 0; g < nbatches && result == SF_OK; g++) {
     const int sl = (int)(g % (uint64_t)NB);
     BatchSlot& bs = ring[(size_t)sl];
@@ -404,6 +415,8 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
       valid[j] = s->frames[frame].pose[0] != -INFINITY;
       rgbf[j] = valid[j] && use_rgb && s->frames[frame].color_bytes != 0;
       if (!valid[j]) { n_skip++; f->frames_skipped++; }
+      else if (s->info.depth_compression == 1) { if (gpu_inflate && zmode[g * (uint64_t)B + (uint64_t)j]) n_dev_z++; else n_host_z++; }
+      if (rgbf[j] && jpeg_colour) { if (bs.coef_mode[j] == 2) n_dev_j++; else n_host_j++; }
     }
     bool any_comp = false;
     const uint64_t k0 = g * (uint64_t)B;   // index of the batch's first frame in the run
@@ -567,27 +580,34 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   for (hipStream_t q : inflate_stream) if (q) (void)hipStreamSynchronize(q);
   if (result == SF_OK && qe == hipSuccess && d_zstatus) {   // a depth frame the device's inflate gave up on fails the run, as it would on the host
     std::vector<int32_t> st((size_t)NB * B * 2);
-    if (hipMemcpy(st.data(), d_zstatus, st.size() * 4, hipMemcpyDeviceToHost) == hipSuccess)
-      for (size_t i = 0; i < st.size(); i += 2)
-        if (st[i] != 0) {
-          result = SF_ERR_FORMAT;
-          err = "inflate: depth frame " + std::to_string(st[i + 1]) + ": corrupt stream, or it does not inflate to the frame's size (device status " + std::to_string(st[i]) + ")";
-          break;
-        }
+    const hipError_t re = hipMemcpy(st.data(), d_zstatus, st.size() * 4, hipMemcpyDeviceToHost);
+    if (re != hipSuccess) { result = SF_ERR_DEVICE; err = std::string("inflate: the device's frame status could not be read back: ") + hipGetErrorString(re); }
+    for (size_t i = 0; i < st.size() && result == SF_OK; i += 2)
+      if (st[i] != 0) {   // the frame itself was fused as "no measurement" (k_inflate_copy zero-fills what it gives up on)
+        result = SF_ERR_FORMAT;
+        err = "inflate: depth frame " + std::to_string(st[i + 1]) + ": corrupt stream, or it does not inflate to the frame's size (device status " + std::to_string(st[i]) + ")";
+      }
   }
   if (result == SF_OK && qe == hipSuccess && d_jstatus) {   // a colour frame the device's entropy decoder gave up on fails the run, as it would on the host
     std::vector<int32_t> st((size_t)NB * B * 2);
-    if (hipMemcpy(st.data(), d_jstatus, st.size() * 4, hipMemcpyDeviceToHost) == hipSuccess)
-      for (size_t i = 0; i < st.size(); i += 2)
-        if (st[i] != 0) {
-          result = SF_ERR_FORMAT;
-          err = "jpeg: colour frame " + std::to_string(st[i + 1]) + ": corrupt or truncated entropy-coded segment (device status " + std::to_string(st[i]) + ")";
-          break;
-        }
+    const hipError_t re = hipMemcpy(st.data(), d_jstatus, st.size() * 4, hipMemcpyDeviceToHost);
+    if (re != hipSuccess) { result = SF_ERR_DEVICE; err = std::string("jpeg: the device's picture status could not be read back: ") + hipGetErrorString(re); }
+    for (size_t i = 0; i < st.size() && result == SF_OK; i += 2)
+      if (st[i] != 0) {
+        result = SF_ERR_FORMAT;
+        err = "jpeg: colour frame " + std::to_string(st[i + 1]) + ": corrupt or truncated entropy-coded segment (device status " + std::to_string(st[i]) + ")";
+      }
   }
   cleanup();
+  t_run_counts[0] = n_dev_z; t_run_counts[1] = n_host_z; t_run_counts[2] = n_dev_j; t_run_counts[3] = n_host_j;
   if (result != SF_OK) return sf::fail(result, "%s", err.c_str());
   if (qe != hipSuccess) return sf::fail(SF_ERR_DEVICE, "device error while fusing: %s", hipGetErrorString(qe));
+  {   // a note, not an error: the run used more streams than the process has hardware queues (see the top of this file)
+    const int streams_used = 2 + (copy_stream ? 2 : 0) + (gpu_inflate ? NZ : 0), queues = hardware_queues_of_the_process();
+    if (streams_used > queues)
+      (void)sf::fail(SF_OK, "note: sf_fuse_run drove %d streams over %d hardware queues (kernels of streams that share a queue run one after the other); "
+                             "export GPU_MAX_HW_QUEUES=12 before the process's first HIP call", streams_used, queues);
+  }
   if (stats) {
     stats->frames_total = total;
     stats->frames_integrated = n_int;
@@ -597,5 +617,13 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
     stats->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     stats->seconds_decode_cpu = (double)decode_ns.load() * 1e-9;
   }
+  return SF_OK;
+}
+
+// scanfuse_internal.h: where the frames of this thread's last sf_fuse_run were decoded -- out[0] depth frames inflated on the device, out[1] zlib
+// depth frames inflated by the host threads, out[2] JPEG colour frames entropy-decoded on the device, out[3] by the host threads.
+SF_API int sf_fuse_run_device_counts(uint64_t out[4]) {
+  if (!out) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  for (int i = 0; i < 4; i++) out[i] = t_run_counts[i];
   return SF_OK;
 }

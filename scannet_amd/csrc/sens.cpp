@@ -201,6 +201,19 @@ SF_API int sf_sens_frame_meta(const sf_sens* s, uint64_t frame, sf_sens_frame_me
   return SF_OK;
 }
 
+// RGBDFrame::getColorCompressed / getDepthCompressed / get*SizeBytes (sensorData.h:418-429): the frame's blobs where they lie (in the mapped
+// file or in the writer's storage); valid until the handle is closed or, for a file under construction, until the next frame is added
+SF_API int sf_sens_frame_blobs(const sf_sens* s, uint64_t frame, const uint8_t** color, uint64_t* color_bytes, const uint8_t** depth, uint64_t* depth_bytes) {
+  if (!s) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  if (frame >= s->frames.size()) return sf::fail(SF_ERR_BOUNDS, "frame %llu out of bounds (%zu frames)", (unsigned long long)frame, s->frames.size());
+  const SensFrame& f = s->frames[frame];
+  if (color) *color = f.color;
+  if (color_bytes) *color_bytes = f.color_bytes;
+  if (depth) *depth = f.depth;
+  if (depth_bytes) *depth_bytes = f.depth_bytes;
+  return SF_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ writer
 SF_API int sf_sens_create(const sf_sens_info* header, sf_sens** out) {
   if (!header || !out) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
@@ -226,6 +239,13 @@ SF_API int sf_sens_add_depth_frames(sf_sens* s, const uint16_t* depth, uint64_t 
   const uint64_t raw = (uint64_t)s->info.depth_width * s->info.depth_height * 2;
   if (frame_stride_bytes < raw) return sf::fail(SF_ERR_INVALID_ARG, "frame stride smaller than a frame");
   if (n == 0) return SF_OK;
+  // all or nothing: a failure in a later chunk takes the earlier chunks' frames back out (their blob pointers were never fixed up)
+  const size_t frames_before = s->frames.size();
+  auto fix_up = [&]() {
+    for (SensFrame& q : s->frames)
+      if (!q.owned.empty()) { q.color = q.owned.data(); q.depth = q.owned.data() + q.color_bytes; }
+  };
+  auto undo = [&](int rc) { s->frames.resize(frames_before); fix_up(); return rc; };
   // no exception may cross the C ABI (std::thread's constructor and every allocation below can throw), and the frames are compressed in
   // CHUNKS: only a chunk's worth of deflate-bound-sized buffers is ever alive beside the frames already shrunk to their compressed size
   try {
@@ -273,12 +293,38 @@ SF_API int sf_sens_add_depth_frames(sf_sens* s, const uint16_t* depth, uint64_t 
       }
       work();
       for (auto& t : pool) t.join();
-      if (failed.load() == 1) return sf::fail(SF_ERR_FORMAT, "sf_sens_add_depth_frames: deflate failed");
-      if (failed.load()) return sf::fail(SF_ERR_IO, "sf_sens_add_depth_frames: out of memory");
+      if (failed.load() == 1) return undo(sf::fail(SF_ERR_FORMAT, "sf_sens_add_depth_frames: deflate failed"));
+      if (failed.load()) return undo(sf::fail(SF_ERR_IO, "sf_sens_add_depth_frames: out of memory"));
       for (auto& f : made) s->frames.push_back(std::move(f));
     }
   } catch (const std::exception& e) {
-    return sf::fail(SF_ERR_IO, "sf_sens_add_depth_frames: %s", e.what());
+    return undo(sf::fail(SF_ERR_IO, "sf_sens_add_depth_frames: %s", e.what()));
+  }
+  fix_up();
+  return SF_OK;
+}
+
+// A frame whose blobs are ALREADY in the container's compression (what loadFromFile keeps per frame, sensorData.h:743-754): transcoding,
+// merging files, or pairing depth streams some other writer compressed with colour pictures -- the bytes are stored as given.
+SF_API int sf_sens_add_frame_blobs(sf_sens* s, const uint8_t* color, uint64_t color_bytes, const uint8_t* depth, uint64_t depth_bytes,
+                                   const float pose[16], uint64_t ts_color, uint64_t ts_depth) {
+  if (!s || !pose || (color_bytes && !color) || (depth_bytes && !depth)) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  const uint64_t raw = (uint64_t)s->info.depth_width * s->info.depth_height * 2;
+  if (depth_bytes && s->info.depth_compression == 0 && depth_bytes != raw) return sf::fail(SF_ERR_INVALID_ARG, "raw depth frame must be depthWidth*depthHeight*2 bytes");
+  if (color_bytes && s->info.color_compression == 0 && color_bytes != (uint64_t)s->info.color_width * s->info.color_height * 3)
+    return sf::fail(SF_ERR_INVALID_ARG, "raw colour frame must be colorWidth*colorHeight*3 bytes");
+  try {
+    SensFrame f;
+    std::memcpy(f.pose, pose, 64);
+    f.ts_color = ts_color; f.ts_depth = ts_depth;
+    f.owned.resize(color_bytes + depth_bytes);
+    if (color_bytes) std::memcpy(f.owned.data(), color, color_bytes);
+    if (depth_bytes) std::memcpy(f.owned.data() + color_bytes, depth, depth_bytes);
+    f.color_bytes = color_bytes;
+    f.depth_bytes = depth_bytes;
+    s->frames.push_back(std::move(f));
+  } catch (const std::exception& e) {
+    return sf::fail(SF_ERR_IO, "sf_sens_add_frame_blobs: %s", e.what());
   }
   for (SensFrame& q : s->frames)
     if (!q.owned.empty()) { q.color = q.owned.data(); q.depth = q.owned.data() + q.color_bytes; }

@@ -5,6 +5,7 @@
 // <dir>/<name>.txt and <dir>/<name>.lut are the parameter file and the distance table (:56-57).  No calibration name:
 // "no calibration name found" and success (:59), as the reference.  Progress on stdout, failures on stderr + non-zero exit.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -31,6 +32,7 @@ std::string trim(std::string s) {
 }  // namespace
 
 int main(int argc, const char** argv) {
+  (void)setenv("GPU_MAX_HW_QUEUES", "12", 0);   // this process's streams on hardware queues of their own (the application's decision; an exported value wins)
   if (argc != 5) {
     std::fprintf(stderr, "requires the input sens filepath, output sens filepath, parameter file, and input undistortion table as a command line arguments\n");
     return 1;

@@ -176,7 +176,14 @@ class Fuser:
         """Fuse frames [first, last) of a scannet_amd.sens.SensorData (threaded decode overlapped with the GPU)."""
         st = SfRunStats()
         check(_abi.lib().sf_fuse_run(self._h, sensor_data._h, int(first), int(last), int(decode_threads), C.byref(st)))
-        return {k: getattr(st, k) for k, _ in SfRunStats._fields_}
+        out = {k: getattr(st, k) for k, _ in SfRunStats._fields_}
+        L = _abi.lib()
+        if hasattr(L, "sf_fuse_run_device_counts"):   # scanfuse_internal.h: where the frames were decoded
+            c = (C.c_uint64 * 4)()
+            L.sf_fuse_run_device_counts.argtypes = [C.POINTER(C.c_uint64)]
+            check(L.sf_fuse_run_device_counts(c))
+            out.update(depth_inflated_on_device=c[0], depth_inflated_on_host=c[1], jpeg_entropy_on_device=c[2], jpeg_entropy_on_host=c[3])
+        return out
 
     # -- one large scan over several GPUs (scannet_amd/partition.py) -------------------------------------
     def set_slab(self, axis, lo_block, hi_block):

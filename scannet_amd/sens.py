@@ -79,6 +79,23 @@ class RGBDFrame:
         self.timestamp_color, self.timestamp_depth = m.timestamp_color, m.timestamp_depth
         self.color_size_bytes, self.depth_size_bytes = m.color_bytes, m.depth_bytes
 
+    def _blobs(self):
+        L = _abi.lib()
+        L.sf_sens_frame_blobs.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        cp, dp, cn, dn = C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_uint64()
+        check(L.sf_sens_frame_blobs(self._o._h, self._i, C.byref(cp), C.byref(cn), C.byref(dp), C.byref(dn)))
+        return (C.string_at(cp, cn.value) if cn.value else b""), (C.string_at(dp, dn.value) if dn.value else b"")
+
+    @property
+    def color_compressed(self):
+        """The colour blob as stored (RGBDFrame::getColorCompressed, sensorData.h:418)."""
+        return self._blobs()[0]
+
+    @property
+    def depth_compressed(self):
+        """The depth blob as stored (RGBDFrame::getDepthCompressed, sensorData.h:421)."""
+        return self._blobs()[1]
+
     def decompress_depth(self, compression_type=None):
         """-> uint16 array [depth_height, depth_width] (the reference returns the raw bytes of the same data)."""
         o = self._o
@@ -168,6 +185,15 @@ class SensorData:
             raise ValueError("depth frame size mismatch")
         c = None if color is None else np.ascontiguousarray(np.frombuffer(color, np.uint8) if isinstance(color, (bytes, bytearray)) else color, np.uint8)
         check(_abi.lib().sf_sens_add_frame(self._h, _ptr(c), 0 if c is None else c.size, _ptr(d), _ptr(pose), timestamp_color, timestamp_depth))
+        self._refresh()
+
+    def add_frame_blobs(self, depth_blob, camera_to_world=None, color_blob=None, timestamp_color=0, timestamp_depth=0):
+        """A frame whose blobs are already compressed as the header says: stored as given."""
+        pose = np.ascontiguousarray(np.eye(4) if camera_to_world is None else camera_to_world, np.float32).reshape(16)
+        L = _abi.lib()
+        L.sf_sens_add_frame_blobs.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64]
+        cb, db = bytes(color_blob or b""), bytes(depth_blob or b"")
+        check(L.sf_sens_add_frame_blobs(self._h, cb or None, len(cb), db or None, len(db), _ptr(pose), int(timestamp_color), int(timestamp_depth)))
         self._refresh()
 
     def add_depth_frames(self, depth, poses, timestamp0=0, timestamp_step=33333, threads=0):

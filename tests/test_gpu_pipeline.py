@@ -378,9 +378,9 @@ def test_jpeg_gpu_reconstruction_equals_the_host_decoder():
 
 def test_gpu_inflate_equals_zlib():
     """sf_zlib_inflate_gpu -- the depth frames' inflate as sf_fuse_run does it (csrc/inflate_gpu.hip: 1024 lanes tokenise a frame from guessed
-    chunk starts iterated to their fixed point, ONE wave copies in 256-byte groups with the window in LDS) -- returns zlib's bytes: the streams of
-    this library's writer and of the reference's (one final fixed-Huffman block) on depth frames, noise, constants; token lists no match finder
-    would produce (runs that copy themselves, chains of short near matches, the longest distance, distances around the group size); corrupt
+    chunk starts iterated to their fixed point, a 256-lane workgroup copies in 1024-byte groups with the window in LDS) -- returns zlib's bytes: the
+    streams of THIS LIBRARY's writer (one final fixed-Huffman block, as the reference's; the reference writer's own bytes are the next test) on depth
+    frames, noise, constants; token lists no match finder would produce (runs that copy themselves, chains of short near matches, the longest distance, distances around the group size); corrupt
     streams fail with the host inflater's verdict; dynamic / multi-block streams are refused (the pipeline inflates those on the host)."""
     import zlib
     from scannet_amd import sens
@@ -441,6 +441,106 @@ def test_gpu_inflate_equals_zlib():
         assert (dev is None) == (host is None) and dev == host, k
         agree[dev is None] += 1
     assert agree[0] >= 3 and agree[1] >= 40, agree
+
+
+def _reference_written_frames(oracle, n_room, W=640, H=480, step=173, total=5578):
+    """(frames [n, H, W] u16, poses [n, 4, 4]): furnished-room frames of the configs[1] walk with hashed noise, then a constant-zero, a constant and a noise frame."""
+    rng = np.random.default_rng(9)
+    poses = [synth.trajectory_pose((step * k) % total, total) for k in range(n_room)]
+    frames = [synth.render_room_depth(poses[k], W, H, noise_frame=k, noise=2, boxes=synth.clutter_boxes()) for k in range(n_room)]
+    return frames, poses, rng
+
+
+def test_gpu_inflate_on_the_reference_writers_streams(oracle):
+    """The bytes real ScanNet files hold: depth frames compressed by the REFERENCE writer (oracle/_ref/libref_sens.so = sensorData.h compiled where it
+    lies: SensorData::createFrame -> compressDepth -> stb::stbi_zlib_compress(.., quality 8), sensorData.h:659-670, stb_image_write.h:721-823) --
+    16 furnished 640x480 frames of the configs[1] walk, zeros, a constant, noise, a ramp -- through sf_zlib_inflate_gpu: zlib.decompress's bytes,
+    which are the frames.  These are not the streams this library's writer makes (other matches, ~9 % more bytes)."""
+    import zlib
+    from scannet_amd import sens
+    if not oracle.ref_sens_available() or not hasattr(oracle.ref_sens(), "ref_sens_add_frames_mt"):
+        pytest.skip("oracle/_ref/libref_sens.so not built (needs /root/reference)")
+    W, H = 640, 480
+    frames, poses, rng = _reference_written_frames(oracle, 16)
+    frames += [np.zeros((H, W), np.uint16), np.full((H, W), 2000, np.uint16), rng.integers(0, 65536, (H, W), dtype=np.uint16), (np.arange(W * H, dtype=np.uint32) // 7).astype(np.uint16).reshape(H, W)]
+    P = np.stack(poses + [np.eye(4, dtype=np.float32)] * 4)
+    blobs = oracle.ref_write_sens(None, np.stack(frames), P, synth.intrinsic_matrix(W, H), want_blobs=True)
+    differ = 0
+    for raw, z in zip(frames, blobs):
+        raw = raw.tobytes()
+        want = zlib.decompress(z)
+        assert want == raw
+        assert sens.zlib_inflate(z, len(raw), device=0) == want
+        differ += z != sens.zlib_deflate(raw)
+    assert differ >= 17, differ          # the reference's streams, not ours
+    assert 300_000 < np.mean([len(z) for z in blobs[:16]]) < 520_000   # real-entropy depth: 0.5-0.85 of the pixels' bytes
+
+
+def test_fuse_run_on_a_reference_written_sens_matches_the_oracle(oracle, tmp_path):
+    """A whole .sens written by the reference writer (initDefault + createFrame per frame + saveToFile through libref_sens.so) -> sf_fuse_run with the
+    device's inflate -> the volume oracle.Volume builds from the same frames (NOT the frame-by-frame GPU path: the checker is the CPU restatement),
+    block set and voxels bit for bit; every depth frame was inflated on the device; the reference's own reader returns the frames the file was written from."""
+    import ctypes as C
+    from scannet_amd import fusion, sens
+    if not oracle.ref_sens_available() or not hasattr(oracle.ref_sens(), "ref_sens_add_frames_mt"):
+        pytest.skip("oracle/_ref/libref_sens.so not built (needs /root/reference)")
+    W, H = 640, 480
+    n = 40
+    frames, poses, _ = _reference_written_frames(oracle, n, step=9)       # 40 consecutive-ish frames of the walk: two passes (32 + 8) of the batched schedule
+    poses[7] = np.full((4, 4), -np.inf, np.float32)                         # tracking lost (sensorData.h:382): skipped
+    p = str(tmp_path / "reference.sens")
+    oracle.ref_write_sens(p, np.stack(frames), np.stack(poses), synth.intrinsic_matrix(W, H))
+    R = oracle.ref_sens()
+    h = R.ref_sens_open(p.encode())
+    out = np.zeros((H, W), np.uint16)
+    assert R.ref_sens_decode_depth(h, 5, out.ctypes.data_as(C.c_void_p)) == 0 and np.array_equal(out, frames[5])
+    R.ref_sens_close(h)
+    fx, fy, mx, my = synth.intrinsics(W, H)
+    gp = fusion.default_params(depth_width=W, depth_height=H, fx=fx, fy=fy, mx=mx, my=my, num_sdf_blocks=1 << 18)
+    op = oracle.default_params(W, H)
+    ovol = oracle.Volume(op, threads=8)
+    for i in range(n):
+        if i != 7:
+            ovol.integrate(frames[i], poses[i])
+    sd = sens.SensorData(p)
+    assert sd.depth_compression_type == "zlib_ushort" and sd.num_frames == n
+    with fusion.Fuser(gp) as f:
+        st = f.run(sd, decode_threads=3)
+        assert (st["frames_total"], st["frames_integrated"], st["frames_skipped"]) == (n, n - 1, 1)
+        assert (st["depth_inflated_on_device"], st["depth_inflated_on_host"]) == (n - 1, 0)
+        gc, gv = f.export_blocks()
+    oc, ov = ovol.export()
+    assert np.array_equal(oc, gc), "allocated block sets differ"
+    assert np.array_equal(ov.view(np.uint8), gv.view(np.uint8)), "voxels differ"
+
+
+def test_a_corrupt_depth_frame_is_fused_as_no_measurement_not_as_stale_pixels(tmp_path):
+    """a depth frame the device's inflate gives up on used to leave its slot's previous pixels (the frame NB batches earlier) to be fused
+    under the new pose while the failure travelled to the host.  Now the copy kernel zero-fills such a frame (depth 0 = no measurement) and the run
+    fails with SF_ERR_FORMAT: the volume is bit for bit what the file's other frames give."""
+    from scannet_amd import fusion, sens
+    from tests import deflate_tools as dt
+    W, H = 320, 240
+    good = str(tmp_path / "good.sens")
+    frames = _write_sens(good, 100, W, H, 1200)
+    bad = str(tmp_path / "bad.sens")
+    import shutil
+    shutil.copy(good, bad)
+    short_tokens = list(range(250)) * 4 + [(258, 1000)] * 591 + [(118, 1000)]                # inflates to four bytes less than a frame: the device reports IL_ST_SIZE
+    _recompress_depth_frames(bad, {70}, lambda raw: dt.zlib_stream(short_tokens))
+    fx, fy, mx, my = synth.intrinsics(W, H)
+    gp = fusion.default_params(depth_width=W, depth_height=H, fx=fx, fy=fy, mx=mx, my=my, voxel_size=0.008, num_sdf_blocks=1 << 17)
+    with fusion.Fuser(gp) as a, fusion.Fuser(gp) as b:
+        with pytest.raises(Exception, match="inflate: depth frame 70"):
+            a.run(sens.SensorData(bad), decode_threads=2)
+        for i, (d, pose) in enumerate(frames):
+            if i != 70:
+                b.integrate(d, pose)
+        ca, va = a.export_blocks()
+        cb, vb = b.export_blocks()
+    # the failure is read back when the run ends: every other frame of the file was fused, frame 70 as a frame without a single measurement
+    assert np.array_equal(ca, cb), "the failed run's block set is not that of the file's valid frames: stale pixels were fused"
+    assert np.array_equal(va.view(np.uint8), vb.view(np.uint8))
 
 
 def test_jpeg_gpu_entropy_decoding_equals_the_host_decoder():

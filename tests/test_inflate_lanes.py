@@ -100,6 +100,33 @@ def test_depth_frames_through_this_library_writer(emulate):
     assert max(c for c, _ in seen) > 100 and all(r <= 6 for _, r in seen), seen
 
 
+def test_depth_frames_through_the_reference_writer(emulate, oracle):
+    """The streams REAL .sens files hold: the reference's writer (SensorData::createFrame -> compressDepth -> stb::stbi_zlib_compress at quality 8,
+    sensorData.h:659-670 / stb_image_write.h:721-823: one fixed-Huffman block, stb's hash-chain matcher -- other matches than this library's
+    writer finds, 9 % more bytes) on furnished 640x480 frames, noise, constants and a ramp, through the lane programs on the host."""
+    if not oracle.ref_sens_available() or not hasattr(oracle.ref_sens(), "ref_sens_add_frames_mt"):
+        pytest.skip("oracle/_ref/libref_sens.so not built (needs /root/reference)")
+    from scannet_amd import sens, synth
+    rng = np.random.default_rng(5)
+    W, H = 640, 480
+    frames = [synth.render_room_depth(synth.trajectory_pose(211 * k, 1200), W, H, noise_frame=k, noise=2, boxes=synth.clutter_boxes()) for k in range(3)]
+    frames += [np.zeros((H, W), np.uint16), np.full((H, W), 2000, np.uint16), rng.integers(0, 65536, (H, W), dtype=np.uint16), (np.arange(W * H, dtype=np.uint32) // 7).astype(np.uint16).reshape(H, W)]
+    poses = np.stack([np.eye(4, dtype=np.float32)] * len(frames))
+    blobs = oracle.ref_write_sens(None, np.stack(frames), poses, synth.intrinsic_matrix(W, H), want_blobs=True)
+    seen = []
+    for raw, z in zip(frames, blobs):
+        raw = raw.tobytes()
+        assert zlib.decompress(z) == raw and (z[2] & 7) == 3          # one final block, fixed code
+        assert z != sens.zlib_deflate(raw) or len(set(raw)) <= 2        # not this library's stream (the constants may coincide)
+        rc, text, got = emulate(z, len(raw))
+        assert rc == 0 and got == raw, text
+        m = re.search(r"chunks (\d+) \| tokens: (\d+) rounds", text)
+        seen.append((int(m.group(1)), int(m.group(2))))
+    # a constant frame is one 13-bit token (258 bytes, a fixed distance) over and over: a decoder started at a wrong bit never falls in step with it, the
+    # chunk starts settle one per round -- 19 chunks, 19 rounds, the bound of stage A's loop (the stream is 6 KB); everything with content: 1-3 rounds
+    assert max(c for c, _ in seen) > 500 and all(r <= 6 for c, r in seen if c > 100) and all(r <= c + 1 for c, r in seen), seen
+
+
 def test_corrupt_and_foreign_streams(emulate):
     rng = np.random.default_rng(1)
     lits = [int(v) for v in rng.integers(0, 256, 4000)]

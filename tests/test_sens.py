@@ -215,6 +215,33 @@ def test_reference_reads_ours_and_we_read_reference(oracle, tmp_path):
     assert a[:hdr - 8] == b[:hdr - 8]
 
 
+def test_frame_blobs_are_stored_and_returned_as_given(oracle, tmp_path):
+    """sf_sens_frame_blobs = RGBDFrame::getColorCompressed / getDepthCompressed (sensorData.h:418-429); sf_sens_add_frame_blobs stores blobs some other
+    writer compressed (here: the reference's stb deflate, when it is built) without touching them: the file re-saved from them is the source file."""
+    import zlib
+    W, H = 64, 48
+    frames = _frames(5, W, H, seed=3)
+    src = str(tmp_path / "src.sens")
+    if oracle.ref_sens_available() and hasattr(oracle.ref_sens(), "ref_sens_add_frames_mt"):
+        oracle.ref_write_sens(src, np.stack([d for d, _, _ in frames]), np.stack([p for _, p, _ in frames]), synth.intrinsic_matrix(W, H), rgb=np.stack([c for _, _, c in frames]),
+                              timestamp_step=5)
+    else:
+        _write_ours(src, frames, W, H)
+    a = sens.SensorData(src)
+    K = synth.intrinsic_matrix(W, H)
+    b = sens.SensorData.create(W, H, W, H, K, K, sensor_name="StructureSensor")
+    for i in range(5):
+        f = a.frames[i]
+        assert len(f.depth_compressed) == f.depth_size_bytes and len(f.color_compressed) == f.color_size_bytes == W * H * 3
+        assert zlib.decompress(f.depth_compressed) == frames[i][0].tobytes() and f.color_compressed == frames[i][2].tobytes()
+        b.add_frame_blobs(f.depth_compressed, f.camera_to_world, color_blob=f.color_compressed, timestamp_color=f.timestamp_color, timestamp_depth=f.timestamp_depth)
+    dst = str(tmp_path / "dst.sens")
+    b.save(dst)
+    assert open(src, "rb").read() == open(dst, "rb").read()
+    with pytest.raises(_abi.ScanfuseError):
+        b.add_frame_blobs(b"", np.eye(4), color_blob=b"abc")      # a raw colour frame of the wrong size
+
+
 def test_python_struct_view_of_our_file(tmp_path):
     """Independent cross-check with the struct formats of SensReader/python/SensorData.py:14-20,54-74."""
     W, H = 32, 24
