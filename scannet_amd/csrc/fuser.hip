@@ -12,7 +12,8 @@
 //   block_keys u64[num_sdf_blocks]                    directory: key of the block living in heap slot i, or EMPTY
 //   heap       i32[num_sdf_blocks] + free counter     free list of heap slots (wave-aggregated pops)
 //   voxels     8 B x 512 x num_sdf_blocks             {f32 sdf; u8 r,g,b,weight}, one 4 KiB tile per block, index z*64+y*8+x
-//   depthf     f32[B][W*H], color u32[B][W*H]         pre-pass outputs of the B <= 16 frames of a batch (L2 / Infinity-Cache resident)
+//   depthf     f32[B][W*H], texel {f32 depth, rgb8} [B][W*H]   pre-pass outputs of the B <= 32 frames of a batch (L2 / Infinity-Cache resident); the
+//                                                             texel plane only for RGB-D batches: ONE 8-byte gather per voxel and frame fetches both
 //   compact    i32[num_sdf_blocks] + u32 mask         heap slots of the blocks some frame of the batch sees; bit j = frame j updates it
 #include <hip/hip_runtime.h>
 
@@ -78,14 +79,16 @@ __device__ inline float min_f32(float a, float b) {
 // gate (zParametersScanNet.txt:34-35) -> -inf; optional rgb -> packed u32.  8 pixels per lane; blockIdx.y = frame
 // of the batch (every frame of a batch is converted by ONE launch).
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_prepass(BatchIn in, float* __restrict__ depthf_all, uint32_t* __restrict__ color_all, int n,
+__global__ __launch_bounds__(256) void k_prepass(BatchIn in, float* __restrict__ depthf_all, uint2* __restrict__ texel_all, int n,
                                                  float shift, float dmin, float dmax, int32_t* counters, int compact_counter, ParamsK P,
                                                  const float* __restrict__ ray_kx, const float* __restrict__ ray_ky) {
   const int j = blockIdx.y;  // frame of the batch
   const uint16_t* __restrict__ depth = in.depth[j];
   const uint8_t* __restrict__ rgb = in.rgb[j];
   float* __restrict__ depthf = depthf_all + (size_t)j * n;
-  uint32_t* __restrict__ color = color_all + (size_t)j * n;
+  // RGB-D: the frame's pixels once more as 8-byte texels {depth as the float's bits, rgb in the low three bytes}: the integrate kernel gathers a
+  // voxel's depth AND colour with one request (round 4: two 4-byte gathers per voxel and frame kept the CU's texture-address unit busy 82 % of a pass)
+  uint2* __restrict__ texel = texel_all + (size_t)j * n;
   const int i0 = (blockIdx.x * 256 + threadIdx.x) * 8;
   if (blockIdx.x == 0 && j == 0 && threadIdx.x == 0) {
     atomicExch(reinterpret_cast<unsigned long long*>(&counters[compact_counter]), 0ull);
@@ -135,12 +138,13 @@ __global__ __launch_bounds__(256) void k_prepass(BatchIn in, float* __restrict__
           const uint64_t two = (uint64_t)w[lo] | ((uint64_t)(lo + 1 < 6 ? w[lo + 1] : 0u) << 32);
           px[k] = (uint32_t)(two >> sh) & 0xFFFFFFu;
         }
-        *reinterpret_cast<uint4*>(color + i0) = make_uint4(px[0], px[1], px[2], px[3]);
-        *reinterpret_cast<uint4*>(color + i0 + 4) = make_uint4(px[4], px[5], px[6], px[7]);
+#pragma unroll
+        for (int k = 0; k < 8; k += 2)
+          *reinterpret_cast<uint4*>(texel + i0 + k) = make_uint4(__float_as_uint(d[k]), px[k], __float_as_uint(d[k + 1]), px[k + 1]);
       } else {
         for (int k = 0; k < 8 && i0 + k < n; k++) {
           const uint8_t* c = rgb + 3 * (size_t)(i0 + k);
-          color[i0 + k] = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
+          texel[i0 + k] = make_uint2(__float_as_uint(d[k]), (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16));
         }
       }
     } else {
@@ -151,9 +155,9 @@ __global__ __launch_bounds__(256) void k_prepass(BatchIn in, float* __restrict__
         const int x = (i0 + k) % P.W, y = (i0 + k) / P.W;
         const float u = fmaf(ray_kx[x], P.cfx, P.cmx) + 0.5f;
         const float v = fmaf(ray_ky[y], P.cfy, P.cmy) + 0.5f;
-        if (!(u >= 0.0f && u < (float)P.cW && v >= 0.0f && v < (float)P.cH)) { color[i0 + k] = 0u; continue; }
+        if (!(u >= 0.0f && u < (float)P.cW && v >= 0.0f && v < (float)P.cH)) { texel[i0 + k] = make_uint2(__float_as_uint(d[k]), 0u); continue; }
         const uint8_t* c = rgb + 3 * ((size_t)(int)v * (size_t)P.cW + (size_t)(int)u);
-        color[i0 + k] = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
+        texel[i0 + k] = make_uint2(__float_as_uint(d[k]), (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16));
       }
     }
   }
@@ -1165,7 +1169,7 @@ __device__ inline __amdgpu_buffer_rsrc_t image_rsrc(const void* base, uint32_t b
 
 template <int SIGN, int COLOR, bool TAB, int WM, int J0, int NJ, bool ROWS>
 __device__ inline void fuse_rows(const ParamsK& P, const float* __restrict__ Ti, const float* __restrict__ depthf,
-                                 const uint32_t* __restrict__ color, const float* rtab, v2f wx, float wy, const float (&wz)[4],
+                                 const uint2* __restrict__ texel, const float* rtab, v2f wx, float wy, const float (&wz)[4],
                                  uint4 (&v)[4], uint64_t (&dirty)[4]) {
   v2f pz[NJ], rcp_m[NJ];
   float d[2 * NJ];
@@ -1184,13 +1188,21 @@ __device__ inline void fuse_rows(const ParamsK& P, const float* __restrict__ Ti,
   // ---- phase A: project; then the gathers, all issued together
   fuse_project<J0, NJ, false>(P, Ti, wx, wy, wz, pz, pix, ok);
   const uint32_t img_bytes = (uint32_t)(P.W * P.H) * 4u;
-  const __amdgpu_buffer_rsrc_t rd = image_rsrc(depthf, img_bytes);
-#pragma unroll
-  for (int k = 0; k < 2 * NJ; k++) d[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, pix[k] << 2, 0, 0));
   if (COLOR) {
-    const __amdgpu_buffer_rsrc_t rc = image_rsrc(color, img_bytes);
+    // RGB-D: depth and colour of a pixel sit side by side in the pre-pass's texel plane -- one 8-byte gather per voxel (two 4-byte gathers into
+    // two planes were 16 requests per lane and frame; the texture-address unit, not the vector ALU, was the busier one)
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t rt = image_rsrc(texel, 2u * img_bytes);
 #pragma unroll
-    for (int k = 0; k < 2 * NJ; k++) c[k] = __builtin_amdgcn_raw_buffer_load_b32(rc, pix[k] << 2, 0, 0);
+    for (int k = 0; k < 2 * NJ; k++) {
+      const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rt, pix[k] << 3, 0, 0);
+      d[k] = __uint_as_float(t.x);
+      c[k] = t.y;
+    }
+  } else {
+    const __amdgpu_buffer_rsrc_t rd = image_rsrc(depthf, img_bytes);
+#pragma unroll
+    for (int k = 0; k < 2 * NJ; k++) d[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, pix[k] << 2, 0, 0));
   }
   fuse_update<SIGN, COLOR, TAB, WM, J0, NJ, ROWS>(P, rcp_m, d, c, pz, ok, v, dirty);
 }
@@ -1200,7 +1212,7 @@ __device__ inline void fuse_rows(const ParamsK& P, const float* __restrict__ Ti,
 template <int SIGN, int COLOR, bool TAB, int WM, bool ROWS>
 __global__ __launch_bounds__(256, 4) void k_integrate(uint4* __restrict__ voxels, const uint64_t* __restrict__ block_keys,
                                                    const int32_t* __restrict__ compact, const uint32_t* __restrict__ cmask,
-                                                   const float* __restrict__ depthf_all, const uint32_t* __restrict__ color_all,
+                                                   const float* __restrict__ depthf_all, const uint2* __restrict__ texel_all,
                                                    int32_t* counters, int32_t* host_mirror, int compact_counter, int xcd_walk, ParamsK P,
                                                    BatchTi B) {
   __shared__ float s_rtab[RTAB];  // correctly rounded 1/m for the weighted-mean division (fuse_tile)
@@ -1252,8 +1264,8 @@ __global__ __launch_bounds__(256, 4) void k_integrate(uint4* __restrict__ voxels
       frames &= frames - 1u;
       const float* Ti = B.Ti[q];
       const float* __restrict__ depthf = depthf_all + (size_t)q * npx;
-      const uint32_t* __restrict__ color = color_all + (size_t)q * npx;
-      fuse_rows<SIGN, COLOR, TAB, WM, 0, 4, ROWS>(P, Ti, depthf, color, s_rtab, wx, wy, wz, v, dirty);
+      const uint2* __restrict__ texel = texel_all + (size_t)q * npx;
+      fuse_rows<SIGN, COLOR, TAB, WM, 0, 4, ROWS>(P, Ti, depthf, texel, s_rtab, wx, wy, wz, v, dirty);
     }
     if (ROWS) {
 #pragma unroll
@@ -2015,7 +2027,7 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
   SF_ALLOC(f->voxels, (size_t)k.num_blocks * 4096);
   for (int q = 0; q < 2; q++) {
     SF_ALLOC(f->depthf2[q], npx * 4 * MAX_BATCH);
-    SF_ALLOC(f->color2[q], npx * 4 * MAX_BATCH);
+    SF_ALLOC(f->color2[q], npx * 8 * MAX_BATCH);   // {depth, rgb} texels of an RGB-D batch
     SF_ALLOC(f->compact2[q], (size_t)k.num_blocks * 4);
     SF_ALLOC(f->cmask2[q], (size_t)k.num_blocks * 4);
   }

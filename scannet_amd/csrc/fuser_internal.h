@@ -146,6 +146,7 @@ __device__ inline int hash_lookup(const HashEntry* __restrict__ table, const Par
 
 #ifdef __HIPCC__
 // Packed fp32 helpers and the two hand-expanded, correctly rounded divisions of k_integrate.
+#ifndef SF_SCALAR_PAIRS
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ inline v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ inline v2f splat(float x) { return (v2f){x, x}; }
@@ -155,6 +156,22 @@ __device__ inline v2f pk_add(v2f a, v2f b) {
   asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+#else
+// The same pairs as two plain fp32 operations each (tools/gpu/valu_peak.hip: on gfx950 a v_pk_*_f32 holds the SIMD for ~4.2 cycles and issues beside
+// nothing, a plain v_fma / v_mul / v_add_f32 for ~2.2 and beside the conversions, compares and selects of another wave).  Same arithmetic, same bits.
+struct v2f {
+  float x, y;
+  __device__ float& operator[](int i) { return i ? y : x; }
+  __device__ const float& operator[](int i) const { return i ? y : x; }
+};
+__device__ inline v2f operator+(v2f a, v2f b) { return v2f{a.x + b.x, a.y + b.y}; }
+__device__ inline v2f operator-(v2f a, v2f b) { return v2f{a.x - b.x, a.y - b.y}; }
+__device__ inline v2f operator*(v2f a, v2f b) { return v2f{a.x * b.x, a.y * b.y}; }
+__device__ inline v2f operator-(v2f a) { return v2f{-a.x, -a.y}; }
+__device__ inline v2f pk_fma(v2f a, v2f b, v2f c) { return v2f{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)}; }
+__device__ inline v2f splat(float x) { return v2f{x, x}; }
+__device__ inline v2f pk_add(v2f a, v2f b) { return a + b; }
+#endif
 // RN(1 / b) for normal-range b: v_rcp_f32 seed (1 ulp) + two Newton steps
 __device__ inline v2f recip_rn(v2f b) {
   v2f r = {__builtin_amdgcn_rcpf(b.x), __builtin_amdgcn_rcpf(b.y)};
@@ -198,7 +215,7 @@ struct sf_fuser {
   bool serial_tail = false;  // the most recent batches ran on `stream` alone (front has not been ordered behind them yet)
   bool overlap = true;  // sf_fuser_tune("overlap", 0) runs everything on one stream
   float* depthf2[2] = {nullptr, nullptr};      // MAX_BATCH x W*H per batch slot
-  uint32_t* color2[2] = {nullptr, nullptr};    // MAX_BATCH x W*H per batch slot
+  uint2* color2[2] = {nullptr, nullptr};       // MAX_BATCH x W*H {depth bits, rgb} texels per batch slot (RGB-D batches)
   int32_t* compact2[2] = {nullptr, nullptr};   // heap slots of the blocks some frame of the batch sees
   uint32_t* cmask2[2] = {nullptr, nullptr};    // per compact entry: bit j = frame j of the batch updates this block
   int32_t* block_entry = nullptr;              // directory: table index of the entry of the block in heap slot i
