@@ -15,6 +15,11 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidde
           "-I" + os.path.join(ROOT, "include")] + os.environ.get("SCANFUSE_BUILD_FLAGS", "").split()   # e.g. -DSF_MEASURE_ABLATE for tools/gpu/r03_ablate.sh
 
 
+# fuser.hip / calib.hip: the voxel pairs of the integrate kernels are two plain fp32 operations each (fuser_internal.h: packed fp32 buys no issue rate on
+# gfx950); the SLP vectoriser would pack them again
+PER_FILE = {} if "-DSF_PACKED_PAIRS" in COMMON else {"fuser.hip": ["-fno-slp-vectorize"], "calib.hip": ["-fno-slp-vectorize"]}
+
+
 def sources():
     src = sorted(glob.glob(os.path.join(HERE, "csrc", "*.hip")) + glob.glob(os.path.join(HERE, "csrc", "*.cpp")))
     return [s for s in src if not os.path.basename(s).startswith("tool_")]
@@ -38,7 +43,7 @@ def build(force=False, verbose=False):
         o = os.path.join(objdir, os.path.basename(s) + ".o")
         objs.append(o)
         if force or _stale(o, [s] + hdr):
-            cmd = [HIPCC, "--offload-arch=gfx950", "-c", s, "-o", o] + COMMON
+            cmd = [HIPCC, "--offload-arch=gfx950", "-c", s, "-o", o] + COMMON + PER_FILE.get(os.path.basename(s), [])
             if s.endswith(".cpp"):
                 cmd = [HIPCC, "-x", "hip", "--offload-arch=gfx950", "-c", s, "-o", o] + COMMON
             if verbose:

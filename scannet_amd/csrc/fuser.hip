@@ -524,7 +524,10 @@ __device__ inline bool ray_walk_bits(const RayWalk& r, const WindowMap& w, uint3
 }
 
 template <bool MULTI>
-__global__ __launch_bounds__(256) void k_alloc_ray(const float* __restrict__ depthf_all, HashEntry* table, int32_t* heap,
+#ifndef SF_ALLOC_WAVES_MIN
+#define SF_ALLOC_WAVES_MIN 1   // waves per SIMD k_alloc_ray is register-budgeted for (8: <= 64 registers: a wave of it fits any slot a 64-register wave of k_integrate frees)
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SF_ALLOC_WAVES_MIN, 8))) void k_alloc_ray(const float* __restrict__ depthf_all, HashEntry* table, int32_t* heap,
                                                    uint64_t* block_keys, int32_t* block_entry, uint8_t* block_flags, int32_t* counters, ParamsK P,
                                                    BatchFrames B, int group_frames, int ablate, const uint16_t* __restrict__ fuse_depth16,
                                                    float* depthf_out, int compact_counter) {
@@ -962,6 +965,35 @@ __global__ __launch_bounds__(256) void k_compactify(const uint64_t* __restrict__
 
 constexpr int RTAB = 512;  // LDS table of correctly rounded 1/m, m = weight + weight_sample < 512
 
+// A wave-uniform value in a VECTOR register -- an experiment kept behind -DSF_VREG_CONSTANTS.  On gfx950 v_fma / v_mul / v_add_f32, v_add_u32, v_and_b32,
+// v_mov_b32 ... issue every ~2.2 cycles per SIMD when all their sources are vector registers or inline constants and every ~4.3 cycles as soon as one
+// source is a scalar register (tools/gpu/valu_peak.hip, profiles/r05_valu_issue_table.txt), and the compiler feeds the per-frame matrix and the camera
+// constants to every fma straight from the scalar registers they were loaded into.  Copying them into vector registers once per frame (18 v_mov, opaque
+// to the compiler) made the pass SLOWER (packed 830 -> 870 us, plain pairs 808 -> 837 us: profiles/r05_integrate_ab.txt): at 4-5 waves per SIMD the kernel
+// is bound by how often a wave gets to issue at all (one instruction per ~6 cycles and wave), not by what an instruction costs the pipe.
+__device__ inline float vreg(float x) {
+#ifdef SF_VREG_CONSTANTS
+  float r;
+  asm("v_mov_b32 %0, %1" : "=v"(r) : "s"(x));
+  return r;
+#else
+  return x;
+#endif
+}
+// the per-frame / per-kernel constants the projection and the update multiply with, in vector registers (fuse_project, fuse_update)
+struct FrameV {
+  float ti[12];
+  float fx, fy, mx, my, tscale, tbase;
+};
+__device__ inline FrameV frame_constants(const ParamsK& P, const float* __restrict__ Ti) {
+  FrameV F;
+#pragma unroll
+  for (int k = 0; k < 12; k++) F.ti[k] = vreg(Ti[k]);
+  F.fx = vreg(P.fx); F.fy = vreg(P.fy); F.mx = vreg(P.mx); F.my = vreg(P.my);
+  F.tscale = vreg(P.tscale); F.tbase = vreg(P.tbase);
+  return F;
+}
+
 __device__ inline int cvt_i32(float x) {  // v_cvt_i32_f32: truncates, saturates, NaN -> 0 (a C cast of NaN / inf would be undefined)
   int r;
   asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));
@@ -990,8 +1022,9 @@ __device__ inline int depth_weight(const ParamsK& P, float d) {
 // CLAMP: pixels that project outside read pixel 0 (callers that gather with plain global loads); without it the index of an outside
 // voxel is whatever the saturating conversion gave (callers that gather through a bounds-checked buffer resource and mask by `ok`).
 template <int J0, int NJ, bool CLAMP>
-__device__ inline void fuse_project(const ParamsK& P, const float* __restrict__ Ti, v2f wx, float wy, const float (&wz)[4], v2f (&pz)[NJ],
+__device__ inline void fuse_project(const ParamsK& P, const FrameV& FV, v2f wx, float wy, const float (&wz)[4], v2f (&pz)[NJ],
                                     uint32_t (&pix)[2 * NJ], bool (&ok)[2 * NJ]) {
+  const float* Ti = FV.ti;
   const uint32_t uw = (uint32_t)P.W, uh = (uint32_t)P.H;
   // Row constants first, two rows or two components per packed instruction:
   //      a{x,y}_j = fma(Ti[1|5], wy, fma(Ti[2|6], wz_j, Ti[3|7])),  az_j = fma(Ti[9], wy, fma(Ti[10], wz_j, Ti[11]))
@@ -1008,8 +1041,8 @@ __device__ inline void fuse_project(const ParamsK& P, const float* __restrict__ 
     const v2f pcy = pk_fma(splat(Ti[4]), wx, splat(axy[j].y));
     const v2f pcz = pk_fma(splat(Ti[8]), wx, splat(azz[j >> 1][j & 1]));
     const v2f rz = recip_rn(pcz);
-    const v2f uf = pk_add(pk_fma(pcx * splat(P.fx), rz, splat(P.mx)), splat(0.5f));
-    const v2f vf = pk_add(pk_fma(pcy * splat(P.fy), rz, splat(P.my)), splat(0.5f));
+    const v2f uf = pk_add(pk_fma(pcx * splat(FV.fx), rz, splat(FV.mx)), splat(0.5f));
+    const v2f vf = pk_add(pk_fma(pcy * splat(FV.fy), rz, splat(FV.my)), splat(0.5f));
     pz[j] = pcz;
 #pragma unroll
     for (int hx = 0; hx < 2; hx++) {
@@ -1035,7 +1068,7 @@ __device__ inline void fuse_project(const ParamsK& P, const float* __restrict__ 
 // itself a compare costs a v_cndmask + v_cmp per row (8 of the 241 VALU instructions of a lane's frame), and a pass of 32 frames is VALU-bound
 // with HBM at 8 % of its peak.
 template <int SIGN, int COLOR, bool TAB, int WM, int J0, int NJ, bool ROWS = true>
-__device__ inline void fuse_update(const ParamsK& P, const v2f (&rcp_m)[NJ], const float (&d)[2 * NJ], const uint32_t (&c)[2 * NJ], const v2f (&pz)[NJ],
+__device__ inline void fuse_update(const ParamsK& P, const FrameV& FV, const v2f (&rcp_m)[NJ], const float (&d)[2 * NJ], const uint32_t (&c)[2 * NJ], const v2f (&pz)[NJ],
                                    const bool (&ok)[2 * NJ], uint4 (&v)[4], uint64_t (&dirty)[4]) {
   constexpr bool WS1 = WM == 1 || WM == 2;
   // ---- phase B1: which voxels does this frame update?  Then a wave-uniform early-out: 10-25 % of the (block, frame) pairs the frustum
@@ -1058,7 +1091,7 @@ __device__ inline void fuse_update(const ParamsK& P, const v2f (&rcp_m)[NJ], con
   for (int j = 0; j < NJ; j++) {
     const v2f dk = {d[2 * j], d[2 * j + 1]};
     v2f sdf = dk - pz[j];
-    const v2f t = pk_fma(splat(P.tscale), dk, splat(P.tbase));
+    const v2f t = pk_fma(splat(FV.tscale), dk, splat(FV.tbase));
 #pragma unroll
     for (int hx = 0; hx < 2; hx++) {
       // valid depth (-inf has the sign bit set, valid depths are positive) below the integration distance, not behind the band
@@ -1186,7 +1219,12 @@ __device__ inline void fuse_rows(const ParamsK& P, const float* __restrict__ Ti,
     }
   }
   // ---- phase A: project; then the gathers, all issued together
-  fuse_project<J0, NJ, false>(P, Ti, wx, wy, wz, pz, pix, ok);
+  const FrameV FV = frame_constants(P, Ti);
+  fuse_project<J0, NJ, false>(P, FV, wx, wy, wz, pz, pix, ok);
+#ifdef SF_ABLATE_GATHER   // measurement only (wrong voxels): every lane gathers ONE texel per row -- what do the gathers' cache look-ups cost a pass?
+#pragma unroll
+  for (int k = 0; k < 2 * NJ; k++) pix[k] = (uint32_t)(SF_ABLATE_GATHER == 1 ? 0 : (pix[k] & ~63u));
+#endif
   const uint32_t img_bytes = (uint32_t)(P.W * P.H) * 4u;
   if (COLOR) {
     // RGB-D: depth and colour of a pixel sit side by side in the pre-pass's texel plane -- one 8-byte gather per voxel (two 4-byte gathers into
@@ -1204,18 +1242,31 @@ __device__ inline void fuse_rows(const ParamsK& P, const float* __restrict__ Ti,
 #pragma unroll
     for (int k = 0; k < 2 * NJ; k++) d[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, pix[k] << 2, 0, 0));
   }
-  fuse_update<SIGN, COLOR, TAB, WM, J0, NJ, ROWS>(P, rcp_m, d, c, pz, ok, v, dirty);
+  fuse_update<SIGN, COLOR, TAB, WM, J0, NJ, ROWS>(P, FV, rcp_m, d, c, pz, ok, v, dirty);
 }
 
 // 4 waves per SIMD (<= 128 VGPRs).  Tried for the one-frame-per-launch case: 5 waves / 96 VGPRs with the tile in two
 // half passes -- the spills cost more than the occupancy buys (183 us vs 112 us per launch).
 template <int SIGN, int COLOR, bool TAB, int WM, bool ROWS>
-__global__ __launch_bounds__(256, 4) void k_integrate(uint4* __restrict__ voxels, const uint64_t* __restrict__ block_keys,
+#ifndef SF_INT_WAVES
+#define SF_INT_WAVES 5   // workgroups (of 4 waves) per CU the register budget of k_integrate is set for (plain pairs: 91 registers)
+#endif
+#ifndef SF_INT_NJ
+#define SF_INT_NJ 4      // rows of the tile fused together per frame: 4 = the whole tile at once, 2 / 1 = in halves / quarters (fewer live registers)
+#endif
+__global__ __launch_bounds__(256, SF_INT_WAVES) void k_integrate(uint4* __restrict__ voxels, const uint64_t* __restrict__ block_keys,
                                                    const int32_t* __restrict__ compact, const uint32_t* __restrict__ cmask,
                                                    const float* __restrict__ depthf_all, const uint2* __restrict__ texel_all,
                                                    int32_t* counters, int32_t* host_mirror, int compact_counter, int xcd_walk, ParamsK P,
                                                    BatchTi B) {
   __shared__ float s_rtab[RTAB];  // correctly rounded 1/m for the weighted-mean division (fuse_tile)
+#ifdef SF_INT_PAD_VGPR
+  // occupancy experiment: name a high register so that the kernel's allocation is SF_INT_PAD_VGPR + 1 registers whatever it uses (fewer waves per SIMD,
+  // slots of the size the allocation kernel's waves need)
+#define SF_STR2(x) #x
+#define SF_STR(x) SF_STR2(x)
+  asm volatile("" ::: "v" SF_STR(SF_INT_PAD_VGPR));
+#endif
   if (TAB) {
     for (int i = threadIdx.x; i < RTAB; i += 256) s_rtab[i] = 1.0f / (float)(i > 0 ? i : 1);
     __syncthreads();
@@ -1265,7 +1316,13 @@ __global__ __launch_bounds__(256, 4) void k_integrate(uint4* __restrict__ voxels
       const float* Ti = B.Ti[q];
       const float* __restrict__ depthf = depthf_all + (size_t)q * npx;
       const uint2* __restrict__ texel = texel_all + (size_t)q * npx;
-      fuse_rows<SIGN, COLOR, TAB, WM, 0, 4, ROWS>(P, Ti, depthf, texel, s_rtab, wx, wy, wz, v, dirty);
+#pragma unroll
+      for (int j0 = 0; j0 < 4; j0 += SF_INT_NJ) {
+        if (j0 == 0) fuse_rows<SIGN, COLOR, TAB, WM, 0, SF_INT_NJ, ROWS>(P, Ti, depthf, texel, s_rtab, wx, wy, wz, v, dirty);
+        if (j0 == 1) fuse_rows<SIGN, COLOR, TAB, WM, 1 % (5 - SF_INT_NJ), SF_INT_NJ, ROWS>(P, Ti, depthf, texel, s_rtab, wx, wy, wz, v, dirty);
+        if (j0 == 2) fuse_rows<SIGN, COLOR, TAB, WM, 2 % (5 - SF_INT_NJ), SF_INT_NJ, ROWS>(P, Ti, depthf, texel, s_rtab, wx, wy, wz, v, dirty);
+        if (j0 == 3) fuse_rows<SIGN, COLOR, TAB, WM, 3 % (5 - SF_INT_NJ), SF_INT_NJ, ROWS>(P, Ti, depthf, texel, s_rtab, wx, wy, wz, v, dirty);
+      }
     }
     if (ROWS) {
 #pragma unroll
@@ -1375,6 +1432,7 @@ __global__ __launch_bounds__(256, 3) void k_integrate_pipe(uint4* __restrict__ v
   const int ly = (lane >> 2) & 7;
   const int lzb = lane >> 5;
   const float* Ti = B.Ti[0];
+  const FrameV FV = frame_constants(P, Ti);   // one frame per launch: the constants are the kernel's
   auto project = [&](uint64_t key, v2f (&pz)[4], uint32_t (&pix)[8], uint32_t& okmask) {
     int bx, by, bz;
     unpack_key(key, bx, by, bz);
@@ -1384,7 +1442,7 @@ __global__ __launch_bounds__(256, 3) void k_integrate_pipe(uint4* __restrict__ v
 #pragma unroll
     for (int j = 0; j < 4; j++) wz[j] = (float)(8 * bz + 2 * j + lzb) * P.voxel;
     bool ok[8];
-    fuse_project<0, 4, true>(P, Ti, wx, wy, wz, pz, pix, ok);
+    fuse_project<0, 4, true>(P, FV, wx, wy, wz, pz, pix, ok);
     okmask = 0u;
 #pragma unroll
     for (int k = 0; k < 8; k++) okmask |= ok[k] ? (1u << k) : 0u;
@@ -1458,7 +1516,7 @@ __global__ __launch_bounds__(256, 3) void k_integrate_pipe(uint4* __restrict__ v
     for (int k = 0; k < 8; k++) ok[k] = (okmask >> k) & 1u;
     uint32_t cdummy[8];
     uint64_t dirty[4] = {0ull, 0ull, 0ull, 0ull};
-    fuse_update<1, 0, TAB, WM, 0, 4>(P, rcp_m, d, cdummy, pz, ok, v, dirty);  // consumes d: the gather slot is free again
+    fuse_update<1, 0, TAB, WM, 0, 4>(P, FV, rcp_m, d, cdummy, pz, ok, v, dirty);  // consumes d: the gather slot is free again
     uint4* vb = voxels + (size_t)slot * 256;
 #pragma unroll
     for (int j = 0; j < 4; j++)

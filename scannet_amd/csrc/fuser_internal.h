@@ -146,7 +146,7 @@ __device__ inline int hash_lookup(const HashEntry* __restrict__ table, const Par
 
 #ifdef __HIPCC__
 // Packed fp32 helpers and the two hand-expanded, correctly rounded divisions of k_integrate.
-#ifndef SF_SCALAR_PAIRS
+#ifdef SF_PACKED_PAIRS   // rounds 1-4: v_pk_fma / v_pk_mul / v_pk_add_f32 on the lane's voxel pair (build with -DSF_PACKED_PAIRS and without -fno-slp-vectorize)
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ inline v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ inline v2f splat(float x) { return (v2f){x, x}; }
@@ -157,8 +157,11 @@ __device__ inline v2f pk_add(v2f a, v2f b) {
   return r;
 }
 #else
-// The same pairs as two plain fp32 operations each (tools/gpu/valu_peak.hip: on gfx950 a v_pk_*_f32 holds the SIMD for ~4.2 cycles and issues beside
-// nothing, a plain v_fma / v_mul / v_add_f32 for ~2.2 and beside the conversions, compares and selects of another wave).  Same arithmetic, same bits.
+// The default since round 5: the same pairs as two plain fp32 operations each.  tools/gpu/valu_peak.hip (profiles/r05_valu_issue_table.txt): on gfx950 a
+// v_pk_*_f32 holds the SIMD for ~4.2 cycles and issues beside nothing; a plain v_fma / v_mul / v_add_f32 holds it ~2.2 cycles and issues beside the
+// conversions, compares and selects of another wave -- packing buys no throughput on this part, and the splats cost moves.  Same arithmetic, same bits;
+// the pass 830 -> 808 us, 9 registers fewer (5 waves per SIMD instead of 4).  fuser.hip is built with -fno-slp-vectorize so that the compiler does not
+// pack the pairs again.
 struct v2f {
   float x, y;
   __device__ float& operator[](int i) { return i ? y : x; }

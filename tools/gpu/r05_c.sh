@@ -1,4 +1,5 @@
 #!/bin/bash
+# (run while the packed pairs were the default build: -DSF_SCALAR_PAIRS selected the plain pairs then; since then plain pairs are the default and -DSF_PACKED_PAIRS selects the round-4 kernels)
 # Round 5, call C: packed pairs (v_pk_*_f32) against plain fp32 pairs in the integrate kernels -- the A/B the VALU issue table asks for.
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (run while the packed pairs were the default build: -DSF_SCALAR_PAIRS selected the plain pairs then; since then plain pairs are the default and -DSF_PACKED_PAIRS selects the round-4 kernels)
 # Round 5, call D: counters of the RGB-D integrate kernel with the texel gather, packed against plain pairs; the list of counters the box offers.
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

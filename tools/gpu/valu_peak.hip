@@ -174,6 +174,42 @@ STREAM(v_mov_b32_dpp_row_shr, X8("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf ba
                                  "v_mov_b32_dpp %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n"
                                  "v_mov_b32_dpp %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf") UREGS)
 
+// ---- round three: is the overlap between neighbouring instructions of ONE wave, or between waves?
+#define FMA4 "v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9"
+#define CVT4 "v_cvt_f32_i32 %2, %2\n v_cvt_f32_i32 %3, %3\n v_cvt_f32_i32 %2, %2\n v_cvt_f32_i32 %3, %3"
+STREAM(clumps_4fma_4cvt, X8(FMA4 "\n" CVT4) MIXREGS)
+STREAM(clumps_32fma_32cvt, FMA4 "\n" FMA4 "\n" FMA4 "\n" FMA4 "\n" FMA4 "\n" FMA4 "\n" FMA4 "\n" FMA4 "\n" CVT4 "\n" CVT4 "\n" CVT4 "\n" CVT4 "\n" CVT4 "\n" CVT4 "\n" CVT4 "\n" CVT4 MIXREGS)
+STREAM(clumps_2fma_2cvt, X8("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_cvt_f32_i32 %2, %2\n v_cvt_f32_i32 %3, %3\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_cvt_f32_i32 %2, %2\n v_cvt_f32_i32 %3, %3") MIXREGS)
+STREAM(alt_fma_cvt_dependent_pairs, X8(ALT4("v_fma_f32 %0, %0, %8, %9", "v_cvt_f32_i32 %0, %0", "v_fma_f32 %1, %1, %8, %9", "v_cvt_f32_i32 %1, %1")) MIXREGS)
+STREAM(alt_mul_cmp, X8(ALT4("v_mul_f32 %0, %0, %8", "v_cmp_gt_u32 vcc, %4, %10", "v_mul_f32 %1, %1, %8", "v_cmp_gt_u32 vcc, %5, %10")) MIXREGS : "vcc")
+STREAM(alt_add_f32_mul24, X8(ALT4("v_add_f32 %0, %0, %8", "v_mul_u32_u24 %4, %4, %10", "v_add_f32 %1, %1, %8", "v_mul_u32_u24 %5, %5, %10")) MIXREGS)
+STREAM(alt_mov_cvt, X8(ALT4("v_mov_b32 %4, %10", "v_cvt_f32_i32 %2, %2", "v_mov_b32 %5, %10", "v_cvt_f32_i32 %3, %3")) MIXREGS)
+STREAM(alt_and_cvt, X8(ALT4("v_and_b32 %4, %4, %10", "v_cvt_f32_i32 %2, %2", "v_and_b32 %5, %5, %10", "v_cvt_f32_i32 %3, %3")) MIXREGS)
+STREAM(alt_fma_add_u32, X8(ALT4("v_fma_f32 %0, %0, %8, %9", "v_add_u32 %4, %4, %10", "v_fma_f32 %1, %1, %8, %9", "v_add_u32 %5, %5, %10")) MIXREGS)
+STREAM(alt_fma_rcp_1_to_3, X8(ALT4("v_rcp_f32 %2, %2", "v_fma_f32 %0, %0, %8, %9", "v_fma_f32 %1, %1, %8, %9", "v_fma_f32 %3, %3, %8, %9")) MIXREGS)
+
+// ---- round four: operands.  An SGPR source made v_fma_f32 a 4-cycle instruction above; which sources keep the 2-cycle rate?
+#define SG3(INS, A, B) INS " %0, %0, " A ", " B "\n" INS " %1, %1, " A ", " B "\n" INS " %2, %2, " A ", " B "\n" INS " %3, %3, " A ", " B "\n" INS " %4, %4, " A ", " B "\n" INS " %5, %5, " A ", " B "\n" INS " %6, %6, " A ", " B "\n" INS " %7, %7, " A ", " B
+#define SG2(INS, A) INS " %0, " A ", %0\n" INS " %1, " A ", %1\n" INS " %2, " A ", %2\n" INS " %3, " A ", %3\n" INS " %4, " A ", %4\n" INS " %5, " A ", %5\n" INS " %6, " A ", %6\n" INS " %7, " A ", %7"
+STREAM(v_mul_f32_sgpr, X8(SG2("v_mul_f32", "s10")) FREGS)
+STREAM(v_add_f32_sgpr, X8(SG2("v_add_f32", "s10")) FREGS)
+STREAM(v_add_u32_sgpr, X8(SG2("v_add_u32", "s10")) UREGS)
+STREAM(v_and_b32_sgpr, X8(SG2("v_and_b32", "s10")) UREGS)
+STREAM(v_mov_b32_from_sgpr, X8("v_mov_b32 %0, s10\n v_mov_b32 %1, s11\n v_mov_b32 %2, s10\n v_mov_b32 %3, s11\n v_mov_b32 %4, s10\n v_mov_b32 %5, s11\n v_mov_b32 %6, s10\n v_mov_b32 %7, s11") UREGS)
+STREAM(v_fma_f32_inline_constant, X8(SG3("v_fma_f32", "%8", "1.0")) FREGS)
+STREAM(v_fma_f32_two_sgprs_same, X8(SG3("v_fma_f32", "s10", "s10")) FREGS)
+STREAM(v_fmac_f32_sgpr, X8(SG2("v_fmac_f32", "s10")) FREGS)
+STREAM(v_mul_f32_inline_constant, X8(SG2("v_mul_f32", "0.5")) FREGS)
+STREAM(v_fma_f32_rotating_vgprs, X8("v_fma_f32 %0, %1, %2, %3\n v_fma_f32 %1, %2, %3, %4\n v_fma_f32 %2, %3, %4, %5\n v_fma_f32 %3, %4, %5, %6\n"
+                                    "v_fma_f32 %4, %5, %6, %7\n v_fma_f32 %5, %6, %7, %0\n v_fma_f32 %6, %7, %0, %1\n v_fma_f32 %7, %0, %1, %2") FREGS)
+STREAM(v_fma_f32_same_source_twice, X8("v_fma_f32 %0, %0, %0, %9\n v_fma_f32 %1, %1, %1, %9\n v_fma_f32 %2, %2, %2, %9\n v_fma_f32 %3, %3, %3, %9\n"
+                                       "v_fma_f32 %4, %4, %4, %9\n v_fma_f32 %5, %5, %5, %9\n v_fma_f32 %6, %6, %6, %9\n v_fma_f32 %7, %7, %7, %9") FREGS)
+STREAM(v_cvt_then_fma_sgpr, X8(ALT4("v_fma_f32 %0, %0, s10, %9", "v_cvt_f32_i32 %2, %2", "v_fma_f32 %1, %1, s10, %9", "v_cvt_f32_i32 %3, %3")) MIXREGS)
+STREAM(v_cmp_gt_f32_sgpr_to_sgprs, X8("v_cmp_gt_f32_e64 s[20:21], s10, %0\n v_cmp_gt_f32_e64 s[22:23], s10, %1\n v_cmp_gt_f32_e64 s[24:25], s10, %2\n v_cmp_gt_f32_e64 s[26:27], s10, %3\n"
+                                      "v_cmp_gt_f32_e64 s[20:21], s10, %4\n v_cmp_gt_f32_e64 s[22:23], s10, %5\n v_cmp_gt_f32_e64 s[24:25], s10, %6\n v_cmp_gt_f32_e64 s[26:27], s10, %7")
+       FREGS : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27")
+STREAM(v_sub_f32_then_min, X8(ALT4("v_sub_f32 %0, %0, %8", "v_min_f32 %2, %2, %9", "v_sub_f32 %1, %1, %8", "v_min_f32 %3, %3, %9")) MIXREGS)
+
 typedef void (*Kern)(WaveRec*, float*, int);
 struct Stream { const char* name; Kern k; int quarter; };
 #define S_(NAME) {#NAME, k_##NAME, 0}
@@ -187,7 +223,11 @@ static const Stream kStreams[] = {
     S_(alt_fma_cmp), S_(alt_fma_cndmask_sgpr), S_(alt_fma_min), S_(alt_fma_perm), S_(alt_fma_lerp), S_(alt_fma_lshl), S_(alt_fma_rcp), S_(alt_add_u32_cvt), S_(alt_pk_fma_cvt),
     S_(alt_pk_fma_add_u32), S_(alt_cvt_cmp), S_(ratio_2fma_1cvt), S_(ratio_3fma_1cvt), S_(ratio_1fma_3cvt), S_(v_lshrrev_b32), S_(v_xor_b32), S_(v_bfi_b32), S_(v_max_u32), S_(v_mul_hi_u32),
     S_(v_mad_u64_u32_skipped_v_add_co_u32), S_(v_cvt_u32_f32), S_(v_trunc_f32), S_(v_med3_f32), S_(v_add_f32_e64_abs), S_(v_mul_f32_e64_clamp), S_(v_fma_f32_neg), S_(v_fma_f32_sgpr_operand),
-    S_(v_mul_f32_literal), S_(v_mov_b32_dpp_row_shr)};
+    S_(v_mul_f32_literal), S_(v_mov_b32_dpp_row_shr),
+    S_(clumps_4fma_4cvt), S_(clumps_32fma_32cvt), S_(clumps_2fma_2cvt), S_(alt_fma_cvt_dependent_pairs), S_(alt_mul_cmp), S_(alt_add_f32_mul24), S_(alt_mov_cvt), S_(alt_and_cvt), S_(alt_fma_add_u32),
+    S_(alt_fma_rcp_1_to_3), S_(v_mul_f32_sgpr), S_(v_add_f32_sgpr), S_(v_add_u32_sgpr), S_(v_and_b32_sgpr), S_(v_mov_b32_from_sgpr), S_(v_fma_f32_inline_constant),
+    S_(v_fma_f32_two_sgprs_same), S_(v_fmac_f32_sgpr), S_(v_mul_f32_inline_constant), S_(v_fma_f32_rotating_vgprs), S_(v_fma_f32_same_source_twice), S_(v_cvt_then_fma_sgpr),
+    S_(v_cmp_gt_f32_sgpr_to_sgprs), S_(v_sub_f32_then_min)};
 constexpr int NUM_OPS = (int)(sizeof(kStreams) / sizeof(kStreams[0]));
 
 int main(int argc, char** argv) {
