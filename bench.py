@@ -19,9 +19,12 @@
                          to the ranks, boundary layers all-gathered over RCCL before marching cubes; one step = one frame (strong scaling).
 
 `roofline` describes the dominant kernel of the timed region and every `frac` is a fraction of a hardware peak (<= 1):
-  * 32 frames per launch (the default schedule) is VALU-issue bound: bound = "valu", frac = SQ_ACTIVE_INST_VALU over the SIMD issue
-    slots of the launch (separate rocprofv3 --pmc pass), hbm_frac = counter traffic / time / 8 TB/s, alg_equiv_GBs = what the launch
-    would have moved without temporal blocking (SURVEY 8d algorithmic bytes / time: NOT a roofline fraction).
+  * 32 frames per launch (the default schedule) is VALU-issue bound: bound = "valu", frac = SQ_INSTS_VALU of the launch (separate
+    rocprofv3 --pmc pass) x the mean issue cost of the kernel's frame loop at the per-class costs MEASURED on the MI355X
+    (tools/gpu/valu_peak.hip, tools/valu_cost_model.py: roofline.valu_peak_calibration) over the SIMD cycles of the launch;
+    issue_ratio_4_cycles = rounds 2-4's SQ_ACTIVE_INST_VALU x 4 / SIMD cycles, kept for continuity (it is not a utilisation: 1.8 on a
+    pure v_fma stream); hbm_frac = counter traffic / time / 8 TB/s, alg_equiv_GBs = what the launch would have moved without temporal
+    blocking (SURVEY 8d algorithmic bytes / time: NOT a roofline fraction).
   * `roofline_single_frame` (one frame per launch, what a live stream gets) is HBM bound: achieved = algorithmic bytes / time.
 """
 import argparse
@@ -267,6 +270,30 @@ def pmc_traffic(args, config, steps, warmup, single_frame, depth_only):
             "alg_bytes_same_launches": alg, "traffic_over_alg": round((read_b + write_b) / alg, 4) if alg else None}
 
 
+_COST_MODEL = {}
+
+
+def valu_cost_model(depth_only):
+    """tools/valu_cost_model.py on the library this process loaded: the frame loop of the timed integrate kernel priced with the per-class issue costs
+    tools/gpu/valu_peak.hip measured on the MI355X (profiles/r05_valu_issue_table.txt).  None when the disassembler is not there."""
+    key = "k_integrateILi1ELi%dELb1ELi2ELb0" % (0 if depth_only else 2)
+    if key not in _COST_MODEL:
+        try:
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("valu_cost_model", os.path.join(ROOT, "tools", "valu_cost_model.py"))
+            m = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(m)
+            text = m.disassemble(os.path.join(ROOT, "scannet_amd", "libscanfuse.so"))
+            _, lines = m.kernel_body(text, key)
+            e = m.price(m.frame_loop(lines))
+            e["costs_cycles"] = {"fast": m.C_FAST, "slow": m.C_SLOW, "trans": m.C_TRANS}
+            e.pop("top_opcodes", None)
+            _COST_MODEL[key] = e
+        except BaseException:   # SystemExit of the tool included: the roofline then falls back to the uncalibrated ratio and says so
+            _COST_MODEL[key] = None
+    return _COST_MODEL[key]
+
+
 def pmc_valu(args, config, steps, warmup, single_frame, depth_only):
     """VALU issue utilisation of the integrate kernel: SQ_ACTIVE_INST_VALU (quad-cycles a SIMD spends issuing VALU, summed over SIMDs)
     over the SIMD quad-cycles of the launch = 1024 SIMDs x (GRBM_GUI_ACTIVE / 8 XCDs) / 4 -- the method of profiles/r01_c."""
@@ -281,7 +308,19 @@ def pmc_valu(args, config, steps, warmup, single_frame, depth_only):
         if all(c in e for c in ("SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE")) and e["GRBM_GUI_ACTIVE"] > 0:
             front[k] = {"valu_util_alone": round(e["SQ_ACTIVE_INST_VALU"] / (NUM_SIMDS * (e["GRBM_GUI_ACTIVE"] / 8.0) / 4.0), 4), "insts_valu": round(e["SQ_INSTS_VALU"]),
                         "avg_us_alone": e.get("avg_us_alone"), "valu_insts_share_of_the_pass": round(e["SQ_INSTS_VALU"] / (e["SQ_INSTS_VALU"] + v["SQ_INSTS_VALU"]), 4)}
-    return {"front_chain": front,
+    cm = None if single_frame else valu_cost_model(depth_only)
+    simd_cycles = NUM_SIMDS * (v["GRBM_GUI_ACTIVE"] / 8.0)
+    cal = None
+    if cm and simd_cycles:
+        cal = {"frac_serial": round(v["SQ_INSTS_VALU"] * cm["cycles_serial_per_instruction"] / simd_cycles, 4),
+               "frac_overlap_floor": round(v["SQ_INSTS_VALU"] * cm["cycles_overlapped_per_instruction"] / simd_cycles, 4),
+               "cycles_per_instruction_and_simd_measured": round(simd_cycles / v["SQ_INSTS_VALU"], 3),
+               "frame_loop": cm, "issue_table": "profiles/r05_valu_issue_table.txt (tools/gpu/valu_peak.hip)",
+               "what": "SQ_INSTS_VALU of the launch x the mean issue cost of the kernel's frame loop (its instructions priced by class: fp32 / simple integer with vector "
+                       "sources 2.25 cycles per wave-instruction and SIMD, v_pk_*, conversions, compares, selects, scalar-source forms, three-operand integer 4.25, "
+                       "transcendentals 8.3 -- measured on this part) / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs).  frac_serial prices every instruction as if nothing "
+                       "overlapped; frac_overlap_floor lets the fp32 fast class issue beside the other classes, as alternating streams do in the microbenchmark"}
+    return {"front_chain": front, "calibrated": cal,
             "valu_util": round(v["SQ_ACTIVE_INST_VALU"] / slots, 4) if slots else None, "active_inst_valu": round(v["SQ_ACTIVE_INST_VALU"]),
             "insts_valu": round(v["SQ_INSTS_VALU"]), "gui_active_clocks_per_xcd": round(v["GRBM_GUI_ACTIVE"] / 8.0),
             "valu_insts_per_voxel_frame": round(v["SQ_INSTS_VALU"] * 64.0 / (blk * 512.0), 2) if blk else None,
@@ -292,20 +331,6 @@ def pmc_valu(args, config, steps, warmup, single_frame, depth_only):
 # ---------------------------------------------------------------------------------------------------------------------------------------
 # configs[1] / configs[2]: one resident stream per rank
 # ---------------------------------------------------------------------------------------------------------------------------------------
-def textured_pictures(cw, ch, count=8, amp=3.0):
-    """Synthetic colour pictures with the entropy of real ones: a smooth scene under two octaves of sensor-like noise.  At quality 90, 4:2:0, a 1296x968
-    picture compresses to ~190-205 KB -- ScanNet's own range is 50-250 KB (sensorData.h:600-616; SURVEY 8a row a3 probed 204 KB); the smooth
-    pictures of round 4 came to 77-110 KB, and Huffman decoding costs per entropy-coded byte."""
-    yy, xx = np.mgrid[0:ch, 0:cw]
-    out = []
-    for k in range(count):
-        rng = np.random.default_rng(k)
-        base = np.stack([(xx // 3 + 31 * k) % 256, (yy // 2 + 17 * k) % 256, (128 + 100 * np.sin(xx / 30.0) * np.cos(yy / 20.0 + k))], -1)
-        coarse = rng.normal(0, amp, (ch // 2 + 1, cw // 2 + 1, 3)).repeat(2, 0).repeat(2, 1)[:ch, :cw]
-        out.append(np.clip(base + coarse + rng.normal(0, amp / 2, (ch, cw, 3)), 0, 255).astype(np.uint8))
-    return out
-
-
 def end_to_end(frames_dev, poses, n, params, local_rank, torch, colour=None):
     """SURVEY 8d "End-to-end frames/s": the first n frames of the run's stream in a .sens in /tmp, then sf_fuse_run: file -> host threads -> pinned
     ring -> H2D -> inflate on the GPU -> fusion.  Wall time from the first byte read to the last kernel.  The file is written by the REFERENCE
@@ -314,7 +339,7 @@ def end_to_end(frames_dev, poses, n, params, local_rank, torch, colour=None):
     library's writer are timed beside it (`other_writer`).  `frames_per_s` is the FIRST run of the file in this process (one process per scan is the
     pipeline's contract, Server/scan_processor.py:138); the second run is in `frames_per_s_first_and_second_run`.
     colour = "jpeg1296": every frame also carries a baseline-JPEG colour picture at ScanNet's real 1296x968 with its own intrinsics, ~200 KB each
-    (textured_pictures; eight distinct ones cycled): entropy decoding on the host threads or the GPU, IDCT / upsampling / YCbCr->RGB on the GPU,
+    (synth.textured_pictures; eight distinct ones cycled): entropy decoding on the host threads or the GPU, IDCT / upsampling / YCbCr->RGB on the GPU,
     then the colour pre-pass samples it under each depth pixel's ray.  The reference cannot encode JPEG off Windows (sensorData.h:576-593), so that
     container is assembled by this library from the reference writer's depth blobs and this library's JPEG encoder."""
     from scannet_amd import fusion, sens, synth
@@ -336,7 +361,7 @@ def end_to_end(frames_dev, poses, n, params, local_rank, torch, colour=None):
             from scannet_amd import calibrate
             cw, ch = 1296, 968
             KC = synth.intrinsic_matrix(cw, ch)
-            blobs = [calibrate.jpeg_encode(img, 90, True) for img in textured_pictures(cw, ch)]
+            blobs = [calibrate.jpeg_encode(img, 90, True) for img in synth.textured_pictures(cw, ch)]
             t0 = time.perf_counter()
             zd = orc.ref_write_sens(None, host, P44, K, want_blobs=True) if orc else None
             sd = sens.SensorData.create(cw, ch, W, H, KC, K, color_compression=2, depth_compression=1, sensor_name="StructureSensor")
@@ -391,6 +416,28 @@ def end_to_end(frames_dev, poses, n, params, local_rank, torch, colour=None):
                 first_run = (rs, st)
             if best is None or rs["seconds_total"] < best[0]["seconds_total"]:
                 best = (rs, st)
+        alternatives = None
+        if colour is not None:   # where the entropy decoding runs and on how many host threads: the same file, one run each (streams and pool exist by now)
+            alternatives = {}
+            for label, env, nt in (("device_huffman_4_threads", {"SF_JPEG_GPU_HUFFMAN": "1"}, threads), ("device_huffman_2_threads", {"SF_JPEG_GPU_HUFFMAN": "1"}, 2),
+                                   ("host_huffman_all_threads", {"SF_JPEG_HOST_HUFFMAN": "1"}, 0), ("host_huffman_4_threads", {"SF_JPEG_HOST_HUFFMAN": "1"}, threads)):
+                saved = {k: os.environ.get(k) for k in ("SF_JPEG_GPU_HUFFMAN", "SF_JPEG_HOST_HUFFMAN")}
+                for k in saved:
+                    os.environ.pop(k, None)
+                os.environ.update(env)
+                try:
+                    with fusion.Fuser(prm, device=local_rank, **TUNE) as f:
+                        ra = f.run(sd, decode_threads=nt)
+                        alternatives[label] = {"frames_per_s": round(ra["frames_total"] / ra["seconds_total"], 1), "decode_threads": int(ra["decode_threads"]),
+                                               "jpeg_entropy_on_device": int(ra.get("jpeg_entropy_on_device", -1)),
+                                               "host_ms_per_frame_per_thread": round(1e3 * ra["seconds_decode_cpu"] / max(ra["frames_total"], 1), 3)}
+                except Exception as ex:
+                    alternatives[label] = {"error": str(ex)[:160]}
+                finally:
+                    for k, v in saved.items():
+                        os.environ.pop(k, None)
+                        if v is not None:
+                            os.environ[k] = v
         other = None
         if len(files) > 1:   # the same frames through the other writer's streams
             w2, p2, tw2 = files[1]
@@ -446,7 +493,7 @@ def end_to_end(frames_dev, poses, n, params, local_rank, torch, colour=None):
                           "bounce buffers with a copy team" % (mc["blocks"], out_b / 1e6))
         r1 = first_run[0]
         return {"marching_cubes": mc, "frames": int(r1["frames_total"]), "frames_per_s": round(r1["frames_total"] / r1["seconds_total"], 1), "seconds": round(r1["seconds_total"], 4),
-                "frames_per_s_best": round(rs["frames_total"] / rs["seconds_total"], 1), "writer": writer, "other_writer": other,
+                "frames_per_s_best": round(rs["frames_total"] / rs["seconds_total"], 1), "writer": writer, "other_writer": other, "alternatives": alternatives,
                 "compressed_bytes_per_frame": round(size / n), "jpeg_bytes_per_picture": jpeg_bytes, "sens_bytes": size, "decode_threads": int(rs["decode_threads"]),
                 "decode_ms_per_frame_per_thread": round(1e3 * rs["seconds_decode_cpu"] / max(rs["frames_total"], 1), 3),
                 "colour_fused": int(rs["color_fused"]), "frames_per_s_first_and_second_run": runs,
@@ -609,8 +656,16 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
         t_s = m["kernel_ms"] * 1e-3 / m["launches"]
         alg_equiv = m["alg_bytes"] / m["launches"] / t_s / 1e9
         batch_gbs = m["batch_bytes"] / m["launches"] / t_s / 1e9
-        r = {"bound": "valu", "achieved": valu["valu_util"] if valu else None, "peak": 1.0, "unit": "fraction of SIMD VALU issue slots",
-             "frac": valu["valu_util"] if valu else None, "traffic": traffic["bytes"] if traffic else None, "kernel": kernel, "sample": sample,
+        # frac: the VALU time the launch's instructions need at the issue costs MEASURED on this part (valu_peak_calibration) over the SIMD time of the launch.
+        # Rounds 2-4 reported SQ_ACTIVE_INST_VALU x 4 / SIMD cycles ("a wave64 instruction holds its SIMD for 4 cycles"); the microbenchmark shows that
+        # counter ticks once per instruction and that the simple fp32 / integer instructions take ~2.2 cycles: that ratio (kept as issue_ratio_4_cycles)
+        # reaches 1.8 on a pure v_fma stream and is not a utilisation.
+        cal = (valu or {}).get("calibrated")
+        frac = cal["frac_serial"] if cal else (valu["valu_util"] if valu else None)
+        r = {"bound": "valu", "achieved": frac, "peak": 1.0,
+             "unit": "VALU issue time of the launch's instructions at the measured per-class issue costs / SIMD time of the launch" if cal else "SQ_ACTIVE_INST_VALU x 4 / SIMD cycles (uncalibrated)",
+             "frac": frac, "valu_peak_calibration": cal, "issue_ratio_4_cycles": valu["valu_util"] if valu else None,
+             "traffic": traffic["bytes"] if traffic else None, "kernel": kernel, "sample": sample,
              "hbm_frac": round(traffic["bytes"] / t_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
              "hbm_GBs": round(traffic["bytes"] / t_s / 1e9, 1) if traffic else None,
              "hbm_alg_batch": {"bytes_per_launch": round(m["batch_bytes"] / m["launches"]), "tiles_per_launch": round(m["tiles"] / m["launches"], 1),

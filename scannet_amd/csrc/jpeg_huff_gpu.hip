@@ -20,7 +20,7 @@ int jpeg_gpu_reconstruct(hipStream_t stream, int n, const uint8_t* const* d_payl
 
 namespace {
 
-constexpr int JH_BATCH = 16;
+constexpr int JH_BATCH = 32;   // pictures per launch: a whole batch of the frame pipeline, one CU each
 constexpr int JH_LANES = 1024;
 
 struct JpegHuffBatch {
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(JH_LANES) void k_jpeg_huff(JpegHuffBatch B) {
 
 }  // namespace
 
-// Entropy-decode up to 16 prepared pictures on `stream`: d_prepared[i] (jpeg_prepare_huff's payload, uploaded) -> d_payload[i] (what
+// Entropy-decode up to 32 prepared pictures on `stream`: d_prepared[i] (jpeg_prepare_huff's payload, uploaded) -> d_payload[i] (what
 // jpeg_gpu_reconstruct reads); max_entries[i] = room for entries in d_payload[i]; d_status (nullable): 2 * n ints the caller zeroed, written only
 // for pictures that fail: {code < 0, tags[i]}.
 int jpeg_gpu_huffman(hipStream_t stream, int n, const uint8_t* const* d_prepared, uint8_t* const* d_payload, const uint32_t* max_entries, const int32_t* tags,

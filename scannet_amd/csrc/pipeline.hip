@@ -41,6 +41,11 @@ int jpeg_gpu_reconstruct(hipStream_t stream, int n, const uint8_t* const* d_payl
 // their own main() before the first HIP call, and a run that finds fewer queues than it has streams says so through
 // sf_last_error() while returning SF_OK (sf_fuse_run_note).
 
+// the default of the JPEG entropy decoding (see gpu_huffman in sf_fuse_run), decided by measurement (profiles/r05_e2e_rgbd.json: 1296x968 pictures of ~200 KB,
+// device + 4 host threads 12.3 k frames/s before the five side streams, host decoding on 16 threads 10.0 k, on 4 threads 3.2 k): on the device whenever the
+// batch has a side stream to decode on
+#define SF_JPEG_DEVICE_HUFFMAN_DEFAULT(has_side_stream) (has_side_stream)
+
 namespace {
 
 thread_local uint64_t t_run_counts[4] = {0, 0, 0, 0};   // of this thread's last sf_fuse_run: depth frames inflated on the device / by the host threads, colour
@@ -58,7 +63,7 @@ int hardware_queues_of_the_process() {   // what the runtime was (or will be) to
 struct RunResources {
   int device = -1;
   bool taken = false;
-  hipStream_t copy[2] = {nullptr, nullptr}, inflate[3] = {nullptr, nullptr, nullptr};
+  hipStream_t copy[2] = {nullptr, nullptr}, inflate[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   uint8_t* h_pool = nullptr;
   size_t h_bytes = 0;
 };
@@ -146,14 +151,18 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   // enough batch slots for every decode thread to be busy while two batches sit between copy and pre-pass
   // 3 slots (one decoding, one in flight, one being read by the pre-pass) are enough: 4, 6 and 10 measured no faster (tools/gpu/h2d_bw.hip:
   // the link moves 57 GB/s from pinned memory on two streams; a colour run is bound by the fusion kernels and ~15 ms of set-up)
-  constexpr int NZ = 3;   // inflate streams: consecutive batches are inflated side by side (a batch takes longer to inflate than to fuse)
+  // side streams: batch g is inflated (and its JPEG pictures entropy-decoded and reconstructed) on stream g % NZ, beside the fusion of the batches before
+  // it.  A batch takes ~1.8 ms to inflate and 0.8 ms to fuse: three in flight; with JPEG colour the side work is ~4.9 ms per batch (k_jpeg_huff 2.4 ms
+  // per 32 pictures of 200 KB on 32 CUs): five (profiles/r05_timeline_e2e_rgbd.txt)
+  constexpr int MAX_NZ = 6;
+  const int NZ = jpeg_colour ? 5 : 3;
   const int NB = (int)std::max<uint64_t>(1, std::min<uint64_t>(std::max<uint64_t>(gpu_inflate ? 3 + NZ : 3, ((uint64_t)nthreads + B - 1) / B + 2), std::max<uint64_t>(nbatches, 1)));
   std::vector<BatchSlot> ring((size_t)NB);
   // two streams = two SDMA engines: one alone moves ~20 GB/s.  With the GPU inflate the batch's copies ride on its inflate stream (and the next
   // one): copy, tokens, copies-kernel of batch g, then the copy of batch g + 3 -- a stream costs ~5 ms to create
   hipStream_t copy_stream = nullptr, copy_stream2 = nullptr;
-  hipStream_t inflate_stream[NZ] = {nullptr, nullptr, nullptr};   // batch g is inflated on stream g % NZ, beside the pre-pass / allocation / integration of the batches before it
-  uint8_t* d_plan[NZ] = {nullptr, nullptr, nullptr};              // scratch of the inflate kernels (one u16 per output byte), one per stream
+  hipStream_t inflate_stream[MAX_NZ] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  uint8_t* d_plan[MAX_NZ] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // scratch of the inflate kernels (one u16 per output byte), one per stream
   int32_t* d_zstatus = nullptr;                                // 2 ints per ring slot and frame, written by the device's inflate only when a frame fails
   // ONE pinned host allocation and ONE device allocation for the whole ring
   uint8_t* h_pool = nullptr;
@@ -186,7 +195,9 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
     }
   }
   const bool gpu_jpeg = pay_b != 0;
-  const bool gpu_huffman = gpu_jpeg && std::getenv("SF_JPEG_GPU_HUFFMAN") != nullptr;
+  // where the entropy decoding runs: on the device when the batch has a side stream for it (the depth inflate's), else on the host threads;
+  // SF_JPEG_GPU_HUFFMAN=1 / SF_JPEG_HOST_HUFFMAN=1 force one or the other
+  const bool gpu_huffman = gpu_jpeg && std::getenv("SF_JPEG_HOST_HUFFMAN") == nullptr && (std::getenv("SF_JPEG_GPU_HUFFMAN") != nullptr || SF_JPEG_DEVICE_HUFFMAN_DEFAULT(gpu_inflate));
   const uint32_t pay_entries = gpu_jpeg ? (uint32_t)((pay_b - sizeof(SfJpegLayout) - 4 * (size_t)pay_blocks) / 4) : 0u;
   int32_t* d_jstatus = nullptr;   // 2 ints per ring slot and frame, written by the device's entropy decoder only when a picture fails
   // GPU inflate: the depth part of a pinned slot is PACKED -- per frame either the zlib stream from its third byte on (the device inflates it)
@@ -216,13 +227,23 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   // pinned slot: depth, then per frame ONE colour area that holds either pixels or coefficients (col_b = the larger of the two);
   // device slot: depth, pixels, coefficients, planes scratch
   const size_t col_b = std::max(rgb_b, pay_b), slot_col = (col_b * B + 255) & ~(size_t)255;
-  const size_t slot_b = slot_depth + slot_col;
+  // With the device's entropy decoder a picture travels as its prepared segment -- never more than its blob in the file plus the tables -- so the PINNED
+  // slot holds that per frame instead of room for a decoded picture (1296x968: 0.26 MB instead of 3.8 MB per frame, 110 MB of page-locked memory for a run
+  // instead of 833 MB: 45 ms of the first run of a process).  A picture the device does not take (restart intervals, ...) is decoded by its host thread
+  // into a pageable buffer of its own and copied from there (coef_mode 3).
+  size_t max_color_bytes = 0;
+  if (gpu_huffman)
+    for (uint64_t k = first; k < last; k++) max_color_bytes = std::max<size_t>(max_color_bytes, (size_t)s->frames[k].color_bytes);
+  const bool small_col = gpu_huffman;
+  const size_t hcol_b = small_col ? (max_color_bytes + sizeof(SfJpegLayout) + sizeof(SfJpegHuffDesc) + 64 + 255) & ~(size_t)255 : col_b;
+  const size_t hslot_col = (hcol_b * B + 255) & ~(size_t)255;
+  const size_t slot_b = slot_depth + hslot_col;
   // the packed depth part on the device, with 256 readable bytes behind it (the lanes of k_inflate_tokens fetch 64 bytes at a time, two fetches ahead)
   const size_t slot_comp = gpu_inflate ? slot_depth + 256 : 0;
   const size_t dslot_b = dslot_depth + slot_col + (gpu_jpeg ? slot_col : 0) + slot_planes + slot_comp;   // every colour area strides by col_b: runs copy as one piece
   auto h_depth = [&](int sl, int j) { return (uint16_t*)(h_pool + (size_t)sl * slot_b + (size_t)j * depth_b); };
   auto d_depth = [&](int sl, int j) { return d_pool + (size_t)sl * dslot_b + (size_t)j * depth_b; };
-  auto h_rgb = [&](int sl, int j) { return h_pool + (size_t)sl * slot_b + slot_depth + (size_t)j * col_b; };
+  auto h_rgb = [&](int sl, int j) { return h_pool + (size_t)sl * slot_b + slot_depth + (size_t)j * hcol_b; };
   auto d_rgb = [&](int sl, int j) { return d_pool + (size_t)sl * dslot_b + dslot_depth + (size_t)j * col_b; };
   auto h_pay = h_rgb;
   auto d_pay = [&](int sl, int j) { return d_pool + (size_t)sl * dslot_b + dslot_depth + slot_col + (size_t)j * col_b; };
@@ -298,6 +319,7 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   if (timing)
     std::fprintf(stderr, "sf_fuse_run set-up: frame table + layout %.1f ms; streams, pinned pool, device pool, events %.1f ms\n",
                  (ts0 - std::chrono::duration<double>(t_start.time_since_epoch()).count()) * 1e3, (t_setup_end - ts0) * 1e3);
+  std::vector<std::vector<uint8_t>> fallback_rgb(small_col ? (size_t)NB * B : 0);   // coef_mode 3: pixels a host thread decoded, pageable, per slot and frame
   std::atomic<uint64_t> next{0}, landed{0}, issued{0};  // frame counter of the pool; batches whose copies completed / were queued
   std::atomic<bool> abort{false};
   std::atomic<uint64_t> decode_ns{0};
@@ -335,11 +357,19 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
           if (gpu_jpeg) {
             uint8_t* pay = h_pay(sl, j);
             const SensFrame& fr = s->frames[frame];
-            if (gpu_huffman && jpeg_prepare_huff(fr.color, fr.color_bytes, s->info.color_width, s->info.color_height, pay, col_b) == SF_OK &&
+            if (gpu_huffman && jpeg_prepare_huff(fr.color, fr.color_bytes, s->info.color_width, s->info.color_height, pay, hcol_b) == SF_OK &&
                 reinterpret_cast<const SfJpegLayout*>(pay)->nblocks == pay_blocks) {
               coef = 2;
               ring[(size_t)sl].pay_used[j] = (uint32_t)(sizeof(SfJpegLayout) + sizeof(SfJpegHuffDesc) +
                                                         4 * (size_t)reinterpret_cast<const SfJpegHuffDesc*>(pay + sizeof(SfJpegLayout))->ecs_words);
+            } else if (small_col) {
+              // not a picture for the device: the host decoder's pixels, in a buffer of this frame's own (the pinned slot has no room for them)
+              try {
+                std::vector<uint8_t>& fb = fallback_rgb[(size_t)sl * B + (size_t)j];
+                fb.resize(rgb_b);
+                rc = sf_sens_decode_color(s, frame, fb.data());
+                coef = 3;
+              } catch (...) { rc = sf::fail(SF_ERR_IO, "out of memory decoding colour frame %llu", (unsigned long long)frame); coef = 3; }
             } else if (jpeg_decode_coef(fr.color, fr.color_bytes, s->info.color_width, s->info.color_height, pay, pay_b) == SF_OK &&
                        reinterpret_cast<const SfJpegLayout*>(pay)->nblocks == pay_blocks) {
               coef = 1;
@@ -445,8 +475,13 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
       any_rgb = true;
       j = j1;
     }
+    for (int j = 0; j < cnt && e == hipSuccess; j++) {   // pictures the host decoded into pageable buffers (the call returns once the bytes are staged)
+      if (!rgbf[j] || bs.coef_mode[j] != 3) continue;
+      e = hipMemcpyAsync(d_rgb(sl, j), fallback_rgb[(size_t)sl * B + (size_t)j].data(), rgb_b, hipMemcpyHostToDevice, cs_rgb);
+      any_rgb = true;
+    }
     for (int j = 0, k = 0; j < cnt && e == hipSuccess; j++) {   // coefficients / entropy-coded segments: what each frame really holds, alternating streams
-      if (!rgbf[j] || !bs.coef_mode[j]) continue;
+      if (!rgbf[j] || !bs.coef_mode[j] || bs.coef_mode[j] == 3) continue;
       // a prepared segment lands where the pixels will be written: it is dead once k_jpeg_huff has turned it into the coefficient payload
       e = hipMemcpyAsync(bs.coef_mode[j] == 2 ? d_rgb(sl, j) : d_pay(sl, j), h_pay(sl, j), bs.pay_used[j], hipMemcpyHostToDevice, (k++ & 1) ? cs_rgb2 : cs_rgb);
       any_rgb = true;
@@ -489,10 +524,50 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
         if (++nz == 32) flush();
       }
       flush();
-      if (e == hipSuccess) e = hipEventRecord(bs.inflated, zs);
       if (e != hipSuccess) { result = SF_ERR_DEVICE; err = std::string("inflate pipeline: ") + hipGetErrorString(e); }
       if (result != SF_OK) break;
     }
+    // JPEG colour on the batch's side stream too (when there is one): entropy decoding of the pictures that travelled as segments and the
+    // reconstruction of every picture that travelled as coefficients or segments -- beside the fusion of the batches before, three batches in flight,
+    // instead of in front of this batch's pre-pass on the fuser's input stream (where a 32-picture batch cost 2 x 1.25 ms of a stream that also
+    // carries allocation and compaction)
+    bool side_jpeg = false;
+    if (gpu_jpeg && gpu_inflate && any_rgb) {
+      hipStream_t zs = inflate_stream[g % NZ];
+      if (!any_comp) e = hipStreamWaitEvent(zs, bs.copied, 0);
+      const uint8_t* pp_[MAX_BATCH];
+      uint8_t* rr_[MAX_BATCH];
+      uint8_t* pl_[MAX_BATCH];
+      int nj = 0;
+      const uint8_t* seg[32];
+      uint8_t* out[32];
+      uint32_t cap[32];
+      int32_t tag[32];
+      int nh = 0, slot0 = 0;
+      auto flush_h = [&]() {
+        if (nh == 0 || result != SF_OK) return;
+        const int rch = jpeg_gpu_huffman(zs, nh, seg, out, cap, tag, d_jstatus + 2 * ((size_t)sl * B + (size_t)slot0));
+        if (rch != SF_OK) { result = rch; err = sf_last_error(); }
+        nh = 0;
+      };
+      for (int q = 0; q < cnt; q++) {
+        if (!(rgbf[q] && (bs.coef_mode[q] == 1 || bs.coef_mode[q] == 2))) continue;
+        pp_[nj] = d_pay(sl, q); rr_[nj] = d_rgb(sl, q); pl_[nj] = d_planes(sl, q); nj++;
+        if (bs.coef_mode[q] != 2) continue;
+        if (nh == 0) slot0 = q;
+        seg[nh] = d_rgb(sl, q); out[nh] = d_pay(sl, q); cap[nh] = pay_entries; tag[nh] = (int32_t)(first + g * (uint64_t)B + (uint64_t)q);
+        if (++nh == 32) flush_h();
+      }
+      flush_h();
+      for (int q0 = 0; q0 < nj && result == SF_OK; q0 += 16) {   // jpeg_gpu.hip reconstructs at most 16 frames per launch
+        const int rcj = jpeg_gpu_reconstruct(zs, std::min(16, nj - q0), pp_ + q0, rr_ + q0, pl_ + q0, pay_blocks, s->info.color_width, s->info.color_height);
+        if (rcj != SF_OK) { result = rcj; err = sf_last_error(); }
+      }
+      if (result != SF_OK) break;
+      side_jpeg = nj > 0;
+    }
+    if ((any_comp || side_jpeg) && e == hipSuccess) e = hipEventRecord(bs.inflated, inflate_stream[g % NZ]);
+    if (e != hipSuccess) { result = SF_ERR_DEVICE; err = std::string("inflate / jpeg pipeline: ") + hipGetErrorString(e); break; }
     if (timing) t_api += now_s() - t1;
     // ---- kernels: the valid frames in order, a sub-batch is all-colour or all-geometry
     const double t2 = timing ? now_s() : 0;
@@ -513,16 +588,16 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
         j++;
       }
       hipStream_t in_stream = sf_input_stream(f, m, rgb, +1);  // the stream this sub-batch's pre-pass runs on
-      if (hipStreamWaitEvent(in_stream, bs.copied, 0) != hipSuccess || (any_comp && hipStreamWaitEvent(in_stream, bs.inflated, 0) != hipSuccess)) {
+      if (hipStreamWaitEvent(in_stream, bs.copied, 0) != hipSuccess || ((any_comp || side_jpeg) && hipStreamWaitEvent(in_stream, bs.inflated, 0) != hipSuccess)) {
         result = SF_ERR_DEVICE; err = "hipStreamWaitEvent failed"; break;
       }
-      if (rgb && gpu_jpeg) {   // IDCT + upsampling + colour conversion of this sub-batch's entropy-decoded frames, ahead of its pre-pass
+      if (rgb && gpu_jpeg && !side_jpeg) {   // no side stream (depth not inflated on the device): IDCT + upsampling + colour conversion of this sub-batch's frames ahead of its pre-pass
         const uint8_t* pp_[MAX_BATCH];
         uint8_t* rr_[MAX_BATCH];
         uint8_t* pl_[MAX_BATCH];
         int nj = 0;
         for (int q = jfirst; q < j; q++)
-          if (valid[q] && rgbf[q] && bs.coef_mode[q]) { pp_[nj] = d_pay(sl, q); rr_[nj] = d_rgb(sl, q); pl_[nj] = d_planes(sl, q); nj++; }
+          if (valid[q] && rgbf[q] && (bs.coef_mode[q] == 1 || bs.coef_mode[q] == 2)) { pp_[nj] = d_pay(sl, q); rr_[nj] = d_rgb(sl, q); pl_[nj] = d_planes(sl, q); nj++; }
         bool jpeg_failed = false;
         {   // entropy decoding of the frames that travelled as segments: one 1024-lane workgroup per picture, 16 pictures per launch
           const uint8_t* seg[16];

@@ -640,11 +640,13 @@ def test_jpeg_gpu_reconstruction_identical_to_the_reference_decoder(oracle, tmp_
     assert n == 27
 
 
-@pytest.mark.parametrize("kind", ["raw", "jpeg", "jpeg_gpu_huffman", "jpeg_host"])
+@pytest.mark.parametrize("kind", ["raw", "jpeg", "jpeg_gpu_huffman", "jpeg_host_huffman", "jpeg_host"])
 def test_fuse_run_with_colour_matches_frame_by_frame(tmp_path, kind, monkeypatch):
-    """Colour at its own resolution through the threaded pipeline (raw; JPEG entropy-decoded by the host threads and reconstructed on the
-    GPU; JPEG entropy-decoded on the GPU too (SF_JPEG_GPU_HUFFMAN); JPEG decoded on the host):
-    the same voxels, colours included, as integrating the host-decoded frames one by one.  One frame has no pose, one no colour."""
+    """Colour at its own resolution through the threaded pipeline -- raw; JPEG as sf_fuse_run takes it by default (entropy decoding on the device, on the
+    batch's side stream: the pictures travel as prepared segments in a pinned slot sized for THOSE; a picture the device does not take -- here every
+    second one has another sampling layout than the scan's first -- is decoded by its host thread into a pageable buffer of its own); the same forced
+    (SF_JPEG_GPU_HUFFMAN); JPEG entropy-decoded by the host threads and reconstructed on the GPU (SF_JPEG_HOST_HUFFMAN); JPEG decoded on the host
+    altogether (SF_JPEG_HOST): the same voxels, colours included, as integrating the host-decoded frames one by one.  One frame has no pose, one no colour."""
     from scannet_amd import calibrate, fusion, sens
     W, H, CW, CH = 160, 120, 324, 242
     n = 37
@@ -672,10 +674,16 @@ def test_fuse_run_with_colour_matches_frame_by_frame(tmp_path, kind, monkeypatch
         monkeypatch.setenv("SF_JPEG_HOST", "1")
     if kind == "jpeg_gpu_huffman":
         monkeypatch.setenv("SF_JPEG_GPU_HUFFMAN", "1")
+    if kind == "jpeg_host_huffman":
+        monkeypatch.setenv("SF_JPEG_HOST_HUFFMAN", "1")
     s = sens.SensorData(p)
     with fusion.Fuser(gp) as a, fusion.Fuser(gp) as b:
         rs = a.run(s, decode_threads=5)
         assert rs["frames_total"] == n and rs["color_fused"] == 1
+        if kind in ("jpeg", "jpeg_gpu_huffman"):      # frames 0, 2, 4, ... share the first frame's layout (5 has no pose); the odd ones fall back to their host thread
+            assert rs["jpeg_entropy_on_device"] == 19 and rs["jpeg_entropy_on_host"] == 16, rs
+        elif kind.startswith("jpeg"):
+            assert rs["jpeg_entropy_on_device"] == 0 and rs["jpeg_entropy_on_host"] == 35, rs
         for i, (d, pose) in enumerate(frames):
             if i == 5:
                 continue

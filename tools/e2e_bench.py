@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--fuse-only", action="store_true", help="stop after the fusion stage")
     ap.add_argument("--scene", type=int, default=synth.SCENE_DEFAULT, help="0 = empty box room, 1 = furnished (default)")
     ap.add_argument("--noise", type=int, default=synth.NOISE_DEFAULT, help="1 = the LCG ramp of rounds 1-2, 2 = hashed per pixel (default)")
+    ap.add_argument("--smooth-pictures", action="store_true", help="--color jpeg: the smooth pictures of rounds 1-4 (77-110 KB at 1296x968) instead of synth.textured_pictures (~200 KB)")
     ap.add_argument("--color-res", default="", help="WxH of the colour frames when it differs from the depth size (ScanNet: 1296x968)")
     a = ap.parse_args()
     W, H = 640, 480
@@ -63,9 +64,12 @@ def main():
     blobs = []
     if a.color == "jpeg":
         from scannet_amd import calibrate
-        for k in range(8):   # eight distinct encoded frames, cycled (encoding thousands of frames would dominate the set-up)
-            img = np.stack([(xx + 8 * k) % 256, (yy * 2) % 256, (128 + 100 * np.sin(xx / 30.0) * np.cos(yy / 20.0 + k))], -1).astype(np.uint8)
-            blobs.append(calibrate.jpeg_encode(img, 90, True))
+        if a.smooth_pictures:
+            for k in range(8):   # eight distinct encoded frames, cycled (encoding thousands of frames would dominate the set-up)
+                img = np.stack([(xx + 8 * k) % 256, (yy * 2) % 256, (128 + 100 * np.sin(xx / 30.0) * np.cos(yy / 20.0 + k))], -1).astype(np.uint8)
+                blobs.append(calibrate.jpeg_encode(img, 90, True))
+        else:
+            blobs = [calibrate.jpeg_encode(img, 90, True) for img in synth.textured_pictures(cw or W, ch or H)]
     if a.color == "none":
         sd.add_depth_frames(depth, poses.reshape(-1, 4, 4))   # threaded deflate
     for i in range(a.frames if a.color != "none" else 0):

@@ -13,6 +13,7 @@
 #define __restrict__ __restrict
 
 struct uint4 { uint32_t x, y, z, w; };
+struct uint2 { uint32_t x, y; };
 
 typedef int hipError_t;
 constexpr hipError_t hipSuccess = 0;
