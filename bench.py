@@ -403,7 +403,7 @@ def end_to_end(frames_dev, poses, n, params, local_rank, torch, colour=None):
         threads = min(4, os.cpu_count() or 4)   # the depth frames are inflated on the GPU: a host thread copies 330-370 KB per frame
         for _ in range(2):   # the second pass reads the file from the page cache, as the stage after `convert` does, and finds the process's streams and pinned pool made
             with fusion.Fuser(prm, device=local_rank, **TUNE) as f:
-                rs = f.run(sd, decode_threads=threads if colour is None else 0)   # JPEG colour: every host thread entropy-decodes (0 = all the process may use)
+                rs = f.run(sd, decode_threads=threads)   # JPEG colour too: the pictures are entropy-decoded on the device, a host thread only prepares the segment
                 st = f.stats()
                 runs.append(round(rs["frames_total"] / rs["seconds_total"], 1))
                 if colour is None:   # what follows the fusion in the `improve` stage: marching cubes over the fused volume (second call: warm)
@@ -443,7 +443,7 @@ def end_to_end(frames_dev, poses, n, params, local_rank, torch, colour=None):
             w2, p2, tw2 = files[1]
             sd2 = sens.SensorData(p2)
             with fusion.Fuser(prm, device=local_rank, **TUNE) as f:
-                r2 = f.run(sd2, decode_threads=threads if colour is None else 0)
+                r2 = f.run(sd2, decode_threads=threads)
                 other = {"writer": w2, "frames_per_s": round(r2["frames_total"] / r2["seconds_total"], 1), "compressed_bytes_per_frame": round(os.path.getsize(p2) / n),
                          "depth_inflated_on_device": int(r2.get("depth_inflated_on_device", -1)), "write_s": round(tw2, 2), "run": "third of the process"}
             sd2.close()
@@ -506,7 +506,8 @@ def end_to_end(frames_dev, poses, n, params, local_rank, torch, colour=None):
                         "of the file in this process (it creates the run's streams and its pinned pool), frames_per_s_best = the better of two; other_writer: the same frames as this "
                         "library's writer compresses them; host_inflate: the same file with the host threads inflating"
                         % (writer, " + baseline-JPEG colour at 1296x968 with its own intrinsics, %d KB per picture" % (jpeg_bytes // 1024) if colour == "jpeg1296" else "", size // n // 1024,
-                           rs["decode_threads"], " and Huffman-decode the colour frames (IDCT / upsampling / RGB on the GPU)" if colour == "jpeg1296" else "")}
+                           rs["decode_threads"], " and strip the byte stuffing of the colour pictures' entropy-coded segments (Huffman decoding, IDCT, upsampling and RGB on the GPU; `alternatives`: the same file "
+                           "with the entropy decoding on the host threads)" if colour == "jpeg1296" else "")}
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
