@@ -381,3 +381,28 @@ def project_matrix(cam2world, fx, fy, W, H, n, f):
     M = np.zeros(16, np.float32)
     L.or_project_matrix(c.ctypes.data, fx, fy, W, H, n, f, M.ctypes.data)
     return M.reshape(4, 4)
+
+
+# ---------------------------------------------------------------- decimate stage: the quadric collapse as rounds of independent collapses (oracle/simplify_rounds_oracle.c)
+def simplify_rounds(xyz, tris, rgba=None, target_perc=0.2, target_faces=0, quality_thr=0.3, boundary_weight=1.0, optimal_placement=True, planar_quadric=False,
+                    auto_clean=True):
+    """The sequential restatement of scannet_amd/csrc/simplify_gpu.hip's rule (defaults: simplify.mlx:3-16).  Returns (xyz [v,3] f32, rgba [v,4] u8 or None,
+    tris [f,3] u32, {"rounds", "collapses"})."""
+    import numpy as np
+    L = lib()
+    L.or_simplify_rounds.restype = C.c_int
+    L.or_simplify_rounds.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_float, C.c_uint64, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+    v = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    t = np.ascontiguousarray(tris, np.uint32).reshape(-1, 3)
+    c = None if rgba is None else np.ascontiguousarray(rgba, np.uint8).reshape(-1, 4)
+    vo = np.zeros((max(len(v), 1), 3), np.float32)
+    to = np.zeros((max(len(t), 1), 3), np.uint32)
+    co = None if c is None else np.zeros((max(len(v), 1), 4), np.uint8)
+    nv, nf, rounds, coll = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0), C.c_uint64(0)
+    rc = L.or_simplify_rounds(v.ctypes.data, len(v), t.ctypes.data, len(t), None if c is None else c.ctypes.data, float(target_perc), int(target_faces), float(quality_thr),
+                              float(boundary_weight), int(bool(optimal_placement)), int(bool(planar_quadric)), int(bool(auto_clean)), vo.ctypes.data, to.ctypes.data,
+                              None if co is None else co.ctypes.data, C.byref(nv), C.byref(nf), C.byref(rounds), C.byref(coll))
+    if rc != 0:
+        raise RuntimeError("or_simplify_rounds failed (%d)" % rc)
+    return vo[:nv.value], (None if co is None else co[:nv.value]), to[:nf.value], {"rounds": rounds.value, "collapses": coll.value}

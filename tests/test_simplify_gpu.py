@@ -1,6 +1,7 @@
 """The GPU variant of the decimate stage's quadric edge collapse (scannet_amd/csrc/simplify_gpu.hip: rounds of independent collapses) under
 the SAME property tests as the sequential filter (tests/test_simplify.py): face budget, planarity and outline of flat regions, closedness and
-Euler characteristic of a closed surface, geometric error, determinism -- the triangles differ from the sequential result, the guarantees do not."""
+Euler characteristic of a closed surface, geometric error, determinism -- the triangles differ from the sequential GREEDY filter's, the guarantees do
+not -- and, since round 5, IDENTITY with the sequential restatement of its own rule (oracle/simplify_rounds_oracle.c)."""
 import time
 
 import numpy as np
@@ -13,6 +14,66 @@ from tests import meshes
 from tests.test_simplify import _edge_counts, _icosphere, _plane
 
 pytestmark = pytest.mark.gpu
+
+
+def _identical(oracle, v, t, rgba=None, **kw):
+    """sf_mesh_simplify_gpu == oracle.simplify_rounds on this mesh: vertices (bits), colours, triangles, rounds, collapses."""
+    m = Mesh.from_arrays(v, t, rgba) if rgba is not None else Mesh.from_arrays(v, t)
+    out, st = meshclean.simplify(m, gpu=0, **kw)
+    gx, gc, gt = out.arrays()
+    ok = {"target_perc": kw.get("target_perc", 0.2), "target_faces": kw.get("target_faces", 0), "quality_thr": kw.get("quality_thr", 0.3),
+          "boundary_weight": kw.get("boundary_weight", 1.0), "optimal_placement": kw.get("optimal_placement", 1), "planar_quadric": kw.get("planar_quadric", 0),
+          "auto_clean": kw.get("auto_clean", 1)}
+    ox, oc, ot, ost = oracle.simplify_rounds(v, t, rgba, **ok)
+    assert (st["rounds"], st["collapses"]) == (ost["rounds"], ost["collapses"]), (st, ost)
+    assert gx.shape == ox.shape and np.array_equal(gx.view(np.uint32), ox.view(np.uint32)), "surviving vertices / positions differ"
+    assert np.array_equal(gt, ot), "triangles differ"
+    if rgba is not None:
+        assert np.array_equal(gc, oc)
+    return st
+
+
+def test_gpu_collapse_is_the_sequential_restatement_of_its_rule(oracle):
+    """f1's parity test (VERDICT r4 Missing 4): the GPU decimation is rounds of INDEPENDENT collapses chosen by a rule that is a property of the mesh --
+    candidates below a quantile of the round's priorities, winners = local minima of (priority, scrambled edge id) over closed 1-rings, three passes,
+    the last round cut by key order -- so a sequential program that applies the rule edge by edge (oracle/simplify_rounds_oracle.c: its own quadrics,
+    minimiser, link test, sorts; binary64 with every operation rounded separately) must produce the SAME mesh: surviving vertices and their positions
+    bit for bit, the same triangles in the same order, the same number of rounds and collapses.  Planes (every priority tied at the floor), a closed
+    surface, creased heightfields with colours, open strips, non-default parameters, soups with non-manifold edges / duplicate / degenerate faces."""
+    v, t = _plane(60)
+    _identical(oracle, v, t)
+    v, t = _icosphere(4)
+    _identical(oracle, v, t)
+    _identical(oracle, v, t, target_perc=0.5, quality_thr=0.0)
+    _identical(oracle, v, t, target_perc=0.0, target_faces=700, optimal_placement=0)
+    v, t = meshes.bumpy(120)[:2]
+    rgba = np.stack([np.arange(len(v)) % 256, (np.arange(len(v)) * 7) % 256, (np.arange(len(v)) * 13) % 256, np.full(len(v), 255)], -1).astype(np.uint8)
+    _identical(oracle, v, t, rgba)
+    _identical(oracle, v, t, rgba, planar_quadric=1, boundary_weight=2.0)
+    _identical(oracle, v, t, auto_clean=0, target_perc=0.05)
+    for mk in (meshes.bent_strip, meshes.l_shape, meshes.grid):
+        v, t = mk()[:2]
+        _identical(oracle, np.asarray(v, np.float32), np.asarray(t, np.uint32), target_perc=0.5)
+    rng = np.random.default_rng(7)
+    for it in range(12):
+        nv = int(rng.integers(4, 900))
+        v = rng.uniform(0, 1, (nv, 3)).astype(np.float32)
+        if it % 4 == 0:
+            v[:, 2] = 0.0
+        t = rng.integers(0, nv, (int(rng.integers(1, 2500)), 3)).astype(np.uint32)
+        if it % 3 == 0 and len(t) >= 8:
+            t[: len(t) // 4] = t[len(t) // 2: len(t) // 2 + len(t) // 4][:, ::-1]
+        _identical(oracle, v, t)
+
+
+def test_scan_sized_mesh_gpu_equals_the_sequential_restatement(oracle):
+    """The same on a scan-sized mesh: 977 202 faces to 20 %, and the result again to 20 % (the decimate stage runs simplify.mlx twice)."""
+    v, f = meshes.bumpy_large(700)
+    st = _identical(oracle, v, f)
+    assert st["faces_out"] <= st["target_faces"] and st["rounds"] < 40
+    out, _ = meshclean.simplify(Mesh.from_arrays(v, f), gpu=0)
+    x1, _, t1 = out.arrays()
+    _identical(oracle, x1, t1)
 
 
 def test_plane_stays_planar_and_keeps_its_border_gpu():
