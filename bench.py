@@ -616,6 +616,20 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
             if ntiles > 0:
                 ceiling = {"tiles": ntiles, "rmw_copy_us": round(rmw_us, 2), "rmw_copy_GBs": round(ntiles * 8192 / rmw_us / 1e3, 1),
                            "read_only_us": round(ro_us, 2), "read_only_GBs": round(ntiles * 4096 / ro_us / 1e3, 1)}
+                if ntiles * 4096 > (512 << 20) and hasattr(fuser, "calib_tile_rmw_ex"):   # out of cache: what holds the read-modify-write below the read-only rate?
+                    dec = {}
+                    for label, kw in (("scattered_rmw", {}), ("scattered_rmw_2_tiles_per_turnaround", {"tiles_per_turnaround": 2}), ("scattered_rmw_4_tiles_per_turnaround", {"tiles_per_turnaround": 4}),
+                                      ("contiguous_rmw", {"contiguous": True}), ("contiguous_rmw_4_tiles_per_turnaround", {"contiguous": True, "tiles_per_turnaround": 4}),
+                                      ("scattered_read_only", {"read_only": True}), ("contiguous_read_only", {"read_only": True, "contiguous": True})):
+                        try:
+                            us, nt_ = fuser.calib_tile_rmw_ex(iters=8, **kw)
+                            dec[label] = {"us": round(us, 1), "GBs": round(nt_ * (4096 if kw.get("read_only") else 8192) / us / 1e3, 1)}
+                        except Exception as ex:
+                            dec[label] = {"error": str(ex)[:120]}
+                    ceiling["rmw_decomposition"] = dec
+                    ceiling["rmw_decomposition_what"] = ("the pass's tile traffic without arithmetic, taken apart: the pass's scattered 4 KiB tiles or one contiguous span of as many tiles "
+                                                         "(tiles 0..n-1 of the pool); every tile written back right after it is read, or 2 / 4 tiles read and then written (fewer read/write "
+                                                         "turnarounds in flight per wave); read only.  Every tile is written back as read")
         batch = fuser.batch_frames
         fuser.close()
         # B_frame = N_blk*(512*8 read + 512*8 write + 16) + W*H*2 + 64, summed over the frames (and the repeats)
@@ -835,6 +849,7 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
                     if roof is not None:
                         roof["hbm_out_of_cache"] = {"frac": ro["frac"], "achieved_GBs": ro["achieved"], "frac_of_rmw_ceiling": (ro.get("pattern_ceiling") or {}).get("frac_of_ceiling"),
                                                     "kernel_alone_frac": (ro.get("kernel_alone") or {}).get("frac"), "footprint_vs_infinity_cache": ro["footprint_vs_infinity_cache"],
+                                                    "rmw_decomposition": (ro.get("pattern_ceiling") or {}).get("rmw_decomposition"),
                                                     "what": "k_integrate_pipe, one depth frame per launch at 1 mm voxels (BASELINE configs[2] geometry): SURVEY 8d algorithmic bytes / launch "
                                                             "duration / 8 TB/s in the shipped schedule; details under roofline_out_of_cache"}
             except _abi.ScanfuseError as e:   # a smaller GPU than the 288 GB part cannot reserve the tiles

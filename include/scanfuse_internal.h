@@ -100,6 +100,10 @@ int sf_selftest_division(int device, uint64_t* recip_mismatches, uint64_t* quot_
  * without its arithmetic -- every tile of that pass's list is read and (read_only == 0) written back unchanged, with the
  * integrate kernel's launch geometry; iters timed launches, average duration in microseconds.  The volume is unchanged. */
 int sf_fuser_calib_tile_rmw(sf_fuser* f, int read_only, int iters, double* avg_us, uint32_t* tiles);
+/* The same traffic taken apart (bench.py roofline.hbm_out_of_cache.rmw_decomposition).  mode bit 0: read only; bit 1: tiles 0 .. n - 1 of the pool -- one
+ * contiguous span of the same size -- instead of the pass's scattered list; bits 2-3: log2 of the tiles a wave reads before it writes them back (1 / 2 / 4).
+ * Every tile is written back as read: the volume is unchanged. */
+int sf_fuser_calib_tile_rmw_ex(sf_fuser* f, int mode, int iters, double* avg_us, uint32_t* tiles);
 
 /* PMC calibration stream (tools/pmc_calibrate.py): known-byte-count 16 B/lane RMW + read-only launches. */
 int sf_calib_stream(int device, uint64_t bytes, int iters);

@@ -1579,6 +1579,52 @@ __global__ __launch_bounds__(256, 4) void k_tile_rmw(uint4* __restrict__ voxels,
   if (read_only && acc == 0x9E3779B9u) *sink = acc;
 }
 
+// The same traffic taken apart (sf_fuser_calib_tile_rmw_ex): WHICH tiles -- the pass's list (scattered over the pool) or tiles 0 .. n - 1 of the pool
+// (one contiguous span of the same size) -- and HOW a wave turns from reading to writing -- tile by tile, or G tiles read and then G tiles written.
+// If the contiguous copy runs no faster than the scattered one, the 4 KiB granularity is not what holds the pattern below the read-only rate; if the
+// batched turnaround does not either, it is HBM's read / write mix itself.
+template <bool NT, int G>
+__global__ __launch_bounds__(256, 4) void k_tile_rmw_ex(uint4* __restrict__ voxels, const int32_t* __restrict__ compact, const int32_t* __restrict__ counters,
+                                                     int compact_counter, int xcd_walk, int read_only, int contiguous, uint32_t* sink) {
+  const int n = counters[compact_counter];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int groups = (n + G - 1) / G;                 // wave-sized units of work: G tiles each
+  const int wg_total = (groups + 3) >> 2;
+  const int chunk = xcd_walk ? (wg_total + 7) >> 3 : wg_total;
+  const int lanes = xcd_walk ? 8 : 1;
+  const int sub = xcd_walk ? (int)(blockIdx.x & 7) : 0;
+  const int per_sub = max(1, (int)gridDim.x / lanes);
+  uint32_t acc = 0;
+  for (int loc = xcd_walk ? (int)(blockIdx.x >> 3) : (int)blockIdx.x; loc < chunk; loc += per_sub) {
+    const int u = ((sub * chunk + loc) << 2) + wave;
+    if (u >= groups) continue;
+    uint4 v[G][4];
+    uint4* vb[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      const int i = min(u * G + g, n - 1);            // the last group repeats its last tile: written back unchanged twice
+      vb[g] = voxels + (size_t)(contiguous ? i : compact[i]) * 256;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (NT) { const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(&vb[g][j * 64 + lane])); v[g][j] = make_uint4(t.x, t.y, t.z, t.w); }
+        else v[g][j] = vb[g][j * 64 + lane];
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (read_only) { acc ^= v[g][j].x ^ v[g][j].y ^ v[g][j].z ^ v[g][j].w; continue; }
+        asm volatile("" : "+v"(v[g][j].x));  // opaque to the optimiser: the store below stays
+        if (NT) __builtin_nontemporal_store((u32x4){v[g][j].x, v[g][j].y, v[g][j].z, v[g][j].w}, reinterpret_cast<u32x4*>(&vb[g][j * 64 + lane]));
+        else vb[g][j * 64 + lane] = v[g][j];
+      }
+    }
+  }
+  if (read_only && acc == 0x9E3779B9u) *sink = acc;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Garbage collection: one 256-thread workgroup per live block; min |sdf| over observed
 // voxels and max weight reduced through wave shuffles + LDS; freed blocks are zeroed, unlinked
@@ -2441,6 +2487,49 @@ SF_API int sf_fuser_calib_tile_rmw(sf_fuser* f, int read_only, int iters, double
     else
       hipLaunchKernelGGL(k_tile_rmw<false>, dim3(grid), dim3(256), 0, f->stream, f->voxels, f->compact2[sl], f->counters, cc, f->xcd_walk ? 1 : 0,
                          read_only ? 1 : 0, sink);
+    SF_HIP_CHECK(hipEventRecord(e1, f->stream));
+    SF_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    SF_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (it > 0) total_ms += ms;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(sink);
+  if (avg_us) *avg_us = total_ms * 1e3 / iters;
+  if (tiles) *tiles = (uint32_t)n;
+  return SF_OK;
+}
+
+// scanfuse_internal.h: the pattern ceiling taken apart.  mode bit 0: read only; bit 1: contiguous tiles 0 .. n - 1 instead of the pass's list; bits 2-3:
+// tiles per turnaround 1 / 2 / 4 (0, 1, 2).  Every tile is written back as it was read: the volume is unchanged whatever it holds.
+SF_API int sf_fuser_calib_tile_rmw_ex(sf_fuser* f, int mode, int iters, double* avg_us, uint32_t* tiles) {
+  if (!f || iters < 1 || mode < 0 || (mode >> 2) > 2) return sf::fail(SF_ERR_INVALID_ARG, "sf_fuser_calib_tile_rmw_ex: bad argument");
+  SF_HIP_CHECK(hipSetDevice(f->device));
+  SF_HIP_CHECK(sf_quiesce(f));
+  const int sl = f->slot ^ 1;  // the list of the most recent pass
+  const int cc = sl ? (int)C_COMPACT_B : (int)C_COMPACT;
+  int32_t n = 0;
+  SF_HIP_CHECK(hipMemcpy(&n, &f->counters[cc], 4, hipMemcpyDeviceToHost));
+  if (n < 1 || (uint32_t)n > (uint32_t)f->p.num_sdf_blocks) return sf::fail(SF_ERR_INVALID_ARG, "sf_fuser_calib_tile_rmw_ex: no pass to repeat");
+  const int read_only = mode & 1, contiguous = (mode >> 1) & 1, G = 1 << (mode >> 2);
+  const int units = (n + G - 1) / G;
+  int grid = (units + units / 4 + 4096 + 3) / 4;
+  if (grid > f->num_cus * 64) grid = f->num_cus * 64;
+  grid = (grid + 7) & ~7;
+  uint32_t* sink = nullptr;
+  SF_HIP_CHECK(hipMalloc((void**)&sink, 4));
+  hipEvent_t e0, e1;
+  SF_HIP_CHECK(hipEventCreate(&e0));
+  SF_HIP_CHECK(hipEventCreate(&e1));
+  const bool nt = f->nt_mode == 1 || (f->nt_mode < 0 && (uint64_t)(uint32_t)n * 4096ull > (512ull << 20));
+  double total_ms = 0;
+  for (int it = 0; it < iters + 1; it++) {  // first launch untimed
+    SF_HIP_CHECK(hipEventRecord(e0, f->stream));
+#define LAUNCH_RMW(NTV, GV) hipLaunchKernelGGL((k_tile_rmw_ex<NTV, GV>), dim3(grid), dim3(256), 0, f->stream, f->voxels, f->compact2[sl], f->counters, cc, f->xcd_walk ? 1 : 0, read_only, contiguous, sink)
+    if (nt) { if (G == 1) LAUNCH_RMW(true, 1); else if (G == 2) LAUNCH_RMW(true, 2); else LAUNCH_RMW(true, 4); }
+    else { if (G == 1) LAUNCH_RMW(false, 1); else if (G == 2) LAUNCH_RMW(false, 2); else LAUNCH_RMW(false, 4); }
+#undef LAUNCH_RMW
     SF_HIP_CHECK(hipEventRecord(e1, f->stream));
     SF_HIP_CHECK(hipEventSynchronize(e1));
     float ms = 0;

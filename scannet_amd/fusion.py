@@ -172,6 +172,15 @@ class Fuser:
         check(_abi.lib().sf_fuser_calib_tile_rmw(self._h, 1 if read_only else 0, int(iters), C.byref(us), C.byref(n)))
         return us.value, n.value
 
+    def calib_tile_rmw_ex(self, read_only=False, contiguous=False, tiles_per_turnaround=1, iters=10):
+        """(average microseconds, tiles) of the most recent pass's tile traffic taken apart: scattered list or one contiguous span, G tiles read before G written."""
+        L = _abi.lib()
+        L.sf_fuser_calib_tile_rmw_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+        mode = (1 if read_only else 0) | (2 if contiguous else 0) | ({1: 0, 2: 1, 4: 2}[int(tiles_per_turnaround)] << 2)
+        us, n = C.c_double(0), C.c_uint32(0)
+        check(L.sf_fuser_calib_tile_rmw_ex(self._h, mode, int(iters), C.byref(us), C.byref(n)))
+        return us.value, n.value
+
     def run(self, sensor_data, first=0, last=0, decode_threads=0):
         """Fuse frames [first, last) of a scannet_amd.sens.SensorData (threaded decode overlapped with the GPU)."""
         st = SfRunStats()
