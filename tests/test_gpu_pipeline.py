@@ -728,15 +728,28 @@ def test_shard_main_runs_the_whole_chain(tmp_path, capsys, monkeypatch):
     for p in paths:
         for sfx, blob in first[p].items():
             assert open(os.path.splitext(p)[0] + sfx, "rb").read() == blob, (p, sfx)
-    # and with the quadric collapse on the GPU as well: the same stages, other triangles
+    # --gpu-decimate is the default spelled out (accepted for old command lines): the same files again
     shard.main([str(lst), "--gpu-decimate"])
+    capsys.readouterr()
+    for p in paths:
+        for sfx, blob in first[p].items():
+            assert open(os.path.splitext(p)[0] + sfx, "rb").read() == blob, (p, sfx)
+    # --host-decimate pins the SEQUENTIAL filter (the restatement of MeshLab's greedy collapse, what rounds 1-3 shipped as the default): the cleaned mesh is
+    # the same file, the decimated one has other triangles than the GPU's rounds -- and is exactly what the library's host filters give for the two scripts
+    from scannet_amd import meshclean
+    shard.main([str(lst), "--host-decimate"])
     capsys.readouterr()
     for p in paths:
         base = os.path.splitext(p)[0]
         assert open(base + "_vh_clean.ply", "rb").read() == first[p]["_vh_clean.ply"]
+        host2 = open(base + "_vh_clean_2.ply", "rb").read()
+        assert host2 != first[p]["_vh_clean_2.ply"]
         hi = segmentator.Mesh.read(base + "_vh_clean.ply").counts()[1]
         lo = segmentator.Mesh.read(base + "_vh_clean_2.ply").counts()[1]
         assert 0 < lo < 0.06 * hi
+        m1, st1 = meshclean.simplify(segmentator.Mesh.read(base + "_vh_clean.ply"))          # the sequential filter, twice, as the stage runs simplify.mlx
+        m2, st2 = meshclean.simplify(m1)
+        assert st1["rounds"] == 0 and st2["rounds"] == 0 and abs(m2.counts()[1] - lo) <= max(8, lo // 10)   # cleanLoRes.mlx may drop small components behind it
     with pytest.raises(SystemExit):
         shard.main([str(lst), "--no-such-flag"])
 

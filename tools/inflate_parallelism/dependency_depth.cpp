@@ -7,7 +7,7 @@
 #include <cstring>
 #include <vector>
 #include <algorithm>
-#include "inflate_lanes.h"
+#include "first_study_lanes.h"
 int main(int argc, char** argv) {
   FILE* f = fopen(argv[1], "rb"); fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
   std::vector<uint8_t> src(n); fread(src.data(), 1, n, f); fclose(f);

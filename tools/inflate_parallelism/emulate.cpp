@@ -8,7 +8,7 @@
 
 #include <cstdio>
 
-#include "inflate_lanes.h"
+#include "first_study_lanes.h"
 
 namespace {
 
