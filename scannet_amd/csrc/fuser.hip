@@ -1247,14 +1247,17 @@ __device__ inline void fuse_rows(const ParamsK& P, const float* __restrict__ Ti,
 
 // 4 waves per SIMD (<= 128 VGPRs).  Tried for the one-frame-per-launch case: 5 waves / 96 VGPRs with the tile in two
 // half passes -- the spills cost more than the occupancy buys (183 us vs 112 us per launch).
-template <int SIGN, int COLOR, bool TAB, int WM, bool ROWS>
 #ifndef SF_INT_WAVES
 #define SF_INT_WAVES 5   // workgroups (of 4 waves) per CU the register budget of k_integrate is set for (plain pairs: 91 registers)
 #endif
 #ifndef SF_INT_NJ
 #define SF_INT_NJ 4      // rows of the tile fused together per frame: 4 = the whole tile at once, 2 / 1 = in halves / quarters (fewer live registers)
 #endif
-__global__ __launch_bounds__(256, SF_INT_WAVES) void k_integrate(uint4* __restrict__ voxels, const uint64_t* __restrict__ block_keys,
+// NJ = 2 (the tile in halves: 63 registers, 8 waves per SIMD) is ~15 % faster ALONE and starves the allocation kernel on the other stream when it is not
+// (profiles/r05_integrate_ab.txt): it runs the LAST pass of a sf_fuser_integrate_batch_device call -- nothing is queued behind that pass, no front chain
+// runs beside it -- and every pass of a long stream but that one runs NJ = 4 at 5 waves.  Same voxels either way.
+template <int SIGN, int COLOR, bool TAB, int WM, bool ROWS, int NJ = SF_INT_NJ>
+__global__ __launch_bounds__(256, NJ == 2 ? 8 : SF_INT_WAVES) void k_integrate(uint4* __restrict__ voxels, const uint64_t* __restrict__ block_keys,
                                                    const int32_t* __restrict__ compact, const uint32_t* __restrict__ cmask,
                                                    const float* __restrict__ depthf_all, const uint2* __restrict__ texel_all,
                                                    int32_t* counters, int32_t* host_mirror, int compact_counter, int xcd_walk, ParamsK P,
@@ -1317,11 +1320,11 @@ __global__ __launch_bounds__(256, SF_INT_WAVES) void k_integrate(uint4* __restri
       const float* __restrict__ depthf = depthf_all + (size_t)q * npx;
       const uint2* __restrict__ texel = texel_all + (size_t)q * npx;
 #pragma unroll
-      for (int j0 = 0; j0 < 4; j0 += SF_INT_NJ) {
-        if (j0 == 0) fuse_rows<SIGN, COLOR, TAB, WM, 0, SF_INT_NJ, ROWS>(P, Ti, depthf, texel, s_rtab, wx, wy, wz, v, dirty);
-        if (j0 == 1) fuse_rows<SIGN, COLOR, TAB, WM, 1 % (5 - SF_INT_NJ), SF_INT_NJ, ROWS>(P, Ti, depthf, texel, s_rtab, wx, wy, wz, v, dirty);
-        if (j0 == 2) fuse_rows<SIGN, COLOR, TAB, WM, 2 % (5 - SF_INT_NJ), SF_INT_NJ, ROWS>(P, Ti, depthf, texel, s_rtab, wx, wy, wz, v, dirty);
-        if (j0 == 3) fuse_rows<SIGN, COLOR, TAB, WM, 3 % (5 - SF_INT_NJ), SF_INT_NJ, ROWS>(P, Ti, depthf, texel, s_rtab, wx, wy, wz, v, dirty);
+      for (int j0 = 0; j0 < 4; j0 += NJ) {
+        if (j0 == 0) fuse_rows<SIGN, COLOR, TAB, WM, 0, NJ, ROWS>(P, Ti, depthf, texel, s_rtab, wx, wy, wz, v, dirty);
+        if (j0 == 1) fuse_rows<SIGN, COLOR, TAB, WM, 1 % (5 - NJ), NJ, ROWS>(P, Ti, depthf, texel, s_rtab, wx, wy, wz, v, dirty);
+        if (j0 == 2) fuse_rows<SIGN, COLOR, TAB, WM, 2 % (5 - NJ), NJ, ROWS>(P, Ti, depthf, texel, s_rtab, wx, wy, wz, v, dirty);
+        if (j0 == 3) fuse_rows<SIGN, COLOR, TAB, WM, 3 % (5 - NJ), NJ, ROWS>(P, Ti, depthf, texel, s_rtab, wx, wy, wz, v, dirty);
       }
     }
     if (ROWS) {
@@ -1974,9 +1977,13 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
 #undef LAUNCH_PIPE
   } else if (sign > 0) {
     if (ws1 && f->pk.wmax == 255) {   // the shipped setting
-      if (col && !f->p.colour_first) LAUNCH_INT(1, 2, true, 2);
+      const bool wide = f->tail_pass && f->tail_wide && n > 1;   // the last pass of a batch call: no front chain beside it, the 8-wave variant (k_integrate)
+#define LAUNCH_INT_WIDE(CL) hipLaunchKernelGGL((k_integrate<1, CL, true, 2, false, 2>), dim3(grid), dim3(256), 0, s, f->voxels, f->block_keys, f->compact2[sl], f->cmask2[sl], \
+                                               f->depthf2[sl], f->color2[sl], f->counters, f->host_mirror, cc, f->xcd_walk ? 1 : 0, f->pk, bt)
+      if (col && !f->p.colour_first) { if (wide) LAUNCH_INT_WIDE(2); else LAUNCH_INT(1, 2, true, 2); }
       else if (col) LAUNCH_INT(1, 1, true, 2);
-      else LAUNCH_INT(1, 0, true, 2);
+      else { if (wide) LAUNCH_INT_WIDE(0); else LAUNCH_INT(1, 0, true, 2); }
+#undef LAUNCH_INT_WIDE
     }
     else if (ws1) { if (col) LAUNCH_INT(1, 1, true, 1); else LAUNCH_INT(1, 0, true, 1); }
     else if (tab)                { if (col) LAUNCH_INT(1, 1, true, 0); else LAUNCH_INT(1, 0, true, 0); }
@@ -2294,7 +2301,9 @@ static int integrate_batch_device(sf_fuser* f, const void* d_depth, uint64_t fra
       else if (f->ramp_geo && pass < 6) want = std::min(f->batch, f->ramp << pass);
     }
     if (m == want || (i == n && m > 0)) {
+      f->tail_pass = i == n;   // nothing of this call follows: its integrate launch has the chip to itself
       const int rc = run_batch(f, dd, d_rgb ? dr : nullptr, pp, m, +1);
+      f->tail_pass = false;
       if (rc != SF_OK) return rc;
       m = 0;
       pass++;
@@ -2384,6 +2393,7 @@ SF_API int sf_fuser_tune(sf_fuser* f, const char* key, int value) {
   else if (k == "alloc_ray" && in(0, 1)) f->alloc_ray = value != 0;   // 1: the ray-space window whatever the geometry (rays outside it take the slow path), 0: the cube window
   else if (k == "ramp" && in(0, MAX_BATCH)) f->ramp = value;
   else if (k == "ramp_geo" && in(0, 1)) f->ramp_geo = value != 0;
+  else if (k == "tail_wide" && in(0, 1)) f->tail_wide = value;
   else return sf::fail(SF_ERR_INVALID_ARG, "sf_fuser_tune: unknown key or value out of range: %s = %d", key, value);
   return SF_OK;
 }

@@ -218,6 +218,8 @@ struct sf_fuser {
   bool serial_tail = false;  // the most recent batches ran on `stream` alone (front has not been ordered behind them yet)
   bool overlap = true;  // sf_fuser_tune("overlap", 0) runs everything on one stream
   float* depthf2[2] = {nullptr, nullptr};      // MAX_BATCH x W*H per batch slot
+  bool tail_pass = false;   // set around the last run_batch of a sf_fuser_integrate_batch_device call
+  int tail_wide = 1;        // tune "tail_wide": that pass runs the 8-waves-per-SIMD variant of k_integrate
   uint2* color2[2] = {nullptr, nullptr};       // MAX_BATCH x W*H {depth bits, rgb} texels per batch slot (RGB-D batches)
   int32_t* compact2[2] = {nullptr, nullptr};   // heap slots of the blocks some frame of the batch sees
   uint32_t* cmask2[2] = {nullptr, nullptr};    // per compact entry: bit j = frame j of the batch updates this block

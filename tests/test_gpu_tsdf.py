@@ -70,10 +70,12 @@ def test_room_stream_bit_exact(oracle):
         _assert_same(ovol, f)
 
 
-def test_batched_pass_equals_frame_by_frame(oracle):
+@pytest.mark.parametrize("tail_wide", [1, 0])
+def test_batched_pass_equals_frame_by_frame(oracle, tail_wide):
     """Temporal blocking: sf_fuser_integrate_batch_device fuses up to 32 frames per pass over the tiles.  The result must
     be the frame-by-frame result bit for bit: blocks born in the middle of a batch (large pose jumps) only receive the
-    frames from their birth on, skipped poses leave gaps, the final batch is partial."""
+    frames from their birth on, skipped poses leave gaps, the final batch is partial.  The call's LAST pass runs the variant of k_integrate
+    that fuses the tile in halves at 8 waves per SIMD (tail_wide 1, the default) or the same kernel as every other pass (0): the same voxels."""
     from scannet_amd import fusion
     W, H = 320, 240
     op, gp = _mk(oracle, W, H, voxel=0.008, num_sdf_blocks=1 << 17)
@@ -98,7 +100,7 @@ def test_batched_pass_equals_frame_by_frame(oracle):
     _abi.check(L.sf_device_malloc(0, depth.nbytes, C.byref(dptr)))
     try:
         _abi.check(L.sf_device_upload(dptr, depth.ctypes.data_as(C.c_void_p), depth.nbytes))
-        with fusion.Fuser(gp) as f:
+        with fusion.Fuser(gp, tail_wide=tail_wide) as f:
             assert f.batch_frames == 32
             f.integrate_batch_device(dptr.value, W * H * 2, poses)
             st = f.stats()
