@@ -1253,9 +1253,11 @@ __device__ inline void fuse_rows(const ParamsK& P, const float* __restrict__ Ti,
 #ifndef SF_INT_NJ
 #define SF_INT_NJ 4      // rows of the tile fused together per frame: 4 = the whole tile at once, 2 / 1 = in halves / quarters (fewer live registers)
 #endif
-// NJ = 2 (the tile in halves: 63 registers, 8 waves per SIMD) is ~15 % faster ALONE and starves the allocation kernel on the other stream when it is not
-// (profiles/r05_integrate_ab.txt): it runs the LAST pass of a sf_fuser_integrate_batch_device call -- nothing is queued behind that pass, no front chain
-// runs beside it -- and every pass of a long stream but that one runs NJ = 4 at 5 waves.  Same voxels either way.
+// NJ = 2 (the tile in halves: 63 registers, 8 waves per SIMD) looks 15 % faster in the two-stream schedule (696 against 814 us per launch) only because its
+// waves take every register of the SIMDs and the allocation kernel on the other stream starves (372 -> 818 us): the pass as a whole is slower
+// (profiles/r05_integrate_ab.txt).  Alone the two variants are within a few per cent.  NJ = 2 runs the LAST pass of a sf_fuser_integrate_batch_device call
+// -- nothing is queued behind that pass, no front chain runs beside it: +0.8 % on a 20-frame call, measured --, every other pass NJ = 4 at 5 waves.  Same
+// voxels either way (tests/test_gpu_tsdf.py::test_batched_pass_equals_frame_by_frame runs both).
 template <int SIGN, int COLOR, bool TAB, int WM, bool ROWS, int NJ = SF_INT_NJ>
 __global__ __launch_bounds__(256, NJ == 2 ? 8 : SF_INT_WAVES) void k_integrate(uint4* __restrict__ voxels, const uint64_t* __restrict__ block_keys,
                                                    const int32_t* __restrict__ compact, const uint32_t* __restrict__ cmask,
