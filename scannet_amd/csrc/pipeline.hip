@@ -66,13 +66,25 @@ struct RunResources {
   hipStream_t copy[2] = {nullptr, nullptr}, inflate[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   uint8_t* h_pool = nullptr;
   size_t h_bytes = 0;
+  std::thread prep;   // sf_run_resources_prepare: fills inflate[0..2] and h_pool in the background; joined by whoever takes the set first
 };
 std::mutex g_res_mu;
 std::vector<RunResources*> g_res;   // never freed: the streams and the pool die with the process
+struct JoinAtExit {
+  ~JoinAtExit() {
+    std::lock_guard<std::mutex> lk(g_res_mu);
+    for (RunResources* r : g_res)
+      if (r->prep.joinable()) r->prep.join();
+  }
+} g_join_at_exit;
 RunResources* acquire_resources(int device) {
   std::lock_guard<std::mutex> lk(g_res_mu);
   for (RunResources* r : g_res)
-    if (r->device == device && !r->taken) { r->taken = true; return r; }
+    if (r->device == device && !r->taken) {
+      if (r->prep.joinable()) r->prep.join();   // the preparation thread never takes g_res_mu
+      r->taken = true;
+      return r;
+    }
   for (RunResources* r : g_res)
     if (r->device == device) return nullptr;   // taken: the caller works with resources of its own
   RunResources* r = new RunResources;
@@ -86,6 +98,35 @@ void release_resources(RunResources* r) {
   std::lock_guard<std::mutex> lk(g_res_mu);
   r->taken = false;
 }
+
+}  // namespace
+
+// fuser_internal.h: called by sf_fuser_create.  The first sf_fuse_run of a process used to spend 23 ms (depth only) creating its three side streams -- the
+// runtime builds a hardware queue per stream, ~5 ms each -- and page-locking its ring before the first frame moved: 13 % of a 5 578-frame scan that is fused in
+// 0.18 s, and one process per scan is the pipeline's contract (Server/scan_processor.py:138).  Now the FIRST fuser a process creates on a device starts that
+// work on a thread of its own, beside its own allocations (4.3 GB of tiles to reserve and clear) and the caller's sf_sens_open; sf_fuse_run joins it.
+// pinned_bytes = a guess of the ring's size (a run that needs more re-allocates, as before).
+void sf_run_resources_prepare(int device, size_t pinned_bytes) {
+  std::lock_guard<std::mutex> lk(g_res_mu);
+  for (RunResources* r : g_res)
+    if (r->device == device) return;   // prepared, being prepared or in use
+  RunResources* r = new RunResources;
+  r->device = device;
+  g_res.push_back(r);
+  try {
+    r->prep = std::thread([r, device, pinned_bytes]() {
+      if (hipSetDevice(device) != hipSuccess) return;
+      for (int q = 0; q < 3; q++)
+        if (hipStreamCreateWithFlags(&r->inflate[q], hipStreamNonBlocking) != hipSuccess) { r->inflate[q] = nullptr; break; }
+      if (pinned_bytes != 0 && hipHostMalloc((void**)&r->h_pool, pinned_bytes, hipHostMallocDefault) == hipSuccess) r->h_bytes = pinned_bytes;
+      else r->h_pool = nullptr;
+    });
+  } catch (...) {
+    // no thread: the first run sets everything up itself, as before
+  }
+}
+
+namespace {
 
 // One ring slot = one batch of B frames: contiguous pinned host buffers, contiguous device buffers, two events.
 struct BatchSlot {
