@@ -46,7 +46,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 # before anything initialises HIP (torch.cuda does, long before libscanfuse.so is loaded): sf_fuse_run drives seven streams, the runtime's
 # default of four hardware queues puts some of them in one queue (scannet_amd/__init__.py)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 TOTAL_FRAMES = 5578
 W, H = 640, 480

@@ -37,7 +37,7 @@ int jpeg_gpu_reconstruct(hipStream_t stream, int n, const uint8_t* const* d_payl
 // The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and kernels of streams that share a queue
 // run one after the other.  sf_fuse_run drives up to seven streams (the fuser's two, two for colour copies, three for the inflate kernels); on four
 // queues every third batch's inflate sat in the integrate pass's queue (29 k -> 20 k frames/s in the loop).  The variable belongs to the PROCESS
-// (it is read at its first HIP call): the library does not touch the environment -- the bin/ tools and bench.py export GPU_MAX_HW_QUEUES=12 in
+// (it is read at its first HIP call): the library does not touch the environment -- the bin/ tools and bench.py export GPU_MAX_HW_QUEUES=16 in
 // their own main() before the first HIP call, and a run that finds fewer queues than it has streams says so through
 // sf_last_error() while returning SF_OK (sf_fuse_run_note).
 
@@ -120,6 +120,17 @@ void sf_run_resources_prepare(int device, size_t pinned_bytes) {
         if (hipStreamCreateWithFlags(&r->inflate[q], hipStreamNonBlocking) != hipSuccess) { r->inflate[q] = nullptr; break; }
       if (pinned_bytes != 0 && hipHostMalloc((void**)&r->h_pool, pinned_bytes, hipHostMallocDefault) == hipSuccess) r->h_bytes = pinned_bytes;
       else r->h_pool = nullptr;
+      // the first DMA out of freshly page-locked memory pays for mapping it (measured: the first run's hipMemcpyAsync calls blocked 0.4 ms each, 37-48 ms
+      // of a run): one pass of copies over the pool here, on this thread, pays it before the run
+      if (r->h_pool) {
+        void* d_scratch = nullptr;
+        const size_t chunk = (size_t)16 << 20;
+        if (hipMalloc(&d_scratch, chunk) == hipSuccess) {
+          for (size_t at = 0; at < r->h_bytes; at += chunk)
+            if (hipMemcpy(d_scratch, r->h_pool + at, std::min(chunk, r->h_bytes - at), hipMemcpyHostToDevice) != hipSuccess) break;
+          (void)hipFree(d_scratch);
+        }
+      }
     });
   } catch (...) {
     // no thread: the first run sets everything up itself, as before
@@ -722,7 +733,7 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
     const int streams_used = 2 + (copy_stream ? 2 : 0) + (gpu_inflate ? NZ : 0), queues = hardware_queues_of_the_process();
     if (streams_used > queues)
       (void)sf::fail(SF_OK, "note: sf_fuse_run drove %d streams over %d hardware queues (kernels of streams that share a queue run one after the other); "
-                             "export GPU_MAX_HW_QUEUES=12 before the process's first HIP call", streams_used, queues);
+                             "export GPU_MAX_HW_QUEUES=16 before the process's first HIP call", streams_used, queues);
   }
   if (stats) {
     stats->frames_total = total;

@@ -32,7 +32,7 @@ std::string trim(std::string s) {
 }  // namespace
 
 int main(int argc, const char** argv) {
-  (void)setenv("GPU_MAX_HW_QUEUES", "12", 0);   // this process's streams on hardware queues of their own (the application's decision; an exported value wins)
+  (void)setenv("GPU_MAX_HW_QUEUES", "16", 0);   // this process's streams on hardware queues of their own (the application's decision; an exported value wins)
   if (argc != 5) {
     std::fprintf(stderr, "requires the input sens filepath, output sens filepath, parameter file, and input undistortion table as a command line arguments\n");
     return 1;

@@ -20,7 +20,7 @@ static int die(const char* what) {
 int main(int argc, const char** argv_in) {
   // This PROCESS drives sf_fuse_run's seven streams: ask the HIP runtime for a hardware queue each before its first call (default 4: kernels of
   // streams that share a queue run one after the other).  The application's decision, not the library's; a value the user exported wins.
-  (void)setenv("GPU_MAX_HW_QUEUES", "12", 0);
+  (void)setenv("GPU_MAX_HW_QUEUES", "16", 0);
   // --upstream[=voxelhashing|bundlefusion]: the upstream-conformance preset (scanfuse.h sf_params_upstream_preset; default: SURVEY App. C).  Not an
   // argument of the tool this replaces -- the pipeline's command line (scan_processor.py:138) stays valid -- and it may stand anywhere.
   const char* argv[8];

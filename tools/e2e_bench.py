@@ -12,7 +12,7 @@ import os
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")   # this process's streams on hardware queues of their own: the application's to export
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # this process's streams on hardware queues of their own: the application's to export
 
 import numpy as np
 
