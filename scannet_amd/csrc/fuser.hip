@@ -2050,7 +2050,10 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
   SF_HIP_CHECK(hipSetDevice(device));
   // the first fuser of the process on this device: sf_fuse_run's side streams and a pinned ring for six batches of compressed depth frames (3/4 of
   // their pixels' bytes) get made on a thread of their own while this function reserves and clears the volume (pipeline.hip)
-  sf_run_resources_prepare(device, (size_t)6 * MAX_BATCH * ((size_t)p->depth_width * p->depth_height * 2 * 3 / 4 + 4096));
+  {
+    const size_t frame_b = (size_t)p->depth_width * p->depth_height * 2, packed = MAX_BATCH * (frame_b * 3 / 4 + 4096);   // a batch of compressed frames
+    sf_run_resources_prepare(device, 6 * packed, 6 * (MAX_BATCH * frame_b + packed + 1024), 2 * frame_b * MAX_BATCH);
+  }
   sf_fuser* f = new sf_fuser();
   // every failure below leaves through sf_fuser_destroy (streams, events, device and pinned allocations made so far)
 #define SF_CREATE_CHECK(call)                                                                               \

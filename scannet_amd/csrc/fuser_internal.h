@@ -277,7 +277,7 @@ struct sf_fuser {
 
 
 hipError_t sf_quiesce(sf_fuser* f);                 // drain both streams
-void sf_run_resources_prepare(int device, size_t pinned_bytes);   // pipeline.hip: the side streams and the pinned ring of sf_fuse_run, created in the background
+void sf_run_resources_prepare(int device, size_t pinned_bytes, size_t device_bytes, size_t plan_bytes);   // pipeline.hip: the side streams and the pinned ring of sf_fuse_run, created in the background
 bool sf_single_stream_batch(const sf_fuser* f, int n, bool color, int sign);   // run_batch keeps this batch on f->stream alone
 hipStream_t sf_input_stream(const sf_fuser* f, int n, bool color, int sign);   // where the batch's frames must be staged
 int sf_compact_live(sf_fuser* f, int32_t* n_out, int include_ghosts = 1);   // live heap slots -> f->compact, synchronous

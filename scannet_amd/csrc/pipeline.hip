@@ -66,6 +66,10 @@ struct RunResources {
   hipStream_t copy[2] = {nullptr, nullptr}, inflate[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   uint8_t* h_pool = nullptr;
   size_t h_bytes = 0;
+  uint8_t* d_pool = nullptr;   // the ring's device side and the inflate kernels' scratch: kept too -- the first DMA into freshly allocated device memory blocked
+  size_t d_bytes = 0;          // the enqueueing thread 0.4 ms per call (36 ms of a first run's loop)
+  uint8_t* d_plan[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t plan_bytes = 0;
   std::thread prep;   // sf_run_resources_prepare: fills inflate[0..2] and h_pool in the background; joined by whoever takes the set first
 };
 std::mutex g_res_mu;
@@ -106,7 +110,7 @@ void release_resources(RunResources* r) {
 // 0.18 s, and one process per scan is the pipeline's contract (Server/scan_processor.py:138).  Now the FIRST fuser a process creates on a device starts that
 // work on a thread of its own, beside its own allocations (4.3 GB of tiles to reserve and clear) and the caller's sf_sens_open; sf_fuse_run joins it.
 // pinned_bytes = a guess of the ring's size (a run that needs more re-allocates, as before).
-void sf_run_resources_prepare(int device, size_t pinned_bytes) {
+void sf_run_resources_prepare(int device, size_t pinned_bytes, size_t device_bytes, size_t plan_bytes) {
   std::lock_guard<std::mutex> lk(g_res_mu);
   for (RunResources* r : g_res)
     if (r->device == device) return;   // prepared, being prepared or in use
@@ -114,7 +118,7 @@ void sf_run_resources_prepare(int device, size_t pinned_bytes) {
   r->device = device;
   g_res.push_back(r);
   try {
-    r->prep = std::thread([r, device, pinned_bytes]() {
+    r->prep = std::thread([r, device, pinned_bytes, device_bytes, plan_bytes]() {
       if (hipSetDevice(device) != hipSuccess) return;
       for (int q = 0; q < 3; q++)
         if (hipStreamCreateWithFlags(&r->inflate[q], hipStreamNonBlocking) != hipSuccess) { r->inflate[q] = nullptr; break; }
@@ -122,14 +126,16 @@ void sf_run_resources_prepare(int device, size_t pinned_bytes) {
       else r->h_pool = nullptr;
       // the first DMA out of freshly page-locked memory pays for mapping it (measured: the first run's hipMemcpyAsync calls blocked 0.4 ms each, 37-48 ms
       // of a run): one pass of copies over the pool here, on this thread, pays it before the run
-      if (r->h_pool) {
-        void* d_scratch = nullptr;
-        const size_t chunk = (size_t)16 << 20;
-        if (hipMalloc(&d_scratch, chunk) == hipSuccess) {
-          for (size_t at = 0; at < r->h_bytes; at += chunk)
-            if (hipMemcpy(d_scratch, r->h_pool + at, std::min(chunk, r->h_bytes - at), hipMemcpyHostToDevice) != hipSuccess) break;
-          (void)hipFree(d_scratch);
-        }
+      if (device_bytes != 0 && hipMalloc((void**)&r->d_pool, device_bytes) == hipSuccess) r->d_bytes = device_bytes;
+      else r->d_pool = nullptr;
+      if (r->h_pool && r->d_pool)   // one pass of copies over both pools: whatever the first transfer out of / into fresh memory pays is paid here
+        for (size_t at = 0; at < r->h_bytes; at += r->d_bytes)
+          if (hipMemcpy(r->d_pool, r->h_pool + at, std::min(r->d_bytes, r->h_bytes - at), hipMemcpyHostToDevice) != hipSuccess) break;
+      if (r->d_pool) (void)hipMemset(r->d_pool, 0, r->d_bytes);
+      for (int q = 0; q < 3 && plan_bytes != 0; q++) {
+        if (hipMalloc((void**)&r->d_plan[q], plan_bytes) != hipSuccess) { r->d_plan[q] = nullptr; break; }
+        (void)hipMemset(r->d_plan[q], 0, plan_bytes);
+        r->plan_bytes = plan_bytes;
       }
     });
   } catch (...) {
@@ -311,9 +317,9 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
       for (hipEvent_t ev : sl.consumed) if (ev) (void)hipEventDestroy(ev);
     }
     if (h_pool && !(res && res->h_pool == h_pool)) (void)hipHostFree(h_pool);
-    if (d_pool) (void)hipFree(d_pool);
+    if (d_pool && !(res && res->d_pool == d_pool)) (void)hipFree(d_pool);
     if (d_jstatus) (void)hipFree(d_jstatus);
-    for (uint8_t* q : d_plan) if (q) (void)hipFree(q);
+    for (int q = 0; q < MAX_NZ; q++) if (d_plan[q] && !(res && res->d_plan[q] == d_plan[q])) (void)hipFree(d_plan[q]);
     if (d_zstatus) (void)hipFree(d_zstatus);
     if (!res) for (hipStream_t q : inflate_stream) if (q) (void)hipStreamDestroy(q);
     if (!res && copy_stream) (void)hipStreamDestroy(copy_stream);
@@ -346,9 +352,24 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
       e_ = hipHostMalloc((void**)&h_pool, h_need, hipHostMallocDefault);
       if (e_ == hipSuccess && res) { res->h_pool = h_pool; res->h_bytes = h_need; }
     }
-    if (e_ == hipSuccess) e_ = hipMalloc((void**)&d_pool, (size_t)NB * dslot_b);
+    const size_t d_need = (size_t)NB * dslot_b, plan_need = 2 * depth_b * (size_t)B;
+    if (e_ == hipSuccess && res && res->d_bytes >= d_need) {
+      d_pool = res->d_pool;
+    } else if (e_ == hipSuccess) {
+      if (res && res->d_pool) { (void)hipFree(res->d_pool); res->d_pool = nullptr; res->d_bytes = 0; }
+      e_ = hipMalloc((void**)&d_pool, d_need);
+      if (e_ == hipSuccess && res) { res->d_pool = d_pool; res->d_bytes = d_need; }
+    }
     if (gpu_inflate) {
-      for (int q = 0; q < NZ && e_ == hipSuccess; q++) e_ = hipMalloc((void**)&d_plan[q], 2 * depth_b * (size_t)B);
+      if (res && res->plan_bytes < plan_need) {   // scratch of another frame size: start over
+        for (uint8_t*& q : res->d_plan) { if (q) (void)hipFree(q); q = nullptr; }
+        res->plan_bytes = plan_need;
+      }
+      for (int q = 0; q < NZ && e_ == hipSuccess; q++) {
+        if (res && res->d_plan[q]) { d_plan[q] = res->d_plan[q]; continue; }
+        e_ = hipMalloc((void**)&d_plan[q], plan_need);
+        if (e_ == hipSuccess && res) res->d_plan[q] = d_plan[q];
+      }
       if (e_ == hipSuccess) e_ = hipMalloc((void**)&d_zstatus, (size_t)NB * B * 8);
       if (e_ == hipSuccess) e_ = hipMemset(d_zstatus, 0, (size_t)NB * B * 8);
     }
