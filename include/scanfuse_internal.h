@@ -25,6 +25,7 @@ extern "C" {
  *   "nt"          -1/0/1 that kernel's tile loads and stores non-temporal: -1 = when the previous pass touched more than 512 MiB of tiles (default)
  *   "front_cus"   0..128 the second stream owns that many CUs (spread over the chip), the main stream the rest (hipExtStreamCreateWithCUMask); 0 = shared
  *   "alloc_group" 1..32  consecutive frames one allocation workgroup walks (default 16: half of a 32-frame pass)
+ *   "alloc_group_head" 0..32 the same for the FIRST pass of a multi-pass batch call, whose front chain nothing hides (default 4; 0 = like every pass)
  *   "alloc_ray"   0/1    the allocation kernel's occupancy bitmap in ray space (k_alloc_ray; default: whenever the voxel size lets the window hold a
  *                        pixel tile's rays: >= 2.5 mm voxels with the shipped camera) or as a 32^3-block cube anchored at the first ray (k_alloc)
  *   "prepass_fuse" 0/1   one colourless frame per pass: the allocation kernel converts the depth itself (default 1), no separate pre-pass launch

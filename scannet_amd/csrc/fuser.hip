@@ -1907,7 +1907,11 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
                        f->p.depth_min, f->p.depth_max, f->counters, cc, f->pk, f->ray_kx, f->ray_ky);
   if (sign > 0) {
     // WIN 64 (32 KiB bitmap) has no room for the second bitmap: one frame per workgroup there
-    const int gf = (f->alloc_win64 && !f->alloc_ray) ? 1 : std::min(f->alloc_group, n);
+    // frames one allocation workgroup walks.  The FIRST pass of a batch call has nothing to run beside: its front chain is pure latency in front of the first
+    // integrate launch (a 20-frame call: k_alloc_ray 133 us of a 650 us region at 8 frames per workgroup), so it is cut into more, shorter workgroups
+    // (tune "alloc_group_head"); every other pass hides its allocation behind the previous integrate launch and takes the cheaper, longer ones
+    const int group = (f->head_pass && f->alloc_group_head > 0) ? std::min(f->alloc_group, f->alloc_group_head) : f->alloc_group;
+    const int gf = (f->alloc_win64 && !f->alloc_ray) ? 1 : std::min(group, n);
     const dim3 ag((f->p.depth_width + 15) / 16, (f->p.depth_height + 15) / 16, (n + gf - 1) / gf);
 #define LAUNCH_ALLOC(WL, MU) \
   hipLaunchKernelGGL((k_alloc<WL, MU>), ag, dim3(256), 0, sa, f->depthf2[sl], f->table, f->heap, f->block_keys, f->block_entry, f->block_flags, f->counters, f->pk, bf, gf)
@@ -2310,8 +2314,10 @@ static int integrate_batch_device(sf_fuser* f, const void* d_depth, uint64_t fra
     }
     if (m == want || (i == n && m > 0)) {
       f->tail_pass = i == n;   // nothing of this call follows: its integrate launch has the chip to itself
+      f->head_pass = pass == 0 && n > (uint64_t)m;   // nothing of this call runs beside its front chain (a one-pass call: neither head nor hidden)
       const int rc = run_batch(f, dd, d_rgb ? dr : nullptr, pp, m, +1);
       f->tail_pass = false;
+      f->head_pass = false;
       if (rc != SF_OK) return rc;
       m = 0;
       pass++;
@@ -2380,6 +2386,7 @@ SF_API int sf_fuser_tune(sf_fuser* f, const char* key, int value) {
     f->front_cus = value;
   }
   else if (k == "alloc_group" && in(1, MAX_BATCH)) f->alloc_group = value;
+  else if (k == "alloc_group_head" && in(0, MAX_BATCH)) f->alloc_group_head = value;
   else if (k == "alloc_wgs" && in(0, 8)) f->alloc_wgs = value;
   else if (k == "prepass_fuse" && in(0, 1)) f->prepass_fuse = value != 0;
 #ifdef SF_MEASURE_ABLATE

@@ -218,6 +218,8 @@ struct sf_fuser {
   bool serial_tail = false;  // the most recent batches ran on `stream` alone (front has not been ordered behind them yet)
   bool overlap = true;  // sf_fuser_tune("overlap", 0) runs everything on one stream
   float* depthf2[2] = {nullptr, nullptr};      // MAX_BATCH x W*H per batch slot
+  bool head_pass = false;   // set around the first run_batch of a multi-pass sf_fuser_integrate_batch_device call
+  int alloc_group_head = 4; // tune "alloc_group_head": frames per allocation workgroup in that pass (0 = as every pass).  A 20-frame call: 30.8 k -> 31.8 k frames/s
   bool tail_pass = false;   // set around the last run_batch of a sf_fuser_integrate_batch_device call
   int tail_wide = 1;        // tune "tail_wide": that pass runs the 8-waves-per-SIMD variant of k_integrate
   uint2* color2[2] = {nullptr, nullptr};       // MAX_BATCH x W*H {depth bits, rgb} texels per batch slot (RGB-D batches)
