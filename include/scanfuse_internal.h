@@ -31,7 +31,8 @@ extern "C" {
  *   "prepass_fuse" 0/1   one colourless frame per pass: the allocation kernel converts the depth itself (default 1), no separate pre-pass launch
  *   "ramp"        0..32  frames of the FIRST pass of a sf_fuser_integrate_batch_device call (default 8; 0 = a full pass): nothing overlaps that
  *                        pass's pre-pass / allocation, so a short one starts the pipeline sooner
- *   "ramp_geo"    0/1    the passes behind the first one double (ramp, 2 ramp, 4 ramp, ... batch) instead of jumping to the batch size (default 1)
+ *   "ramp_geo"    0/1    the passes behind the first one double (ramp, 2 ramp, 4 ramp, ... batch) instead of jumping to the batch size, and a call of more than
+ *                        `ramp` but no more than `batch` frames is fused as two halves (default 1)
  *   "tail_wide"   0/1    the LAST pass of a sf_fuser_integrate_batch_device call (no front chain runs beside it) takes the variant of k_integrate that fuses
  *                        the tile in halves at 8 waves per SIMD (default 1: +0.8 % on a 20-frame call; slower for a pass as a whole when allocation runs beside it)
  * Synchronises the fuser.  SF_ERR_INVALID_ARG for an unknown key or a value out of range. */

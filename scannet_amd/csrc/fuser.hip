@@ -2307,9 +2307,12 @@ static int integrate_batch_device(sf_fuser* f, const void* d_depth, uint64_t fra
     // the first pass of a call has nothing to hide its pre-pass / allocation / compaction behind: a short one (f->ramp frames) gets the
     // integrate stream busy sooner, and (ramp_geo) the passes behind it double -- ramp, 2 ramp, 4 ramp ... up to the batch size -- so that the
     // front chain of pass k + 1 still fits under the integrate launch of pass k (same voxels under any batching)
+    // A call that would fit ONE pass (ramp < n <= batch) is fused as two halves: the second half's front chain hides behind the first half's integrate launch
+    // (20 frames: 8 + 12 gives 31.4 k frames/s, 10 + 10 32.5 k, 6 + 12 + 2 29.6 k, 12 + 8 31.2 k).
     int want = f->batch;
     if (f->ramp > 0 && f->ramp < f->batch && n > (uint64_t)f->ramp) {
-      if (pass == 0) want = f->ramp;
+      if (n <= (uint64_t)f->batch && f->ramp_geo) want = (int)((n + 1) / 2);
+      else if (pass == 0) want = f->ramp;
       else if (f->ramp_geo && pass < 6) want = std::min(f->batch, f->ramp << pass);
     }
     if (m == want || (i == n && m > 0)) {
