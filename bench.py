@@ -276,7 +276,7 @@ _COST_MODEL = {}
 def valu_cost_model(depth_only):
     """tools/valu_cost_model.py on the library this process loaded: the frame loop of the timed integrate kernel priced with the per-class issue costs
     tools/gpu/valu_peak.hip measured on the MI355X (profiles/r05_valu_issue_table.txt).  None when the disassembler is not there."""
-    key = "k_integrateILi1ELi%dELb1ELi2ELb0" % (0 if depth_only else 2)
+    key = "k_integrateILi1ELi%dELb1ELi2ELb0ELi4E" % (0 if depth_only else 2)   # <SIGN 1, COLOR, TAB, WM 2, ROWS false, NJ 4>: the variant every pass but a call's last runs
     if key not in _COST_MODEL:
         try:
             import importlib.util

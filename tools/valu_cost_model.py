@@ -109,7 +109,7 @@ def main():
     text = disassemble(a.so)
     out = {"costs_cycles_per_wave_instruction_and_simd": {"fast": C_FAST, "slow": C_SLOW, "trans": C_TRANS}, "source": "tools/gpu/valu_peak.hip on MI355X: profiles/r05_valu_issue_table.txt",
            "kernels": {}}
-    for pat in (a.kernel or ["k_integrateILi1ELi2ELb1ELi2ELb0", "k_integrateILi1ELi0ELb1ELi2ELb0"]):
+    for pat in (a.kernel or ["k_integrateILi1ELi2ELb1ELi2ELb0ELi4E", "k_integrateILi1ELi0ELb1ELi2ELb0ELi4E"]):
         name, lines = kernel_body(text, pat)
         out["kernels"][pat] = {"whole_kernel": price(lines), "frame_loop": price(frame_loop(lines))}
     print(json.dumps(out, indent=1))
