@@ -969,8 +969,9 @@ constexpr int RTAB = 512;  // LDS table of correctly rounded 1/m, m = weight + w
 // v_mov_b32 ... issue every ~2.2 cycles per SIMD when all their sources are vector registers or inline constants and every ~4.3 cycles as soon as one
 // source is a scalar register (tools/gpu/valu_peak.hip, profiles/r05_valu_issue_table.txt), and the compiler feeds the per-frame matrix and the camera
 // constants to every fma straight from the scalar registers they were loaded into.  Copying them into vector registers once per frame (18 v_mov, opaque
-// to the compiler) made the pass SLOWER (packed 830 -> 870 us, plain pairs 808 -> 837 us: profiles/r05_integrate_ab.txt): at 4-5 waves per SIMD the kernel
-// is bound by how often a wave gets to issue at all (one instruction per ~6 cycles and wave), not by what an instruction costs the pipe.
+// to the compiler) made the pass SLOWER (packed 830 -> 870 us, plain pairs 808 -> 837 us: profiles/r05_integrate_ab.txt).  The launch already runs at the
+// no-overlap price of its instruction mix (frac 1.03); why 88 fp32 instructions fewer in the 4.3-cycle class do not show up in it is not
+// understood -- the 18 extra moves per frame and what they do to the schedule cost more than the cheaper fma's gave back.
 __device__ inline float vreg(float x) {
 #ifdef SF_VREG_CONSTANTS
   float r;
