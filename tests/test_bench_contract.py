@@ -40,3 +40,24 @@ def test_repeats_rule_is_a_function_of_the_arguments_alone():
     spec.loader.exec_module(b)
     assert b.repeats_for(20) == 1667 and b.repeats_for(5514) == 7 and b.repeats_for(10 ** 7) == 3 and b.repeats_for(1) == 2000
     assert b.repeats_for(192, "1mm") == 6 and b.repeats_for(20, "1mm") == 50
+
+
+def test_valu_cost_model_prices_the_shipped_kernels():
+    """roofline.frac of the batched integrate kernel = SQ_INSTS_VALU x the mean issue cost of the kernel's frame loop / SIMD cycles; the cost comes from
+    tools/valu_cost_model.py: the shipped library disassembled, the frame loop of the timed kernel priced by instruction class (issue costs measured on
+    the MI355X: profiles/r05_valu_issue_table.txt).  Here, without a GPU: the disassembler is there, both timed kernels are found by name, the loop has
+    the size of a frame's work, and the price lies between the all-simple and the all-slow class."""
+    import importlib.util
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("no llvm-objdump")
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    for depth_only in (False, True):
+        m = b.valu_cost_model(depth_only)
+        assert m is not None, "the kernel bench.py times was not found in libscanfuse.so (renamed template arguments?)"
+        n = m["by_class"]
+        assert 200 < m["valu_instructions"] < 500 and n["fast"] + n["slow"] + n["trans"] == m["valu_instructions"] and n["trans"] == 8   # 8 reciprocals: one per voxel of the lane
+        assert 2.25 < m["cycles_overlapped_per_instruction"] <= m["cycles_serial_per_instruction"] < 4.4
+        assert m["costs_cycles"] == {"fast": 2.25, "slow": 4.25, "trans": 8.3}
+    assert b.valu_cost_model(False)["valu_instructions"] > b.valu_cost_model(True)["valu_instructions"]      # colour costs instructions
