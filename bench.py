@@ -382,17 +382,21 @@ def end_to_end(frames_dev, poses, n, params, local_rank, torch, colour=None):
         else:
             jpeg_bytes = None
             if orc:
+                try:
+                    t0 = time.perf_counter()
+                    path = os.path.join(d, "reference_writer.sens")
+                    orc.ref_write_sens(path, host, P44, K)
+                    files.append(("reference (stb)", path, time.perf_counter() - t0))
+                except Exception:   # the leg then runs on this library's file alone
+                    files = []
+            if not files or shutil.disk_usage(d).free > 3 * n * W * H:   # room left for a second file of the scan (each ~0.6 of the pixels' bytes; 1.5 asked for)
                 t0 = time.perf_counter()
-                path = os.path.join(d, "reference_writer.sens")
-                orc.ref_write_sens(path, host, P44, K)
-                files.append(("reference (stb)", path, time.perf_counter() - t0))
-            t0 = time.perf_counter()
-            sd = sens.SensorData.create(0, 0, W, H, K, K, depth_compression=1, sensor_name="StructureSensor")
-            sd.add_depth_frames(host, P44)
-            path = os.path.join(d, "this_library.sens")
-            sd.save(path)
-            sd.close()
-            files.append(("this library", path, time.perf_counter() - t0))
+                sd = sens.SensorData.create(0, 0, W, H, K, K, depth_compression=1, sensor_name="StructureSensor")
+                sd.add_depth_frames(host, P44)
+                path = os.path.join(d, "this_library.sens")
+                sd.save(path)
+                sd.close()
+                files.append(("this library", path, time.perf_counter() - t0))
         writer, path, t_write = files[0]
         size = os.path.getsize(path)
         sd = sens.SensorData(path)
@@ -855,9 +859,15 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
             except _abi.ScanfuseError as e:   # a smaller GPU than the 288 GB part cannot reserve the tiles
                 out["roofline_out_of_cache"] = {"error": str(e)}
         if e2e_n:
-            out["end_to_end"] = end_to_end(frames, poses, e2e_n, params, local_rank, torch)
+            try:
+                out["end_to_end"] = end_to_end(frames, poses, e2e_n, params, local_rank, torch)
+            except Exception as ex:   # a leg beside the metric (disk full in /tmp, ...): never take the line down
+                out["end_to_end"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
             if rgbd and not args.no_e2e_rgbd:
-                out["end_to_end_rgbd"] = end_to_end(frames, poses, min(e2e_n, args.e2e_rgbd_frames), params, local_rank, torch, colour="jpeg1296")
+                try:
+                    out["end_to_end_rgbd"] = end_to_end(frames, poses, min(e2e_n, args.e2e_rgbd_frames), params, local_rank, torch, colour="jpeg1296")
+                except Exception as ex:
+                    out["end_to_end_rgbd"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
         if cpu_n:   # rank 0 at N = 1 only
             host = frames[:cpu_n].cpu().numpy().view(np.uint16)
             rgb_dev = colour_tensor(max(cpu_n, 1)) if rgbd else None
