@@ -458,6 +458,15 @@ int sf_mesh_copy(const sf_mesh* m, float* xyz, uint8_t* rgba, uint32_t* tris, ui
 /* marching-cubes meshes only: the key of the cube each face came from (faces are in ascending key order) -- the meshes of a
  * partitioned scan merge into the one-GPU face order by a stable sort on it (scannet_amd/partition.py) */
 int sf_mesh_copy_face_keys(const sf_mesh* m, uint64_t* face_keys);
+/* One scan over several GPUs (BASELINE configs[4]; no reference counterpart: DepthSensing fuses a scan on one GPU, Server/scan_processor.py:138):
+ * sf_mesh_create_keyed rebuilds a marching-cubes mesh from the arrays sf_mesh_copy / sf_mesh_copy_face_keys gave (another process's part);
+ * sf_mesh_merge_parts turns the parts of a partitioned scan (sf_fuser_set_stripes / sf_fuser_set_slab, ghosts exchanged before meshing) into the
+ * mesh ONE fuser would have extracted, byte for byte: vertices unique by edge key in key order (of the copies of a shared edge the lowest part's),
+ * faces re-indexed and -- when every part has face keys -- stably sorted by cube key; without face keys they stay part after part (slabs in
+ * rank order).  The merged mesh carries its keys, so merges nest.  bin/depthsensing --ranks N is the caller. */
+int sf_mesh_create_keyed(const float* xyz, const uint8_t* rgba /*nullable*/, const uint64_t* keys, uint64_t num_vertices, const uint32_t* tris,
+                         const uint64_t* face_keys /*nullable*/, uint64_t num_faces, sf_mesh** out);
+int sf_mesh_merge_parts(const sf_mesh* const* parts, int n_parts, sf_mesh** out);
 int sf_mesh_write_ply(const sf_mesh* m, const char* path);        /* the PLY surface above */
 void sf_mesh_free(sf_mesh* m);
 

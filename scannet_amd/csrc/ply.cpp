@@ -7,6 +7,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -338,6 +339,102 @@ SF_API int sf_mesh_create(const float* xyz, const uint8_t* rgba, uint64_t nv, co
   if (rgba) m->col.assign(rgba, rgba + nv * 4);
   m->tri.assign(tris, tris + nf * 3);
   *out = m;
+  return SF_OK;
+}
+
+SF_API int sf_mesh_create_keyed(const float* xyz, const uint8_t* rgba, const uint64_t* keys, uint64_t nv, const uint32_t* tris, const uint64_t* face_keys,
+                                uint64_t nf, sf_mesh** out) {
+  if (!keys && nv) return sf::fail(SF_ERR_INVALID_ARG, "NULL vertex keys");
+  sf_mesh* m = nullptr;
+  const int rc = sf_mesh_create(xyz, rgba, nv, tris, nf, &m);
+  if (rc != SF_OK) return rc;
+  m->keys.assign(keys, keys + nv);
+  if (face_keys) m->tkeys.assign(face_keys, face_keys + nf);
+  *out = m;
+  return SF_OK;
+}
+
+// The meshes of a partitioned scan -> the mesh one fuser would have extracted (scannet_amd/partition.py merge_slab_meshes is the same rule in numpy;
+// tests/test_partition_merge.py holds the two against each other).  Every vertex carries the key of the lattice edge it sits on, every face the key of its cube:
+//   vertices: unique by key, in key order; of the copies of a key (an edge shared by cubes of two ranks: same key, same position, same colour on
+//             both) the one of the lowest part is kept;
+//   faces:    re-indexed through the keys, parts concatenated, then -- when every part has face keys -- stably sorted by cube key (each cube belongs to
+//             one rank, so that is the one-fuser order whatever the partition); without face keys the order stays "part after part" (contiguous slabs).
+SF_API int sf_mesh_merge_parts(const sf_mesh* const* parts, int n_parts, sf_mesh** out) {
+  if (!out || n_parts < 0 || (!parts && n_parts)) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  uint64_t nv = 0, nf = 0;
+  bool colour = false, face_keys = n_parts > 0;
+  for (int p = 0; p < n_parts; p++) {
+    const sf_mesh* m = parts[p];
+    if (!m) return sf::fail(SF_ERR_INVALID_ARG, "NULL part %d", p);
+    if (m->keys.size() * 3 != m->pos.size()) return sf::fail(SF_ERR_INVALID_ARG, "part %d has no vertex keys (not a marching-cubes mesh)", p);
+    nv += m->keys.size();
+    nf += m->tri.size() / 3;
+    colour |= !m->col.empty();
+    face_keys &= m->tkeys.size() * 3 == m->tri.size();
+  }
+  if (nv >> 32) return sf::fail(SF_ERR_BOUNDS, "%llu vertices in the parts: face indices are 32 bits", (unsigned long long)nv);
+  struct KV { uint64_t key; uint32_t part, idx; };
+  std::vector<KV> all;
+  all.reserve(nv);
+  std::vector<uint64_t> base(n_parts + 1, 0);
+  for (int p = 0; p < n_parts; p++) {
+    const sf_mesh* m = parts[p];
+    for (size_t i = 0; i < m->keys.size(); i++) all.push_back({m->keys[i], (uint32_t)p, (uint32_t)i});
+    base[p + 1] = base[p] + m->keys.size();
+  }
+  std::sort(all.begin(), all.end(), [](const KV& a, const KV& b) { return a.key != b.key ? a.key < b.key : a.part != b.part ? a.part < b.part : a.idx < b.idx; });
+  sf_mesh* r = new sf_mesh();
+  std::vector<uint32_t> remap(nv);   // concatenated vertex index -> merged index
+  uint64_t nu = 0;
+  for (size_t i = 0; i < all.size(); i++) {
+    if (i == 0 || all[i].key != all[i - 1].key) nu++;
+    remap[base[all[i].part] + all[i].idx] = (uint32_t)(nu - 1);
+  }
+  r->pos.resize(nu * 3);
+  r->keys.resize(nu);
+  if (colour) r->col.resize(nu * 4);
+  for (size_t i = 0, u = 0; i < all.size(); i++) {
+    if (i != 0 && all[i].key == all[i - 1].key) continue;
+    const sf_mesh* m = parts[all[i].part];
+    const size_t v = all[i].idx;
+    r->keys[u] = all[i].key;
+    std::memcpy(&r->pos[u * 3], &m->pos[v * 3], 12);
+    if (colour) {
+      if (m->col.empty()) std::memset(&r->col[u * 4], 255, 4);
+      else std::memcpy(&r->col[u * 4], &m->col[v * 4], 4);
+    }
+    u++;
+  }
+  std::vector<KV>().swap(all);
+  sf::mesh_vec<uint32_t> tri(nf * 3);
+  sf::mesh_vec<uint64_t> fk(face_keys ? nf : 0);
+  uint64_t at = 0;
+  for (int p = 0; p < n_parts; p++) {
+    const sf_mesh* m = parts[p];
+    const uint64_t n = m->tri.size() / 3, pv = m->keys.size();
+    for (uint64_t i = 0; i < n * 3; i++) {
+      if (m->tri[i] >= pv) { delete r; return sf::fail(SF_ERR_BOUNDS, "part %d: face index %u out of range (%llu vertices)", p, m->tri[i], (unsigned long long)pv); }
+      tri[(at + i / 3) * 3 + i % 3] = remap[base[p] + m->tri[i]];
+    }
+    if (face_keys && n) std::memcpy(&fk[at], m->tkeys.data(), n * 8);
+    at += n;
+  }
+  if (face_keys && n_parts > 1) {
+    std::vector<uint64_t> order(nf);
+    for (uint64_t i = 0; i < nf; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return fk[a] < fk[b]; });
+    r->tri.resize(nf * 3);
+    r->tkeys.resize(nf);
+    for (uint64_t i = 0; i < nf; i++) {
+      std::memcpy(&r->tri[i * 3], &tri[order[i] * 3], 12);
+      r->tkeys[i] = fk[order[i]];
+    }
+  } else {
+    r->tri.swap(tri);
+    r->tkeys.swap(fk);
+  }
+  *out = r;
   return SF_OK;
 }
 

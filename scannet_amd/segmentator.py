@@ -29,12 +29,26 @@ class Mesh:
         return cls(h)
 
     @classmethod
-    def from_arrays(cls, xyz, tris, rgba=None):
+    def from_arrays(cls, xyz, tris, rgba=None, keys=None, face_keys=None):
+        """keys (one u64 per vertex) [+ face_keys (one per face)]: a marching-cubes mesh as Mesh.arrays(keys=True) / Mesh.face_keys() gave it --
+        what sf_mesh_merge_parts needs of another process's part."""
         xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
         tris = np.ascontiguousarray(tris, np.uint32).reshape(-1, 3)
         if rgba is not None:
             rgba = np.ascontiguousarray(rgba, np.uint8).reshape(-1, 4)
         L = _abi.lib()
+        if keys is not None:
+            keys = np.ascontiguousarray(keys, np.uint64).reshape(-1)
+            if len(keys) != len(xyz):
+                raise ValueError("one key per vertex")
+            if face_keys is not None:
+                face_keys = np.ascontiguousarray(face_keys, np.uint64).reshape(-1)
+                if len(face_keys) != len(tris):
+                    raise ValueError("one face key per face")
+            L.sf_mesh_create_keyed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
+            h = C.c_void_p()
+            check(L.sf_mesh_create_keyed(_ptr(xyz), _ptr(rgba), _ptr(keys), len(xyz), _ptr(tris), _ptr(face_keys), len(tris), C.byref(h)))
+            return cls(h)
         L.sf_mesh_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
         h = C.c_void_p()
         check(L.sf_mesh_create(_ptr(xyz), _ptr(rgba), len(xyz), _ptr(tris), len(tris), C.byref(h)))
@@ -60,6 +74,17 @@ class Mesh:
         k = np.zeros(nf, np.uint64)
         check(_abi.lib().sf_mesh_copy_face_keys(self._h, _ptr(k)))
         return k
+
+    @classmethod
+    def merge_parts(cls, parts):
+        """The meshes the ranks of a partitioned scan extracted (Mesh handles with keys) -> the mesh one fuser would have extracted
+        (sf_mesh_merge_parts; partition.merge_slab_meshes is the same rule on numpy arrays)."""
+        L = _abi.lib()
+        arr = (C.c_void_p * max(len(parts), 1))(*[p._h for p in parts])
+        L.sf_mesh_merge_parts.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]
+        h = C.c_void_p()
+        check(L.sf_mesh_merge_parts(arr, len(parts), C.byref(h)))
+        return cls(h)
 
     def write_ply(self, path):
         check(_abi.lib().sf_mesh_write_ply(self._h, os.fsencode(path)))
