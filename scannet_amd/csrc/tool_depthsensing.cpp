@@ -17,6 +17,7 @@
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include <cerrno>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -227,6 +228,8 @@ int fuse_scan(const Args& a) {
 }
 
 // ---- the parent of a partitioned run: starts the ranks, waits, merges -------------------------------------------------------------------------------
+volatile sig_atomic_t g_stop = 0;   // SIGTERM / SIGINT reached the parent: stop the ranks, remove the exchange directory, fail
+void on_stop(int) { g_stop = 1; }
 void remove_exchange_dir(const std::string& dir, int ranks) {
   for (int r = 0; r < ranks; r++)
     for (const char* stem : {"b", "m"})
@@ -261,6 +264,11 @@ int run_ranks(const Args& a, int argc_in, const char** argv_in) {
   std::fflush(stdout);   // before the ranks write to the same stream
   std::vector<pid_t> pids(a.ranks, -1);
   int failed = 0;
+  struct sigaction sa;
+  std::memset(&sa, 0, sizeof sa);
+  sa.sa_handler = on_stop;   // no SA_RESTART: the waitpid below returns with EINTR
+  sigaction(SIGTERM, &sa, nullptr);
+  sigaction(SIGINT, &sa, nullptr);
   for (int r = 0; r < a.ranks && !failed; r++) {
     std::vector<std::string> args(argv_in, argv_in + argc_in);   // the command line as given (its --ranks included) ...
     args[0] = exe;
@@ -289,6 +297,10 @@ int run_ranks(const Args& a, int argc_in, const char** argv_in) {
     }
     int status = 0;
     const pid_t done = ::waitpid(-1, &status, 0);
+    if (done < 0 && errno == EINTR) {
+      if (g_stop && !failed) failed = 1;
+      continue;
+    }
     if (done < 0) break;
     for (pid_t& p : pids)
       if (p == done) {
@@ -299,7 +311,7 @@ int run_ranks(const Args& a, int argc_in, const char** argv_in) {
   }
   if (failed) {
     remove_exchange_dir(dir, a.ranks);
-    return die_msg("a rank of the partitioned run failed (its message is above); nothing written");
+    return die_msg(g_stop ? "stopped by a signal; nothing written" : "a rank of the partitioned run failed (its message is above); nothing written");
   }
   std::vector<Part> parts(a.ranks);
   std::vector<sf_mesh*> meshes(a.ranks, nullptr);

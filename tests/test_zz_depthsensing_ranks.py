@@ -3,8 +3,11 @@ Python").  The tool starts N copies of itself, one per GPU; they fuse their stri
 merges the parts with sf_mesh_merge_parts (tests/test_partition_merge.py holds that merge against the numpy rule).
 
 What runs where:
-  * without a GPU (here): the protocol -- the ranks refuse loudly ("no CPU fallback"), the parent reports ONE failure, exits non-zero, writes nothing
-    and leaves no exchange directory behind; argument errors print the usage;
+  * anywhere (no GPU needed): the TOOL'S OWN LOGIC against a stand-in for the device half of the library (tests/fake_fuser/: the real host half -- .sens
+    reader, parameter files, sf_mesh_merge_parts, the PLY writer -- plus a fake fuser whose "volume" is a fixed block set with checked contents and whose
+    "mesh" needs the +x neighbour block, as marching cubes does): 2, 3, 4 and 6 ranks write the one-rank file byte for byte; a slow rank is waited for;
+    a failing rank, a damaged boundary layer and a SIGTERM each fail the run once, write nothing and leave no exchange directory;
+  * without a GPU (here), the shipped binary: the ranks refuse loudly ("no CPU fallback"), the parent reports ONE failure; argument errors print the usage;
   * on a one-GPU box: `--ranks 2 --share-gpu` (both ranks on GPU 0) must write the SAME file as the plain tool.  This mode was written after round 5's
     GPU minutes were spent: it has not run on hardware before this commit, so the test is `xfail(strict=False)` -- it reports XPASS when the mode
     works and XFAIL when it does not, and in neither case hides the rest of the suite behind `-x`.  The file sorts last for the same reason;
@@ -49,9 +52,13 @@ def _scan(tmp_path, n, W, H):
     return [str(params), str(tmp_path / "t.txt"), path]
 
 
-def _run(args, timeout=600):
+def _run(args, timeout=600, tool=None, env=None, after_start=None):
     """The tool in a process group of its own: on a timeout the whole group goes (the parent and its ranks), by exact group id."""
-    p = subprocess.Popen([TOOL] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    e = dict(os.environ)
+    e.update(env or {})
+    p = subprocess.Popen([tool or TOOL] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True, env=e)
+    if after_start:
+        after_start(p)
     try:
         out, err = p.communicate(timeout=timeout)
     except subprocess.TimeoutExpired:
@@ -84,6 +91,66 @@ def test_ranks_argument_errors_print_the_usage(tmp_path):
     for bad in (["--ranks", "0"], ["--ranks=65"], ["--rank-of=0"], ["--rank-of=2", "--ranks=2", "--exchange-dir=/tmp"], ["--no-such-switch"]):
         rc, out, err = _run(bad + ["a", "b", "c"])
         assert rc == 255 and out.startswith("Usage: depthsensing") and "--ranks N" in out and err == "", bad
+
+
+@pytest.fixture(scope="module")
+def fake_tool(tmp_path_factory):
+    """tool_depthsensing.cpp compiled against the real host half of the library + tests/fake_fuser/fake_fuser.cpp (no HIP anywhere)."""
+    d = str(tmp_path_factory.mktemp("fake_ds"))
+    r = subprocess.run(["bash", os.path.join(ROOT, "tests", "fake_fuser", "build.sh"), d], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return os.path.join(d, "depthsensing")
+
+
+def test_tool_logic_ranks_write_the_one_rank_file(fake_tool, tmp_path):
+    args = _scan(tmp_path, 5, 64, 48)
+    one = str(tmp_path / "one.ply")
+    rc, out, err = _run(args + [one], tool=fake_tool)
+    assert rc == 0 and err == "" and "Mesh with" in out and "[rank" not in out
+    whole = open(one, "rb").read()
+    before = _exchange_dirs()
+    for extra, env in ((["--ranks", "2"], {}), (["--ranks=3"], {}), (["--ranks=4"], {}), (["--ranks=3"], {"SF_DEVICE": "1"}),
+                       (["--ranks=6", "--share-gpu"], {"FAKE_DEVICES": "1"}), (["--ranks=3"], {"FAKE_SLOW_DEVICE": "1"}), (["--ranks=2"], {"FAKE_SLOW_DEVICE": "0"})):
+        n = int(extra[0].split("=")[1]) if "=" in extra[0] else int(extra[1])
+        ply = str(tmp_path / "parts.ply")
+        rc, out, err = _run(extra + args + [ply], tool=fake_tool, env=env)
+        assert rc == 0 and err == "", (extra, env, out[-1500:], err[-1500:])
+        assert open(ply, "rb").read() == whole, (extra, env)
+        os.remove(ply)
+        assert out.count("Integrated 5 frames") == n and out.count("Exchange:") == n and out.count("handed to the parent") == n
+        sent = sum(int(ln.split("Exchange: ")[1].split()[0]) for ln in out.splitlines() if "Exchange:" in ln)
+        kept = sum(int(ln.split("sent to rank ")[1].split(", ")[1].split()[0]) for ln in out.splitlines() if "Exchange:" in ln)
+        assert sent == kept > 0                                       # every boundary block is some rank's ghost: nothing lost, nothing doubled
+        assert all(ln.startswith("[rank ") or ln.startswith("Partitioned run") or ln.startswith("Mesh with") for ln in out.splitlines())
+        assert _exchange_dirs() == before
+    # the default output name: next to the .sens (Server/scan_processor.py:141)
+    rc, out, err = _run(["--ranks", "2"] + args, tool=fake_tool)
+    assert rc == 0 and open(str(tmp_path / "scan_vh.ply"), "rb").read() == whole
+
+
+def test_tool_logic_failures_fail_once_and_leave_nothing(fake_tool, tmp_path):
+    import time
+    args = _scan(tmp_path, 5, 64, 48)
+    ply = str(tmp_path / "never.ply")
+    before = _exchange_dirs()
+    t0 = time.time()
+    rc, out, err = _run(["--ranks=3"] + args + [ply], tool=fake_tool, env={"FAKE_FAIL_DEVICE": "1"})      # rank 0 is waiting for rank 1's layers when it fails
+    assert rc == 1 and "[rank 1/3] fuse: fake: device 1 was told to fail" in err and err.count("a rank of the partitioned run failed") == 1
+    assert time.time() - t0 < 20 and not os.path.exists(ply) and _exchange_dirs() == before
+    rc, out, err = _run(["--ranks=3"] + args + [ply], tool=fake_tool, env={"FAKE_CORRUPT_DEVICE": "2"})   # rank 1 reads rank 2's layers
+    assert rc == 1 and "[rank 1/3] ghost import: fake: block" in err and "arrived damaged" in err and not os.path.exists(ply) and _exchange_dirs() == before
+    rc, out, err = _run(["--ranks=5"] + args + [ply], tool=fake_tool)                                      # four devices
+    assert rc == 1 and "needs 5 GPUs, 4 visible" in err and "[rank" not in out + err
+    rc, out, err = _run(["--ranks=3"] + args + [ply], tool=fake_tool, env={"SF_DEVICE": "2"})
+    assert rc == 1 and "from device 2 needs 5 GPUs, 4 visible" in err
+
+    def stop(p):
+        time.sleep(0.7)
+        os.kill(p.pid, signal.SIGTERM)            # the parent, by pid
+    t0 = time.time()
+    rc, out, err = _run(["--ranks=3"] + args + [ply], tool=fake_tool, env={"FAKE_SLOW_DEVICE": "1", "FAKE_SLOW_MS": "8000"}, after_start=stop)
+    assert rc == 1 and "stopped by a signal; nothing written" in err and time.time() - t0 < 6
+    assert not os.path.exists(ply) and _exchange_dirs() == before
 
 
 def _same_file_as_one_rank(tmp_path, extra):
