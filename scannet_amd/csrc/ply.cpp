@@ -13,6 +13,7 @@
 #include <cstring>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "mesh.h"
@@ -360,11 +361,76 @@ SF_API int sf_mesh_create_keyed(const float* xyz, const uint8_t* rgba, const uin
 //             both) the one of the lowest part is kept;
 //   faces:    re-indexed through the keys, parts concatenated, then -- when every part has face keys -- stably sorted by cube key (each cube belongs to
 //             one rank, so that is the one-fuser order whatever the partition); without face keys the order stays "part after part" (contiguous slabs).
+namespace {
+
+template <class F>
+void parallel_for(int n_threads, F&& fn) {   // fn(t) for t in [0, n_threads); the caller's thread takes t = 0
+  std::vector<std::thread> th;
+  for (int t = 1; t < n_threads; t++) th.emplace_back([&fn, t]() { fn(t); });
+  fn(0);
+  for (auto& x : th) x.join();
+}
+
+// k sorted runs (run p = positions [lo[p], hi[p]) of part p, key(p, i) ascending in i) merged in ascending (key, part, position) order: take(p, i, key).
+// The smallest head, the lowest part among equals -- k is the number of GPUs, a scan over the heads beats a heap -- and everything of that run below the
+// next-best head goes out in one go (the runs of one rank's stripe are long).
+template <class Key, class Take>
+void merge_runs(int k, std::vector<size_t> at, const std::vector<size_t>& hi, Key&& key, Take&& take) {
+  for (;;) {
+    int best = -1;
+    uint64_t bk = 0;
+    for (int p = 0; p < k; p++)
+      if (at[p] < hi[p]) {
+        const uint64_t h = key(p, at[p]);
+        if (best < 0 || h < bk) { best = p; bk = h; }
+      }
+    if (best < 0) return;
+    uint64_t limit = 0;
+    bool limited = false;
+    for (int p = 0; p < k; p++)
+      if (p != best && at[p] < hi[p]) {
+        const uint64_t h = key(p, at[p]);
+        const uint64_t lim = p < best ? h : h + 1;   // a later part with the same key waits for this one; an earlier part cannot hold it (it would be `best`)
+        if (!limited || lim < limit) { limit = lim; limited = true; }
+      }
+    size_t i = at[best];
+    do { take(best, i, key(best, i)); i++; } while (i < hi[best] && (!limited || key(best, i) < limit));
+    at[best] = i;
+  }
+}
+
+// T - 1 keys that cut the union of the runs into T ranges of about equal size (quantiles of a sample), and where each range begins in each run
+template <class Key>
+std::vector<std::vector<size_t>> split_runs(int k, const std::vector<size_t>& size, int T, Key&& key) {
+  std::vector<uint64_t> sample;
+  for (int p = 0; p < k; p++)
+    for (int j = 0; j < 256 && size[p]; j++) sample.push_back(key(p, (size_t)((size[p] - 1) * (double)j / 255.0)));
+  std::sort(sample.begin(), sample.end());
+  std::vector<std::vector<size_t>> cut(T + 1, std::vector<size_t>(k, 0));
+  for (int p = 0; p < k; p++) cut[T][p] = size[p];
+  for (int t = 1; t < T; t++) {
+    const uint64_t split = sample.empty() ? 0 : sample[sample.size() * (size_t)t / T];
+    for (int p = 0; p < k; p++) {   // first position of run p whose key is >= split (equal keys of all runs land in one range)
+      size_t lo = cut[t - 1][p], hi = size[p];
+      while (lo < hi) {
+        const size_t mid = lo + (hi - lo) / 2;
+        if (key(p, mid) < split) lo = mid + 1;
+        else hi = mid;
+      }
+      cut[t][p] = lo;
+    }
+  }
+  return cut;
+}
+
+}  // namespace
+
 SF_API int sf_mesh_merge_parts(const sf_mesh* const* parts, int n_parts, sf_mesh** out) {
   if (!out || n_parts < 0 || (!parts && n_parts)) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  const int k = n_parts;
   uint64_t nv = 0, nf = 0;
-  bool colour = false, face_keys = n_parts > 0;
-  for (int p = 0; p < n_parts; p++) {
+  bool colour = false, face_keys = k > 0;
+  for (int p = 0; p < k; p++) {
     const sf_mesh* m = parts[p];
     if (!m) return sf::fail(SF_ERR_INVALID_ARG, "NULL part %d", p);
     if (m->keys.size() * 3 != m->pos.size()) return sf::fail(SF_ERR_INVALID_ARG, "part %d has no vertex keys (not a marching-cubes mesh)", p);
@@ -374,65 +440,116 @@ SF_API int sf_mesh_merge_parts(const sf_mesh* const* parts, int n_parts, sf_mesh
     face_keys &= m->tkeys.size() * 3 == m->tri.size();
   }
   if (nv >> 32) return sf::fail(SF_ERR_BOUNDS, "%llu vertices in the parts: face indices are 32 bits", (unsigned long long)nv);
-  struct KV { uint64_t key; uint32_t part, idx; };
-  std::vector<KV> all;
-  all.reserve(nv);
-  std::vector<uint64_t> base(n_parts + 1, 0);
-  for (int p = 0; p < n_parts; p++) {
-    const sf_mesh* m = parts[p];
-    for (size_t i = 0; i < m->keys.size(); i++) all.push_back({m->keys[i], (uint32_t)p, (uint32_t)i});
-    base[p + 1] = base[p] + m->keys.size();
+  const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)sf::usable_cpus(), 32, (nv + nf) / 200000 + 1}));
+  // marching cubes hands every part over with its vertices ascending by key and its faces ascending by cube key: then both merges are k-way merges of
+  // sorted runs, cut into T key ranges that T threads merge side by side (a scan-sized mesh has tens of millions of each; one thread sorting them again
+  // cost twenty times the extraction).  Parts in any other order are sorted below.  The same sweep checks the face indices.
+  std::vector<int> bad_part(T, -1), unsorted(T, 0);
+  parallel_for(T, [&](int t) {
+    for (int p = 0; p < k; p++) {
+      const sf_mesh* m = parts[p];
+      const size_t pv = m->keys.size(), n3 = m->tri.size();
+      for (size_t i = n3 * t / T; i < n3 * (t + 1) / T; i++)
+        if (m->tri[i] >= pv) bad_part[t] = p;
+      for (size_t i = std::max<size_t>(1, pv * t / T); i < pv * (t + 1) / T; i++) unsorted[t] |= m->keys[i - 1] > m->keys[i];
+      if (face_keys)
+        for (size_t i = std::max<size_t>(1, n3 / 3 * t / T); i < n3 / 3 * (t + 1) / T; i++) unsorted[t] |= m->tkeys[i - 1] > m->tkeys[i];
+    }
+  });
+  bool sorted = true;
+  for (int t = 0; t < T; t++) {
+    if (bad_part[t] >= 0) return sf::fail(SF_ERR_BOUNDS, "part %d: a face index is out of range (%llu vertices)", bad_part[t], (unsigned long long)parts[bad_part[t]]->keys.size());
+    sorted &= !unsorted[t];
   }
-  std::sort(all.begin(), all.end(), [](const KV& a, const KV& b) { return a.key != b.key ? a.key < b.key : a.part != b.part ? a.part < b.part : a.idx < b.idx; });
+  std::vector<uint64_t> base(k + 1, 0);
+  std::vector<size_t> vsize(k), fsize(k);
+  for (int p = 0; p < k; p++) {
+    base[p + 1] = base[p] + parts[p]->keys.size();
+    vsize[p] = parts[p]->keys.size();
+    fsize[p] = parts[p]->tri.size() / 3;
+  }
   sf_mesh* r = new sf_mesh();
   std::vector<uint32_t> remap(nv);   // concatenated vertex index -> merged index
-  uint64_t nu = 0;
-  for (size_t i = 0; i < all.size(); i++) {
-    if (i == 0 || all[i].key != all[i - 1].key) nu++;
-    remap[base[all[i].part] + all[i].idx] = (uint32_t)(nu - 1);
-  }
-  r->pos.resize(nu * 3);
-  r->keys.resize(nu);
-  if (colour) r->col.resize(nu * 4);
-  for (size_t i = 0, u = 0; i < all.size(); i++) {
-    if (i != 0 && all[i].key == all[i - 1].key) continue;
-    const sf_mesh* m = parts[all[i].part];
-    const size_t v = all[i].idx;
-    r->keys[u] = all[i].key;
+  auto put_vertex = [&](uint64_t u, uint64_t key, int p, size_t v) {
+    const sf_mesh* m = parts[p];
+    r->keys[u] = key;
     std::memcpy(&r->pos[u * 3], &m->pos[v * 3], 12);
     if (colour) {
       if (m->col.empty()) std::memset(&r->col[u * 4], 255, 4);
       else std::memcpy(&r->col[u * 4], &m->col[v * 4], 4);
     }
-    u++;
-  }
-  std::vector<KV>().swap(all);
-  sf::mesh_vec<uint32_t> tri(nf * 3);
-  sf::mesh_vec<uint64_t> fk(face_keys ? nf : 0);
-  uint64_t at = 0;
-  for (int p = 0; p < n_parts; p++) {
-    const sf_mesh* m = parts[p];
-    const uint64_t n = m->tri.size() / 3, pv = m->keys.size();
-    for (uint64_t i = 0; i < n * 3; i++) {
-      if (m->tri[i] >= pv) { delete r; return sf::fail(SF_ERR_BOUNDS, "part %d: face index %u out of range (%llu vertices)", p, m->tri[i], (unsigned long long)pv); }
-      tri[(at + i / 3) * 3 + i % 3] = remap[base[p] + m->tri[i]];
-    }
-    if (face_keys && n) std::memcpy(&fk[at], m->tkeys.data(), n * 8);
-    at += n;
-  }
-  if (face_keys && n_parts > 1) {
-    std::vector<uint64_t> order(nf);
-    for (uint64_t i = 0; i < nf; i++) order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return fk[a] < fk[b]; });
-    r->tri.resize(nf * 3);
-    r->tkeys.resize(nf);
-    for (uint64_t i = 0; i < nf; i++) {
-      std::memcpy(&r->tri[i * 3], &tri[order[i] * 3], 12);
-      r->tkeys[i] = fk[order[i]];
-    }
+  };
+  auto size_vertices = [&](uint64_t nu) {
+    r->keys.resize(nu);
+    r->pos.resize(nu * 3);
+    if (colour) r->col.resize(nu * 4);
+  };
+  auto vkey = [&](int p, size_t i) { return (uint64_t)parts[p]->keys[i]; };
+  auto fkey = [&](int p, size_t i) { return (uint64_t)parts[p]->tkeys[i]; };
+  if (sorted) {
+    const auto cut = split_runs(k, vsize, T, vkey);
+    std::vector<uint64_t> first(T + 1, 0);   // merged index of the first vertex of range t: a pass that counts, a pass that writes
+    parallel_for(T, [&](int t) {
+      uint64_t n = 0, last = 0;
+      merge_runs(k, cut[t], cut[t + 1], vkey, [&](int, size_t, uint64_t key) { n += (n == 0 || key != last); last = key; });
+      first[t + 1] = n;
+    });
+    for (int t = 0; t < T; t++) first[t + 1] += first[t];
+    size_vertices(first[T]);
+    parallel_for(T, [&](int t) {
+      uint64_t u = first[t], last = 0;
+      bool any = false;
+      merge_runs(k, cut[t], cut[t + 1], vkey, [&](int p, size_t i, uint64_t key) {
+        if (!any || key != last) put_vertex(u++, key, p, i);
+        remap[base[p] + i] = (uint32_t)(u - 1);
+        last = key;
+        any = true;
+      });
+    });
   } else {
-    r->tri.swap(tri);
-    r->tkeys.swap(fk);
+    struct KV { uint64_t key; uint32_t part, idx; };
+    std::vector<KV> all;
+    all.reserve(nv);
+    for (int p = 0; p < k; p++)
+      for (size_t i = 0; i < vsize[p]; i++) all.push_back({parts[p]->keys[i], (uint32_t)p, (uint32_t)i});
+    std::sort(all.begin(), all.end(), [](const KV& a, const KV& b) { return a.key != b.key ? a.key < b.key : a.part != b.part ? a.part < b.part : a.idx < b.idx; });
+    uint64_t nu = 0;
+    for (size_t i = 0; i < all.size(); i++) nu += i == 0 || all[i].key != all[i - 1].key;
+    size_vertices(nu);
+    uint64_t u = 0;
+    for (size_t i = 0; i < all.size(); i++) {
+      if (i == 0 || all[i].key != all[i - 1].key) put_vertex(u++, all[i].key, (int)all[i].part, all[i].idx);
+      remap[base[all[i].part] + all[i].idx] = (uint32_t)(u - 1);
+    }
+  }
+  r->tri.resize(nf * 3);
+  if (face_keys) r->tkeys.resize(nf);
+  auto put_face = [&](uint64_t dst, int p, size_t f) {
+    const sf_mesh* m = parts[p];
+    for (int c = 0; c < 3; c++) r->tri[dst * 3 + c] = remap[base[p] + m->tri[f * 3 + c]];
+    if (face_keys) r->tkeys[dst] = m->tkeys[f];
+  };
+  if (face_keys && k > 1 && sorted) {
+    const auto cut = split_runs(k, fsize, T, fkey);
+    parallel_for(T, [&](int t) {
+      uint64_t dst = 0;
+      for (int p = 0; p < k; p++) dst += cut[t][p];
+      merge_runs(k, cut[t], cut[t + 1], fkey, [&](int p, size_t i, uint64_t) { put_face(dst++, p, i); });
+    });
+  } else if (face_keys && k > 1) {
+    std::vector<std::pair<uint32_t, uint32_t>> src;   // (part, face) in part order, stably sorted by cube key
+    src.reserve(nf);
+    for (int p = 0; p < k; p++)
+      for (size_t f = 0; f < fsize[p]; f++) src.push_back({(uint32_t)p, (uint32_t)f});
+    std::stable_sort(src.begin(), src.end(), [&](const auto& a, const auto& b) { return parts[a.first]->tkeys[a.second] < parts[b.first]->tkeys[b.second]; });
+    for (uint64_t dst = 0; dst < nf; dst++) put_face(dst, (int)src[dst].first, src[dst].second);
+  } else {   // part after part: cut evenly over the threads
+    std::vector<uint64_t> fbase(k + 1, 0);
+    for (int p = 0; p < k; p++) fbase[p + 1] = fbase[p] + fsize[p];
+    parallel_for(T, [&](int t) {
+      for (int p = 0; p < k; p++)
+        for (size_t f = fsize[p] * t / T; f < fsize[p] * (t + 1) / T; f++) put_face(fbase[p] + f, p, f);
+    });
   }
   *out = r;
   return SF_OK;

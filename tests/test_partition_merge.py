@@ -46,6 +46,38 @@ def test_merge_parts_is_the_numpy_rule(world, kw):
     assert all(np.array_equal(a, b) for a, b in zip(again.arrays(keys=True), (xyz, rgba, tris, keys)))
 
 
+@pytest.mark.parametrize("interleave", [True, False])
+def test_merge_at_a_size_that_takes_several_threads(interleave):
+    """Above ~200 k elements per thread the merge cuts the key space into ranges and merges them side by side (csrc/ply.cpp split_runs): shared keys
+    on both sides of a cut, faces interleaved key by key (worst case) or in long runs (what stripes give)."""
+    rng = np.random.default_rng(3)
+    parts = _parts(rng, 3, 500000, 400000, shared=0.3, interleave=interleave)
+    if not interleave:   # long runs: stripes of cube keys dealt round-robin
+        parts = [(p[0], p[1], p[2], p[3], np.sort(((np.arange(len(p[4]), dtype=np.uint64) // 5000) * 3 + r) * 100000 + (p[4] % 100000))) for r, p in enumerate(parts)]
+    want = partition.merge_slab_meshes(parts)
+    m = Mesh.merge_parts([Mesh.from_arrays(p[0], p[2], rgba=p[1], keys=p[3], face_keys=p[4]) for p in parts])
+    xyz, rgba, tris, keys = m.arrays(keys=True)
+    assert np.array_equal(keys, want[3]) and np.array_equal(xyz, want[0]) and np.array_equal(rgba, want[1]) and np.array_equal(tris, want[2])
+
+
+def test_merge_of_parts_that_are_not_sorted():
+    """Marching cubes hands sorted parts over (the k-way merge); arrays in any other order go through the sort and give the same mesh."""
+    rng = np.random.default_rng(23)
+    parts = []
+    for xyz, rgba, tris, keys, fk in _parts(rng, 3, 4000, 2500, shared=0.2):
+        perm = rng.permutation(len(keys))                      # new position -> old vertex
+        inv = np.argsort(perm)
+        fperm = rng.permutation(len(fk))
+        parts.append((xyz[perm], rgba[perm], inv[tris.astype(np.int64)].astype(np.uint32)[fperm], keys[perm], fk[fperm]))
+    want = partition.merge_slab_meshes(parts)
+    m = Mesh.merge_parts([Mesh.from_arrays(p[0], p[2], rgba=p[1], keys=p[3], face_keys=p[4]) for p in parts])
+    xyz, rgba, tris, keys = m.arrays(keys=True)
+    assert np.array_equal(keys, want[3]) and np.array_equal(xyz, want[0]) and np.array_equal(rgba, want[1])
+    # equal cube keys within one shuffled part have no defined order in either rule beyond stability: compare as sorted-by-key groups
+    fk = m.face_keys()
+    assert np.all(fk[1:] >= fk[:-1]) and np.array_equal(tris, want[2])
+
+
 def test_merge_without_face_keys_keeps_the_parts_in_order():
     """Contiguous slabs: no face keys needed, faces stay part after part (merge_slab_meshes with 4-tuples)."""
     rng = np.random.default_rng(5)
