@@ -14,6 +14,7 @@
 #include <signal.h>
 #include <spawn.h>
 #include <sys/stat.h>
+#include <sys/statvfs.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -255,10 +256,15 @@ int run_ranks(const Args& a, int argc_in, const char** argv_in) {
   const ssize_t len = ::readlink("/proc/self/exe", exe, sizeof exe - 1);
   if (len <= 0) return die_msg("could not find this executable (/proc/self/exe)");
   exe[len] = 0;
-  char shm[] = "/dev/shm/sf_ranks_XXXXXX", tmp[] = "/tmp/sf_ranks_XXXXXX";
-  const char* made = ::mkdtemp(shm);
-  if (!made) made = ::mkdtemp(tmp);
-  if (!made) return die_msg("could not create the exchange directory in /dev/shm or /tmp");
+  // the exchange directory: memory-backed /dev/shm when it has room for a scan-sized exchange (boundary layers ~1/16 of the blocks x 4 KiB, then the
+  // mesh parts: a few GB for a 50 000-frame scan; containers often give /dev/shm 64 MB), else $TMPDIR or /tmp (short-lived files: page cache)
+  struct statvfs vfs;
+  const bool shm_has_room = ::statvfs("/dev/shm", &vfs) == 0 && (double)vfs.f_bavail * (double)vfs.f_frsize >= 8e9;
+  const char* tmpdir = std::getenv("TMPDIR");
+  std::string shm = "/dev/shm/sf_ranks_XXXXXX", tmp = std::string(tmpdir && *tmpdir ? tmpdir : "/tmp") + "/sf_ranks_XXXXXX";
+  const char* made = shm_has_room ? ::mkdtemp(&shm[0]) : nullptr;
+  if (!made) made = ::mkdtemp(&tmp[0]);
+  if (!made) return die_msg("could not create the exchange directory in /dev/shm or %s", tmp.c_str());
   const std::string dir = made;
   say("Partitioned run: %d ranks%s, stripes of %d block layers along x, exchange through %s\n", a.ranks, a.share_gpu ? " sharing one device" : "", STRIPE_BLOCKS, dir.c_str());
   std::fflush(stdout);   // before the ranks write to the same stream
