@@ -153,25 +153,30 @@ def test_tool_logic_failures_fail_once_and_leave_nothing(fake_tool, tmp_path):
     assert not os.path.exists(ply) and _exchange_dirs() == before
 
 
-def _same_file_as_one_rank(tmp_path, extra):
+def _same_file_as_one_rank(tmp_path, extra, tool=None, min_faces=10000):
     from scannet_amd import segmentator
     args = _scan(tmp_path, 24, 320, 240)
     one, two = str(tmp_path / "one.ply"), str(tmp_path / "two.ply")
-    rc, out, err = _run(args + [one])
+    rc, out1, err = _run(args + [one], timeout=240, tool=tool)
     assert rc == 0 and err == "", err
     before = _exchange_dirs()
-    rc, out, err = _run(extra + args + [two])
+    rc, out, err = _run(extra + args + [two], timeout=240, tool=tool)
     assert rc == 0 and err == "", (out[-2000:], err[-2000:])          # the pipeline's protocol: nothing on stderr on success (Server/util.py:42-44)
     assert _exchange_dirs() == before
     assert out.count("Integrated 24 frames") == 2 and "[rank 0/2] Exchange:" in out and "[rank 1/2] Exchange:" in out
     sent = [int(ln.split("Exchange: ")[1].split()[0]) for ln in out.splitlines() if "Exchange:" in ln]
     assert min(sent) > 0                                              # both ranks own stripes with a layer to hand on
     nv, nf = segmentator.Mesh.read(one).counts()
-    assert nf > 10000
+    assert nf > min_faces
     assert open(one, "rb").read() == open(two, "rb").read()           # the merged mesh IS the one-GPU mesh
     blocks = [int(ln.split("; ")[1].split()[0]) for ln in out.splitlines() if "Integrated 24 frames" in ln]
-    whole = [int(ln.split("; ")[1].split()[0]) for ln in _run(args + [one])[1].splitlines() if "Integrated 24 frames" in ln]
-    assert sum(blocks) == whole[0] and min(blocks) > 0                # every block fused by exactly one rank
+    whole = [int(ln.split("; ")[1].split()[0]) for ln in out1.splitlines() if "Integrated 24 frames" in ln]
+    assert len(blocks) == 2 and sum(blocks) == whole[0] and min(blocks) > 0   # every block fused by exactly one rank
+
+
+def test_the_hardware_comparison_itself_on_the_stand_in(fake_tool, tmp_path):
+    """The checks of the two GPU tests below, run against the stand-in: a parsing mistake in them must not read as a failure of the mode on hardware."""
+    _same_file_as_one_rank(tmp_path, ["--ranks", "2", "--share-gpu"], tool=fake_tool, min_faces=100)
 
 
 @pytest.mark.gpu
