@@ -8,6 +8,8 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cerrno>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -585,31 +587,53 @@ SF_API int sf_mesh_copy(const sf_mesh* m, float* xyz, uint8_t* rgba, uint32_t* t
   return SF_OK;
 }
 
+// The file is header + nv records of 16 bytes + nf records of 13 bytes at known offsets: T threads format their slices into 4 MB buffers and pwrite them
+// (one thread filling one zero-initialised vector per element wrote 0.26 GB/s: 0.4 s for the mesh of a scan that is fused in 0.2 s).
 SF_API int sf_mesh_write_ply(const sf_mesh* m, const char* path) {
   if (!m || !path) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
-  FILE* fp = std::fopen(path, "wb");
-  if (!fp) return sf::fail(SF_ERR_IO, "unable to open file for writing: %s", path);
+  const int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+  if (fd < 0) return sf::fail(SF_ERR_IO, "unable to open file for writing: %s", path);
   const uint64_t nv = m->pos.size() / 3, nf = m->tri.size() / 3;
-  std::fprintf(fp,
-               "ply\nformat binary_little_endian 1.0\ncomment scanfuse-mi355x\nelement vertex %llu\nproperty float x\nproperty float y\nproperty float z\n"
-               "property uchar red\nproperty uchar green\nproperty uchar blue\nproperty uchar alpha\nelement face %llu\n"
-               "property list uchar int vertex_indices\nend_header\n",
-               (unsigned long long)nv, (unsigned long long)nf);
-  std::vector<uint8_t> buf;
-  buf.resize(nv * 16);
-  for (uint64_t i = 0; i < nv; i++) {
-    std::memcpy(&buf[i * 16], &m->pos[3 * i], 12);
-    if (m->col.empty()) { buf[i * 16 + 12] = buf[i * 16 + 13] = buf[i * 16 + 14] = 255; buf[i * 16 + 15] = 255; }
-    else std::memcpy(&buf[i * 16 + 12], &m->col[4 * i], 4);
-  }
-  bool ok = nv == 0 || std::fwrite(buf.data(), 1, buf.size(), fp) == buf.size();
-  buf.resize(nf * 13);
-  for (uint64_t i = 0; i < nf; i++) {
-    buf[i * 13] = 3;
-    std::memcpy(&buf[i * 13 + 1], &m->tri[3 * i], 12);
-  }
-  ok = ok && (nf == 0 || std::fwrite(buf.data(), 1, buf.size(), fp) == buf.size());
-  if (std::fclose(fp) != 0) ok = false;
+  char header[512];
+  const int hl = std::snprintf(header, sizeof header,
+                               "ply\nformat binary_little_endian 1.0\ncomment scanfuse-mi355x\nelement vertex %llu\nproperty float x\nproperty float y\nproperty float z\n"
+                               "property uchar red\nproperty uchar green\nproperty uchar blue\nproperty uchar alpha\nelement face %llu\n"
+                               "property list uchar int vertex_indices\nend_header\n",
+                               (unsigned long long)nv, (unsigned long long)nf);
+  auto write_at = [fd](const uint8_t* src, size_t n, uint64_t off) {
+    while (n) {
+      const ssize_t w = ::pwrite(fd, src, n, (off_t)off);
+      if (w < 0 && errno == EINTR) continue;
+      if (w <= 0) return false;
+      src += w; n -= (size_t)w; off += (uint64_t)w;
+    }
+    return true;
+  };
+  std::atomic<bool> ok{write_at((const uint8_t*)header, (size_t)hl, 0)};
+  const uint64_t off_v = (uint64_t)hl, off_f = off_v + nv * 16;
+  const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)sf::usable_cpus(), 16, (nv + nf) / 500000 + 1}));
+  const uint64_t CHUNK = 1 << 18;   // records per buffer
+  parallel_for(T, [&](int t) {
+    sf::mesh_vec<uint8_t> buf(CHUNK * 16);
+    for (uint64_t a0 = nv * t / T, a1 = nv * (t + 1) / T; a0 < a1 && ok.load(std::memory_order_relaxed); a0 += CHUNK) {
+      const uint64_t n = std::min(CHUNK, a1 - a0);
+      for (uint64_t i = 0; i < n; i++) {
+        std::memcpy(&buf[i * 16], &m->pos[3 * (a0 + i)], 12);
+        if (m->col.empty()) std::memset(&buf[i * 16 + 12], 255, 4);
+        else std::memcpy(&buf[i * 16 + 12], &m->col[4 * (a0 + i)], 4);
+      }
+      if (!write_at(buf.data(), n * 16, off_v + a0 * 16)) ok = false;
+    }
+    for (uint64_t a0 = nf * t / T, a1 = nf * (t + 1) / T; a0 < a1 && ok.load(std::memory_order_relaxed); a0 += CHUNK) {
+      const uint64_t n = std::min(CHUNK, a1 - a0);
+      for (uint64_t i = 0; i < n; i++) {
+        buf[i * 13] = 3;
+        std::memcpy(&buf[i * 13 + 1], &m->tri[3 * (a0 + i)], 12);
+      }
+      if (!write_at(buf.data(), n * 13, off_f + a0 * 13)) ok = false;
+    }
+  });
+  if (::close(fd) != 0) ok = false;
   if (!ok) return sf::fail(SF_ERR_IO, "write to %s failed", path);
   return SF_OK;
 }
