@@ -12,7 +12,9 @@
 // file per rank in /dev/shm -- host processes without a process group; scannet_amd/partition.py is the same exchange over RCCL for callers that have
 // one); every rank meshes its own blocks and the parent merges the parts by key (sf_mesh_merge_parts) into the mesh one GPU would have written.
 #include <signal.h>
+#include <fcntl.h>
 #include <spawn.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <sys/statvfs.h>
 #include <sys/wait.h>
@@ -93,26 +95,46 @@ bool wait_for(const std::string& path, const std::string& abort_flag, pid_t pare
   }
 }
 
-struct Part {   // a rank's mesh as it travels to the parent
+// A rank's mesh as it travels to the parent: {nv, nf} then the arrays, widest element type first so that every array is aligned in the mapping --
+// keys nv x u64, face keys nf x u64, xyz nv x 3 f32, tris nf x 3 u32, rgba nv x 4 u8.  The parent maps the file and hands the pointers to
+// sf_mesh_create_keyed (one copy, into the handle).
+struct Part {
   uint64_t nv = 0, nf = 0;
-  std::vector<float> xyz;
-  std::vector<uint8_t> rgba;
-  std::vector<uint64_t> keys, fkeys;
-  std::vector<uint32_t> tris;
-};
-bool read_part(const std::string& path, Part* p) {
-  FILE* fp = std::fopen(path.c_str(), "rb");
-  if (!fp) return false;
-  uint64_t hdr[2];
-  bool ok = read_exact(fp, hdr, sizeof hdr);
-  if (ok) {
-    p->nv = hdr[0]; p->nf = hdr[1];
-    p->xyz.resize(p->nv * 3); p->rgba.resize(p->nv * 4); p->keys.resize(p->nv); p->tris.resize(p->nf * 3); p->fkeys.resize(p->nf);
-    ok = read_exact(fp, p->xyz.data(), p->nv * 12) && read_exact(fp, p->rgba.data(), p->nv * 4) && read_exact(fp, p->keys.data(), p->nv * 8) &&
-         read_exact(fp, p->tris.data(), p->nf * 12) && read_exact(fp, p->fkeys.data(), p->nf * 8);
+  void* map = nullptr;
+  size_t bytes = 0;
+  const uint64_t *keys = nullptr, *fkeys = nullptr;
+  const float* xyz = nullptr;
+  const uint32_t* tris = nullptr;
+  const uint8_t* rgba = nullptr;
+  void unmap() {
+    if (map) ::munmap(map, bytes);
+    map = nullptr;
   }
-  std::fclose(fp);
-  return ok;
+};
+bool map_part(const std::string& path, Part* p) {
+  const int fd = ::open(path.c_str(), O_RDONLY);
+  if (fd < 0) return false;
+  struct stat st;
+  bool ok = ::fstat(fd, &st) == 0 && st.st_size >= 16;
+  if (ok) {
+    p->bytes = (size_t)st.st_size;
+    p->map = ::mmap(nullptr, p->bytes, PROT_READ, MAP_PRIVATE, fd, 0);
+    ok = p->map != MAP_FAILED;
+    if (!ok) p->map = nullptr;
+  }
+  ::close(fd);
+  if (!ok) return false;
+  const uint8_t* at = (const uint8_t*)p->map;
+  std::memcpy(&p->nv, at, 8);
+  std::memcpy(&p->nf, at + 8, 8);
+  if (p->nv > (1ull << 32) || p->nf > (1ull << 34) || p->bytes != 16 + p->nv * 24 + p->nf * 20) { p->unmap(); return false; }
+  at += 16;
+  p->keys = (const uint64_t*)at;  at += p->nv * 8;
+  p->fkeys = (const uint64_t*)at; at += p->nf * 8;
+  p->xyz = (const float*)at;      at += p->nv * 12;
+  p->tris = (const uint32_t*)at;  at += p->nf * 12;
+  p->rgba = at;
+  return true;
 }
 
 std::string output_path(const Args& a) {
@@ -208,13 +230,15 @@ int fuse_scan(const Args& a) {
   uint64_t nv = 0, nf = 0;
   sf_mesh_counts(mesh, &nv, &nf);
   if (part) {
-    Part pt;
-    pt.xyz.resize(nv * 3); pt.rgba.resize(nv * 4); pt.keys.resize(nv); pt.tris.resize(nf * 3); pt.fkeys.resize(nf);
-    if (nv && sf_mesh_copy(mesh, pt.xyz.data(), pt.rgba.data(), pt.tris.data(), pt.keys.data()) != SF_OK) return die("mesh copy");
-    if (nf && sf_mesh_copy_face_keys(mesh, pt.fkeys.data()) != SF_OK) return die("face keys");
+    std::vector<float> xyz(nv * 3);
+    std::vector<uint8_t> rgba(nv * 4);
+    std::vector<uint64_t> keys(nv), fkeys(nf);
+    std::vector<uint32_t> tris(nf * 3);
+    if (nv && sf_mesh_copy(mesh, xyz.data(), rgba.data(), tris.data(), keys.data()) != SF_OK) return die("mesh copy");
+    if (nf && sf_mesh_copy_face_keys(mesh, fkeys.data()) != SF_OK) return die("face keys");
     const uint64_t hdr[2] = {nv, nf};
     if (!write_file(a.ipc + "/m" + std::to_string(a.rank) + ".bin",
-                    {{hdr, 16}, {pt.xyz.data(), nv * 12}, {pt.rgba.data(), nv * 4}, {pt.keys.data(), nv * 8}, {pt.tris.data(), nf * 12}, {pt.fkeys.data(), nf * 8}}))
+                    {{hdr, 16}, {keys.data(), nv * 8}, {fkeys.data(), nf * 8}, {xyz.data(), nv * 12}, {tris.data(), nf * 12}, {rgba.data(), nv * 4}}))
       return die_msg("could not write the mesh part into %s", a.ipc.c_str());
     say("Mesh part with %llu vertices, %llu faces handed to the parent\n", (unsigned long long)nv, (unsigned long long)nf);
   } else {
@@ -319,14 +343,13 @@ int run_ranks(const Args& a, int argc_in, const char** argv_in) {
     remove_exchange_dir(dir, a.ranks);
     return die_msg(g_stop ? "stopped by a signal; nothing written" : "a rank of the partitioned run failed (its message is above); nothing written");
   }
-  std::vector<Part> parts(a.ranks);
   std::vector<sf_mesh*> meshes(a.ranks, nullptr);
   int rc = 0;
   for (int r = 0; r < a.ranks && !rc; r++) {
-    if (!read_part(dir + "/m" + std::to_string(r) + ".bin", &parts[r])) { rc = die_msg("could not read the mesh part of rank %d", r); break; }
-    const Part& p = parts[r];
-    if (sf_mesh_create_keyed(p.xyz.data(), p.rgba.data(), p.keys.data(), p.nv, p.tris.data(), p.fkeys.data(), p.nf, &meshes[r]) != SF_OK) rc = die("mesh part");
-    parts[r] = Part();   // the handle holds its own copy
+    Part p;
+    if (!map_part(dir + "/m" + std::to_string(r) + ".bin", &p)) { rc = die_msg("could not read the mesh part of rank %d", r); break; }
+    if (sf_mesh_create_keyed(p.xyz, p.rgba, p.keys, p.nv, p.tris, p.fkeys, p.nf, &meshes[r]) != SF_OK) rc = die("mesh part");
+    p.unmap();   // the handle holds its own copy
   }
   remove_exchange_dir(dir, a.ranks);
   sf_mesh* merged = nullptr;
