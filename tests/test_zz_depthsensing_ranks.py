@@ -109,8 +109,9 @@ def test_tool_logic_ranks_write_the_one_rank_file(fake_tool, tmp_path):
     assert rc == 0 and err == "" and "Mesh with" in out and "[rank" not in out
     whole = open(one, "rb").read()
     before = _exchange_dirs()
+    # (8 ranks over the stand-in's 6 stripes: two ranks own nothing and hand over empty parts)
     for extra, env in ((["--ranks", "2"], {}), (["--ranks=3"], {}), (["--ranks=4"], {}), (["--ranks=3"], {"SF_DEVICE": "1"}),
-                       (["--ranks=6", "--share-gpu"], {"FAKE_DEVICES": "1"}), (["--ranks=8"], {"FAKE_DEVICES": "8"}),   # 8 ranks over 6 stripes: two own nothing (["--ranks=3"], {"FAKE_SLOW_DEVICE": "1"}), (["--ranks=2"], {"FAKE_SLOW_DEVICE": "0"})):
+                       (["--ranks=6", "--share-gpu"], {"FAKE_DEVICES": "1"}), (["--ranks=8"], {"FAKE_DEVICES": "8"}), (["--ranks=3"], {"FAKE_SLOW_DEVICE": "1"}), (["--ranks=2"], {"FAKE_SLOW_DEVICE": "0"})):
         n = int(extra[0].split("=")[1]) if "=" in extra[0] else int(extra[1])
         ply = str(tmp_path / "parts.ply")
         rc, out, err = _run(extra + args + [ply], tool=fake_tool, env=env)
