@@ -315,7 +315,7 @@ SF_API int sf_capture_open(const char* any_capture_file, sf_capture** out) {
     off += len;
   }
   c->ts_depth.assign(n, 0.0);
-  if (off + 8 * n <= total) std::memcpy(c->ts_depth.data(), &c->depth_file[off], 8 * n);  // a capture cut short has none: zeros
+  if (n != 0 && off + 8 * n <= total) std::memcpy(c->ts_depth.data(), &c->depth_file[off], 8 * n);  // a capture cut short has none: zeros (n = 0: nothing to copy, and no NULL into memcpy)
   if (!read_file(c->base + ".imu", c->imu)) c->imu.clear();  // optional here; the convert tool insists on it as the reference does
   *out = c;
   return SF_OK;

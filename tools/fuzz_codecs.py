@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Mutation fuzzing of the parsers a .sens file (and the mesh tools) feed with untrusted bytes -- baseline JPEG, zlib inflate, PNG, PLY, the
-Occipital depth code -- against the ASan + UBSan build of the host code (tools/sanitize.py): valid inputs are truncated, bit-flipped,
+"""Mutation fuzzing of the parsers a .sens file (and the mesh tools) feed with untrusted bytes -- baseline JPEG, zlib inflate, PNG, PLY / OBJ (and the Segmentator
+behind them), the Occipital depth code, the .sens container, ScannerApp captures, parameter files and filter scripts -- against the ASan + UBSan build of the host code (tools/sanitize.py): valid inputs are truncated, bit-flipped,
 spliced and length-poked; every call must return (SF_OK or an error), never trip a sanitizer.
 
     python tools/fuzz_codecs.py [iterations per codec = 4000] [seed = 1]      # builds the sanitizer library if needed, re-executes under libasan
@@ -206,6 +206,52 @@ def main():
     for it in range(n_iter // 2):
         open(path, "wb").write(mutate(rng, ptxt if it & 1 else mtxt))
         tally("text", L.sf_params_load_file(path, C.byref(pp)) if it & 1 else L.sf_mlx_load(path, C.byref(ms)))
+    # ---- a ScannerApp capture (<base>.txt + .depth): the metadata file or the frame stream damaged, every frame of whatever opens decoded
+    # (round 5: numDepthFrames = 0 reached memcpy with a NULL destination in sf_capture_open)
+    from scannet_amd import capture
+    base = os.path.join(tmp, "cap")
+    meta = [tuple(x.split(" = ")) for x in ("colorWidth = 32", "colorHeight = 24", "depthWidth = 32", "depthHeight = 24", "fx_color = 30", "fy_color = 30", "mx_color = 16",
+                                             "my_color = 12", "fx_depth = 30", "fy_depth = 30", "mx_depth = 16", "my_depth = 12", "numDepthFrames = 2", "numColorFrames = 2",
+                                             "numIMUmeasurements = 0")]
+    capture.write_capture(base, [rng.integers(0, 2048, (24, 32)).astype(np.uint16) for _ in range(2)], [0.1, 0.2], meta)
+    good = {ext: open(base + ext, "rb").read() for ext in (".txt", ".depth")}
+    cl = capture._lib()
+    for it in range(n_iter // 4):
+        ext = ".txt" if it & 1 else ".depth"
+        open(base + ext, "wb").write(mutate(rng, good[ext]))
+        h = vp()
+        rc = cl.sf_capture_open((base + ".txt").encode(), C.byref(h))
+        if rc == 0:
+            m = capture.SfCaptureMeta()
+            cl.sf_capture_get_meta(h, C.byref(m))
+            npx = int(m.depth_width) * int(m.depth_height)
+            if 0 < npx <= 1 << 22:
+                dd, ts = np.zeros(npx, np.uint16), C.c_uint64(0)
+                for fr in range(min(int(m.num_depth_frames), 4)):
+                    cl.sf_capture_decode_depth(h, fr, dd.ctypes.data, C.byref(ts))
+            cl.sf_capture_close(h)
+        open(base + ext, "wb").write(good[ext])
+        tally("capture", rc)
+    # ---- .obj through the mesh reader, and whatever mesh comes out through the Segmentator (indices of a damaged file must not reach it unchecked)
+    obj = ("".join("v %f %f %f\n" % tuple(x) for x in v) + "".join("f %d %d %d\n" % tuple(int(i) + 1 for i in f) for f in t)).encode()
+    L.sf_mesh_counts.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.sf_mesh_copy.argtypes = [vp, vp, vp, vp, vp]
+    L.sf_segment_mesh.argtypes = [vp, C.c_uint64, vp, C.c_uint64, C.c_float, C.c_int, vp]
+    path = os.path.join(tmp, "f.obj").encode()
+    path_ply = os.path.join(tmp, "g.ply").encode()
+    for it in range(n_iter // 4):
+        src, pth = (obj, path) if it & 1 else (plys[0], path_ply)
+        open(pth, "wb").write(mutate(rng, src))
+        rc = L.sf_ply_read(pth, C.byref(mh))
+        if rc == 0:
+            nv, nf = C.c_uint64(0), C.c_uint64(0)
+            L.sf_mesh_counts(mh, C.byref(nv), C.byref(nf))
+            if nv.value < 1 << 20 and nf.value < 1 << 20:
+                xyz, tri, seg = np.zeros(max(nv.value, 1) * 3, np.float32), np.zeros(max(nf.value, 1) * 3, np.uint32), np.zeros(max(nv.value, 1), np.int32)
+                L.sf_mesh_copy(mh, xyz.ctypes.data, None, tri.ctypes.data, None)
+                L.sf_segment_mesh(xyz.ctypes.data, nv.value, tri.ctypes.data, nf.value, 0.01, 20, seg.ctypes.data)
+            L.sf_mesh_free(mh)
+        tally("obj/segment", rc)
     for name, (ok, err) in counts.items():
         print("fuzz %-10s %6d decoded, %6d rejected" % (name, ok, err))
     print("fuzz: no sanitizer report")
