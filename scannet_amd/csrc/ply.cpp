@@ -600,9 +600,10 @@ SF_API int sf_mesh_write_ply(const sf_mesh* m, const char* path) {
                                "property uchar red\nproperty uchar green\nproperty uchar blue\nproperty uchar alpha\nelement face %llu\n"
                                "property list uchar int vertex_indices\nend_header\n",
                                (unsigned long long)nv, (unsigned long long)nf);
-  auto write_at = [fd](const uint8_t* src, size_t n, uint64_t off) {
+  const bool seekable = ::lseek(fd, 0, SEEK_CUR) != (off_t)-1;   // a pipe or a terminal (/dev/stdout): one thread, plain writes in file order
+  auto write_at = [fd, seekable](const uint8_t* src, size_t n, uint64_t off) {
     while (n) {
-      const ssize_t w = ::pwrite(fd, src, n, (off_t)off);
+      const ssize_t w = seekable ? ::pwrite(fd, src, n, (off_t)off) : ::write(fd, src, n);
       if (w < 0 && errno == EINTR) continue;
       if (w <= 0) return false;
       src += w; n -= (size_t)w; off += (uint64_t)w;
@@ -611,7 +612,7 @@ SF_API int sf_mesh_write_ply(const sf_mesh* m, const char* path) {
   };
   std::atomic<bool> ok{write_at((const uint8_t*)header, (size_t)hl, 0)};
   const uint64_t off_v = (uint64_t)hl, off_f = off_v + nv * 16;
-  const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)sf::usable_cpus(), 16, (nv + nf) / 500000 + 1}));
+  const int T = !seekable ? 1 : (int)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)sf::usable_cpus(), 16, (nv + nf) / 500000 + 1}));
   const uint64_t CHUNK = 1 << 18;   // records per buffer
   parallel_for(T, [&](int t) {
     sf::mesh_vec<uint8_t> buf(CHUNK * 16);

@@ -34,3 +34,20 @@ def test_ply_write_failure_is_reported(tmp_path):
     m = Mesh.from_arrays(np.zeros((3, 3), np.float32), np.array([[0, 1, 2]], np.uint32))
     with pytest.raises(Exception, match="unable to open"):
         m.write_ply(str(tmp_path / "no" / "such" / "dir" / "m.ply"))
+
+
+def test_ply_into_a_pipe(tmp_path):
+    """A destination that cannot seek (a FIFO, /dev/stdout) gets the same bytes from one thread writing in file order."""
+    import os
+    import subprocess
+    rng = np.random.default_rng(1)
+    nv, nf = 600001, 700003
+    m = Mesh.from_arrays(rng.standard_normal((nv, 3)).astype(np.float32), rng.integers(0, nv, (nf, 3)).astype(np.uint32), rgba=rng.integers(0, 256, (nv, 4), dtype=np.uint8))
+    plain, fifo, got = str(tmp_path / "file.ply"), str(tmp_path / "fifo.ply"), str(tmp_path / "from_fifo.ply")
+    m.write_ply(plain)
+    os.mkfifo(fifo)
+    with open(got, "wb") as out:
+        p = subprocess.Popen(["cat", fifo], stdout=out)
+        m.write_ply(fifo)
+        assert p.wait(timeout=60) == 0
+    assert open(plain, "rb").read() == open(got, "rb").read()
