@@ -402,6 +402,9 @@ int sf_filter2d_frame(sf_filter2d* f, const uint16_t* depth, const uint8_t* rgb,
  * write.  *data is malloc'ed (sf_free); 16-bit samples are in host byte order. */
 int sf_png_read(const char* path, uint32_t* width, uint32_t* height, int* channels, int* bits, void** data);
 int sf_png_write_gray(const char* path, const void* data, uint32_t width, uint32_t height, int bits);
+/* grey (channels = 1) or RGB (channels = 3), 8 or 16 bits: the 16-bit depth PNGs of SensReader/python/SensorData.py:78-91 (pypng there) and the
+ * colour PNG that SensorData::saveToImages makes of a TYPE_RAW colour frame (sensorData.h:1432-1440) */
+int sf_png_write(const char* path, const void* data, uint32_t width, uint32_t height, int channels, int bits);
 void sf_free(void* p);
 
 /* ------------------------------------------------------------------------------------------------

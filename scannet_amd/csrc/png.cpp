@@ -235,10 +235,11 @@ SF_API int sf_png_read(const char* path, uint32_t* width, uint32_t* height, int*
 
 SF_API void sf_free(void* p) { std::free(p); }
 
-// Writes a grey image (bits = 8: uint8 samples, bits = 16: uint16 samples in host byte order).
-SF_API int sf_png_write_gray(const char* path, const void* data, uint32_t width, uint32_t height, int bits) {
-  if (!path || !data || width == 0 || height == 0 || (bits != 8 && bits != 16)) return sf::fail(SF_ERR_INVALID_ARG, "sf_png_write_gray: bad argument");
-  const size_t bpp = bits / 8, stride = (size_t)width * bpp;
+// Writes a grey (channels = 1) or RGB (channels = 3) image; bits = 8: uint8 samples, bits = 16: uint16 samples in host byte order.
+SF_API int sf_png_write(const char* path, const void* data, uint32_t width, uint32_t height, int channels, int bits) {
+  if (!path || !data || width == 0 || height == 0 || (bits != 8 && bits != 16) || (channels != 1 && channels != 3))
+    return sf::fail(SF_ERR_INVALID_ARG, "sf_png_write: bad argument (grey or RGB, 8 or 16 bits)");
+  const size_t bpp = bits / 8, stride = (size_t)width * bpp * channels;
   std::vector<uint8_t> raw((stride + 1) * height);
   const uint8_t* src = (const uint8_t*)data;
   // filter 2 (Up) on every row but the first: label and instance images are piecewise constant, so the difference to the row above is
@@ -266,7 +267,7 @@ SF_API int sf_png_write_gray(const char* path, const void* data, uint32_t width,
   };
   std::vector<uint8_t> ihdr;
   put32(ihdr, width); put32(ihdr, height);
-  ihdr.push_back((uint8_t)bits); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+  ihdr.push_back((uint8_t)bits); ihdr.push_back(channels == 3 ? 2 : 0); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
   chunk("IHDR", ihdr.data(), ihdr.size());
   chunk("IDAT", z.data(), (size_t)zn);
   chunk("IEND", nullptr, 0);
@@ -276,3 +277,5 @@ SF_API int sf_png_write_gray(const char* path, const void* data, uint32_t width,
   std::fclose(fp);
   return ok ? SF_OK : sf::fail(SF_ERR_IO, "short write to %s", path);
 }
+
+SF_API int sf_png_write_gray(const char* path, const void* data, uint32_t width, uint32_t height, int bits) { return sf_png_write(path, data, width, height, 1, bits); }

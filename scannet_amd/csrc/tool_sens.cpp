@@ -1,0 +1,152 @@
+// tool_sens.cpp -- drop-in for the reference's .sens exporter, SensReader/c++ `sens <sensFile> <outputDir>` (src/main.cpp:35-106, README.txt:3-9):
+// every frame spat out as an image pair and a pose, the header as text --
+//     <outputDir>/_info.txt                     sensorData.h:1383-1407  (names " = " values; the four 4x4 matrices row-major, 16 numbers and a trailing blank)
+//     <outputDir>/frame-%06d.color.jpg | .png   :1431-1450  the stored JPEG / PNG blob as it is; a TYPE_RAW frame as a PNG made here (the reference needs
+//                                                           its Windows-only encoder for that one, :576-593: off Windows it throws after _info.txt)
+//     <outputDir>/frame-%06d.depth.pgm          :1342-1359  binary PGM, comment line with the depth shift, 16-bit samples big-endian
+//     <outputDir>/frame-%06d.pose.txt           :1706-1714  camera-to-world, four rows, no newline after the last
+// The file names count as the reference's StringCounter does (:1317-1328), the numbers are written by the same iostream formatting, stdout follows
+// main.cpp (header dump :1941-1955, "[ processing frame i of n ]" progress, "All done :)"), failures print "Exception caught! ..." and exit non-zero.
+// tests/test_sens_export.py holds the output directory against the compiled reference's, byte for byte.
+// Thin C++ host over libscanfuse.so's C ABI (sf_sens_open / frame_blobs / decode_depth / pose); no GPU involved.
+#include <sys/stat.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <limits>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "scanfuse.h"
+
+namespace {
+
+struct Counter {   // StringCounter (sensorData.h:1292-1337): base + zero padding to `digits` + count + ending
+  std::string base, ending;
+  unsigned digits, current = 0;
+  Counter(const std::string& b, const std::string& e, unsigned d) : base(b), ending(e[0] == '.' ? e : "." + e), digits(d) {}
+  std::string next() {
+    std::stringstream ss;
+    ss << base;
+    for (unsigned i = std::max(1u, (unsigned)ceilf(log10f((float)current + 1))); i < digits; i++) ss << "0";
+    ss << current++ << ending;
+    return ss.str();
+  }
+};
+
+int fail(const std::string& what) {   // main.cpp:82-90
+  std::cout << "Exception caught! " << what << std::endl;
+  return EXIT_FAILURE;
+}
+
+bool write_blob(const std::string& path, const void* data, size_t n) {
+  FILE* fp = std::fopen(path.c_str(), "wb");
+  if (!fp) return false;
+  const bool ok = n == 0 || std::fwrite(data, 1, n, fp) == n;
+  return std::fclose(fp) == 0 && ok;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  std::string filename = "scene0001_00.sens", out_dir = "./out/";
+  if (argc >= 2) filename = argv[1];
+  else {
+    std::cout << "run ./sens <sensfilename>.sens";
+    std::cout << "type in filename manually: ";
+    std::cin >> filename;
+  }
+  if (argc >= 3) out_dir = argv[2];
+  std::cout << "filename =\t" << filename << std::endl;
+  std::cout << "outDir =\t" << out_dir << std::endl;
+  std::cout << "loading from file... ";
+  sf_sens* s = nullptr;
+  if (sf_sens_open(filename.c_str(), &s) != SF_OK) return fail(sf_last_error());
+  std::cout << "done!" << std::endl;
+  sf_sens_info info;
+  sf_sens_get_info(s, &info);
+  std::cout << "CalibratedSensorData:\n"
+            << "\tsensorData.m_versionNumber=" << info.version << '\n'
+            << "\tsensorData.m_sensorName=" << info.sensor_name << '\n'
+            << "\tsensorData.m_colorWidth=" << info.color_width << '\n'
+            << "\tsensorData.m_colorHeight=" << info.color_height << '\n'
+            << "\tsensorData.m_depthWidth=" << info.depth_width << '\n'
+            << "\tsensorData.m_depthHeight=" << info.depth_height << '\n'
+            << "\tsensorData.m_depthShift=" << info.depth_shift << '\n'
+            << "\tsensorData.m_frames.size()=" << info.num_frames << '\n'
+            << "\tsensorData.m_IMUFrames.size()=" << info.num_imu << '\n'
+            << std::endl;
+  struct stat st;
+  if (::stat(out_dir.c_str(), &st) != 0) ::mkdir(out_dir.c_str(), 0777);   // one level, as ml::util::makeDirectory
+  {
+    std::ofstream meta(out_dir + "/_info.txt");
+    if (!meta) return fail("cannot open file " + out_dir + "/_info.txt");
+    meta << "m_versionNumber = " << info.version << '\n';
+    meta << "m_sensorName = " << info.sensor_name << '\n';
+    meta << "m_colorWidth = " << info.color_width << '\n';
+    meta << "m_colorHeight = " << info.color_height << '\n';
+    meta << "m_depthWidth = " << info.depth_width << '\n';
+    meta << "m_depthHeight = " << info.depth_height << '\n';
+    meta << "m_depthShift = " << info.depth_shift << '\n';
+    const struct { const char* name; const float* m; } mats[4] = {{"m_calibrationColorIntrinsic", info.color_intrinsic}, {"m_calibrationColorExtrinsic", info.color_extrinsic},
+                                                                 {"m_calibrationDepthIntrinsic", info.depth_intrinsic}, {"m_calibrationDepthExtrinsic", info.depth_extrinsic}};
+    for (const auto& m : mats) {
+      meta << m.name << " = ";
+      for (int i = 0; i < 16; i++) meta << m.m[i] << " ";
+      meta << "\n";
+    }
+    meta << "m_frames.size = " << info.num_frames << "\n";
+    if (info.num_imu > 0) std::cout << "warning sensor has imu frames; but writing is not implemented here" << std::endl;
+  }
+  if (info.num_frames != 0) {
+    const std::string color_ending = info.color_compression == 2 ? "jpg" : "png";
+    Counter color(out_dir + "/frame-", "color." + color_ending, 6), pose(out_dir + "/frame-", ".pose.txt", 6), pgm(out_dir + "/frame-", "depth.pgm", 6);
+    std::cout << std::endl;
+    std::vector<uint16_t> depth((size_t)info.depth_width * info.depth_height);
+    for (uint64_t i = 0; i < info.num_frames; i++) {
+      std::cout << "\r[ processing frame " << std::to_string(i) << " of " << std::to_string(info.num_frames) << " ]";
+      const std::string color_file = color.next(), pose_file = pose.next(), pgm_file = pgm.next();
+      const uint8_t *cblob = nullptr, *dblob = nullptr;
+      uint64_t cbytes = 0, dbytes = 0;
+      if (sf_sens_frame_blobs(s, i, &cblob, &cbytes, &dblob, &dbytes) != SF_OK) return fail(sf_last_error());
+      if (info.color_compression == 0 && cbytes != 0) {   // TYPE_RAW pixels: a PNG of them
+        if (cbytes != (uint64_t)info.color_width * info.color_height * 3) return fail("raw colour frame of " + std::to_string(cbytes) + " bytes");
+        if (sf_png_write(color_file.c_str(), cblob, info.color_width, info.color_height, 3, 8) != SF_OK) return fail("cannot open file " + color_file);
+      } else if (info.color_compression == 0) {
+        // a TYPE_RAW file without colour (depth only): no colour file (the reference throws on the first frame of any TYPE_RAW file off Windows)
+      } else if (info.color_compression == 1 || info.color_compression == 2) {
+        if (!write_blob(color_file, cblob, (size_t)cbytes)) return fail("cannot open file " + color_file);
+      } else {
+        return fail("unknown format");
+      }
+      if (sf_sens_decode_depth(s, i, depth.data()) != SF_OK) return fail(sf_last_error());
+      {
+        std::ofstream of(pgm_file, std::ios::binary);
+        std::stringstream ss;
+        ss << "P5\n";
+        ss << "# data values are 16-bit each; depth shift is " << info.depth_shift << "\n";
+        ss << info.depth_width << " " << info.depth_height << "\n";
+        ss << std::numeric_limits<unsigned short>::max() << "\n";
+        of << ss.str();
+        for (uint16_t& v : depth) v = (uint16_t)((v << 8) | (v >> 8));   // PGM samples are big-endian
+        of.write((const char*)depth.data(), (std::streamsize)(depth.size() * 2));
+      }
+      float m[16];
+      int valid = 0;
+      if (sf_sens_pose(s, i, m, &valid) != SF_OK) return fail(sf_last_error());
+      std::ofstream pf(pose_file);
+      pf << m[0] << " " << m[1] << " " << m[2] << " " << m[3] << "\n"
+         << m[4] << " " << m[5] << " " << m[6] << " " << m[7] << "\n"
+         << m[8] << " " << m[9] << " " << m[10] << " " << m[11] << "\n"
+         << m[12] << " " << m[13] << " " << m[14] << " " << m[15];
+    }
+  }
+  std::cout << std::endl;
+  std::cout << "All done :)" << std::endl;
+  sf_sens_close(s);
+  return 0;
+}

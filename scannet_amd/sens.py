@@ -236,11 +236,43 @@ class SensorData:
                 name = "%s_%s" % (kind, camera)
                 self.save_mat_to_file(getattr(self, name), os.path.join(output_path, name + ".txt"))
 
-    def export_depth_images(self, output_path, frame_skip=1):
-        """16-bit PGM dumps (the reference writes 16-bit PNG through pypng, which is not available here)."""
+    @staticmethod
+    def _resize_nearest(image, image_size):
+        """cv2.resize(image, (image_size[1], image_size[0]), interpolation=cv2.INTER_NEAREST) as SensorData.py:84,99 calls it (image_size = (height,
+        width)): destination pixel (y, x) takes source pixel (min(floor(y * H / h), H - 1), min(floor(x * W / w), W - 1))."""
+        h, w = int(image_size[0]), int(image_size[1])
+        H, W = image.shape[:2]
+        ys = np.minimum(np.floor(np.arange(h) * (H / h)).astype(np.int64), H - 1)
+        xs = np.minimum(np.floor(np.arange(w) * (W / w)).astype(np.int64), W - 1)
+        return np.ascontiguousarray(image[ys][:, xs])
+
+    def export_depth_images(self, output_path, image_size=None, frame_skip=1):
+        """<output_path>/<frame index>.png: 16-bit grey PNG of every frame_skip-th depth frame (SensorData.py:78-91; written by sf_png_write, the
+        reference goes through pypng), optionally resized to image_size = (height, width) with nearest-neighbour sampling."""
         os.makedirs(output_path, exist_ok=True)
+        L = _abi.lib()
+        L.sf_png_write.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
         for f in range(0, len(self.frames), frame_skip):
             d = self.frames[f].decompress_depth()
-            with open(os.path.join(output_path, str(f) + '.pgm'), 'wb') as fh:
-                fh.write(b"P5\n%d %d\n65535\n" % (d.shape[1], d.shape[0]))
-                fh.write(d.astype('>u2').tobytes())
+            if image_size is not None:
+                d = self._resize_nearest(d, image_size)
+            check(L.sf_png_write(os.fsencode(os.path.join(output_path, str(f) + ".png")), _ptr(d), d.shape[1], d.shape[0], 1, 16))
+
+    def export_color_images(self, output_path, image_size=None, frame_skip=1):
+        """<output_path>/<frame index>.jpg of every frame_skip-th colour frame (SensorData.py:93-101).  The reference decodes every frame and encodes
+        it again (imageio); a stored JPEG that is not resized is written as it is here -- the camera's own bytes, no second generation loss --,
+        anything else (raw / PNG colour, or image_size given) is decoded, resized nearest-neighbour and encoded by sf_jpeg_encode (quality 75,
+        imageio's default)."""
+        from . import calibrate
+        os.makedirs(output_path, exist_ok=True)
+        for f in range(0, len(self.frames), frame_skip):
+            frame = self.frames[f]
+            if image_size is None and self.color_compression_type == "jpeg":
+                blob = frame.color_compressed
+            else:
+                color = frame.decompress_color()
+                if image_size is not None:
+                    color = self._resize_nearest(color, image_size)
+                blob = calibrate.jpeg_encode(color, 75, True)
+            with open(os.path.join(output_path, str(f) + ".jpg"), "wb") as out:
+                out.write(blob)

@@ -1,0 +1,159 @@
+"""The exporters either side of the .sens reader: `bin/sens <file> <outDir>` (drop-in of SensReader/c++ main.cpp: frame-%06d.color.jpg / .depth.pgm /
+.pose.txt + _info.txt) and the Python exports of SensReader/python (reader.py, SensorData.py:78-124).  bin/sens is held against the REFERENCE exporter
+byte for byte: against the committed golden directory everywhere (tests/golden/sens_export, made by make_sens_export.py from oracle/_ref/sens_ref),
+and against the compiled reference itself on more files where it is built.  No GPU."""
+import filecmp
+import io
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from scannet_amd import calibrate, sens, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOL = os.path.join(ROOT, "bin", "sens")
+REF = os.path.join(ROOT, "oracle", "_ref", "sens_ref")
+GOLD = os.path.join(ROOT, "tests", "golden", "sens_export")
+
+
+def _same_dirs(a, b):
+    names = sorted(os.listdir(a))
+    assert names == sorted(os.listdir(b))
+    match, mismatch, errors = filecmp.cmpfiles(a, b, names, shallow=False)
+    assert mismatch == [] and errors == [] and len(match) == len(names)
+    return names
+
+
+def test_bin_sens_writes_the_reference_exporters_bytes(tmp_path):
+    """The golden scan: 14 frames (the file names cross frame-000009 / -000010), JPEG colour, one -inf pose, a sensor name with a blank."""
+    r = subprocess.run([TOOL, "scan.sens", str(tmp_path / "out")], capture_output=True, cwd=GOLD)
+    assert r.returncode == 0 and r.stderr == b""
+    names = _same_dirs(os.path.join(GOLD, "reference_out"), str(tmp_path / "out"))
+    assert len(names) == 1 + 3 * 14 and "frame-000013.depth.pgm" in names and "_info.txt" in names
+    want = open(os.path.join(GOLD, "reference_stdout.txt"), "rb").read()
+    assert r.stdout.replace(str(tmp_path / "out").encode(), b"reference_out") == want
+    assert open(str(tmp_path / "out" / "frame-000004.pose.txt")).read() == "\n".join(["-inf -inf -inf -inf"] * 4)
+
+
+def _scan(path, n, W, H, colour, rng):
+    K = synth.intrinsic_matrix(W, H)
+    KC = synth.intrinsic_matrix(2 * W, 2 * H) if colour == "jpeg_big" else K
+    cw, ch = (2 * W, 2 * H) if colour == "jpeg_big" else (W, H)
+    ctype = {"jpeg": 2, "jpeg_big": 2, "png": 1, "raw": 0, "none": 0}[colour]
+    sd = sens.SensorData.create(cw if colour != "none" else 0, ch if colour != "none" else 0, W, H, KC, K, color_compression=ctype, depth_compression=1,
+                                sensor_name="StructureSensor")
+    yy, xx = np.mgrid[0:ch, 0:cw]
+    pictures = [np.clip(np.stack([xx * 255 // cw, yy * 255 // ch, (xx + yy) * 127 // (cw + ch) + 60 * k], -1) + rng.integers(-8, 9, (ch, cw, 3)), 0, 255).astype(np.uint8)
+                for k in range(2)]     # smooth with a little noise: a JPEG of it stays close to it
+    depths = []
+    for i in range(n):
+        pose = synth.trajectory_pose(i * 11, 1200) * np.float32(1 + 1e-3 * i)
+        d = rng.integers(0, 65536, (H, W), dtype=np.uint16)
+        depths.append(d)
+        if colour in ("jpeg", "jpeg_big"):
+            sd.add_frame(d, pose, color=calibrate.jpeg_encode(pictures[i % 2], 85, True), timestamp_depth=i)
+        elif colour == "png":
+            from PIL import Image
+            bio = io.BytesIO()
+            Image.fromarray(pictures[i % 2]).save(bio, "PNG")
+            sd.add_frame_blobs(sens.zlib_deflate(d.tobytes()), pose, color_blob=bio.getvalue(), timestamp_depth=i)
+        elif colour == "raw":
+            sd.add_frame(d, pose, color=pictures[i % 2], timestamp_depth=i)
+        else:
+            sd.add_frame(d, pose, timestamp_depth=i)
+    sd.save(path)
+    sd.close()
+    return depths, pictures
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/sens_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("colour,n", [("jpeg", 3), ("jpeg_big", 11), ("png", 5), ("jpeg", 101)])
+def test_bin_sens_against_the_compiled_reference(tmp_path, colour, n):
+    _scan(str(tmp_path / "s.sens"), n, 40, 30, colour, np.random.default_rng(n))
+    a = subprocess.run([REF, "s.sens", "ref"], capture_output=True, cwd=str(tmp_path))
+    b = subprocess.run([TOOL, "s.sens", "our"], capture_output=True, cwd=str(tmp_path))
+    assert a.returncode == 0 and b.returncode == 0
+    names = _same_dirs(str(tmp_path / "ref"), str(tmp_path / "our"))
+    assert len(names) == 1 + 3 * n and ("frame-%06d.color.%s" % (n - 1, "png" if colour == "png" else "jpg")) in names
+    assert a.stdout.replace(b"ref", b"our") == b.stdout
+
+
+def test_bin_sens_on_raw_colour_and_on_depth_only_files(tmp_path):
+    """TYPE_RAW colour: the reference needs its Windows-only encoder (sensorData.h:576-593: off Windows it throws on the first frame, after _info.txt);
+    here the pixels become a PNG.  A depth-only file gets no colour files.  _info.txt is the reference's in both cases."""
+    from PIL import Image
+    depths, pictures = _scan(str(tmp_path / "raw.sens"), 3, 40, 30, "raw", np.random.default_rng(1))
+    r = subprocess.run([TOOL, "raw.sens", "out"], capture_output=True, cwd=str(tmp_path))
+    assert r.returncode == 0
+    for i in range(3):
+        assert np.array_equal(np.asarray(Image.open(str(tmp_path / "out" / ("frame-%06d.color.png" % i)))), pictures[i % 2])
+        pgm = open(str(tmp_path / "out" / ("frame-%06d.depth.pgm" % i)), "rb").read()
+        head = b"P5\n# data values are 16-bit each; depth shift is 1000\n40 30\n65535\n"
+        assert pgm.startswith(head) and np.array_equal(np.frombuffer(pgm[len(head):], ">u2").reshape(30, 40), depths[i])
+    _scan(str(tmp_path / "d.sens"), 2, 40, 30, "none", np.random.default_rng(2))
+    r = subprocess.run([TOOL, "d.sens", "dout"], capture_output=True, cwd=str(tmp_path))
+    assert r.returncode == 0 and sorted(os.listdir(str(tmp_path / "dout"))) == ["_info.txt", "frame-000000.depth.pgm", "frame-000000.pose.txt", "frame-000001.depth.pgm",
+                                                                                "frame-000001.pose.txt"]
+    if os.path.exists(REF):
+        a = subprocess.run([REF, "raw.sens", "ref"], capture_output=True, cwd=str(tmp_path))
+        assert a.returncode != 0 and b"need UPLINK_COMPRESSION" in a.stdout          # what the reference does with such a file here
+        assert open(str(tmp_path / "ref" / "_info.txt"), "rb").read() == open(str(tmp_path / "out" / "_info.txt"), "rb").read()
+    # failure protocol of main.cpp: the message on stdout, a non-zero exit
+    bad = subprocess.run([TOOL, "missing.sens", "x"], capture_output=True, cwd=str(tmp_path))
+    assert bad.returncode != 0 and b"Exception caught!" in bad.stdout
+
+
+def test_python_exports(tmp_path):
+    """SensorData.py:78-124 / reader.py: depth/<i>.png 16-bit grey, color/<i>.jpg, pose/<i>.txt, intrinsic/*.txt."""
+    from PIL import Image
+    from scannet_amd import reader
+    depths, pictures = _scan(str(tmp_path / "s.sens"), 5, 40, 30, "jpeg", np.random.default_rng(3))
+    assert reader.main(["--filename", str(tmp_path / "s.sens"), "--output_path", str(tmp_path / "out"), "--export_depth_images", "--export_color_images", "--export_poses",
+                        "--export_intrinsics"]) == 0
+    sd = sens.SensorData(str(tmp_path / "s.sens"))
+    for i in range(5):
+        im = Image.open(str(tmp_path / "out" / "depth" / ("%d.png" % i)))
+        assert im.mode in ("I;16", "I;16B", "I") and np.array_equal(np.asarray(im).astype(np.uint16), depths[i])
+        assert open(str(tmp_path / "out" / "color" / ("%d.jpg" % i)), "rb").read() == sd.frames[i].color_compressed     # the stored picture, not a re-encoding
+        rows = open(str(tmp_path / "out" / "pose" / ("%d.txt" % i))).read().splitlines()
+        assert rows == [" ".join("%f" % v for v in row) for row in sd.frames[i].camera_to_world]
+    assert sorted(os.listdir(str(tmp_path / "out" / "intrinsic"))) == ["extrinsic_color.txt", "extrinsic_depth.txt", "intrinsic_color.txt", "intrinsic_depth.txt"]
+    # image_size = (height, width), every second frame: cv2.INTER_NEAREST's sampling rule
+    sd.export_depth_images(str(tmp_path / "small"), image_size=(12, 16), frame_skip=2)
+    sd.export_color_images(str(tmp_path / "smallc"), image_size=(12, 16), frame_skip=2)
+    assert sorted(os.listdir(str(tmp_path / "small"))) == ["0.png", "2.png", "4.png"]
+    ys, xs = np.minimum((np.arange(12) * 30 / 12).astype(int), 29), np.minimum((np.arange(16) * 40 / 16).astype(int), 39)
+    assert np.array_equal(np.asarray(Image.open(str(tmp_path / "small" / "2.png"))).astype(np.uint16), depths[2][ys][:, xs])
+    small = np.asarray(Image.open(str(tmp_path / "smallc" / "2.jpg")))
+    want = sd.frames[2].decompress_color()[ys][:, xs]
+    assert small.shape == (12, 16, 3) and np.abs(small.astype(int) - want.astype(int)).mean() < 12      # a JPEG of the resized picture
+    sd.close()
+    # the module as a command, as reader.py is run
+    r = subprocess.run([sys.executable, "-m", "scannet_amd.reader", "--filename", str(tmp_path / "s.sens"), "--output_path", str(tmp_path / "o2"), "--export_poses"],
+                       capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0 and "exporting 5 camera poses to" in r.stdout and len(os.listdir(str(tmp_path / "o2" / "pose"))) == 5
+
+
+def test_png_writer_rgb_and_grey(tmp_path):
+    from PIL import Image
+    import ctypes as C
+    from scannet_amd import _abi
+    L = _abi.lib()
+    L.sf_png_write.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
+    rng = np.random.default_rng(0)
+    for shape, ch, bits, dt in (((17, 23, 3), 3, 8, np.uint8), ((17, 23), 1, 8, np.uint8), ((17, 23), 1, 16, np.uint16), ((9, 5, 3), 3, 16, np.uint16)):
+        a = rng.integers(0, 1 << bits, shape).astype(dt)
+        p = str(tmp_path / ("p_%d_%d.png" % (ch, bits)))
+        assert L.sf_png_write(p.encode(), a.ctypes.data, shape[1], shape[0], ch, bits) == 0
+        if ch == 3 and bits == 16:      # PIL narrows 16-bit RGB to 8: read it back with this library's reader
+            w, h, c, b, data = C.c_uint32(), C.c_uint32(), C.c_int(), C.c_int(), C.c_void_p()
+            assert L.sf_png_read(p.encode(), C.byref(w), C.byref(h), C.byref(c), C.byref(b), C.byref(data)) == 0
+            back = np.ctypeslib.as_array(C.cast(data, C.POINTER(C.c_uint16)), shape=shape).copy()
+            L.sf_free(data)
+            assert (w.value, h.value, c.value, b.value) == (5, 9, 3, 16) and np.array_equal(back, a)
+        else:
+            assert np.array_equal(np.asarray(Image.open(p)).astype(dt), a)
+    assert L.sf_png_write(b"/tmp/x.png", a.ctypes.data, 5, 9, 2, 8) != 0
