@@ -287,8 +287,12 @@ int sf_sens_set_pose(sf_sens* s, uint64_t frame, const float pose[16]);
 int sf_sens_save(const sf_sens* s, const char* path);
 
 /* IMU frames of a .sens under construction: 128 bytes each = rotationRate, acceleration, magneticField, attitude, gravity
- * (5 x 3 doubles) + u64 time stamp in microseconds (sensorData.h:796-803); addIMUFrame :1111-1113. */
+ * (5 x 3 doubles) + u64 time stamp in microseconds (sensorData.h:796-803); addIMUFrame :923-926. */
 int sf_sens_add_imu(sf_sens* s, const void* frame128);
+/* Reading them back: sf_sens_imu = m_IMUFrames[index] (:1691); sf_sens_find_closest_imu = findClosestIMUFrame(frameIdx, basedOnRGB) (:1000-1044,
+ * README.txt:49): nearest in time to the frame's colour (based_on_rgb) or depth time stamp; frame128 / index may be NULL. */
+int sf_sens_imu(const sf_sens* s, uint64_t index, void* frame128);
+int sf_sens_find_closest_imu(const sf_sens* s, uint64_t frame, int based_on_rgb, void* frame128, uint64_t* index);
 
 /* ------------------------------------------------------------------------------------------------
  * ScannerApp captures and the `convert` stage (scannet_amd/csrc/occipital.cpp).  Replaces

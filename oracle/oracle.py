@@ -225,6 +225,10 @@ def ref_sens():
             L.ref_sens_add_frames_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int]
             L.ref_sens_depth_blob.restype = C.c_void_p
             L.ref_sens_depth_blob.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        if hasattr(L, "ref_sens_find_closest_imu"):
+            L.ref_sens_add_imu.argtypes = [C.c_void_p, C.c_void_p]
+            L.ref_sens_find_closest_imu.restype = C.c_int64
+            L.ref_sens_find_closest_imu.argtypes = [C.c_void_p, C.c_uint64, C.c_int]
         _ref = L
     return _ref
 

@@ -144,6 +144,25 @@ const uint8_t* ref_sens_depth_blob(void* h, uint64_t frame, uint64_t* bytes) {
   return sd.m_frames[frame].getDepthCompressed();
 }
 
+// IMU frames: addIMUFrame (sensorData.h:923-926) and findClosestIMUFrame(frameIdx, basedOnRGB) (:1042-1044) -> the index of the frame it returns
+// (-1: it threw).  The caller keeps keys away from the last time stamp: there the reference's bisection reads m_IMUFrames[size] (:1033-1038).
+int ref_sens_add_imu(void* h, const void* frame128) {
+  ml::SensorData& sd = *(ml::SensorData*)h;
+  ml::SensorData::IMUFrame f;
+  const uint8_t* b = (const uint8_t*)frame128;
+  std::memcpy(&f.rotationRate, b, 24); std::memcpy(&f.acceleration, b + 24, 24); std::memcpy(&f.magneticField, b + 48, 24);
+  std::memcpy(&f.attitude, b + 72, 24); std::memcpy(&f.gravity, b + 96, 24); std::memcpy(&f.timeStamp, b + 120, 8);
+  sd.addIMUFrame(f);
+  return 0;
+}
+int64_t ref_sens_find_closest_imu(void* h, uint64_t frame, int based_on_rgb) {
+  const ml::SensorData& sd = *(ml::SensorData*)h;
+  try {
+    const ml::SensorData::IMUFrame& f = sd.findClosestIMUFrame((size_t)frame, based_on_rgb != 0);
+    return (int64_t)(&f - &sd.m_IMUFrames[0]);
+  } catch (...) { return -1; }
+}
+
 int ref_sens_save(void* h, const char* path) {
   try { ((ml::SensorData*)h)->saveToFile(std::string(path)); return 0; } catch (...) { return -1; }
 }

@@ -392,6 +392,45 @@ SF_API int sf_sens_add_imu(sf_sens* s, const void* frame128) {
   return SF_OK;
 }
 
+// m_IMUFrames[index] (sensorData.h:1691): the 128 bytes as stored
+SF_API int sf_sens_imu(const sf_sens* s, uint64_t index, void* frame128) {
+  if (!s || !frame128) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  if (index >= s->imu.size() / 128) return sf::fail(SF_ERR_BOUNDS, "IMU frame %llu out of bounds (%zu frames)", (unsigned long long)index, s->imu.size() / 128);
+  std::memcpy(frame128, &s->imu[index * 128], 128);
+  return SF_OK;
+}
+
+// SensorData::findClosestIMUFrame(frameIdx, basedOnRGB) (sensorData.h:1000-1044): the IMU frame nearest in time to the frame's colour (or depth) time
+// stamp -- the first / last one outside the recorded span, an exact hit as it is, else the nearer of the two neighbours with the LATER one on a tie
+// (`<`, :1035).  The reference's bisection reads one element past the end when the key equals the last time stamp (:1033-1038 with end == size);
+// here that case returns the last frame, which is what it finds when the read happens to succeed.
+SF_API int sf_sens_find_closest_imu(const sf_sens* s, uint64_t frame, int based_on_rgb, void* frame128, uint64_t* index) {
+  if (!s) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  if (frame >= s->frames.size()) return sf::fail(SF_ERR_BOUNDS, "frame %llu out of bounds (%zu frames)", (unsigned long long)frame, s->frames.size());
+  const size_t n = s->imu.size() / 128;
+  if (n == 0) return sf::fail(SF_ERR_INVALID_ARG, "no imu data available");
+  auto stamp = [&](size_t i) { uint64_t t; std::memcpy(&t, &s->imu[i * 128 + 120], 8); return t; };
+  const uint64_t key = based_on_rgb ? s->frames[frame].ts_color : s->frames[frame].ts_depth;
+  size_t found;
+  if (key < stamp(0)) found = 0;
+  else if (key > stamp(n - 1)) found = n - 1;
+  else {
+    size_t begin = 0, end = n;
+    bool exact = false;
+    while (begin + 1 < end) {
+      const size_t middle = begin + (end - begin) / 2;
+      if (stamp(middle) == key) { begin = middle; exact = true; break; }
+      if (stamp(middle) > key) end = middle;
+      else begin = middle;
+    }
+    if (exact || end == n) found = begin;
+    else found = key - stamp(begin) < stamp(end) - key ? begin : end;
+  }
+  if (frame128) std::memcpy(frame128, &s->imu[found * 128], 128);
+  if (index) *index = found;
+  return SF_OK;
+}
+
 SF_API int sf_sens_save(const sf_sens* s, const char* path) {
   if (!s || !path) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
   FILE* fp = std::fopen(path, "wb");

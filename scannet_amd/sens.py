@@ -207,6 +207,34 @@ class SensorData:
         check(L.sf_sens_add_depth_frames(self._h, _ptr(d), self.depth_width * self.depth_height * 2, len(d), _ptr(p), int(timestamp0), int(timestamp_step), int(threads)))
         self._refresh()
 
+    # -- IMU frames (sensorData.h:760-858): 128 bytes each = rotationRate, acceleration, magneticField, attitude, gravity (5 x 3 doubles) + time stamp (us)
+    IMU_DTYPE = np.dtype([("rotationRate", "<f8", 3), ("acceleration", "<f8", 3), ("magneticField", "<f8", 3), ("attitude", "<f8", 3), ("gravity", "<f8", 3),
+                          ("timeStamp", "<u8")])
+
+    def add_imu_frame(self, record):
+        """record: an IMU_DTYPE scalar (or anything numpy turns into one)."""
+        r = np.asarray(record, self.IMU_DTYPE).reshape(1)
+        check(_abi.lib().sf_sens_add_imu(self._h, _ptr(r)))
+        self._refresh()
+
+    @property
+    def imu_frames(self):
+        """m_IMUFrames as one structured array."""
+        L = _abi.lib()
+        L.sf_sens_imu.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+        out = np.zeros(self.num_imu_frames, self.IMU_DTYPE)
+        for i in range(self.num_imu_frames):
+            check(L.sf_sens_imu(self._h, i, out[i:i + 1].ctypes.data))
+        return out
+
+    def find_closest_imu_frame(self, frame, based_on_rgb=True):
+        """SensorData::findClosestIMUFrame(frameIdx, basedOnRGB) (sensorData.h:1000-1044): -> (index, IMU_DTYPE record)."""
+        L = _abi.lib()
+        L.sf_sens_find_closest_imu.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]
+        out, idx = np.zeros(1, self.IMU_DTYPE), C.c_uint64(0)
+        check(L.sf_sens_find_closest_imu(self._h, int(frame), 1 if based_on_rgb else 0, out.ctypes.data, C.byref(idx)))
+        return idx.value, out[0]
+
     def set_pose(self, frame, camera_to_world):
         pose = np.ascontiguousarray(camera_to_world, np.float32).reshape(16)
         check(_abi.lib().sf_sens_set_pose(self._h, frame, _ptr(pose)))

@@ -599,3 +599,54 @@ def test_bulk_depth_writer_writes_the_file_of_the_frame_by_frame_writer(tmp_path
         assert open(pa, "rb").read() == open(pb, "rb").read()
         r = sens.SensorData(pb)
         assert r.num_frames == N and np.array_equal(r.frames[36].decompress_depth(), depth[36])
+
+
+def test_imu_frames_and_the_closest_one_to_a_frame(oracle, tmp_path):
+    """m_IMUFrames read back as stored, and findClosestIMUFrame(frameIdx, basedOnRGB) (sensorData.h:1000-1044) against the reference itself on the file
+    both read: keys before / inside / after the recorded span, exact hits, ties between two neighbours (the later one wins), colour and depth stamps."""
+    import ctypes as C
+    rng = np.random.default_rng(9)
+    W, H = 16, 12
+    K = synth.intrinsic_matrix(W, H)
+    sd = sens.SensorData.create(0, 0, W, H, K, K, sensor_name="StructureSensor")
+    stamps = np.sort(rng.choice(np.arange(1000, 90000, 10), 60, replace=False)).astype(np.uint64)
+    recs = np.zeros(60, sens.SensorData.IMU_DTYPE)
+    for name in ("rotationRate", "acceleration", "magneticField", "attitude", "gravity"):
+        recs[name] = rng.standard_normal((60, 3))
+    recs["timeStamp"] = stamps
+    keys = [0, 999, 1000, int(stamps[7]), int(stamps[7]) + 1, int(stamps[20] + stamps[21]) // 2, int(stamps[30]) - 1, int(stamps[58]) + 3, int(stamps[59]) - 1,
+            int(stamps[59]) + 1, 10 ** 9] + [int(x) for x in rng.integers(0, 95000, 80)]
+    keys += [int(stamps[i] + (stamps[i + 1] - stamps[i]) // 2) for i in (3, 11, 40)]          # exact midpoints (the gaps are multiples of 10): ties
+    for i, k in enumerate(keys):
+        sd.add_frame(np.full((H, W), 1000, np.uint16), np.eye(4, dtype=np.float32), timestamp_color=k, timestamp_depth=keys[-1 - i])
+    for r in recs:
+        sd.add_imu_frame(r)
+    path = str(tmp_path / "imu.sens")
+    sd.save(path)
+    sd.close()
+    sd = sens.SensorData(path)
+    assert sd.num_imu_frames == 60 and sd.imu_frames.tobytes() == recs.tobytes()
+    R = oracle.ref_sens() if oracle.ref_sens_available() else None
+    h = R.ref_sens_open(path.encode()) if R is not None and hasattr(R, "ref_sens_find_closest_imu") else None
+    checked = 0
+    for f in range(len(keys)):
+        for rgb in (True, False):
+            key = keys[f] if rgb else keys[-1 - f]
+            idx, rec = sd.find_closest_imu_frame(f, rgb)
+            assert rec.tobytes() == recs[idx].tobytes()
+            d = np.abs(stamps.astype(np.int64) - key)
+            assert d[idx] == d.min()                                   # nearest in time ...
+            if (d == d.min()).sum() == 2 and stamps[0] <= key <= stamps[-1]:
+                assert idx == np.flatnonzero(d == d.min())[1]          # ... and of two equally near ones the later (`<` at :1035)
+            if h is not None and key != int(stamps[-1]):               # at the last stamp the reference reads m_IMUFrames[size] (see sf_sens_find_closest_imu)
+                assert R.ref_sens_find_closest_imu(h, f, 1 if rgb else 0) == idx, (f, rgb, key)
+                checked += 1
+    if h is not None:
+        assert checked > 150
+        R.ref_sens_close(h)
+    no_imu = sens.SensorData.create(0, 0, W, H, K, K)
+    no_imu.add_frame(np.zeros((H, W), np.uint16))
+    with pytest.raises(Exception, match="no imu data available"):      # the reference's message (:1002)
+        no_imu.find_closest_imu_frame(0)
+    with pytest.raises(Exception, match="out of bounds"):
+        sd.find_closest_imu_frame(10 ** 6)
