@@ -25,7 +25,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "scanfuse.h"
@@ -184,7 +186,10 @@ int fuse_scan(const Args& a) {
   if (sf_fuser_create(&p, device, &fuser) != SF_OK) return die("fuser");
   if (part && sf_fuser_set_stripes(fuser, 0, 0, STRIPE_BLOCKS, a.ranks, a.rank) != SF_OK) return die("stripes");
   sf_run_stats rs;
-  if (sf_fuse_run(fuser, sens, 0, 0, 0, &rs) != SF_OK) return die("fuse");
+  // decode threads: the library's default (one per usable core) for one process; the ranks of a partitioned run share the host's cores
+  const int cores = (int)std::thread::hardware_concurrency();
+  const int decode_threads = part ? std::max(4, cores / std::max(1, a.ranks)) : 0;
+  if (sf_fuse_run(fuser, sens, 0, 0, decode_threads, &rs) != SF_OK) return die("fuse");
   sf_stats st;
   sf_fuser_stats(fuser, &st);
   say("Integrated %llu frames (%llu skipped: invalid pose) in %.3f s = %.1f frames/s with %u decode threads; %u SDF blocks, heapFreeCount = %u\n",
