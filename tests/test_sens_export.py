@@ -104,6 +104,17 @@ def test_bin_sens_on_raw_colour_and_on_depth_only_files(tmp_path):
     # failure protocol of main.cpp: the message on stdout, a non-zero exit
     bad = subprocess.run([TOOL, "missing.sens", "x"], capture_output=True, cwd=str(tmp_path))
     assert bad.returncode != 0 and b"Exception caught!" in bad.stdout
+    # a frame whose depth stream is damaged, somewhere in the middle of a file the pool of threads is working through
+    K = synth.intrinsic_matrix(40, 30)
+    sd = sens.SensorData.create(0, 0, 40, 30, K, K, sensor_name="StructureSensor")
+    good = sens.zlib_deflate(np.full((30, 40), 1234, np.uint16).tobytes())
+    for i in range(40):
+        sd.add_frame_blobs(good if i != 23 else good[:len(good) // 2] + b"\xff" * 9, np.eye(4, dtype=np.float32), timestamp_depth=i)
+    sd.save(str(tmp_path / "damaged.sens"))
+    sd.close()
+    bad = subprocess.run([TOOL, "damaged.sens", "dmg"], capture_output=True, cwd=str(tmp_path))
+    assert bad.returncode != 0 and b"Exception caught!" in bad.stdout and b"[ processing frame 23 of 40 ]" in bad.stdout and b"frame 24 of 40" not in bad.stdout
+    assert b"All done" not in bad.stdout
 
 
 def test_python_exports(tmp_path):
