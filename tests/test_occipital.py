@@ -213,3 +213,40 @@ def test_converter_cli(tmp_path):
     assert usage.returncode != 0 and usage.stderr != ""
 
 
+
+
+def test_bin_depth2pgm_writes_the_reference_tools_files(tmp_path):
+    """bin/depth2pgm against the compiled ScannerApp/depth2pgm (oracle/_ref/depth2pgm_ref): the PGMs of the first frames of a `.depth` capture and
+    the stdout lines, byte for byte; a capture cut short is an error message and a non-zero exit here (the reference reads on)."""
+    import os
+    import subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool, ref = os.path.join(ROOT, "bin", "depth2pgm"), os.path.join(ROOT, "oracle", "_ref", "depth2pgm_ref")
+    rng = np.random.default_rng(4)
+    frames = []
+    for i in range(3):
+        f = (600 + 40 * i + (np.arange(640 * 480) % 640) // 3).astype(np.uint16).reshape(480, 640)
+        f[rng.random((480, 640)) < 0.05] = 2047                      # holes: no measurement
+        f[100:120, 200:260] = rng.integers(0, 2048, (20, 60))        # noise
+        frames.append(f)
+    base = str(tmp_path / "cap")
+    capture.write_capture(base, frames, [0.1, 0.2, 0.3], [("depthWidth", 640), ("depthHeight", 480), ("numDepthFrames", 3)])
+    r = subprocess.run([tool, base + ".depth", str(tmp_path / "our"), "3"], capture_output=True)
+    assert r.returncode == 0 and r.stderr == b"" and r.stdout.count(b"[bytes] \n") == 3
+    for i in range(3):
+        pgm = open(str(tmp_path / ("our_%d.pgm" % i)), "rb").read()
+        head = b"P5\n# data values are 16-bit each\n640 480\n65535\n"
+        assert pgm.startswith(head)
+        want = capture.shift2depth(frames[i], zero_invalid=True)
+        assert np.array_equal(np.frombuffer(pgm[len(head):], ">u2").reshape(480, 640), want) and (want == 0).sum() > 10000
+    if os.path.exists(ref):
+        a = subprocess.run([ref, base + ".depth", str(tmp_path / "ref"), "3"], capture_output=True)
+        assert a.returncode == 0 and a.stdout == r.stdout
+        for i in range(3):
+            assert open(str(tmp_path / ("ref_%d.pgm" % i)), "rb").read() == open(str(tmp_path / ("our_%d.pgm" % i)), "rb").read()
+    one = subprocess.run([tool, base + ".depth", str(tmp_path / "one")], capture_output=True)          # the default: one frame
+    assert one.returncode == 0 and os.path.exists(str(tmp_path / "one_0.pgm")) and not os.path.exists(str(tmp_path / "one_1.pgm"))
+    short = subprocess.run([tool, base + ".depth", str(tmp_path / "s"), "5"], capture_output=True)
+    assert short.returncode != 0 and b"frame 3" in short.stderr          # "ends before / inside frame 3": what follows the frames are the time stamps
+    usage = subprocess.run([tool], capture_output=True)
+    assert usage.returncode == 0 and usage.stderr.startswith(b"Usage: depth2pgm path/to/file.depth pgm_seq_basename [numDepthFrames]")
