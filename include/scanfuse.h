@@ -285,6 +285,17 @@ int sf_sens_add_frame_blobs(sf_sens* s, const uint8_t* color, uint64_t color_byt
                             const float pose[16], uint64_t timestamp_color, uint64_t timestamp_depth);
 int sf_sens_set_pose(sf_sens* s, uint64_t frame, const float pose[16]);
 int sf_sens_save(const sf_sens* s, const char* path);
+/* Editing a file in memory, opened or under construction (then sf_sens_save):
+ *   sf_sens_replace_depth   SensorData::replaceDepth(frameIdx, depth)  :948-955,499-502 (W*H u16, compressed with the file's type; depth time stamp -> 0
+ *                           as freeDepth leaves it, :516-521) -- what the Calibrate stage does to every frame (Calibrate/src/calibration.h:303)
+ *   sf_sens_replace_color   SensorData::replaceColor(frameIdx, color)  :957-964,505-508 (`color` as sf_sens_add_frame takes it; colour time stamp -> 0)
+ *   sf_sens_append          SensorData::append(second)                 :1605-1624 (frames only, no IMU; ANY difference in frame sizes or compression
+ *                           types is refused -- the reference's test joins its six comparisons with && and so lets almost everything through)
+ *   sf_sens_equal           SensorData::operator==                     :1626-1650 (floats and doubles compared as numbers: -inf equals -inf, NaN nothing) */
+int sf_sens_replace_depth(sf_sens* s, uint64_t frame, const uint16_t* depth);
+int sf_sens_replace_color(sf_sens* s, uint64_t frame, const uint8_t* color, uint64_t color_bytes);
+int sf_sens_append(sf_sens* s, const sf_sens* other);
+int sf_sens_equal(const sf_sens* a, const sf_sens* b, int* equal);
 
 /* IMU frames of a .sens under construction: 128 bytes each = rotationRate, acceleration, magneticField, attitude, gravity
  * (5 x 3 doubles) + u64 time stamp in microseconds (sensorData.h:796-803); addIMUFrame :923-926. */

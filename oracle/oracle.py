@@ -229,6 +229,10 @@ def ref_sens():
             L.ref_sens_add_imu.argtypes = [C.c_void_p, C.c_void_p]
             L.ref_sens_find_closest_imu.restype = C.c_int64
             L.ref_sens_find_closest_imu.argtypes = [C.c_void_p, C.c_uint64, C.c_int]
+        if hasattr(L, "ref_sens_equal"):
+            L.ref_sens_append.argtypes = [C.c_void_p, C.c_void_p]
+            L.ref_sens_equal.argtypes = [C.c_void_p, C.c_void_p]
+            L.ref_sens_replace_depth.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
         _ref = L
     return _ref
 

@@ -163,6 +163,15 @@ int64_t ref_sens_find_closest_imu(void* h, uint64_t frame, int based_on_rgb) {
   } catch (...) { return -1; }
 }
 
+// SensorData::append (:1605-1624), operator== (:1626-1650), replaceDepth (:948-955) on the reference's own objects
+int ref_sens_append(void* h, void* second) {
+  try { ((ml::SensorData*)h)->append(*(const ml::SensorData*)second); return 0; } catch (...) { return -1; }
+}
+int ref_sens_equal(void* a, void* b) { return *(const ml::SensorData*)a == *(const ml::SensorData*)b ? 1 : 0; }
+int ref_sens_replace_depth(void* h, uint64_t frame, const uint16_t* depth) {
+  try { ((ml::SensorData*)h)->replaceDepth((size_t)frame, depth); return 0; } catch (...) { return -1; }
+}
+
 int ref_sens_save(void* h, const char* path) {
   try { ((ml::SensorData*)h)->saveToFile(std::string(path)); return 0; } catch (...) { return -1; }
 }

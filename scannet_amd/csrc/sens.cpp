@@ -392,6 +392,131 @@ SF_API int sf_sens_add_imu(sf_sens* s, const void* frame128) {
   return SF_OK;
 }
 
+namespace {
+// a frame's blobs rebuilt in writer-owned storage (colour then depth), whatever they were before (in the mapped file or owned)
+int set_blobs(sf_sens* s, SensFrame& f, const uint8_t* color, uint64_t color_bytes, const uint8_t* depth, uint64_t depth_bytes) {
+  try {
+    std::vector<uint8_t> next(color_bytes + depth_bytes);
+    if (color_bytes) std::memcpy(next.data(), color, color_bytes);       // the sources may lie in f.owned: copy before the swap
+    if (depth_bytes) std::memcpy(next.data() + color_bytes, depth, depth_bytes);
+    f.owned.swap(next);
+  } catch (const std::exception& e) {
+    return sf::fail(SF_ERR_IO, "out of memory: %s", e.what());
+  }
+  f.color_bytes = color_bytes;
+  f.depth_bytes = depth_bytes;
+  f.color = f.owned.data();
+  f.depth = f.owned.data() + color_bytes;
+  (void)s;
+  return SF_OK;
+}
+}  // namespace
+
+// SensorData::replaceDepth(frameIdx, depth) (sensorData.h:948-955 -> RGBDFrame::replaceDepth :499-502): the frame's depth compressed anew with the file's
+// depth compression type; colour, pose and the COLOUR time stamp stay -- the depth time stamp goes to 0, as freeDepth() leaves it (:516-521).
+// Works on an opened file too (the Calibrate stage's use, Calibrate/src/calibration.h:303): the frame then lives in writer-owned memory.
+SF_API int sf_sens_replace_depth(sf_sens* s, uint64_t frame, const uint16_t* depth) {
+  if (!s || !depth) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  if (frame >= s->frames.size()) return sf::fail(SF_ERR_BOUNDS, "frame %llu out of bounds (%zu frames)", (unsigned long long)frame, s->frames.size());
+  const uint64_t raw = (uint64_t)s->info.depth_width * s->info.depth_height * 2;
+  std::vector<uint8_t> blob;
+  uint64_t n = raw;
+  if (s->info.depth_compression == 0) blob.assign((const uint8_t*)depth, (const uint8_t*)depth + raw);
+  else if (s->info.depth_compression == 2) {
+    blob.resize(sf_occ_encode_bound(raw / 2));
+    const int rc = sf_occ_encode(depth, raw / 2, blob.data(), blob.size(), &n);
+    if (rc != SF_OK) return rc;
+  } else {
+    blob.resize(sf_zlib_deflate_bound(raw));
+    const int rc = sf_zlib_deflate(depth, raw, blob.data(), blob.size(), &n);
+    if (rc != SF_OK) return rc;
+  }
+  SensFrame& f = s->frames[frame];
+  const int rc = set_blobs(s, f, f.color, f.color_bytes, blob.data(), n);
+  if (rc == SF_OK) f.ts_depth = 0;
+  return rc;
+}
+
+// SensorData::replaceColor(frameIdx, color) (:957-964 -> RGBDFrame::replaceColor :505-508): `color` as sf_sens_add_frame takes it -- W*H*3 RGB bytes for a
+// TYPE_RAW file, an encoded JPEG / PNG blob otherwise (the reference encodes the pixels itself, with its Windows-only encoder, :576-593); the colour time
+// stamp goes to 0 (freeColor, :510-515).
+SF_API int sf_sens_replace_color(sf_sens* s, uint64_t frame, const uint8_t* color, uint64_t color_bytes) {
+  if (!s || (!color && color_bytes)) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  if (frame >= s->frames.size()) return sf::fail(SF_ERR_BOUNDS, "frame %llu out of bounds (%zu frames)", (unsigned long long)frame, s->frames.size());
+  if (color_bytes && s->info.color_compression == 0 && color_bytes != (uint64_t)s->info.color_width * s->info.color_height * 3)
+    return sf::fail(SF_ERR_INVALID_ARG, "raw colour frame must be colorWidth*colorHeight*3 bytes");
+  SensFrame& f = s->frames[frame];
+  const int rc = set_blobs(s, f, color, color_bytes, f.depth, f.depth_bytes);
+  if (rc == SF_OK) f.ts_color = 0;
+  return rc;
+}
+
+// SensorData::append(second) (:1605-1624): the frames of `other` (blobs, poses, time stamps) behind this file's; its IMU frames are not taken, as in the
+// reference.  The reference means to refuse incompatible files but joins its six tests with && (it throws only when ALL of them differ): here any
+// difference in frame sizes or compression types is refused.
+SF_API int sf_sens_append(sf_sens* s, const sf_sens* other) {
+  if (!s || !other) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  const sf_sens_info &a = s->info, &b = other->info;
+  if (a.color_width != b.color_width || a.color_height != b.color_height || a.depth_width != b.depth_width || a.depth_height != b.depth_height ||
+      a.color_compression != b.color_compression || a.depth_compression != b.depth_compression)
+    return sf::fail(SF_ERR_INVALID_ARG, "sensor data incompatible");
+  const size_t n = other->frames.size();   // `other` may be `s` itself
+  try {
+    s->frames.reserve(s->frames.size() + n);
+    for (size_t i = 0; i < n; i++) {
+      const SensFrame& o = other->frames[i];
+      SensFrame f;
+      std::memcpy(f.pose, o.pose, 64);
+      f.ts_color = o.ts_color; f.ts_depth = o.ts_depth;
+      f.owned.resize(o.color_bytes + o.depth_bytes);
+      if (o.color_bytes) std::memcpy(f.owned.data(), o.color, o.color_bytes);
+      if (o.depth_bytes) std::memcpy(f.owned.data() + o.color_bytes, o.depth, o.depth_bytes);
+      f.color_bytes = o.color_bytes; f.depth_bytes = o.depth_bytes;
+      s->frames.push_back(std::move(f));
+    }
+  } catch (const std::exception& e) {
+    return sf::fail(SF_ERR_IO, "sf_sens_append: %s", e.what());
+  }
+  for (SensFrame& q : s->frames)
+    if (!q.owned.empty()) { q.color = q.owned.data(); q.depth = q.owned.data() + q.color_bytes; }
+  return SF_OK;
+}
+
+// SensorData::operator== (:1626-1650): version, sensor name, both calibrations, compression types, sizes, depth shift, every frame (blob sizes, time
+// stamps, the pose compared as floats -- an all -inf pose equals itself, a NaN nothing --, blob bytes: RGBDFrame::operator== :756-771) and every IMU
+// frame (doubles compared as doubles, :813-821).
+SF_API int sf_sens_equal(const sf_sens* x, const sf_sens* y, int* equal) {
+  if (!x || !y || !equal) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  *equal = 0;
+  const sf_sens_info &a = x->info, &b = y->info;
+  if (a.version != b.version || std::strncmp(a.sensor_name, b.sensor_name, sizeof a.sensor_name) != 0) return SF_OK;
+  for (int i = 0; i < 16; i++)
+    if (a.color_intrinsic[i] != b.color_intrinsic[i] || a.color_extrinsic[i] != b.color_extrinsic[i] || a.depth_intrinsic[i] != b.depth_intrinsic[i] ||
+        a.depth_extrinsic[i] != b.depth_extrinsic[i])
+      return SF_OK;
+  if (a.color_compression != b.color_compression || a.depth_compression != b.depth_compression || a.color_width != b.color_width ||
+      a.color_height != b.color_height || a.depth_width != b.depth_width || a.depth_height != b.depth_height || a.depth_shift != b.depth_shift)
+    return SF_OK;
+  if (x->frames.size() != y->frames.size() || x->imu.size() != y->imu.size()) return SF_OK;
+  for (size_t i = 0; i < x->frames.size(); i++) {
+    const SensFrame &f = x->frames[i], &g = y->frames[i];
+    if (f.color_bytes != g.color_bytes || f.depth_bytes != g.depth_bytes || f.ts_color != g.ts_color || f.ts_depth != g.ts_depth) return SF_OK;
+    for (int k = 0; k < 16; k++)
+      if (f.pose[k] != g.pose[k]) return SF_OK;
+    if ((f.color_bytes && std::memcmp(f.color, g.color, f.color_bytes) != 0) || (f.depth_bytes && std::memcmp(f.depth, g.depth, f.depth_bytes) != 0)) return SF_OK;
+  }
+  for (size_t i = 0; i < x->imu.size() / 128; i++) {
+    double p[15], q[15];
+    std::memcpy(p, &x->imu[i * 128], 120);
+    std::memcpy(q, &y->imu[i * 128], 120);
+    for (int k = 0; k < 15; k++)
+      if (p[k] != q[k]) return SF_OK;
+    if (std::memcmp(&x->imu[i * 128 + 120], &y->imu[i * 128 + 120], 8) != 0) return SF_OK;
+  }
+  *equal = 1;
+  return SF_OK;
+}
+
 // m_IMUFrames[index] (sensorData.h:1691): the 128 bytes as stored
 SF_API int sf_sens_imu(const sf_sens* s, uint64_t index, void* frame128) {
   if (!s || !frame128) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");

@@ -235,6 +235,38 @@ class SensorData:
         check(L.sf_sens_find_closest_imu(self._h, int(frame), 1 if based_on_rgb else 0, out.ctypes.data, C.byref(idx)))
         return idx.value, out[0]
 
+    # -- editing in memory (then save): SensorData::replaceDepth / replaceColor / append / operator== (sensorData.h:948-964,1605-1650) ------------------
+    def replace_depth(self, frame, depth):
+        d = np.ascontiguousarray(depth, np.uint16)
+        if d.shape != (self.depth_height, self.depth_width):
+            raise ValueError("depth must be [depth_height, depth_width]")
+        check(_abi.lib().sf_sens_replace_depth(self._h, int(frame), _ptr(d)))
+        self._frames = None
+
+    def replace_color(self, frame, color):
+        """color: [color_height, color_width, 3] uint8 for a raw-colour file, an encoded JPEG / PNG blob (bytes) otherwise."""
+        L = _abi.lib()
+        L.sf_sens_replace_color.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+        if isinstance(color, (bytes, bytearray)):
+            b = np.frombuffer(bytes(color), np.uint8)
+        else:
+            b = np.ascontiguousarray(color, np.uint8).reshape(-1)
+        check(L.sf_sens_replace_color(self._h, int(frame), _ptr(b), b.size))
+        self._frames = None
+
+    def append(self, second):
+        check(_abi.lib().sf_sens_append(self._h, second._h))
+        self._refresh()
+
+    def __eq__(self, other):
+        if not isinstance(other, SensorData):
+            return NotImplemented
+        eq = C.c_int(0)
+        check(_abi.lib().sf_sens_equal(self._h, other._h, C.byref(eq)))
+        return bool(eq.value)
+
+    __hash__ = None
+
     def set_pose(self, frame, camera_to_world):
         pose = np.ascontiguousarray(camera_to_world, np.float32).reshape(16)
         check(_abi.lib().sf_sens_set_pose(self._h, frame, _ptr(pose)))

@@ -650,3 +650,79 @@ def test_imu_frames_and_the_closest_one_to_a_frame(oracle, tmp_path):
         no_imu.find_closest_imu_frame(0)
     with pytest.raises(Exception, match="out of bounds"):
         sd.find_closest_imu_frame(10 ** 6)
+
+
+def test_replace_append_and_equality_against_the_reference(oracle, tmp_path):
+    """SensorData::replaceDepth / replaceColor / append / operator== (sensorData.h:948-964,1605-1650): the same edits made by this library and by the
+    reference on the same files -- what each reads back of the other's result, the reference's operator== on the pairs, and the saved bytes of an append."""
+    rng = np.random.default_rng(12)
+    W, H = 24, 18
+    K = synth.intrinsic_matrix(W, H)
+
+    def scan(path, n, seed, lost=()):
+        r = np.random.default_rng(seed)
+        sd = sens.SensorData.create(W, H, W, H, K, K, color_compression=0, depth_compression=1, sensor_name="StructureSensor")
+        for i in range(n):
+            pose = np.full((4, 4), -np.inf, np.float32) if i in lost else synth.trajectory_pose(i * 31 + seed, 1200)
+            sd.add_frame(r.integers(0, 5000, (H, W), dtype=np.uint16), pose, color=r.integers(0, 256, (H, W, 3), dtype=np.uint8), timestamp_color=100 + i, timestamp_depth=200 + i)
+        sd.save(path)
+        sd.close()
+    a_path, b_path = str(tmp_path / "a.sens"), str(tmp_path / "b.sens")
+    scan(a_path, 5, 1, lost=(2,))
+    scan(b_path, 3, 2)
+    a, a2, b = sens.SensorData(a_path), sens.SensorData(a_path), sens.SensorData(b_path)
+    assert a == a2 and not (a == b) and a != b                       # a frame with the all -inf pose equals itself
+    R = oracle.ref_sens() if oracle.ref_sens_available() and hasattr(oracle.ref_sens(), "ref_sens_equal") else None
+    if R is not None:
+        ra, ra2, rb = (R.ref_sens_open(p.encode()) for p in (a_path, a_path, b_path))
+        assert R.ref_sens_equal(ra, ra2) == 1 and R.ref_sens_equal(ra, rb) == 0
+    # replaceDepth on an OPENED file (the Calibrate stage's use): new pixels, depth time stamp zeroed, everything else kept
+    new_d = rng.integers(0, 5000, (H, W), dtype=np.uint16)
+    before = [(f.color_compressed, f.camera_to_world.copy(), f.timestamp_color) for f in a.frames]
+    a.replace_depth(3, new_d)
+    assert not (a == a2)
+    f3 = a.frames[3]
+    assert np.array_equal(f3.decompress_depth(), new_d) and f3.timestamp_depth == 0 and f3.timestamp_color == before[3][2] and f3.color_compressed == before[3][0]
+    assert np.array_equal(a.frames[2].decompress_depth(), a2.frames[2].decompress_depth())
+    edited = str(tmp_path / "edited.sens")
+    a.save(edited)
+    if R is not None:
+        assert R.ref_sens_replace_depth(ra, 3, new_d.ctypes.data) == 0
+        ref_edited = str(tmp_path / "ref_edited.sens")
+        assert R.ref_sens_save(ra, ref_edited.encode()) == 0
+        ours, theirs = sens.SensorData(edited), sens.SensorData(ref_edited)        # the depth streams differ (two deflaters), what they hold does not
+        for fo, ft in zip(ours.frames, theirs.frames):
+            assert np.array_equal(fo.decompress_depth(), ft.decompress_depth()) and fo.color_compressed == ft.color_compressed
+            assert (fo.timestamp_color, fo.timestamp_depth) == (ft.timestamp_color, ft.timestamp_depth) and np.array_equal(fo.camera_to_world, ft.camera_to_world)
+        r_ours = R.ref_sens_open(edited.encode())
+        out = np.zeros((H, W), np.uint16)
+        R.ref_sens_decode_depth(r_ours, 3, out.ctypes.data)
+        assert np.array_equal(out, new_d)                                           # the reference reads the edited file
+        R.ref_sens_close(r_ours)
+    # replaceColor: raw pixels, colour time stamp zeroed
+    new_c = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    a.replace_color(0, new_c)
+    assert np.array_equal(a.frames[0].decompress_color(), new_c) and a.frames[0].timestamp_color == 0 and a.frames[0].timestamp_depth == 200
+    with pytest.raises(Exception, match="colorWidth"):
+        a.replace_color(0, new_c[:-1])
+    with pytest.raises(Exception, match="out of bounds"):
+        a.replace_depth(99, new_d)
+    # append: b's frames behind a2's; the saved file is the reference's, byte for byte (blobs are copied as they are)
+    a2.append(b)
+    assert a2.num_frames == 8 and np.array_equal(a2.frames[6].decompress_depth(), b.frames[1].decompress_depth())
+    joined = str(tmp_path / "joined.sens")
+    a2.save(joined)
+    if R is not None:
+        assert R.ref_sens_append(ra2, rb) == 0
+        ref_joined = str(tmp_path / "ref_joined.sens")
+        assert R.ref_sens_save(ra2, ref_joined.encode()) == 0
+        assert open(joined, "rb").read() == open(ref_joined, "rb").read()
+        rj = R.ref_sens_open(joined.encode())
+        assert R.ref_sens_equal(rj, ra2) == 1
+        for h in (ra, ra2, rb, rj):
+            R.ref_sens_close(h)
+    other = sens.SensorData.create(W, H, W + 8, H, K, K, color_compression=0, depth_compression=1)
+    with pytest.raises(Exception, match="incompatible"):
+        a2.append(other)
+    a2.append(a2)                                                                   # a file behind itself
+    assert a2.num_frames == 16 and a2.frames[15].depth_compressed == a2.frames[7].depth_compressed
