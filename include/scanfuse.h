@@ -296,6 +296,8 @@ int sf_sens_replace_depth(sf_sens* s, uint64_t frame, const uint16_t* depth);
 int sf_sens_replace_color(sf_sens* s, uint64_t frame, const uint8_t* color, uint64_t color_bytes);
 int sf_sens_append(sf_sens* s, const sf_sens* other);
 int sf_sens_equal(const sf_sens* a, const sf_sens* b, int* equal);
+/* SensorData::applyTransform(t) (:1047-1054): camera-to-world of every tracked frame <- t * m (row-major); all -inf poses are left alone */
+int sf_sens_apply_transform(sf_sens* s, const float t[16]);
 
 /* IMU frames of a .sens under construction: 128 bytes each = rotationRate, acceleration, magneticField, attitude, gravity
  * (5 x 3 doubles) + u64 time stamp in microseconds (sensorData.h:796-803); addIMUFrame :923-926. */

@@ -482,6 +482,25 @@ SF_API int sf_sens_append(sf_sens* s, const sf_sens* other) {
   return SF_OK;
 }
 
+// SensorData::applyTransform(t) (:1047-1054, behind _HAS_MLIB): every tracked frame's camera-to-world becomes t * m (row-major 4x4 product, float sums in
+// index order; mLib itself is not in the reference tree, so the rounding of its product is not pinned); frames whose pose is the all -inf "tracking lost"
+// mark (m(0,0) == -inf) stay as they are.  What the pipeline's alignment step does to a scan's trajectory (Alignment/src/alignment.h, out of scope here).
+SF_API int sf_sens_apply_transform(sf_sens* s, const float t[16]) {
+  if (!s || !t) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  for (SensFrame& f : s->frames) {
+    if (f.pose[0] == -std::numeric_limits<float>::infinity()) continue;
+    float r[16];
+    for (int i = 0; i < 4; i++)
+      for (int j = 0; j < 4; j++) {
+        float acc = t[i * 4 + 0] * f.pose[0 * 4 + j];
+        for (int k = 1; k < 4; k++) acc = acc + t[i * 4 + k] * f.pose[k * 4 + j];
+        r[i * 4 + j] = acc;
+      }
+    std::memcpy(f.pose, r, 64);
+  }
+  return SF_OK;
+}
+
 // SensorData::operator== (:1626-1650): version, sensor name, both calibrations, compression types, sizes, depth shift, every frame (blob sizes, time
 // stamps, the pose compared as floats -- an all -inf pose equals itself, a NaN nothing --, blob bytes: RGBDFrame::operator== :756-771) and every IMU
 // frame (doubles compared as doubles, :813-821).

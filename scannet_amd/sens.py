@@ -258,6 +258,12 @@ class SensorData:
         check(_abi.lib().sf_sens_append(self._h, second._h))
         self._refresh()
 
+    def apply_transform(self, t):
+        """SensorData::applyTransform: every tracked pose <- t @ pose (4x4, row-major); "tracking lost" poses stay."""
+        m = np.ascontiguousarray(t, np.float32).reshape(16)
+        check(_abi.lib().sf_sens_apply_transform(self._h, _ptr(m)))
+        self._frames = None
+
     def __eq__(self, other):
         if not isinstance(other, SensorData):
             return NotImplemented

@@ -726,3 +726,24 @@ def test_replace_append_and_equality_against_the_reference(oracle, tmp_path):
         a2.append(other)
     a2.append(a2)                                                                   # a file behind itself
     assert a2.num_frames == 16 and a2.frames[15].depth_compressed == a2.frames[7].depth_compressed
+
+
+def test_apply_transform_moves_tracked_poses_only(tmp_path):
+    W, H = 8, 6
+    K = synth.intrinsic_matrix(W, H)
+    sd = sens.SensorData.create(0, 0, W, H, K, K)
+    poses = [synth.trajectory_pose(i * 40, 1200) for i in range(4)]
+    poses[2] = np.full((4, 4), -np.inf, np.float32)
+    for p in poses:
+        sd.add_frame(np.zeros((H, W), np.uint16), p)
+    t = synth.trajectory_pose(333, 1200)
+    t[:3, 3] += np.float32(0.25)
+    sd.apply_transform(t)
+    for i, p in enumerate(poses):
+        got = sd.frames[i].camera_to_world
+        if i == 2:
+            assert np.all(np.isneginf(got))
+        else:
+            assert np.allclose(got, t.astype(np.float64) @ p.astype(np.float64), atol=2e-6) and got.dtype == np.float32
+    sd.save(str(tmp_path / "moved.sens"))
+    assert np.array_equal(sens.SensorData(str(tmp_path / "moved.sens")).frames[1].camera_to_world, sd.frames[1].camera_to_world)
