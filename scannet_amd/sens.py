@@ -96,6 +96,18 @@ class RGBDFrame:
         """The depth blob as stored (RGBDFrame::getDepthCompressed, sensorData.h:421)."""
         return self._blobs()[1]
 
+    # the reference's attribute and method names for the same things (SensorData.py:19-45)
+    color_data = color_compressed
+    depth_data = depth_compressed
+
+    def decompress_depth_zlib(self):
+        """zlib.decompress(self.depth_data), SensorData.py:31-32: the frame's pixels as bytes (W*H little-endian u16)."""
+        return self.decompress_depth().tobytes()
+
+    def decompress_color_jpeg(self):
+        """imageio.imread(self.color_data), SensorData.py:42-43: [H, W, 3] uint8."""
+        return self.decompress_color()
+
     def decompress_depth(self, compression_type=None):
         """-> uint16 array [depth_height, depth_width] (the reference returns the raw bytes of the same data)."""
         o = self._o
@@ -141,6 +153,7 @@ class SensorData:
         self.depth_width, self.depth_height = info.depth_width, info.depth_height
         self.depth_shift = info.depth_shift
         self.num_frames, self.num_imu_frames = info.num_frames, info.num_imu
+        self.version = info.version
         self._frames = None
 
     @property

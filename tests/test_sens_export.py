@@ -132,6 +132,12 @@ def test_python_exports(tmp_path):
         rows = open(str(tmp_path / "out" / "pose" / ("%d.txt" % i))).read().splitlines()
         assert rows == [" ".join("%f" % v for v in row) for row in sd.frames[i].camera_to_world]
     assert sorted(os.listdir(str(tmp_path / "out" / "intrinsic"))) == ["extrinsic_color.txt", "extrinsic_depth.txt", "intrinsic_color.txt", "intrinsic_depth.txt"]
+    # the reference's names for a frame's blobs and decoders (SensorData.py:19-45), usable as a script written against it uses them
+    import zlib
+    f0 = sd.frames[0]
+    assert sd.version == 4 and f0.depth_data == f0.depth_compressed and f0.color_data == f0.color_compressed and len(f0.color_data) == f0.color_size_bytes
+    assert zlib.decompress(f0.depth_data) == f0.decompress_depth_zlib() == depths[0].tobytes()
+    assert np.array_equal(f0.decompress_color_jpeg(), f0.decompress_color(sd.color_compression_type))
     # image_size = (height, width), every second frame: cv2.INTER_NEAREST's sampling rule
     sd.export_depth_images(str(tmp_path / "small"), image_size=(12, 16), frame_skip=2)
     sd.export_color_images(str(tmp_path / "smallc"), image_size=(12, 16), frame_skip=2)
