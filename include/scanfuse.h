@@ -285,6 +285,11 @@ int sf_sens_add_frame_blobs(sf_sens* s, const uint8_t* color, uint64_t color_byt
                             const float pose[16], uint64_t timestamp_color, uint64_t timestamp_depth);
 int sf_sens_set_pose(sf_sens* s, uint64_t frame, const float pose[16]);
 int sf_sens_save(const sf_sens* s, const char* path);
+/* SensorData::loadFromImages(sourceFolder, basename = "frame-", colorEnding = "png") (sensorData.h:1468-1559, FreeImage builds only): a folder as
+ * saveToImages / bin/sens writes it -- info.txt (or _info.txt), <basename>%06d.color.jpg|png (kept as the colour blob), .depth.png (16-bit grey; or
+ * the .depth.pgm saveToImages really writes), .pose.txt -- into a .sens in memory (zlib depth, time stamps 0), frames until one is incomplete.
+ * basename NULL: "frame-"; color_ending NULL: what frame 0 has.  scannet_amd/csrc/sens_images.cpp. */
+int sf_sens_load_from_images(const char* folder, const char* basename, const char* color_ending, sf_sens** out);
 /* Editing a file in memory, opened or under construction (then sf_sens_save):
  *   sf_sens_replace_depth   SensorData::replaceDepth(frameIdx, depth)  :948-955,499-502 (W*H u16, compressed with the file's type; depth time stamp -> 0
  *                           as freeDepth leaves it, :516-521) -- what the Calibrate stage does to every frame (Calibrate/src/calibration.h:303)

@@ -58,6 +58,20 @@ bool write_blob(const std::string& path, const void* data, size_t n) {
 }  // namespace
 
 int main(int argc, char** argv) {
+  // sens --from-images <folder> <out.sens> [jpg|png]: the way back (not an argument of the reference's tool; its library has the function,
+  // SensorData::loadFromImages, sensorData.h:1468-1559, in FreeImage builds): a folder as this tool writes it -> a .sens
+  if (argc >= 2 && std::string(argv[1]) == "--from-images") {
+    if (argc < 4) { std::cout << "run ./sens --from-images <folder> <out.sens> [jpg|png]" << std::endl; return EXIT_FAILURE; }
+    sf_sens* s = nullptr;
+    if (sf_sens_load_from_images(argv[2], nullptr, argc >= 5 ? argv[4] : nullptr, &s) != SF_OK) return fail(sf_last_error());
+    sf_sens_info info;
+    sf_sens_get_info(s, &info);
+    if (sf_sens_save(s, argv[3]) != SF_OK) return fail(sf_last_error());
+    std::cout << "DONE" << std::endl;   // loadFromImages' own last word (:1510)
+    std::cout << info.num_frames << " frames from " << argv[2] << " written to " << argv[3] << std::endl;
+    sf_sens_close(s);
+    return 0;
+  }
   std::string filename = "scene0001_00.sens", out_dir = "./out/";
   if (argc >= 2) filename = argv[1];
   else {

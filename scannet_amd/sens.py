@@ -191,6 +191,16 @@ class SensorData:
         check(_abi.lib().sf_sens_create(C.byref(info), C.byref(h)))
         return cls(_handle=h)
 
+    @classmethod
+    def load_from_images(cls, folder, basename="frame-", color_ending=None):
+        """SensorData::loadFromImages (sensorData.h:1468-1559): a folder as `bin/sens` / saveToImages writes it -> a SensorData in memory (then save())."""
+        L = _abi.lib()
+        L.sf_sens_load_from_images.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
+        h = C.c_void_p()
+        check(L.sf_sens_load_from_images(os.fsencode(folder), None if basename is None else basename.encode(), None if color_ending is None else color_ending.encode(),
+                                         C.byref(h)))
+        return cls(_handle=h)
+
     def add_frame(self, depth, camera_to_world=None, color=None, timestamp_color=0, timestamp_depth=0):
         pose = np.ascontiguousarray(np.eye(4) if camera_to_world is None else camera_to_world, np.float32).reshape(16)
         d = None if depth is None else np.ascontiguousarray(depth, np.uint16)

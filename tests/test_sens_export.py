@@ -174,3 +174,59 @@ def test_png_writer_rgb_and_grey(tmp_path):
         else:
             assert np.array_equal(np.asarray(Image.open(p)).astype(dt), a)
     assert L.sf_png_write(b"/tmp/x.png", a.ctypes.data, 5, 9, 2, 8) != 0
+
+
+def test_images_back_into_a_sens(tmp_path):
+    """SensorData::loadFromImages (sensorData.h:1468-1559): the folder `bin/sens` wrote, read back -- colour blobs and depth pixels exactly, the numbers
+    that went through text (poses, calibration: six significant digits, as the reference prints them) to that precision, the -inf pose as itself."""
+    r = subprocess.run([TOOL, "scan.sens", str(tmp_path / "out")], capture_output=True, cwd=GOLD)
+    assert r.returncode == 0
+    back_path = str(tmp_path / "back.sens")
+    r = subprocess.run([TOOL, "--from-images", str(tmp_path / "out"), back_path], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("DONE\n14 frames from"), (r.stdout, r.stderr)
+    a, b = sens.SensorData(os.path.join(GOLD, "scan.sens")), sens.SensorData(back_path)
+    assert b.num_frames == 14 and b.sensor_name == a.sensor_name == "Structure Sensor" and (b.color_width, b.depth_height, b.depth_shift) == (32, 24, 1000.0)
+    assert b.color_compression_type == "jpeg" and b.depth_compression_type == "zlib_ushort"
+    assert np.allclose(a.intrinsic_depth, b.intrinsic_depth, rtol=1e-5) and np.allclose(a.extrinsic_color, b.extrinsic_color)
+    for fa, fb in zip(a.frames, b.frames):
+        assert fa.color_compressed == fb.color_compressed and np.array_equal(fa.decompress_depth(), fb.decompress_depth())
+        if fa.valid_pose:
+            assert np.allclose(fa.camera_to_world, fb.camera_to_world, rtol=1e-5, atol=1e-6)
+        else:
+            assert not fb.valid_pose and np.all(np.isneginf(fb.camera_to_world))
+        assert fb.timestamp_color == fb.timestamp_depth == 0
+    # the reference's own reader opens what came back
+    if os.path.exists(REF):
+        rr = subprocess.run([REF, back_path, str(tmp_path / "again")], capture_output=True)
+        assert rr.returncode == 0 and len(os.listdir(str(tmp_path / "again"))) == 43
+    # depth as 16-bit PNG (the reference's loader reads .depth.png), PNG colour, "info.txt", another base name -- through the library call
+    from PIL import Image
+    d = tmp_path / "seven"
+    d.mkdir()
+    rng = np.random.default_rng(5)
+    K = synth.intrinsic_matrix(20, 10)
+    (d / "info.txt").write_text("m_versionNumber = 4\nm_sensorName = Kinect.V1\nm_colorWidth = 20\nm_colorHeight = 10\nm_depthWidth = 20\nm_depthHeight = 10\nm_depthShift = 1000\n"
+                                + "".join("%s = %s \n" % (n, " ".join("%g" % x for x in m.reshape(-1))) for n, m in
+                                          (("m_calibrationColorIntrinsic", K), ("m_calibrationColorExtrinsic", np.eye(4)), ("m_calibrationDepthIntrinsic", K),
+                                           ("m_calibrationDepthExtrinsic", np.eye(4)))) + "m_frames.size = 3\n")
+    depths, blobs = [], []
+    for i in range(3):
+        dd = rng.integers(0, 65536, (10, 20), dtype=np.uint16)
+        depths.append(dd)
+        Image.fromarray(dd).save(str(d / ("seq-%06d.depth.png" % i)))
+        Image.fromarray(rng.integers(0, 256, (10, 20, 3), dtype=np.uint8)).save(str(d / ("seq-%06d.color.png" % i)))
+        blobs.append(open(str(d / ("seq-%06d.color.png" % i)), "rb").read())
+        (d / ("seq-%06d.pose.txt" % i)).write_text("1 0 0 %d\n0 1 0 0.5\n0 0 1 -2\n0 0 0 1" % i)
+    (d / "seq-000004.pose.txt").write_text("1 0 0 0\n0 1 0 0\n0 0 1 0\n0 0 0 1")       # frame 3 is missing: the sequence ends there
+    sd = sens.SensorData.load_from_images(str(d), basename="seq-")
+    assert sd.num_frames == 3 and sd.color_compression_type == "png" and sd.sensor_name == "Kinect.V1"
+    for i, f in enumerate(sd.frames):
+        assert np.array_equal(f.decompress_depth(), depths[i]) and f.color_compressed == blobs[i] and f.camera_to_world[0, 3] == i and f.camera_to_world[2, 3] == -2
+        assert np.array_equal(f.decompress_color(), np.asarray(Image.open(io.BytesIO(blobs[i]))))
+    with pytest.raises(Exception, match="info.txt"):
+        sens.SensorData.load_from_images(str(tmp_path))
+    with pytest.raises(Exception, match="invalid color format"):
+        sens.SensorData.load_from_images(str(d), basename="seq-", color_ending="bmp")
+    (d / "seq-000001.depth.png").write_bytes(open(str(d / "seq-000001.color.png"), "rb").read())     # an RGB picture where the depth belongs
+    with pytest.raises(Exception, match="16-bit grey"):
+        sens.SensorData.load_from_images(str(d), basename="seq-")
