@@ -252,6 +252,32 @@ def main():
                 L.sf_segment_mesh(xyz.ctypes.data, nv.value, tri.ctypes.data, nf.value, 0.01, 20, seg.ctypes.data)
             L.sf_mesh_free(mh)
         tally("obj/segment", rc)
+    # ---- a folder of images -> .sens (sf_sens_load_from_images): info.txt, a pose file or a depth PGM damaged
+    from scannet_amd import calibrate
+    folder = os.path.join(tmp, "images")
+    os.makedirs(folder, exist_ok=True)
+    L.sf_sens_load_from_images.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(vp)]
+    K4 = synth.intrinsic_matrix(16, 12)
+    mat = lambda m: " ".join("%g" % x for x in np.asarray(m).reshape(-1))
+    files = {"info.txt": ("m_versionNumber = 4\nm_sensorName = fuzz\nm_colorWidth = 16\nm_colorHeight = 12\nm_depthWidth = 16\nm_depthHeight = 12\nm_depthShift = 1000\n"
+                          "m_calibrationColorIntrinsic = %s \nm_calibrationColorExtrinsic = %s \nm_calibrationDepthIntrinsic = %s \nm_calibrationDepthExtrinsic = %s \n"
+                          "m_frames.size = 2\n" % (mat(K4), mat(np.eye(4)), mat(K4), mat(np.eye(4)))).encode()}
+    for i in range(2):
+        files["frame-%06d.color.jpg" % i] = calibrate.jpeg_encode((rng.random((12, 16, 3)) * 255).astype(np.uint8), 80, True)
+        files["frame-%06d.depth.pgm" % i] = b"P5\n# c\n16 12\n65535\n" + (rng.integers(0, 65536, 192)).astype(">u2").tobytes()
+        files["frame-%06d.pose.txt" % i] = b"1 0 0 0.5\n0 1 0 -inf\n0 0 1 2\n0 0 0 1"
+    for name, body in files.items():
+        open(os.path.join(folder, name), "wb").write(body)
+    names = [n for n in files if not n.endswith(".jpg")]
+    for it in range(n_iter // 4):
+        name = names[it % len(names)]
+        open(os.path.join(folder, name), "wb").write(mutate(rng, files[name]))
+        h = vp()
+        rc = L.sf_sens_load_from_images(folder.encode(), None, None, C.byref(h))
+        if rc == 0:
+            L.sf_sens_close(h)
+        open(os.path.join(folder, name), "wb").write(files[name])
+        tally("images", rc)
     for name, (ok, err) in counts.items():
         print("fuzz %-10s %6d decoded, %6d rejected" % (name, ok, err))
     print("fuzz: no sanitizer report")
