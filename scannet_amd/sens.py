@@ -326,6 +326,21 @@ class SensorData:
                 self.save_mat_to_file(getattr(self, name), os.path.join(output_path, name + ".txt"))
 
     @staticmethod
+    def _for_frames(fn, indices):
+        """fn(i) for every index on a small pool of threads: the library calls (inflate, PNG / JPEG coding) run outside the interpreter lock, so a scan's
+        worth of exports takes the cores' time, not one core's; the first exception is raised after the pool has drained."""
+        from concurrent.futures import ThreadPoolExecutor
+        indices = list(indices)
+        workers = max(1, min(8, os.cpu_count() or 1, len(indices)))
+        if workers == 1:
+            for i in indices:
+                fn(i)
+            return
+        with ThreadPoolExecutor(workers) as pool:
+            for _ in pool.map(fn, indices):
+                pass
+
+    @staticmethod
     def _resize_nearest(image, image_size):
         """cv2.resize(image, (image_size[1], image_size[0]), interpolation=cv2.INTER_NEAREST) as SensorData.py:84,99 calls it (image_size = (height,
         width)): destination pixel (y, x) takes source pixel (min(floor(y * H / h), H - 1), min(floor(x * W / w), W - 1))."""
@@ -341,11 +356,14 @@ class SensorData:
         os.makedirs(output_path, exist_ok=True)
         L = _abi.lib()
         L.sf_png_write.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
-        for f in range(0, len(self.frames), frame_skip):
-            d = self.frames[f].decompress_depth()
+        frames = self.frames
+
+        def one(f):
+            d = frames[f].decompress_depth()
             if image_size is not None:
                 d = self._resize_nearest(d, image_size)
             check(L.sf_png_write(os.fsencode(os.path.join(output_path, str(f) + ".png")), _ptr(d), d.shape[1], d.shape[0], 1, 16))
+        self._for_frames(one, range(0, len(frames), frame_skip))
 
     def export_color_images(self, output_path, image_size=None, frame_skip=1):
         """<output_path>/<frame index>.jpg of every frame_skip-th colour frame (SensorData.py:93-101).  The reference decodes every frame and encodes
@@ -354,8 +372,10 @@ class SensorData:
         imageio's default)."""
         from . import calibrate
         os.makedirs(output_path, exist_ok=True)
-        for f in range(0, len(self.frames), frame_skip):
-            frame = self.frames[f]
+        frames = self.frames
+
+        def one(f):
+            frame = frames[f]
             if image_size is None and self.color_compression_type == "jpeg":
                 blob = frame.color_compressed
             else:
@@ -365,3 +385,4 @@ class SensorData:
                 blob = calibrate.jpeg_encode(color, 75, True)
             with open(os.path.join(output_path, str(f) + ".jpg"), "wb") as out:
                 out.write(blob)
+        self._for_frames(one, range(0, len(frames), frame_skip))
