@@ -290,6 +290,11 @@ int sf_sens_save(const sf_sens* s, const char* path);
  * the .depth.pgm saveToImages really writes), .pose.txt -- into a .sens in memory (zlib depth, time stamps 0), frames until one is incomplete.
  * basename NULL: "frame-"; color_ending NULL: what frame 0 has.  scannet_amd/csrc/sens_images.cpp. */
 int sf_sens_load_from_images(const char* folder, const char* basename, const char* color_ending, sf_sens** out);
+/* SensorData::saveToImages(outputFolder, basename = "frame-") (sensorData.h:1380-1466): _info.txt + per frame <basename>%06d.color.jpg|png (the stored
+ * blob; a TYPE_RAW frame as a PNG), .depth.pgm (16-bit big-endian, depth shift in the comment), .pose.txt -- the folder the reference writes, byte for
+ * byte.  Frames are written by a pool of threads; progress (nullable) is called on the caller's thread with (frame, num_frames, user) in frame order.
+ * bin/sens is this call plus the reference tool's stdout. */
+int sf_sens_save_to_images(const sf_sens* s, const char* folder, const char* basename, void (*progress)(uint64_t, uint64_t, void*), void* user);
 /* Editing a file in memory, opened or under construction (then sf_sens_save):
  *   sf_sens_replace_depth   SensorData::replaceDepth(frameIdx, depth)  :948-955,499-502 (W*H u16, compressed with the file's type; depth time stamp -> 0
  *                           as freeDepth leaves it, :516-521) -- what the Calibrate stage does to every frame (Calibrate/src/calibration.h:303)

@@ -11,13 +11,21 @@
 // Frames are taken until one of a frame's three files is missing (:1509-1512); time stamps are 0.  Differences from the reference, all on the tolerant
 // side: a sensor name with blanks is read to the end of its line (the reference's `>>` stops at the first blank and derails, :1481), the colour ending
 // may be left to what frame 0 has, the file names count as StringCounter does.
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <limits>
+#include <mutex>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "sens.h"
@@ -153,5 +161,118 @@ SF_API int sf_sens_load_from_images(const char* folder_, const char* basename_, 
   }
   if (rc != SF_OK) { sf_sens_close(s); return rc; }
   *out = s;
+  return SF_OK;
+}
+
+// ---- the other direction: SensorData::saveToImages(outputFolder, basename = "frame-") (sensorData.h:1380-1466) ---------------------------------------
+//     <folder>/_info.txt                       :1383-1407  names " = " values; the four 4x4 matrices row-major, 16 numbers and a trailing blank
+//     <folder>/<basename>%06d.color.jpg | .png :1431-1450  the stored JPEG / PNG blob as it is; a TYPE_RAW frame as a PNG made here (the reference needs its
+//                                                          Windows-only encoder for that one, :576-593: off Windows it throws on the first frame)
+//     <folder>/<basename>%06d.depth.pgm        :1342-1359  binary PGM, comment line with the depth shift, 16-bit samples big-endian
+//     <folder>/<basename>%06d.pose.txt         :1706-1714  camera-to-world, four rows, no newline after the last
+// Every number goes through the iostream formatting the reference uses, the names count as its StringCounter does: the folder is the compiled
+// reference's byte for byte (tests/test_sens_export.py).  The frames are independent (three files each): a pool of threads takes them in index order;
+// progress(i, n, user) is called on the CALLER's thread, in index order, before frame i is waited for -- where the reference prints its progress line.
+SF_API int sf_sens_save_to_images(const sf_sens* s, const char* folder_, const char* basename_, void (*progress)(uint64_t, uint64_t, void*), void* user) {
+  if (!s || !folder_) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  const std::string out_dir = folder_, base = out_dir + "/" + (basename_ ? basename_ : "frame-");
+  sf_sens_info info;
+  sf_sens_get_info(s, &info);
+  struct stat st;
+  if (::stat(out_dir.c_str(), &st) != 0) ::mkdir(out_dir.c_str(), 0777);   // one level, as ml::util::makeDirectory
+  {
+    std::ofstream meta(out_dir + "/_info.txt");
+    if (!meta) return sf::fail(SF_ERR_IO, "cannot open file %s/_info.txt", out_dir.c_str());
+    meta << "m_versionNumber = " << info.version << '\n';
+    meta << "m_sensorName = " << info.sensor_name << '\n';
+    meta << "m_colorWidth = " << info.color_width << '\n';
+    meta << "m_colorHeight = " << info.color_height << '\n';
+    meta << "m_depthWidth = " << info.depth_width << '\n';
+    meta << "m_depthHeight = " << info.depth_height << '\n';
+    meta << "m_depthShift = " << info.depth_shift << '\n';
+    const struct { const char* name; const float* m; } mats[4] = {{"m_calibrationColorIntrinsic", info.color_intrinsic}, {"m_calibrationColorExtrinsic", info.color_extrinsic},
+                                                                 {"m_calibrationDepthIntrinsic", info.depth_intrinsic}, {"m_calibrationDepthExtrinsic", info.depth_extrinsic}};
+    for (const auto& m : mats) {
+      meta << m.name << " = ";
+      for (int i = 0; i < 16; i++) meta << m.m[i] << " ";
+      meta << "\n";
+    }
+    meta << "m_frames.size = " << info.num_frames << "\n";
+  }
+  const uint64_t n = info.num_frames;
+  if (n == 0) return SF_OK;
+  const std::string color_ending = info.color_compression == 2 ? "jpg" : "png";
+  std::vector<char> done(n, 0);
+  std::vector<std::string> error(n);
+  std::atomic<uint64_t> next{0};
+  std::atomic<bool> failed{false};
+  std::mutex mu;
+  std::condition_variable cv;
+  auto work = [&]() {
+    std::vector<uint16_t> depth((size_t)info.depth_width * info.depth_height);
+    for (;;) {
+      const uint64_t i = next.fetch_add(1);
+      if (i >= n) return;
+      std::string err;
+      if (!failed.load()) {
+        const std::string color_file = counted(base, (unsigned)i, ".color." + color_ending), pose_file = counted(base, (unsigned)i, ".pose.txt"),
+                          pgm_file = counted(base, (unsigned)i, ".depth.pgm");
+        const uint8_t *cblob = nullptr, *dblob = nullptr;
+        uint64_t cbytes = 0, dbytes = 0;
+        if (sf_sens_frame_blobs(s, i, &cblob, &cbytes, &dblob, &dbytes) != SF_OK) err = sf_last_error();
+        else if (info.color_compression == 0 && cbytes != 0) {   // TYPE_RAW pixels: a PNG of them
+          if (cbytes != (uint64_t)info.color_width * info.color_height * 3) err = "raw colour frame of " + std::to_string(cbytes) + " bytes";
+          else if (sf_png_write(color_file.c_str(), cblob, info.color_width, info.color_height, 3, 8) != SF_OK) err = "cannot open file " + color_file;
+        } else if (info.color_compression == 0) {
+          // a TYPE_RAW file without colour (depth only): no colour file
+        } else if (info.color_compression == 1 || info.color_compression == 2) {
+          FILE* fp = std::fopen(color_file.c_str(), "wb");
+          const bool ok = fp && (cbytes == 0 || std::fwrite(cblob, 1, (size_t)cbytes, fp) == cbytes);
+          if (fp) std::fclose(fp);
+          if (!ok) err = "cannot open file " + color_file;
+        } else {
+          err = "unknown format";
+        }
+        if (err.empty() && sens_decode_depth(s, i, depth.data()) != SF_OK) err = sf_last_error();
+        if (err.empty()) {
+          std::ofstream of(pgm_file, std::ios::binary);
+          std::stringstream ss;
+          ss << "P5\n";
+          ss << "# data values are 16-bit each; depth shift is " << info.depth_shift << "\n";
+          ss << info.depth_width << " " << info.depth_height << "\n";
+          ss << std::numeric_limits<unsigned short>::max() << "\n";
+          of << ss.str();
+          for (uint16_t& v : depth) v = (uint16_t)((v << 8) | (v >> 8));   // PGM samples are big-endian
+          of.write((const char*)depth.data(), (std::streamsize)(depth.size() * 2));
+          const float* m = s->frames[i].pose;
+          std::ofstream pf(pose_file);
+          pf << m[0] << " " << m[1] << " " << m[2] << " " << m[3] << "\n"
+             << m[4] << " " << m[5] << " " << m[6] << " " << m[7] << "\n"
+             << m[8] << " " << m[9] << " " << m[10] << " " << m[11] << "\n"
+             << m[12] << " " << m[13] << " " << m[14] << " " << m[15];
+          if (!of || !pf) err = "cannot write " + pgm_file;
+        }
+        if (!err.empty()) failed.store(true);
+      }
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        error[i] = err;
+        done[i] = 1;
+      }
+      cv.notify_all();
+    }
+  };
+  const uint64_t T = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>((uint64_t)sf::usable_cpus(), 16), n));
+  std::vector<std::thread> pool;
+  for (uint64_t t = 0; t < T; t++) pool.emplace_back(work);
+  std::string first_error;
+  for (uint64_t i = 0; i < n && first_error.empty(); i++) {
+    if (progress) progress(i, n, user);
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return done[i] != 0; });
+    first_error = error[i];
+  }
+  for (auto& t : pool) t.join();
+  if (!first_error.empty()) return sf::fail(SF_ERR_IO, "%s", first_error.c_str());
   return SF_OK;
 }

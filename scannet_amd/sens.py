@@ -191,6 +191,12 @@ class SensorData:
         check(_abi.lib().sf_sens_create(C.byref(info), C.byref(h)))
         return cls(_handle=h)
 
+    def save_to_images(self, output_folder, basename="frame-"):
+        """SensorData::saveToImages (sensorData.h:1380-1466): _info.txt + frame-%06d.color.jpg|png / .depth.pgm / .pose.txt, the reference's bytes."""
+        L = _abi.lib()
+        L.sf_sens_save_to_images.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p]
+        check(L.sf_sens_save_to_images(self._h, os.fsencode(output_folder), None if basename is None else basename.encode(), None, None))
+
     @classmethod
     def load_from_images(cls, folder, basename="frame-", color_ending=None):
         """SensorData::loadFromImages (sensorData.h:1468-1559): a folder as `bin/sens` / saveToImages writes it -> a SensorData in memory (then save())."""

@@ -185,6 +185,8 @@ def test_images_back_into_a_sens(tmp_path):
     r = subprocess.run([TOOL, "--from-images", str(tmp_path / "out"), back_path], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.startswith("DONE\n14 frames from"), (r.stdout, r.stderr)
     a, b = sens.SensorData(os.path.join(GOLD, "scan.sens")), sens.SensorData(back_path)
+    a.save_to_images(str(tmp_path / "lib"))                                # the library call behind the tool, through the Python mirror
+    _same_dirs(os.path.join(GOLD, "reference_out"), str(tmp_path / "lib"))
     assert b.num_frames == 14 and b.sensor_name == a.sensor_name == "Structure Sensor" and (b.color_width, b.depth_height, b.depth_shift) == (32, 24, 1000.0)
     assert b.color_compression_type == "jpeg" and b.depth_compression_type == "zlib_ushort"
     assert np.allclose(a.intrinsic_depth, b.intrinsic_depth, rtol=1e-5) and np.allclose(a.extrinsic_color, b.extrinsic_color)
