@@ -309,6 +309,21 @@ int sf_sens_equal(const sf_sens* a, const sf_sens* b, int* equal);
 /* SensorData::applyTransform(t) (:1047-1054): camera-to-world of every tracked frame <- t * m (row-major); all -inf poses are left alone */
 int sf_sens_apply_transform(sf_sens* s, const float t[16]);
 
+/* Frames streamed into a file as they arrive: SensorData::LiveSensorDataWriter (sensorData.h:1112-1246, _HAS_MLIB builds only there).  The header goes
+ * out at open (a path that exists: overwritten, or -- overwrite = 0 -- the name's numeric suffix is counted up until it is free, :1118-1131;
+ * sf_sens_writer_path says which); add copies the caller's buffers into a queue of at most cache_frames (0: 500, the reference's default) and blocks
+ * while it is full; one background thread compresses and writes in order; close drains, writes "0 IMU frames" and patches the frame count (:1146-1157).
+ * The file is byte for byte what the in-memory writer saves.  An error of any frame is returned by the next add and by close.
+ * scannet_amd/csrc/sens_writer.cpp. */
+typedef struct sf_sens_writer sf_sens_writer;
+int sf_sens_writer_open(const sf_sens_info* header, const char* path, int overwrite, uint32_t cache_frames, sf_sens_writer** out);
+const char* sf_sens_writer_path(const sf_sens_writer* w);
+int sf_sens_writer_add_frame(sf_sens_writer* w, const uint8_t* color, uint64_t color_bytes, const uint16_t* depth, const float pose[16],
+                             uint64_t timestamp_color, uint64_t timestamp_depth);
+int sf_sens_writer_add_frame_blobs(sf_sens_writer* w, const uint8_t* color, uint64_t color_bytes, const uint8_t* depth, uint64_t depth_bytes,
+                                   const float pose[16], uint64_t timestamp_color, uint64_t timestamp_depth);
+int sf_sens_writer_close(sf_sens_writer* w, uint64_t* frames_written /*nullable*/);
+
 /* IMU frames of a .sens under construction: 128 bytes each = rotationRate, acceleration, magneticField, attitude, gravity
  * (5 x 3 doubles) + u64 time stamp in microseconds (sensorData.h:796-803); addIMUFrame :923-926. */
 int sf_sens_add_imu(sf_sens* s, const void* frame128);

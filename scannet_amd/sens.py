@@ -392,3 +392,79 @@ class SensorData:
             with open(os.path.join(output_path, str(f) + ".jpg"), "wb") as out:
                 out.write(blob)
         self._for_frames(one, range(0, len(frames), frame_skip))
+
+
+class SensorDataWriter:
+    """Frames streamed into a .sens as they arrive (SensorData::LiveSensorDataWriter, sensorData.h:1112-1246): `cache_frames` frames of memory instead of a
+    whole scan's.  The file is what SensorData.create + add_frame + save write.
+
+        with SensorDataWriter(path, color_width, ..., sensor_name="StructureSensor") as w:
+            w.add_frame(depth, pose, color=jpeg_bytes)
+        print(w.frames_written, w.path)          # path: the name really used (overwrite=False counts a numeric suffix up past existing files)
+    """
+
+    def __init__(self, filename, color_width, color_height, depth_width, depth_height, intrinsic_color, intrinsic_depth, extrinsic_color=None, extrinsic_depth=None,
+                 color_compression=0, depth_compression=1, depth_shift=1000.0, sensor_name="StructureSensor", overwrite=True, cache_frames=0):
+        info = SfSensInfo()
+        info.version = 4
+        info.color_width, info.color_height, info.depth_width, info.depth_height = color_width, color_height, depth_width, depth_height
+        info.color_compression, info.depth_compression, info.depth_shift = color_compression, depth_compression, depth_shift
+        eye = np.eye(4, dtype=np.float32)
+        for name, m in (("color_intrinsic", intrinsic_color), ("depth_intrinsic", intrinsic_depth), ("color_extrinsic", eye if extrinsic_color is None else extrinsic_color),
+                        ("depth_extrinsic", eye if extrinsic_depth is None else extrinsic_depth)):
+            getattr(info, name)[:] = list(np.asarray(m, np.float32).reshape(16))
+        info.sensor_name = sensor_name.encode("latin-1")
+        L = _abi.lib()
+        L.sf_sens_writer_open.argtypes = [C.POINTER(SfSensInfo), C.c_char_p, C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.sf_sens_writer_path.restype = C.c_char_p
+        L.sf_sens_writer_path.argtypes = [C.c_void_p]
+        L.sf_sens_writer_add_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
+        L.sf_sens_writer_add_frame_blobs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64]
+        L.sf_sens_writer_close.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        self._h = C.c_void_p()
+        check(L.sf_sens_writer_open(C.byref(info), os.fsencode(filename), 1 if overwrite else 0, int(cache_frames), C.byref(self._h)))
+        self.path = os.fsdecode(L.sf_sens_writer_path(self._h))
+        self.frames_written = 0
+        self._shape = (depth_height, depth_width)
+
+    @staticmethod
+    def _bytes(a):
+        if a is None:
+            return None, 0
+        b = np.frombuffer(bytes(a), np.uint8) if isinstance(a, (bytes, bytearray)) else np.ascontiguousarray(a, np.uint8).reshape(-1)
+        return b, b.size
+
+    def add_frame(self, depth, camera_to_world=None, color=None, timestamp_color=0, timestamp_depth=0):
+        d = None if depth is None else np.ascontiguousarray(depth, np.uint16)
+        if d is not None and d.shape != self._shape:
+            raise ValueError("depth must be [depth_height, depth_width]")
+        pose = np.ascontiguousarray(np.eye(4) if camera_to_world is None else camera_to_world, np.float32).reshape(16)
+        c, cn = self._bytes(color)
+        check(_abi.lib().sf_sens_writer_add_frame(self._h, _ptr(c), cn, _ptr(d), _ptr(pose), int(timestamp_color), int(timestamp_depth)))
+
+    def add_frame_blobs(self, depth_blob, camera_to_world=None, color_blob=None, timestamp_color=0, timestamp_depth=0):
+        pose = np.ascontiguousarray(np.eye(4) if camera_to_world is None else camera_to_world, np.float32).reshape(16)
+        c, cn = self._bytes(color_blob)
+        d, dn = self._bytes(depth_blob)
+        check(_abi.lib().sf_sens_writer_add_frame_blobs(self._h, _ptr(c), cn, _ptr(d), dn, _ptr(pose), int(timestamp_color), int(timestamp_depth)))
+
+    def close(self):
+        if self._h:
+            n = C.c_uint64(0)
+            h, self._h = self._h, None
+            rc = _abi.lib().sf_sens_writer_close(h, C.byref(n))
+            self.frames_written = n.value
+            check(rc)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+

@@ -747,3 +747,68 @@ def test_apply_transform_moves_tracked_poses_only(tmp_path):
             assert np.allclose(got, t.astype(np.float64) @ p.astype(np.float64), atol=2e-6) and got.dtype == np.float32
     sd.save(str(tmp_path / "moved.sens"))
     assert np.array_equal(sens.SensorData(str(tmp_path / "moved.sens")).frames[1].camera_to_world, sd.frames[1].camera_to_world)
+
+
+def test_streaming_writer_writes_the_in_memory_writers_file(oracle, tmp_path):
+    """SensorData::LiveSensorDataWriter (sensorData.h:1112-1246): frames through the queue and the background thread (a cache of two frames: the calls block)
+    = the file create + add_frame + save write, byte for byte; the reference's reader reads it; the numeric-suffix rule; errors of a frame reach the caller."""
+    rng = np.random.default_rng(21)
+    W, H, n = 40, 30, 25
+    K = synth.intrinsic_matrix(W, H)
+    depth = rng.integers(0, 6000, (n, H, W), dtype=np.uint16)
+    colour = rng.integers(0, 256, (n, H, W, 3), dtype=np.uint8)
+    poses = [synth.trajectory_pose(i * 17, 1200) if i != 6 else np.full((4, 4), -np.inf, np.float32) for i in range(n)]
+    whole = sens.SensorData.create(W, H, W, H, K, K, color_compression=0, depth_compression=1, sensor_name="StructureSensor")
+    for i in range(n):
+        whole.add_frame(depth[i], poses[i], color=colour[i], timestamp_color=10 * i, timestamp_depth=10 * i + 3)
+    a = str(tmp_path / "whole.sens")
+    whole.save(a)
+    b = str(tmp_path / "stream.sens")
+    with sens.SensorDataWriter(b, W, H, W, H, K, K, color_compression=0, depth_compression=1, sensor_name="StructureSensor", cache_frames=2) as w:
+        for i in range(n):
+            w.add_frame(depth[i], poses[i], color=colour[i], timestamp_color=10 * i, timestamp_depth=10 * i + 3)
+    assert w.frames_written == n and w.path == b and open(a, "rb").read() == open(b, "rb").read()
+    if oracle.ref_sens_available():
+        R = oracle.ref_sens()
+        h = R.ref_sens_open(b.encode())
+        info = oracle.RefSensInfo()
+        R.ref_sens_get_info(h, C.byref(info))
+        out = np.zeros((H, W), np.uint16)
+        R.ref_sens_decode_depth(h, n - 1, out.ctypes.data)
+        assert info.num_frames == n and info.num_imu == 0 and np.array_equal(out, depth[n - 1])
+        R.ref_sens_close(h)
+    # overwrite=False: the name's numeric suffix counts up past the files that exist (:1118-1131)
+    names = []
+    for _ in range(3):
+        with sens.SensorDataWriter(b, 0, 0, W, H, K, K, overwrite=False) as w2:
+            w2.add_frame(depth[0])
+        names.append(os.path.basename(w2.path))
+    assert names == ["stream1.sens", "stream2.sens", "stream3.sens"] and sens.SensorData(str(tmp_path / "stream2.sens")).num_frames == 1
+    assert open(b, "rb").read() == open(a, "rb").read()                      # and the first file was left alone
+    # blobs as they are (transcoding): the frames of `whole` streamed into a third file
+    c = str(tmp_path / "copy.sens")
+    with sens.SensorDataWriter(c, W, H, W, H, K, K, color_compression=0, depth_compression=1, sensor_name="StructureSensor") as w3:
+        for f in whole.frames:
+            w3.add_frame_blobs(f.depth_compressed, f.camera_to_world, color_blob=f.color_compressed, timestamp_color=f.timestamp_color, timestamp_depth=f.timestamp_depth)
+    assert open(c, "rb").read() == open(a, "rb").read()
+    # a bad argument is refused at once; a frame that fails on the background thread (an Occipital shift value above 2047) fails the next call or the close
+    with pytest.raises(Exception, match="colorWidth"):
+        with sens.SensorDataWriter(str(tmp_path / "bad.sens"), W, H, W, H, K, K) as w4:
+            w4.add_frame(depth[0], color=colour[0][:-1])
+    w5 = sens.SensorDataWriter(str(tmp_path / "occ.sens"), 0, 0, W, H, K, K, depth_compression=2)
+    w5.add_frame(np.full((H, W), 1000, np.uint16))
+    w5.add_frame(np.full((H, W), 5000, np.uint16))                           # not a shift value
+    seen = []
+    try:
+        for _ in range(50):
+            w5.add_frame(np.full((H, W), 1000, np.uint16))
+    except Exception as e:                                                   # the next add after the background thread met the frame ...
+        seen.append(str(e))
+    try:
+        w5.close()
+    except Exception as e:                                                   # ... and the close, which still finishes the file
+        seen.append(str(e))
+    assert seen and all("does not fit" in m for m in seen)
+    assert sens.SensorData(str(tmp_path / "occ.sens")).num_frames == 1      # what was written before the failure is a valid file
+    with pytest.raises(Exception, match="Unable to open"):
+        sens.SensorDataWriter(str(tmp_path / "no" / "dir" / "x.sens"), 0, 0, W, H, K, K)
