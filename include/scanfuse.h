@@ -265,6 +265,8 @@ int sf_sens_get_info(const sf_sens* s, sf_sens_info* out);
 int sf_sens_decode_depth(const sf_sens* s, uint64_t frame, uint16_t* dst);
 int sf_sens_decode_color(const sf_sens* s, uint64_t frame, uint8_t* dst_rgb);
 int sf_sens_pose(const sf_sens* s, uint64_t frame, float out16[16], int* valid);
+/* SensorData::computeDepthImage(frameIdx) (:968-982): W*H floats in metres, (float)depth / depthShift, 0 -> 0.0f (its invalid value) */
+int sf_sens_depth_image(const sf_sens* s, uint64_t frame, float* dst_metres);
 int sf_sens_frame_meta(const sf_sens* s, uint64_t frame, sf_sens_frame_meta_t* out);
 /* RGBDFrame::getColorCompressed / getDepthCompressed (sensorData.h:418-429): the frame's compressed blobs where they lie (any out pointer may be
  * NULL); valid until sf_sens_close or, for a file under construction, until the next frame is added. */

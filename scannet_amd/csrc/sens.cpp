@@ -482,6 +482,19 @@ SF_API int sf_sens_append(sf_sens* s, const sf_sens* other) {
   return SF_OK;
 }
 
+// SensorData::computeDepthImage(frameIdx) (:968-982, behind _HAS_MLIB): the frame in metres -- (float)depth / depthShift, the "no measurement" 0 as 0.0f
+// (DepthImage32's invalid value there, :971).  The fusion path does this conversion in its pre-pass on the GPU; this is the reference's host convenience.
+SF_API int sf_sens_depth_image(const sf_sens* s, uint64_t frame, float* dst) {
+  if (!s || !dst) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  const size_t n = (size_t)s->info.depth_width * s->info.depth_height;
+  std::vector<uint16_t> d(n);
+  const int rc = sf_sens_decode_depth(s, frame, d.data());
+  if (rc != SF_OK) return rc;
+  const float shift = s->info.depth_shift;
+  for (size_t i = 0; i < n; i++) dst[i] = d[i] == 0 ? 0.0f : (float)d[i] / shift;
+  return SF_OK;
+}
+
 // SensorData::applyTransform(t) (:1047-1054, behind _HAS_MLIB): every tracked frame's camera-to-world becomes t * m (row-major 4x4 product, float sums in
 // index order; mLib itself is not in the reference tree, so the rounding of its product is not pinned); frames whose pose is the all -inf "tracking lost"
 // mark (m(0,0) == -inf) stay as they are.  What the pipeline's alignment step does to a scan's trajectory (Alignment/src/alignment.h, out of scope here).

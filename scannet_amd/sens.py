@@ -115,6 +115,13 @@ class RGBDFrame:
         check(_abi.lib().sf_sens_decode_depth(o._h, self._i, _ptr(out)))
         return out
 
+    def compute_depth_image(self):
+        """SensorData::computeDepthImage (sensorData.h:968-982): float32 [depth_height, depth_width] in metres, 0 where there is no measurement."""
+        o = self._o
+        out = np.empty((o.depth_height, o.depth_width), np.float32)
+        check(_abi.lib().sf_sens_depth_image(o._h, self._i, _ptr(out)))
+        return out
+
     def decompress_color(self, compression_type=None):
         o = self._o
         out = np.empty((o.color_height, o.color_width, 3), np.uint8)

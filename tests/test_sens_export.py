@@ -138,6 +138,8 @@ def test_python_exports(tmp_path):
     assert sd.version == 4 and f0.depth_data == f0.depth_compressed and f0.color_data == f0.color_compressed and len(f0.color_data) == f0.color_size_bytes
     assert zlib.decompress(f0.depth_data) == f0.decompress_depth_zlib() == depths[0].tobytes()
     assert np.array_equal(f0.decompress_color_jpeg(), f0.decompress_color(sd.color_compression_type))
+    metres = f0.compute_depth_image()                                      # computeDepthImage: (float)d / depthShift, 0 stays 0
+    assert metres.dtype == np.float32 and np.array_equal(metres, np.where(depths[0] == 0, np.float32(0), depths[0].astype(np.float32) / np.float32(sd.depth_shift)))
     # image_size = (height, width), every second frame: cv2.INTER_NEAREST's sampling rule
     sd.export_depth_images(str(tmp_path / "small"), image_size=(12, 16), frame_skip=2)
     sd.export_color_images(str(tmp_path / "smallc"), image_size=(12, 16), frame_skip=2)
