@@ -25,6 +25,14 @@ def test_tsan_fuse_run_pipeline():
 
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
+def test_tsan_host_thread_pools():
+    """tools/tsan/run_host.sh: the thread pools that have no GPU in them -- the streaming .sens writer (producer against the background writer through a
+    two-frame queue), the image export pool with its in-order progress, the mesh merge over key ranges and the PLY writer's slices -- under ThreadSanitizer."""
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "tsan", "run_host.sh")], capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert r.returncode == 0 and "tsan: clean" in r.stdout and "merged" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
 def test_codec_mutation_fuzz_under_asan():
     """tools/fuzz_codecs.py: truncated, bit-flipped, spliced and length-poked JPEG / zlib / PNG / PLY / Occipital inputs through the
     ASan + UBSan build: every call returns, none trips a sanitizer (a short run here; the tool takes an iteration count)."""
