@@ -10,38 +10,45 @@ import sys
 
 from .sens import SensorData
 
+# switch of the reference's command line -> (sub-folder of --output_path, SensorData method, what the progress line calls the items)
+EXPORTS = (
+    ("export_depth_images", "depth", "export_depth_images", " depth frames"),
+    ("export_color_images", "color", "export_color_images", "color frames"),
+    ("export_poses", "pose", "export_poses", "camera poses"),
+    ("export_intrinsics", "intrinsic", "export_intrinsics", None),
+)
+
+
+def parse(argv):
+    ap = argparse.ArgumentParser(prog="python -m scannet_amd.reader", description="export the contents of a .sens file")
+    ap.add_argument("--filename", required=True, help="path to sens file to read")
+    ap.add_argument("--output_path", required=True, help="path to output folder")
+    for switch, folder, _, _ in EXPORTS:
+        ap.add_argument("--" + switch, action="store_true", default=False, help="write <output_path>/%s" % folder)
+    return ap.parse_args(argv)
+
 
 def main(argv=None):
-    parser = argparse.ArgumentParser()
-    parser.add_argument('--filename', required=True, help='path to sens file to read')
-    parser.add_argument('--output_path', required=True, help='path to output folder')
-    parser.add_argument('--export_depth_images', dest='export_depth_images', action='store_true')
-    parser.add_argument('--export_color_images', dest='export_color_images', action='store_true')
-    parser.add_argument('--export_poses', dest='export_poses', action='store_true')
-    parser.add_argument('--export_intrinsics', dest='export_intrinsics', action='store_true')
-    parser.set_defaults(export_depth_images=False, export_color_images=False, export_poses=False, export_intrinsics=False)
-    opt = parser.parse_args(argv)
+    opt = parse(argv)
     print(opt)
     os.makedirs(opt.output_path, exist_ok=True)
-    sys.stdout.write('loading %s...' % opt.filename)
-    sd = SensorData(opt.filename)
-    sys.stdout.write('loaded!\n')
-    n = len(sd.frames)
-    if opt.export_depth_images:
-        print('exporting', n, ' depth frames to', os.path.join(opt.output_path, 'depth'))
-        sd.export_depth_images(os.path.join(opt.output_path, 'depth'))
-    if opt.export_color_images:
-        print('exporting', n, 'color frames to', os.path.join(opt.output_path, 'color'))
-        sd.export_color_images(os.path.join(opt.output_path, 'color'))
-    if opt.export_poses:
-        print('exporting', n, 'camera poses to', os.path.join(opt.output_path, 'pose'))
-        sd.export_poses(os.path.join(opt.output_path, 'pose'))
-    if opt.export_intrinsics:
-        print('exporting camera intrinsics to', os.path.join(opt.output_path, 'intrinsic'))
-        sd.export_intrinsics(os.path.join(opt.output_path, 'intrinsic'))
-    sd.close()
+    sys.stdout.write("loading %s..." % opt.filename)
+    with_frames = SensorData(opt.filename)
+    sys.stdout.write("loaded!\n")
+    try:
+        for switch, folder, method, items in EXPORTS:
+            if not getattr(opt, switch):
+                continue
+            target = os.path.join(opt.output_path, folder)
+            if items is None:
+                print("exporting camera intrinsics to", target)
+            else:
+                print("exporting", len(with_frames.frames), items, "to", target)
+            getattr(with_frames, method)(target)
+    finally:
+        with_frames.close()
     return 0
 
 
-if __name__ == '__main__':
+if __name__ == "__main__":
     sys.exit(main())
