@@ -61,3 +61,59 @@ def test_valu_cost_model_prices_the_shipped_kernels():
         assert 2.25 < m["cycles_overlapped_per_instruction"] <= m["cycles_serial_per_instruction"] < 4.4
         assert m["costs_cycles"] == {"fast": 2.25, "slow": 4.25, "trans": 8.3}
     assert b.valu_cost_model(False)["valu_instructions"] > b.valu_cost_model(True)["valu_instructions"]      # colour costs instructions
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    return b
+
+
+def _blob(path):
+    import json
+    raw = open(path).read()
+    try:
+        return json.loads(raw)
+    except ValueError:
+        return json.loads([ln for ln in raw.splitlines() if ln.startswith('{"')][-1])
+
+
+def test_the_line_bench_prints_is_compact_and_parseable():
+    """Round 5's record was one 24 KB JSON line; the driver keeps an 8 KB tail of stdout and could not parse it (BENCH_r05.json: parsed null).  The line is
+    now built by compact_line(): the contract's keys, roofline and cpu_baseline as numbers, < 4 KB; the full measurement goes to bench_detail.json.
+    Checked here on the full blobs of earlier rounds (every configuration bench.py runs)."""
+    import glob
+    import json
+    b = _load_bench()
+    blobs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[2-5]_bench_*.json")))
+    assert len(blobs) >= 10
+    for path in blobs:
+        out = _blob(path)
+        if "metric" not in out:
+            continue
+        line = b.compact_line(out, "bench_detail.json")
+        assert len(line) < 4096 and "\n" not in line, (path, len(line))
+        c = json.loads(line)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert k in c, (path, k)
+        assert c["value"] == out["value"] and c["ms_per_step"] == out["ms_per_step"] and isinstance(c["config"]["workload"], str) and c["config"]["workload"]
+        if isinstance(out.get("roofline"), dict):
+            for k in ("bound", "frac", "achieved", "peak", "unit", "traffic"):
+                assert k in c["roofline"], (path, k)
+        if isinstance(out.get("cpu_baseline"), dict):
+            for k in ("value", "unit", "cores", "kind", "sample"):
+                assert k in c["cpu_baseline"], (path, k)
+
+
+def test_compact_line_sheds_optional_groups_before_it_exceeds_the_limit():
+    import json
+    b = _load_bench()
+    out = _blob(os.path.join(ROOT, "profiles", "r05_bench_4mm_driver_args.json"))
+    out["config"]["workload"] = "w" * 5000
+    out["cpu_baseline"]["sample"] = "s" * 5000
+    out["end_to_end"]["error"] = "e" * 9000
+    line = b.compact_line(out, "d")
+    c = json.loads(line)
+    assert len(line) < 4096 and c["value"] == out["value"] and c["roofline"]["frac"] is not None and c["cpu_baseline"]["value"] == out["cpu_baseline"]["value"]
