@@ -365,9 +365,12 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
         for (uint8_t*& q : res->d_plan) { if (q) (void)hipFree(q); q = nullptr; }
         res->plan_bytes = plan_need;
       }
+      // every cached entry holds res->plan_bytes (>= this run's need): an entry allocated NOW must have that size too, or a later run whose need
+      // lies between the two would reuse it undersized (device out-of-bounds write of k_inflate_*)
+      const size_t plan_alloc = res ? std::max(plan_need, res->plan_bytes) : plan_need;
       for (int q = 0; q < NZ && e_ == hipSuccess; q++) {
         if (res && res->d_plan[q]) { d_plan[q] = res->d_plan[q]; continue; }
-        e_ = hipMalloc((void**)&d_plan[q], plan_need);
+        e_ = hipMalloc((void**)&d_plan[q], plan_alloc);
         if (e_ == hipSuccess && res) res->d_plan[q] = d_plan[q];
       }
       if (e_ == hipSuccess) e_ = hipMalloc((void**)&d_zstatus, (size_t)NB * B * 8);
@@ -430,7 +433,7 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
           if (gpu_jpeg) {
             uint8_t* pay = h_pay(sl, j);
             const SensFrame& fr = s->frames[frame];
-            if (gpu_huffman && jpeg_prepare_huff(fr.color, fr.color_bytes, s->info.color_width, s->info.color_height, pay, hcol_b) == SF_OK &&
+            if (gpu_huffman && jpeg_prepare_huff(fr.color, fr.color_bytes, s->info.color_width, s->info.color_height, pay, std::min(hcol_b, col_b)) == SF_OK &&   // the DEVICE area strides by col_b: a longer entropy segment takes the host path
                 reinterpret_cast<const SfJpegLayout*>(pay)->nblocks == pay_blocks) {
               coef = 2;
               ring[(size_t)sl].pay_used[j] = (uint32_t)(sizeof(SfJpegLayout) + sizeof(SfJpegHuffDesc) +

@@ -16,6 +16,9 @@
 #include <sstream>
 #include <string>
 #include <thread>
+#include <exception>
+#include <mutex>
+#include <memory>
 #include <vector>
 
 #include "mesh.h"
@@ -337,22 +340,30 @@ SF_API int sf_mesh_create(const float* xyz, const uint8_t* rgba, uint64_t nv, co
   if ((!xyz && nv) || (!tris && nf) || !out) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
   for (uint64_t i = 0; i < nf * 3; i++)
     if (tris[i] >= nv) return sf::fail(SF_ERR_BOUNDS, "face index %u out of range (%llu vertices)", tris[i], (unsigned long long)nv);
-  sf_mesh* m = new sf_mesh();
-  m->pos.assign(xyz, xyz + nv * 3);
-  if (rgba) m->col.assign(rgba, rgba + nv * 4);
-  m->tri.assign(tris, tris + nf * 3);
-  *out = m;
+  try {
+    std::unique_ptr<sf_mesh> m(new sf_mesh());
+    m->pos.assign(xyz, xyz + nv * 3);
+    if (rgba) m->col.assign(rgba, rgba + nv * 4);
+    m->tri.assign(tris, tris + nf * 3);
+    *out = m.release();
+  } catch (...) { return sf::fail(SF_ERR_IO, "out of memory for a mesh of %llu vertices, %llu faces", (unsigned long long)nv, (unsigned long long)nf); }
   return SF_OK;
 }
 
 SF_API int sf_mesh_create_keyed(const float* xyz, const uint8_t* rgba, const uint64_t* keys, uint64_t nv, const uint32_t* tris, const uint64_t* face_keys,
                                 uint64_t nf, sf_mesh** out) {
+  if (!out) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
   if (!keys && nv) return sf::fail(SF_ERR_INVALID_ARG, "NULL vertex keys");
   sf_mesh* m = nullptr;
   const int rc = sf_mesh_create(xyz, rgba, nv, tris, nf, &m);
   if (rc != SF_OK) return rc;
-  m->keys.assign(keys, keys + nv);
-  if (face_keys) m->tkeys.assign(face_keys, face_keys + nf);
+  try {
+    m->keys.assign(keys, keys + nv);
+    if (face_keys) m->tkeys.assign(face_keys, face_keys + nf);
+  } catch (...) {
+    delete m;
+    return sf::fail(SF_ERR_IO, "out of memory for the keys of a mesh of %llu vertices, %llu faces", (unsigned long long)nv, (unsigned long long)nf);
+  }
   *out = m;
   return SF_OK;
 }
@@ -368,9 +379,17 @@ namespace {
 template <class F>
 void parallel_for(int n_threads, F&& fn) {   // fn(t) for t in [0, n_threads); the caller's thread takes t = 0
   std::vector<std::thread> th;
-  for (int t = 1; t < n_threads; t++) th.emplace_back([&fn, t]() { fn(t); });
-  fn(0);
+  std::exception_ptr err;
+  std::mutex mu;
+  auto guarded = [&](int t) {   // an exception inside a std::thread is std::terminate: carry the first one to the caller's thread
+    try { fn(t); } catch (...) { std::lock_guard<std::mutex> lk(mu); if (!err) err = std::current_exception(); }
+  };
+  try {
+    for (int t = 1; t < n_threads; t++) th.emplace_back(guarded, t);
+  } catch (...) { std::lock_guard<std::mutex> lk(mu); if (!err) err = std::current_exception(); }
+  guarded(0);
   for (auto& x : th) x.join();
+  if (err) std::rethrow_exception(err);
 }
 
 // k sorted runs (run p = positions [lo[p], hi[p]) of part p, key(p, i) ascending in i) merged in ascending (key, part, position) order: take(p, i, key).
@@ -427,8 +446,14 @@ std::vector<std::vector<size_t>> split_runs(int k, const std::vector<size_t>& si
 
 }  // namespace
 
+static int mesh_merge_parts(const sf_mesh* const* parts, int n_parts, sf_mesh** out);
 SF_API int sf_mesh_merge_parts(const sf_mesh* const* parts, int n_parts, sf_mesh** out) {
   if (!out || n_parts < 0 || (!parts && n_parts)) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  try { return mesh_merge_parts(parts, n_parts, out); }   // no exception crosses the C ABI
+  catch (const std::exception& e) { return sf::fail(SF_ERR_IO, "sf_mesh_merge_parts: %s", e.what()); }
+  catch (...) { return sf::fail(SF_ERR_IO, "sf_mesh_merge_parts: unknown exception"); }
+}
+static int mesh_merge_parts(const sf_mesh* const* parts, int n_parts, sf_mesh** out) {
   const int k = n_parts;
   uint64_t nv = 0, nf = 0;
   bool colour = false, face_keys = k > 0;
@@ -470,7 +495,8 @@ SF_API int sf_mesh_merge_parts(const sf_mesh* const* parts, int n_parts, sf_mesh
     vsize[p] = parts[p]->keys.size();
     fsize[p] = parts[p]->tri.size() / 3;
   }
-  sf_mesh* r = new sf_mesh();
+  std::unique_ptr<sf_mesh> r_owner(new sf_mesh());
+  sf_mesh* const r = r_owner.get();
   std::vector<uint32_t> remap(nv);   // concatenated vertex index -> merged index
   auto put_vertex = [&](uint64_t u, uint64_t key, int p, size_t v) {
     const sf_mesh* m = parts[p];
@@ -553,7 +579,7 @@ SF_API int sf_mesh_merge_parts(const sf_mesh* const* parts, int n_parts, sf_mesh
         for (size_t f = fsize[p] * t / T; f < fsize[p] * (t + 1) / T; f++) put_face(fbase[p] + f, p, f);
     });
   }
-  *out = r;
+  *out = r_owner.release();
   return SF_OK;
 }
 

@@ -415,8 +415,13 @@ int set_blobs(sf_sens* s, SensFrame& f, const uint8_t* color, uint64_t color_byt
 // SensorData::replaceDepth(frameIdx, depth) (sensorData.h:948-955 -> RGBDFrame::replaceDepth :499-502): the frame's depth compressed anew with the file's
 // depth compression type; colour, pose and the COLOUR time stamp stay -- the depth time stamp goes to 0, as freeDepth() leaves it (:516-521).
 // Works on an opened file too (the Calibrate stage's use, Calibrate/src/calibration.h:303): the frame then lives in writer-owned memory.
+static int sens_replace_depth(sf_sens* s, uint64_t frame, const uint16_t* depth);
 SF_API int sf_sens_replace_depth(sf_sens* s, uint64_t frame, const uint16_t* depth) {
   if (!s || !depth) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  try { return sens_replace_depth(s, frame, depth); }   // no exception crosses the C ABI
+  catch (...) { return sf::fail(SF_ERR_IO, "out of memory replacing the depth of frame %llu", (unsigned long long)frame); }
+}
+static int sens_replace_depth(sf_sens* s, uint64_t frame, const uint16_t* depth) {
   if (frame >= s->frames.size()) return sf::fail(SF_ERR_BOUNDS, "frame %llu out of bounds (%zu frames)", (unsigned long long)frame, s->frames.size());
   const uint64_t raw = (uint64_t)s->info.depth_width * s->info.depth_height * 2;
   std::vector<uint8_t> blob;
