@@ -706,7 +706,7 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
         bound, unit, achieved, peak = "valu", "SQ_INSTS_VALU x 2 cycles / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs)", frac, 1.0
         if frac is None:   # no counter pass (no rocprofv3, --no-pmc, N > 1): the memory roofline of the pass, from its must-move bytes and the HIP-event duration
             bound, unit, achieved, peak, frac = "hbm", "GB/s", round(batch_gbs, 1), HBM_PEAK_GBS, round(batch_gbs / HBM_PEAK_GBS, 4)
-        r = {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
+        r = {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": frac,
              "valu_frac_2cycle": valu.get("valu_frac_2cycle") if valu else None, "frac_class_priced": cal["frac_serial"] if cal else None,
              "valu_peak_calibration": cal, "issue_ratio_4_cycles": valu["valu_util"] if valu else None,
              "traffic": traffic["bytes"] if traffic else None, "kernel": kernel, "sample": sample,
@@ -1350,6 +1350,11 @@ def main():
         out = run_partition(args, rank, local_rank, world, dist, torch)
     if rank == 0 and out is not None:
         # the record: ONE compact line (< 4 KB) as the last line of stdout; everything else of the measurement goes to bench_detail.json
+        if args.child:   # a counter pass of another bench.py: the parent reads the whole measurement from this line
+            print(json.dumps(out))
+            sys.stdout.flush()
+            out = None
+    if rank == 0 and out is not None:
         detail = os.environ.get("SF_BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json"))
         try:
             with open(detail, "w") as f:

@@ -125,9 +125,10 @@ def test_drop_in_executables(tmp_path):
     sens_path = str(tmp_path / "scene0000_00.sens")
     _write_sens(sens_path, 30, W, H, 1200)
     params = tmp_path / "zParametersScanNet.txt"
-    ref_params = "/root/reference/Server/tools/recons/zParametersScanNet.txt"
-    text = open(ref_params).read() if os.path.exists(ref_params) else "s_SDFVoxelSize = 0.010f;\ns_SDFTruncation = 0.06f;\ns_SDFTruncationScale = 0.02f;\n"
-    params.write_text(text + "\ns_hashNumSDFBlocks = 200000;\n")
+    # the fusion keys of Server/tools/recons/zParametersScanNet.txt:34-35,47-52 (values only: nothing under /root/reference is read by a GPU test)
+    params.write_text("s_sensorDepthMin = 0.1f;\ns_sensorDepthMax = 6.0f;\ns_SDFVoxelSize = 0.010f;\ns_SDFMarchingCubeThreshFactor = 10.0f;\ns_SDFTruncation = 0.06f;\n"
+                      "s_SDFTruncationScale = 0.02f;\ns_SDFMaxIntegrationDistance = 4.0f;\ns_SDFIntegrationWeightSample = 1;\ns_SDFIntegrationWeightMax = 99999999;\n"
+                      "s_hashNumSDFBlocks = 200000;\n")
     (tmp_path / "zParametersTrackingDefault.txt").write_text("// tracking parameters are not used by the fusion stage\n")
     out = subprocess.run([os.path.join(ROOT, "bin", "depthsensing"), str(params), str(tmp_path / "zParametersTrackingDefault.txt"), sens_path],
                          capture_output=True, text=True, cwd=str(tmp_path))
@@ -153,6 +154,21 @@ def test_drop_in_executables(tmp_path):
     js = json.load(open(str(tmp_path / "scene0000_00_vh_clean.0.010000.segs.json")))
     assert js["params"] == {"kThresh": 0.01, "segMinVerts": 20} and js["sceneId"] == "/scene0000_00_vh_clean"
     assert len(js["segIndices"]) == nv
+    # north_star: "bit-exact on segIndices for a fixed kThresh" -- the REFERENCE Segmentator (oracle/_ref/segmentator_ref, compiled from the reference's
+    # own sources by oracle/Makefile; it travels to the GPU box prebuilt) on the very mesh the GPU extracted and cleaned: same segIndices, same file bytes
+    # (segmentator.cpp:253-287 writes beside its input, so it gets a copy of the mesh in a directory of its own)
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "segmentator_ref")
+    assert os.path.exists(ref_bin), "oracle/_ref/segmentator_ref is missing: __graft_entry__.build() makes it where /root/reference exists and it ships with the snapshot"
+    ref_dir = tmp_path / "ref"
+    ref_dir.mkdir()
+    shutil.copy(clean_ply, str(ref_dir / "scene0000_00_vh_clean.ply"))
+    rr = subprocess.run([ref_bin, str(ref_dir / "scene0000_00_vh_clean.ply")], capture_output=True, text=True)
+    assert rr.returncode == 0, rr.stderr
+    ours = open(str(tmp_path / "scene0000_00_vh_clean.0.010000.segs.json"), "rb").read()
+    theirs = open(str(ref_dir / "scene0000_00_vh_clean.0.010000.segs.json"), "rb").read()
+    assert json.loads(theirs)["segIndices"] == js["segIndices"]
+    assert len(set(js["segIndices"])) > 10          # a real over-segmentation, not one label
+    assert ours == theirs
     # failure protocol: non-zero exit and a message on stderr
     bad = subprocess.run([os.path.join(ROOT, "bin", "depthsensing"), str(params), str(params), str(tmp_path / "missing.sens")], capture_output=True, text=True)
     assert bad.returncode != 0 and "could not open" in bad.stderr
@@ -825,13 +841,18 @@ def test_bench_with_two_ranks_sharing_one_gpu():
     never read measures one GPU (round 3).  The rates mean nothing here."""
     import sys
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    import tempfile
     for extra in (["--steps", "64", "--warmup", "5", "--repeats", "3", "--no-pmc"], ["--config", "partition", "--scan-frames", "600"]):
+        detail = os.path.join(tempfile.mkdtemp(prefix="sf_bench_"), "detail.json")
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu"] + extra,
-                           capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
+                           capture_output=True, text=True, cwd=ROOT, timeout=600, env=dict(env, SF_BENCH_DETAIL=detail))
         assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         assert len(lines) == 1, r.stdout[-1500:]          # rank 0 prints ONE line
-        j = json.loads(lines[0])
+        line = json.loads(lines[0])                       # ... the compact record (< 4 KB, the last line of stdout); the full measurement is in the detail file
+        assert len(lines[0]) < 4096 and r.stdout.rstrip().splitlines()[-1] == lines[0] and line["detail"] == detail
+        j = json.load(open(detail))
+        assert line["value"] == j["value"] and line["n_gpus"] == 2 and line["process_group"] == "gloo"
         assert j["n_gpus"] == 2 and j["value"] > 0 and j["unit"] == "frames/s" and j["process_group"] == "gloo"
         if "partition" in extra:
             assert j["exchange"]["mode"] == "neighbour" and j["exchange"]["boundary_blocks_sent_total"] == j["exchange"]["ghost_blocks_received_total"] > 0

@@ -28,11 +28,15 @@ needs_two = pytest.mark.skipif(_gpus() < 2, reason="needs two GPUs (RCCL refuses
 
 def _bench(extra, timeout=900):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + extra, capture_output=True, text=True, cwd=ROOT, timeout=timeout, env=env)
+    import tempfile
+    detail = os.path.join(tempfile.mkdtemp(prefix="sf_bench_"), "detail.json")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + extra, capture_output=True, text=True, cwd=ROOT, timeout=timeout,
+                       env=dict(env, SF_BENCH_DETAIL=detail))
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-1500:]          # rank 0 prints ONE line
-    return json.loads(lines[0])
+    assert len(lines) == 1 and len(lines[0]) < 4096, r.stdout[-1500:]          # rank 0 prints ONE compact line; the full measurement goes to the detail file
+    assert json.loads(lines[0])["n_gpus"] == 2
+    return json.load(open(detail))
 
 
 @needs_two
