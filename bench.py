@@ -293,7 +293,8 @@ _COST_MODEL = {}
 def valu_cost_model(depth_only):
     """tools/valu_cost_model.py on the library this process loaded: the frame loop of the timed integrate kernel priced with the per-class issue costs
     tools/gpu/valu_peak.hip measured on the MI355X (profiles/r05_valu_issue_table.txt).  None when the disassembler is not there."""
-    key = "k_integrateILi1ELi%dELb1ELi2ELb0ELi4E" % (0 if depth_only else 2)   # <SIGN 1, COLOR, TAB, WM 2, ROWS false, NJ 4>: the variant every pass but a call's last runs
+    # <SIGN 1, COLOR, TAB, WM 2, ROWS false, NJ 4, XR>: the variant every pass but a call's last runs (XR: the x-row lane layout, tune "xrow", default on)
+    key = "k_integrateILi1ELi%dELb1ELi2ELb0ELi4ELb%dE" % (0 if depth_only else 2, 1 if TUNE.get("xrow", 1) else 0)
     if key not in _COST_MODEL:
         try:
             import importlib.util
@@ -735,7 +736,8 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
         return r
 
     R = 1 if child else (args.repeats if args.repeats else repeats_for(K, cfg_name))
-    kname = "k_integrate<1,2,true,2,false>" if rgbd else "k_integrate<1,0,true,2,false>"
+    xr = "true" if TUNE.get("xrow", 1) else "false"
+    kname = ("k_integrate<1,2,true,2,false,4,%s>" if rgbd else "k_integrate<1,0,true,2,false,4,%s>") % xr
     # the timed region runs WITHOUT the HIP events around every integrate launch (they cost ~2 % of the frames/s: profiles/r03_small_experiments.txt);
     # kernel durations come from the roofline sample below, fused again with the events on.  --single-frame keeps them: its line is the roofline.
     m = run(Wm, K, args.single_frame and not args.no_profile, single_frame=args.single_frame, repeats=R)
@@ -810,7 +812,7 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
             out["value_depth_only"] = round(K / md["elapsed"], 2)
             mdr = run(roof_W, roof_K, True, colour=False)
             vd = pmc_valu(args, cfg_name, roof_K, roof_W, False, True) if pmc_on else None
-            rd = roofline_valu(mdr, roof_K, "k_integrate<1,0,true,2,false>", vd, None,
+            rd = roofline_valu(mdr, roof_K, "k_integrate<1,0,true,2,false,4,%s>" % xr, vd, None,
                                "frames %d..%d of the stream without the colour frames, HIP events around every integrate launch" % (roof_W, roof_W + roof_K - 1))
             if rd is not None:
                 rd["frames_per_s"] = out["value_depth_only"]

@@ -35,6 +35,9 @@ extern "C" {
  *                        `ramp` but no more than `batch` frames is fused as two halves (default 1)
  *   "tail_wide"   0/1    the LAST pass of a sf_fuser_integrate_batch_device call (no front chain runs beside it) takes the variant of k_integrate that fuses
  *                        the tile in halves at 8 waves per SIMD (default 1: +0.8 % on a 20-frame call; slower for a pass as a whole when allocation runs beside it)
+ *   "xrow"        0/1    passes of several frames run k_integrate in the x-row lane layout: a lane holds one x-row of the block (y = lane & 7, z = lane >> 3)
+ *                        instead of two x-neighbours in four z-layers -- the same voxels, 18 fma fewer per lane and frame, and the gathers of one instruction
+ *                        fall on two image rows instead of four or five (default 1)
  * Synchronises the fuser.  SF_ERR_INVALID_ARG for an unknown key or a value out of range. */
 int sf_fuser_tune(sf_fuser* f, const char* key, int value);
 

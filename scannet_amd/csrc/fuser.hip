@@ -864,6 +864,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SF_ALLOC_WA
 // saturates at ~88 atomics/us on this chip).  all_live = 1 lists every live block (export), 2 every live block this
 // fuser owns (GC, meshing); ghost copies of a neighbour slab's blocks are never fused.
 // ---------------------------------------------------------------------------------------------------
+// The frustum tests of a batch are (directory entry) x (frame) independent tests of ~25 instructions.  Until round 5 every lane ran the B.n tests of its four
+// entries one after the other with the frame's constants re-read from the kernarg segment per test: 62-105 us per pass at 2 % of the vector ALUs' issue rate
+// (1 600 waves in flight, each a serial chain of 128 scalar-load round trips).  Now, for batches of more than FEW frames, a lane IS a (entry, frame) pair:
+// lane = sub * FPL + q holds frame q's constants in registers for the life of the workgroup (FPL = 8 / 16 / 32 frames per lane group), the workgroup's 1024
+// block coordinates wait in LDS, and one step tests 64 / FPL entries against all frames at once -- the ballot of the step IS the entries' frame masks.
+// Same function (block_in_frustum), same operands: the masks are the ones the serial loop produced.
+constexpr int COMPACT_FEW = 4;   // up to this many frames per pass the serial loop stays (a live stream's one frame per pass would leave 31 of 32 lanes idle)
+
 __global__ __launch_bounds__(256) void k_compactify(const uint64_t* __restrict__ block_keys, const int32_t* __restrict__ block_entry,
                                                     const uint8_t* __restrict__ block_flags, const HashEntry* __restrict__ table,
                                                     int32_t* __restrict__ compact,
@@ -871,26 +879,74 @@ __global__ __launch_bounds__(256) void k_compactify(const uint64_t* __restrict__
                                                     BatchFrames B) {
   __shared__ int s_wtot[4], s_wlast[4], s_wpop[4];
   __shared__ int s_base;
+  __shared__ int4 s_c[1024];        // (bx, by, bz, listed?) of the workgroup's 1024 directory entries
+  __shared__ uint32_t s_m[1024];    // their frame masks
   const int hw = counters[C_HIGH_WATER];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t last_bit = 1u << (B.n - 1);
+  const bool wide = !all_live && B.n > COMPACT_FEW;   // uniform
+  // frames per lane group: the smallest of 8 / 16 / 32 that holds the batch
+  const int fshift = B.n <= 8 ? 3 : (B.n <= 16 ? 4 : 5);
+  const int q = lane & ((1 << fshift) - 1), sub = lane >> fshift, epi = 64 >> fshift;
+  FrameK F;
+  if (wide) {
+    // frame q's constants into this lane's registers: uniform-index reads of the kernarg segment, kept by the lanes of that frame
+    F = B.f[0];
+    for (int qq = 1; qq < B.n; qq++) {
+      const FrameK& G = B.f[qq];
+      if (q == qq) F = G;
+    }
+  }
   for (int base = blockIdx.x * 1024; base < hw; base += gridDim.x * 1024) {
     uint32_t m[4];
     int rank[4];
     int wtotal = 0, wlast = 0, pop = 0;
+    if (wide) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int i = base + j * 256 + threadIdx.x;
+        int4 c = make_int4(0, 0, 0, 0);
+        if (i < hw) {
+          const uint64_t k = block_keys[i];
+          if (k != KEY_EMPTY && !(block_flags[i] & 1)) {   // ghosts are never fused
+            unpack_key(k, c.x, c.y, c.z);
+            c.w = 1;
+          }
+        }
+        s_c[j * 256 + threadIdx.x] = c;
+      }
+      __syncthreads();
+      const uint64_t gmask = fshift == 5 ? 0xFFFFFFFFull : ((1ull << (1 << fshift)) - 1ull);
+      for (int e0 = wave * 256; e0 < wave * 256 + 256; e0 += epi) {   // this wave's quarter of the workgroup's entries, 64 / FPL of them per step
+        const int4 c = s_c[e0 + sub];
+        const bool in = c.w != 0 && q < B.n && block_in_frustum(P, F, c.x, c.y, c.z);
+        const uint64_t bal = __ballot(in);
+        if (q == 0) s_m[e0 + sub] = (uint32_t)((bal >> (sub << fshift)) & gmask);
+      }
+      __syncthreads();
+    }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const int i = base + j * 256 + threadIdx.x;
       m[j] = 0u;
-      if (i < hw) {
+      if (wide) {
+        m[j] = s_m[j * 256 + threadIdx.x];
+        if (m[j] != 0u) {
+          const uint32_t birth = table[block_entry[i]].birth;
+          if (birth > B.seq0) {
+            const uint32_t d = birth - B.seq0;
+            m[j] = d >= 32u ? 0u : (m[j] & ~((1u << d) - 1u));
+          }
+        }
+      } else if (i < hw) {
         const uint64_t k = block_keys[i];
         if (k != KEY_EMPTY && !(all_live != 1 && (block_flags[i] & 1))) {  // ghosts are listed by all_live == 1 only
           if (all_live) m[j] = 1u;
           else {
             int bx, by, bz;
             unpack_key(k, bx, by, bz);
-            for (int q = 0; q < B.n; q++)
-              if (block_in_frustum(P, B.f[q], bx, by, bz)) m[j] |= 1u << q;
+            for (int qq = 0; qq < B.n; qq++)
+              if (block_in_frustum(P, B.f[qq], bx, by, bz)) m[j] |= 1u << qq;
             if (m[j] != 0u && B.n > 1) {
               const uint32_t birth = table[block_entry[i]].birth;
               if (birth > B.seq0) {
@@ -1058,6 +1114,40 @@ __device__ inline void fuse_project(const ParamsK& P, const FrameV& FV, v2f wx, 
   }
 }
 
+// The same projection for the X-ROW layout (XR): a lane holds the eight voxels of ONE x-row of the block -- y = lane & 7, z = lane >> 3, register pair j =
+// voxels x = 2j, 2j + 1 -- instead of two x-neighbours in each of four z-layers.  Two things follow:
+//   * the inner two fma of every camera-space coordinate, fma(Ti[1], wy, fma(Ti[2], wz, Ti[3])), depend on (y, z) only: ONE set per lane and frame instead of one
+//     per z-row (6 fma instead of 24; the nesting -- hence every bit -- is the specification's);
+//   * one gather instruction now reads the voxels of one x-plane of the block, 8 y x 8 z: 16 consecutive lanes (the unit the L1 coalesces) are 8 y x 2 z at one
+//     x -- two image rows' worth of pixels for a level camera -- where the pair layout spread 4 x by 4 y over four or five rows.  The L1 tag pipeline was the
+//     busiest unit of the pass (0.79-0.86 look-ups per CU and clock, 33.6 per gather instruction: profiles/r06_*).
+template <int J0, int NJ>
+__device__ inline void fuse_project_xr(const ParamsK& P, const FrameV& FV, const v2f (&wxp)[4], float wy, float wz, v2f (&pz)[NJ],
+                                       uint32_t (&pix)[2 * NJ], bool (&ok)[2 * NJ]) {
+  const float* Ti = FV.ti;
+  const uint32_t uw = (uint32_t)P.W, uh = (uint32_t)P.H;
+  const float ax = fmaf(Ti[1], wy, fmaf(Ti[2], wz, Ti[3]));
+  const float ay = fmaf(Ti[5], wy, fmaf(Ti[6], wz, Ti[7]));
+  const float az = fmaf(Ti[9], wy, fmaf(Ti[10], wz, Ti[11]));
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    const v2f pcx = pk_fma(splat(Ti[0]), wxp[J0 + j], splat(ax));
+    const v2f pcy = pk_fma(splat(Ti[4]), wxp[J0 + j], splat(ay));
+    const v2f pcz = pk_fma(splat(Ti[8]), wxp[J0 + j], splat(az));
+    const v2f rz = recip_rn(pcz);
+    const v2f uf = pk_add(pk_fma(pcx * splat(FV.fx), rz, splat(FV.mx)), splat(0.5f));
+    const v2f vf = pk_add(pk_fma(pcy * splat(FV.fy), rz, splat(FV.my)), splat(0.5f));
+    pz[j] = pcz;
+#pragma unroll
+    for (int hx = 0; hx < 2; hx++) {
+      const uint32_t px = (uint32_t)cvt_i32(uf[hx]), py = (uint32_t)cvt_i32(vf[hx]);
+      const bool in = (pcz[hx] > 0.0f) && (px < uw) && (py < uh);
+      ok[2 * j + hx] = in;
+      pix[2 * j + hx] = __umul24(py, uw) + px;
+    }
+  }
+}
+
 // Phase B: the update of DESIGN.md 3.5 from the gathered depths (colours) into the tile registers.
 // WM (weight mode): 0 = any weight_sample / weight_max, 1 = weight_sample == 1, 2 = weight_sample == 1 and weight_max == 255 (the shipped
 // parameters after the uchar clamp): the weight byte then increments with saturation as ONE add-with-carry on the {rgb, weight} word;
@@ -1201,9 +1291,9 @@ __device__ inline __amdgpu_buffer_rsrc_t image_rsrc(const void* base, uint32_t b
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);   // raw buffer, dword data format (gfx9)
 }
 
-template <int SIGN, int COLOR, bool TAB, int WM, int J0, int NJ, bool ROWS>
+template <int SIGN, int COLOR, bool TAB, int WM, int J0, int NJ, bool ROWS, bool XR = false>
 __device__ inline void fuse_rows(const ParamsK& P, const float* __restrict__ Ti, const float* __restrict__ depthf,
-                                 const uint2* __restrict__ texel, const float* rtab, v2f wx, float wy, const float (&wz)[4],
+                                 const uint2* __restrict__ texel, const float* rtab, v2f wx, float wy, const float (&wz)[4], const v2f (&wxp)[4],
                                  uint4 (&v)[4], uint64_t (&dirty)[4]) {
   v2f pz[NJ], rcp_m[NJ];
   float d[2 * NJ];
@@ -1221,7 +1311,8 @@ __device__ inline void fuse_rows(const ParamsK& P, const float* __restrict__ Ti,
   }
   // ---- phase A: project; then the gathers, all issued together
   const FrameV FV = frame_constants(P, Ti);
-  fuse_project<J0, NJ, false>(P, FV, wx, wy, wz, pz, pix, ok);
+  if (XR) fuse_project_xr<J0, NJ>(P, FV, wxp, wy, wz[0], pz, pix, ok);   // wz[0]: the lane's one z
+  else fuse_project<J0, NJ, false>(P, FV, wx, wy, wz, pz, pix, ok);
 #ifdef SF_ABLATE_GATHER   // measurement only (wrong voxels): every lane gathers ONE texel per row -- what do the gathers' cache look-ups cost a pass?
 #pragma unroll
   for (int k = 0; k < 2 * NJ; k++) pix[k] = (uint32_t)(SF_ABLATE_GATHER == 1 ? 0 : (pix[k] & ~63u));
@@ -1259,8 +1350,8 @@ __device__ inline void fuse_rows(const ParamsK& P, const float* __restrict__ Ti,
 // (profiles/r05_integrate_ab.txt).  Alone the two variants are within a few per cent.  NJ = 2 runs the LAST pass of a sf_fuser_integrate_batch_device call
 // -- nothing is queued behind that pass, no front chain runs beside it: +0.8 % on a 20-frame call, measured --, every other pass NJ = 4 at 5 waves.  Same
 // voxels either way (tests/test_gpu_tsdf.py::test_batched_pass_equals_frame_by_frame runs both).
-template <int SIGN, int COLOR, bool TAB, int WM, bool ROWS, int NJ = SF_INT_NJ>
-__global__ __launch_bounds__(256, NJ == 2 ? 8 : SF_INT_WAVES) void k_integrate(uint4* __restrict__ voxels, const uint64_t* __restrict__ block_keys,
+template <int SIGN, int COLOR, bool TAB, int WM, bool ROWS, int NJ = SF_INT_NJ, bool XR = false>
+__global__ __launch_bounds__(256, NJ == 2 ? (XR ? 7 : 8) : SF_INT_WAVES) void k_integrate(uint4* __restrict__ voxels, const uint64_t* __restrict__ block_keys,
                                                    const int32_t* __restrict__ compact, const uint32_t* __restrict__ cmask,
                                                    const float* __restrict__ depthf_all, const uint2* __restrict__ texel_all,
                                                    int32_t* counters, int32_t* host_mirror, int compact_counter, int xcd_walk, ParamsK P,
@@ -1284,9 +1375,11 @@ __global__ __launch_bounds__(256, NJ == 2 ? 8 : SF_INT_WAVES) void k_integrate(u
     atomicExch(&counters[C_LAST_BLOCKS], counters[compact_counter + 1]);  // counters share cache lines with words the front stream updates atomically
     if (host_mirror) *host_mirror = n;
   }
-  const int lx = (2 * lane) & 7;
-  const int ly = (lane >> 2) & 7;
-  const int lzb = lane >> 5;
+  // pair layout: lane l, load j = uint4 64 j + l = voxels x = (2l) & 7 (+1), y = (l >> 2) & 7, z = 2j + (l >> 5);
+  // x-row layout (XR): lane l, load j = uint4 4 l + j = voxels x = 2j (+1), y = l & 7, z = l >> 3 (the lane's 64 contiguous bytes of the tile)
+  const int lx = XR ? 0 : (2 * lane) & 7;
+  const int ly = XR ? lane & 7 : (lane >> 2) & 7;
+  const int lzb = XR ? lane >> 3 : lane >> 5;
   const size_t npx = (size_t)P.W * P.H;
   // XCD-aware walk of the list: workgroup b runs on XCD b % 8 (observed placement; a speed hint only, any placement is
   // correct).  Each XCD takes ONE contiguous eighth of the list -- neighbouring list entries are neighbouring blocks
@@ -1307,12 +1400,16 @@ __global__ __launch_bounds__(256, NJ == 2 ? 8 : SF_INT_WAVES) void k_integrate(u
     uint4* vb = voxels + (size_t)slot * 256;
     uint4 v[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) v[j] = vb[j * 64 + lane];
+    for (int j = 0; j < 4; j++) v[j] = vb[XR ? lane * 4 + j : j * 64 + lane];
     const v2f wx = {(float)(8 * bx + lx) * P.voxel, (float)(8 * bx + lx + 1) * P.voxel};
     const float wy = (float)(8 * by + ly) * P.voxel;
     float wz[4];
+    v2f wxp[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) wz[j] = (float)(8 * bz + 2 * j + lzb) * P.voxel;
+    for (int j = 0; j < 4; j++) {
+      wz[j] = (float)(8 * bz + (XR ? 0 : 2 * j) + lzb) * P.voxel;
+      wxp[j] = v2f{(float)(8 * bx + 2 * j) * P.voxel, (float)(8 * bx + 2 * j + 1) * P.voxel};
+    }
     uint64_t dirty[4] = {0ull, 0ull, 0ull, 0ull};
     // temporal blocking: the tile stays in registers while every frame of the batch that sees the block is fused
     // into it, in frame order (the same sequence of updates per voxel as frame-by-frame integration)
@@ -1324,19 +1421,19 @@ __global__ __launch_bounds__(256, NJ == 2 ? 8 : SF_INT_WAVES) void k_integrate(u
       const uint2* __restrict__ texel = texel_all + (size_t)q * npx;
 #pragma unroll
       for (int j0 = 0; j0 < 4; j0 += NJ) {
-        if (j0 == 0) fuse_rows<SIGN, COLOR, TAB, WM, 0, NJ, ROWS>(P, Ti, depthf, texel, s_rtab, wx, wy, wz, v, dirty);
-        if (j0 == 1) fuse_rows<SIGN, COLOR, TAB, WM, 1 % (5 - NJ), NJ, ROWS>(P, Ti, depthf, texel, s_rtab, wx, wy, wz, v, dirty);
-        if (j0 == 2) fuse_rows<SIGN, COLOR, TAB, WM, 2 % (5 - NJ), NJ, ROWS>(P, Ti, depthf, texel, s_rtab, wx, wy, wz, v, dirty);
-        if (j0 == 3) fuse_rows<SIGN, COLOR, TAB, WM, 3 % (5 - NJ), NJ, ROWS>(P, Ti, depthf, texel, s_rtab, wx, wy, wz, v, dirty);
+        if (j0 == 0) fuse_rows<SIGN, COLOR, TAB, WM, 0, NJ, ROWS, XR>(P, Ti, depthf, texel, s_rtab, wx, wy, wz, wxp, v, dirty);
+        if (j0 == 1) fuse_rows<SIGN, COLOR, TAB, WM, 1 % (5 - NJ), NJ, ROWS, XR>(P, Ti, depthf, texel, s_rtab, wx, wy, wz, wxp, v, dirty);
+        if (j0 == 2) fuse_rows<SIGN, COLOR, TAB, WM, 2 % (5 - NJ), NJ, ROWS, XR>(P, Ti, depthf, texel, s_rtab, wx, wy, wz, wxp, v, dirty);
+        if (j0 == 3) fuse_rows<SIGN, COLOR, TAB, WM, 3 % (5 - NJ), NJ, ROWS, XR>(P, Ti, depthf, texel, s_rtab, wx, wy, wz, wxp, v, dirty);
       }
     }
     if (ROWS) {
 #pragma unroll
       for (int j = 0; j < 4; j++)
-        if ((dirty[j] >> lane) & 1ull) vb[j * 64 + lane] = v[j];
+        if ((dirty[j] >> lane) & 1ull) vb[XR ? lane * 4 + j : j * 64 + lane] = v[j];
     } else if (dirty[0] != 0ull) {   // wave-uniform: some frame of the pass changed a voxel of this tile -- the whole tile goes back, four 1 KiB stores
 #pragma unroll
-      for (int j = 0; j < 4; j++) vb[j * 64 + lane] = v[j];
+      for (int j = 0; j < 4; j++) vb[XR ? lane * 4 + j : j * 64 + lane] = v[j];
     }
   }
 }
@@ -1987,9 +2084,14 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
       const bool wide = f->tail_pass && f->tail_wide && n > 1;   // the last pass of a batch call: no front chain beside it, the 8-wave variant (k_integrate)
 #define LAUNCH_INT_WIDE(CL) hipLaunchKernelGGL((k_integrate<1, CL, true, 2, false, 2>), dim3(grid), dim3(256), 0, s, f->voxels, f->block_keys, f->compact2[sl], f->cmask2[sl], \
                                                f->depthf2[sl], f->color2[sl], f->counters, f->host_mirror, cc, f->xcd_walk ? 1 : 0, f->pk, bt)
-      if (col && !f->p.colour_first) { if (wide) LAUNCH_INT_WIDE(2); else LAUNCH_INT(1, 2, true, 2); }
+      // the x-row lane layout (fuse_project_xr) for every pass of several frames: same voxels, the gathers of one instruction on two image rows instead of five
+#define LAUNCH_INT_XR(CL, NJV) hipLaunchKernelGGL((k_integrate<1, CL, true, 2, false, NJV, true>), dim3(grid), dim3(256), 0, s, f->voxels, f->block_keys, f->compact2[sl], f->cmask2[sl], \
+                                                  f->depthf2[sl], f->color2[sl], f->counters, f->host_mirror, cc, f->xcd_walk ? 1 : 0, f->pk, bt)
+      const bool xr = f->xrow && n > 1;
+      if (col && !f->p.colour_first) { if (xr && wide) LAUNCH_INT_XR(2, 2); else if (xr) LAUNCH_INT_XR(2, SF_INT_NJ); else if (wide) LAUNCH_INT_WIDE(2); else LAUNCH_INT(1, 2, true, 2); }
       else if (col) LAUNCH_INT(1, 1, true, 2);
-      else { if (wide) LAUNCH_INT_WIDE(0); else LAUNCH_INT(1, 0, true, 2); }
+      else { if (xr && wide) LAUNCH_INT_XR(0, 2); else if (xr) LAUNCH_INT_XR(0, SF_INT_NJ); else if (wide) LAUNCH_INT_WIDE(0); else LAUNCH_INT(1, 0, true, 2); }
+#undef LAUNCH_INT_XR
 #undef LAUNCH_INT_WIDE
     }
     else if (ws1) { if (col) LAUNCH_INT(1, 1, true, 1); else LAUNCH_INT(1, 0, true, 1); }
@@ -2413,6 +2515,7 @@ SF_API int sf_fuser_tune(sf_fuser* f, const char* key, int value) {
   else if (k == "ramp" && in(0, MAX_BATCH)) f->ramp = value;
   else if (k == "ramp_geo" && in(0, 1)) f->ramp_geo = value != 0;
   else if (k == "tail_wide" && in(0, 1)) f->tail_wide = value;
+  else if (k == "xrow" && in(0, 1)) f->xrow = value != 0;
   else return sf::fail(SF_ERR_INVALID_ARG, "sf_fuser_tune: unknown key or value out of range: %s = %d", key, value);
   return SF_OK;
 }

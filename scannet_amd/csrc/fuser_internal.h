@@ -222,6 +222,7 @@ struct sf_fuser {
   int alloc_group_head = 4; // tune "alloc_group_head": frames per allocation workgroup in that pass (0 = as every pass).  A 20-frame call: 30.8 k -> 31.8 k frames/s
   bool tail_pass = false;   // set around the last run_batch of a sf_fuser_integrate_batch_device call
   int tail_wide = 1;        // tune "tail_wide": that pass runs the 8-waves-per-SIMD variant of k_integrate
+  bool xrow = true;         // tune "xrow": passes of several frames run k_integrate in the x-row lane layout (a lane = one x-row of the block: fuse_project_xr)
   uint2* color2[2] = {nullptr, nullptr};       // MAX_BATCH x W*H {depth bits, rgb} texels per batch slot (RGB-D batches)
   int32_t* compact2[2] = {nullptr, nullptr};   // heap slots of the blocks some frame of the batch sees
   uint32_t* cmask2[2] = {nullptr, nullptr};    // per compact entry: bit j = frame j of the batch updates this block

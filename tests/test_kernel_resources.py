@@ -31,8 +31,8 @@ def test_fusion_kernels_live_in_registers(rows):
         assert r["lds"] <= 160 * 1024, (r["short"], r["lds"])                       # one CU's LDS on gfx950
     integ = [r for r in hot if r["short"].startswith("k_integrate<")]
     assert len(integ) >= 20 and max(r["vgpr"] + r["agpr"] for r in integ) <= 96      # at least 5 waves per SIMD (512 // 96) for every variant
-    timed = [r for r in integ if r["short"] in ("k_integrate<1, 2, true, 2, false, 4>", "k_integrate<1, 0, true, 2, false, 4>")]
-    assert len(timed) == 2                                                           # the two kernels bench.py times (RGB-D, depth only)
+    timed = [r for r in integ if r["short"] in ("k_integrate<1, 2, true, 2, false, 4, true>", "k_integrate<1, 0, true, 2, false, 4, true>")]
+    assert len(timed) == 2                                                           # the two kernels bench.py times (RGB-D, depth only; x-row lane layout)
 
 
 def test_kernels_with_private_memory_are_the_known_ones(rows):
