@@ -184,6 +184,21 @@ int sf_fuser_set_stripes(sf_fuser* f, int axis, int32_t origin_block, int32_t th
 int sf_fuser_export_boundary(sf_fuser* f, int32_t* coords, void* voxels, uint64_t capacity, uint64_t* n, int dst_on_device);
 int sf_fuser_import_ghosts(sf_fuser* f, const int32_t* coords, const void* voxels, uint64_t n, int src_on_device, uint64_t* imported);
 
+/* The exchange step itself for host programs WITHOUT a process group (bin/depthsensing --ranks N: N copies of one executable, one per GPU; callers that
+ * have torch.distributed use scannet_amd/partition.py): rank r's boundary layers go to rank r - 1, rank r + 1's come in and the wanted ones are kept
+ * as ghosts -- from device memory to device memory, nothing staged on the host.  Transport: RCCL (ncclSend / ncclRecv over xGMI; librccl.so is loaded
+ * with dlopen when the first exchange is created) for ranks on distinct GPUs, a hipIpc mapping of the owner's buffer for ranks that share a device
+ * (RCCL refuses those) or where librccl is absent; SF_EXCHANGE_AUTO picks -- identically on every rank, from notes the ranks leave in
+ * `rendezvous_dir` (a directory only this run's ranks see; a file named "abort" in it makes every wait give up).  The north star's all-gather of the
+ * boundary blocks is this ring shift with the blocks nobody but one neighbour needs left out (SURVEY 8e "cheaper equivalent").
+ * SF_ERR_UNSUPPORTED: no device-to-device transport on every rank -- the caller falls back to its own (files). */
+typedef struct sf_exchange sf_exchange;
+enum { SF_EXCHANGE_AUTO = 0, SF_EXCHANGE_RCCL = 1, SF_EXCHANGE_IPC = 2 };
+int sf_exchange_create(const char* rendezvous_dir, int rank, int ranks, int device, int transport, sf_exchange** out);
+int sf_exchange_boundary(sf_exchange* x, sf_fuser* f, uint64_t* sent, uint64_t* received, uint64_t* kept);
+const char* sf_exchange_transport(const sf_exchange* x);   /* what sf_exchange_create chose, for the log */
+void sf_exchange_destroy(sf_exchange* x);
+
 /* Fuse frames [first, last) of an opened .sens file (last = 0: to the end): a pool of `decode_threads` (0 = one
  * per core, at most 32 / 64) fills pinned buffers in frame order -- zlib depth frames as the reference's writer
  * stores them (one fixed-Huffman block, stb_image_write.h:733-736) are copied COMPRESSED and inflated on the GPU

@@ -8,9 +8,10 @@
 //
 // --ranks N (not an argument of the tool this replaces): ONE scan over N GPUs, BASELINE configs[4] -- this process starts N copies of itself, one per
 // GPU (SF_DEVICE + rank).  Every rank reads the whole file and fuses the stripes of the block space it owns (sf_fuser_set_stripes: 16 block layers
-// along x dealt round-robin); before meshing, rank r hands the lowest layer of each of its stripes to rank r - 1 (the only exchange of the path: one
-// file per rank in /dev/shm -- host processes without a process group; scannet_amd/partition.py is the same exchange over RCCL for callers that have
-// one); every rank meshes its own blocks and the parent merges the parts by key (sf_mesh_merge_parts) into the mesh one GPU would have written.
+// along x dealt round-robin); before meshing, rank r hands the lowest layer of each of its stripes to rank r - 1 -- the only exchange of the path, device
+// to device: RCCL send / recv between the GPUs, a hipIpc mapping between ranks that share one (csrc/exchange.hip; files in the exchange directory only
+// when neither comes up; scannet_amd/partition.py is the same exchange for callers that have a torch.distributed process group); every rank meshes its
+// own blocks and the parent merges the parts by key (sf_mesh_merge_parts) into the mesh one GPU would have written.
 #include <signal.h>
 #include <fcntl.h>
 #include <spawn.h>
@@ -203,7 +204,24 @@ int fuse_scan(const Args& a) {
   }
   if (part) {
     // the exchange step: my stripes' lowest layers out, my right neighbour's in (rank r's stripes lie right above rank r - 1's; ghosts are read as
-    // neighbours by marching cubes and never fused or meshed).  sf_fuser_import_ghosts keeps only the blocks this fuser needs.
+    // neighbours by marching cubes and never fused or meshed).  Device to device (sf_exchange_*: RCCL send / recv between GPUs, a hipIpc mapping
+    // between ranks that share one); SF_EXCHANGE=file|ipc|rccl forces a transport, and files in the exchange directory are what is left when no
+    // device-to-device transport comes up on every rank (the decision is the same on every rank: sf_exchange_create).
+    const char* want = std::getenv("SF_EXCHANGE");
+    const bool files_only = want && !std::strcmp(want, "file");
+    const int transport = want && !std::strcmp(want, "rccl") ? SF_EXCHANGE_RCCL : (want && !std::strcmp(want, "ipc") ? SF_EXCHANGE_IPC : SF_EXCHANGE_AUTO);
+    if (want && !files_only && transport == SF_EXCHANGE_AUTO && std::strcmp(want, "auto")) return die_msg("SF_EXCHANGE=%s: expected file, ipc, rccl or auto", want);
+    sf_exchange* xch = nullptr;
+    int xrc = files_only ? SF_ERR_UNSUPPORTED : sf_exchange_create(a.ipc.c_str(), a.rank, a.ranks, device, transport, &xch);
+    if (xrc != SF_OK && xrc != SF_ERR_UNSUPPORTED) return die("exchange set-up");
+    if (xrc != SF_OK && !files_only && transport != SF_EXCHANGE_AUTO) return die("exchange set-up");   // a transport that was asked for by name is not replaced silently
+    if (xrc == SF_OK) {
+      uint64_t n = 0, k = 0, got = 0;
+      if (sf_exchange_boundary(xch, fuser, &n, &k, &got) != SF_OK) return die("exchange");
+      say("Exchange: %llu boundary blocks sent to rank %d, %llu of rank %d's %llu kept as ghosts -- over %s\n", (unsigned long long)n,
+          (a.rank + a.ranks - 1) % a.ranks, (unsigned long long)got, (a.rank + 1) % a.ranks, (unsigned long long)k, sf_exchange_transport(xch));
+      sf_exchange_destroy(xch);
+    } else {
     const pid_t parent = getppid();
     uint64_t n = 0, got = 0;
     if (sf_fuser_export_boundary(fuser, nullptr, nullptr, 0, &n, 0) != SF_OK) return die("boundary count");
@@ -227,8 +245,9 @@ int fuse_scan(const Args& a) {
     if (fp) std::fclose(fp);
     if (!ok) return die_msg("could not read %s", from.c_str());
     if (k && sf_fuser_import_ghosts(fuser, coords.data(), voxels.data(), k, 0, &got) != SF_OK) return die("ghost import");
-    say("Exchange: %llu boundary blocks sent to rank %d, %llu of rank %d's %llu kept as ghosts\n", (unsigned long long)n, (a.rank + a.ranks - 1) % a.ranks,
-        (unsigned long long)got, (a.rank + 1) % a.ranks, (unsigned long long)k);
+    say("Exchange: %llu boundary blocks sent to rank %d, %llu of rank %d's %llu kept as ghosts -- over files in %s (no device-to-device transport)\n", (unsigned long long)n,
+        (a.rank + a.ranks - 1) % a.ranks, (unsigned long long)got, (a.rank + 1) % a.ranks, (unsigned long long)k, a.ipc.c_str());
+    }
   }
   sf_mesh* mesh = nullptr;
   if (sf_fuser_extract_mesh(fuser, &mesh) != SF_OK) return die("marching cubes");
@@ -261,10 +280,13 @@ int fuse_scan(const Args& a) {
 volatile sig_atomic_t g_stop = 0;   // SIGTERM / SIGINT reached the parent: stop the ranks, remove the exchange directory, fail
 void on_stop(int) { g_stop = 1; }
 void remove_exchange_dir(const std::string& dir, int ranks) {
-  for (int r = 0; r < ranks; r++)
+  for (int r = 0; r < ranks; r++) {
     for (const char* stem : {"b", "m"})
       for (const char* ext : {".bin", ".bin.tmp"}) std::remove((dir + "/" + stem + std::to_string(r) + ext).c_str());
-  std::remove((dir + "/abort").c_str());
+    for (const char* stem : {"dev", "ipc0_", "done0_"})   // the rendezvous notes of sf_exchange_* (one exchange per run: round 0)
+      for (const char* ext : {"", ".tmp"}) std::remove((dir + "/" + stem + std::to_string(r) + ext).c_str());
+  }
+  for (const char* name : {"abort", "nccl.id", "nccl.id.tmp"}) std::remove((dir + "/" + name).c_str());
   ::rmdir(dir.c_str());
 }
 
@@ -376,6 +398,8 @@ int main(int argc, const char** argv_in) {
   // This PROCESS drives sf_fuse_run's seven streams: ask the HIP runtime for a hardware queue each before its first call (default 4: kernels of
   // streams that share a queue run one after the other).  The application's decision, not the library's; a value the user exported wins.
   (void)setenv("GPU_MAX_HW_QUEUES", "16", 0);
+  // ranks of a partitioned run hand device memory to each other (RCCL, hipIpc): the host driver of this platform supports dmabuf IPC only
+  (void)setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
   // --upstream[=voxelhashing|bundlefusion]: the upstream-conformance preset (scanfuse.h sf_params_upstream_preset; default: SURVEY App. C).  Not an
   // argument of the tool this replaces -- the pipeline's command line (scan_processor.py:138) stays valid -- and it may stand anywhere.  So may
   // --ranks N / --ranks=N and --share-gpu (see the top of this file); --rank-of= and --exchange-dir= are what the parent of a partitioned run adds.

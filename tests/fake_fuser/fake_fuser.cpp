@@ -19,6 +19,7 @@
 #include <cstring>
 #include <map>
 #include <tuple>
+#include <string>
 #include <vector>
 
 #include "common.h"
@@ -121,6 +122,53 @@ SF_API int sf_fuser_import_ghosts(sf_fuser* f, const int32_t* coords, const void
   if (imported) *imported = kept;
   return SF_OK;
 }
+// The device-to-device exchange (csrc/exchange.hip) as the tool sees it.  Default: "no transport on every rank" (SF_ERR_UNSUPPORTED), which sends the
+// tool down its file exchange -- the fallback is what most tests here run.  FAKE_EXCHANGE=1: a stand-in transport (the same ring shift through files
+// of its own in the rendezvous directory) so that the tool's sf_exchange_* branch, its log line and its clean-up are exercised too; FAKE_EXCHANGE=2:
+// the set-up fails with a device error (a transport asked for by name must fail the run, not fall back).
+struct sf_exchange { std::string dir; int rank, ranks; };
+SF_API int sf_exchange_create(const char* dir, int rank, int ranks, int, int transport, sf_exchange** out) {
+  const int mode = env_int("FAKE_EXCHANGE", 0);
+  if (mode == 2) return sf::fail(SF_ERR_DEVICE, "fake: the transport could not be set up");
+  if (mode == 0) return sf::fail(SF_ERR_UNSUPPORTED, "fake: no device-to-device transport (transport %d asked for)", transport);
+  *out = new sf_exchange{dir, rank, ranks};
+  return SF_OK;
+}
+SF_API const char* sf_exchange_transport(const sf_exchange*) { return "the stand-in transport"; }
+SF_API void sf_exchange_destroy(sf_exchange* x) { delete x; }
+SF_API int sf_exchange_boundary(sf_exchange* x, sf_fuser* f, uint64_t* sent, uint64_t* received, uint64_t* kept) {
+  uint64_t n = 0, m = 0, k = 0, got = 0;
+  if (sf_fuser_export_boundary(f, nullptr, nullptr, 0, &n, 0) != SF_OK) return SF_ERR_DEVICE;
+  std::vector<int32_t> coords(n * 3);
+  std::vector<uint8_t> voxels(n * 4096);
+  if (n && sf_fuser_export_boundary(f, coords.data(), voxels.data(), n, &m, 0) != SF_OK) return SF_ERR_DEVICE;
+  const std::string mine = x->dir + "/ipc0_" + std::to_string(x->rank), tmp = mine + ".tmp";
+  FILE* fp = std::fopen(tmp.c_str(), "wb");
+  if (!fp) return sf::fail(SF_ERR_IO, "fake: exchange file");
+  std::fwrite(&n, 8, 1, fp);
+  if (n) { std::fwrite(coords.data(), 12, n, fp); std::fwrite(voxels.data(), 4096, n, fp); }
+  std::fclose(fp);
+  std::rename(tmp.c_str(), mine.c_str());
+  const std::string from = x->dir + "/ipc0_" + std::to_string((x->rank + 1) % x->ranks);
+  for (int spin = 0;; spin++) {
+    if (FILE* t = std::fopen(from.c_str(), "rb")) { fp = t; break; }
+    if (FILE* t = std::fopen((x->dir + "/abort").c_str(), "rb")) { std::fclose(t); return sf::fail(SF_ERR_IO, "fake: exchange aborted"); }
+    if (spin > 60000) return sf::fail(SF_ERR_IO, "fake: exchange timed out");
+    usleep(500);
+  }
+  bool ok = std::fread(&k, 8, 1, fp) == 1;
+  coords.resize(k * 3);
+  voxels.resize(k * 4096);
+  ok = ok && (k == 0 || (std::fread(coords.data(), 12, k, fp) == k && std::fread(voxels.data(), 4096, k, fp) == k));
+  std::fclose(fp);
+  if (!ok) return sf::fail(SF_ERR_IO, "fake: short exchange file");
+  if (k && sf_fuser_import_ghosts(f, coords.data(), voxels.data(), k, 0, &got) != SF_OK) return SF_ERR_FORMAT;
+  if (sent) *sent = n;
+  if (received) *received = k;
+  if (kept) *kept = got;
+  return SF_OK;
+}
+
 SF_API int sf_fuser_extract_mesh(sf_fuser* f, sf_mesh** out) {
   auto known = [&](int x, int y, int z) { return present(x, y, z, f->frames) && (f->owns(x) || f->ghosts.count({x, y, z}) != 0); };
   std::map<uint64_t, std::tuple<int, int, int>> verts;   // key -> lattice point, ascending
