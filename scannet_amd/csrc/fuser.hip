@@ -872,15 +872,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SF_ALLOC_WA
 // Same function (block_in_frustum), same operands: the masks are the ones the serial loop produced.
 constexpr int COMPACT_FEW = 4;   // up to this many frames per pass the serial loop stays (a live stream's one frame per pass would leave 31 of 32 lanes idle)
 
-__global__ __launch_bounds__(256) void k_compactify(const uint64_t* __restrict__ block_keys, const int32_t* __restrict__ block_entry,
-                                                    const uint8_t* __restrict__ block_flags, const HashEntry* __restrict__ table,
-                                                    int32_t* __restrict__ compact,
-                                                    uint32_t* __restrict__ cmask, int32_t* counters, int counter_id, int all_live, ParamsK P,
-                                                    BatchFrames B) {
+// ONE by-value argument, so that the frames' constants sit at a known offset of the kernarg segment: the workgroup copies them into LDS with one round of
+// vector loads (all in flight together).  Read as `B.f[q]` they arrive through the scalar unit, a few cache lines per frame, each a separate round trip
+// the wave waits for: the chain of ~80 such loads per workgroup, not the tests, was what the kernel's 56-62 us consisted of (0.9 M wave instructions, 2 %
+// of the issue rate; profiles/r06_compactify.txt).
+struct CompactArgs {
+  const uint64_t* block_keys;
+  const int32_t* block_entry;
+  const uint8_t* block_flags;
+  const HashEntry* table;
+  int32_t* compact;
+  uint32_t* cmask;
+  int32_t* counters;
+  int counter_id, all_live;
+  ParamsK P;
+  BatchFrames B;
+};
+constexpr int FRAMEK_WORDS = (int)(sizeof(FrameK) / 4);
+
+__global__ __launch_bounds__(256) void k_compactify(CompactArgs A) {
+  const uint64_t* __restrict__ block_keys = A.block_keys;
+  const int32_t* __restrict__ block_entry = A.block_entry;
+  const uint8_t* __restrict__ block_flags = A.block_flags;
+  const HashEntry* __restrict__ table = A.table;
+  int32_t* __restrict__ compact = A.compact;
+  uint32_t* __restrict__ cmask = A.cmask;
+  int32_t* counters = A.counters;
+  const int counter_id = A.counter_id, all_live = A.all_live;
+  const ParamsK& P = A.P;
+  const BatchFrames& B = A.B;
   __shared__ int s_wtot[4], s_wlast[4], s_wpop[4];
   __shared__ int s_base;
   __shared__ int4 s_c[1024];        // (bx, by, bz, listed?) of the workgroup's 1024 directory entries
   __shared__ uint32_t s_m[1024];    // their frame masks
+  __shared__ uint32_t s_fk[MAX_BATCH * FRAMEK_WORDS];   // the batch's FrameK array, copied from the kernarg segment
   const int hw = counters[C_HIGH_WATER];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t last_bit = 1u << (B.n - 1);
@@ -889,13 +914,18 @@ __global__ __launch_bounds__(256) void k_compactify(const uint64_t* __restrict__
   const int fshift = B.n <= 8 ? 3 : (B.n <= 16 ? 4 : 5);
   const int q = lane & ((1 << fshift) - 1), sub = lane >> fshift, epi = 64 >> fshift;
   FrameK F;
-  if (wide) {
-    // frame q's constants into this lane's registers: uniform-index reads of the kernarg segment, kept by the lanes of that frame
-    F = B.f[0];
-    for (int qq = 1; qq < B.n; qq++) {
-      const FrameK& G = B.f[qq];
-      if (q == qq) F = G;
-    }
+  if (wide && (int)(blockIdx.x * 1024) < hw) {
+    // the frames' constants: kernarg segment -> LDS by vector loads (per-lane addresses: every load of the workgroup is in flight at once), then frame q's
+    // into this lane's registers for the life of the workgroup
+    typedef __attribute__((address_space(4))) const uint32_t* karg_t;
+    typedef __attribute__((address_space(4))) const char* kbyte_t;
+    const karg_t kp = (karg_t)((kbyte_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(CompactArgs, B) + offsetof(BatchFrames, f));
+    for (int i = threadIdx.x; i < B.n * FRAMEK_WORDS; i += 256) s_fk[i] = kp[i];
+    __syncthreads();
+    uint32_t* fw = reinterpret_cast<uint32_t*>(&F);
+    const uint32_t* mine = s_fk + (q < B.n ? q : 0) * FRAMEK_WORDS;
+#pragma unroll
+    for (int i = 0; i < FRAMEK_WORDS; i++) fw[i] = mine[i];
   }
   for (int base = blockIdx.x * 1024; base < hw; base += gridDim.x * 1024) {
     uint32_t m[4];
@@ -2027,8 +2057,8 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
 #undef LAUNCH_ALLOC
 #undef LAUNCH_ALLOC_RAY
   }
-  hipLaunchKernelGGL(k_compactify, dim3(f->compact_grid), dim3(256), 0, sa, f->block_keys, f->block_entry, f->block_flags, f->table, f->compact2[sl],
-                     f->cmask2[sl], f->counters, cc, 0, f->pk, bf);
+  hipLaunchKernelGGL(k_compactify, dim3(f->compact_grid), dim3(256), 0, sa, (CompactArgs{f->block_keys, f->block_entry, f->block_flags, f->table, f->compact2[sl],
+                     f->cmask2[sl], f->counters, cc, 0, f->pk, bf}));
   if (f->overlap && sa != s) {
     (void)hipEventRecord(f->ev_compact[sl], sa);
     (void)hipStreamWaitEvent(s, f->ev_compact[sl], 0);
@@ -2682,8 +2712,8 @@ int sf_compact_live(sf_fuser* f, int32_t* n_out, int include_ghosts) {
   std::memset(&dummy, 0, sizeof(dummy));
   dummy.n = 1;
   SF_HIP_CHECK(hipMemsetAsync(&f->counters[C_EXPORT], 0, 8, f->stream));
-  hipLaunchKernelGGL(k_compactify, dim3(f->compact_grid), dim3(256), 0, f->stream, f->block_keys, f->block_entry, f->block_flags, f->table, f->compact,
-                     f->cmask2[0], f->counters, (int)C_EXPORT, include_ghosts ? 1 : 2, f->pk, dummy);
+  hipLaunchKernelGGL(k_compactify, dim3(f->compact_grid), dim3(256), 0, f->stream, (CompactArgs{f->block_keys, f->block_entry, f->block_flags, f->table, f->compact,
+                     f->cmask2[0], f->counters, (int)C_EXPORT, include_ghosts ? 1 : 2, f->pk, dummy}));
   SF_HIP_CHECK(hipMemcpyAsync(n_out, &f->counters[C_EXPORT], 4, hipMemcpyDeviceToHost, f->stream));
   SF_HIP_CHECK(sf_quiesce(f));
   return SF_OK;

@@ -2,6 +2,7 @@
 entry point and through the two drop-in executables (the `improve` and `segment` stages of Server/scan_processor.py)."""
 import json
 import os
+import shutil
 import subprocess
 
 import numpy as np
