@@ -351,7 +351,7 @@ def pmc_valu(args, config, steps, warmup, single_frame, depth_only):
 # ---------------------------------------------------------------------------------------------------------------------------------------
 # configs[1] / configs[2]: one resident stream per rank
 # ---------------------------------------------------------------------------------------------------------------------------------------
-def end_to_end(frames_dev, poses, n, params, local_rank, torch, colour=None):
+def end_to_end(frames_dev, poses, n, params, local_rank, torch, colour=None, cache=None, alt_frames=1024):
     """SURVEY 8d "End-to-end frames/s": the first n frames of the run's stream in a .sens in /tmp, then sf_fuse_run: file -> host threads -> pinned
     ring -> H2D -> inflate on the GPU -> fusion.  Wall time from the first byte read to the last kernel.  The file is written by the REFERENCE
     writer when oracle/_ref/libref_sens.so is there (SensorData::createFrame per frame: stb deflate at quality 8, sensorData.h:659-670 ->
@@ -384,6 +384,8 @@ def end_to_end(frames_dev, poses, n, params, local_rank, torch, colour=None):
             blobs = [calibrate.jpeg_encode(img, 90, True) for img in synth.textured_pictures(cw, ch)]
             t0 = time.perf_counter()
             zd = orc.ref_write_sens(None, host, P44, K, want_blobs=True) if orc else None
+            if cache is not None and zd is not None:
+                cache["zd"] = zd   # the reference writer's depth streams of these frames: the depth-only leg stores the same blobs
             sd = sens.SensorData.create(cw, ch, W, H, KC, K, color_compression=2, depth_compression=1, sensor_name="StructureSensor")
             for i in range(n):
                 if zd is not None:
@@ -401,7 +403,17 @@ def end_to_end(frames_dev, poses, n, params, local_rank, torch, colour=None):
             jpeg_bytes = round(sum(len(b) for b in blobs) / len(blobs))
         else:
             jpeg_bytes = None
-            if orc:
+            zd = (cache or {}).get("zd")
+            if zd is not None and len(zd) >= n:   # the reference writer's streams of the same frames, compressed once for the RGB-D leg
+                t0 = time.perf_counter()
+                sd = sens.SensorData.create(0, 0, W, H, K, K, depth_compression=1, sensor_name="StructureSensor")
+                for i in range(n):
+                    sd.add_frame_blobs(zd[i], P44[i], timestamp_depth=33333 * i)
+                path = os.path.join(d, "reference_streams.sens")
+                sd.save(path)
+                sd.close()
+                files.append(("reference (stb)", path, time.perf_counter() - t0))
+            elif orc:
                 try:
                     t0 = time.perf_counter()
                     path = os.path.join(d, "reference_writer.sens")
@@ -451,8 +463,8 @@ def end_to_end(frames_dev, poses, n, params, local_rank, torch, colour=None):
                 os.environ.update(env)
                 try:
                     with fusion.Fuser(prm, device=local_rank, **TUNE) as f:
-                        ra = f.run(sd, decode_threads=nt)
-                        alternatives[label] = {"frames_per_s": round(ra["frames_total"] / ra["seconds_total"], 1), "decode_threads": int(ra["decode_threads"]),
+                        ra = f.run(sd, 0, min(n, alt_frames), decode_threads=nt)   # a prefix: these are comparisons, not the leg's figure
+                        alternatives[label] = {"frames_per_s": round(ra["frames_total"] / ra["seconds_total"], 1), "frames": int(ra["frames_total"]), "decode_threads": int(ra["decode_threads"]),
                                                "jpeg_entropy_on_device": int(ra.get("jpeg_entropy_on_device", -1)),
                                                "host_ms_per_frame_per_thread": round(1e3 * ra["seconds_decode_cpu"] / max(ra["frames_total"], 1), 3)}
                 except Exception as ex:
@@ -525,6 +537,8 @@ def end_to_end(frames_dev, poses, n, params, local_rank, torch, colour=None):
                 "jpeg_entropy_on_device": int(rs.get("jpeg_entropy_on_device", -1)), "jpeg_entropy_on_host": int(rs.get("jpeg_entropy_on_host", -1)),
                 "depth_inflate": "gpu (csrc/inflate_gpu.hip)", "inflate_kernels": kernels, "host_inflate": host_inflate,
                 "blocks_live_end": st["blocks_allocated"], "alloc_failures": st["alloc_failures"], "write_s": round(t_write, 2),
+                "page_cache": "warm: the file was written by this process seconds before the timed read and is mmapped (no disk I/O is timed; the stage behind "
+                              "`convert` finds its input the same way)",
                 "what": ".sens on disk written by: %s (zlib depth%s, %d KB per frame) -> %d host threads copy the compressed depth frames%s into the pinned ring -> H2D -> inflate on the GPU -> "
                         "pre-pass / allocation / compaction / integrate, 32 frames per pass; wall time of sf_fuse_run (first byte read -> last kernel complete); frames_per_s = the FIRST run "
                         "of the file in this process (it creates the run's streams and its pinned pool), frames_per_s_best = the better of two; other_writer: the same frames as this "
@@ -893,15 +907,30 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
             except _abi.ScanfuseError as e:   # a smaller GPU than the 288 GB part cannot reserve the tiles
                 out["roofline_out_of_cache"] = {"error": str(e)}
         if e2e_n:
-            try:
-                out["end_to_end"] = end_to_end(frames, poses, e2e_n, params, local_rank, torch)
-            except Exception as ex:   # a leg beside the metric (disk full in /tmp, ...): never take the line down
-                out["end_to_end"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+            # the metric is RGB-D: the leg named end_to_end is the WHOLE scan with ScanNet's real colour stream (1296x968 baseline JPEG over zlib depth), the first
+            # sf_fuse_run of this process (the 5 578-frame leg was depth only and the RGB-D one 1 024 frames); the geometry-only file of the same
+            # frames (the same reference-written depth streams) follows as end_to_end.depth_only
+            zcache = {}
+            e_rgbd = None
             if rgbd and not args.no_e2e_rgbd:
+                n_rgbd = min(e2e_n, args.e2e_rgbd_frames)
+                if shutil.disk_usage("/tmp").free < 2 * n_rgbd * 700000:   # ~590 KB per frame, and the depth-only files behind it
+                    n_rgbd = min(n_rgbd, 1024)
                 try:
-                    out["end_to_end_rgbd"] = end_to_end(frames, poses, min(e2e_n, args.e2e_rgbd_frames), params, local_rank, torch, colour="jpeg1296")
-                except Exception as ex:
-                    out["end_to_end_rgbd"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+                    e_rgbd = end_to_end(frames, poses, n_rgbd, params, local_rank, torch, colour="jpeg1296", cache=zcache)
+                except Exception as ex:   # a leg beside the metric (disk full in /tmp, ...): never take the line down
+                    e_rgbd = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+            try:
+                e_depth = end_to_end(frames, poses, e2e_n, params, local_rank, torch, cache=zcache)
+            except Exception as ex:
+                e_depth = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+            zcache.clear()
+            if e_rgbd is not None:
+                out["end_to_end"] = dict(e_rgbd, depth_only=e_depth)
+                out["end_to_end_rgbd"] = {k: e_rgbd.get(k) for k in ("frames_per_s", "frames_per_s_best", "frames", "colour_fused", "decode_threads", "error") if k in e_rgbd}
+                out["end_to_end_rgbd"]["what"] = "the same leg as end_to_end (kept under the name earlier rounds reported it by)"
+            else:
+                out["end_to_end"] = e_depth
         if cpu_n:   # rank 0 at N = 1 only
             host = frames[:cpu_n].cpu().numpy().view(np.uint16)
             rgb_dev = colour_tensor(max(cpu_n, 1)) if rgbd else None
@@ -1235,7 +1264,12 @@ def compact_line(out, detail_path=None):
     for key in ("end_to_end", "end_to_end_rgbd"):
         e = out.get(key)
         if isinstance(e, dict):
-            optional.append((key, _pick(e, "frames_per_s", "frames_per_s_best", "frames", "colour_fused", "decode_threads", "page_cache", "error")))
+            ee = _pick(e, "frames_per_s", "frames_per_s_best", "frames", "colour_fused", "decode_threads", "error")
+            if isinstance(e.get("page_cache"), str):
+                ee["page_cache"] = e["page_cache"].split(":")[0]
+            if isinstance(e.get("depth_only"), dict):
+                ee["depth_only"] = _pick(e["depth_only"], "frames_per_s", "frames_per_s_best", "frames", "error")
+            optional.append((key, ee))
     for key in ("value_depth_only", "per_rank_frames_per_s", "rccl_ranks", "process_group"):
         if out.get(key) is not None:
             optional.append((key, out[key]))
@@ -1280,7 +1314,7 @@ def main():
     ap.add_argument("--noise", type=int, choices=[0, 1, 2], default=2, help="depth noise: 1 = the LCG ramp of rounds 1-2, 2 = three LSBs hashed per pixel and frame (default)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (.sens in /tmp -> sf_fuse_run)")
     ap.add_argument("--e2e-frames", type=int, default=5578, help="frames of the end-to-end leg (.sens in /tmp -> sf_fuse_run): the whole scene0000_00-scale scan by default")
-    ap.add_argument("--e2e-rgbd-frames", type=int, default=1024, help="frames of its RGB-D variant (1296x968 JPEG colour: encoding and writing the file is what takes the time)")
+    ap.add_argument("--e2e-rgbd-frames", type=int, default=5578, help="frames of the RGB-D end-to-end leg (1296x968 JPEG colour over zlib depth): the whole scan by default")
     ap.add_argument("--cpu-frames", type=int, default=200, help="frames of the CPU-baseline / parity leg")
     ap.add_argument("--no-out-of-cache", action="store_true", help="skip the bounded 1 mm (configs[2]) sub-measurement")
     ap.add_argument("--host-stage", choices=["full", "gpu-decimate", "gpu", "clean", "none"], default="gpu",

@@ -333,15 +333,19 @@ static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t e
       for (int i = 0; i < ncomp; i++) { put(D->dc[i], hdc[comp[i].td]); put(D->ac[i], hac[comp[i].ta]); }
       uint8_t* ecs = payload + sizeof(SfJpegLayout) + sizeof(SfJpegHuffDesc);
       const uint64_t cap = payload_capacity - sizeof(SfJpegLayout) - sizeof(SfJpegHuffDesc);
-      uint64_t w = 0;
-      for (uint64_t i = pos; i < n; i++) {
-        const uint8_t b = data[i];
-        if (b == 0xFF) {
-          if (i + 1 < n && data[i + 1] == 0x00) i++;   // stuffed zero
-          else break;                                   // a marker ends the segment (EOI; RSTn cannot occur: no restart interval)
-        }
-        if (w + 16 > cap) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: the entropy-coded segment does not fit the payload");
-        ecs[w++] = b;
+      // runs between 0xFF bytes are copied whole (memchr + memcpy: a 200 KB segment holds ~800 of them; byte by byte this loop was 40 % of a host
+      // thread's time per frame); 0xFF 0x00 is a stuffed 0xFF, any other 0xFF ends the segment (EOI; RSTn cannot occur: no restart interval)
+      uint64_t w = 0, i = pos;
+      while (i < n) {
+        const uint8_t* ff = static_cast<const uint8_t*>(std::memchr(data + i, 0xFF, (size_t)(n - i)));
+        const uint64_t run = ff ? (uint64_t)(ff - (data + i)) : n - i;
+        if (w + run + 17 > cap) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: the entropy-coded segment does not fit the payload");
+        std::memcpy(ecs + w, data + i, (size_t)run);
+        w += run;
+        i += run;
+        if (!ff) break;
+        if (i + 1 < n && data[i + 1] == 0x00) { ecs[w++] = 0xFF; i += 2; }
+        else break;
       }
       D->ecs_bytes = (uint32_t)w;
       while (w & 3) ecs[w++] = 0;

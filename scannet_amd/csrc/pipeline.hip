@@ -46,7 +46,22 @@ int jpeg_gpu_reconstruct(hipStream_t stream, int n, const uint8_t* const* d_payl
 // batch has a side stream to decode on
 #define SF_JPEG_DEVICE_HUFFMAN_DEFAULT(has_side_stream) (has_side_stream)
 
+// The side streams (inflate and JPEG kernels, colour copies) at the device's highest stream priority: their kernels are small grids of LARGE workgroups
+// (1024 lanes, 100+ registers per lane) that need a whole free CU -- at the default priority they wait behind the integrate pass, whose waves fill every
+// CU, and a batch's decode chain (tokens -> copy -> Huffman -> IDCT -> RGB, ~5 ms) stretches.  -DSF_SIDE_PRIO=0 builds the round-5 behaviour for A/B runs.
+#ifndef SF_SIDE_PRIO
+#define SF_SIDE_PRIO 1
+#endif
+
 namespace {
+
+hipError_t create_side_stream(hipStream_t* out) {
+#if SF_SIDE_PRIO
+  int lo = 0, hi = 0;
+  if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo) return hipStreamCreateWithPriority(out, hipStreamNonBlocking, hi);
+#endif
+  return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
 
 thread_local uint64_t t_run_counts[4] = {0, 0, 0, 0};   // of this thread's last sf_fuse_run: depth frames inflated on the device / by the host threads, colour
                                                         // frames entropy-decoded on the device / by the host threads (sf_fuse_run_device_counts)
@@ -121,7 +136,7 @@ void sf_run_resources_prepare(int device, size_t pinned_bytes, size_t device_byt
     r->prep = std::thread([r, device, pinned_bytes, device_bytes, plan_bytes]() {
       if (hipSetDevice(device) != hipSuccess) return;
       for (int q = 0; q < 3; q++)
-        if (hipStreamCreateWithFlags(&r->inflate[q], hipStreamNonBlocking) != hipSuccess) { r->inflate[q] = nullptr; break; }
+        if (create_side_stream(&r->inflate[q]) != hipSuccess) { r->inflate[q] = nullptr; break; }
       if (pinned_bytes != 0 && hipHostMalloc((void**)&r->h_pool, pinned_bytes, hipHostMallocDefault) == hipSuccess) r->h_bytes = pinned_bytes;
       else r->h_pool = nullptr;
       // the first DMA out of freshly page-locked memory pays for mapping it (measured: the first run's hipMemcpyAsync calls blocked 0.4 ms each, 37-48 ms
@@ -161,6 +176,8 @@ struct BatchSlot {
   // 2 = the entropy-coded segment, prepared (the GPU decodes AND reconstructs)
   uint8_t coef_mode[MAX_BATCH] = {0};
   uint32_t pay_used[MAX_BATCH] = {0};    // bytes of that payload
+  bool packed_segs = false;   // every colour frame of the batch travelled as a prepared segment and the batch's segments went to the device as ONE piece (two halves):
+                              // frame j's segment sits at d_rgb(slot, 0) + j * hcol_b -- the pinned stride -- instead of at the head of its own pixel area
 };
 
 }  // namespace
@@ -335,7 +352,7 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
     auto want_stream = [&](hipStream_t* cached, hipStream_t* out) {
       if (e_ != hipSuccess) return;
       if (cached && *cached) { *out = *cached; return; }
-      e_ = hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+      e_ = create_side_stream(out);
       if (e_ == hipSuccess && cached) *cached = *out;
     };
     if (!gpu_inflate || use_rgb) {   // with the GPU inflate: for the colour part only (behind the inflate kernels of an earlier batch it arrived late)
@@ -556,7 +573,24 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
       e = hipMemcpyAsync(d_rgb(sl, j), fallback_rgb[(size_t)sl * B + (size_t)j].data(), rgb_b, hipMemcpyHostToDevice, cs_rgb);
       any_rgb = true;
     }
-    for (int j = 0, k = 0; j < cnt && e == hipSuccess; j++) {   // coefficients / entropy-coded segments: what each frame really holds, alternating streams
+    // Every frame a prepared segment (the usual batch of a JPEG-colour scan): the pinned colour areas are one contiguous piece (stride hcol_b), and so they
+    // travel -- two copies per batch, one per copy stream, instead of one ~200 KB copy per frame (32 calls of the runtime per batch: 0.4-0.5 ms of this
+    // thread, the largest item of the loop).  They land packed at the head of the slot's pixel region; k_jpeg_huff of the WHOLE batch has read them before
+    // the first k_jpeg_rgb writes a pixel there (same stream, in order).
+    bs.packed_segs = false;
+    if (small_col && cnt > 1 && (size_t)cnt * hcol_b <= slot_col) {
+      bool all2 = true;
+      for (int j = 0; j < cnt; j++) all2 = all2 && valid[j] && rgbf[j] && bs.coef_mode[j] == 2;
+      if (all2 && e == hipSuccess) {
+        const int jm = cnt / 2;
+        const size_t tail = (size_t)(cnt - 1 - jm) * hcol_b + bs.pay_used[cnt - 1];   // the last frame's area only as far as it is used
+        e = hipMemcpyAsync(d_rgb(sl, 0), h_pay(sl, 0), (size_t)jm * hcol_b, hipMemcpyHostToDevice, cs_rgb);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_rgb(sl, 0) + (size_t)jm * hcol_b, h_pay(sl, jm), tail, hipMemcpyHostToDevice, cs_rgb2);
+        bs.packed_segs = true;
+        any_rgb = true;
+      }
+    }
+    for (int j = 0, k = 0; j < cnt && e == hipSuccess && !bs.packed_segs; j++) {   // coefficients / entropy-coded segments: what each frame really holds, alternating streams
       if (!rgbf[j] || !bs.coef_mode[j] || bs.coef_mode[j] == 3) continue;
       // a prepared segment lands where the pixels will be written: it is dead once k_jpeg_huff has turned it into the coefficient payload
       e = hipMemcpyAsync(bs.coef_mode[j] == 2 ? d_rgb(sl, j) : d_pay(sl, j), h_pay(sl, j), bs.pay_used[j], hipMemcpyHostToDevice, (k++ & 1) ? cs_rgb2 : cs_rgb);
@@ -631,7 +665,8 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
         pp_[nj] = d_pay(sl, q); rr_[nj] = d_rgb(sl, q); pl_[nj] = d_planes(sl, q); nj++;
         if (bs.coef_mode[q] != 2) continue;
         if (nh == 0) slot0 = q;
-        seg[nh] = d_rgb(sl, q); out[nh] = d_pay(sl, q); cap[nh] = pay_entries; tag[nh] = (int32_t)(first + g * (uint64_t)B + (uint64_t)q);
+        seg[nh] = bs.packed_segs ? d_rgb(sl, 0) + (size_t)q * hcol_b : d_rgb(sl, q);
+        out[nh] = d_pay(sl, q); cap[nh] = pay_entries; tag[nh] = (int32_t)(first + g * (uint64_t)B + (uint64_t)q);
         if (++nh == 32) flush_h();
       }
       flush_h();
@@ -690,7 +725,8 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
           for (int q = jfirst; q < j; q++) {
             if (!(valid[q] && rgbf[q] && bs.coef_mode[q] == 2)) continue;
             if (nh == 0) slot0 = q;
-            seg[nh] = d_rgb(sl, q); out[nh] = d_pay(sl, q); cap[nh] = pay_entries; tag[nh] = (int32_t)(first + g * (uint64_t)B + (uint64_t)q);
+            seg[nh] = bs.packed_segs ? d_rgb(sl, 0) + (size_t)q * hcol_b : d_rgb(sl, q);
+            out[nh] = d_pay(sl, q); cap[nh] = pay_entries; tag[nh] = (int32_t)(first + g * (uint64_t)B + (uint64_t)q);
             if (++nh == 16) flush();
           }
           flush();

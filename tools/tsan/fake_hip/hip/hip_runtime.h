@@ -27,6 +27,8 @@ constexpr unsigned hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostM
 const char* hipGetErrorString(hipError_t);
 hipError_t hipSetDevice(int);
 hipError_t hipStreamCreateWithFlags(hipStream_t*, unsigned);
+hipError_t hipStreamCreateWithPriority(hipStream_t*, unsigned, int);
+hipError_t hipDeviceGetStreamPriorityRange(int*, int*);
 hipError_t hipStreamDestroy(hipStream_t);
 hipError_t hipStreamSynchronize(hipStream_t);
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned);
