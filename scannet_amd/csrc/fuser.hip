@@ -890,7 +890,12 @@ struct CompactArgs {
 };
 constexpr int FRAMEK_WORDS = (int)(sizeof(FrameK) / 4);
 
-__global__ __launch_bounds__(256) void k_compactify(CompactArgs A) {
+constexpr int COMPACT_THREADS = 1024;   // one thread per directory entry of the workgroup's 1024: 16 waves share the (entry, frame) tests -- 32 steps of
+                                        // ~300 dependent cycles per wave instead of 128 (four waves per workgroup left most SIMDs with one wave and the
+                                        // kernel at the length of that one chain: 52 us of which 1.4 M wave instructions account for two)
+constexpr int COMPACT_WAVES = COMPACT_THREADS / 64;
+
+__global__ __launch_bounds__(COMPACT_THREADS) void k_compactify(CompactArgs A) {
   const uint64_t* __restrict__ block_keys = A.block_keys;
   const int32_t* __restrict__ block_entry = A.block_entry;
   const uint8_t* __restrict__ block_flags = A.block_flags;
@@ -901,7 +906,7 @@ __global__ __launch_bounds__(256) void k_compactify(CompactArgs A) {
   const int counter_id = A.counter_id, all_live = A.all_live;
   const ParamsK& P = A.P;
   const BatchFrames& B = A.B;
-  __shared__ int s_wtot[4], s_wlast[4], s_wpop[4];
+  __shared__ int s_wtot[COMPACT_WAVES], s_wlast[COMPACT_WAVES], s_wpop[COMPACT_WAVES];
   __shared__ int s_base;
   __shared__ int4 s_c[1024];        // (bx, by, bz, listed?) of the workgroup's 1024 directory entries
   __shared__ uint32_t s_m[1024];    // their frame masks
@@ -920,7 +925,7 @@ __global__ __launch_bounds__(256) void k_compactify(CompactArgs A) {
     typedef __attribute__((address_space(4))) const uint32_t* karg_t;
     typedef __attribute__((address_space(4))) const char* kbyte_t;
     const karg_t kp = (karg_t)((kbyte_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(CompactArgs, B) + offsetof(BatchFrames, f));
-    for (int i = threadIdx.x; i < B.n * FRAMEK_WORDS; i += 256) s_fk[i] = kp[i];
+    for (int i = threadIdx.x; i < B.n * FRAMEK_WORDS; i += COMPACT_THREADS) s_fk[i] = kp[i];
     __syncthreads();
     uint32_t* fw = reinterpret_cast<uint32_t*>(&F);
     const uint32_t* mine = s_fk + (q < B.n ? q : 0) * FRAMEK_WORDS;
@@ -928,78 +933,66 @@ __global__ __launch_bounds__(256) void k_compactify(CompactArgs A) {
     for (int i = 0; i < FRAMEK_WORDS; i++) fw[i] = mine[i];
   }
   for (int base = blockIdx.x * 1024; base < hw; base += gridDim.x * 1024) {
-    uint32_t m[4];
-    int rank[4];
-    int wtotal = 0, wlast = 0, pop = 0;
+    const int i = base + (int)threadIdx.x;   // this thread's directory entry
+    uint32_t m = 0u;
     if (wide) {
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int i = base + j * 256 + threadIdx.x;
-        int4 c = make_int4(0, 0, 0, 0);
-        if (i < hw) {
-          const uint64_t k = block_keys[i];
-          if (k != KEY_EMPTY && !(block_flags[i] & 1)) {   // ghosts are never fused
-            unpack_key(k, c.x, c.y, c.z);
-            c.w = 1;
-          }
+      int4 c = make_int4(0, 0, 0, 0);
+      if (i < hw) {
+        const uint64_t k = block_keys[i];
+        if (k != KEY_EMPTY && !(block_flags[i] & 1)) {   // ghosts are never fused
+          unpack_key(k, c.x, c.y, c.z);
+          c.w = 1;
         }
-        s_c[j * 256 + threadIdx.x] = c;
       }
+      s_c[threadIdx.x] = c;
       __syncthreads();
       const uint64_t gmask = fshift == 5 ? 0xFFFFFFFFull : ((1ull << (1 << fshift)) - 1ull);
-      for (int e0 = wave * 256; e0 < wave * 256 + 256; e0 += epi) {   // this wave's quarter of the workgroup's entries, 64 / FPL of them per step
-        const int4 c = s_c[e0 + sub];
-        const bool in = c.w != 0 && q < B.n && block_in_frustum(P, F, c.x, c.y, c.z);
+#pragma unroll 2
+      for (int e0 = wave * 64; e0 < wave * 64 + 64; e0 += epi) {   // this wave's 64 entries, 64 / FPL of them per step, against all frames at once
+        const int4 cc = s_c[e0 + sub];
+        const bool in = cc.w != 0 && q < B.n && block_in_frustum(P, F, cc.x, cc.y, cc.z);
         const uint64_t bal = __ballot(in);
         if (q == 0) s_m[e0 + sub] = (uint32_t)((bal >> (sub << fshift)) & gmask);
       }
       __syncthreads();
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int i = base + j * 256 + threadIdx.x;
-      m[j] = 0u;
-      if (wide) {
-        m[j] = s_m[j * 256 + threadIdx.x];
-        if (m[j] != 0u) {
-          const uint32_t birth = table[block_entry[i]].birth;
-          if (birth > B.seq0) {
-            const uint32_t d = birth - B.seq0;
-            m[j] = d >= 32u ? 0u : (m[j] & ~((1u << d) - 1u));
-          }
+      m = s_m[threadIdx.x];
+      if (m != 0u) {
+        const uint32_t birth = table[block_entry[i]].birth;
+        if (birth > B.seq0) {
+          const uint32_t d = birth - B.seq0;
+          m = d >= 32u ? 0u : (m & ~((1u << d) - 1u));
         }
-      } else if (i < hw) {
-        const uint64_t k = block_keys[i];
-        if (k != KEY_EMPTY && !(all_live != 1 && (block_flags[i] & 1))) {  // ghosts are listed by all_live == 1 only
-          if (all_live) m[j] = 1u;
-          else {
-            int bx, by, bz;
-            unpack_key(k, bx, by, bz);
-            for (int qq = 0; qq < B.n; qq++)
-              if (block_in_frustum(P, B.f[qq], bx, by, bz)) m[j] |= 1u << qq;
-            if (m[j] != 0u && B.n > 1) {
-              const uint32_t birth = table[block_entry[i]].birth;
-              if (birth > B.seq0) {
-                const uint32_t d = birth - B.seq0;
-                m[j] = d >= 32u ? 0u : (m[j] & ~((1u << d) - 1u));
-              }
+      }
+    } else if (i < hw) {
+      const uint64_t k = block_keys[i];
+      if (k != KEY_EMPTY && !(all_live != 1 && (block_flags[i] & 1))) {  // ghosts are listed by all_live == 1 only
+        if (all_live) m = 1u;
+        else {
+          int bx, by, bz;
+          unpack_key(k, bx, by, bz);
+          for (int qq = 0; qq < B.n; qq++)
+            if (block_in_frustum(P, B.f[qq], bx, by, bz)) m |= 1u << qq;
+          if (m != 0u && B.n > 1) {
+            const uint32_t birth = table[block_entry[i]].birth;
+            if (birth > B.seq0) {
+              const uint32_t d = birth - B.seq0;
+              m = d >= 32u ? 0u : (m & ~((1u << d) - 1u));
             }
           }
         }
       }
-      const uint64_t bal = __ballot(m[j] != 0u);
-      rank[j] = wtotal + __popcll((unsigned long long)(bal & ((1ull << lane) - 1ull)));
-      wtotal += __popcll((unsigned long long)bal);
-      wlast += __popcll((unsigned long long)__ballot((m[j] & last_bit) != 0u));
-      pop += __popc(m[j]);
     }
+    const uint64_t bal = __ballot(m != 0u);
+    const int rank = __popcll((unsigned long long)(bal & ((1ull << lane) - 1ull)));
+    const int wtotal = __popcll((unsigned long long)bal);
+    const int wlast = __popcll((unsigned long long)__ballot((m & last_bit) != 0u));
+    int pop = __popc(m);
     for (int o = 32; o > 0; o >>= 1) pop += __shfl_xor(pop, o);
     if (lane == 0) { s_wtot[wave] = wtotal; s_wlast[wave] = wlast; s_wpop[wave] = pop; }
     __syncthreads();
     if (threadIdx.x == 0) {
-      const int total = s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
-      const int tlast = s_wlast[0] + s_wlast[1] + s_wlast[2] + s_wlast[3];
-      const int tpop = s_wpop[0] + s_wpop[1] + s_wpop[2] + s_wpop[3];
+      int total = 0, tlast = 0, tpop = 0;
+      for (int w = 0; w < COMPACT_WAVES; w++) { total += s_wtot[w]; tlast += s_wlast[w]; tpop += s_wpop[w]; }
       s_base = 0;
       if (total) {
         const unsigned long long add = (unsigned long long)(uint32_t)total | ((unsigned long long)(uint32_t)tlast << 32);
@@ -1013,12 +1006,10 @@ __global__ __launch_bounds__(256) void k_compactify(CompactArgs A) {
     __syncthreads();
     int off = s_base;
     for (int w = 0; w < wave; w++) off += s_wtot[w];
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-      if (m[j] != 0u) {
-        compact[off + rank[j]] = base + j * 256 + threadIdx.x;
-        cmask[off + rank[j]] = m[j];
-      }
+    if (m != 0u) {
+      compact[off + rank] = i;
+      cmask[off + rank] = m;
+    }
     __syncthreads();
   }
 }
@@ -2057,7 +2048,7 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
 #undef LAUNCH_ALLOC
 #undef LAUNCH_ALLOC_RAY
   }
-  hipLaunchKernelGGL(k_compactify, dim3(f->compact_grid), dim3(256), 0, sa, (CompactArgs{f->block_keys, f->block_entry, f->block_flags, f->table, f->compact2[sl],
+  hipLaunchKernelGGL(k_compactify, dim3(f->compact_grid), dim3(COMPACT_THREADS), 0, sa, (CompactArgs{f->block_keys, f->block_entry, f->block_flags, f->table, f->compact2[sl],
                      f->cmask2[sl], f->counters, cc, 0, f->pk, bf}));
   if (f->overlap && sa != s) {
     (void)hipEventRecord(f->ev_compact[sl], sa);
@@ -2712,7 +2703,7 @@ int sf_compact_live(sf_fuser* f, int32_t* n_out, int include_ghosts) {
   std::memset(&dummy, 0, sizeof(dummy));
   dummy.n = 1;
   SF_HIP_CHECK(hipMemsetAsync(&f->counters[C_EXPORT], 0, 8, f->stream));
-  hipLaunchKernelGGL(k_compactify, dim3(f->compact_grid), dim3(256), 0, f->stream, (CompactArgs{f->block_keys, f->block_entry, f->block_flags, f->table, f->compact,
+  hipLaunchKernelGGL(k_compactify, dim3(f->compact_grid), dim3(COMPACT_THREADS), 0, f->stream, (CompactArgs{f->block_keys, f->block_entry, f->block_flags, f->table, f->compact,
                      f->cmask2[0], f->counters, (int)C_EXPORT, include_ghosts ? 1 : 2, f->pk, dummy}));
   SF_HIP_CHECK(hipMemcpyAsync(n_out, &f->counters[C_EXPORT], 4, hipMemcpyDeviceToHost, f->stream));
   SF_HIP_CHECK(sf_quiesce(f));
