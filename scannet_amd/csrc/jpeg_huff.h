@@ -124,7 +124,9 @@ JH_HD JHState jh_run(const SfJpegHuffGeom& D, const SfJpegHuffTable* dc, const S
       s.k = 1;
       s.open = 1;
       n.entries++;
-      n.dc_sum[ci] += diff;
+      n.dc_sum[0] += ci == 0 ? diff : 0;   // three registers and selects: an array indexed by the component lives in private memory on the device
+      n.dc_sum[1] += ci == 1 ? diff : 0;
+      n.dc_sum[2] += ci == 2 ? diff : 0;
       E.dc(ci, diff);
     } else {
       const int rs = jh_symbol(ac[ci], w, len);

@@ -60,9 +60,16 @@ struct DeviceWriter {
   uint32_t* entries;
   uint32_t* final_entries;   // the lane that completes the picture's last block leaves the number of entries here
   uint32_t ordinal, e;
-  int pred[3];
-  __device__ void dc(int ci, int diff) { pred[ci] += diff; entries[e++] = (uint32_t)(uint16_t)(int16_t)pred[ci]; }
-  __device__ void ac(int k, int v) { entries[e++] = ((uint32_t)jh_zigzag(k) << 16) | (uint32_t)(uint16_t)(int16_t)v; }
+  int pred0, pred1, pred2;   // the DC predictors, one register each (as an array indexed by the component they were 12 of the kernel's 72 bytes of private memory)
+  const uint8_t* zz;         // the zig-zag table in LDS (jh_zigzag's own table is a constant in global memory: a load per coefficient)
+  __device__ void dc(int ci, int diff) {
+    pred0 += ci == 0 ? diff : 0;
+    pred1 += ci == 1 ? diff : 0;
+    pred2 += ci == 2 ? diff : 0;
+    const int p = ci == 0 ? pred0 : (ci == 1 ? pred1 : pred2);
+    entries[e++] = (uint32_t)(uint16_t)(int16_t)p;
+  }
+  __device__ void ac(int k, int v) { entries[e++] = ((uint32_t)zz[k & 63] << 16) | (uint32_t)(uint16_t)(int16_t)v; }
   __device__ bool block_done(int, int bi, uint32_t cnt) {
     if (ordinal >= G.total_blocks) return false;
     table[jh_block_index(L, G, ordinal, bi)] = ((e - cnt) << 7) | cnt;
@@ -79,8 +86,10 @@ __global__ __launch_bounds__(JH_LANES) void k_jpeg_huff(JpegHuffBatch B) {
   __shared__ JHState s_end[JH_LANES];
   __shared__ int s_wave[JH_LANES / 64];
   __shared__ uint32_t s_nentries;
+  __shared__ uint8_t s_zz[64];
   const int f = blockIdx.x;
   if (B.payload[f] == nullptr) return;
+  if (threadIdx.x < 64) s_zz[threadIdx.x] = (uint8_t)jh_zigzag((int)threadIdx.x);
   const uint32_t* __restrict__ prep = reinterpret_cast<const uint32_t*>(B.prepared[f]);
   if (threadIdx.x == 0) s_nentries = 0u;
   {
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(JH_LANES) void k_jpeg_huff(JpegHuffBatch B) {
   else if ((uint32_t)total_entries > B.max_entries[f]) status = -4;           // more coefficients than the payload holds
   if (status == 0 && mine && ord0 < G.total_blocks) {
     // ---- stage C: the same decode once more, written
-    DeviceWriter w{s_layout, G, table, entries, &s_nentries, ord0, ent0, {p0, p1, p2}};
+    DeviceWriter w{s_layout, G, table, entries, &s_nentries, ord0, ent0, p0, p1, p2, s_zz};
     JHCounts again;
     (void)jh_run(G, s_dc, s_ac, words, start, limit, again, w);
     if (again.bad) status = -2;   // an invalid code on the true path
