@@ -517,8 +517,11 @@ __device__ inline bool ray_walk_bits(const RayWalk& r, const WindowMap& w, uint3
     k += go_a ? dk : 0;
     ru += go_u ? s_u : 0;
     rv += (!go_a && !go_u) ? s_v : 0;
-    const bool done = go_a ? k == k_end : (go_u ? ru == ru_end : rv == rv_end);
-    if (done) break;
+    // "the coordinate that moved reached its end" as two selects and ONE compare: written as a nested conditional of three compares the compiler built it out of
+    // nested exec-mask regions (three s_and_saveexec / s_cbranch_execz pairs per step of the hot walk)
+    const int moved = go_a ? k : (go_u ? ru : rv);
+    const int moved_end = go_a ? k_end : (go_u ? ru_end : rv_end);
+    if (moved == moved_end) break;
   }
   return left_window;
 }
