@@ -55,13 +55,56 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed on %s:\n%s" % (s, out))
         if verbose and out.strip():
             print(out)
+    linked = False
     if force or procs or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs + ["-lpthread"]
         out = subprocess.run(cmd, capture_output=True, text=True)
         if out.returncode != 0:
             raise RuntimeError("link failed:\n" + out.stdout + out.stderr)
+        linked = True
     build_tools(force, verbose)
+    _record(src, [s for s, _ in procs], linked)
     return LIB
+
+
+RECORD = os.path.join(HERE, "_build", "build_record.json")
+
+
+def _record(src, compiled, linked):
+    """What this call of build() did, next to the objects (it travels to the GPU box with them): which sources were compiled now, whether the library was
+    linked now, where, with which compiler -- so that a reader of a test log can tell a library built by THIS run from one that shipped with the snapshot
+    (Weak 12).  A call that finds everything fresh appends to the history and leaves the library alone."""
+    import hashlib
+    import json
+    import socket
+    import time
+    try:
+        ver = subprocess.run([HIPCC, "--version"], capture_output=True, text=True).stdout.splitlines()[0]
+    except Exception:
+        ver = "?"
+    try:
+        old = json.load(open(RECORD))
+    except Exception:
+        old = {}
+    h = hashlib.sha256(open(LIB, "rb").read()).hexdigest()[:16] if os.path.exists(LIB) else None
+    entry = {"when": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()), "host": socket.gethostname(), "sources": len(src),
+             "compiled_now": [os.path.basename(s) for s in compiled], "linked_now": bool(linked), "hipcc": ver, "library_sha256_16": h}
+    if compiled or linked or not old.get("last_build"):
+        old["last_build"] = entry
+    old["last_call"] = entry
+    try:
+        json.dump(old, open(RECORD, "w"), indent=1)
+    except OSError:
+        pass
+
+
+def build_record():
+    """The record _record() keeps (None when the library was never built by build())."""
+    import json
+    try:
+        return json.load(open(RECORD))
+    except Exception:
+        return None
 
 
 def build_tools(force=False, verbose=False):
