@@ -437,6 +437,7 @@ def end_to_end(frames_dev, poses, n, params, local_rank, torch, colour=None, cac
         mc = None
         runs = []
         threads = min(4, os.cpu_count() or 4)   # the depth frames are inflated on the GPU: a host thread copies 330-370 KB per frame
+        fusion.Fuser.prepare_run(sd, prm, local_rank)   # as bin/depthsensing does: the run's streams and rings for THIS file start being made before the fuser is
         for _ in range(2):   # the second pass reads the file from the page cache, as the stage after `convert` does, and finds the process's streams and pinned pool made
             with fusion.Fuser(prm, device=local_rank, **TUNE) as f:
                 rs = f.run(sd, decode_threads=threads)   # JPEG colour too: the pictures are entropy-decoded on the device, a host thread only prepares the segment

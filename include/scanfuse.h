@@ -220,6 +220,12 @@ typedef struct sf_run_stats {
 } sf_run_stats;
 struct sf_sens;
 int sf_fuse_run(sf_fuser* f, const struct sf_sens* s, uint64_t first, uint64_t last, int decode_threads, sf_run_stats* stats);
+/* Optional, for a process that fuses ONE scan (the pipeline's contract: one `DepthSensing.exe` per scan, Server/scan_processor.py:138): with the file open
+ * and BEFORE sf_fuser_create, start making what sf_fuse_run will want for THIS file -- its side streams (a hardware queue each: ~5 ms), the page-locked ring,
+ * the device ring, one pass of copies over both -- on a thread of its own, beside sf_fuser_create's own gigabytes of allocation.  A JPEG-colour scan wants
+ * several times what a depth-only one does; without this call the first sf_fuse_run pays the difference inside its loop (RGB-D: 9.8 k frames/s in the first
+ * run of a process against 16 k in the second).  Changes nothing a run computes. */
+int sf_fuse_run_prepare(const struct sf_sens* s, const sf_params* p, int device);
 
 /* Iso-surface extraction (marching cubes over all live blocks, exact weld): the `<id>_vh.ply` product of the
  * improve stage (Server/scan_processor.py:141, scan_stages.json:33-42).  Vertices are ordered by grid-edge key,

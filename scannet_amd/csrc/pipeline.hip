@@ -46,11 +46,11 @@ int jpeg_gpu_reconstruct(hipStream_t stream, int n, const uint8_t* const* d_payl
 // batch has a side stream to decode on
 #define SF_JPEG_DEVICE_HUFFMAN_DEFAULT(has_side_stream) (has_side_stream)
 
-// The side streams (inflate and JPEG kernels, colour copies) at the device's highest stream priority: their kernels are small grids of LARGE workgroups
-// (1024 lanes, 100+ registers per lane) that need a whole free CU -- at the default priority they wait behind the integrate pass, whose waves fill every
-// CU, and a batch's decode chain (tokens -> copy -> Huffman -> IDCT -> RGB, ~5 ms) stretches.  -DSF_SIDE_PRIO=0 builds the round-5 behaviour for A/B runs.
+// -DSF_SIDE_PRIO=1 creates the side streams (inflate and JPEG kernels, colour copies) at the device's highest stream priority.  The idea: their kernels are
+// small grids of LARGE workgroups (1024 lanes, 100+ registers per lane) that need a whole free CU, and at the default priority they might wait behind the
+// integrate pass.  Measured (profiles/r06_e2e_rgbd_ab.txt): 16 267 against 16 182 frames/s on a 2 048-frame RGB-D scan -- nothing; the default stays 0.
 #ifndef SF_SIDE_PRIO
-#define SF_SIDE_PRIO 1
+#define SF_SIDE_PRIO 0
 #endif
 
 namespace {
@@ -71,6 +71,10 @@ int hardware_queues_of_the_process() {   // what the runtime was (or will be) to
   const int n = v ? std::atoi(v) : 0;
   return n > 0 ? n : 4;
 }
+
+}  // namespace
+void sf_run_resources_prepare_ex(int device, size_t pinned_bytes, size_t device_bytes, size_t plan_bytes, int side_streams, int copy_streams);
+namespace {
 
 // What sf_fuse_run sets up and does not need fresh: five streams (a hardware queue each: ~5 ms to create, and the runtime creates them one
 // after the other whatever the threads do) and the pinned pool (~6 ms per 100 MB).  Kept per device for the life of the process and handed
@@ -126,31 +130,69 @@ void release_resources(RunResources* r) {
 // work on a thread of its own, beside its own allocations (4.3 GB of tiles to reserve and clear) and the caller's sf_sens_open; sf_fuse_run joins it.
 // pinned_bytes = a guess of the ring's size (a run that needs more re-allocates, as before).
 void sf_run_resources_prepare(int device, size_t pinned_bytes, size_t device_bytes, size_t plan_bytes) {
+  sf_run_resources_prepare_ex(device, pinned_bytes, device_bytes, plan_bytes, 3, 0);
+}
+
+// The same with the number of side streams / copy streams the run will want, and GROWING a set that exists: a set prepared for depth-only runs (what
+// sf_fuser_create asks for) is too small for a JPEG-colour scan -- 8 slots instead of 6, five side streams instead of three, two copy streams, 170 MB pinned
+// and 2.7 GB of device memory instead of 87 / 205 MB -- and the first sf_fuse_run of such a scan paid for the difference inside its timed loop: 52 ms of set-up
+// and ~110 ms of copy calls that blocked on fresh memory, of a scan that is fused in 0.3 s (profiles/r06_e2e_phase_clock.txt).  sf_fuse_run_prepare (the C ABI:
+// the caller has the file open and knows) sizes the set from the file before the fuser is created; the work runs on a thread beside sf_fuser_create.
+void sf_run_resources_prepare_ex(int device, size_t pinned_bytes, size_t device_bytes, size_t plan_bytes, int side_streams, int copy_streams) {
   std::lock_guard<std::mutex> lk(g_res_mu);
-  for (RunResources* r : g_res)
-    if (r->device == device) return;   // prepared, being prepared or in use
-  RunResources* r = new RunResources;
-  r->device = device;
-  g_res.push_back(r);
+  RunResources* r = nullptr;
+  for (RunResources* q : g_res)
+    if (q->device == device) {
+      if (q->taken) return;   // a run is using the set
+      r = q;
+    }
+  if (r) {
+    if (r->prep.joinable()) r->prep.join();   // the preparation thread never takes g_res_mu
+    int have_side = 0, have_copy = 0;
+    for (hipStream_t x : r->inflate) have_side += x != nullptr;
+    for (hipStream_t x : r->copy) have_copy += x != nullptr;
+    if (r->h_bytes >= pinned_bytes && r->d_bytes >= device_bytes && (plan_bytes == 0 || r->plan_bytes >= plan_bytes) && have_side >= side_streams && have_copy >= copy_streams) return;
+  } else {
+    r = new RunResources;
+    r->device = device;
+    g_res.push_back(r);
+  }
+  side_streams = std::min(side_streams, 6);
+  copy_streams = std::min(copy_streams, 2);
   try {
-    r->prep = std::thread([r, device, pinned_bytes, device_bytes, plan_bytes]() {
+    r->prep = std::thread([r, device, pinned_bytes, device_bytes, plan_bytes, side_streams, copy_streams]() {
       if (hipSetDevice(device) != hipSuccess) return;
-      for (int q = 0; q < 3; q++)
-        if (create_side_stream(&r->inflate[q]) != hipSuccess) { r->inflate[q] = nullptr; break; }
-      if (pinned_bytes != 0 && hipHostMalloc((void**)&r->h_pool, pinned_bytes, hipHostMallocDefault) == hipSuccess) r->h_bytes = pinned_bytes;
-      else r->h_pool = nullptr;
+      for (int q = 0; q < side_streams; q++)
+        if (!r->inflate[q] && create_side_stream(&r->inflate[q]) != hipSuccess) { r->inflate[q] = nullptr; break; }
+      for (int q = 0; q < copy_streams; q++)
+        if (!r->copy[q] && create_side_stream(&r->copy[q]) != hipSuccess) { r->copy[q] = nullptr; break; }
+      if (pinned_bytes > r->h_bytes) {
+        if (r->h_pool) { (void)hipHostFree(r->h_pool); r->h_pool = nullptr; r->h_bytes = 0; }
+        if (hipHostMalloc((void**)&r->h_pool, pinned_bytes, hipHostMallocDefault) == hipSuccess) r->h_bytes = pinned_bytes;
+        else r->h_pool = nullptr;
+      }
       // the first DMA out of freshly page-locked memory pays for mapping it (measured: the first run's hipMemcpyAsync calls blocked 0.4 ms each, 37-48 ms
       // of a run): one pass of copies over the pool here, on this thread, pays it before the run
-      if (device_bytes != 0 && hipMalloc((void**)&r->d_pool, device_bytes) == hipSuccess) r->d_bytes = device_bytes;
-      else r->d_pool = nullptr;
+      bool fresh_device = false;
+      if (device_bytes > r->d_bytes) {
+        if (r->d_pool) { (void)hipFree(r->d_pool); r->d_pool = nullptr; r->d_bytes = 0; }
+        if (hipMalloc((void**)&r->d_pool, device_bytes) == hipSuccess) { r->d_bytes = device_bytes; fresh_device = true; }
+        else r->d_pool = nullptr;
+      }
       if (r->h_pool && r->d_pool)   // one pass of copies over both pools: whatever the first transfer out of / into fresh memory pays is paid here
         for (size_t at = 0; at < r->h_bytes; at += r->d_bytes)
           if (hipMemcpy(r->d_pool, r->h_pool + at, std::min(r->d_bytes, r->h_bytes - at), hipMemcpyHostToDevice) != hipSuccess) break;
-      if (r->d_pool) (void)hipMemset(r->d_pool, 0, r->d_bytes);
-      for (int q = 0; q < 3 && plan_bytes != 0; q++) {
-        if (hipMalloc((void**)&r->d_plan[q], plan_bytes) != hipSuccess) { r->d_plan[q] = nullptr; break; }
-        (void)hipMemset(r->d_plan[q], 0, plan_bytes);
-        r->plan_bytes = plan_bytes;
+      if (r->d_pool && fresh_device) (void)hipMemset(r->d_pool, 0, r->d_bytes);
+      if (plan_bytes != 0) {
+        if (r->plan_bytes < plan_bytes) {   // scratch of another frame size: start over
+          for (uint8_t*& q : r->d_plan) { if (q) (void)hipFree(q); q = nullptr; }
+          r->plan_bytes = plan_bytes;
+        }
+        for (int q = 0; q < side_streams; q++) {
+          if (r->d_plan[q]) continue;
+          if (hipMalloc((void**)&r->d_plan[q], r->plan_bytes) != hipSuccess) { r->d_plan[q] = nullptr; break; }
+          (void)hipMemset(r->d_plan[q], 0, r->plan_bytes);
+        }
       }
     });
   } catch (...) {
@@ -804,6 +846,46 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
     stats->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     stats->seconds_decode_cpu = (double)decode_ns.load() * 1e-9;
   }
+  return SF_OK;
+}
+
+// scanfuse.h: the streams, the page-locked ring and the device ring a later sf_fuse_run of THIS file will want, made on a thread of their own from now on -- call it
+// with the file open and BEFORE sf_fuser_create, whose own allocations (the volume: gigabytes to reserve and clear) then run beside it.  Sizes are upper
+// bounds of what sf_fuse_run computes (a set that is large enough is taken as it is; one that is not is re-made by the run, as before): nothing here
+// changes what a run does, only when the set-up is paid.
+SF_API int sf_fuse_run_prepare(const sf_sens* s, const sf_params* p, int device) {
+  if (!s || !p) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return sf::fail(SF_ERR_DEVICE, "no HIP device %d", device);
+  const size_t npx = (size_t)s->info.depth_width * s->info.depth_height, depth_b = npx * 2;
+  if (npx == 0 || s->frames.empty()) return SF_OK;
+  const int B = MAX_BATCH;
+  const bool same_res = s->info.color_width == s->info.depth_width && s->info.color_height == s->info.depth_height;
+  const bool own_res = p->color_width > 0 && (uint32_t)p->color_width == s->info.color_width && (uint32_t)p->color_height == s->info.color_height;
+  const bool use_rgb = ((same_res && p->color_width == 0) || own_res) && s->info.color_compression >= 0 && s->info.color_compression <= 2;
+  const bool jpeg = use_rgb && s->info.color_compression == 2;
+  const bool gpu_inflate = s->info.depth_compression == 1;
+  const int NZ = jpeg ? 5 : 3, NB = gpu_inflate ? 3 + NZ : 3;
+  size_t max_depth = 0, max_color = 0;
+  for (const SensFrame& fr : s->frames) {
+    max_depth = std::max<size_t>(max_depth, (size_t)fr.depth_bytes);
+    max_color = std::max<size_t>(max_color, (size_t)fr.color_bytes);
+  }
+  const size_t seg = gpu_inflate ? ((std::min(max_depth, depth_b) + 63) & ~(size_t)63) : depth_b;   // a frame's share of the packed depth part, at most
+  const size_t slot_depth = (seg * B + 255) & ~(size_t)255, dslot_depth = (depth_b * B + 255) & ~(size_t)255;
+  const size_t cpx = use_rgb ? (size_t)s->info.color_width * s->info.color_height : 0, rgb_b = cpx * 3;
+  size_t hcol_b = rgb_b, col_b = rgb_b, planes_b = 0;
+  if (jpeg) {
+    const size_t padded = (size_t)((s->info.color_width + 15) & ~15u) * ((s->info.color_height + 15) & ~15u);
+    col_b = (sizeof(SfJpegLayout) + padded * 3 / 16 + rgb_b + 255) & ~(size_t)255;   // table of at most 3 padded / 64 blocks + as many entries as the pixels have bytes
+    planes_b = (padded * 3 + 255) & ~(size_t)255;
+    hcol_b = gpu_inflate ? (max_color + sizeof(SfJpegLayout) + sizeof(SfJpegHuffDesc) + 64 + 255) & ~(size_t)255 : col_b;   // entropy decoding on the device: the prepared segment
+  }
+  const size_t slot_col = (col_b * B + 255) & ~(size_t)255, hslot_col = (hcol_b * B + 255) & ~(size_t)255;
+  const size_t slot_comp = gpu_inflate ? slot_depth + 256 : 0;
+  const size_t h_need = (size_t)NB * (slot_depth + (use_rgb ? hslot_col : 0));
+  const size_t d_need = (size_t)NB * (dslot_depth + (use_rgb ? slot_col : 0) + (jpeg ? slot_col : 0) + planes_b * B + slot_comp);
+  sf_run_resources_prepare_ex(device, h_need, d_need, gpu_inflate ? 2 * depth_b * (size_t)B : 0, gpu_inflate ? NZ : 0, (!gpu_inflate || use_rgb) ? 2 : 0);
   return SF_OK;
 }
 

@@ -183,6 +183,7 @@ int fuse_scan(const Args& a) {
     p.cfx = info.color_intrinsic[0]; p.cfy = info.color_intrinsic[5]; p.cmx = info.color_intrinsic[2]; p.cmy = info.color_intrinsic[6];
   }
   const int device = std::getenv("SF_DEVICE") ? std::atoi(std::getenv("SF_DEVICE")) : 0;
+  (void)sf_fuse_run_prepare(sens, &p, device);   // the run's streams and rings, sized for this file, made beside the fuser's own allocations (an optimisation: failures surface in sf_fuser_create)
   sf_fuser* fuser = nullptr;
   if (sf_fuser_create(&p, device, &fuser) != SF_OK) return die("fuser");
   if (part && sf_fuser_set_stripes(fuser, 0, 0, STRIPE_BLOCKS, a.ranks, a.rank) != SF_OK) return die("stripes");

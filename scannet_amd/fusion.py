@@ -181,6 +181,13 @@ class Fuser:
         check(L.sf_fuser_calib_tile_rmw_ex(self._h, mode, int(iters), C.byref(us), C.byref(n)))
         return us.value, n.value
 
+    @staticmethod
+    def prepare_run(sensor_data, params, device=0):
+        """sf_fuse_run_prepare: with the file open and BEFORE the Fuser is created, start making the streams and rings a run of this file wants."""
+        L = _abi.lib()
+        L.sf_fuse_run_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        check(L.sf_fuse_run_prepare(sensor_data._h, C.byref(params), int(device)))
+
     def run(self, sensor_data, first=0, last=0, decode_threads=0):
         """Fuse frames [first, last) of a scannet_amd.sens.SensorData (threaded decode overlapped with the GPU)."""
         st = SfRunStats()

@@ -66,6 +66,7 @@ SF_API int sf_fuser_set_stripes(sf_fuser* f, int axis, int32_t origin, int32_t t
   f->striped = true; f->origin = origin; f->thick = thick; f->world = world; f->rank = rank;
   return SF_OK;
 }
+SF_API int sf_fuse_run_prepare(const sf_sens*, const sf_params*, int) { return SF_OK; }
 SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t, uint64_t, int, sf_run_stats* rs) {
   if (env_int("FAKE_FAIL_DEVICE", -1) == f->device) return sf::fail(SF_ERR_FORMAT, "fake: device %d was told to fail", f->device);
   sf_sens_info info;

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--gpu-decimate", action="store_true", help="the decimate stage on the GPU (sf_mesh_simplify_gpu) instead of the sequential filter")
     ap.add_argument("--gpu-clean", action="store_true", help="the cleaning filters on the GPU (sf_mesh_clean_gpu: same output) instead of the host filters")
     ap.add_argument("--fuse-only", action="store_true", help="stop after the fusion stage")
+    ap.add_argument("--no-prepare", action="store_true", help="do not call sf_fuse_run_prepare before the first fuser is created (A/B of the first run's set-up)")
     ap.add_argument("--scene", type=int, default=synth.SCENE_DEFAULT, help="0 = empty box room, 1 = furnished (default)")
     ap.add_argument("--noise", type=int, default=synth.NOISE_DEFAULT, help="1 = the LCG ramp of rounds 1-2, 2 = hashed per pixel (default)")
     ap.add_argument("--smooth-pictures", action="store_true", help="--color jpeg: the smooth pictures of rounds 1-4 (77-110 KB at 1296x968) instead of synth.textured_pictures (~200 KB)")
@@ -94,6 +95,8 @@ def main():
     sd = sens.SensorData(path)
     # the same scan fused twice by two fusers: sf_fuse_run keeps its streams and its pinned pool for the next run of the process (a dataset
     # rebuild fuses 1513 scans per process); the first run creates them.  Both rates are reported; the stages below continue from the second.
+    if not a.no_prepare:
+        fusion.Fuser.prepare_run(sd, gp, 0)   # as bin/depthsensing does (sf_fuse_run_prepare): the first run finds its streams and rings made
     with fusion.Fuser(gp) as f0:
         rs0 = f0.run(sd, decode_threads=a.threads)
     with fusion.Fuser(gp) as f:

@@ -54,6 +54,7 @@ struct FakeStream {
 
 const char* hipGetErrorString(hipError_t) { return "fake hip error"; }
 hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = new FakeStream(); return hipSuccess; }
 hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = new FakeStream(); return hipSuccess; }
 hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = -1; return hipSuccess; }

@@ -26,6 +26,7 @@ constexpr unsigned hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostM
 
 const char* hipGetErrorString(hipError_t);
 hipError_t hipSetDevice(int);
+hipError_t hipGetDeviceCount(int*);
 hipError_t hipStreamCreateWithFlags(hipStream_t*, unsigned);
 hipError_t hipStreamCreateWithPriority(hipStream_t*, unsigned, int);
 hipError_t hipDeviceGetStreamPriorityRange(int*, int*);
