@@ -22,7 +22,7 @@ typedef enum sf_status {
   SF_ERR_INVALID_ARG = -1,
   SF_ERR_IO = -2,
   SF_ERR_FORMAT = -3,      /* bad .sens / PLY / zlib / parameter file */
-  SF_ERR_UNSUPPORTED = -4, /* e.g. progressive JPEG colour, PreserveBoundary in simplify.mlx */
+  SF_ERR_UNSUPPORTED = -4, /* e.g. arithmetic-coded JPEG colour, PreserveBoundary in simplify.mlx */
   SF_ERR_DEVICE = -5,      /* HIP error, no GPU */
   SF_ERR_CAPACITY = -6,    /* SDF block heap or hash table exhausted */
   SF_ERR_BOUNDS = -7,

@@ -1,9 +1,9 @@
-// jpeg.cpp -- baseline (SOF0 / SOF1 Huffman, 8-bit) JPEG decoder for .sens colour frames.
+// jpeg.cpp -- JPEG decoder (8-bit Huffman: baseline SOF0 / SOF1, and progressive SOF2 on the host) for .sens colour frames.
 //
 // Replaces stb::stbi_load_from_memory as called by RGBDFrame::decompressColorAlloc_stb
 // (SensReader/c++/src/sensorData.h:609-616 -> sensorData/stb_image.h:1067,3411).  ScanNet colour frames are
-// baseline YCbCr 4:2:0 / 4:2:2 JPEGs written by the capture app; progressive streams are rejected with
-// SF_ERR_UNSUPPORTED.  Entropy decoding is written from ITU-T T.81 (and is the serial part); the reconstruction --
+// baseline YCbCr 4:2:0 / 4:2:2 JPEGs written by the capture app -- the case the device paths take; progressive
+// pictures (which the reference decodes too, stb_image.h:1771-1900) are decoded here on the host.  Entropy decoding is written from ITU-T T.81 (and is the serial part); the reconstruction --
 // integer IDCT, chroma upsampling, YCbCr -> RGB (jpeg_idct.h, shared with the GPU path of the frame pipeline) -- reproduces the
 // integer arithmetic of the reference's decoder, so the pixels are IDENTICAL to the reference's (tests/test_sens.py), including
 // its handling of the last columns of a 4:2:2 picture.  Like the reference: 8-bit quantisation tables only, over-subscribed
@@ -186,6 +186,94 @@ void idct_block(int* blk, bool dc_only, uint8_t* out, int stride) {
     for (int x = 0; x < 8; x++) out[(size_t)y * stride + x] = (uint8_t)blk[y * 8 + x];
 }
 
+// ---- progressive JPEG (SOF2), host only.  The reference's decoder takes these (stb_image.h:1771-1900 block decoders, :2520-2556 scan loops, :2582-2598
+// dequantise + IDCT at the end) and RGBDFrame::decompressColorAlloc_stb hands them through like any other picture; ScanNet's own colour frames are baseline,
+// so this path is for .sens files that passed through other tools.  Coefficients are 16-bit as the reference keeps them (every store wraps to short, the
+// dequantisation multiplies in short): T.81 G.1.2 spectral selection + successive approximation, with the reference's checks.
+struct ProgScan {
+  int ns = 0, order[3] = {0, 0, 0};
+  int ss = 0, se = 0, ah = 0, al = 0;
+};
+
+// first DC scan / DC refinement of one block
+inline int prog_dc(BitSrc& bs, int16_t* blk, const HuffDC_AC& h, Component& c, const ProgScan& sc) {
+  if (sc.ah == 0) {
+    std::memset(blk, 0, 64 * sizeof(int16_t));
+    const int t = decode_huff(bs, h);
+    if (t < 0 || t > 15) return sf::fail(SF_ERR_FORMAT, "jpeg: bad DC code");
+    const int diff = t ? extend(bs.get(t), t) : 0;
+    c.pred += diff;
+    blk[0] = (int16_t)(uint16_t)((uint32_t)c.pred << sc.al);
+  } else if (bs.get(1)) {
+    blk[0] = (int16_t)(blk[0] + (int16_t)(1 << sc.al));
+  }
+  return SF_OK;
+}
+
+// first AC scan / AC refinement of one block (band [ss, se] of the zig-zag order); eob_run carries over blocks
+inline int prog_ac(BitSrc& bs, int16_t* blk, const HuffDC_AC& h, const ProgScan& sc, int& eob_run) {
+  if (sc.ah == 0) {
+    if (eob_run) { --eob_run; return SF_OK; }
+    int k = sc.ss;
+    do {
+      const int rs = decode_huff(bs, h);
+      if (rs < 0) return sf::fail(SF_ERR_FORMAT, "jpeg: bad AC code");
+      const int s = rs & 15, r = rs >> 4;
+      if (s == 0) {
+        if (r < 15) {
+          eob_run = 1 << r;
+          if (r) eob_run += bs.get(r);
+          --eob_run;
+          break;
+        }
+        k += 16;
+      } else {
+        k += r;
+        if (k > 63) return sf::fail(SF_ERR_FORMAT, "jpeg: AC run past the end of the block");
+        blk[ZIGZAG[k++]] = (int16_t)(uint16_t)((uint32_t)extend(bs.get(s), s) << sc.al);
+      }
+    } while (k <= sc.se);
+    return SF_OK;
+  }
+  const int16_t bit = (int16_t)(1 << sc.al);
+  auto refine = [&](int16_t& v) {   // a correction bit for a coefficient that is non-zero already
+    if (bs.get(1) && (v & bit) == 0) v = (int16_t)(v > 0 ? v + bit : v - bit);
+  };
+  if (eob_run) {
+    --eob_run;
+    for (int k = sc.ss; k <= sc.se; ++k) {
+      int16_t& v = blk[ZIGZAG[k]];
+      if (v != 0) refine(v);
+    }
+    return SF_OK;
+  }
+  int k = sc.ss;
+  do {
+    const int rs = decode_huff(bs, h);
+    if (rs < 0) return sf::fail(SF_ERR_FORMAT, "jpeg: bad AC code");
+    int s = rs & 15, r = rs >> 4;
+    if (s == 0) {
+      if (r < 15) {
+        eob_run = (1 << r) - 1;
+        if (r) eob_run += bs.get(r);
+        r = 64;   // the rest of the band only receives correction bits
+      }           // r == 15: sixteen zero-history coefficients are skipped, nothing is written
+    } else {
+      if (s != 1) return sf::fail(SF_ERR_FORMAT, "jpeg: bad AC refinement code");
+      s = bs.get(1) ? bit : -bit;
+    }
+    while (k <= sc.se) {
+      int16_t& v = blk[ZIGZAG[k++]];
+      if (v != 0) refine(v);
+      else {
+        if (r == 0) { v = (int16_t)s; break; }
+        --r;
+      }
+    }
+  } while (k <= sc.se);
+  return SF_OK;
+}
+
 }  // namespace
 
 // dst != nullptr: decode to RGB.  dst == nullptr: entropy-decode only -- the layout goes to *L, block table and non-zero quantised
@@ -206,6 +294,39 @@ static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t e
   uint64_t pos = 2;
   bool have_sof = false;
   auto u16 = [&](uint64_t at) { return (int)((data[at] << 8) | data[at + 1]); };
+  bool progressive = false;
+  auto parse_dqt = [&](uint64_t seg, uint64_t seg_end) -> int {
+    uint64_t q = seg;
+    while (q < seg_end) {
+      const int pq = data[q] >> 4, tq = data[q] & 15;
+      q++;
+      if (pq != 0) return sf::fail(SF_ERR_FORMAT, "jpeg: 16-bit quantisation table (the reference decoder takes 8-bit tables only, stb_image.h:2625)");
+      if (tq > 3 || q + 64 > seg_end) return sf::fail(SF_ERR_FORMAT, "jpeg: bad DQT");
+      for (int i = 0; i < 64; i++) qt[tq][ZIGZAG[i]] = data[q + i];
+      q += 64;
+      qt_ok[tq] = true;
+    }
+    return SF_OK;
+  };
+  auto parse_dht = [&](uint64_t seg, uint64_t seg_end) -> int {
+    uint64_t q = seg;
+    while (q < seg_end) {
+      const int tc = data[q] >> 4, th = data[q] & 15;
+      q++;
+      if (tc > 1 || th > 3 || q + 16 > seg_end) return sf::fail(SF_ERR_FORMAT, "jpeg: bad DHT");
+      HuffDC_AC& h = tc ? hac[th] : hdc[th];
+      int total = 0;
+      h.bits[0] = 0;
+      for (int i = 1; i <= 16; i++) { h.bits[i] = data[q + i - 1]; total += h.bits[i]; }
+      q += 16;
+      if (total > 256 || q + total > seg_end) return sf::fail(SF_ERR_FORMAT, "jpeg: bad DHT counts");
+      std::memcpy(h.vals, data + q, (size_t)total);
+      q += total;
+      if (!h.build(tc != 0 && !progressive)) return sf::fail(SF_ERR_FORMAT, "jpeg: bad Huffman code lengths");   // the progressive block decoders take symbols one at a time
+    }
+    return SF_OK;
+  };
+  uint64_t first_sos = 0;   // progressive: where the first scan header starts (its length field)
   while (true) {
     if (pos + 4 > n) return sf::fail(SF_ERR_FORMAT, "jpeg: truncated before SOS");
     if (data[pos] != 0xFF) return sf::fail(SF_ERR_FORMAT, "jpeg: expected a marker");
@@ -218,33 +339,13 @@ static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t e
     if (len < 2 || pos + len > n) return sf::fail(SF_ERR_FORMAT, "jpeg: bad segment length");
     const uint64_t seg = pos + 2, seg_end = pos + len;
     if (m == 0xDB) {
-      uint64_t q = seg;
-      while (q < seg_end) {
-        const int pq = data[q] >> 4, tq = data[q] & 15;
-        q++;
-        if (pq != 0) return sf::fail(SF_ERR_FORMAT, "jpeg: 16-bit quantisation table (the reference decoder takes 8-bit tables only, stb_image.h:2625)");
-        if (tq > 3 || q + 64 > seg_end) return sf::fail(SF_ERR_FORMAT, "jpeg: bad DQT");
-        for (int i = 0; i < 64; i++) qt[tq][ZIGZAG[i]] = data[q + i];
-        q += 64;
-        qt_ok[tq] = true;
-      }
+      const int rc = parse_dqt(seg, seg_end);
+      if (rc != SF_OK) return rc;
     } else if (m == 0xC4) {
-      uint64_t q = seg;
-      while (q < seg_end) {
-        const int tc = data[q] >> 4, th = data[q] & 15;
-        q++;
-        if (tc > 1 || th > 3 || q + 16 > seg_end) return sf::fail(SF_ERR_FORMAT, "jpeg: bad DHT");
-        HuffDC_AC& h = tc ? hac[th] : hdc[th];
-        int total = 0;
-        h.bits[0] = 0;
-        for (int i = 1; i <= 16; i++) { h.bits[i] = data[q + i - 1]; total += h.bits[i]; }
-        q += 16;
-        if (total > 256 || q + total > seg_end) return sf::fail(SF_ERR_FORMAT, "jpeg: bad DHT counts");
-        std::memcpy(h.vals, data + q, (size_t)total);
-        q += total;
-        if (!h.build(tc != 0)) return sf::fail(SF_ERR_FORMAT, "jpeg: bad Huffman code lengths");
-      }
-    } else if (m == 0xC0 || m == 0xC1) {
+      const int rc = parse_dht(seg, seg_end);
+      if (rc != SF_OK) return rc;
+    } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
+      progressive = m == 0xC2;
       if (len < 8 || data[seg] != 8) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: only 8-bit precision is supported");
       height = u16(seg + 1); width = u16(seg + 3); ncomp = data[seg + 5];
       if (ncomp != 1 && ncomp != 3) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: %d components not supported", ncomp);
@@ -257,13 +358,14 @@ static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t e
         hmax = comp[i].h > hmax ? comp[i].h : hmax; vmax = comp[i].v > vmax ? comp[i].v : vmax;
       }
       have_sof = true;
-    } else if (m == 0xC2 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC)) {
-      return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: progressive / lossless / arithmetic JPEG (SOF%d) is not supported", m - 0xC0);
+    } else if (m == 0xC3 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC)) {
+      return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: lossless / hierarchical / arithmetic JPEG (SOF%d) is not supported", m - 0xC0);
     } else if (m == 0xDD) {
       if (len != 4) return sf::fail(SF_ERR_FORMAT, "jpeg: bad DRI length");
       restart = u16(seg);
     } else if (m == 0xDA) {
       if (!have_sof) return sf::fail(SF_ERR_FORMAT, "jpeg: SOS before SOF");
+      if (progressive) { first_sos = pos; break; }   // scan headers of a progressive picture are read by its scan loop below
       const int ns = data[seg];
       if (ns != ncomp || len < 6 + 2 * ns) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: non-interleaved scans are not supported");
       for (int i = 0; i < ns; i++) {
@@ -283,8 +385,10 @@ static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t e
   }
   if ((uint32_t)width != expect_w || (uint32_t)height != expect_h)
     return sf::fail(SF_ERR_FORMAT, "jpeg: image is %dx%d, header says %ux%u", width, height, expect_w, expect_h);
-  for (int i = 0; i < ncomp; i++)
+  for (int i = 0; i < ncomp && !progressive; i++)
     if (!qt_ok[comp[i].tq] || !hdc[comp[i].td].present || !hac[comp[i].ta].present) return sf::fail(SF_ERR_FORMAT, "jpeg: missing quantisation / Huffman table");
+  if (progressive && dst == nullptr)
+    return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: a progressive picture takes the host decoder (the device paths reconstruct one scan)");
   const int mcu_w = 8 * hmax, mcu_h = 8 * vmax;
   const int mcux = (width + mcu_w - 1) / mcu_w, mcuy = (height + mcu_h - 1) / mcu_h;
   const bool to_coef = dst == nullptr;
@@ -367,9 +471,122 @@ static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t e
     comp[i].plane = scratch[i].data();
     comp[i].pred = 0;
   }
+  if (progressive) {
+    static thread_local std::vector<int16_t> coef[3];
+    int cbw[3] = {0, 0, 0};   // blocks per row of the component's (MCU-padded) plane
+    for (int i = 0; i < ncomp; i++) {
+      cbw[i] = comp[i].bw / 8;
+      coef[i].assign((size_t)cbw[i] * (size_t)(comp[i].bh / 8) * 64, 0);
+    }
+    // how many blocks of a component a NON-interleaved scan holds: its real samples, whatever the MCU grid pads (stb_image.h:2521-2527)
+    auto blocks_w = [&](int i) { return ((width * comp[i].h + hmax - 1) / hmax + 7) >> 3; };
+    auto blocks_h = [&](int i) { return ((height * comp[i].v + vmax - 1) / vmax + 7) >> 3; };
+    uint64_t at = first_sos;   // at a scan header's length field
+    bool more = true;
+    while (more) {
+      // ---- scan header (stbi__process_scan_header, stb_image.h:2663-2698)
+      if (at + 2 > n) return sf::fail(SF_ERR_FORMAT, "jpeg: truncated scan header");
+      const int Ls = u16(at);
+      if (Ls < 6 || at + Ls > n) return sf::fail(SF_ERR_FORMAT, "jpeg: bad SOS length");
+      ProgScan sc;
+      sc.ns = data[at + 2];
+      if (sc.ns < 1 || sc.ns > ncomp || Ls != 6 + 2 * sc.ns) return sf::fail(SF_ERR_FORMAT, "jpeg: bad SOS component count");
+      for (int i = 0; i < sc.ns; i++) {
+        const int cid = data[at + 3 + 2 * i], tt = data[at + 4 + 2 * i];
+        int ci = -1;
+        for (int k = 0; k < ncomp; k++) if (comp[k].id == cid) { ci = k; break; }
+        if (ci < 0) return sf::fail(SF_ERR_FORMAT, "jpeg: scan refers to an unknown component");
+        comp[ci].td = tt >> 4; comp[ci].ta = tt & 15;
+        if (comp[ci].td > 3 || comp[ci].ta > 3) return sf::fail(SF_ERR_FORMAT, "jpeg: bad table selector");
+        sc.order[i] = ci;
+      }
+      sc.ss = data[at + 3 + 2 * sc.ns]; sc.se = data[at + 4 + 2 * sc.ns];
+      sc.ah = data[at + 5 + 2 * sc.ns] >> 4; sc.al = data[at + 5 + 2 * sc.ns] & 15;
+      if (sc.ss > 63 || sc.se > 63 || sc.ss > sc.se || sc.ah > 13 || sc.al > 13) return sf::fail(SF_ERR_FORMAT, "jpeg: bad SOS");
+      if (sc.ss == 0 ? sc.se != 0 : sc.ns != 1) return sf::fail(SF_ERR_FORMAT, "jpeg: a scan cannot merge DC and AC coefficients");
+      for (int i = 0; i < sc.ns; i++) {
+        const Component& c = comp[sc.order[i]];
+        if (sc.ss == 0 ? (sc.ah == 0 && !hdc[c.td].present) : !hac[c.ta].present) return sf::fail(SF_ERR_FORMAT, "jpeg: missing Huffman table");
+      }
+      // ---- entropy-coded data of the scan
+      BitSrc bs{data + at + Ls, data + n};
+      int todo = restart ? restart : 0x7FFFFFFF, eob_run = 0;
+      for (int i = 0; i < ncomp; i++) comp[i].pred = 0;
+      auto restart_point = [&]() {   // as the baseline loop below: on to the RSTn marker, predictors and the end-of-band run start over
+        bs.reset();
+        // ... if that is what comes next: behind the last interval of a scan stands the next scan's header, not a restart marker
+        while (bs.p + 1 < bs.end && !(bs.p[0] == 0xFF && bs.p[1] != 0x00 && bs.p[1] != 0xFF)) bs.p++;
+        if (bs.p + 1 < bs.end && bs.p[1] >= 0xD0 && bs.p[1] <= 0xD7) bs.p += 2;
+        for (int i = 0; i < ncomp; i++) comp[i].pred = 0;
+        eob_run = 0;
+        todo = restart;
+      };
+      if (sc.ns == 1) {
+        const int ci = sc.order[0];
+        Component& c = comp[ci];
+        const int bwn = blocks_w(ci), bhn = blocks_h(ci);
+        for (int by = 0; by < bhn; by++)
+          for (int bx = 0; bx < bwn; bx++) {
+            int16_t* blk = coef[ci].data() + 64 * ((size_t)bx + (size_t)by * cbw[ci]);
+            const int rc = sc.ss == 0 ? prog_dc(bs, blk, hdc[c.td], c, sc) : prog_ac(bs, blk, hac[c.ta], sc, eob_run);
+            if (rc != SF_OK) return rc;
+            if (--todo <= 0) restart_point();
+          }
+      } else {
+        for (int my = 0; my < mcuy; my++)
+          for (int mx = 0; mx < mcux; mx++) {
+            for (int k = 0; k < sc.ns; k++) {
+              const int ci = sc.order[k];
+              Component& c = comp[ci];
+              for (int by = 0; by < c.v; by++)
+                for (int bx = 0; bx < c.h; bx++) {
+                  int16_t* blk = coef[ci].data() + 64 * ((size_t)(mx * c.h + bx) + (size_t)(my * c.v + by) * cbw[ci]);
+                  const int rc = prog_dc(bs, blk, hdc[c.td], c, sc);
+                  if (rc != SF_OK) return rc;
+                }
+            }
+            if (--todo <= 0) restart_point();
+          }
+      }
+      // ---- on to the next marker; tables may be redefined between scans
+      uint64_t q = (uint64_t)(bs.p - data);
+      more = false;
+      while (q + 1 < n) {
+        if (data[q] != 0xFF || data[q + 1] == 0x00 || data[q + 1] == 0xFF || (data[q + 1] >= 0xD0 && data[q + 1] <= 0xD7)) { q++; continue; }
+        const int m = data[q + 1];
+        q += 2;
+        if (m == 0xD9) break;   // EOI
+        if (q + 2 > n) return sf::fail(SF_ERR_FORMAT, "jpeg: truncated segment");
+        const int len = u16(q);
+        if (len < 2 || q + len > n) return sf::fail(SF_ERR_FORMAT, "jpeg: bad segment length");
+        if (m == 0xDA) { at = q; more = true; break; }
+        int rc = SF_OK;
+        if (m == 0xDB) rc = parse_dqt(q + 2, q + len);
+        else if (m == 0xC4) rc = parse_dht(q + 2, q + len);
+        else if (m == 0xDD) { if (len != 4) return sf::fail(SF_ERR_FORMAT, "jpeg: bad DRI length"); restart = u16(q + 2); }
+        if (rc != SF_OK) return rc;
+        q += len;
+      }
+    }
+    // ---- every coefficient is in: dequantise in 16 bits and reconstruct the blocks that hold real samples (stbi__jpeg_finish, stb_image.h:2582-2598)
+    int blk[64];
+    for (int ci = 0; ci < ncomp; ci++) {
+      Component& c = comp[ci];
+      if (!qt_ok[c.tq]) return sf::fail(SF_ERR_FORMAT, "jpeg: missing quantisation table");
+      const uint16_t* q = qt[c.tq];
+      const int bwn = blocks_w(ci), bhn = blocks_h(ci);
+      for (int by = 0; by < bhn; by++)
+        for (int bx = 0; bx < bwn; bx++) {
+          const int16_t* src = coef[ci].data() + 64 * ((size_t)bx + (size_t)by * cbw[ci]);
+          for (int z = 0; z < 64; z++) blk[z] = sf_jpeg_dequant16(src[z], q[z]);
+          idct_block(blk, false, c.plane + (size_t)(by * 8) * c.bw + bx * 8, c.bw);
+        }
+    }
+  }
   BitSrc bs{data + pos, data + n};
   int todo = restart ? restart : 0x7FFFFFFF;
   int blk[64];
+  if (!progressive)
   for (int my = 0; my < mcuy; my++)
     for (int mx = 0; mx < mcux; mx++) {
       for (int ci = 0; ci < ncomp; ci++) {

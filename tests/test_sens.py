@@ -351,6 +351,35 @@ def test_jpeg_decode_identical_to_reference(oracle, tmp_path, size):
             assert np.array_equal(ours, ref), (size, sub, q, rst, int(np.abs(ours.astype(int) - ref).max()))
 
 
+@pytest.mark.parametrize("size", [(136, 104), (17, 9), (1, 1), (2, 3), (33, 31), (16, 16), (15, 16), (3, 50), (640, 480)])
+def test_progressive_jpeg_identical_to_reference(oracle, tmp_path, size):
+    """The reference's decoder takes progressive pictures too (stb_image.h:1771-1900, 2520-2556, 2582-2598) and RGBDFrame::decompressColorAlloc_stb hands
+    them through: DC scans interleaved, AC bands per component, successive approximation with refinement scans, restart intervals, tables redefined
+    between scans -- libjpeg's progression as PIL writes it, 4:4:4 / 4:2:2 / 4:2:0, sizes that are not whole MCUs; the same bytes as the reference."""
+    PIL = pytest.importorskip("PIL")
+    from PIL import Image
+    if not oracle.ref_sens_available():
+        pytest.skip("reference build absent")
+    W, H = size
+    img = _test_picture(W, H)
+    n = 0
+    for sub in (0, 1, 2):
+        for q, rst, opt in ((90, 0, False), (30, 3, True), (100, 0, True), (5, 0, False)) if W * H < 100000 else ((90, 0, True),):
+            buf = io.BytesIO()
+            kw = dict(restart_marker_blocks=rst) if rst else {}
+            Image.fromarray(img).save(buf, format="JPEG", quality=q, subsampling=sub, progressive=True, optimize=opt, **kw)
+            blob = buf.getvalue()
+            assert b"\xff\xc2" in blob and blob.count(b"\xff\xda") > 3            # SOF2 and several scans
+            ours, ref = _decode_both(oracle, tmp_path, blob, W, H)
+            assert np.array_equal(ours, ref), (size, sub, q, rst, int(np.abs(ours.astype(int) - ref).max()))
+            n += 1
+    assert n >= 3
+    grey = io.BytesIO()
+    Image.fromarray(img[..., 1]).save(grey, format="JPEG", quality=80, progressive=True)
+    ours, ref = _decode_both(oracle, tmp_path, grey.getvalue(), W, H)
+    assert np.array_equal(ours, ref)
+
+
 LAYOUTS = {"440": ((1, 2), (1, 1), (1, 1)), "411": ((4, 1), (1, 1), (1, 1)), "410": ((4, 2), (1, 1), (1, 1)), "422": ((2, 1), (1, 1), (1, 1)),
            "420": ((2, 2), (1, 1), (1, 1)), "v4": ((1, 4), (1, 1), (1, 1)), "h2v4": ((2, 4), (1, 1), (1, 1)), "luma-subsampled": ((1, 1), (2, 2), (2, 2)),
            "mixed": ((2, 2), (2, 1), (1, 2)), "h3": ((3, 1), (1, 1), (1, 1)), "grey": ((1, 1),)}
