@@ -318,6 +318,10 @@ int sf_sens_load_from_images(const char* folder, const char* basename, const cha
  * byte.  Frames are written by a pool of threads; progress (nullable) is called on the caller's thread with (frame, num_frames, user) in frame order.
  * bin/sens is this call plus the reference tool's stdout. */
 int sf_sens_save_to_images(const sf_sens* s, const char* folder, const char* basename, void (*progress)(uint64_t, uint64_t, void*), void* user);
+/* SensorData::saveToPointCloud(filename, frameFrom, frameTo) (:1564-1602, compiled only with mLib; the reference's statement of the unprojection, SURVEY 8a row
+ * a6): every valid depth pixel of frames [frame_from, frame_to) (frame_to = 0: one frame) unprojected with K_depth^-1, moved by the frame's camera-to-world
+ * (identity for a lost pose) and coloured by the pixel the colour camera sees there (alpha 255; (0,0,0,0) outside the colour image) -> a binary PLY point cloud. */
+int sf_sens_save_point_cloud(const sf_sens* s, const char* ply_path, uint64_t frame_from, uint64_t frame_to, uint64_t* n_points);
 /* Editing a file in memory, opened or under construction (then sf_sens_save):
  *   sf_sens_replace_depth   SensorData::replaceDepth(frameIdx, depth)  :948-955,499-502 (W*H u16, compressed with the file's type; depth time stamp -> 0
  *                           as freeDepth leaves it, :516-521) -- what the Calibrate stage does to every frame (Calibrate/src/calibration.h:303)

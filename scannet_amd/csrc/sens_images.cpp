@@ -276,3 +276,103 @@ SF_API int sf_sens_save_to_images(const sf_sens* s, const char* folder_, const c
   if (!first_error.empty()) return sf::fail(SF_ERR_IO, "%s", first_error.c_str());
   return SF_OK;
 }
+
+// SensorData::saveToPointCloud(filename, frameFrom, frameTo) (sensorData.h:1564-1602; compiled only where mLib is present -- SURVEY 8a row a6 cites it as the
+// reference's statement of the unprojection): every valid depth pixel of frames [from, to) as a world-space point with the colour the colour camera sees
+// there.  Per pixel, in fp32 and in the reference's order:
+//     d = (float)depth / depthShift;  cam = K_depth^-1 * (x d, y d, d, 0);  world = camToWorld * cam   (identity when the pose is -inf or starts with 0, :1573)
+//     c = K_colour * (E_depth * cam);  u = c.x / c.z, v = c.y / c.z;  pixel = round(u), round(v);  inside the colour image: its rgb, alpha 255; else (0, 0, 0, 0)
+// K^-1 by cofactors and one division of the determinant (the public mLib's Matrix4x4::getInverse; mLib itself is not in the reference tree, so the last bits
+// of that inverse are not pinned).  Output: binary little-endian PLY, vertex = float x, y, z + uchar red, green, blue, alpha -- the layout the pipeline's
+// other PLY files have (README.md:45-46).  frame_to = 0: one frame.
+namespace {
+bool invert4(const float* m, float* inv) {
+  float t[16];
+  t[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+  t[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+  t[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+  t[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+  t[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+  t[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+  t[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+  t[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+  t[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+  t[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+  t[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+  t[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+  t[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+  t[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+  t[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+  t[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+  const float det = m[0] * t[0] + m[1] * t[4] + m[2] * t[8] + m[3] * t[12];
+  if (det == 0.0f) return false;
+  const float r = 1.0f / det;
+  for (int i = 0; i < 16; i++) inv[i] = t[i] * r;
+  return true;
+}
+inline void mul_point(const float* m, const float* p, float* o) {   // rows 0..2 of m * (p, 1)
+  for (int r = 0; r < 3; r++) o[r] = m[4 * r] * p[0] + m[4 * r + 1] * p[1] + m[4 * r + 2] * p[2] + m[4 * r + 3];
+}
+}  // namespace
+
+SF_API int sf_sens_save_point_cloud(const sf_sens* s, const char* ply_path, uint64_t frame_from, uint64_t frame_to, uint64_t* n_points) {
+  if (!s || !ply_path) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  try {
+    sf_sens_info info;
+    sf_sens_get_info(s, &info);
+    if (frame_to == 0) frame_to = frame_from + 1;
+    if (frame_from >= frame_to || frame_to > info.num_frames) return sf::fail(SF_ERR_BOUNDS, "frames [%llu, %llu) of %llu", (unsigned long long)frame_from, (unsigned long long)frame_to, (unsigned long long)info.num_frames);
+    float kinv[16];
+    if (!invert4(info.depth_intrinsic, kinv)) return sf::fail(SF_ERR_FORMAT, "the depth intrinsic is singular");
+    const uint32_t W = info.depth_width, H = info.depth_height, CW = info.color_width, CH = info.color_height;
+    std::vector<uint16_t> depth((size_t)W * H);
+    std::vector<uint8_t> color((size_t)CW * CH * 3);
+    struct Vtx { float x, y, z; uint8_t r, g, b, a; };
+    static_assert(sizeof(Vtx) == 16, "PLY vertex record");
+    std::vector<Vtx> pts;
+    for (uint64_t f = frame_from; f < frame_to; f++) {
+      int rc = sf_sens_decode_depth(s, f, depth.data());
+      if (rc != SF_OK) return rc;
+      sf_sens_frame_meta_t meta;
+      sf_sens_frame_meta(s, f, &meta);
+      const bool has_color = meta.color_bytes != 0 && CW != 0 && CH != 0;
+      if (has_color && (rc = sf_sens_decode_color(s, f, color.data())) != SF_OK) return rc;
+      float T[16];
+      int valid = 0;
+      sf_sens_pose(s, f, T, &valid);
+      if (T[0] == -std::numeric_limits<float>::infinity() || T[0] == 0.0f) {
+        std::memset(T, 0, sizeof T);
+        T[0] = T[5] = T[10] = T[15] = 1.0f;
+      }
+      for (uint32_t i = 0; i < W * H; i++) {
+        if (depth[i] == 0) continue;
+        const uint32_t x = i % W, y = i / W;
+        const float d = (float)depth[i] / info.depth_shift;
+        const float v4[3] = {(float)x * d, (float)y * d, d};   // w = 0: the fourth column of K^-1 does not take part
+        float cam[3], world[3], cf[3], cc[3];
+        for (int r = 0; r < 3; r++) cam[r] = kinv[4 * r] * v4[0] + kinv[4 * r + 1] * v4[1] + kinv[4 * r + 2] * v4[2];
+        mul_point(T, cam, world);
+        mul_point(info.depth_extrinsic, cam, cf);
+        mul_point(info.color_intrinsic, cf, cc);
+        Vtx v{world[0], world[1], world[2], 0, 0, 0, 0};
+        if (has_color) {
+          const float u = cc[0] / cc[2], w = cc[1] / cc[2];
+          const long long px = (long long)std::floor(u + 0.5f), py = (long long)std::floor(w + 0.5f);
+          if (px >= 0 && px < (long long)CW && py >= 0 && py < (long long)CH) {
+            const uint8_t* c = &color[3 * ((size_t)py * CW + (size_t)px)];
+            v.r = c[0]; v.g = c[1]; v.b = c[2]; v.a = 255;
+          }
+        }
+        pts.push_back(v);
+      }
+    }
+    FILE* fp = std::fopen(ply_path, "wb");
+    if (!fp) return sf::fail(SF_ERR_IO, "cannot open file %s", ply_path);
+    std::fprintf(fp, "ply\nformat binary_little_endian 1.0\nelement vertex %zu\nproperty float x\nproperty float y\nproperty float z\nproperty uchar red\nproperty uchar green\n"
+                     "property uchar blue\nproperty uchar alpha\nend_header\n", pts.size());
+    const bool ok = pts.empty() || std::fwrite(pts.data(), sizeof(Vtx), pts.size(), fp) == pts.size();
+    if (std::fclose(fp) != 0 || !ok) return sf::fail(SF_ERR_IO, "short write to %s", ply_path);
+    if (n_points) *n_points = pts.size();
+    return SF_OK;
+  } catch (...) { return sf::fail(SF_ERR_IO, "out of memory building the point cloud"); }
+}

@@ -232,6 +232,14 @@ class SensorData:
         check(L.sf_sens_add_frame_blobs(self._h, cb or None, len(cb), db or None, len(db), _ptr(pose), int(timestamp_color), int(timestamp_depth)))
         self._refresh()
 
+    def save_point_cloud(self, ply_path, frame_from=0, frame_to=0):
+        """SensorData::saveToPointCloud (sensorData.h:1564-1602): the valid depth pixels of frames [frame_from, frame_to) as coloured world-space points; returns the count."""
+        L = _abi.lib()
+        L.sf_sens_save_point_cloud.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+        n = C.c_uint64(0)
+        check(L.sf_sens_save_point_cloud(self._h, os.fsencode(ply_path), int(frame_from), int(frame_to), C.byref(n)))
+        return n.value
+
     def add_depth_frames(self, depth, poses, timestamp0=0, timestamp_step=33333, threads=0):
         """n depth-only frames [n, H, W] uint16 with poses [n, 4, 4], compressed on `threads` threads (0 = all this process may use)."""
         d = np.ascontiguousarray(depth, np.uint16)

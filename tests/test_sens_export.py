@@ -234,3 +234,60 @@ def test_images_back_into_a_sens(tmp_path):
     (d / "seq-000001.depth.png").write_bytes(open(str(d / "seq-000001.color.png"), "rb").read())     # an RGB picture where the depth belongs
     with pytest.raises(Exception, match="16-bit grey"):
         sens.SensorData.load_from_images(str(d), basename="seq-")
+
+
+def test_save_point_cloud_follows_the_reference_formula(tmp_path):
+    """SensorData::saveToPointCloud (sensorData.h:1564-1602; compiled only with mLib, which the reference tree does not hold -- so this is a restatement of its
+    statements in numpy, float32 like the reference, not a run of it): d = depth / shift, cam = K^-1 (x d, y d, d, 0), world = camToWorld cam (identity for a
+    lost pose), colour = the colour frame at round(K_c E_d cam) or (0, 0, 0, 0) outside; one point per non-zero depth pixel, frames in order."""
+    from scannet_amd import sens, synth
+    W, H, CW, CH = 40, 30, 64, 48
+    K = synth.intrinsic_matrix(W, H)
+    KC = np.eye(4, dtype=np.float32)
+    KC[0, 0], KC[1, 1], KC[0, 2], KC[1, 2] = 60.5, 61.25, 33.0, 22.5      # a colour camera that does not see every depth pixel
+    rng = np.random.default_rng(5)
+    sd = sens.SensorData.create(CW, CH, W, H, KC, K, color_compression=0, depth_compression=1)
+    poses, depths, colours = [], [], []
+    for i in range(3):
+        d = rng.integers(400, 4000, (H, W)).astype(np.uint16)
+        d[rng.random((H, W)) < 0.2] = 0
+        c = rng.integers(0, 256, (CH, CW, 3)).astype(np.uint8)
+        pose = synth.trajectory_pose(40 * i, 400) if i != 1 else np.full((4, 4), -np.inf, np.float32)
+        sd.add_frame(d, pose, color=c)
+        poses.append(pose); depths.append(d); colours.append(c)
+    p = str(tmp_path / "pc.sens")
+    sd.save(p)
+    sd.close()
+    s = sens.SensorData(p)
+    out = str(tmp_path / "cloud.ply")
+    n = s.save_point_cloud(out, 0, 3)
+    raw = open(out, "rb").read()
+    head, body = raw.split(b"end_header\n", 1)
+    assert b"format binary_little_endian 1.0" in head and ("element vertex %d" % n).encode() in head and b"property uchar alpha" in head
+    got = np.frombuffer(body, dtype=np.dtype([("xyz", "<f4", 3), ("rgba", "u1", 4)]))
+    assert len(got) == n == sum(int((d != 0).sum()) for d in depths)
+    f32 = np.float32
+    Kinv = np.linalg.inv(K.astype(np.float64)).astype(f32)
+    want_xyz, want_rgba = [], []
+    for d, c, pose in zip(depths, colours, poses):
+        T = np.eye(4, dtype=f32) if (pose[0, 0] == -np.inf or pose[0, 0] == 0) else pose.astype(f32)
+        yy, xx = np.nonzero(d)            # row-major order: i = y * W + x ascending
+        dm = d[yy, xx].astype(f32) / f32(1000.0)
+        v = np.stack([xx.astype(f32) * dm, yy.astype(f32) * dm, dm], -1)
+        cam = (v.astype(np.float64) @ Kinv[:3, :3].astype(np.float64).T).astype(f32)
+        world = (cam.astype(np.float64) @ T[:3, :3].astype(np.float64).T + T[:3, 3]).astype(f32)
+        cc = cam.astype(np.float64) @ KC[:3, :3].astype(np.float64).T          # depth extrinsic = identity
+        px, py = np.floor(cc[:, 0] / cc[:, 2] + 0.5).astype(np.int64), np.floor(cc[:, 1] / cc[:, 2] + 0.5).astype(np.int64)
+        inside = (px >= 0) & (px < CW) & (py >= 0) & (py < CH)
+        rgba = np.zeros((len(dm), 4), np.uint8)
+        rgba[inside, :3] = c[py[inside], px[inside]]
+        rgba[inside, 3] = 255
+        want_xyz.append(world); want_rgba.append(rgba)
+    want_xyz, want_rgba = np.concatenate(want_xyz), np.concatenate(want_rgba)
+    assert np.abs(got["xyz"] - want_xyz).max() < 2e-6 * max(1.0, np.abs(want_xyz).max())      # fp32 sums in another order than numpy's
+    differ = (got["rgba"] != want_rgba).any(1)
+    assert differ.mean() < 2e-3                                      # a projected coordinate within an ulp of .5 may round to the neighbouring pixel
+    assert (got["rgba"][:, 3] == 0).any() and (got["rgba"][:, 3] == 255).any()
+    assert s.save_point_cloud(str(tmp_path / "one.ply"), 2) == int((depths[2] != 0).sum())      # frame_to = 0: one frame
+    with pytest.raises(Exception):
+        s.save_point_cloud(out, 2, 9)
