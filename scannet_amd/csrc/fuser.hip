@@ -893,9 +893,12 @@ struct CompactArgs {
 };
 constexpr int FRAMEK_WORDS = (int)(sizeof(FrameK) / 4);
 
-constexpr int COMPACT_THREADS = 1024;   // one thread per directory entry of the workgroup's 1024: 16 waves share the (entry, frame) tests -- 32 steps of
-                                        // ~300 dependent cycles per wave instead of 128 (four waves per workgroup left most SIMDs with one wave and the
-                                        // kernel at the length of that one chain: 52 us of which 1.4 M wave instructions account for two)
+// One thread per directory entry, COMPACT_THREADS entries per workgroup: a wave tests its 64 entries against all frames in 32 steps of ~300 dependent cycles.
+// (Four entries per thread -- 128 steps per wave -- left the kernel at the length of that one chain: 52-62 us for 1.4 M wave instructions.  1024 threads per
+// workgroup took the chain to 20 us ALONE but 170 us beside the integrate pass: a workgroup of 16 waves of 90 registers needs a whole CU to itself, and the
+// integrate kernel's waves hold 480 of a SIMD's 512 registers -- a workgroup of 4 waves finds a home as soon as one wave per SIMD retires:
+// profiles/r06_compactify.txt.)
+constexpr int COMPACT_THREADS = 256;
 constexpr int COMPACT_WAVES = COMPACT_THREADS / 64;
 
 __global__ __launch_bounds__(COMPACT_THREADS) void k_compactify(CompactArgs A) {
@@ -911,8 +914,8 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_compactify(CompactArgs A) {
   const BatchFrames& B = A.B;
   __shared__ int s_wtot[COMPACT_WAVES], s_wlast[COMPACT_WAVES], s_wpop[COMPACT_WAVES];
   __shared__ int s_base;
-  __shared__ int4 s_c[1024];        // (bx, by, bz, listed?) of the workgroup's 1024 directory entries
-  __shared__ uint32_t s_m[1024];    // their frame masks
+  __shared__ int4 s_c[COMPACT_THREADS];        // (bx, by, bz, listed?) of the workgroup's directory entries
+  __shared__ uint32_t s_m[COMPACT_THREADS];    // their frame masks
   __shared__ uint32_t s_fk[MAX_BATCH * FRAMEK_WORDS];   // the batch's FrameK array, copied from the kernarg segment
   const int hw = counters[C_HIGH_WATER];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -922,7 +925,7 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_compactify(CompactArgs A) {
   const int fshift = B.n <= 8 ? 3 : (B.n <= 16 ? 4 : 5);
   const int q = lane & ((1 << fshift) - 1), sub = lane >> fshift, epi = 64 >> fshift;
   FrameK F;
-  if (wide && (int)(blockIdx.x * 1024) < hw) {
+  if (wide && (int)(blockIdx.x * COMPACT_THREADS) < hw) {
     // the frames' constants: kernarg segment -> LDS by vector loads (per-lane addresses: every load of the workgroup is in flight at once), then frame q's
     // into this lane's registers for the life of the workgroup
     typedef __attribute__((address_space(4))) const uint32_t* karg_t;
@@ -935,7 +938,7 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_compactify(CompactArgs A) {
 #pragma unroll
     for (int i = 0; i < FRAMEK_WORDS; i++) fw[i] = mine[i];
   }
-  for (int base = blockIdx.x * 1024; base < hw; base += gridDim.x * 1024) {
+  for (int base = blockIdx.x * COMPACT_THREADS; base < hw; base += gridDim.x * COMPACT_THREADS) {
     const int i = base + (int)threadIdx.x;   // this thread's directory entry
     uint32_t m = 0u;
     if (wide) {
@@ -994,16 +997,19 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_compactify(CompactArgs A) {
     if (lane == 0) { s_wtot[wave] = wtotal; s_wlast[wave] = wlast; s_wpop[wave] = pop; }
     __syncthreads();
     if (threadIdx.x == 0) {
-      int total = 0, tlast = 0, tpop = 0;
-      for (int w = 0; w < COMPACT_WAVES; w++) { total += s_wtot[w]; tlast += s_wlast[w]; tpop += s_wpop[w]; }
+      int total = 0, tlast = 0;
+      for (int w = 0; w < COMPACT_WAVES; w++) { total += s_wtot[w]; tlast += s_wlast[w]; }
       s_base = 0;
       if (total) {
         const unsigned long long add = (unsigned long long)(uint32_t)total | ((unsigned long long)(uint32_t)tlast << 32);
         s_base = (int)(uint32_t)atomicAdd(reinterpret_cast<unsigned long long*>(&counters[counter_id]), add);
-        if (!all_live) {
-          atomicAdd(reinterpret_cast<unsigned long long*>(&counters[C_TOTAL_LO]), (unsigned long long)tpop);
-          atomicAdd(reinterpret_cast<unsigned long long*>(&counters[C_TILES_LO]), (unsigned long long)total);
-        }
+      }
+    } else if (threadIdx.x == 64 && !all_live) {   // the two statistics: another wave's lane, so that nobody waits for them behind the returning atomic
+      int total = 0, tpop = 0;
+      for (int w = 0; w < COMPACT_WAVES; w++) { total += s_wtot[w]; tpop += s_wpop[w]; }
+      if (total) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(&counters[C_TOTAL_LO]), (unsigned long long)tpop);
+        atomicAdd(reinterpret_cast<unsigned long long*>(&counters[C_TILES_LO]), (unsigned long long)total);
       }
     }
     __syncthreads();
@@ -2051,7 +2057,7 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
 #undef LAUNCH_ALLOC
 #undef LAUNCH_ALLOC_RAY
   }
-  hipLaunchKernelGGL(k_compactify, dim3(f->compact_grid), dim3(COMPACT_THREADS), 0, sa, (CompactArgs{f->block_keys, f->block_entry, f->block_flags, f->table, f->compact2[sl],
+  hipLaunchKernelGGL(k_compactify, dim3(f->compact_grid * (1024 / COMPACT_THREADS)), dim3(COMPACT_THREADS), 0, sa, (CompactArgs{f->block_keys, f->block_entry, f->block_flags, f->table, f->compact2[sl],
                      f->cmask2[sl], f->counters, cc, 0, f->pk, bf}));
   if (f->overlap && sa != s) {
     (void)hipEventRecord(f->ev_compact[sl], sa);
@@ -2706,7 +2712,7 @@ int sf_compact_live(sf_fuser* f, int32_t* n_out, int include_ghosts) {
   std::memset(&dummy, 0, sizeof(dummy));
   dummy.n = 1;
   SF_HIP_CHECK(hipMemsetAsync(&f->counters[C_EXPORT], 0, 8, f->stream));
-  hipLaunchKernelGGL(k_compactify, dim3(f->compact_grid), dim3(COMPACT_THREADS), 0, f->stream, (CompactArgs{f->block_keys, f->block_entry, f->block_flags, f->table, f->compact,
+  hipLaunchKernelGGL(k_compactify, dim3(f->compact_grid * (1024 / COMPACT_THREADS)), dim3(COMPACT_THREADS), 0, f->stream, (CompactArgs{f->block_keys, f->block_entry, f->block_flags, f->table, f->compact,
                      f->cmask2[0], f->counters, (int)C_EXPORT, include_ghosts ? 1 : 2, f->pk, dummy}));
   SF_HIP_CHECK(hipMemcpyAsync(n_out, &f->counters[C_EXPORT], 4, hipMemcpyDeviceToHost, f->stream));
   SF_HIP_CHECK(sf_quiesce(f));

@@ -332,6 +332,14 @@ __global__ __launch_bounds__(IG_COPY_LANES) void k_inflate_copy(InflateBatch B) 
 // count -- per chunk, prefix sum or total -- can wrap (2^24 * 159 = 2.7e9 < 2^32).  A depth frame's stream is bounded by its pixels anyway.
 constexpr uint64_t IG_MAX_STREAM_BYTES = 1ull << 24;
 static_assert(IG_MAX_STREAM_BYTES * 8 / 13 * 258 < (1ull << 32), "32-bit output counts of the inflate kernels");
+// The code object of this file is loaded by the runtime when one of its kernels is first used (milliseconds, inside a scan's first sf_fuse_run unless somebody asks
+// earlier): the preparation thread of the frame pipeline asks (pipeline.hip, sf_run_resources_prepare_ex).
+void inflate_gpu_warm() {
+  hipFuncAttributes a;
+  (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(k_inflate_tokens));
+  (void)hipGetLastError();
+}
+
 bool inflate_gpu_takes(const uint8_t* z, uint64_t n) {
   return n >= 8 && (z[0] & 0x0F) == 8 && ((z[0] << 8 | z[1]) % 31) == 0 && !(z[1] & 0x20) && (z[2] & 7) == 3 && n - 2 < IG_MAX_STREAM_BYTES;
 }

@@ -129,6 +129,14 @@ __global__ __launch_bounds__(256) void k_jpeg_rgb(JpegBatch B) {
 // Reconstruct up to 16 entropy-decoded frames on `stream`.  d_payload[i]: SfJpegLayout + coefficients (16-byte aligned), d_rgb[i]: the
 // RGB image out (nullptr: skip the slot), d_planes[i]: scratch of at least the summed plane sizes.  max_blocks / max_width x max_height bound the
 // grid (the layouts live on the device).
+// The code object of this file is loaded by the runtime when one of its kernels is first used (milliseconds, inside a scan's first sf_fuse_run unless somebody asks
+// earlier): the preparation thread of the frame pipeline asks (pipeline.hip, sf_run_resources_prepare_ex).
+void jpeg_gpu_warm() {
+  hipFuncAttributes a;
+  (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(k_jpeg_idct));
+  (void)hipGetLastError();
+}
+
 int jpeg_gpu_reconstruct(hipStream_t stream, int n, const uint8_t* const* d_payload, uint8_t* const* d_rgb, uint8_t* const* d_planes, uint32_t max_blocks,
                          uint32_t max_width, uint32_t max_height) {
   if (n < 1 || n > JPEG_MAX_BATCH) return sf::fail(SF_ERR_INVALID_ARG, "jpeg_gpu_reconstruct: %d frames", n);

@@ -168,6 +168,14 @@ __global__ __launch_bounds__(JH_LANES) void k_jpeg_huff(JpegHuffBatch B) {
 
 }  // namespace
 
+// The code object of this file is loaded by the runtime when one of its kernels is first used (milliseconds, inside a scan's first sf_fuse_run unless somebody asks
+// earlier): the preparation thread of the frame pipeline asks (pipeline.hip, sf_run_resources_prepare_ex).
+void jpeg_huff_gpu_warm() {
+  hipFuncAttributes a;
+  (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(k_jpeg_huff));
+  (void)hipGetLastError();
+}
+
 // Entropy-decode up to 32 prepared pictures on `stream`: d_prepared[i] (jpeg_prepare_huff's payload, uploaded) -> d_payload[i] (what
 // jpeg_gpu_reconstruct reads); max_entries[i] = room for entries in d_payload[i]; d_status (nullable): 2 * n ints the caller zeroed, written only
 // for pictures that fail: {code < 0, tags[i]}.

@@ -25,6 +25,9 @@
 
 int sf_fuser_run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb, const float* const* poses, int n);  // fuser.hip
 int jpeg_decode_coef(const uint8_t* data, uint64_t n, uint32_t expect_w, uint32_t expect_h, uint8_t* payload, uint64_t payload_capacity);  // jpeg.cpp
+void inflate_gpu_warm();     // inflate_gpu.hip, jpeg_gpu.hip, jpeg_huff_gpu.hip: load the file's code object now
+void jpeg_gpu_warm();
+void jpeg_huff_gpu_warm();
 bool inflate_gpu_takes(const uint8_t* z, uint64_t n);  // inflate_gpu.hip
 int inflate_gpu_batch(hipStream_t stream, int n, const uint32_t* const* d_words, const uint32_t* nbytes, uint8_t* const* d_out, uint16_t* const* d_plan, uint32_t expect,
                       const int32_t* tags, int32_t* d_status);  // inflate_gpu.hip
@@ -162,6 +165,8 @@ void sf_run_resources_prepare_ex(int device, size_t pinned_bytes, size_t device_
   try {
     r->prep = std::thread([r, device, pinned_bytes, device_bytes, plan_bytes, side_streams, copy_streams]() {
       if (hipSetDevice(device) != hipSuccess) return;
+      if (side_streams > 0) inflate_gpu_warm();                       // the code objects of the kernels the side streams run
+      if (side_streams > 3) { jpeg_gpu_warm(); jpeg_huff_gpu_warm(); }   // (five side streams: a JPEG-colour scan)
       for (int q = 0; q < side_streams; q++)
         if (!r->inflate[q] && create_side_stream(&r->inflate[q]) != hipSuccess) { r->inflate[q] = nullptr; break; }
       for (int q = 0; q < copy_streams; q++)

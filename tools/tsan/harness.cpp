@@ -49,6 +49,9 @@ int sf_fuser_run_batch(sf_fuser* f, const void* const* d_depth, const void* cons
 // "device" copy of the compressed bytes into the frame buffer the pre-pass will read, and scribbles over the launch's plan scratch (shared by the
 // launches of one stream: a second stream using it at the same time is a race TSan sees).  Two frames in three travel compressed, the third is
 // inflated by a host thread -- both kinds in every batch, as a file with foreign streams gives.
+void inflate_gpu_warm() {}
+void jpeg_gpu_warm() {}
+void jpeg_huff_gpu_warm() {}
 bool inflate_gpu_takes(const uint8_t* z, uint64_t n) {
   return n >= 8 && (z[0] & 0x0F) == 8 && ((z[0] << 8 | z[1]) % 31) == 0 && !(z[1] & 0x20) && (z[2] & 7) == 3 && (z[n - 1] + z[n - 2]) % 3 != 0;
 }
