@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "fuser_internal.h"
+#include "jpeg_idct.h"
 
 namespace {
 
@@ -74,6 +75,40 @@ __device__ inline float min_f32(float a, float b) {
   return r;
 }
 
+// One pixel of a JPEG picture from its component planes (what k_jpeg_idct of jpeg_gpu.hip leaves): chroma upsampling and the fixed-point YCbCr -> RGB of
+// jpeg_idct.h, the integer functions the host decoder and k_jpeg_rgb are built from -- the same bytes, for the pixels the pre-pass looks up only.
+struct YccPicture {
+  int ncomp, sx[3], sy[3], cw[3], ch[3], bw[3];
+  const uint8_t* plane[3];
+  __device__ YccPicture(const SfJpegLayout* __restrict__ L, const uint8_t* planes) {
+    const int W = L->width, H = L->height;
+    ncomp = L->ncomp;
+    const uint8_t* q = planes;
+    for (int c = 0; c < 3; c++) {
+      const int cc = c < ncomp ? c : 0;
+      sx[c] = L->hmax > L->h[cc] ? 2 : 1; sy[c] = L->vmax > L->v[cc] ? 2 : 1;
+      cw[c] = (W + sx[c] - 1) >> (sx[c] - 1); ch[c] = (H * L->v[cc] + L->vmax - 1) >> (L->vmax - 1);
+      bw[c] = L->bw[cc];
+      plane[c] = q;
+      if (c < ncomp) q += (size_t)L->bw[cc] * L->bh[cc];
+    }
+  }
+  __device__ uint32_t pixel(int x, int y) const {   // r | g << 8 | b << 16
+    uint8_t o[3];
+    if (ncomp == 1) { o[0] = o[1] = o[2] = plane[0][(size_t)y * bw[0] + x]; }
+    else {
+      int v[3];
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        __builtin_assume(sx[c] >= 1 && sx[c] <= 2 && sy[c] >= 1 && sy[c] <= 2);
+        v[c] = sf_jpeg_upsample(plane[c], bw[c], cw[c], ch[c], sx[c], sy[c], x, y);
+      }
+      sf_jpeg_ycc_to_rgb(v[0], v[1], v[2], o);
+    }
+    return (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16);
+  }
+};
+
 // ---------------------------------------------------------------------------------------------------
 // K1: depth pre-pass.  u16 -> metres (sensorData.h:968-977: d = depth / depthShift, 0 invalid), range
 // gate (zParametersScanNet.txt:34-35) -> -inf; optional rgb -> packed u32.  8 pixels per lane; blockIdx.y = frame
@@ -93,7 +128,8 @@ __global__ __launch_bounds__(256) void k_prepass(BatchIn in, float* __restrict__
   if (blockIdx.x == 0 && j == 0 && threadIdx.x == 0) {
     atomicExch(reinterpret_cast<unsigned long long*>(&counters[compact_counter]), 0ull);
   }
-  if (i0 >= n) return;
+  const bool ycc = rgb != nullptr && in.lay[j] != nullptr;   // uniform
+  if (i0 >= n && !ycc) return;   // (the planes' look-ups below are dealt out across the whole workgroup)
   uint16_t u[8];
   if (P.inW > 0) {
     // s_integrationWidth / Height: nearest resample of the inW x inH input (scanfuse.h sf_params::integration_width)
@@ -123,7 +159,32 @@ __global__ __launch_bounds__(256) void k_prepass(BatchIn in, float* __restrict__
   } else {
     for (int k = 0; k < 8 && i0 + k < n; k++) depthf[i0 + k] = d[k];
   }
-  if (rgb) {
+  if (ycc) {
+    // a JPEG picture as component planes: the pixel under each depth pixel (its own, or -- colour at its own resolution -- the one under the depth pixel's ray,
+    // the look-up below) is upsampled and converted here.  Consecutive LANES take consecutive pixels for this part (the depths change hands through LDS): a
+    // wave's look-ups then fall on one or two rows of each plane and its texel stores are whole 512-byte runs; with the lane's own eight consecutive pixels
+    // every byte load of a wave touched 64 different cache lines (k_prepass 200 -> 440 us per 32-frame batch beside the fusion).
+    __shared__ float s_d[2048];
+#pragma unroll
+    for (int k = 0; k < 8; k++) s_d[threadIdx.x * 8 + k] = d[k];
+    __syncthreads();
+    const YccPicture pic(reinterpret_cast<const SfJpegLayout*>(in.lay[j]), rgb);
+    const int wg0 = blockIdx.x * 2048;
+#pragma unroll 2
+    for (int k = 0; k < 8; k++) {
+      const int p = wg0 + k * 256 + (int)threadIdx.x;
+      if (p >= n) break;
+      const int y = p / P.W, x = p - y * P.W;
+      uint32_t c = 0u;
+      if (P.cW == 0) c = pic.pixel(x, y);
+      else {
+        const float u = fmaf(ray_kx[x], P.cfx, P.cmx) + 0.5f;
+        const float v = fmaf(ray_ky[y], P.cfy, P.cmy) + 0.5f;
+        if (u >= 0.0f && u < (float)P.cW && v >= 0.0f && v < (float)P.cH) c = pic.pixel((int)u, (int)v);
+      }
+      texel[p] = make_uint2(__float_as_uint(s_d[k * 256 + (int)threadIdx.x]), c);
+    }
+  } else if (rgb) {
     if (P.cW == 0) {
       // colour at depth resolution: the lane's 8 pixels are 24 contiguous bytes = three 8-byte loads (24 * lane is 8-byte aligned when the
       // image base is), repacked to one dword per pixel
@@ -1991,7 +2052,7 @@ hipStream_t sf_input_stream(const sf_fuser* f, int n, bool color, int sign) {
 
 namespace {
 
-int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb, const float* const* poses, int n, int sign) {
+int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb, const float* const* poses, int n, int sign, const void* const* d_lay = nullptr) {
   BatchIn in;
   BatchFrames bf;
   BatchTi bt;
@@ -2006,6 +2067,7 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
     std::memcpy(bt.Ti[j], bf.f[j].Ti, sizeof(bt.Ti[j]));
     in.depth[j] = (const uint16_t*)d_depth[j];
     in.rgb[j] = col ? (const uint8_t*)d_rgb[j] : nullptr;
+    in.lay[j] = (col && d_lay) ? (const uint8_t*)d_lay[j] : nullptr;
   }
   f->frame_seq += (uint32_t)n;
   const int npx = f->p.depth_width * f->p.depth_height;
@@ -2554,6 +2616,12 @@ SF_API int sf_fuser_tune(sf_fuser* f, const char* key, int value) {
 int sf_fuser_run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb, const float* const* poses, int n) {
   if (n < 1 || n > f->batch) return sf::fail(SF_ERR_INVALID_ARG, "batch of %d frames (limit %d)", n, f->batch);
   return run_batch(f, d_depth, d_rgb, poses, n, +1);
+}
+
+// ... the colour frames as JPEG component planes (d_planes[j]: what jpeg_gpu_planes left; d_layout[j]: the picture's SfJpegLayout on the device)
+int sf_fuser_run_batch_ycc(sf_fuser* f, const void* const* d_depth, const void* const* d_planes, const void* const* d_layout, const float* const* poses, int n) {
+  if (n < 1 || n > f->batch) return sf::fail(SF_ERR_INVALID_ARG, "batch of %d frames (limit %d)", n, f->batch);
+  return run_batch(f, d_depth, d_planes, poses, n, +1, d_layout);
 }
 
 SF_API int sf_fuser_sync(sf_fuser* f) {

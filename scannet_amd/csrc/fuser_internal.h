@@ -79,7 +79,8 @@ struct FrameK {
 // Per-batch kernel arguments (passed by value: kernarg segment, read with scalar loads).
 struct BatchIn {  // k_prepass
   const uint16_t* depth[MAX_BATCH];
-  const uint8_t* rgb[MAX_BATCH];
+  const uint8_t* rgb[MAX_BATCH];   // RGB8 pixels -- or, where lay[j] is set, the component planes k_jpeg_idct left of a JPEG picture
+  const uint8_t* lay[MAX_BATCH];   // nullptr, or the picture's SfJpegLayout (device): the pre-pass upsamples and converts the pixels it looks up itself
 };
 struct BatchFrames {  // k_alloc, k_compactify
   int n;
@@ -94,7 +95,7 @@ struct BatchTi {  // k_integrate: world -> camera rows 0..2 of every frame of th
 // -m gpu test launches them).  The bound below is what this code relies on having been tested; a toolchain with a smaller limit fails the launch
 // loudly (hipErrorInvalidValue -> SF_ERR_DEVICE), it does not truncate.
 static_assert(sizeof(BatchFrames) == 8 + MAX_BATCH * sizeof(FrameK) && sizeof(BatchFrames) + 512 <= 6144, "BatchFrames kernarg grew: re-test the launch or move FrameK to a device buffer");
-static_assert(sizeof(BatchIn) <= 512 && sizeof(BatchTi) <= 1536, "kernarg structs");
+static_assert(sizeof(BatchIn) <= 768 && sizeof(BatchTi) <= 1536, "kernarg structs");
 
 enum Counter {
   C_HEAP_FREE = 0,

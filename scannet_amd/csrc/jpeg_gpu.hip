@@ -1,7 +1,7 @@
 // jpeg_gpu.hip -- the data-parallel half of baseline JPEG decoding on gfx950.  The frame pipeline's host threads only entropy-decode
 // (jpeg.cpp: jpeg_decode_coef -- Huffman decoding is serial per frame); the non-zero quantised coefficients go over PCIe in place of the
 // RGB image (about a third of its bytes) and two kernels reconstruct the picture where the fuser wants it anyway, in HBM:
-//   k_jpeg_idct   one lane per 8 x 8 block: its non-zero coefficients scattered into a zeroed LDS column and dequantised to 16 bits,
+//   k_jpeg_idct   one lane per 8 x 8 block: its non-zero coefficients (fetched eight at a time) scattered into a zeroed 16-bit LDS column, dequantised,
 //                 integer 1-D passes down the columns and along the rows, clamp, eight 8-byte stores into the plane
 //   k_jpeg_rgb    four pixels per lane: chroma upsampling, fixed-point YCbCr -> RGB, three dword stores
 // Every arithmetic step is the integer function of jpeg_idct.h the host decoder is built from, so the bytes are the ones
@@ -26,8 +26,11 @@ struct JpegBatch {
   uint8_t* planes[JPEG_MAX_BATCH];          // scratch for the component planes of this frame
 };
 
+// LDS: one 16-bit column of 64 dequantised coefficients per lane (32 KiB per workgroup: five workgroups per CU; as 32-bit words it was 64 KiB, two per CU, and the
+// kernel -- two waves per SIMD, each waiting for its block's entries one load at a time -- took 280-410 us per 16 pictures beside the fusion).
 __global__ __launch_bounds__(256) void k_jpeg_idct(JpegBatch B) {
-  extern __shared__ int s_blk[];   // [64][256]: coefficient z of lane t at z * 256 + t (no bank conflicts either way)
+  __shared__ uint4 s_blk4[64 * 256 * 2 / 16];   // [64][256] int16: coefficient z of lane t at z * 256 + t
+  int16_t* const s_blk = reinterpret_cast<int16_t*>(s_blk4);
   const int f = blockIdx.y;
   if (B.rgb[f] == nullptr) return;
   const SfJpegLayout* __restrict__ L = reinterpret_cast<const SfJpegLayout*>(B.payload[f]);
@@ -35,6 +38,8 @@ __global__ __launch_bounds__(256) void k_jpeg_idct(JpegBatch B) {
   const uint32_t* __restrict__ entries = table + L->nblocks;
   __shared__ int s_q[3][64];
   for (int t = threadIdx.x; t < 64 * L->ncomp; t += 256) s_q[t >> 6][t & 63] = L->q[t >> 6][t & 63];
+#pragma unroll
+  for (int k = 0; k < 8; k++) s_blk4[k * 256 + threadIdx.x] = make_uint4(0, 0, 0, 0);
   __syncthreads();
   const uint32_t block = blockIdx.x * 256 + threadIdx.x;   // block index over all components
   if (block >= L->nblocks) return;
@@ -44,16 +49,21 @@ __global__ __launch_bounds__(256) void k_jpeg_idct(JpegBatch B) {
   for (int i = 0; i < c; i++) plane_off += (size_t)L->bw[i] * L->bh[i];
   const uint32_t b = block - L->block_off[c];
   const int blocks_w = L->bw[c] / 8;
-  // the block's non-zero coefficients scattered into a zeroed LDS column, dequantised on the way
-  int* col = s_blk + threadIdx.x;
-#pragma unroll
-  for (int z = 0; z < 64; z++) col[z * 256] = 0;
+  // the block's non-zero coefficients scattered into the lane's (zeroed) LDS column, dequantised on the way; eight entries are asked for at a time
+  int16_t* col = s_blk + threadIdx.x;
   const uint32_t te = table[block];
   const uint32_t* e = entries + (te >> 7);
-  for (uint32_t k = 0; k < (te & 127u); k++) {
-    const uint32_t w = e[k];
-    const int z = (int)((w >> 16) & 63u);
-    col[z * 256] = sf_jpeg_dequant16((int)(int16_t)(w & 0xffffu), s_q[c][z]);
+  const uint32_t cnt = te & 127u;
+  for (uint32_t k0 = 0; k0 < cnt; k0 += 8) {
+    uint32_t w[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) w[k] = e[min(k0 + k, cnt - 1u)];
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++)
+      if (k0 + k < cnt) {
+        const int z = (int)((w[k] >> 16) & 63u);
+        col[z * 256] = (int16_t)sf_jpeg_dequant16((int)(int16_t)(w[k] & 0xffffu), s_q[c][z]);
+      }
   }
   int blk[64];
 #pragma unroll
@@ -146,16 +156,23 @@ int jpeg_gpu_reconstruct(hipStream_t stream, int n, const uint8_t* const* d_payl
     b.rgb[i] = i < n ? d_rgb[i] : nullptr;
     b.planes[i] = i < n ? d_planes[i] : nullptr;
   }
-  // 64 KiB of dynamic LDS per workgroup: the attribute belongs to the device's copy of the kernel, set once per device
-  static std::atomic<uint64_t> lds_set{0};
-  int dev = 0;
-  SF_HIP_CHECK(hipGetDevice(&dev));
-  if (dev >= 64 || !(lds_set.load(std::memory_order_acquire) & (1ull << dev))) {
-    SF_HIP_CHECK(hipFuncSetAttribute((const void*)k_jpeg_idct, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 256 * (int)sizeof(float)));
-    if (dev < 64) lds_set.fetch_or(1ull << dev, std::memory_order_release);
-  }
-  hipLaunchKernelGGL(k_jpeg_idct, dim3((max_blocks + 255) / 256, n), dim3(256), 64 * 256 * sizeof(float), stream, b);
+  hipLaunchKernelGGL(k_jpeg_idct, dim3((max_blocks + 255) / 256, n), dim3(256), 0, stream, b);
   hipLaunchKernelGGL(k_jpeg_rgb, dim3((max_width + 255) / 256, (max_height + 3) / 4, n), dim3(256), 0, stream, b);
+  SF_HIP_CHECK(hipGetLastError());
+  return SF_OK;
+}
+
+// The component planes only (k_jpeg_idct): for a consumer that converts the pixels it needs itself -- the fuser's pre-pass looks up ONE colour pixel per depth
+// pixel (640x480 of a 1296x968 picture: a quarter of them), so the frame pipeline no longer has k_jpeg_rgb write 3.8 MB of RGB per picture for it to pick from.
+int jpeg_gpu_planes(hipStream_t stream, int n, const uint8_t* const* d_payload, uint8_t* const* d_planes, uint32_t max_blocks) {
+  if (n < 1 || n > JPEG_MAX_BATCH) return sf::fail(SF_ERR_INVALID_ARG, "jpeg_gpu_planes: %d frames", n);
+  JpegBatch b;
+  for (int i = 0; i < JPEG_MAX_BATCH; i++) {
+    b.payload[i] = i < n ? d_payload[i] : nullptr;
+    b.rgb[i] = i < n ? d_planes[i] : nullptr;   // k_jpeg_idct only asks whether the slot is used
+    b.planes[i] = i < n ? d_planes[i] : nullptr;
+  }
+  hipLaunchKernelGGL(k_jpeg_idct, dim3((max_blocks + 255) / 256, n), dim3(256), 0, stream, b);
   SF_HIP_CHECK(hipGetLastError());
   return SF_OK;
 }

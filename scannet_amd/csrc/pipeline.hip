@@ -24,6 +24,7 @@
 #include "sens.h"
 
 int sf_fuser_run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb, const float* const* poses, int n);  // fuser.hip
+int sf_fuser_run_batch_ycc(sf_fuser* f, const void* const* d_depth, const void* const* d_planes, const void* const* d_layout, const float* const* poses, int n);  // fuser.hip
 int jpeg_decode_coef(const uint8_t* data, uint64_t n, uint32_t expect_w, uint32_t expect_h, uint8_t* payload, uint64_t payload_capacity);  // jpeg.cpp
 void inflate_gpu_warm();     // inflate_gpu.hip, jpeg_gpu.hip, jpeg_huff_gpu.hip: load the file's code object now
 void jpeg_gpu_warm();
@@ -34,6 +35,7 @@ int inflate_gpu_batch(hipStream_t stream, int n, const uint32_t* const* d_words,
 int jpeg_prepare_huff(const uint8_t* data, uint64_t n, uint32_t expect_w, uint32_t expect_h, uint8_t* payload, uint64_t payload_capacity);  // jpeg.cpp
 int jpeg_gpu_huffman(hipStream_t stream, int n, const uint8_t* const* d_prepared, uint8_t* const* d_payload, const uint32_t* max_entries, const int32_t* tags,
                      int32_t* d_status);  // jpeg_huff_gpu.hip
+int jpeg_gpu_planes(hipStream_t stream, int n, const uint8_t* const* d_payload, uint8_t* const* d_planes, uint32_t max_blocks);   // jpeg_gpu.hip
 int jpeg_gpu_reconstruct(hipStream_t stream, int n, const uint8_t* const* d_payload, uint8_t* const* d_rgb, uint8_t* const* d_planes, uint32_t max_blocks,
                          uint32_t max_width, uint32_t max_height);  // jpeg_gpu.hip
 
@@ -317,6 +319,8 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
     }
   }
   const bool gpu_jpeg = pay_b != 0;
+  // SF_JPEG_RGB_IMAGE=1: the device writes every picture out as RGB (k_jpeg_rgb) and the pre-pass picks its pixels from that, as until round 5 (A/B measurements)
+  const bool ycc_ok = gpu_jpeg && std::getenv("SF_JPEG_RGB_IMAGE") == nullptr;
   // where the entropy decoding runs: on the device when the batch has a side stream for it (the depth inflate's), else on the host threads;
   // SF_JPEG_GPU_HUFFMAN=1 / SF_JPEG_HOST_HUFFMAN=1 force one or the other
   const bool gpu_huffman = gpu_jpeg && std::getenv("SF_JPEG_HOST_HUFFMAN") == nullptr && (std::getenv("SF_JPEG_GPU_HUFFMAN") != nullptr || SF_JPEG_DEVICE_HUFFMAN_DEFAULT(gpu_inflate));
@@ -688,7 +692,7 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
     // reconstruction of every picture that travelled as coefficients or segments -- beside the fusion of the batches before, three batches in flight,
     // instead of in front of this batch's pre-pass on the fuser's input stream (where a 32-picture batch cost 2 x 1.25 ms of a stream that also
     // carries allocation and compaction)
-    bool side_jpeg = false;
+    bool side_jpeg = false, ycc_batch = false;
     if (gpu_jpeg && gpu_inflate && any_rgb) {
       hipStream_t zs = inflate_stream[g % NZ];
       if (!any_comp) e = hipStreamWaitEvent(zs, bs.copied, 0);
@@ -717,8 +721,14 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
         if (++nh == 32) flush_h();
       }
       flush_h();
+      // every colour frame of the batch a picture the device reconstructs: the component planes are all the pre-pass needs (it converts the one pixel per
+      // depth pixel it looks up: k_prepass, YccPicture) -- no k_jpeg_rgb, no 3.8 MB RGB image per picture written and read back
+      int n_rgbf = 0;
+      for (int q = 0; q < cnt; q++) n_rgbf += rgbf[q] ? 1 : 0;
+      ycc_batch = ycc_ok && nj > 0 && nj == n_rgbf;
       for (int q0 = 0; q0 < nj && result == SF_OK; q0 += 16) {   // jpeg_gpu.hip reconstructs at most 16 frames per launch
-        const int rcj = jpeg_gpu_reconstruct(zs, std::min(16, nj - q0), pp_ + q0, rr_ + q0, pl_ + q0, pay_blocks, s->info.color_width, s->info.color_height);
+        const int rcj = ycc_batch ? jpeg_gpu_planes(zs, std::min(16, nj - q0), pp_ + q0, pl_ + q0, pay_blocks)
+                                  : jpeg_gpu_reconstruct(zs, std::min(16, nj - q0), pp_ + q0, rr_ + q0, pl_ + q0, pay_blocks, s->info.color_width, s->info.color_height);
         if (rcj != SF_OK) { result = rcj; err = sf_last_error(); }
       }
       if (result != SF_OK) break;
@@ -734,6 +744,7 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
       if (!valid[j]) { j++; continue; }
       const void* dd[MAX_BATCH];
       const void* dr[MAX_BATCH];
+      const void* dl[MAX_BATCH];
       const float* pp[MAX_BATCH];
       int m = 0;
       const bool rgb = rgbf[j];
@@ -742,7 +753,7 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
         if (valid[j]) {
           // pixels: inflated on the device into the slot's frame area, or (a stream the device does not take) as the host thread decoded them
           dd[m] = (gpu_inflate && !zmode[k0 + (uint64_t)j]) ? d_stage(sl) + zoff[k0 + (uint64_t)j] : d_depth(sl, j);
-          dr[m] = rgb ? d_rgb(sl, j) : nullptr; pp[m] = s->frames[first + g * (uint64_t)B + (uint64_t)j].pose; m++; }
+          dr[m] = rgb ? (ycc_batch ? d_planes(sl, j) : d_rgb(sl, j)) : nullptr; dl[m] = (rgb && ycc_batch) ? d_pay(sl, j) : nullptr; pp[m] = s->frames[first + g * (uint64_t)B + (uint64_t)j].pose; m++; }
         j++;
       }
       hipStream_t in_stream = sf_input_stream(f, m, rgb, +1);  // the stream this sub-batch's pre-pass runs on
@@ -784,7 +795,7 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
         }
         if (jpeg_failed) break;
       }
-      const int rc = sf_fuser_run_batch(f, dd, rgb ? dr : nullptr, pp, m);
+      const int rc = (rgb && ycc_batch) ? sf_fuser_run_batch_ycc(f, dd, dr, dl, pp, m) : sf_fuser_run_batch(f, dd, rgb ? dr : nullptr, pp, m);
       if (rc != SF_OK) { result = rc; err = sf_last_error(); break; }
       n_int += (uint64_t)m;
       if (used_streams[0] == nullptr || used_streams[0] == in_stream) used_streams[0] = in_stream;

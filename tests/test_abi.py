@@ -87,7 +87,7 @@ def test_no_cpu_fallback():
 def test_product_reads_no_measurement_switch_from_the_environment():
     """Round-1 finding: sf_fuser_create read eight SF_* variables.  The fuser's scheduling switches are sf_fuser_tune
     (scanfuse_internal.h); what is left in the environment are deployment knobs documented in INTEGRATION.md."""
-    allowed = {"SF_DEVICE", "SF_JPEG_HOST", "SF_JPEG_GPU_HUFFMAN", "SF_JPEG_HOST_HUFFMAN", "SF_INFLATE_HOST", "SF_RUN_TIMING", "SF_CLEAN_TIMING", "SF_HOST_WORKERS",
+    allowed = {"SF_DEVICE", "SF_JPEG_HOST", "SF_JPEG_GPU_HUFFMAN", "SF_JPEG_HOST_HUFFMAN", "SF_JPEG_RGB_IMAGE", "SF_INFLATE_HOST", "SF_RUN_TIMING", "SF_CLEAN_TIMING", "SF_HOST_WORKERS",
                "SF_EXCHANGE"}   # bin/depthsensing --ranks: file | ipc | rccl | auto -- the transport of the boundary exchange (INTEGRATION.md section 4)
     found = set()
     for dirpath, _, files in os.walk(os.path.join(ROOT, "scannet_amd")):

@@ -81,6 +81,8 @@ int inflate_gpu_batch(hipStream_t stream, int n, const uint32_t* const* d_words,
 }
 int jpeg_gpu_huffman(hipStream_t, int, const uint8_t* const*, uint8_t* const*, const uint32_t*, const int32_t*, int32_t*) { return SF_OK; }
 int jpeg_gpu_reconstruct(hipStream_t, int, const uint8_t* const*, uint8_t* const*, uint8_t* const*, uint32_t, uint32_t, uint32_t) { return SF_OK; }   // raw colour in this harness
+int jpeg_gpu_planes(hipStream_t, int, const uint8_t* const*, uint8_t* const*, uint32_t) { return SF_OK; }
+int sf_fuser_run_batch_ycc(sf_fuser*, const void* const*, const void* const*, const void* const*, const float* const*, int) { return SF_OK; }   // JPEG colour only
 
 int main(int argc, char** argv) {
   const int W = 160, H = 120, N = argc > 1 ? atoi(argv[1]) : 300, threads = argc > 2 ? atoi(argv[2]) : 8;
