@@ -1085,21 +1085,23 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_compactify(CompactArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K4: integrate / deintegrate.  One wave per 8^3 block: the 4 KiB tile is read with four fully
-// coalesced 16 B-per-lane loads (1 KiB per instruction, two x-adjacent voxels per load), updated in
+// K4: integrate / deintegrate.  One wave per 8^3 block: the 4 KiB tile is read with four 16 B-per-lane
+// loads (two x-adjacent voxels per load; in the x-row layout of multi-frame passes the lane's own 64 contiguous bytes), updated in
 // registers by EVERY frame of the batch that sees the block (temporal blocking: HBM traffic per frame
 // falls by the batch size, the kernel turns from HBM-bound at B = 1 to VALU/L2-gather-bound) and written
 // back with the same pattern.  There is no reuse inside a tile, so it is not
 // staged through LDS; the depth image (1.2 MB f32) is gathered through L1/L2.
-// lane l, load j: uint4 q = 64 j + l -> voxels 2q, 2q+1 -> x = (2l)&7 (+1), y = (l>>2)&7, z = 2j + (l>>5).
+// pair layout: lane l, load j: uint4 q = 64 j + l -> voxels 2q, 2q+1 -> x = (2l)&7 (+1), y = (l>>2)&7, z = 2j + (l>>5);
+// x-row layout (XR): lane l, load j: uint4 q = 4 l + j -> x = 2j (+1), y = l & 7, z = l >> 3.
 // ---------------------------------------------------------------------------------------------------
-// One frame into one tile held in registers (8 voxels per lane).  The kernel is VALU-issue bound once a batch
-// amortises the HBM traffic (SQ_ACTIVE_INST_VALU ~ 100 %, profiles/), so the update is written for instruction count:
+// One frame into one tile held in registers (8 voxels per lane).  Once a batch amortises the HBM traffic the kernel sits on its instruction mix
+// (SQ_INSTS_VALU x 2 clk / SIMD clk = 0.57 of the guide's issue peak, the texture addresser busy 0.56 of the time, HBM at 9 %: bench.py `roofline`,
+// profiles/r06_integrate_xrow_ab.txt), so the update is written for instruction count:
 //   * two straight-line phases: phase A projects all eight voxels and issues the eight depth gathers together at
 //     clamped addresses, phase B applies the update under a select (a per-voxel early-out chain serialises eight
 //     L2 round trips and costs a scalar branch pair per test);
-//   * the two x-adjacent voxels of a lane go through packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32:
-//     two IEEE operations per issue slot);
+//   * the lane's voxel pairs are written as v2f pairs (fuser_internal.h) and compiled as two plain fp32 operations each: on gfx950 a v_pk_*_f32 holds the
+//     SIMD as long as two plain ones and issues beside nothing (rounds 1-4 shipped the packed form; -DSF_PACKED_PAIRS still builds it);
 //   * the two IEEE divisions of DESIGN.md 3.5 are expanded by hand.  1/pcz: v_rcp_f32 seed + two Newton steps --
 //     the arithmetic core of the compiler's own correctly rounded expansion without the div_scale / div_fixup
 //     range handling (pcz is a camera-space depth in metres; exhaustive check over all mantissas and seed errors up

@@ -443,7 +443,7 @@ static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t e
       while (i < n) {
         const uint8_t* ff = static_cast<const uint8_t*>(std::memchr(data + i, 0xFF, (size_t)(n - i)));
         const uint64_t run = ff ? (uint64_t)(ff - (data + i)) : n - i;
-        if (w + run + 17 > cap) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: the entropy-coded segment does not fit the payload");
+        if (w + run + 25 > cap) return sf::fail(SF_ERR_UNSUPPORTED, "jpeg: the entropy-coded segment does not fit the payload");
         std::memcpy(ecs + w, data + i, (size_t)run);
         w += run;
         i += run;
@@ -453,7 +453,7 @@ static int decode_impl(const uint8_t* data, uint64_t n, uint8_t* dst, uint32_t e
       }
       D->ecs_bytes = (uint32_t)w;
       while (w & 3) ecs[w++] = 0;
-      for (int i = 0; i < 8; i++) ecs[w++] = 0;
+      for (int i = 0; i < 16; i++) ecs[w++] = 0;   // the lanes fetch four words at a time (jpeg_huff.h jh_fill): the last fill stays inside
       D->ecs_words = (uint32_t)(w / 4);
       return SF_OK;
     }

@@ -65,20 +65,21 @@ struct JHCounts {
   uint32_t bad;   // an invalid code was met (counts only on the true path)
 };
 
-// 32 bits of the segment starting at bit p (words are the file's bytes in order: big-endian bit numbering)
+// 32 bits of the segment starting at bit p (words are the file's bytes in order: big-endian bit numbering), out of a lane's buffer of FOUR words.
+// The buffer is refilled by every lane at once, every third symbol, wherever the lane stands: a symbol takes at most 16 + 15 bits, so from a bit
+// offset below 32 three symbols look no further than bit 93 + 32 of the 128 (the segment is padded with 16 zero bytes for the last fill:
+// jpeg_prepare_huff).  Round 5 kept two words per lane and reloaded when the position crossed into another word -- one lane in six per symbol, so nearly
+// every symbol step of a WAVE ran the reload path and waited for its load; now one 16-byte load per lane and three symbols, the same for all lanes.
 JH_HD uint32_t jh_be32(uint32_t w) { return (w >> 24) | ((w >> 8) & 0xFF00u) | ((w << 8) & 0xFF0000u) | (w << 24); }
-// the two words around the current bit, reloaded only when the position crosses into another word (a symbol is ~5 bits: one load per ~6 symbols)
-struct JHWindow {
-  uint32_t wi, d0, d1;
-};
-JH_HD uint32_t jh_peek32(const uint32_t* words, uint32_t nwords, uint32_t p, JHWindow& win) {
-  const uint32_t w = p >> 5, s = p & 31u;
-  if (w != win.wi) {
-    win.d0 = (w == win.wi + 1u) ? win.d1 : (w < nwords ? jh_be32(words[w]) : 0u);
-    win.d1 = w + 1 < nwords ? jh_be32(words[w + 1]) : 0u;
-    win.wi = w;
-  }
-  return s ? (win.d0 << s) | (win.d1 >> (32u - s)) : win.d0;
+// four words of the segment from word w on, byte-swapped
+JH_HD void jh_fill(const uint32_t* words, uint32_t w, uint32_t& d0, uint32_t& d1, uint32_t& d2, uint32_t& d3) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef uint32_t jh_u32x4 __attribute__((ext_vector_type(4), aligned(4)));   // ONE global_load_dwordx4 at a 4-byte aligned address
+  const jh_u32x4 v = *reinterpret_cast<const jh_u32x4*>(words + w);
+  d0 = jh_be32(v.x); d1 = jh_be32(v.y); d2 = jh_be32(v.z); d3 = jh_be32(v.w);
+#else
+  d0 = jh_be32(words[w]); d1 = jh_be32(words[w + 1]); d2 = jh_be32(words[w + 2]); d3 = jh_be32(words[w + 3]);
+#endif
 }
 // one Huffman symbol from the 32 bits `w`: its value, code length in len; -1 = no such code
 JH_HD int jh_symbol(const SfJpegHuffTable& t, uint32_t w, int& len) {
@@ -103,51 +104,48 @@ JH_HD int jh_zigzag(int k) {
 }
 
 // Decode from state s while symbols START before `limit` (and inside the segment).  E receives what stage C writes:
-//   E.dc(component, difference) -> called at every DC symbol; E.ac(zig-zag index, value); E.block_done(component, bi, entries of the block)
-// and returns false to stop (the picture is complete).  Stage A passes an E that does nothing.
+//   E.entry(is_dc, component, zig-zag index, value) -> at every DC symbol (value = the DC difference) and every non-zero AC coefficient;
+//   E.block_done(component, bi, entries of the block) returns false to stop (the picture is complete).  Stage A passes an E that does nothing.
+// A DC and an AC symbol go down ONE path (the table is a select, the rest arithmetic on the same registers): the lanes of a wave sit at different
+// coefficient indices, and with a branch per kind every symbol step of the wave ran both.
 template <class Emit>
 JH_HD JHState jh_run(const SfJpegHuffGeom& D, const SfJpegHuffTable* dc, const SfJpegHuffTable* ac, const uint32_t* words, JHState s, uint32_t limit, JHCounts& n, Emit& E) {
   const uint32_t nbits = D.ecs_bytes * 8u;
   n.blocks = n.entries = 0;
   n.dc_sum[0] = n.dc_sum[1] = n.dc_sum[2] = 0;
   n.bad = 0;
-  JHWindow win{0xFFFFFFF0u, 0u, 0u};
+  uint32_t wb = 0u, d0 = 0u, d1 = 0u, d2 = 0u, d3 = 0u;   // the lane's window: words wb .. wb + 3 (plain registers: a struct handed about by reference ended up in LDS)
+  uint32_t until_fill = 0u;
   while (s.p < limit && s.p < nbits) {
+    if (until_fill == 0u) { wb = s.p >> 5; jh_fill(words, wb, d0, d1, d2, d3); until_fill = 3u; }
+    until_fill--;
     const int ci = D.comp_of[s.bi];
-    const uint32_t w = jh_peek32(words, D.ecs_words, s.p, win);
-    int len;
-    if (s.k == 0) {
-      const int t = jh_symbol(dc[ci], w, len);
-      if (t < 0 || t > 11) { n.bad = 1; s.p += 1; continue; }   // invalid under this state: slip a bit and keep going (a guess; an error on the true path)
-      const int diff = t ? jh_extend((int)((w << len) >> (32 - t)), t) : 0;
-      s.p += (uint32_t)(len + t);
-      s.k = 1;
-      s.open = 1;
-      n.entries++;
-      n.dc_sum[0] += ci == 0 ? diff : 0;   // three registers and selects: an array indexed by the component lives in private memory on the device
-      n.dc_sum[1] += ci == 1 ? diff : 0;
-      n.dc_sum[2] += ci == 2 ? diff : 0;
-      E.dc(ci, diff);
-    } else {
-      const int rs = jh_symbol(ac[ci], w, len);
-      if (rs < 0) { n.bad = 1; s.p += 1; continue; }
-      const int run = rs >> 4, size = rs & 15;
-      s.p += (uint32_t)(len + size);
-      if (size == 0) {
-        if (run == 15) s.k = (uint16_t)(s.k + 16);
-        else s.k = 64;   // end of block
-      } else {
-        const int k = s.k + run;
-        if (k > 63) { n.bad = 1; s.k = 64; }
-        else {
-          E.ac(k, jh_extend((int)((w << len) >> (32 - size)), size));
-          s.open++;
-          n.entries++;
-          s.k = (uint16_t)(k + 1);
-        }
-      }
-      if (s.k > 64) s.k = 64;   // sixteen zeros past the end of the block end it (as the host decoder's loop does)
+    uint32_t w;
+    {
+      const uint32_t i = (s.p >> 5) - wb, sh = s.p & 31u;   // i <= 2 on this schedule
+      const uint32_t lo = i == 0u ? d0 : (i == 1u ? d1 : d2), hi = i == 0u ? d1 : (i == 1u ? d2 : d3);
+      w = (uint32_t)(((((uint64_t)lo << 32) | (uint64_t)hi) << sh) >> 32);
     }
+    const bool isdc = s.k == 0;
+    int len;
+    const int rs = jh_symbol(isdc ? dc[ci] : ac[ci], w, len);
+    if (rs < 0 || (isdc && rs > 11)) { n.bad = 1; s.p += 1; continue; }   // invalid under this state: slip a bit and keep going (a guess; an error on the true path)
+    const int run = isdc ? 0 : rs >> 4, size = isdc ? rs : rs & 15;
+    const int val = size ? jh_extend((int)(((w << len) >> 1) >> (31 - size)), size) : 0;   // len + size <= 31
+    s.p += (uint32_t)(len + size);
+    const int k = (int)s.k + run;
+    const bool over = !isdc && size != 0 && k > 63;                 // a run past the end of the block
+    const bool emit = isdc || (size != 0 && k <= 63);
+    if (over) n.bad = 1;
+    int knew = isdc ? 1 : (size == 0 ? (run == 15 ? (int)s.k + 16 : 64) : (k > 63 ? 64 : k + 1));
+    if (knew > 64) knew = 64;   // sixteen zeros past the end of the block end it (as the host decoder's loop does)
+    s.k = (uint16_t)knew;
+    s.open = isdc ? 1u : s.open + (emit ? 1u : 0u);
+    n.entries += emit ? 1u : 0u;
+    n.dc_sum[0] += (isdc && ci == 0) ? val : 0;   // three registers and selects: an array indexed by the component lives in private memory on the device
+    n.dc_sum[1] += (isdc && ci == 1) ? val : 0;
+    n.dc_sum[2] += (isdc && ci == 2) ? val : 0;
+    if (emit) E.entry(isdc, ci, k, val);
     if (s.k >= 64) {
       n.blocks++;
       const bool more = E.block_done(ci, s.bi, s.open);
@@ -161,8 +159,7 @@ JH_HD JHState jh_run(const SfJpegHuffGeom& D, const SfJpegHuffTable* dc, const S
 }
 
 struct JHNoEmit {
-  JH_HD void dc(int, int) {}
-  JH_HD void ac(int, int) {}
+  JH_HD void entry(bool, int, int, int) {}
   JH_HD bool block_done(int, int, uint32_t) { return true; }
 };
 

@@ -62,14 +62,13 @@ struct DeviceWriter {
   uint32_t ordinal, e;
   int pred0, pred1, pred2;   // the DC predictors, one register each (as an array indexed by the component they were 12 of the kernel's 72 bytes of private memory)
   const uint8_t* zz;         // the zig-zag table in LDS (jh_zigzag's own table is a constant in global memory: a load per coefficient)
-  __device__ void dc(int ci, int diff) {
-    pred0 += ci == 0 ? diff : 0;
-    pred1 += ci == 1 ? diff : 0;
-    pred2 += ci == 2 ? diff : 0;
+  __device__ void entry(bool isdc, int ci, int k, int v) {   // a DC entry carries the value itself: predictor + difference, at position 0
+    pred0 += (isdc && ci == 0) ? v : 0;
+    pred1 += (isdc && ci == 1) ? v : 0;
+    pred2 += (isdc && ci == 2) ? v : 0;
     const int p = ci == 0 ? pred0 : (ci == 1 ? pred1 : pred2);
-    entries[e++] = (uint32_t)(uint16_t)(int16_t)p;
+    entries[e++] = isdc ? (uint32_t)(uint16_t)(int16_t)p : ((uint32_t)zz[k & 63] << 16) | (uint32_t)(uint16_t)(int16_t)v;
   }
-  __device__ void ac(int k, int v) { entries[e++] = ((uint32_t)zz[k & 63] << 16) | (uint32_t)(uint16_t)(int16_t)v; }
   __device__ bool block_done(int, int bi, uint32_t cnt) {
     if (ordinal >= G.total_blocks) return false;
     table[jh_block_index(L, G, ordinal, bi)] = ((e - cnt) << 7) | cnt;

@@ -21,8 +21,10 @@ struct Writer {
   uint32_t* entries;
   uint32_t ordinal, e;   // next block ordinal, next entry index
   int pred[3];
-  void dc(int ci, int diff) { pred[ci] += diff; entries[e++] = (uint32_t)(uint16_t)(int16_t)pred[ci]; }
-  void ac(int k, int v) { entries[e++] = ((uint32_t)jh_zigzag(k) << 16) | (uint32_t)(uint16_t)(int16_t)v; }
+  void entry(bool isdc, int ci, int k, int v) {
+    if (isdc) { pred[ci] += v; entries[e++] = (uint32_t)(uint16_t)(int16_t)pred[ci]; }
+    else entries[e++] = ((uint32_t)jh_zigzag(k) << 16) | (uint32_t)(uint16_t)(int16_t)v;
+  }
   bool block_done(int, int bi, uint32_t cnt) {
     if (ordinal >= D.total_blocks) return false;
     table[jh_block_index(L, D, ordinal, bi)] = ((e - cnt) << 7) | cnt;
