@@ -220,6 +220,9 @@ typedef struct sf_run_stats {
 } sf_run_stats;
 struct sf_sens;
 int sf_fuse_run(sf_fuser* f, const struct sf_sens* s, uint64_t first, uint64_t last, int decode_threads, sf_run_stats* stats);
+/* A hint about the calling thread's most recent successful sf_fuse_run that is NOT an error ("" when there is none): today, that the run drove more streams than
+ * the process has hardware queues (GPU_MAX_HW_QUEUES, read by the HIP runtime at its first call: INTEGRATION.md section 4).  sf_last_error() stays empty on success. */
+const char* sf_fuse_run_note(void);
 /* Optional, for a process that fuses ONE scan (the pipeline's contract: one `DepthSensing.exe` per scan, Server/scan_processor.py:138): with the file open
  * and BEFORE sf_fuser_create, start making what sf_fuse_run will want for THIS file -- its side streams (a hardware queue each: ~5 ms), the page-locked ring,
  * the device ring, one pass of copies over both -- on a thread of its own, beside sf_fuser_create's own gigabytes of allocation.  A JPEG-colour scan wants

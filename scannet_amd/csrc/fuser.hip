@@ -2249,12 +2249,9 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
     return sf::fail(SF_ERR_DEVICE, "no HIP device: libscanfuse has no CPU fallback, the fuser needs an MI355X");
   if (device < 0 || device >= ndev) return sf::fail(SF_ERR_INVALID_ARG, "device %d out of range (%d devices)", device, ndev);
   SF_HIP_CHECK(hipSetDevice(device));
-  // the first fuser of the process on this device: sf_fuse_run's side streams and a pinned ring for six batches of compressed depth frames (3/4 of
-  // their pixels' bytes) get made on a thread of their own while this function reserves and clears the volume (pipeline.hip)
-  {
-    const size_t frame_b = (size_t)p->depth_width * p->depth_height * 2, packed = MAX_BATCH * (frame_b * 3 / 4 + 4096);   // a batch of compressed frames
-    sf_run_resources_prepare(device, 6 * packed, 6 * (MAX_BATCH * frame_b + packed + 1024), 2 * frame_b * MAX_BATCH);
-  }
+  // (until round 6 the first fuser of a process started sf_fuse_run's side streams and rings on a background thread here -- 90 MB pinned and
+  // 330 MB of device memory also for callers that never run a file.  A caller that will -- bin/depthsensing, bench.py, tools/e2e_bench.py -- asks with
+  // sf_fuse_run_prepare(file, params, device) before this call; without it the first sf_fuse_run makes its set itself.)
   sf_fuser* f = new sf_fuser();
   // every failure below leaves through sf_fuser_destroy (streams, events, device and pinned allocations made so far)
 #define SF_CREATE_CHECK(call)                                                                               \

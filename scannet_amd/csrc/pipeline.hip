@@ -69,6 +69,7 @@ hipError_t create_side_stream(hipStream_t* out) {
 }
 
 thread_local uint64_t t_run_counts[4] = {0, 0, 0, 0};   // of this thread's last sf_fuse_run: depth frames inflated on the device / by the host threads, colour
+thread_local char t_run_note[320] = "";   // sf_fuse_run_note(): a hint about the calling thread's last run that is not an error
                                                         // frames entropy-decoded on the device / by the host threads (sf_fuse_run_device_counts)
 
 int hardware_queues_of_the_process() {   // what the runtime was (or will be) told; its default is 4
@@ -849,9 +850,10 @@ SF_API int sf_fuse_run(sf_fuser* f, const sf_sens* s, uint64_t first, uint64_t l
   if (qe != hipSuccess) return sf::fail(SF_ERR_DEVICE, "device error while fusing: %s", hipGetErrorString(qe));
   {   // a note, not an error: the run used more streams than the process has hardware queues (see the top of this file)
     const int streams_used = 2 + (copy_stream ? 2 : 0) + (gpu_inflate ? NZ : 0), queues = hardware_queues_of_the_process();
-    if (streams_used > queues)
-      (void)sf::fail(SF_OK, "note: sf_fuse_run drove %d streams over %d hardware queues (kernels of streams that share a queue run one after the other); "
-                             "export GPU_MAX_HW_QUEUES=16 before the process's first HIP call", streams_used, queues);
+    t_run_note[0] = 0;
+    if (streams_used > queues)   // through sf_fuse_run_note(), not sf_last_error(): a caller that reads a non-empty last error as a failure must not
+      std::snprintf(t_run_note, sizeof(t_run_note), "sf_fuse_run drove %d streams over %d hardware queues (kernels of streams that share a queue run one after the other); "
+                    "export GPU_MAX_HW_QUEUES=16 before the process's first HIP call", streams_used, queues);
   }
   if (stats) {
     stats->frames_total = total;
@@ -907,6 +909,8 @@ SF_API int sf_fuse_run_prepare(const sf_sens* s, const sf_params* p, int device)
 
 // scanfuse_internal.h: where the frames of this thread's last sf_fuse_run were decoded -- out[0] depth frames inflated on the device, out[1] zlib
 // depth frames inflated by the host threads, out[2] JPEG colour frames entropy-decoded on the device, out[3] by the host threads.
+SF_API const char* sf_fuse_run_note(void) { return t_run_note; }
+
 SF_API int sf_fuse_run_device_counts(uint64_t out[4]) {
   if (!out) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
   for (int i = 0; i < 4; i++) out[i] = t_run_counts[i];
