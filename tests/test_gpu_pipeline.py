@@ -721,6 +721,66 @@ def test_fuse_run_with_colour_matches_frame_by_frame(tmp_path, kind, monkeypatch
         assert len(ca) > 500
 
 
+@pytest.mark.parametrize("res", ["own", "same"])
+@pytest.mark.parametrize("layout", ["420", "444", "grey"])
+def test_fuse_run_converts_the_looked_up_pixels_from_the_jpeg_planes(tmp_path, res, layout, monkeypatch):
+    """Round 6: when every colour frame of a batch is a picture the device reconstructs, sf_fuse_run stops at the component planes (k_jpeg_idct) and the fuser's
+    pre-pass upsamples and converts the ONE pixel per depth pixel it looks up (k_prepass, YccPicture) -- no RGB image per picture.  A scan whose pictures all share
+    one layout (4:2:0 with the triangle filters, 4:4:4, grey), colour at its own resolution (the look-up under the depth pixel's ray, odd sizes) or at the depth
+    resolution, a frame count and an image size that leave partial batches and partial workgroups: the same voxels, colours included, as integrating the
+    host-decoded frames one by one, and as the run that writes the RGB images out (SF_JPEG_RGB_IMAGE=1)."""
+    import io
+    from PIL import Image
+    from scannet_amd import fusion, sens
+    W, H = 160, 120
+    CW, CH = (323, 241) if res == "own" else (W, H)
+    n = 45
+    K = synth.intrinsic_matrix(W, H)
+    fx, fy, mx, my = synth.intrinsics(W, H)
+    KC = np.eye(4, dtype=np.float32)
+    if res == "own":
+        KC[0, 0], KC[1, 1], KC[0, 2], KC[1, 2] = 340.3, 338.1, 160.2, 119.7
+    else:
+        KC[:] = K
+    sd = sens.SensorData.create(CW, CH, W, H, KC, K, color_compression=2, depth_compression=1)
+    frames = []
+    for i in range(n):
+        pose = synth.trajectory_pose(i * 7, 1200)
+        d = synth.render_room_depth(pose, W, H, noise_frame=i)
+        img = _smooth_image(CW, CH, i)
+        buf = io.BytesIO()
+        if layout == "grey":
+            Image.fromarray(img[..., 1]).save(buf, format="JPEG", quality=88)
+        else:
+            Image.fromarray(img).save(buf, format="JPEG", quality=88, subsampling=2 if layout == "420" else 0)
+        sd.add_frame(d, pose, color=buf.getvalue(), timestamp_depth=i)
+        frames.append((d, pose))
+    p = str(tmp_path / "y.sens")
+    sd.save(p)
+    sd.close()
+    gp = fusion.default_params(depth_width=W, depth_height=H, fx=fx, fy=fy, mx=mx, my=my, voxel_size=0.016, num_sdf_blocks=1 << 16)
+    if res == "own":
+        gp.color_width, gp.color_height, gp.cfx, gp.cfy, gp.cmx, gp.cmy = CW, CH, 340.3, 338.1, 160.2, 119.7
+    s = sens.SensorData(p)
+    with fusion.Fuser(gp) as a, fusion.Fuser(gp) as b, fusion.Fuser(gp) as c:
+        rs = a.run(s, decode_threads=3)
+        assert rs["frames_total"] == n and rs["color_fused"] == 1 and rs["jpeg_entropy_on_device"] == n, rs
+        monkeypatch.setenv("SF_JPEG_RGB_IMAGE", "1")
+        rc = c.run(s, decode_threads=3)
+        monkeypatch.delenv("SF_JPEG_RGB_IMAGE")
+        assert rc["jpeg_entropy_on_device"] == n
+        for i, (d, pose) in enumerate(frames):
+            assert b.integrate(d, pose, rgb=s.frames[i].decompress_color())
+        ca, va = a.export_blocks()
+        cb, vb = b.export_blocks()
+        cc, vc = c.export_blocks()
+        oa, ob, oc = np.lexsort(ca.T[::-1]), np.lexsort(cb.T[::-1]), np.lexsort(cc.T[::-1])
+        assert np.array_equal(ca[oa], cb[ob]) and np.array_equal(ca[oa], cc[oc])
+        assert np.array_equal(va[oa], vb[ob]), "voxels (sdf, weight, colour) differ from the host-decoded frames'"
+        assert np.array_equal(va[oa], vc[oc]), "voxels differ from the RGB-image run's"
+        assert len(ca) > 500 and (va["r"] > 0).any()
+
+
 def test_shard_main_runs_the_whole_chain(tmp_path, capsys, monkeypatch):
     """python -m scannet_amd.shard on two small scans (one process, no process group): the GPU part of the second scan runs while host
     threads clean, decimate (twice) and segment the first; every output file of the reference's improve / decimate / segment stages."""
