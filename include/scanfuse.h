@@ -624,6 +624,10 @@ int sf_mesh_clean_script(const sf_mesh* in, sf_clean_script* script, sf_mesh** o
  * ---------------------------------------------------------------------------------------------- */
 int sf_segment_mesh(const float* xyz, uint64_t num_vertices, const uint32_t* tris, uint64_t num_faces, float kThresh,
                     int segMinVerts, int32_t* segIndices_out);
+/* The same labels with the two data-parallel stages -- vertex normals (a lane per vertex walks its faces in face order: the running mean's order is the
+ * reference's) and edge weights -- on GPU `device` (csrc/segment_gpu.hip); the sort and the sweeps stay on the host.  Fails without a device. */
+int sf_segment_mesh_gpu(const float* xyz, uint64_t num_vertices, const uint32_t* tris, uint64_t num_faces, float kThresh,
+                        int segMinVerts, int device, int32_t* segIndices_out);
 /* Reads mesh_path (.ply/.obj), segments, writes the JSON.  out_json NULL => reference naming:
  * <mesh minus extension>.<std::to_string(kThresh)>.segs.json (segmentator.cpp:282-286).  Prints nothing. */
 int sf_segment_file(const char* mesh_path, float kThresh, int segMinVerts, const char* out_json, uint64_t* num_segments);
@@ -631,6 +635,9 @@ int sf_segment_file(const char* mesh_path, float kThresh, int segMinVerts, const
  * faces.size()}, the path written, and whether an .obj held more than one shape (only the first is used, :166-169). */
 int sf_segment_file_ex(const char* mesh_path, float kThresh, int segMinVerts, const char* out_json, uint64_t* num_segments,
                        uint64_t* counts4, char* out_path, uint64_t out_path_cap, int* obj_multi);
+/* sf_segment_file_ex with sf_segment_mesh_gpu inside (`bin/segmentator ... --gpu [device]`, not a flag of the reference's): the same JSON. */
+int sf_segment_file_gpu(const char* mesh_path, float kThresh, int segMinVerts, const char* out_json, uint64_t* num_segments,
+                        uint64_t* counts4, char* out_path, uint64_t out_path_cap, int* obj_multi, int device);
 
 
 

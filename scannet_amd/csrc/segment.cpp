@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <new>
 #include <sstream>
 #include <string>
 #include <thread>
@@ -113,7 +114,12 @@ void in_parallel(size_t n, size_t grain, Fn fn) {
   for (std::thread& th : team) th.join();
 }
 
-void segment_core(const float* xyz, size_t nv, const uint32_t* tri, size_t nf, float kthr, int min_verts, int32_t* out) {
+// keys_in: the 3 F weight keys already made (segment_gpu.hip: normals and weights on the GPU), or nullptr: made here
+void segment_core(const float* xyz, size_t nv, const uint32_t* tri, size_t nf, float kthr, int min_verts, int32_t* out, std::vector<WeightKey>* keys_in = nullptr) {
+  const size_t ne = nf * 3;
+  std::vector<WeightKey> keys_own;
+  std::vector<WeightKey>& keys = keys_in ? *keys_in : keys_own;
+  if (!keys_in) {
   // ---- vertex normals: running mean of the unit face normals in face order (:185-208).  Per face: the unit normal (cross product divided
   // by its length: a zero-area face gives NaN, :107-112), then for each corner n <- t * fn + (1 - t) * n with t = 1 / (faces seen so far + 1)
   // (:113-116; the counts move only after all three corners, :205-207 -- a face that names a vertex twice blends it twice with the same t).
@@ -138,8 +144,7 @@ void segment_core(const float* xyz, size_t nv, const uint32_t* tri, size_t nf, f
     vn[t[0]].faces++; vn[t[1]].faces++; vn[t[2]].faces++;
   }
   // ---- edge weights (:211-229): 1 - n_u . n_v, squared where the edge is convex (n_v leans along u -> v).  Independent per edge.
-  const size_t ne = nf * 3;
-  std::vector<WeightKey> keys(ne);
+  keys.resize(ne);
   in_parallel(ne, 1 << 16, [&](size_t lo, size_t hi) {
     for (size_t e = lo; e < hi; e++) {
       const EdgeEnds ends = edge_ends(tri, (uint32_t)e);
@@ -156,6 +161,7 @@ void segment_core(const float* xyz, size_t nv, const uint32_t* tri, size_t nf, f
       keys[e] = WeightKey{w, (uint32_t)e};
     }
   });
+  }   // !keys_in
   // ---- the reference's sort call on the reference's comparator (:74); see "Layout" for why the keys may be smaller than its records
   std::sort(keys.begin(), keys.end());
   std::vector<EdgeEnds> sorted_ends(ne);
@@ -207,6 +213,27 @@ SF_API int sf_segment_mesh(const float* xyz, uint64_t nv, const uint32_t* tris, 
   return SF_OK;
 }
 
+int segment_weight_keys_gpu(const float* xyz, size_t nv, const uint32_t* tri, size_t nf, int device, void* keys_out);   // segment_gpu.hip
+
+// The same labels with the vertex normals and the edge weights computed on GPU `device` (segment_gpu.hip: a lane per vertex walks its faces in face order, a
+// lane per edge): the weight keys are the host's bit for bit, the sort and the sweeps are the host's.  No fallback: without a device the call fails.
+SF_API int sf_segment_mesh_gpu(const float* xyz, uint64_t nv, const uint32_t* tris, uint64_t nf, float kThresh, int segMinVerts, int device, int32_t* out) {
+  if ((!xyz && nv) || (!tris && nf) || (!out && nv)) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  if (nv > 0x7FFFFFFFull || nf * 3 > 0x7FFFFFFFull) return sf::fail(SF_ERR_INVALID_ARG, "mesh too large for 32-bit vertex / edge indices");
+  for (uint64_t i = 0; i < nf * 3; i++)
+    if (tris[i] >= nv) return sf::fail(SF_ERR_BOUNDS, "face index %u out of range (%llu vertices)", tris[i], (unsigned long long)nv);
+  try {
+    std::vector<WeightKey> keys((size_t)nf * 3);
+    static_assert(sizeof(WeightKey) == 8, "the device writes {float weight, uint32 edge} records");
+    const int rc = segment_weight_keys_gpu(xyz, (size_t)nv, tris, (size_t)nf, device, keys.data());
+    if (rc != SF_OK) return rc;
+    segment_core(xyz, (size_t)nv, tris, (size_t)nf, kThresh, segMinVerts, out, &keys);
+  } catch (const std::bad_alloc&) {
+    return sf::fail(SF_ERR_IO, "sf_segment_mesh_gpu: out of memory");
+  }
+  return SF_OK;
+}
+
 // JSON surface, segmentator.cpp:253-266: no whitespace, kThresh through ostream<<float, ints as decimal
 static int write_segs_json(const std::string& file, const std::string& scene, float kthr, int min_verts, const std::vector<int32_t>& seg) {
   std::string body;
@@ -233,9 +260,9 @@ static int write_segs_json(const std::string& file, const std::string& scene, fl
 }
 
 // shared with the drop-in CLI (tool_segmentator.cpp) through the C ABI below
-SF_API int sf_segment_file_ex(const char* mesh_path, float kThresh, int segMinVerts, const char* out_json, uint64_t* num_segments,
-                              uint64_t* counts4 /* vertexCount, verts.size, faceCount, faces.size */, char* out_path, uint64_t out_path_cap,
-                              int* obj_multi) {
+static int segment_file(const char* mesh_path, float kThresh, int segMinVerts, const char* out_json, uint64_t* num_segments,
+                        uint64_t* counts4 /* vertexCount, verts.size, faceCount, faces.size */, char* out_path, uint64_t out_path_cap,
+                        int* obj_multi, int device /* < 0: the host path */) {
   if (!mesh_path) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
   sf_mesh m;
   bool multi = false;
@@ -245,7 +272,8 @@ SF_API int sf_segment_file_ex(const char* mesh_path, float kThresh, int segMinVe
   const uint64_t nv = m.pos.size() / 3, nf = m.tri.size() / 3;
   if (counts4) { counts4[0] = nv; counts4[1] = m.pos.size(); counts4[2] = nf; counts4[3] = m.tri.size(); }
   std::vector<int32_t> seg(nv);
-  rc = sf_segment_mesh(m.pos.data(), nv, m.tri.data(), nf, kThresh, segMinVerts, seg.data());
+  rc = device < 0 ? sf_segment_mesh(m.pos.data(), nv, m.tri.data(), nf, kThresh, segMinVerts, seg.data())
+                  : sf_segment_mesh_gpu(m.pos.data(), nv, m.tri.data(), nf, kThresh, segMinVerts, device, seg.data());
   if (rc != SF_OK) return rc;
   if (num_segments) {
     std::unordered_set<int32_t> ids(seg.begin(), seg.end());
@@ -259,6 +287,17 @@ SF_API int sf_segment_file_ex(const char* mesh_path, float kThresh, int segMinVe
   const std::string file = out_json ? std::string(out_json) : base + "." + std::to_string(kThresh) + ".segs.json";
   if (out_path && out_path_cap) { std::strncpy(out_path, file.c_str(), (size_t)out_path_cap - 1); out_path[out_path_cap - 1] = 0; }
   return write_segs_json(file, scene, kThresh, segMinVerts, seg);
+}
+
+SF_API int sf_segment_file_ex(const char* mesh_path, float kThresh, int segMinVerts, const char* out_json, uint64_t* num_segments,
+                              uint64_t* counts4, char* out_path, uint64_t out_path_cap, int* obj_multi) {
+  return segment_file(mesh_path, kThresh, segMinVerts, out_json, num_segments, counts4, out_path, out_path_cap, obj_multi, -1);
+}
+// ... with the normals and the edge weights on GPU `device` (sf_segment_mesh_gpu): the same file
+SF_API int sf_segment_file_gpu(const char* mesh_path, float kThresh, int segMinVerts, const char* out_json, uint64_t* num_segments,
+                               uint64_t* counts4, char* out_path, uint64_t out_path_cap, int* obj_multi, int device) {
+  if (device < 0) return sf::fail(SF_ERR_INVALID_ARG, "sf_segment_file_gpu: device %d", device);
+  return segment_file(mesh_path, kThresh, segMinVerts, out_json, num_segments, counts4, out_path, out_path_cap, obj_multi, device);
 }
 
 SF_API int sf_segment_file(const char* mesh_path, float kThresh, int segMinVerts, const char* out_json, uint64_t* num_segments) {

@@ -5,6 +5,7 @@
 // Server/util.py:42-44).  A thin host over libscanfuse.so's C ABI.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "scanfuse.h"
 
@@ -15,6 +16,14 @@ int main(int argc, const char** argv) {
     std::printf("Usage: ./segmentator input.ply [kThresh] [segMinVerts] (defaults: kThresh=0.01 segMinVerts=20)\n");
     return 255;  // the reference calls exit(-1)
   }
+  // `--gpu [device]` behind the reference's arguments (not a flag of the reference's): vertex normals and edge weights on that GPU, the same file
+  int device = -1;
+  for (int i = 2; i < argc; i++)
+    if (std::strcmp(argv[i], "--gpu") == 0) {
+      device = (i + 1 < argc && argv[i + 1][0] >= '0' && argv[i + 1][0] <= '9') ? std::atoi(argv[i + 1]) : 0;
+      argc = i;
+      break;
+    }
   const char* mesh = argv[1];
   const float kthr = argc > 2 ? (float)std::atof(argv[2]) : 0.01f;
   const int min_verts = argc > 3 ? std::atoi(argv[3]) : 20;
@@ -22,7 +31,8 @@ int main(int argc, const char** argv) {
   uint64_t nseg = 0, counts[4] = {0, 0, 0, 0};
   char out[4096];
   int multi = 0;
-  const int rc = sf_segment_file_ex(mesh, kthr, min_verts, nullptr, &nseg, counts, out, sizeof(out), &multi);
+  const int rc = device < 0 ? sf_segment_file_ex(mesh, kthr, min_verts, nullptr, &nseg, counts, out, sizeof(out), &multi)
+                            : sf_segment_file_gpu(mesh, kthr, min_verts, nullptr, &nseg, counts, out, sizeof(out), &multi, device);
   if (rc != SF_OK) {
     std::fprintf(stderr, "%s\n", sf_last_error());
     return 1;

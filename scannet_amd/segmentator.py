@@ -101,11 +101,17 @@ class Mesh:
             pass
 
 
-def segment_arrays(xyz, tris, kthr=0.01, seg_min_verts=20):
+def segment_arrays(xyz, tris, kthr=0.01, seg_min_verts=20, device=None):
+    """device: None = the host path (sf_segment_mesh); an int = vertex normals and edge weights on that GPU (sf_segment_mesh_gpu: the same labels)."""
     xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
     tris = np.ascontiguousarray(tris, np.uint32).reshape(-1, 3)
     out = np.zeros(len(xyz), np.int32)
-    check(_abi.lib().sf_segment_mesh(_ptr(xyz), len(xyz), _ptr(tris), len(tris), float(kthr), int(seg_min_verts), _ptr(out)))
+    if device is None:
+        check(_abi.lib().sf_segment_mesh(_ptr(xyz), len(xyz), _ptr(tris), len(tris), float(kthr), int(seg_min_verts), _ptr(out)))
+    else:
+        L = _abi.lib()
+        L.sf_segment_mesh_gpu.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_float, C.c_int, C.c_int, C.c_void_p]
+        check(L.sf_segment_mesh_gpu(_ptr(xyz), len(xyz), _ptr(tris), len(tris), float(kthr), int(seg_min_verts), int(device), _ptr(out)))
     return out
 
 
