@@ -94,6 +94,30 @@ JH_HD int jh_symbol(const SfJpegHuffTable& t, uint32_t w, int& len) {
   len = l;
   return t.vals[(t.valptr[l] + code - t.mincode[l]) & 255];
 }
+// The same through a 12-bit first-level table (what the device keeps in LDS, built there from the canonical ranges): with 9 bits one symbol in twenty of a
+// photo-like picture took the ladder above, so nearly every symbol step of a WAVE did, up to seven rounds of it; with 12 bits it is one in hundreds.
+constexpr int JH_LOOK12 = 4096;
+JH_HD uint16_t jh_look12_entry(const SfJpegHuffTable& t, uint32_t idx) {   // idx = the next 12 bits
+  int l = 1, code = (int)(idx >> 11);
+  while (l < 13 && code > t.maxcode[l]) {
+    l++;
+    code = (int)(idx >> (12 - l));
+  }
+  if (l > 12) return 0;
+  return (uint16_t)((l << 8) | t.vals[(t.valptr[l] + code - t.mincode[l]) & 255]);
+}
+JH_HD int jh_symbol12(const SfJpegHuffTable& t, const uint16_t* look12, uint32_t w, int& len) {
+  const uint16_t e = look12[w >> 20];
+  if (e) { len = e >> 8; return e & 0xFF; }
+  int l = 12, code = (int)(w >> 20);
+  while (l < 17 && code > t.maxcode[l]) {
+    l++;
+    code = (int)(w >> (32 - l));
+  }
+  if (l > 16) { len = 1; return -1; }
+  len = l;
+  return t.vals[(t.valptr[l] + code - t.mincode[l]) & 255];
+}
 JH_HD int jh_extend(int v, int t) { return v < (1 << (t - 1)) ? v - (1 << t) + 1 : v; }
 
 // natural-order position of zig-zag index k (T.81 figure A.6)
@@ -109,7 +133,8 @@ JH_HD int jh_zigzag(int k) {
 // A DC and an AC symbol go down ONE path (the table is a select, the rest arithmetic on the same registers): the lanes of a wave sit at different
 // coefficient indices, and with a branch per kind every symbol step of the wave ran both.
 template <class Emit>
-JH_HD JHState jh_run(const SfJpegHuffGeom& D, const SfJpegHuffTable* dc, const SfJpegHuffTable* ac, const uint32_t* words, JHState s, uint32_t limit, JHCounts& n, Emit& E) {
+JH_HD JHState jh_run(const SfJpegHuffGeom& D, const SfJpegHuffTable* dc, const SfJpegHuffTable* ac, const uint16_t* dc12, const uint16_t* ac12, const uint32_t* words, JHState s,
+                     uint32_t limit, JHCounts& n, Emit& E) {   // dc12 / ac12: [3][JH_LOOK12] first-level tables (jh_look12_entry) or nullptr: the tables' own 9-bit ones
   const uint32_t nbits = D.ecs_bytes * 8u;
   n.blocks = n.entries = 0;
   n.dc_sum[0] = n.dc_sum[1] = n.dc_sum[2] = 0;
@@ -128,7 +153,7 @@ JH_HD JHState jh_run(const SfJpegHuffGeom& D, const SfJpegHuffTable* dc, const S
     }
     const bool isdc = s.k == 0;
     int len;
-    const int rs = jh_symbol(isdc ? dc[ci] : ac[ci], w, len);
+    const int rs = dc12 ? jh_symbol12(isdc ? dc[ci] : ac[ci], (isdc ? dc12 : ac12) + ci * JH_LOOK12, w, len) : jh_symbol(isdc ? dc[ci] : ac[ci], w, len);
     if (rs < 0 || (isdc && rs > 11)) { n.bad = 1; s.p += 1; continue; }   // invalid under this state: slip a bit and keep going (a guess; an error on the true path)
     const int run = isdc ? 0 : rs >> 4, size = isdc ? rs : rs & 15;
     const int val = size ? jh_extend((int)(((w << len) >> 1) >> (31 - size)), size) : 0;   // len + size <= 31

@@ -53,6 +53,11 @@ __device__ inline int block_exscan(int v, int* s_wave, int& total) {
   return base + incl - v;
 }
 
+struct JHChunkCounts {
+  uint32_t blocks, entries;
+  int32_t dc0, dc1, dc2;
+};
+
 struct DeviceWriter {
   const SfJpegLayout& L;
   const SfJpegHuffGeom& G;
@@ -82,10 +87,13 @@ __global__ __launch_bounds__(JH_LANES) void k_jpeg_huff(JpegHuffBatch B) {
   __shared__ SfJpegHuffTable s_dc[3], s_ac[3];
   __shared__ SfJpegHuffGeom s_geom;
   __shared__ SfJpegLayout s_layout;
-  __shared__ JHState s_end[JH_LANES];
+  __shared__ JHState s_end[JH_LANES], s_start[JH_LANES];   // per CHUNK: where its decode starts (the left neighbour's end of the round before) and ends
+  __shared__ JHChunkCounts s_cnt[JH_LANES];                // ... and what it holds
+  __shared__ uint16_t s_list[JH_LANES];                    // the dirty chunks of a round
   __shared__ int s_wave[JH_LANES / 64];
   __shared__ uint32_t s_nentries;
   __shared__ uint8_t s_zz[64];
+  __shared__ uint16_t s_dc12[3 * JH_LOOK12], s_ac12[3 * JH_LOOK12];   // 12-bit first-level tables, built below (48 KiB: the workgroup has the CU to itself anyway)
   const int f = blockIdx.x;
   if (B.payload[f] == nullptr) return;
   if (threadIdx.x < 64) s_zz[threadIdx.x] = (uint8_t)jh_zigzag((int)threadIdx.x);
@@ -106,6 +114,12 @@ __global__ __launch_bounds__(JH_LANES) void k_jpeg_huff(JpegHuffBatch B) {
     for (uint32_t i = threadIdx.x; i < 3 * sizeof(SfJpegHuffTable) / 4; i += JH_LANES) da[i] = src[i];
   }
   __syncthreads();
+  for (uint32_t i = threadIdx.x; i < 6u * JH_LOOK12; i += JH_LANES) {
+    const uint32_t tb = i / JH_LOOK12, idx = i % JH_LOOK12;
+    if (tb < 3u) s_dc12[i] = jh_look12_entry(s_dc[tb], idx);
+    else s_ac12[i - 3u * JH_LOOK12] = jh_look12_entry(s_ac[tb - 3u], idx);
+  }
+  __syncthreads();
   const uint32_t* __restrict__ words = prep + (sizeof(SfJpegLayout) + sizeof(SfJpegHuffDesc)) / 4;
   const SfJpegHuffGeom& G = s_geom;
   const uint32_t nbits = G.ecs_bytes * 8u;
@@ -114,31 +128,48 @@ __global__ __launch_bounds__(JH_LANES) void k_jpeg_huff(JpegHuffBatch B) {
   const uint32_t c = threadIdx.x;
   const bool mine = c < C;
   const uint32_t limit = (c + 1 == C) ? nbits : (c + 1) * Bc;
-  // ---- stage A: chunk states to their fixed point
-  JHState start{mine ? c * Bc : 0u, 0, 0, 0u};
-  JHCounts cnt;
-  cnt.blocks = cnt.entries = 0; cnt.dc_sum[0] = cnt.dc_sum[1] = cnt.dc_sum[2] = 0; cnt.bad = 0;
-  bool dirty = mine;
+  // ---- stage A: chunk states to their fixed point.  Round 0 decodes every chunk from a guess, round 1 nearly every chunk again (its left neighbour's end state
+  // is news); from then on only the chunks whose neighbour did not fall in step inside its own chunk are dirty -- one in ten, then fewer.  A wave takes as long
+  // over one dirty lane as over sixty-four, so the dirty chunks are DEALT OUT AGAIN every round: lane i takes the i-th dirty chunk (states and counts of all
+  // chunks live in LDS), the late rounds run on one or two waves instead of on all sixteen (rounds 3-6 cost a full chunk decode each until round 6).
+  if (mine) s_start[c] = JHState{c * Bc, 0, 0, 0u};
   JHNoEmit none;
+  {
+    JHCounts cnt;
+    cnt.blocks = cnt.entries = 0; cnt.dc_sum[0] = cnt.dc_sum[1] = cnt.dc_sum[2] = 0; cnt.bad = 0;
+    if (mine) s_end[c] = jh_run(G, s_dc, s_ac, s_dc12, s_ac12, words, s_start[c], limit, cnt, none);
+    s_cnt[c] = JHChunkCounts{cnt.blocks, cnt.entries, cnt.dc_sum[0], cnt.dc_sum[1], cnt.dc_sum[2]};
+  }
   for (uint32_t round = 0; round < C + 2u; round++) {
-    if (dirty) s_end[c] = jh_run(G, s_dc, s_ac, words, start, limit, cnt, none);
-    __syncthreads();
+    __syncthreads();   // every end state of the round before is written
     bool changed = false;
     if (mine && c > 0) {
       const JHState ns = s_end[c - 1];
-      changed = !jh_same(ns, start);
-      start = ns;
+      changed = !jh_same(ns, s_start[c]);
+      s_start[c] = ns;
     }
-    dirty = changed;
-    if (!__syncthreads_or((int)changed)) break;
+    int ndirty;
+    const int at = block_exscan(changed ? 1 : 0, s_wave, ndirty);
+    if (ndirty == 0) break;
+    if (changed) s_list[at] = (uint16_t)c;
+    __syncthreads();
+    for (int i = (int)threadIdx.x; i < ndirty; i += JH_LANES) {
+      const uint32_t d = s_list[i];
+      JHCounts cnt;
+      s_end[d] = jh_run(G, s_dc, s_ac, s_dc12, s_ac12, words, s_start[d], (d + 1 == C) ? nbits : (d + 1) * Bc, cnt, none);
+      s_cnt[d] = JHChunkCounts{cnt.blocks, cnt.entries, cnt.dc_sum[0], cnt.dc_sum[1], cnt.dc_sum[2]};
+    }
   }
+  __syncthreads();
+  const JHState start = mine ? s_start[c] : JHState{0u, 0, 0, 0u};
+  const JHChunkCounts cnt = s_cnt[c];
   // ---- stage B: where every chunk's blocks, entries and DC predictors start
   int total_blocks_seen, total_entries, t0, t1, t2;
   const uint32_t ord0 = (uint32_t)block_exscan(mine ? (int)cnt.blocks : 0, s_wave, total_blocks_seen);
   const uint32_t ent0 = (uint32_t)block_exscan(mine ? (int)cnt.entries : 0, s_wave, total_entries);
-  const int p0 = block_exscan(mine ? cnt.dc_sum[0] : 0, s_wave, t0);
-  const int p1 = block_exscan(mine ? cnt.dc_sum[1] : 0, s_wave, t1);
-  const int p2 = block_exscan(mine ? cnt.dc_sum[2] : 0, s_wave, t2);
+  const int p0 = block_exscan(mine ? cnt.dc0 : 0, s_wave, t0);
+  const int p1 = block_exscan(mine ? cnt.dc1 : 0, s_wave, t1);
+  const int p2 = block_exscan(mine ? cnt.dc2 : 0, s_wave, t2);
   uint32_t* out = reinterpret_cast<uint32_t*>(B.payload[f]);
   uint32_t* table = out + sizeof(SfJpegLayout) / 4;
   uint32_t* entries = table + s_layout.nblocks;
@@ -149,7 +180,7 @@ __global__ __launch_bounds__(JH_LANES) void k_jpeg_huff(JpegHuffBatch B) {
     // ---- stage C: the same decode once more, written
     DeviceWriter w{s_layout, G, table, entries, &s_nentries, ord0, ent0, p0, p1, p2, s_zz};
     JHCounts again;
-    (void)jh_run(G, s_dc, s_ac, words, start, limit, again, w);
+    (void)jh_run(G, s_dc, s_ac, s_dc12, s_ac12, words, start, limit, again, w);
     if (again.bad) status = -2;   // an invalid code on the true path
   }
   const int any_bad = __syncthreads_or(status != 0);

@@ -51,6 +51,9 @@ int main(int argc, char** argv) {
   const uint32_t* words = (const uint32_t*)((const uint8_t*)prep.data() + sizeof(SfJpegLayout) + sizeof(SfJpegHuffDesc));
   uint32_t C, B;
   jh_geometry(D.ecs_bytes * 8u, C, B);
+  std::vector<uint16_t> dc12(3 * JH_LOOK12), ac12(3 * JH_LOOK12);   // the device's 12-bit first-level tables, built the way the kernel builds them
+  for (int t = 0; t < 3; t++)
+    for (uint32_t i = 0; i < (uint32_t)JH_LOOK12; i++) { dc12[t * JH_LOOK12 + i] = jh_look12_entry(D.dc[t], i); ac12[t * JH_LOOK12 + i] = jh_look12_entry(D.ac[t], i); }
   std::vector<JHState> start(C), end(C);
   std::vector<JHCounts> cnt(C);
   std::vector<char> dirty(C, 1);
@@ -60,7 +63,7 @@ int main(int argc, char** argv) {
   for (;;) {
     rounds++;
     for (uint32_t c = 0; c < C; c++)
-      if (dirty[c]) { end[c] = jh_run(D, D.dc, D.ac, words, start[c], (c + 1 == C) ? D.ecs_bytes * 8u : (c + 1) * B, cnt[c], none); scans++; }
+      if (dirty[c]) { end[c] = jh_run(D, D.dc, D.ac, dc12.data(), ac12.data(), words, start[c], (c + 1 == C) ? D.ecs_bytes * 8u : (c + 1) * B, cnt[c], none); scans++; }
     bool any = false;
     for (uint32_t c = 1; c < C; c++) { dirty[c] = !jh_same(end[c - 1], start[c]); start[c] = end[c - 1]; any = any || dirty[c]; }
     dirty[0] = 0;
@@ -77,7 +80,7 @@ int main(int argc, char** argv) {
     Writer wtr{L, D, table, entries, ord, ent, {pred[0], pred[1], pred[2]}};
     JHCounts k;
     k.bad = 0;
-    if (ord < D.total_blocks) (void)jh_run(D, D.dc, D.ac, words, start[c], (c + 1 == C) ? D.ecs_bytes * 8u : (c + 1) * B, k, wtr);
+    if (ord < D.total_blocks) (void)jh_run(D, D.dc, D.ac, dc12.data(), ac12.data(), words, start[c], (c + 1 == C) ? D.ecs_bytes * 8u : (c + 1) * B, k, wtr);
     bad += k.bad;   // of the writing pass, which stops at the picture's last block: the padding bits behind it are not a code
     ord += cnt[c].blocks; ent += cnt[c].entries;
     for (int i = 0; i < 3; i++) pred[i] += cnt[c].dc_sum[i];
