@@ -309,23 +309,34 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_
                                                uint64_t* block_keys, int32_t* block_entry, uint8_t* block_flags, int32_t* counters, ParamsK P,
                                                BatchFrames B, int group_frames) {
   constexpr int WIN = 1 << WIN_LOG2;                // window edge in blocks
+  // the queue of a workgroup: at 1 mm voxels (WIN 64) a pixel tile's rays visit ~1 300 blocks per frame -- with the 512 entries that serve 4 mm ALL of them
+  // overflowed into the one-by-one path (sf_fuser_alloc_direct_count: 1.3 M blocks per frame, k_alloc<6> 2.2 ms: tools/gpu/alloc_1mm_probe.py)
+  constexpr int LIST = WIN_LOG2 >= 6 ? 4096 : ALLOC_LIST;
+  // (8 192 entries and a 2 048-slot set take the direct path from 1.3 M to 8 k blocks per frame and the kernel nowhere: its time is the table probes themselves,
+  // profiles/r06_alloc_1mm.txt; 4 096 entries keep two workgroups per CU)
+  constexpr int SET_LOG2 = 8, SET = 1 << SET_LOG2;
   constexpr int WIN_WORDS = (WIN * WIN * WIN) / 32; // occupancy bitmap words: 4 KiB (WIN 32) / 32 KiB (WIN 64)
   __shared__ uint32_t s_frame[WIN_WORDS];           // blocks the current frame's rays visit
   __shared__ uint32_t s_done[MULTI ? WIN_WORDS : 1];// blocks an earlier frame of the group has already queued
-  __shared__ unsigned long long s_keys[ALLOC_SET];  // the same for blocks outside the window
-  __shared__ unsigned long long s_list[ALLOC_LIST]; // queue for phase 2
-  __shared__ uint8_t s_birth[ALLOC_LIST];           // ... and the frame (index in the batch) that queued the key
+  __shared__ unsigned long long s_keys[SET];  // the same for blocks outside the window
+  __shared__ unsigned long long s_list[LIST]; // queue for phase 2
+  __shared__ uint8_t s_birth[LIST];           // ... and the frame (index in the batch) that queued the key
   __shared__ int s_count;
   __shared__ int s_chooser;
   __shared__ int s_anchored;
   __shared__ int s_anchor[3];
+  // the current frame's constants for the frustum tests of the scan (and of rays outside the window), two frames' worth so that a frame's copy never lands
+  // under the previous frame's readers.  Read as B.f[j] they come through the scalar unit from the kernarg segment, a few words per load, each load a round
+  // trip the wave waits for: at 1 mm voxels a tile names ~1 300 blocks per frame and a wave of k_alloc<6> spent its life -- 610 scalar loads, three quarters
+  // of its cycles waiting (profiles/r06_pmc_alloc_1mm.txt) -- in that chain
+  __shared__ uint32_t s_fk[2][sizeof(FrameK) / 4];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) { s_count = 0; s_chooser = 256; s_anchored = 0; }
   const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
   const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
   const HashRefs h{table, heap, block_keys, block_entry, block_flags, counters};
-  for (int i = threadIdx.x; i < ALLOC_SET; i += 256) s_keys[i] = KEY_EMPTY;
+  for (int i = threadIdx.x; i < SET; i += 256) s_keys[i] = KEY_EMPTY;
   if (MULTI)
     for (int i = threadIdx.x; i < WIN_WORDS; i += 256) s_done[i] = 0u;
   const size_t npx = (size_t)P.W * P.H;
@@ -353,6 +364,8 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_
     // the next frame's depth is requested now and lands while this frame's rays are walked
     d_next = in_image && j + 1 < j_end ? depthf_all[(size_t)(j + 1) * npx + (size_t)(y * P.W + x)] : -INFINITY;
     for (int i = threadIdx.x; i < WIN_WORDS; i += 256) s_frame[i] = 0u;
+    if (threadIdx.x < sizeof(FrameK) / 4) s_fk[j & 1][threadIdx.x] = reinterpret_cast<const uint32_t*>(&B.f[j])[threadIdx.x];   // per-lane words: vector loads
+    const FrameK& FL = *reinterpret_cast<const FrameK*>(s_fk[j & 1]);   // valid behind the barrier below
 
     // ---- ray set-up
     bool active = false;
@@ -419,7 +432,11 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_
     const int anx = s_anchor[0], any_ = s_anchor[1], anz = s_anchor[2];
 
     // ---- DDA: one LDS bit per visited block
+#ifdef SF_ABLATE_ALLOC_WALK   // measurement only (the volume is WRONG): no DDA walk
+    if (false) {
+#else
     if (active) {
+#endif
       uint64_t last_key = KEY_EMPTY;
       for (int it = 0; it < MAX_DDA_ITERS; ++it) {
         const uint32_t ux = (uint32_t)(a_cx - anx), uy = (uint32_t)(a_cy - any_), uz = (uint32_t)(a_cz - anz);
@@ -435,18 +452,18 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_
           const uint64_t key = pack_key(a_cx, a_cy, a_cz);
           if (key != last_key) {
             last_key = key;
-            if (slab_owns(P, a_cx, a_cy, a_cz) && block_in_frustum(P, F, a_cx, a_cy, a_cz)) {
-              uint32_t sl = ((uint32_t)(key ^ (key >> 21) ^ (key >> 42)) * 2654435761u) >> 24;  // 8 bits
+            if (slab_owns(P, a_cx, a_cy, a_cz) && block_in_frustum(P, FL, a_cx, a_cy, a_cz)) {
+              uint32_t sl = ((uint32_t)(key ^ (key >> 21) ^ (key >> 42)) * 2654435761u) >> (32 - SET_LOG2);
               bool placed = false;
               for (int pr = 0; pr < ALLOC_SET_PROBES; ++pr) {
                 const unsigned long long old = atomicCAS(&s_keys[sl], (unsigned long long)KEY_EMPTY, (unsigned long long)key);
                 if (old == key) { placed = true; break; }  // queued by an earlier step / ray / frame
                 if (old == KEY_EMPTY) {
                   const int pos = atomicAdd(&s_count, 1);
-                  if (pos < ALLOC_LIST) { s_list[pos] = key; s_birth[pos] = (uint8_t)j; placed = true; }
+                  if (pos < LIST) { s_list[pos] = key; s_birth[pos] = (uint8_t)j; placed = true; }
                   break;  // queue full: direct path below
                 }
-                sl = (sl + 1) & (ALLOC_SET - 1);
+                sl = (sl + 1) & (SET - 1);
               }
               if (!placed) direct(key, a_cx, a_cy, a_cz, B.seq0 + (uint32_t)j);
             }
@@ -461,6 +478,7 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_
     }
     __syncthreads();
     // ---- scan: blocks this frame visits that no earlier frame of the group queued -> frustum test -> queue
+#ifndef SF_ABLATE_ALLOC_SCAN   // measurement only (the volume is WRONG): no scan
     for (int w = threadIdx.x; w < WIN_WORDS; w += 256) {
       uint32_t bits = MULTI ? (s_frame[w] & ~s_done[w]) : s_frame[w];
       uint32_t queued = 0u;
@@ -470,19 +488,24 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_
         const uint32_t bit = ((uint32_t)w << 5) | (uint32_t)b;
         const int bx = anx + (int)(bit & (WIN - 1)), by = any_ + (int)((bit >> WIN_LOG2) & (WIN - 1)), bz = anz + (int)(bit >> (2 * WIN_LOG2));
         if (!slab_owns(P, bx, by, bz)) { queued |= 1u << b; continue; }  // another GPU's block: never ours, stop looking at it
-        if (!block_in_frustum(P, F, bx, by, bz)) continue;  // a later frame may still want it
+        if (!block_in_frustum(P, FL, bx, by, bz)) continue;  // a later frame may still want it
         queued |= 1u << b;
         const int pos = atomicAdd(&s_count, 1);
-        if (pos < ALLOC_LIST) { s_list[pos] = pack_key(bx, by, bz); s_birth[pos] = (uint8_t)j; }
+        if (pos < LIST) { s_list[pos] = pack_key(bx, by, bz); s_birth[pos] = (uint8_t)j; }
         else direct(pack_key(bx, by, bz), bx, by, bz, B.seq0 + (uint32_t)j);
       }
       if (MULTI && queued) s_done[w] |= queued;  // word w is only ever touched by this thread
     }
+#endif
   }
   __syncthreads();
 
   // ---- phase 2: queued keys -> global hash, all lanes in parallel
-  const int n_unique = min(s_count, ALLOC_LIST);
+#ifdef SF_ABLATE_ALLOC_PHASE2   // measurement only (the volume is WRONG): no table probes
+  const int n_unique = 0;
+#else
+  const int n_unique = min(s_count, LIST);
+#endif
   for (int i0 = 0; i0 < n_unique; i0 += 256) {
     const int i = i0 + threadIdx.x;
     const uint64_t key = i < n_unique ? s_list[i] : KEY_EMPTY;
@@ -2103,7 +2126,8 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
     // integrate launch (a 20-frame call: k_alloc_ray 133 us of a 650 us region at 8 frames per workgroup), so it is cut into more, shorter workgroups
     // (tune "alloc_group_head"); every other pass hides its allocation behind the previous integrate launch and takes the cheaper, longer ones
     const int group = (f->head_pass && f->alloc_group_head > 0) ? std::min(f->alloc_group, f->alloc_group_head) : f->alloc_group;
-    const int gf = (f->alloc_win64 && !f->alloc_ray) ? 1 : std::min(group, n);
+    // WIN 64 (32 KiB bitmap): a second bitmap of that size makes the workgroup 102 KiB -- one per CU; tune "alloc_group_win64" (default 1: one frame per workgroup)
+    const int gf = (f->alloc_win64 && !f->alloc_ray) ? std::min(f->alloc_group_win64, n) : std::min(group, n);
     const dim3 ag((f->p.depth_width + 15) / 16, (f->p.depth_height + 15) / 16, (n + gf - 1) / gf);
 #define LAUNCH_ALLOC(WL, MU) \
   hipLaunchKernelGGL((k_alloc<WL, MU>), ag, dim3(256), 0, sa, f->depthf2[sl], f->table, f->heap, f->block_keys, f->block_entry, f->block_flags, f->counters, f->pk, bf, gf)
@@ -2115,7 +2139,7 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
   hipLaunchKernelGGL((k_alloc_ray<MU>), ag, dim3(256), alloc_pad, sa, f->depthf2[sl], f->table, f->heap, f->block_keys, f->block_entry, f->block_flags, f->counters, f->pk, bf, gf, f->alloc_ablate, \
                      fuse_pre ? in.depth[0] : (const uint16_t*)nullptr, f->depthf2[sl], cc)
     if (f->alloc_ray) { if (gf == 1) LAUNCH_ALLOC_RAY(false); else LAUNCH_ALLOC_RAY(true); }
-    else if (f->alloc_win64) LAUNCH_ALLOC(6, false);
+    else if (f->alloc_win64) { if (gf == 1) LAUNCH_ALLOC(6, false); else LAUNCH_ALLOC(6, true); }
     else if (gf == 1) LAUNCH_ALLOC(5, false);
     else LAUNCH_ALLOC(5, true);
 #undef LAUNCH_ALLOC
@@ -2584,6 +2608,7 @@ SF_API int sf_fuser_tune(sf_fuser* f, const char* key, int value) {
   }
   else if (k == "alloc_group" && in(1, MAX_BATCH)) f->alloc_group = value;
   else if (k == "alloc_group_head" && in(0, MAX_BATCH)) f->alloc_group_head = value;
+  else if (k == "alloc_group_win64" && in(1, MAX_BATCH)) f->alloc_group_win64 = value;
   else if (k == "alloc_wgs" && in(0, 8)) f->alloc_wgs = value;
   else if (k == "prepass_fuse" && in(0, 1)) f->prepass_fuse = value != 0;
 #ifdef SF_MEASURE_ABLATE

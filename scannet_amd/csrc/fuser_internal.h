@@ -268,6 +268,7 @@ struct sf_fuser {
   int pipe_overlap = -1;  // the next frame's pre-pass / allocation / compaction on the front stream beside k_integrate_pipe: -1 = when the previous pass's tiles exceed 512 MiB, 0 never, 1 always (tune "pipe_overlap")
   int ramp = 8;         // > 0: the first pass of an integrate_batch call takes only that many frames (tune "ramp"; a 20-frame call: 29.3 k frames/s at 0, 30.0 k at 4, 30.7 k at 8)
   bool ramp_geo = true; // the passes behind the first double (ramp, 2 ramp, ... batch) instead of jumping to the batch size (tune "ramp_geo")
+  int alloc_group_win64 = 1;   // the same for k_alloc<6> (voxels below ~1.6 mm: the 64^3-block window), tune "alloc_group_win64"
   int alloc_group = 16; // consecutive frames of a batch one k_alloc workgroup walks (tune "alloc_group"; 4 -> 16: 35.0 -> 35.8 k frames/s, the blocks a pixel tile queues are looked up in the table once per batch)
   int compact_grid = 1024;  // 1024 directory entries per workgroup, grid-stride beyond
   uint64_t frames_integrated = 0, frames_skipped = 0;
