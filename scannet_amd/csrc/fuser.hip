@@ -272,7 +272,7 @@ __device__ inline void note_birth(HashEntry* e, uint32_t seq) {
 
 // find-or-claim `key`; returns the claimed entry (needs a heap block) or nullptr (already present / table full)
 __device__ inline HashEntry* hash_find_or_claim(const HashRefs& h, const ParamsK& P, uint64_t key, int bx, int by, int bz, uint32_t seq) {
-  uint32_t slot = hash_bucket(bx, by, bz, P.num_buckets) * P.bucket_size;
+  uint32_t slot = hash_home(P, bx, by, bz);
   for (int probe = 0; probe < MAX_PROBES; ++probe) {
     HashEntry* e = h.table + slot;
     const uint64_t k = __hip_atomic_load(&e->key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1880,7 +1880,7 @@ __global__ __launch_bounds__(256) void k_gc(uint4* voxels, uint64_t* block_keys,
         const uint64_t key = block_keys[slot];
         int bx, by, bz;
         unpack_key(key, bx, by, bz);
-        uint32_t s = hash_bucket(bx, by, bz, P.num_buckets) * P.bucket_size;
+        uint32_t s = hash_home(P, bx, by, bz);
         for (int probe = 0; probe < MAX_PROBES; ++probe) {
           if (table[s].key == key) { table[s].key = KEY_TOMB; table[s].ptr = -1; break; }
           if (table[s].key == KEY_EMPTY) break;
@@ -1908,7 +1908,7 @@ __global__ __launch_bounds__(256) void k_rehash(HashEntry* table, const uint64_t
     if (key == KEY_EMPTY) continue;
     int bx, by, bz;
     unpack_key(key, bx, by, bz);
-    uint32_t at = hash_bucket(bx, by, bz, P.num_buckets) * P.bucket_size;
+    uint32_t at = hash_home(P, bx, by, bz);
     for (int probe = 0; probe < MAX_PROBES; ++probe) {
       if (atomicCAS((unsigned long long*)&table[at].key, (unsigned long long)KEY_EMPTY, (unsigned long long)key) == KEY_EMPTY) {
         table[at].ptr = slot;

@@ -129,12 +129,16 @@ __device__ inline uint32_t hash_bucket(int x, int y, int z, uint32_t num_buckets
   const uint32_t h = ((uint32_t)x * 73856093u) ^ ((uint32_t)y * 19349669u) ^ ((uint32_t)z * 83492791u);
   return h % num_buckets;
 }
-
+// Where a block's probe sequence starts in the table (open addressing over all num_buckets x bucket_size slots, linear from here): every block hashed on its
+// own.  (Round 6 tried a brick-local start -- the 64 blocks of a 4x4x4 brick at 64 consecutive slots, so that the ~1 300 blocks a pixel tile names per frame at
+// 1 mm fall on a few hundred cache lines: linear probing over clustered starts makes long runs wherever two bricks meet, and every look-up got slower:
+// one frame per launch 10.2 k -> 8.8 k frames/s at 4 mm, 324 -> 260 at 1 mm.  profiles/r06_alloc_1mm.txt)
+__device__ inline uint32_t hash_home(const ParamsK& P, int x, int y, int z) { return hash_bucket(x, y, z, P.num_buckets) * P.bucket_size; }
 
 // lookup only: heap slot of block (x,y,z) or -1
 __device__ inline int hash_lookup(const HashEntry* __restrict__ table, const ParamsK& P, int x, int y, int z) {
   const uint64_t key = pack_key(x, y, z);
-  uint32_t slot = hash_bucket(x, y, z, P.num_buckets) * P.bucket_size;
+  uint32_t slot = hash_home(P, x, y, z);
   for (int probe = 0; probe < MAX_PROBES; ++probe) {
     const uint64_t k = table[slot].key;
     if (k == key) return table[slot].ptr;
