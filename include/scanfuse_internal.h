@@ -38,8 +38,15 @@ extern "C" {
  *   "xrow"        0/1    passes of several frames run k_integrate in the x-row lane layout: a lane holds one x-row of the block (y = lane & 7, z = lane >> 3)
  *                        instead of two x-neighbours in four z-layers -- the same voxels, 18 fma fewer per lane and frame, and the gathers of one instruction
  *                        fall on two image rows instead of four or five (default 1)
+ *   "brick_cache" 0/1    the allocation kernels ask the presence cache (one {tag, 64-bit mask} entry per 4x4x4-block brick: "this block is in the table and
+ *                        older than this batch") before they probe the hash table (default 1; 0: every look-up probes the table, rounds 1-5).  The allocated
+ *                        set and every birth frame are the same either way.
  * Synchronises the fuser.  SF_ERR_INVALID_ARG for an unknown key or a value out of range. */
 int sf_fuser_tune(sf_fuser* f, const char* key, int value);
+
+/* How many look-ups of the allocation kernels went to the hash table since the fuser was created or reset (32-bit, wraps): with the presence cache
+ * on, what is left are new blocks, blocks of the previous batch and bricks whose cache entry another brick holds. */
+int sf_fuser_alloc_probe_count(sf_fuser* f, uint64_t* out);
 
 /* How many blocks the allocation kernels took to the global hash table one by one because a workgroup's LDS queue / hash set was full (the slow
  * path k_alloc_ray exists to avoid; the volume is the same either way).  tests/test_gpu_tsdf.py asserts 0 on the bench walk's corners. */

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -261,13 +262,17 @@ struct HashRefs {
   int32_t* block_entry;
   uint8_t* block_flags;
   int32_t* counters;
+  BrickCache bricks;   // presence cache (fuser_internal.h); bricks.e == nullptr: none
+  uint32_t seq0;       // sequence number of the batch's first frame: a block born before it is older than every frame that asks now
 };
 
 // A block is "born" in the first frame that asks for it: frames of one batch are allocated by ONE launch, so the
 // entry keeps the minimum sequence number over everybody who found or claimed it (the frames before its birth
 // must not update the block -- sequentially it did not exist yet).
-__device__ inline void note_birth(HashEntry* e, uint32_t seq) {
-  if (__hip_atomic_load(&e->birth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > seq) atomicMin(&e->birth, seq);
+__device__ inline uint32_t note_birth(HashEntry* e, uint32_t seq) {
+  const uint32_t b = __hip_atomic_load(&e->birth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (b > seq) atomicMin(&e->birth, seq);
+  return b;
 }
 
 // find-or-claim `key`; returns the claimed entry (needs a heap block) or nullptr (already present / table full)
@@ -276,7 +281,11 @@ __device__ inline HashEntry* hash_find_or_claim(const HashRefs& h, const ParamsK
   for (int probe = 0; probe < MAX_PROBES; ++probe) {
     HashEntry* e = h.table + slot;
     const uint64_t k = __hip_atomic_load(&e->key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (k == key) { note_birth(e, seq); return nullptr; }
+    if (k == key) {
+      // found, and born before this batch: no later frame has anything to do for this block -- the presence cache may say so from now on
+      if (note_birth(e, seq) < h.seq0 && h.bricks.e != nullptr) brick_note(h.bricks, bx, by, bz);
+      return nullptr;
+    }
     if (k == KEY_EMPTY) {
       const uint64_t old = atomicCAS((unsigned long long*)&e->key, (unsigned long long)KEY_EMPTY, (unsigned long long)key);
       if (old == KEY_EMPTY) { note_birth(e, seq); return e; }
@@ -304,14 +313,27 @@ __device__ inline void give_block(const HashRefs& h, HashEntry* e, uint64_t key,
   }
 }
 
+// -DSF_ALLOC_TIMING (measurement build, tools/gpu/alloc_1mm_probe.py): where a workgroup of k_alloc spends its time -- thread 0 adds the 100 MHz clock between
+// the barriers that separate the phases into g_alloc_t (sf_alloc_timing_read): [0] zeroing + ray set-up, [1] anchoring, [2] walk, [3] scan, [4] drain, [5] whole
+// workgroup, [8] the longest workgroup, [9] rounds walked, [10] workgroups
+#ifdef SF_ALLOC_TIMING
+__device__ unsigned long long g_alloc_t[16];
+#define AT_MARK(i) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_alloc_t[i], now_ - at_prev_); at_prev_ = now_; } } while (0)
+#else
+#define AT_MARK(i) do { } while (0)
+#endif
+
 template <int WIN_LOG2, bool MULTI>
 __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_all, HashEntry* table, int32_t* heap,
                                                uint64_t* block_keys, int32_t* block_entry, uint8_t* block_flags, int32_t* counters, ParamsK P,
-                                               BatchFrames B, int group_frames) {
+                                               BatchFrames B, int group_frames, BrickCache bricks) {
   constexpr int WIN = 1 << WIN_LOG2;                // window edge in blocks
   // the queue of a workgroup: at 1 mm voxels (WIN 64) a pixel tile's rays visit ~1 300 blocks per frame -- with the 512 entries that serve 4 mm ALL of them
   // overflowed into the one-by-one path (sf_fuser_alloc_direct_count: 1.3 M blocks per frame, k_alloc<6> 2.2 ms: tools/gpu/alloc_1mm_probe.py)
-  constexpr int LIST = WIN_LOG2 >= 6 ? 4096 : ALLOC_LIST;
+#ifndef SF_ALLOC6_LIST
+#define SF_ALLOC6_LIST 4096
+#endif
+  constexpr int LIST = WIN_LOG2 >= 6 ? SF_ALLOC6_LIST : ALLOC_LIST;
   // (8 192 entries and a 2 048-slot set take the direct path from 1.3 M to 8 k blocks per frame and the kernel nowhere: its time is the table probes themselves,
   // profiles/r06_alloc_1mm.txt; 4 096 entries keep two workgroups per CU)
   constexpr int SET_LOG2 = 8, SET = 1 << SET_LOG2;
@@ -325,17 +347,23 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_
   __shared__ int s_chooser;
   __shared__ int s_anchored;
   __shared__ int s_anchor[3];
+  __shared__ int s_box[6];
   // the current frame's constants for the frustum tests of the scan (and of rays outside the window), two frames' worth so that a frame's copy never lands
   // under the previous frame's readers.  Read as B.f[j] they come through the scalar unit from the kernarg segment, a few words per load, each load a round
   // trip the wave waits for: at 1 mm voxels a tile names ~1 300 blocks per frame and a wave of k_alloc<6> spent its life -- 610 scalar loads, three quarters
   // of its cycles waiting (profiles/r06_pmc_alloc_1mm.txt) -- in that chain
   __shared__ uint32_t s_fk[2][sizeof(FrameK) / 4];
+#ifdef SF_ALLOC_TIMING
+  unsigned long long at_prev_ = wall_clock64();
+  const unsigned long long at_start_ = at_prev_;
+#endif
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) { s_count = 0; s_chooser = 256; s_anchored = 0; }
+  if (threadIdx.x < 6) s_box[threadIdx.x] = threadIdx.x < 3 ? INT_MAX : INT_MIN;
   const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
   const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
-  const HashRefs h{table, heap, block_keys, block_entry, block_flags, counters};
+  const HashRefs h{table, heap, block_keys, block_entry, block_flags, counters, bricks, B.seq0};
   for (int i = threadIdx.x; i < SET; i += 256) s_keys[i] = KEY_EMPTY;
   if (MULTI)
     for (int i = threadIdx.x; i < WIN_WORDS; i += 256) s_done[i] = 0u;
@@ -345,8 +373,11 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_
 
   // a block the workgroup cannot queue (queue full: pathological tile) goes straight to the global table
   int n_direct = 0;   // sf_fuser_alloc_direct_count (added up once per wave at the end: one atomic per call on a single word halved the 1 mm front chain)
+  int n_probed = 0;   // look-ups that went to the hash table (the presence cache did not answer): sf_fuser_alloc_probe_count
   auto direct = [&](uint64_t key, int bx, int by, int bz, uint32_t seq) {
     n_direct++;
+    if (h.bricks.e != nullptr && brick_known(h.bricks, bx, by, bz)) return;
+    n_probed++;
     HashEntry* e = hash_find_or_claim(h, P, key, bx, by, bz, seq);
     if (e) {
       atomicAdd(&counters[C_SLOTS_USED], 1);
@@ -354,6 +385,45 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_
     }
   };
 
+  // ---- phase 2: queued keys -> global hash, all lanes in parallel (callers put a barrier between the last queue write and this)
+  auto drain = [&]() {
+#ifdef SF_ABLATE_ALLOC_PHASE2   // measurement only (the volume is WRONG): no table probes
+    const int n_unique = 0;
+#else
+    const int n_unique = min(s_count, LIST);
+#endif
+    for (int i0 = 0; i0 < n_unique; i0 += 256) {
+      const int i = i0 + threadIdx.x;
+      const uint64_t key = i < n_unique ? s_list[i] : KEY_EMPTY;
+      HashEntry* claimed = nullptr;
+      if (key != KEY_EMPTY) {
+        int bx, by, bz;
+        unpack_key(key, bx, by, bz);
+        if (h.bricks.e == nullptr || !brick_known(h.bricks, bx, by, bz)) {
+          n_probed++;
+          claimed = hash_find_or_claim(h, P, key, bx, by, bz, B.seq0 + (uint32_t)s_birth[i]);
+        }
+      }
+      // wave-aggregated heap pop for the freshly claimed slots
+      const uint64_t cm = __ballot(claimed != nullptr);
+      if (cm != 0ull) {
+        const int n = __popcll((unsigned long long)cm);
+        const int first = __ffsll((unsigned long long)cm) - 1;
+        int base = 0;
+        if (lane == first) {
+          base = atomicSub(&counters[C_HEAP_FREE], n);
+          atomicAdd(&counters[C_SLOTS_USED], n);
+        }
+        base = __shfl(base, first);
+        if (claimed != nullptr) {
+          const int rank = __popcll((unsigned long long)(cm & ((1ull << lane) - 1ull)));
+          give_block(h, claimed, key, base - 1 - rank);
+        }
+      }
+    }
+  };
+
+  constexpr int ROUNDS = (WIN_LOG2 >= 6 && !MULTI) ? 3 : 1;   // windows a frame's rays may be walked in before the slow path (below)
   const bool in_image = x < P.W && y < P.H;
   const float kx = ((float)x - P.mx) / P.fx, ky = ((float)y - P.my) / P.fy;  // the pixel's ray direction is the same for every frame
   const float rvoxel = 1.0f / P.voxel;                                        // RN(1 / voxel) for world_to_block
@@ -415,125 +485,171 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_
         }
       }
     }
-    __syncthreads();  // s_frame zeroed, previous frame's scan finished
-    // The tile's rays stay inside a small region of block space: the first active lane of the first frame that has
-    // one anchors the WIN^3 window there for the whole group.
-    if (s_anchored == 0) {
-      if (active) atomicMin(&s_chooser, (int)threadIdx.x);
-      __syncthreads();
-      if ((int)threadIdx.x == s_chooser) {
-        s_anchor[0] = a_cx - (a_sx >= 0 ? WIN / 4 : 3 * WIN / 4);
-        s_anchor[1] = a_cy - (a_sy >= 0 ? WIN / 4 : 3 * WIN / 4);
-        s_anchor[2] = a_cz - (a_sz >= 0 ? WIN / 4 : 3 * WIN / 4);
-        s_anchored = 1;
+    // ROUNDS > 1 (the 64^3 window, one frame per workgroup): rays that leave the window are not taken through the slow path at once -- the window is laid
+    // out again around THEM and they walk again, up to ROUNDS times.  A pixel tile on a depth discontinuity has two clusters of rays metres apart; one window
+    // holds one of them, and the other's ~5 000 block visits went one by one through a 256-slot LDS set and then the global table (profiles/r06_alloc_1mm.txt:
+    // ~35 such tiles per frame set the kernel's duration).  A block two rounds name is queued twice and found the second time: the set is the same.
+    bool pending = active;
+#pragma unroll 1
+    for (int round = 0; round < ROUNDS; ++round) {
+      if (round > 0) {   // behind drain()'s barrier: nobody reads the previous round's window any more
+        if (threadIdx.x == 0) { s_chooser = 256; s_anchored = 0; }
+        if (threadIdx.x < 6) s_box[threadIdx.x] = threadIdx.x < 3 ? INT_MAX : INT_MIN;
+        for (int i = threadIdx.x; i < WIN_WORDS; i += 256) s_frame[i] = 0u;
       }
-      __syncthreads();
-    }
-    const int anx = s_anchor[0], any_ = s_anchor[1], anz = s_anchor[2];
-
-    // ---- DDA: one LDS bit per visited block
-#ifdef SF_ABLATE_ALLOC_WALK   // measurement only (the volume is WRONG): no DDA walk
-    if (false) {
-#else
-    if (active) {
-#endif
-      uint64_t last_key = KEY_EMPTY;
-      for (int it = 0; it < MAX_DDA_ITERS; ++it) {
-        const uint32_t ux = (uint32_t)(a_cx - anx), uy = (uint32_t)(a_cy - any_), uz = (uint32_t)(a_cz - anz);
-        const bool inwin = (ux | uy | uz) < (uint32_t)WIN;
-        const uint32_t bit = inwin ? ((uz << (2 * WIN_LOG2)) | (uy << WIN_LOG2) | ux) : 0xFFFFFFFFu;
-        // The 8x8 pixel patch of a wave mostly sits in ONE block: 64 ds_or to the same LDS word serialise.  Drop
-        // the lane when its left neighbour (DPP row_shr:1, free) sets the same bit; a disabled or out-of-row
-        // neighbour reads as "different" (old value, bound_ctrl off), so run heads always write.
-        const uint32_t left = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFEu, (int)bit, 0x111, 0xF, 0xF, false);
-        if (inwin) {
-          if (left != bit) atomicOr(&s_frame[bit >> 5], 1u << (bit & 31));
-        } else {
-          const uint64_t key = pack_key(a_cx, a_cy, a_cz);
-          if (key != last_key) {
-            last_key = key;
-            if (slab_owns(P, a_cx, a_cy, a_cz) && block_in_frustum(P, FL, a_cx, a_cy, a_cz)) {
-              uint32_t sl = ((uint32_t)(key ^ (key >> 21) ^ (key >> 42)) * 2654435761u) >> (32 - SET_LOG2);
-              bool placed = false;
-              for (int pr = 0; pr < ALLOC_SET_PROBES; ++pr) {
-                const unsigned long long old = atomicCAS(&s_keys[sl], (unsigned long long)KEY_EMPTY, (unsigned long long)key);
-                if (old == key) { placed = true; break; }  // queued by an earlier step / ray / frame
-                if (old == KEY_EMPTY) {
-                  const int pos = atomicAdd(&s_count, 1);
-                  if (pos < LIST) { s_list[pos] = key; s_birth[pos] = (uint8_t)j; placed = true; }
-                  break;  // queue full: direct path below
-                }
-                sl = (sl + 1) & (SET - 1);
-              }
-              if (!placed) direct(key, a_cx, a_cy, a_cz, B.seq0 + (uint32_t)j);
-            }
+      __syncthreads();  // s_frame zeroed, previous frame's scan finished
+      AT_MARK(0);
+      // The tile's rays stay inside a small region of block space: the first active lane of the first frame that has
+      // one anchors the WIN^3 window there for the whole group.
+      if (s_anchored == 0) {
+        if (pending) atomicMin(&s_chooser, (int)threadIdx.x);
+        if (WIN_LOG2 >= 6) {
+          // the box around every ray segment of the tile (first and last block per axis): where it fits, the window is centred on it.  Anchored on the first
+          // active ray alone (WIN / 4 blocks behind its start), a tile whose other rays start 16 blocks nearer -- 13 cm at 1 mm voxels -- loses those rays
+          int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
+          if (pending) {
+            const int ex = a_ex - a_sx, ey = a_ey - a_sy, ez = a_ez - a_sz;   // the last block of the walk
+            lo[0] = min(a_cx, ex); hi[0] = max(a_cx, ex);
+            lo[1] = min(a_cy, ey); hi[1] = max(a_cy, ey);
+            lo[2] = min(a_cz, ez); hi[2] = max(a_cz, ez);
+          }
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            for (int o = 32; o > 0; o >>= 1) { lo[c] = min(lo[c], __shfl_xor(lo[c], o)); hi[c] = max(hi[c], __shfl_xor(hi[c], o)); }
+            if (lane == 0 && lo[c] <= hi[c]) { atomicMin(&s_box[c], lo[c]); atomicMax(&s_box[3 + c], hi[c]); }
           }
         }
-        bool done;
-        if (a_tmx < a_tmy && a_tmx < a_tmz) { a_cx += a_sx; done = (a_cx == a_ex); a_tmx += a_tdx; }
-        else if (a_tmz < a_tmy) { a_cz += a_sz; done = (a_cz == a_ez); a_tmz += a_tdz; }
-        else { a_cy += a_sy; done = (a_cy == a_ey); a_tmy += a_tdy; }
-        if (done) break;
+        __syncthreads();
+        if ((int)threadIdx.x == s_chooser) {
+          // (a multiple of 4 in x: a word of the bitmap is then 8 whole bricks of the presence cache; where the window lies never changes WHAT is allocated)
+          int an[3] = {a_cx - (a_sx >= 0 ? WIN / 4 : 3 * WIN / 4), a_cy - (a_sy >= 0 ? WIN / 4 : 3 * WIN / 4), a_cz - (a_sz >= 0 ? WIN / 4 : 3 * WIN / 4)};
+          if (WIN_LOG2 >= 6) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+              const int ext = s_box[3 + c] - s_box[c] + 1;
+              if (ext <= WIN) an[c] = s_box[c] - (WIN - ext) / 2;   // else: clusters of rays more than a window apart -- the first ray's stays, the rest is the next round's
+            }
+          }
+          s_anchor[0] = an[0] & ~3;
+          s_anchor[1] = an[1];
+          s_anchor[2] = an[2];
+          s_anchored = 1;
+        }
+        __syncthreads();
       }
-    }
-    __syncthreads();
-    // ---- scan: blocks this frame visits that no earlier frame of the group queued -> frustum test -> queue
-#ifndef SF_ABLATE_ALLOC_SCAN   // measurement only (the volume is WRONG): no scan
-    for (int w = threadIdx.x; w < WIN_WORDS; w += 256) {
-      uint32_t bits = MULTI ? (s_frame[w] & ~s_done[w]) : s_frame[w];
-      uint32_t queued = 0u;
-      while (bits) {
-        const int b = __ffs((int)bits) - 1;
-        bits &= bits - 1u;
-        const uint32_t bit = ((uint32_t)w << 5) | (uint32_t)b;
-        const int bx = anx + (int)(bit & (WIN - 1)), by = any_ + (int)((bit >> WIN_LOG2) & (WIN - 1)), bz = anz + (int)(bit >> (2 * WIN_LOG2));
-        if (!slab_owns(P, bx, by, bz)) { queued |= 1u << b; continue; }  // another GPU's block: never ours, stop looking at it
-        if (!block_in_frustum(P, FL, bx, by, bz)) continue;  // a later frame may still want it
-        queued |= 1u << b;
-        const int pos = atomicAdd(&s_count, 1);
-        if (pos < LIST) { s_list[pos] = pack_key(bx, by, bz); s_birth[pos] = (uint8_t)j; }
-        else direct(pack_key(bx, by, bz), bx, by, bz, B.seq0 + (uint32_t)j);
-      }
-      if (MULTI && queued) s_done[w] |= queued;  // word w is only ever touched by this thread
-    }
+      if (ROUNDS > 1 && s_chooser == 256) break;   // uniform: no ray (left) to walk
+      const int anx = s_anchor[0], any_ = s_anchor[1], anz = s_anchor[2];
+      AT_MARK(1);
+#ifdef SF_ALLOC_TIMING
+      if (threadIdx.x == 0) atomicAdd(&g_alloc_t[9], 1ull);
 #endif
+
+      // ---- DDA: one LDS bit per visited block
+      bool left_window = false;
+#ifdef SF_ABLATE_ALLOC_WALK   // measurement only (the volume is WRONG): no DDA walk
+      if (false) {
+#else
+      if (pending) {
+#endif
+        int c_x = a_cx, c_y = a_cy, c_z = a_cz;   // (the ray's start stays: it may walk again)
+        float tmx = a_tmx, tmy = a_tmy, tmz = a_tmz;
+        uint64_t last_key = KEY_EMPTY;
+        for (int it = 0; it < MAX_DDA_ITERS; ++it) {
+          const uint32_t ux = (uint32_t)(c_x - anx), uy = (uint32_t)(c_y - any_), uz = (uint32_t)(c_z - anz);
+          const bool inwin = (ux | uy | uz) < (uint32_t)WIN;
+          const uint32_t bit = inwin ? ((uz << (2 * WIN_LOG2)) | (uy << WIN_LOG2) | ux) : 0xFFFFFFFFu;
+          // The 8x8 pixel patch of a wave mostly sits in ONE block: 64 ds_or to the same LDS word serialise.  Drop
+          // the lane when its left neighbour (DPP row_shr:1, free) sets the same bit; a disabled or out-of-row
+          // neighbour reads as "different" (old value, bound_ctrl off), so run heads always write.
+          const uint32_t left = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFEu, (int)bit, 0x111, 0xF, 0xF, false);
+          if (inwin) {
+            if (left != bit) atomicOr(&s_frame[bit >> 5], 1u << (bit & 31));
+          } else if (round + 1 < ROUNDS) {
+            left_window = true;   // walks again in the next round's window
+          } else {
+            const uint64_t key = pack_key(c_x, c_y, c_z);
+            if (key != last_key) {
+              last_key = key;
+              if (slab_owns(P, c_x, c_y, c_z) && block_in_frustum(P, FL, c_x, c_y, c_z)) {
+                uint32_t sl = ((uint32_t)(key ^ (key >> 21) ^ (key >> 42)) * 2654435761u) >> (32 - SET_LOG2);
+                bool placed = false;
+                for (int pr = 0; pr < ALLOC_SET_PROBES; ++pr) {
+                  const unsigned long long old = atomicCAS(&s_keys[sl], (unsigned long long)KEY_EMPTY, (unsigned long long)key);
+                  if (old == key) { placed = true; break; }  // queued by an earlier step / ray / frame
+                  if (old == KEY_EMPTY) {
+                    const int pos = atomicAdd(&s_count, 1);
+                    if (pos < LIST) { s_list[pos] = key; s_birth[pos] = (uint8_t)j; placed = true; }
+                    break;  // queue full: direct path below
+                  }
+                  sl = (sl + 1) & (SET - 1);
+                }
+                if (!placed) direct(key, c_x, c_y, c_z, B.seq0 + (uint32_t)j);
+              }
+            }
+          }
+          bool done;
+          if (tmx < tmy && tmx < tmz) { c_x += a_sx; done = (c_x == a_ex); tmx += a_tdx; }
+          else if (tmz < tmy) { c_z += a_sz; done = (c_z == a_ez); tmz += a_tdz; }
+          else { c_y += a_sy; done = (c_y == a_ey); tmy += a_tdy; }
+          if (done) break;
+        }
+      }
+      pending = left_window;
+      __syncthreads();
+      AT_MARK(2);
+      // ---- scan: blocks this frame visits that no earlier frame of the group queued -> frustum test -> queue
+#ifndef SF_ABLATE_ALLOC_SCAN   // measurement only (the volume is WRONG): no scan
+      for (int w = threadIdx.x; w < WIN_WORDS; w += 256) {
+        uint32_t bits = MULTI ? (s_frame[w] & ~s_done[w]) : s_frame[w];
+        uint32_t queued = 0u;
+        if (bits != 0u && bricks.e != nullptr) {
+          // the word's 32 x-consecutive blocks are 8 whole bricks: what the presence cache knows of them is in the table already and older than this batch --
+          // nothing to test, queue or probe for those (and nothing for a later frame of the group either)
+          const uint32_t bit0 = (uint32_t)w << 5;
+          const uint32_t known = brick_known_row(bricks, anx + (int)(bit0 & (WIN - 1)), any_ + (int)((bit0 >> WIN_LOG2) & (WIN - 1)), anz + (int)(bit0 >> (2 * WIN_LOG2)));
+          queued = bits & known;
+          bits &= ~known;
+        }
+        while (bits) {
+          const int b = __ffs((int)bits) - 1;
+          bits &= bits - 1u;
+          const uint32_t bit = ((uint32_t)w << 5) | (uint32_t)b;
+          const int bx = anx + (int)(bit & (WIN - 1)), by = any_ + (int)((bit >> WIN_LOG2) & (WIN - 1)), bz = anz + (int)(bit >> (2 * WIN_LOG2));
+          if (!slab_owns(P, bx, by, bz)) { queued |= 1u << b; continue; }  // another GPU's block: never ours, stop looking at it
+          if (!block_in_frustum(P, FL, bx, by, bz)) continue;  // a later frame may still want it
+          queued |= 1u << b;
+          const int pos = atomicAdd(&s_count, 1);
+          if (pos < LIST) { s_list[pos] = pack_key(bx, by, bz); s_birth[pos] = (uint8_t)j; }
+          else direct(pack_key(bx, by, bz), bx, by, bz, B.seq0 + (uint32_t)j);
+        }
+        if (MULTI && queued) s_done[w] |= queued;  // word w is only ever touched by this thread
+      }
+#endif
+      if (ROUNDS > 1) {   // the queue is emptied between rounds
+        __syncthreads();
+        AT_MARK(3);
+        drain();
+        __syncthreads();
+        AT_MARK(4);
+        if (threadIdx.x == 0) s_count = 0;
+      }
+    }
   }
   __syncthreads();
-
-  // ---- phase 2: queued keys -> global hash, all lanes in parallel
-#ifdef SF_ABLATE_ALLOC_PHASE2   // measurement only (the volume is WRONG): no table probes
-  const int n_unique = 0;
-#else
-  const int n_unique = min(s_count, LIST);
-#endif
-  for (int i0 = 0; i0 < n_unique; i0 += 256) {
-    const int i = i0 + threadIdx.x;
-    const uint64_t key = i < n_unique ? s_list[i] : KEY_EMPTY;
-    HashEntry* claimed = nullptr;
-    if (key != KEY_EMPTY) {
-      int bx, by, bz;
-      unpack_key(key, bx, by, bz);
-      claimed = hash_find_or_claim(h, P, key, bx, by, bz, B.seq0 + (uint32_t)s_birth[i]);
-    }
-    // wave-aggregated heap pop for the freshly claimed slots
-    const uint64_t cm = __ballot(claimed != nullptr);
-    if (cm != 0ull) {
-      const int n = __popcll((unsigned long long)cm);
-      const int first = __ffsll((unsigned long long)cm) - 1;
-      int base = 0;
-      if (lane == first) {
-        base = atomicSub(&counters[C_HEAP_FREE], n);
-        atomicAdd(&counters[C_SLOTS_USED], n);
-      }
-      base = __shfl(base, first);
-      if (claimed != nullptr) {
-        const int rank = __popcll((unsigned long long)(cm & ((1ull << lane) - 1ull)));
-        give_block(h, claimed, key, base - 1 - rank);
-      }
-    }
-  }
-  for (int o = 32; o > 0; o >>= 1) n_direct += __shfl_xor(n_direct, o);
+  AT_MARK(3);
+  drain();
+  for (int o = 32; o > 0; o >>= 1) { n_direct += __shfl_xor(n_direct, o); n_probed += __shfl_xor(n_probed, o); }
   if (lane == 0 && n_direct) atomicAdd(&counters[C_ALLOC_DIRECT], n_direct);
+  if (lane == 0 && n_probed) atomicAdd(&counters[C_ALLOC_PROBED], n_probed);
+#ifdef SF_ALLOC_TIMING
+  __syncthreads();
+  AT_MARK(4);
+  if (threadIdx.x == 0) {
+    atomicAdd(&g_alloc_t[5], at_prev_ - at_start_);
+    atomicMax(&g_alloc_t[8], at_prev_ - at_start_);
+    atomicAdd(&g_alloc_t[10], 1ull);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -617,7 +733,7 @@ template <bool MULTI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SF_ALLOC_WAVES_MIN, 8))) void k_alloc_ray(const float* __restrict__ depthf_all, HashEntry* table, int32_t* heap,
                                                    uint64_t* block_keys, int32_t* block_entry, uint8_t* block_flags, int32_t* counters, ParamsK P,
                                                    BatchFrames B, int group_frames, int ablate, const uint16_t* __restrict__ fuse_depth16,
-                                                   float* depthf_out, int compact_counter) {
+                                                   float* depthf_out, int compact_counter, BrickCache bricks) {
   // ablate (tune "alloc_ablate", measurements only -- the volume is wrong with any bit set): 1 no LDS atomics, 2 no scan, 4 no DDA walk, 8 no barriers
   // fuse_depth16 != nullptr (one frame per pass, no colour, no resampling: a live stream): the kernel is ALSO the depth pre-pass -- every lane
   // converts its own pixel (k_prepass's arithmetic), stores it for the integrate kernel's gathers and walks it; one launch and one
@@ -634,7 +750,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SF_ALLOC_WA
   if (threadIdx.x == 0) s_count = 0;
   const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
   const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
-  const HashRefs h{table, heap, block_keys, block_entry, block_flags, counters};
+  const HashRefs h{table, heap, block_keys, block_entry, block_flags, counters, bricks, B.seq0};
   for (int i = threadIdx.x; i < ALLOC_SET; i += 256) s_keys[i] = KEY_EMPTY;
   for (int i = threadIdx.x; i < RW_WORDS / 4; i += 256) s_frame4[i] = make_uint4(0, 0, 0, 0);
   if (MULTI)
@@ -644,8 +760,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SF_ALLOC_WA
   const int j_end = min(B.n, j_begin + group_frames);
 
   int n_direct = 0;   // sf_fuser_alloc_direct_count (added up once per wave at the end: one atomic per call on a single word halved the 1 mm front chain)
+  int n_probed = 0;   // look-ups that went to the hash table (the presence cache did not answer): sf_fuser_alloc_probe_count
   auto direct = [&](uint64_t key, int bx, int by, int bz, uint32_t seq) {
     n_direct++;
+    if (h.bricks.e != nullptr && brick_known(h.bricks, bx, by, bz)) return;
+    n_probed++;
     HashEntry* e = hash_find_or_claim(h, P, key, bx, by, bz, seq);
     if (e) {
       atomicAdd(&counters[C_SLOTS_USED], 1);
@@ -919,7 +1038,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SF_ALLOC_WA
     if (key != KEY_EMPTY) {
       int bx, by, bz;
       unpack_key(key, bx, by, bz);
-      claimed = hash_find_or_claim(h, P, key, bx, by, bz, B.seq0 + (uint32_t)s_birth[i]);
+      if (h.bricks.e == nullptr || !brick_known(h.bricks, bx, by, bz)) {
+        n_probed++;
+        claimed = hash_find_or_claim(h, P, key, bx, by, bz, B.seq0 + (uint32_t)s_birth[i]);
+      }
     }
     const uint64_t cm = __ballot(claimed != nullptr);
     if (cm != 0ull) {
@@ -937,8 +1059,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SF_ALLOC_WA
       }
     }
   }
-  for (int o = 32; o > 0; o >>= 1) n_direct += __shfl_xor(n_direct, o);
+  for (int o = 32; o > 0; o >>= 1) { n_direct += __shfl_xor(n_direct, o); n_probed += __shfl_xor(n_probed, o); }
   if (lane == 0 && n_direct) atomicAdd(&counters[C_ALLOC_DIRECT], n_direct);
+  if (lane == 0 && n_probed) atomicAdd(&counters[C_ALLOC_PROBED], n_probed);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2129,15 +2252,16 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
     // WIN 64 (32 KiB bitmap): a second bitmap of that size makes the workgroup 102 KiB -- one per CU; tune "alloc_group_win64" (default 1: one frame per workgroup)
     const int gf = (f->alloc_win64 && !f->alloc_ray) ? std::min(f->alloc_group_win64, n) : std::min(group, n);
     const dim3 ag((f->p.depth_width + 15) / 16, (f->p.depth_height + 15) / 16, (n + gf - 1) / gf);
+    const BrickCache bc{f->brick_on ? f->bricks : nullptr, f->brick_lines - 1u};
 #define LAUNCH_ALLOC(WL, MU) \
-  hipLaunchKernelGGL((k_alloc<WL, MU>), ag, dim3(256), 0, sa, f->depthf2[sl], f->table, f->heap, f->block_keys, f->block_entry, f->block_flags, f->counters, f->pk, bf, gf)
+  hipLaunchKernelGGL((k_alloc<WL, MU>), ag, dim3(256), 0, sa, f->depthf2[sl], f->table, f->heap, f->block_keys, f->block_entry, f->block_flags, f->counters, f->pk, bf, gf, bc)
     // alloc_wgs > 0: at most that many allocation workgroups per CU, by asking for LDS the kernel does not use (160 KiB per CU).  The kernel
     // is latency-bound (barriers, LDS atomics: 35 % VALU utilisation) and, unthrottled, parks 4-5 waves of 72 VGPRs on every SIMD for ~200 us of
     // each pass -- registers the integrate kernel next to it needs for ITS waves (timeline: profiles/r03_timeline_*.txt)
     const unsigned alloc_pad = (f->alloc_wgs > 0 && n > 1) ? (unsigned)std::max(0, (160 * 1024) / (f->alloc_wgs + 1) + 1024 - 23048) : 0u;
 #define LAUNCH_ALLOC_RAY(MU) \
   hipLaunchKernelGGL((k_alloc_ray<MU>), ag, dim3(256), alloc_pad, sa, f->depthf2[sl], f->table, f->heap, f->block_keys, f->block_entry, f->block_flags, f->counters, f->pk, bf, gf, f->alloc_ablate, \
-                     fuse_pre ? in.depth[0] : (const uint16_t*)nullptr, f->depthf2[sl], cc)
+                     fuse_pre ? in.depth[0] : (const uint16_t*)nullptr, f->depthf2[sl], cc, bc)
     if (f->alloc_ray) { if (gf == 1) LAUNCH_ALLOC_RAY(false); else LAUNCH_ALLOC_RAY(true); }
     else if (f->alloc_win64) { if (gf == 1) LAUNCH_ALLOC(6, false); else LAUNCH_ALLOC(6, true); }
     else if (gf == 1) LAUNCH_ALLOC(5, false);
@@ -2361,6 +2485,14 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
   }
   SF_CREATE_CHECK(hipEventCreateWithFlags(&f->ev_input, hipEventDisableTiming));
   SF_ALLOC(f->table, (size_t)k.total_slots * sizeof(HashEntry));
+  {
+    // one entry per 8 heap blocks, 8 entries per line: 2 MB at 2^20 blocks (4 mm), 64 MB at 2^25 (1 mm) -- what a frame touches of it is ~100 x less than
+    // the table entries it would probe
+    uint32_t lines = 1024;
+    while ((uint64_t)lines * 64ull < (uint64_t)k.num_blocks && lines < (1u << 24)) lines <<= 1;
+    f->brick_lines = lines;
+    SF_ALLOC(f->bricks, (size_t)lines * 8 * 16);
+  }
   SF_ALLOC(f->heap, (size_t)k.num_blocks * 4);
   SF_ALLOC(f->block_keys, (size_t)k.num_blocks * 8);
   SF_ALLOC(f->block_entry, (size_t)k.num_blocks * 4);
@@ -2391,6 +2523,7 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
   SF_CREATE_CHECK(hipHostMalloc((void**)&f->host_mirror, 64, hipHostMallocMapped));
   *f->host_mirror = 0;
   SF_CREATE_CHECK(hipMemsetAsync(f->table, 0xFF, (size_t)k.total_slots * sizeof(HashEntry), f->stream));
+  SF_CREATE_CHECK(hipMemsetAsync(f->bricks, 0, (size_t)f->brick_lines * 128, f->stream));
   SF_CREATE_CHECK(hipMemsetAsync(f->voxels, 0, (size_t)k.num_blocks * 4096, f->stream));
   SF_CREATE_CHECK(hipMemsetAsync(f->block_flags, 0, (size_t)k.num_blocks, f->stream));
   SF_CREATE_CHECK(hipMemsetAsync(f->counters, 0, C_COUNT * 4, f->stream));
@@ -2410,7 +2543,7 @@ SF_API void sf_fuser_destroy(sf_fuser* f) {
   if (f->front) (void)hipStreamSynchronize(f->front);   // both streams drained before ANYTHING they read or write goes (the host-frame ring's
   if (f->stream) (void)hipStreamSynchronize(f->stream); // page-locked slots are read by copies queued on either of them)
   for (auto& e : f->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-  (void)hipFree(f->table); (void)hipFree(f->heap); (void)hipFree(f->block_keys); (void)hipFree(f->block_entry); (void)hipFree(f->block_flags); (void)hipFree(f->voxels);
+  (void)hipFree(f->table); (void)hipFree(f->bricks); (void)hipFree(f->heap); (void)hipFree(f->block_keys); (void)hipFree(f->block_entry); (void)hipFree(f->block_flags); (void)hipFree(f->voxels);
   for (int q = 0; q < 2; q++) { (void)hipFree(f->depthf2[q]); (void)hipFree(f->color2[q]); (void)hipFree(f->compact2[q]); (void)hipFree(f->cmask2[q]); }
   (void)hipFree(f->counters); (void)hipFree(f->ray_kx); (void)hipFree(f->ray_ky);
   for (int q = 0; q < 2; q++) { if (f->ev_compact[q]) (void)hipEventDestroy(f->ev_compact[q]); if (f->ev_fused[q]) (void)hipEventDestroy(f->ev_fused[q]); }
@@ -2442,6 +2575,7 @@ SF_API int sf_fuser_reset(sf_fuser* f) {
   const ParamsK& k = f->pk;
   if (hw < 0 || (uint32_t)hw > k.num_blocks) hw = (int32_t)k.num_blocks;
   SF_HIP_CHECK(hipMemsetAsync(f->table, 0xFF, (size_t)k.total_slots * sizeof(HashEntry), f->stream));
+  SF_HIP_CHECK(hipMemsetAsync(f->bricks, 0, (size_t)f->brick_lines * 128, f->stream));
   if (hw > 0) {
     SF_HIP_CHECK(hipMemsetAsync(f->voxels, 0, (size_t)hw * 4096, f->stream));
     SF_HIP_CHECK(hipMemsetAsync(f->block_flags, 0, (size_t)hw, f->stream));
@@ -2632,6 +2766,11 @@ SF_API int sf_fuser_tune(sf_fuser* f, const char* key, int value) {
   else if (k == "ramp_geo" && in(0, 1)) f->ramp_geo = value != 0;
   else if (k == "tail_wide" && in(0, 1)) f->tail_wide = value;
   else if (k == "xrow" && in(0, 1)) f->xrow = value != 0;
+  else if (k == "brick_cache" && in(0, 1)) {   // 0: every look-up of the allocation kernels probes the table
+    f->brick_on = value != 0;
+    SF_HIP_CHECK(hipMemsetAsync(f->bricks, 0, (size_t)f->brick_lines * 128, f->stream));
+    SF_HIP_CHECK(sf_quiesce(f));
+  }
   else return sf::fail(SF_ERR_INVALID_ARG, "sf_fuser_tune: unknown key or value out of range: %s = %d", key, value);
   return SF_OK;
 }
@@ -2688,6 +2827,29 @@ SF_API int sf_fuser_alloc_direct_count(sf_fuser* f, uint64_t* out) {
   *out = (uint64_t)(uint32_t)c;
   return SF_OK;
 }
+
+SF_API int sf_fuser_alloc_probe_count(sf_fuser* f, uint64_t* out) {
+  if (!f || !out) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  SF_HIP_CHECK(hipSetDevice(f->device));
+  SF_HIP_CHECK(sf_quiesce(f));
+  int32_t c = 0;
+  SF_HIP_CHECK(hipMemcpy(&c, &f->counters[C_ALLOC_PROBED], 4, hipMemcpyDeviceToHost));
+  *out = (uint64_t)(uint32_t)c;
+  return SF_OK;
+}
+
+#ifdef SF_ALLOC_TIMING
+// measurement build only: the 16 words of g_alloc_t, cleared behind the read
+SF_API int sf_alloc_timing_read(sf_fuser* f, uint64_t* out16) {
+  if (!f || !out16) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  SF_HIP_CHECK(hipSetDevice(f->device));
+  SF_HIP_CHECK(sf_quiesce(f));
+  SF_HIP_CHECK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_alloc_t), 16 * 8));
+  unsigned long long z[16] = {};
+  SF_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_alloc_t), z, 16 * 8));
+  return SF_OK;
+}
+#endif
 
 SF_API int sf_fuser_profile_enable(sf_fuser* f, int on) {
   if (!f) return sf::fail(SF_ERR_INVALID_ARG, "NULL fuser");
@@ -2829,6 +2991,7 @@ SF_API int sf_fuser_garbage_collect(sf_fuser* f, uint32_t* freed) {
   if (fr > 0) {   // leave no tombstone behind: rebuild the table from the directory
     SF_HIP_CHECK(hipMemcpyAsync(&fail0, &f->counters[C_ALLOC_FAIL], 4, hipMemcpyDeviceToHost, f->stream));
     SF_HIP_CHECK(hipMemsetAsync(f->table, 0xFF, (size_t)f->pk.total_slots * sizeof(HashEntry), f->stream));
+    SF_HIP_CHECK(hipMemsetAsync(f->bricks, 0, (size_t)f->brick_lines * 128, f->stream));   // blocks left the table: the presence cache starts again
     SF_HIP_CHECK(hipMemsetAsync(&f->counters[C_SLOTS_USED], 0, 4, f->stream));
     hipLaunchKernelGGL(k_rehash, dim3(f->compact_grid), dim3(256), 0, f->stream, f->table, f->block_keys, f->block_entry, f->counters, f->pk);
     SF_HIP_CHECK(hipMemcpyAsync(&fail1, &f->counters[C_ALLOC_FAIL], 4, hipMemcpyDeviceToHost, f->stream));

@@ -105,6 +105,7 @@ enum Counter {
   C_LAST_BLOCKS = 5,
   C_GC_FREED = 7,
   C_IMPORTED = 8,
+  C_ALLOC_PROBED = 10,  // look-ups of the allocation kernels that went to the hash table (not answered by the presence cache)
   C_ALLOC_DIRECT = 9,   // blocks an allocation workgroup could not queue in LDS and took to the global table one by one (the slow path)
   // 64-bit compaction counters (8-byte aligned, own cache line): low word = entries in the compact list,
   // high word = blocks the LAST frame of the batch updates
@@ -134,6 +135,66 @@ __device__ inline uint32_t hash_bucket(int x, int y, int z, uint32_t num_buckets
 // 1 mm fall on a few hundred cache lines: linear probing over clustered starts makes long runs wherever two bricks meet, and every look-up got slower:
 // one frame per launch 10.2 k -> 8.8 k frames/s at 4 mm, 324 -> 260 at 1 mm.  profiles/r06_alloc_1mm.txt)
 __device__ inline uint32_t hash_home(const ParamsK& P, int x, int y, int z) { return hash_bucket(x, y, z, P.num_buckets) * P.bucket_size; }
+
+// ---------------------------------------------------------------------------------------------------
+// Presence cache of the allocation kernels ("bricks", round 6).  A frame names every block of its truncation band -- 1.55 M at 1 mm voxels -- and all but the
+// ~1 % the camera's motion adds exist already; finding that out cost one probe of the hash table per block and frame: random 16-byte reads of a 671 MB table,
+// 1.7 of k_alloc<6>'s 2.1 ms (profiles/r06_alloc_1mm.txt).  The cache answers "this block is in the table, and was before this batch began" from a structure
+// whose footprint per frame is ~100 x smaller: one 16-byte entry {tag, 64-bit mask} per 4x4x4-block BRICK, direct-mapped, the 8 x-consecutive bricks of a
+// row in one 128-byte line (a word of the cube window's occupancy bitmap = 32 x-consecutive blocks = that row: one or two lines answer the whole word).
+//   * it only ever says "present" for a block some lane FOUND in the table with a birth frame before its own batch (hash_find_or_claim): such a block needs
+//     neither a slot nor a birth update from any later frame, so skipping the probe changes nothing -- the allocated set and every birth frame stay the
+//     same, bit for bit (tests/test_gpu_tsdf.py runs every allocation test with the cache on and off);
+//   * within a launch a tag goes 0 -> brick once (CAS) and never changes, mask bits are only ever set, and only behind a matching tag: a reader that sees a
+//     stale line misses and probes the table as before; conflicts (another brick owns the entry) are simply not cached;
+//   * whatever removes entries from the table (garbage collection, reset) clears the cache in stream order.
+// ---------------------------------------------------------------------------------------------------
+struct BrickCache {
+  unsigned long long* e;   // {tag, mask} pairs; nullptr: no cache
+  uint32_t line_mask;      // lines - 1 (a line = 8 entries)
+};
+#ifdef __HIPCC__   // (the host-only sanitizer builds of tools/tsan include this header with g++)
+constexpr unsigned long long BRICK_TAG = 1ull << 63;   // pack_key uses 63 bits: a live tag is never 0, the cleared state
+__device__ inline unsigned long long brick_tag(int X, int Y, int Z) { return pack_key(X, Y, Z) | BRICK_TAG; }
+__device__ inline uint32_t brick_index(uint32_t line_mask, int X, int Y, int Z) {
+  uint32_t h = ((uint32_t)(X >> 3) * 73856093u) ^ ((uint32_t)Y * 19349669u) ^ ((uint32_t)Z * 83492791u);
+  h ^= h >> 15;
+  return ((h & line_mask) << 3) | ((uint32_t)X & 7u);
+}
+__device__ inline uint32_t brick_bit(int bx, int by, int bz) { return (uint32_t)((bx & 3) | ((by & 3) << 2) | ((bz & 3) << 4)); }
+// "block (bx, by, bz) is in the table and was born before this batch"
+__device__ inline bool brick_known(const BrickCache& c, int bx, int by, int bz) {
+  const int X = bx >> 2, Y = by >> 2, Z = bz >> 2;
+  const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(c.e + 2 * (size_t)brick_index(c.line_mask, X, Y, Z));
+  return v.x == brick_tag(X, Y, Z) && ((v.y >> brick_bit(bx, by, bz)) & 1ull) != 0ull;
+}
+// the same for the 32 x-consecutive blocks bx0 .. bx0 + 31 (bx0 a multiple of 4) of row (by, bz): bit i = block bx0 + i is known
+__device__ inline uint32_t brick_known_row(const BrickCache& c, int bx0, int by, int bz) {
+  const int X0 = bx0 >> 2, Y = by >> 2, Z = bz >> 2;
+  const uint32_t off = (uint32_t)(((by & 3) << 2) | ((bz & 3) << 4));
+  uint32_t known = 0u;
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(c.e + 2 * (size_t)brick_index(c.line_mask, X0 + q, Y, Z));
+    const uint32_t nib = v.x == brick_tag(X0 + q, Y, Z) ? (uint32_t)(v.y >> off) & 0xFu : 0u;
+    known |= nib << (4 * q);
+  }
+  return known;
+}
+// a lane found the block in the table, born before this batch: remember it
+__device__ inline void brick_note(const BrickCache& c, int bx, int by, int bz) {
+  const int X = bx >> 2, Y = by >> 2, Z = bz >> 2;
+  unsigned long long* e = c.e + 2 * (size_t)brick_index(c.line_mask, X, Y, Z);
+  const unsigned long long tag = brick_tag(X, Y, Z);
+  unsigned long long t = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (t == 0ull) {
+    t = atomicCAS(e, 0ull, tag);
+    if (t == 0ull) t = tag;
+  }
+  if (t == tag) atomicOr(e + 1, 1ull << brick_bit(bx, by, bz));   // no return value wanted: fire and forget
+}
+
+#endif  // __HIPCC__
 
 // lookup only: heap slot of block (x,y,z) or -1
 __device__ inline int hash_lookup(const HashEntry* __restrict__ table, const ParamsK& P, int x, int y, int z) {
@@ -236,6 +297,9 @@ struct sf_fuser {
   uint32_t frame_seq = 1;                      // sequence number of the next frame
   int batch = DEFAULT_BATCH;                   // frames per pass (sf_fuser_tune "batch", 1..MAX_BATCH)
   HashEntry* table = nullptr;
+  unsigned long long* bricks = nullptr;        // presence cache of the allocation kernels: brick_lines x 8 entries of {tag, mask} (BrickCache above)
+  uint32_t brick_lines = 0;
+  bool brick_on = true;                        // tune "brick_cache" 0: every look-up probes the table (rounds 1-5)
   int32_t* heap = nullptr;
   uint64_t* block_keys = nullptr;
   uint4* voxels = nullptr;

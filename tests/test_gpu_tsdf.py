@@ -838,6 +838,72 @@ def test_allocation_kernels_on_a_furnished_scene(oracle, alloc_ray):
             dev.close()
 
 
+def _probe_count(f):
+    import ctypes as C
+    from scannet_amd import _abi
+    L = _abi.lib()
+    L.sf_fuser_alloc_probe_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    n = C.c_uint64(0)
+    _abi.check(L.sf_fuser_alloc_probe_count(f._h, C.byref(n)))
+    return n.value
+
+
+@pytest.mark.parametrize("kernel", ["ray", "cube32", "cube64"])
+def test_presence_cache_changes_nothing_but_the_probes(oracle, kernel):
+    """The allocation kernels' presence cache (fuser_internal.h BrickCache: "this block is in the table and older than this batch") on and off, on the
+    three allocation kernels, one frame per launch and 32 per pass: the same block set, birth frames (hence voxels) as the oracle either way -- also across a
+    deintegration + garbage collection that takes blocks OUT of the table (the cache must forget them: the frames fused afterwards allocate them again) --
+    and, one frame per launch, a fraction of the table probes."""
+    from scannet_amd import fusion
+    # cube64: voxels small enough for the 64^3-block window (k_alloc<6>: a ray segment of more than 20 blocks), on a small image to keep the oracle quick
+    W, H = (128, 96) if kernel == "cube64" else (320, 240)
+    boxes = synth.clutter_boxes()
+    idx = list(range(0, 36)) + [400, 401, 402, 37, 38, 39]
+    depth = np.zeros((len(idx), H, W), np.uint16)
+    poses = np.zeros((len(idx), 16), np.float32)
+    for k, i in enumerate(idx):
+        pose = synth.trajectory_pose(i, 1200)
+        depth[k] = synth.render_room_depth(pose, W, H, noise_frame=i, noise=2, boxes=boxes)
+        poses[k] = pose.reshape(16)
+    voxel = 0.0015 if kernel == "cube64" else 0.008
+    over = dict(num_sdf_blocks=1 << 20, hash_num_buckets=1 << 20) if kernel == "cube64" else dict(num_sdf_blocks=1 << 17)
+    op, gp = _mk(oracle, W, H, voxel=voxel, **over)
+    ovol = oracle.Volume(op, threads=8)
+    n_first = 30
+    for k in range(n_first):
+        ovol.integrate(depth[k], poses[k].reshape(4, 4))
+    oc0, ov0 = ovol.export()
+    for k in range(20, n_first):
+        ovol.deintegrate(depth[k], poses[k].reshape(4, 4))
+    freed = ovol.garbage_collect()
+    assert freed > 0
+    for k in range(n_first, len(idx)):
+        ovol.integrate(depth[k], poses[k].reshape(4, 4))
+    dev = _DeviceFrames(depth)
+    probes = {}
+    try:
+        for batch in (1, 32):
+            for cache in (1, 0):
+                tune = dict(batch=batch, brick_cache=cache)
+                if kernel != "cube64":
+                    tune["alloc_ray"] = 1 if kernel == "ray" else 0
+                with fusion.Fuser(gp, **tune) as f:
+                    dev.fuse(f, poses, 0, n_first)
+                    gc0, gv0 = f.export_blocks()
+                    assert np.array_equal(oc0, gc0) and np.array_equal(ov0.view(np.uint8), gv0.view(np.uint8)), (kernel, tune)
+                    probes[(batch, cache)] = _probe_count(f)
+                    for k in range(20, n_first):
+                        assert f.deintegrate(depth[k], poses[k].reshape(4, 4))
+                    assert f.garbage_collect() == freed
+                    dev.fuse(f, poses, n_first, len(idx))
+                    assert f.stats()["alloc_failures"] == 0
+                    _assert_same(ovol, f)
+        assert probes[(1, 1)] * 3 < probes[(1, 0)], probes   # one frame per launch: all but the new blocks and the previous frame's are answered by the cache
+        assert probes[(32, 1)] <= probes[(32, 0)], probes
+    finally:
+        dev.close()
+
+
 def test_ray_space_allocation_at_full_size_on_the_furnished_stream(oracle):
     """640x480, 4 mm, the furnished bench stream with hashed noise and sensor holes: 48 frames through the default schedule, bit for bit."""
     from scannet_amd import fusion
