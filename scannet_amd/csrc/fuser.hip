@@ -276,9 +276,10 @@ __device__ inline uint32_t note_birth(HashEntry* e, uint32_t seq) {
 }
 
 // find-or-claim `key`; returns the claimed entry (needs a heap block) or nullptr (already present / table full)
-__device__ inline HashEntry* hash_find_or_claim(const HashRefs& h, const ParamsK& P, uint64_t key, int bx, int by, int bz, uint32_t seq) {
-  uint32_t slot = hash_home(P, bx, by, bz);
-  for (int probe = 0; probe < MAX_PROBES; ++probe) {
+__device__ inline HashEntry* hash_find_or_claim(const HashRefs& h, const ParamsK& P, uint64_t key, int bx, int by, int bz, uint32_t seq, int probe0 = 0) {
+  uint32_t slot = hash_home(P, bx, by, bz) + (uint32_t)probe0;   // (probe0 > 0: the caller has looked at the first probe0 slots itself)
+  if (slot >= P.total_slots) slot -= P.total_slots;
+  for (int probe = probe0; probe < MAX_PROBES; ++probe) {
     HashEntry* e = h.table + slot;
     const uint64_t k = __hip_atomic_load(&e->key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (k == key) {
@@ -288,7 +289,7 @@ __device__ inline HashEntry* hash_find_or_claim(const HashRefs& h, const ParamsK
     }
     if (k == KEY_EMPTY) {
       const uint64_t old = atomicCAS((unsigned long long*)&e->key, (unsigned long long)KEY_EMPTY, (unsigned long long)key);
-      if (old == KEY_EMPTY) { note_birth(e, seq); return e; }
+      if (old == KEY_EMPTY) { atomicMin(&e->birth, seq); return e; }   // (ours: no need to look at the birth frame first -- one round trip less in a chain of four)
       if (old == key) { note_birth(e, seq); return nullptr; }
     }
     slot++;
@@ -298,27 +299,35 @@ __device__ inline HashEntry* hash_find_or_claim(const HashRefs& h, const ParamsK
   return nullptr;
 }
 
-__device__ inline void give_block(const HashRefs& h, HashEntry* e, uint64_t key, int at) {
+// hands heap position `at` to the claimed entry; returns the block's index + 1 for the caller's high-water mark (0: heap exhausted)
+__device__ inline int give_block_quiet(const HashRefs& h, HashEntry* e, uint64_t key, int at) {
   if (at >= 0) {
     const int idx = h.heap[at];
     e->ptr = idx;
     h.block_keys[idx] = key;
     h.block_entry[idx] = (int32_t)(e - h.table);
     h.block_flags[idx] = 0;
-    atomicMax(&h.counters[C_HIGH_WATER], idx + 1);
-  } else {
-    // heap exhausted: the entry stays claimed without a block; undo the pop
-    atomicAdd(&h.counters[C_HEAP_FREE], 1);
-    atomicAdd(&h.counters[C_ALLOC_FAIL], 1);
+    return idx + 1;
   }
+  // heap exhausted: the entry stays claimed without a block; undo the pop
+  atomicAdd(&h.counters[C_HEAP_FREE], 1);
+  atomicAdd(&h.counters[C_ALLOC_FAIL], 1);
+  return 0;
 }
+// the high-water mark only moves while the heap still hands out blocks it never handed out before: ask first (a load the L2 answers), an atomic on the
+// one word every workgroup shares only when it has to move
+__device__ inline void raise_high_water(const HashRefs& h, int hw) {
+  if (hw > __hip_atomic_load(&h.counters[C_HIGH_WATER], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&h.counters[C_HIGH_WATER], hw);
+}
+__device__ inline void give_block(const HashRefs& h, HashEntry* e, uint64_t key, int at) { raise_high_water(h, give_block_quiet(h, e, key, at)); }
 
 // -DSF_ALLOC_TIMING (measurement build, tools/gpu/alloc_1mm_probe.py): where a workgroup of k_alloc spends its time -- thread 0 adds the 100 MHz clock between
 // the barriers that separate the phases into g_alloc_t (sf_alloc_timing_read): [0] zeroing + ray set-up, [1] anchoring, [2] walk, [3] scan, [4] drain, [5] whole
 // workgroup, [8] the longest workgroup, [9] rounds walked, [10] workgroups
 #ifdef SF_ALLOC_TIMING
 __device__ unsigned long long g_alloc_t[16];
-#define AT_MARK(i) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_alloc_t[i], now_ - at_prev_); at_prev_ = now_; } } while (0)
+__device__ unsigned int g_alloc_log[1 + 256 * 12];   // workgroups that took more than 250 us: [0] how many, then 12 words each (sf_alloc_timing_log)
+#define AT_MARK(i) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_alloc_t[i], now_ - at_prev_); at_ph_[i] += (unsigned)(now_ - at_prev_); at_prev_ = now_; } } while (0)
 #else
 #define AT_MARK(i) do { } while (0)
 #endif
@@ -348,6 +357,7 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_
   __shared__ int s_anchored;
   __shared__ int s_anchor[3];
   __shared__ int s_box[6];
+  __shared__ int s_claimed, s_pop_base;   // drain(): entries claimed by the workgroup in this call, and where its blocks start in the heap
   // the current frame's constants for the frustum tests of the scan (and of rays outside the window), two frames' worth so that a frame's copy never lands
   // under the previous frame's readers.  Read as B.f[j] they come through the scalar unit from the kernarg segment, a few words per load, each load a round
   // trip the wave waits for: at 1 mm voxels a tile names ~1 300 blocks per frame and a wave of k_alloc<6> spent its life -- 610 scalar loads, three quarters
@@ -356,6 +366,7 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_
 #ifdef SF_ALLOC_TIMING
   unsigned long long at_prev_ = wall_clock64();
   const unsigned long long at_start_ = at_prev_;
+  unsigned at_ph_[5] = {0, 0, 0, 0, 0}, at_rounds_ = 0, at_queued_ = 0;
 #endif
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -385,45 +396,103 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_
     }
   };
 
-  // ---- phase 2: queued keys -> global hash, all lanes in parallel (callers put a barrier between the last queue write and this)
+  // ---- phase 2: queued keys -> global hash, all lanes in parallel (callers put a barrier between the last queue write and this; every thread calls it)
+  // The heap is popped ONCE per workgroup and call: the entries the lanes claimed are first packed into LDS (their table slots, 4 bytes each, over the keys
+  // already read), then one atomic on the heap's free count serves them all.  Popped per wave and iteration -- and the high-water mark raised per lane --
+  // the three words every workgroup of the launch shares were what a tile of a newly seen surface waited for: at 1 mm voxels ~1 900 new blocks, 8 iterations,
+  // 25 us each; such workgroups (3 % of them) took 200 - 800 us where the mean is 59, and the longest one IS the kernel (profiles/r06_alloc_1mm.txt).
   auto drain = [&]() {
 #ifdef SF_ABLATE_ALLOC_PHASE2   // measurement only (the volume is WRONG): no table probes
     const int n_unique = 0;
 #else
     const int n_unique = min(s_count, LIST);
 #endif
-    for (int i0 = 0; i0 < n_unique; i0 += 256) {
-      const int i = i0 + threadIdx.x;
-      const uint64_t key = i < n_unique ? s_list[i] : KEY_EMPTY;
-      HashEntry* claimed = nullptr;
-      if (key != KEY_EMPTY) {
+    uint32_t* const s_ent = reinterpret_cast<uint32_t*>(s_list);
+    if (threadIdx.x == 0) s_claimed = 0;
+    // DU keys per lane and iteration, their first probes side by side: the table is 16-byte entries scattered over hundreds of megabytes, a look-up is a chain
+    // of round trips (the key, the compare-and-swap, the birth frame), and a chain at a time kept a tile of ~4 000 new blocks 13 us per 256 keys
+    constexpr int DU = 4;
+    for (int i0 = 0; i0 < n_unique; i0 += 256 * DU) {
+      uint64_t key[DU], k0[DU];
+      uint32_t seq[DU];
+      HashEntry* e0[DU];
+      HashEntry* claimed[DU];
+      bool live[DU], won[DU];
+#pragma unroll
+      for (int u = 0; u < DU; u++) {
+        const int i = i0 + u * 256 + (int)threadIdx.x;
+        key[u] = i < n_unique ? s_list[i] : KEY_EMPTY;
+        const uint32_t bi = i < n_unique ? s_birth[i] : 0u;   // bit 7: queued by a ray outside the window -- the presence cache has not been asked about this block yet
+        seq[u] = B.seq0 + (bi & 0x7Fu);
+        live[u] = key[u] != KEY_EMPTY;
+        claimed[u] = nullptr;
         int bx, by, bz;
-        unpack_key(key, bx, by, bz);
-        if (h.bricks.e == nullptr || !brick_known(h.bricks, bx, by, bz)) {
-          n_probed++;
-          claimed = hash_find_or_claim(h, P, key, bx, by, bz, B.seq0 + (uint32_t)s_birth[i]);
+        unpack_key(key[u], bx, by, bz);
+        if (live[u] && (bi & 0x80u) != 0u && h.bricks.e != nullptr && brick_known(h.bricks, bx, by, bz)) live[u] = false;   // (the scan queues only what the cache does not know)
+        e0[u] = h.table + hash_home(P, bx, by, bz);
+        k0[u] = live[u] ? __hip_atomic_load(&e0[u]->key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        if (live[u]) n_probed++;
+      }
+      __syncthreads();   // the keys of this iteration are in registers: the packed entries (never more than the keys read so far, half their size) may grow over them
+#pragma unroll
+      for (int u = 0; u < DU; u++)   // an empty home slot: try to take it
+        won[u] = live[u] && k0[u] == KEY_EMPTY && atomicCAS((unsigned long long*)&e0[u]->key, (unsigned long long)KEY_EMPTY, (unsigned long long)key[u]) == KEY_EMPTY;
+#pragma unroll
+      for (int u = 0; u < DU; u++) {
+        if (!live[u]) continue;
+        if (won[u]) { atomicMin(&e0[u]->birth, seq[u]); claimed[u] = e0[u]; }   // taken
+        else {   // somebody else's, ours already, or lost the race for it: the general walk from the home slot (one entry it has seen before, rarely)
+          int bx, by, bz;
+          unpack_key(key[u], bx, by, bz);
+          claimed[u] = hash_find_or_claim(h, P, key[u], bx, by, bz, seq[u]);
         }
       }
-      // wave-aggregated heap pop for the freshly claimed slots
-      const uint64_t cm = __ballot(claimed != nullptr);
-      if (cm != 0ull) {
-        const int n = __popcll((unsigned long long)cm);
-        const int first = __ffsll((unsigned long long)cm) - 1;
-        int base = 0;
-        if (lane == first) {
-          base = atomicSub(&counters[C_HEAP_FREE], n);
-          atomicAdd(&counters[C_SLOTS_USED], n);
-        }
-        base = __shfl(base, first);
-        if (claimed != nullptr) {
-          const int rank = __popcll((unsigned long long)(cm & ((1ull << lane) - 1ull)));
-          give_block(h, claimed, key, base - 1 - rank);
+      uint64_t cm[DU];
+      int n_wave = 0;
+#pragma unroll
+      for (int u = 0; u < DU; u++) { cm[u] = __ballot(claimed[u] != nullptr); n_wave += __popcll((unsigned long long)cm[u]); }
+      if (n_wave != 0) {
+        int wbase = 0;
+        if (lane == 0) wbase = atomicAdd(&s_claimed, n_wave);
+        wbase = __builtin_amdgcn_readfirstlane(wbase);
+#pragma unroll
+        for (int u = 0; u < DU; u++) {
+          if (claimed[u] != nullptr) s_ent[wbase + __popcll((unsigned long long)(cm[u] & ((1ull << lane) - 1ull)))] = (uint32_t)(claimed[u] - h.table);
+          wbase += __popcll((unsigned long long)cm[u]);
         }
       }
     }
+    __syncthreads();
+    const int n_claimed = s_claimed;
+    if (n_claimed == 0) return;   // (uniform)
+    if (threadIdx.x == 0) {
+      s_pop_base = atomicSub(&counters[C_HEAP_FREE], n_claimed);
+      atomicAdd(&counters[C_SLOTS_USED], n_claimed);
+    }
+    __syncthreads();
+    const int base = s_pop_base;
+    int hw = 0;
+    for (int i0 = 0; i0 < n_claimed; i0 += 256 * DU) {
+      HashEntry* e[DU];
+      uint64_t key[DU];
+#pragma unroll
+      for (int u = 0; u < DU; u++) {
+        const int i = i0 + u * 256 + (int)threadIdx.x;
+        e[u] = i < n_claimed ? h.table + s_ent[i] : nullptr;
+        key[u] = e[u] != nullptr ? __hip_atomic_load(&e[u]->key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < DU; u++)
+        if (e[u] != nullptr) hw = max(hw, give_block_quiet(h, e[u], key[u], base - 1 - (i0 + u * 256 + (int)threadIdx.x)));
+    }
+    for (int o = 32; o > 0; o >>= 1) hw = max(hw, __shfl_xor(hw, o));
+    if (lane == 0) raise_high_water(h, hw);
   };
 
-  constexpr int ROUNDS = (WIN_LOG2 >= 6 && !MULTI) ? 3 : 1;   // windows a frame's rays may be walked in before the slow path (below)
+#ifndef SF_ALLOC6_ROUNDS
+#define SF_ALLOC6_ROUNDS 8
+#endif
+  constexpr int ROUNDS = (WIN_LOG2 >= 6 && !MULTI) ? SF_ALLOC6_ROUNDS : 1;   // windows a frame's rays may be walked in before the slow path (below)
   const bool in_image = x < P.W && y < P.H;
   const float kx = ((float)x - P.mx) / P.fx, ky = ((float)y - P.my) / P.fy;  // the pixel's ray direction is the same for every frame
   const float rvoxel = 1.0f / P.voxel;                                        // RN(1 / voxel) for world_to_block
@@ -541,7 +610,7 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_
       const int anx = s_anchor[0], any_ = s_anchor[1], anz = s_anchor[2];
       AT_MARK(1);
 #ifdef SF_ALLOC_TIMING
-      if (threadIdx.x == 0) atomicAdd(&g_alloc_t[9], 1ull);
+      if (threadIdx.x == 0) { atomicAdd(&g_alloc_t[9], 1ull); at_rounds_++; }
 #endif
 
       // ---- DDA: one LDS bit per visited block
@@ -578,7 +647,7 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_
                   if (old == key) { placed = true; break; }  // queued by an earlier step / ray / frame
                   if (old == KEY_EMPTY) {
                     const int pos = atomicAdd(&s_count, 1);
-                    if (pos < LIST) { s_list[pos] = key; s_birth[pos] = (uint8_t)j; placed = true; }
+                    if (pos < LIST) { s_list[pos] = key; s_birth[pos] = (uint8_t)(j | 0x80); placed = true; }
                     break;  // queue full: direct path below
                   }
                   sl = (sl + 1) & (SET - 1);
@@ -599,35 +668,62 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_
       AT_MARK(2);
       // ---- scan: blocks this frame visits that no earlier frame of the group queued -> frustum test -> queue
 #ifndef SF_ABLATE_ALLOC_SCAN   // measurement only (the volume is WRONG): no scan
-      for (int w = threadIdx.x; w < WIN_WORDS; w += 256) {
-        uint32_t bits = MULTI ? (s_frame[w] & ~s_done[w]) : s_frame[w];
-        uint32_t queued = 0u;
+      // A lane takes a WORD (32 x-consecutive blocks) as far as whole words go -- read it, take out what an earlier frame of the group queued and what the presence
+      // cache knows -- and a BLOCK from there on: the wave then walks the words that have bits left two at a time, lane b of each half-wave testing block b.
+      // (One thread per word all the way -- a loop over the word's bits around the frustum test -- kept a wave as long as the fullest of its 64 words: a tile that looks at
+      // a surface for the first time has ~5 500 blocks in ~400 words, a sixth of the lanes busy, and took 200 us here where the mean is 17; the longest workgroup IS
+      // the kernel at one frame per launch.  profiles/r06_alloc_1mm.txt)
+      for (int base = wave * 64; base < WIN_WORDS; base += 256) {
+        const int w = base + lane;
+        const uint32_t seen = MULTI ? (s_frame[w] & ~s_done[w]) : s_frame[w];
+        uint32_t bits = seen;
         if (bits != 0u && bricks.e != nullptr) {
-          // the word's 32 x-consecutive blocks are 8 whole bricks: what the presence cache knows of them is in the table already and older than this batch --
-          // nothing to test, queue or probe for those (and nothing for a later frame of the group either)
+          // the word's 32 blocks are 8 whole bricks: what the presence cache knows of them is in the table already and older than this batch -- nothing to test,
+          // queue or probe for those (and nothing for a later frame of the group either)
           const uint32_t bit0 = (uint32_t)w << 5;
-          const uint32_t known = brick_known_row(bricks, anx + (int)(bit0 & (WIN - 1)), any_ + (int)((bit0 >> WIN_LOG2) & (WIN - 1)), anz + (int)(bit0 >> (2 * WIN_LOG2)));
-          queued = bits & known;
-          bits &= ~known;
+          bits &= ~brick_known_row(bricks, anx + (int)(bit0 & (WIN - 1)), any_ + (int)((bit0 >> WIN_LOG2) & (WIN - 1)), anz + (int)(bit0 >> (2 * WIN_LOG2)));
         }
-        while (bits) {
-          const int b = __ffs((int)bits) - 1;
-          bits &= bits - 1u;
-          const uint32_t bit = ((uint32_t)w << 5) | (uint32_t)b;
-          const int bx = anx + (int)(bit & (WIN - 1)), by = any_ + (int)((bit >> WIN_LOG2) & (WIN - 1)), bz = anz + (int)(bit >> (2 * WIN_LOG2));
-          if (!slab_owns(P, bx, by, bz)) { queued |= 1u << b; continue; }  // another GPU's block: never ours, stop looking at it
-          if (!block_in_frustum(P, FL, bx, by, bz)) continue;  // a later frame may still want it
-          queued |= 1u << b;
-          const int pos = atomicAdd(&s_count, 1);
-          if (pos < LIST) { s_list[pos] = pack_key(bx, by, bz); s_birth[pos] = (uint8_t)j; }
-          else direct(pack_key(bx, by, bz), bx, by, bz, B.seq0 + (uint32_t)j);
+        uint32_t queued = seen & ~bits;
+        uint64_t todo = __ballot(bits != 0u);
+        while (todo != 0ull) {   // (uniform)
+          const int l0 = __ffsll((unsigned long long)todo) - 1;
+          todo &= todo - 1ull;
+          const int l1 = todo != 0ull ? __ffsll((unsigned long long)todo) - 1 : l0;
+          const bool second = todo != 0ull;
+          todo &= todo - 1ull;   // (0 stays 0)
+          const int src = lane < 32 ? l0 : l1;
+          const uint32_t wbits = (uint32_t)__shfl((int)bits, src);
+          const int b = lane & 31;
+          const uint32_t wbit0 = (uint32_t)(base + src) << 5;
+          const int bx = anx + (int)(wbit0 & (WIN - 1)) + b, by = any_ + (int)((wbit0 >> WIN_LOG2) & (WIN - 1)), bz = anz + (int)(wbit0 >> (2 * WIN_LOG2));
+          const bool mine = ((wbits >> b) & 1u) != 0u && (lane < 32 || second);
+          const bool foreign = mine && !slab_owns(P, bx, by, bz);   // another GPU's block: never ours, stop looking at it
+          const bool pass = mine && !foreign && block_in_frustum(P, FL, bx, by, bz);   // (outside this frame's frustum: a later frame may still want it)
+          const uint64_t pm = __ballot(pass);
+          if (pm != 0ull) {
+            int pos = 0;
+            if (lane == 0) pos = atomicAdd(&s_count, __popcll((unsigned long long)pm));
+            pos = __builtin_amdgcn_readfirstlane(pos) + __popcll((unsigned long long)(pm & ((1ull << lane) - 1ull)));
+            if (pass) {
+              if (pos < LIST) { s_list[pos] = pack_key(bx, by, bz); s_birth[pos] = (uint8_t)j; }
+              else direct(pack_key(bx, by, bz), bx, by, bz, B.seq0 + (uint32_t)j);
+            }
+          }
+          if (MULTI) {
+            const uint64_t qm = __ballot(pass || foreign);
+            if (lane == l0) queued |= (uint32_t)qm;
+            if (second && lane == l1) queued |= (uint32_t)(qm >> 32);
+          }
         }
-        if (MULTI && queued) s_done[w] |= queued;  // word w is only ever touched by this thread
+        if (MULTI && queued) s_done[w] |= queued;  // word w is only ever touched by this lane
       }
 #endif
       if (ROUNDS > 1) {   // the queue is emptied between rounds
         __syncthreads();
         AT_MARK(3);
+#ifdef SF_ALLOC_TIMING
+        if (threadIdx.x == 0) at_queued_ += (unsigned)s_count;
+#endif
         drain();
         __syncthreads();
         AT_MARK(4);
@@ -648,6 +744,14 @@ __global__ __launch_bounds__(256) void k_alloc(const float* __restrict__ depthf_
     atomicAdd(&g_alloc_t[5], at_prev_ - at_start_);
     atomicMax(&g_alloc_t[8], at_prev_ - at_start_);
     atomicAdd(&g_alloc_t[10], 1ull);
+  }
+  if (threadIdx.x == 0 && at_prev_ - at_start_ > 25000ull) {
+    const unsigned slot = atomicAdd(&g_alloc_log[0], 1u);
+    if (slot < 256u) {
+      unsigned* r = &g_alloc_log[1 + 12 * slot];
+      r[0] = blockIdx.x | (blockIdx.y << 16); r[1] = at_rounds_; r[2] = at_ph_[0]; r[3] = at_ph_[1]; r[4] = at_ph_[2]; r[5] = at_ph_[3]; r[6] = at_ph_[4];
+      r[7] = (unsigned)(at_prev_ - at_start_); r[8] = (unsigned)n_direct; r[9] = (unsigned)n_probed; r[10] = at_queued_ + (unsigned)s_count; r[11] = 0;
+    }
   }
 #endif
 }
@@ -1176,25 +1280,7 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_compactify(CompactArgs A) {
           m = d >= 32u ? 0u : (m & ~((1u << d) - 1u));
         }
       }
-    } else if (i < hw) {
-      const uint64_t k = block_keys[i];
-      if (k != KEY_EMPTY && !(all_live != 1 && (block_flags[i] & 1))) {  // ghosts are listed by all_live == 1 only
-        if (all_live) m = 1u;
-        else {
-          int bx, by, bz;
-          unpack_key(k, bx, by, bz);
-          for (int qq = 0; qq < B.n; qq++)
-            if (block_in_frustum(P, B.f[qq], bx, by, bz)) m |= 1u << qq;
-          if (m != 0u && B.n > 1) {
-            const uint32_t birth = table[block_entry[i]].birth;
-            if (birth > B.seq0) {
-              const uint32_t d = birth - B.seq0;
-              m = d >= 32u ? 0u : (m & ~((1u << d) - 1u));
-            }
-          }
-        }
-      }
-    }
+    }   // (passes of up to COMPACT_FEW frames and the list of every live block: k_compactify_few)
     const uint64_t bal = __ballot(m != 0u);
     const int rank = __popcll((unsigned long long)(bal & ((1ull << lane) - 1ull)));
     const int wtotal = __popcll((unsigned long long)bal);
@@ -1225,6 +1311,111 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_compactify(CompactArgs A) {
     if (m != 0u) {
       compact[off + rank] = i;
       cmask[off + rank] = m;
+    }
+    __syncthreads();
+  }
+}
+
+// The same list for FEW frames per pass (up to COMPACT_FEW: a live stream's one frame per launch) or for every live block (all_live): one thread per entry and a
+// loop over the frames -- no lane groups, no LDS staging of the frames' constants -- and a kernel of its own so that neither sets the other's register budget.
+__global__ __launch_bounds__(COMPACT_THREADS) void k_compactify_few(CompactArgs A) {
+  const uint64_t* __restrict__ block_keys = A.block_keys;
+  const int32_t* __restrict__ block_entry = A.block_entry;
+  const uint8_t* __restrict__ block_flags = A.block_flags;
+  const HashEntry* __restrict__ table = A.table;
+  int32_t* __restrict__ compact = A.compact;
+  uint32_t* __restrict__ cmask = A.cmask;
+  int32_t* counters = A.counters;
+  const int counter_id = A.counter_id, all_live = A.all_live;
+  const ParamsK& P = A.P;
+  const BatchFrames& B = A.B;
+  __shared__ int s_wlast[COMPACT_WAVES], s_wpop[COMPACT_WAVES];
+  __shared__ int s_base;
+  const int hw = counters[C_HIGH_WATER];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t last_bit = 1u << (B.n - 1);
+  // Few frames per pass and a long directory (a live stream at small voxels: 1.6 M entries at 1 mm): EU entries per thread and ONE place in the list asked for
+  // per workgroup and 2 048 entries.  Asked for per 256 entries, the 6 100 returning atomics on the one list counter (and twice as many on the two statistics
+  // words) WERE the kernel: 150 us for a pass over 15 MB of keys, ~25 ns per atomic (tools/gpu/period_summary.py, profiles/r06_alloc_1mm.txt).  The list keeps
+  // its order: ascending directory index within a workgroup's stretch.
+  constexpr int EU = 8;
+  __shared__ int s_ut[EU][COMPACT_WAVES];
+  for (int base = blockIdx.x * COMPACT_THREADS * EU; base < hw; base += gridDim.x * COMPACT_THREADS * EU) {
+    uint64_t k[EU];
+    uint8_t fl[EU];
+    uint32_t m[EU];
+    int rank[EU];
+#pragma unroll
+    for (int u = 0; u < EU; u++) {   // every load of the stretch in flight together
+      const int i = base + u * COMPACT_THREADS + (int)threadIdx.x;
+      k[u] = i < hw ? block_keys[i] : KEY_EMPTY;
+      fl[u] = i < hw ? block_flags[i] : (uint8_t)0;
+    }
+    int wlast = 0, pop = 0;
+#pragma unroll
+    for (int u = 0; u < EU; u++) {
+      m[u] = 0u;
+      if (k[u] != KEY_EMPTY && !(all_live != 1 && (fl[u] & 1))) {  // ghosts are listed by all_live == 1 only
+        if (all_live) m[u] = 1u;
+        else {
+          int bx, by, bz;
+          unpack_key(k[u], bx, by, bz);
+          for (int qq = 0; qq < B.n; qq++)
+            if (block_in_frustum(P, B.f[qq], bx, by, bz)) m[u] |= 1u << qq;
+          if (m[u] != 0u && B.n > 1) {
+            const uint32_t birth = table[block_entry[base + u * COMPACT_THREADS + (int)threadIdx.x]].birth;
+            if (birth > B.seq0) {
+              const uint32_t d = birth - B.seq0;
+              m[u] = d >= 32u ? 0u : (m[u] & ~((1u << d) - 1u));
+            }
+          }
+        }
+      }
+      const uint64_t bal = __ballot(m[u] != 0u);
+      rank[u] = __popcll((unsigned long long)(bal & ((1ull << lane) - 1ull)));
+      if (lane == 0) s_ut[u][wave] = __popcll((unsigned long long)bal);
+      wlast += __popcll((unsigned long long)__ballot((m[u] & last_bit) != 0u));
+      pop += __popc(m[u]);
+    }
+    for (int o = 32; o > 0; o >>= 1) pop += __shfl_xor(pop, o);
+    if (lane == 0) { s_wlast[wave] = wlast; s_wpop[wave] = pop; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int total = 0, tlast = 0;
+      for (int w = 0; w < COMPACT_WAVES; w++) {
+        tlast += s_wlast[w];
+        for (int u = 0; u < EU; u++) total += s_ut[u][w];
+      }
+      s_base = 0;
+      if (total) {
+        const unsigned long long add = (unsigned long long)(uint32_t)total | ((unsigned long long)(uint32_t)tlast << 32);
+        s_base = (int)(uint32_t)atomicAdd(reinterpret_cast<unsigned long long*>(&counters[counter_id]), add);
+      }
+    } else if (threadIdx.x == 64 && !all_live) {   // the two statistics: another wave's lane, so that nobody waits for them behind the returning atomic
+      int total = 0, tpop = 0;
+      for (int w = 0; w < COMPACT_WAVES; w++) {
+        tpop += s_wpop[w];
+        for (int u = 0; u < EU; u++) total += s_ut[u][w];
+      }
+      if (total) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(&counters[C_TOTAL_LO]), (unsigned long long)tpop);
+        atomicAdd(reinterpret_cast<unsigned long long*>(&counters[C_TILES_LO]), (unsigned long long)total);
+      }
+    }
+    __syncthreads();
+    int off = s_base;
+#pragma unroll
+    for (int u = 0; u < EU; u++) {
+      int mine = off;
+      for (int w = 0; w < COMPACT_WAVES; w++) {
+        const int t = s_ut[u][w];
+        if (w < wave) mine += t;
+        off += t;
+      }
+      if (m[u] != 0u) {
+        compact[mine + rank[u]] = base + u * COMPACT_THREADS + (int)threadIdx.x;
+        cmask[mine + rank[u]] = m[u];
+      }
     }
     __syncthreads();
   }
@@ -2269,8 +2460,12 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
 #undef LAUNCH_ALLOC
 #undef LAUNCH_ALLOC_RAY
   }
-  hipLaunchKernelGGL(k_compactify, dim3(f->compact_grid * (1024 / COMPACT_THREADS)), dim3(COMPACT_THREADS), 0, sa, (CompactArgs{f->block_keys, f->block_entry, f->block_flags, f->table, f->compact2[sl],
-                     f->cmask2[sl], f->counters, cc, 0, f->pk, bf}));
+  if (n > COMPACT_FEW)
+    hipLaunchKernelGGL(k_compactify, dim3(f->compact_grid * (1024 / COMPACT_THREADS)), dim3(COMPACT_THREADS), 0, sa, (CompactArgs{f->block_keys, f->block_entry, f->block_flags, f->table, f->compact2[sl],
+                       f->cmask2[sl], f->counters, cc, 0, f->pk, bf}));
+  else
+    hipLaunchKernelGGL(k_compactify_few, dim3(f->compact_grid * (1024 / COMPACT_THREADS)), dim3(COMPACT_THREADS), 0, sa, (CompactArgs{f->block_keys, f->block_entry, f->block_flags, f->table, f->compact2[sl],
+                       f->cmask2[sl], f->counters, cc, 0, f->pk, bf}));
   if (f->overlap && sa != s) {
     (void)hipEventRecord(f->ev_compact[sl], sa);
     (void)hipStreamWaitEvent(s, f->ev_compact[sl], 0);
@@ -2849,6 +3044,16 @@ SF_API int sf_alloc_timing_read(sf_fuser* f, uint64_t* out16) {
   SF_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_alloc_t), z, 16 * 8));
   return SF_OK;
 }
+// ... and the log of its slow workgroups: 1 + 256 * 12 words, cleared behind the read
+SF_API int sf_alloc_timing_log(sf_fuser* f, uint32_t* out) {
+  if (!f || !out) return sf::fail(SF_ERR_INVALID_ARG, "NULL argument");
+  SF_HIP_CHECK(hipSetDevice(f->device));
+  SF_HIP_CHECK(sf_quiesce(f));
+  SF_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_alloc_log), (1 + 256 * 12) * 4));
+  static unsigned z[1 + 256 * 12];
+  SF_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_alloc_log), z, sizeof(z)));
+  return SF_OK;
+}
 #endif
 
 SF_API int sf_fuser_profile_enable(sf_fuser* f, int on) {
@@ -2966,7 +3171,7 @@ int sf_compact_live(sf_fuser* f, int32_t* n_out, int include_ghosts) {
   std::memset(&dummy, 0, sizeof(dummy));
   dummy.n = 1;
   SF_HIP_CHECK(hipMemsetAsync(&f->counters[C_EXPORT], 0, 8, f->stream));
-  hipLaunchKernelGGL(k_compactify, dim3(f->compact_grid * (1024 / COMPACT_THREADS)), dim3(COMPACT_THREADS), 0, f->stream, (CompactArgs{f->block_keys, f->block_entry, f->block_flags, f->table, f->compact,
+  hipLaunchKernelGGL(k_compactify_few, dim3(f->compact_grid * (1024 / COMPACT_THREADS)), dim3(COMPACT_THREADS), 0, f->stream, (CompactArgs{f->block_keys, f->block_entry, f->block_flags, f->table, f->compact,
                      f->cmask2[0], f->counters, (int)C_EXPORT, include_ghosts ? 1 : 2, f->pk, dummy}));
   SF_HIP_CHECK(hipMemcpyAsync(n_out, &f->counters[C_EXPORT], 4, hipMemcpyDeviceToHost, f->stream));
   SF_HIP_CHECK(sf_quiesce(f));

@@ -29,5 +29,10 @@ for batch, gw in (((1, 1),) if os.environ.get("SF_PROBE_ONLY_BATCH1") else ((1, 
             wg = max(1, t16[10]); us = lambda v: round(v / 100.0 / wg, 1)
             print("k_alloc timing per workgroup, us: setup", us(t16[0]), "anchor", us(t16[1]), "walk", us(t16[2]), "scan", us(t16[3]), "drain", us(t16[4]), "whole", us(t16[5]),
                   "| longest workgroup", round(t16[8] / 100.0, 1), "| rounds per workgroup", round(t16[9] / wg, 2), "| workgroups", t16[10])
+            lg = (C.c_uint32 * (1 + 256 * 12))(); L.sf_alloc_timing_log.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]; _abi.check(L.sf_alloc_timing_log(f._h, lg))
+            rows = sorted((list(lg[1 + 12 * i: 13 + 12 * i]) for i in range(min(256, lg[0]))), key=lambda r: -r[7])
+            print("workgroups over 250 us:", lg[0], "(the 24 longest of the first 256: tile x y | rounds | setup anchor walk scan drain whole, us | direct probed queued)")
+            for r in rows[:24]:
+                print("   tile", r[0] & 0xffff, r[0] >> 16, "| rounds", r[1], "|", " ".join(str(round(v / 100.0, 1)) for v in r[2:8]), "|", r[8], r[9], r[10])
         print("brick_cache", BC, "table probes in 16 frames", q1.value - q0.value, end=" ")
         print("batch", batch, "alloc_group_win64", gw, "fps", round((N - 8) / dt, 1), "direct-path blocks in 16 frames", n1.value - n0.value, "blocks allocated", st["blocks_allocated"], "frame blocks", st["last_frame_blocks"])
