@@ -2322,6 +2322,7 @@ __global__ __launch_bounds__(256) void k_import(const int32_t* __restrict__ coor
 hipError_t sf_quiesce(sf_fuser* f) {
   hipError_t e = hipSuccess;
   if (f->front) e = hipStreamSynchronize(f->front);
+  if (f->front_lo) { const hipError_t e1 = hipStreamSynchronize(f->front_lo); if (e == hipSuccess) e = e1; }
   const hipError_t e2 = hipStreamSynchronize(f->stream);
   return e != hipSuccess ? e : e2;
 }
@@ -2386,7 +2387,14 @@ static bool big_pass(const sf_fuser* f) { return (uint64_t)(uint32_t)*f->host_mi
 bool sf_single_stream_batch(const sf_fuser* f, int n, bool color, int sign) { return pipe_batch(f, n, color, sign) && !f->pipe_beside; }
 // the stream the pre-pass of such a batch reads its frames on: where callers must have staged them
 hipStream_t sf_input_stream(const sf_fuser* f, int n, bool color, int sign) {
-  return (f->overlap && !sf_single_stream_batch(f, n, color, sign)) ? f->front : f->stream;
+  if (!f->overlap || sf_single_stream_batch(f, n, color, sign)) return f->stream;
+  // The front stream has the device's highest priority: in a pass of several frames its short kernels must slip in between the workgroups of the integrate
+  // kernel, or the next pass waits for them.  Beside the PERSISTENT kernel of one frame per launch (1 mm voxels: the tile set is far beyond the cache) that
+  // priority is what the integrate kernel pays for: the allocation's 72 KiB workgroups, dispatched first, take the LDS its third workgroup per CU needs until
+  // they are through -- measured 0.54 of peak HBM shipped against 0.61-0.62 with the front chain at the LOWEST priority, three runs each, nothing else changed
+  // (tools/gpu/r06_zk.sh).  So such a frame's front chain goes down a second, low-priority stream (front_prio -1, the default; 1 / 0: always high / low).
+  const bool lo = f->front_lo != nullptr && (f->front_prio == 0 || (f->front_prio < 0 && pipe_batch(f, n, color, sign)));
+  return lo ? f->front_lo : f->front;
 }
 
 namespace {
@@ -2422,6 +2430,11 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
   const bool pipe = pipe_batch(f, n, col, sign);
   hipStream_t sa = sf_input_stream(f, n, col, sign);  // callers stage the batch's frames on this stream too
   if (f->overlap && sa != s) {
+    if (f->last_front != nullptr && f->last_front != sa) {   // the other front stream served the pass before: this pass's front chain starts behind that one's
+      (void)hipEventRecord(f->ev_front_switch, f->last_front);
+      (void)hipStreamWaitEvent(sa, f->ev_front_switch, 0);
+    }
+    f->last_front = sa;
     if (f->serial_tail) {  // single-stream batches came before: the front stream starts behind everything they queued
       (void)hipEventRecord(f->ev_input, s);
       (void)hipStreamWaitEvent(sa, f->ev_input, 0);
@@ -2673,6 +2686,8 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
     int prio_lo = 0, prio_hi = 0;
     SF_CREATE_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     SF_CREATE_CHECK(hipStreamCreateWithPriority(&f->front, hipStreamNonBlocking, prio_hi));
+    SF_CREATE_CHECK(hipStreamCreateWithPriority(&f->front_lo, hipStreamNonBlocking, prio_lo));   // (sf_input_stream: the front chain beside the persistent kernel)
+    SF_CREATE_CHECK(hipEventCreateWithFlags(&f->ev_front_switch, hipEventDisableTiming));
   }
   for (int q = 0; q < 2; q++) {
     SF_CREATE_CHECK(hipEventCreateWithFlags(&f->ev_compact[q], hipEventDisableTiming));
@@ -2735,7 +2750,8 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
 SF_API void sf_fuser_destroy(sf_fuser* f) {
   if (!f) return;
   (void)hipSetDevice(f->device);
-  if (f->front) (void)hipStreamSynchronize(f->front);   // both streams drained before ANYTHING they read or write goes (the host-frame ring's
+  if (f->front) (void)hipStreamSynchronize(f->front);   // every stream drained before ANYTHING they read or write goes (the host-frame ring's
+  if (f->front_lo) (void)hipStreamSynchronize(f->front_lo);
   if (f->stream) (void)hipStreamSynchronize(f->stream); // page-locked slots are read by copies queued on either of them)
   for (auto& e : f->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   (void)hipFree(f->table); (void)hipFree(f->bricks); (void)hipFree(f->heap); (void)hipFree(f->block_keys); (void)hipFree(f->block_entry); (void)hipFree(f->block_flags); (void)hipFree(f->voxels);
@@ -2744,6 +2760,8 @@ SF_API void sf_fuser_destroy(sf_fuser* f) {
   for (int q = 0; q < 2; q++) { if (f->ev_compact[q]) (void)hipEventDestroy(f->ev_compact[q]); if (f->ev_fused[q]) (void)hipEventDestroy(f->ev_fused[q]); }
   if (f->ev_input) (void)hipEventDestroy(f->ev_input);
   if (f->front) { (void)hipStreamSynchronize(f->front); (void)hipStreamDestroy(f->front); }
+  if (f->front_lo) { (void)hipStreamSynchronize(f->front_lo); (void)hipStreamDestroy(f->front_lo); }
+  if (f->ev_front_switch) (void)hipEventDestroy(f->ev_front_switch);
   for (int q = 0; q < sf_fuser::HOST_RING; q++) {
     (void)hipFree(f->staging_depth[q]); (void)hipFree(f->staging_rgb[q]);
     if (f->pinned_depth[q]) (void)hipHostFree(f->pinned_depth[q]);
@@ -2931,8 +2949,14 @@ SF_API int sf_fuser_tune(sf_fuser* f, const char* key, int value) {
     }
     (void)hipStreamDestroy(f->stream);
     (void)hipStreamDestroy(f->front);
+    if (f->front_lo) { (void)hipStreamDestroy(f->front_lo); f->front_lo = nullptr; }
     f->stream = ns;
     f->front = nf;
+    f->last_front = nullptr;
+    if (value == 0) {   // (a CU-masked front stream is the only front stream: the mask, not a priority, keeps it out of the integrate kernel's way)
+      int lo2 = 0, hi2 = 0;
+      if (hipDeviceGetStreamPriorityRange(&lo2, &hi2) == hipSuccess) (void)hipStreamCreateWithPriority(&f->front_lo, hipStreamNonBlocking, lo2);
+    }
     f->front_cus = value;
   }
   else if (k == "alloc_group" && in(1, MAX_BATCH)) f->alloc_group = value;
@@ -2946,16 +2970,9 @@ SF_API int sf_fuser_tune(sf_fuser* f, const char* key, int value) {
   else if (k == "alloc_ablate")
     return sf::fail(SF_ERR_INVALID_ARG, "sf_fuser_tune: alloc_ablate switches parts of the allocation off (the volume is wrong under it): only in a library built with -DSF_MEASURE_ABLATE");
 #endif
-  else if (k == "front_prio" && in(0, 1)) {   // 1: the front stream at the device's highest priority (default), 0: at the default priority
-    if (f->front_cus > 0)
-      return sf::fail(SF_ERR_INVALID_ARG, "sf_fuser_tune: front_prio would replace the CU-masked front stream (front_cus = %d) by an unmasked one; set front_cus 0 first", f->front_cus);
-    int prio_lo = 0, prio_hi = 0;
-    SF_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    hipStream_t nf = nullptr;
-    SF_HIP_CHECK(hipStreamCreateWithPriority(&nf, hipStreamNonBlocking, value ? prio_hi : prio_lo));
-    (void)hipStreamDestroy(f->front);
-    f->front = nf;
-  }
+  // which of the two front streams a pass's pre-pass / allocation / compaction goes down (sf_input_stream): -1 the low-priority one beside the persistent kernel of
+  // one frame per launch, the high-priority one otherwise (default); 1 always the high-priority one (rounds 2-5); 0 always the low-priority one
+  else if (k == "front_prio" && in(-1, 1)) f->front_prio = value;
   else if (k == "alloc_ray" && in(0, 1)) f->alloc_ray = value != 0;   // 1: the ray-space window whatever the geometry (rays outside it take the slow path), 0: the cube window
   else if (k == "ramp" && in(0, MAX_BATCH)) f->ramp = value;
   else if (k == "ramp_geo" && in(0, 1)) f->ramp_geo = value != 0;

@@ -269,15 +269,30 @@ __global__ void k_lock(Mesh M, const uint64_t* __restrict__ ukey, uint32_t E, co
 __global__ void k_winners(Mesh M, const uint64_t* __restrict__ ukey, const uint32_t* __restrict__ ucnt, uint32_t E, const float* __restrict__ pri, float tau, uint32_t salt,
                           const unsigned long long* __restrict__ lock, uint8_t* taken_next, unsigned long long* win, uint32_t* counters) {
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E) return;
-  const float p = pri[e];
-  if (!(p <= tau)) return;
-  const uint32_t v0 = (uint32_t)(ukey[e] >> 32), v1 = (uint32_t)ukey[e];
-  const unsigned long long key = lock_key(p, e, salt);
-  if (lock[v0] != key || lock[v1] != key) return;   // only candidates that were still free wrote keys: no need to look at `taken` again
-  win[atomicAdd(&counters[0], 1u)] = ((unsigned long long)__float_as_uint(p) << 32) | e;
-  atomicAdd(&counters[1], ucnt[e]);
-  atomicMax(&counters[2], __float_as_uint(p));
+  const float p = e < E ? pri[e] : INFINITY;
+  bool won = e < E && p <= tau;
+  uint32_t v0 = 0, v1 = 0;
+  if (won) {
+    v0 = (uint32_t)(ukey[e] >> 32);
+    v1 = (uint32_t)ukey[e];
+    const unsigned long long key = lock_key(p, e, salt);
+    won = lock[v0] == key && lock[v1] == key;   // only candidates that were still free wrote keys: no need to look at `taken` again
+  }
+  // the three counters are single words the whole launch shares: one atomic each per WAVE (a returning atomic per winner on one address is ~25 ns apiece, in a row)
+  const uint64_t wm = __ballot(won);
+  if (wm == 0ull) return;
+  const int lane = (int)(threadIdx.x & 63u), leader = __ffsll((unsigned long long)wm) - 1;
+  uint32_t faces = won ? ucnt[e] : 0u, top = won ? __float_as_uint(p) : 0u;   // (winning priorities are finite and >= 0: their bit patterns order like the values)
+  for (int o = 32; o > 0; o >>= 1) { faces += (uint32_t)__shfl_xor((int)faces, o); top = max(top, (uint32_t)__shfl_xor((int)top, o)); }
+  uint32_t base = 0;
+  if (lane == leader) {
+    base = atomicAdd(&counters[0], (uint32_t)__popcll((unsigned long long)wm));
+    atomicAdd(&counters[1], faces);
+    atomicMax(&counters[2], top);
+  }
+  base = (uint32_t)__shfl((int)base, leader);
+  if (!won) return;
+  win[base + (uint32_t)__popcll((unsigned long long)(wm & ((1ull << lane) - 1ull)))] = ((unsigned long long)__float_as_uint(p) << 32) | e;
   for_closed_rings(M, v0, v1, [&](uint32_t u) { taken_next[u] = 1; });
 }
 
