@@ -41,13 +41,13 @@ extern "C" {
  *   "front_prio"  -1/0/1 which front stream a pass's pre-pass / allocation / compaction goes down: -1 (default) the LOW-priority one beside the persistent kernel of one
  *                        frame per launch out of cache reach (its 72 KiB allocation workgroups otherwise take the LDS the integrate kernel's third workgroup per CU
  *                        needs: 0.54 -> 0.61 of peak HBM shipped at 1 mm), the high-priority one for passes of several frames; 1 always high (rounds 2-5), 0 always low
- *   "brick_cache" 0/1    the allocation kernels ask the presence cache (one {tag, 64-bit mask} entry per 4x4x4-block brick: "this block is in the table and
+ *   "brick_cache" 0/1    the cube-window allocation kernels (voxels under 2.5 mm, or "alloc_ray" 0) ask the presence cache (one {tag, 64-bit mask} entry per 4x4x4-block brick: "this block is in the table and
  *                        older than this batch") before they probe the hash table (default 1; 0: every look-up probes the table, rounds 1-5).  The allocated
  *                        set and every birth frame are the same either way.
  * Synchronises the fuser.  SF_ERR_INVALID_ARG for an unknown key or a value out of range. */
 int sf_fuser_tune(sf_fuser* f, const char* key, int value);
 
-/* How many look-ups of the allocation kernels went to the hash table since the fuser was created or reset (32-bit, wraps): with the presence cache
+/* How many look-ups of the cube-window allocation kernels went to the hash table since the fuser was created or reset (32-bit, wraps): with the presence cache
  * on, what is left are new blocks, blocks of the previous batch and bricks whose cache entry another brick holds. */
 int sf_fuser_alloc_probe_count(sf_fuser* f, uint64_t* out);
 

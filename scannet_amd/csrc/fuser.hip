@@ -314,10 +314,10 @@ __device__ inline int give_block_quiet(const HashRefs& h, HashEntry* e, uint64_t
   atomicAdd(&h.counters[C_ALLOC_FAIL], 1);
   return 0;
 }
-// the high-water mark only moves while the heap still hands out blocks it never handed out before: ask first (a load the L2 answers), an atomic on the
-// one word every workgroup shares only when it has to move
+// (no look at the mark first: a load of the word every workgroup's atomics land on waits in their queue like one of them, and the wave waits for IT -- measured
+// on a 20-frame call into an empty volume, where every block is new: k_alloc_ray 114 -> 151 us per launch; the atomic without a return value costs the wave nothing)
 __device__ inline void raise_high_water(const HashRefs& h, int hw) {
-  if (hw > __hip_atomic_load(&h.counters[C_HIGH_WATER], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&h.counters[C_HIGH_WATER], hw);
+  if (hw > 0) atomicMax(&h.counters[C_HIGH_WATER], hw);
 }
 __device__ inline void give_block(const HashRefs& h, HashEntry* e, uint64_t key, int at) { raise_high_water(h, give_block_quiet(h, e, key, at)); }
 
@@ -837,7 +837,7 @@ template <bool MULTI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SF_ALLOC_WAVES_MIN, 8))) void k_alloc_ray(const float* __restrict__ depthf_all, HashEntry* table, int32_t* heap,
                                                    uint64_t* block_keys, int32_t* block_entry, uint8_t* block_flags, int32_t* counters, ParamsK P,
                                                    BatchFrames B, int group_frames, int ablate, const uint16_t* __restrict__ fuse_depth16,
-                                                   float* depthf_out, int compact_counter, BrickCache bricks) {
+                                                   float* depthf_out, int compact_counter) {
   // ablate (tune "alloc_ablate", measurements only -- the volume is wrong with any bit set): 1 no LDS atomics, 2 no scan, 4 no DDA walk, 8 no barriers
   // fuse_depth16 != nullptr (one frame per pass, no colour, no resampling: a live stream): the kernel is ALSO the depth pre-pass -- every lane
   // converts its own pixel (k_prepass's arithmetic), stores it for the integrate kernel's gathers and walks it; one launch and one
@@ -854,7 +854,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SF_ALLOC_WA
   if (threadIdx.x == 0) s_count = 0;
   const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
   const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
-  const HashRefs h{table, heap, block_keys, block_entry, block_flags, counters, bricks, B.seq0};
+  // No presence cache here (fuser_internal.h BrickCache: the cube window's kernels use it): the "already queued" bitmap of the ray-space window leaves this kernel
+  // few look-ups to save -- 34.7 k against 34.8 k frames/s on the long stream with the cache on / off -- and its code, even switched off at run time, cost a 20-frame
+  // call into an empty volume 2 % (35.1 k -> 34.3 k, five libraries on one box: tools/gpu/r06_zr.sh).  The cache stays right: it only ever holds blocks the cube
+  // kernels FOUND in the table, and whatever takes blocks out of the table clears it.
+  const HashRefs h{table, heap, block_keys, block_entry, block_flags, counters, BrickCache{nullptr, 0u}, B.seq0};
   for (int i = threadIdx.x; i < ALLOC_SET; i += 256) s_keys[i] = KEY_EMPTY;
   for (int i = threadIdx.x; i < RW_WORDS / 4; i += 256) s_frame4[i] = make_uint4(0, 0, 0, 0);
   if (MULTI)
@@ -864,11 +868,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SF_ALLOC_WA
   const int j_end = min(B.n, j_begin + group_frames);
 
   int n_direct = 0;   // sf_fuser_alloc_direct_count (added up once per wave at the end: one atomic per call on a single word halved the 1 mm front chain)
-  int n_probed = 0;   // look-ups that went to the hash table (the presence cache did not answer): sf_fuser_alloc_probe_count
   auto direct = [&](uint64_t key, int bx, int by, int bz, uint32_t seq) {
     n_direct++;
-    if (h.bricks.e != nullptr && brick_known(h.bricks, bx, by, bz)) return;
-    n_probed++;
     HashEntry* e = hash_find_or_claim(h, P, key, bx, by, bz, seq);
     if (e) {
       atomicAdd(&counters[C_SLOTS_USED], 1);
@@ -1142,10 +1143,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SF_ALLOC_WA
     if (key != KEY_EMPTY) {
       int bx, by, bz;
       unpack_key(key, bx, by, bz);
-      if (h.bricks.e == nullptr || !brick_known(h.bricks, bx, by, bz)) {
-        n_probed++;
-        claimed = hash_find_or_claim(h, P, key, bx, by, bz, B.seq0 + (uint32_t)s_birth[i]);
-      }
+      claimed = hash_find_or_claim(h, P, key, bx, by, bz, B.seq0 + (uint32_t)s_birth[i]);
     }
     const uint64_t cm = __ballot(claimed != nullptr);
     if (cm != 0ull) {
@@ -1157,15 +1155,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SF_ALLOC_WA
         atomicAdd(&counters[C_SLOTS_USED], n);
       }
       base = __shfl(base, first);
+      int hw = 0;
       if (claimed != nullptr) {
         const int rank = __popcll((unsigned long long)(cm & ((1ull << lane) - 1ull)));
-        give_block(h, claimed, key, base - 1 - rank);
+        hw = give_block_quiet(h, claimed, key, base - 1 - rank);
       }
+      for (int o = 32; o > 0; o >>= 1) hw = max(hw, __shfl_xor(hw, o));   // the high-water mark once per wave, not per lane
+      if (lane == first) raise_high_water(h, hw);
     }
   }
-  for (int o = 32; o > 0; o >>= 1) { n_direct += __shfl_xor(n_direct, o); n_probed += __shfl_xor(n_probed, o); }
+  for (int o = 32; o > 0; o >>= 1) n_direct += __shfl_xor(n_direct, o);
   if (lane == 0 && n_direct) atomicAdd(&counters[C_ALLOC_DIRECT], n_direct);
-  if (lane == 0 && n_probed) atomicAdd(&counters[C_ALLOC_PROBED], n_probed);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2465,7 +2465,7 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
     const unsigned alloc_pad = (f->alloc_wgs > 0 && n > 1) ? (unsigned)std::max(0, (160 * 1024) / (f->alloc_wgs + 1) + 1024 - 23048) : 0u;
 #define LAUNCH_ALLOC_RAY(MU) \
   hipLaunchKernelGGL((k_alloc_ray<MU>), ag, dim3(256), alloc_pad, sa, f->depthf2[sl], f->table, f->heap, f->block_keys, f->block_entry, f->block_flags, f->counters, f->pk, bf, gf, f->alloc_ablate, \
-                     fuse_pre ? in.depth[0] : (const uint16_t*)nullptr, f->depthf2[sl], cc, bc)
+                     fuse_pre ? in.depth[0] : (const uint16_t*)nullptr, f->depthf2[sl], cc)
     if (f->alloc_ray) { if (gf == 1) LAUNCH_ALLOC_RAY(false); else LAUNCH_ALLOC_RAY(true); }
     else if (f->alloc_win64) { if (gf == 1) LAUNCH_ALLOC(6, false); else LAUNCH_ALLOC(6, true); }
     else if (gf == 1) LAUNCH_ALLOC(5, false);
@@ -2556,6 +2556,13 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
   if (f->overlap && sa != s) (void)hipEventRecord(f->ev_fused[sl], s);
   if (f->overlap && sa == s) f->serial_tail = true;  // no cross-stream traffic at all while single-stream batches follow each other
   f->pipe_beside = f->pipe_overlap == 1 || (f->pipe_overlap < 0 && big_pass(f));
+  if ((f->pipe_beside || f->front_prio == 0) && f->front_lo == nullptr && f->front_cus == 0 && f->overlap) {   // the low-priority front stream, on first need (sf_input_stream)
+    int prio_lo = 0, prio_hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess || hipStreamCreateWithPriority(&f->front_lo, hipStreamNonBlocking, prio_lo) != hipSuccess) {
+      f->front_lo = nullptr;   // (the high-priority one serves)
+      (void)hipGetLastError();
+    }
+  }
   const hipError_t err = hipGetLastError();
   if (err != hipSuccess) return sf::fail(SF_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(err));
   f->frames_integrated += (uint64_t)n;
@@ -2686,7 +2693,8 @@ SF_API int sf_fuser_create(const sf_params* p, int device, sf_fuser** out) {
     int prio_lo = 0, prio_hi = 0;
     SF_CREATE_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     SF_CREATE_CHECK(hipStreamCreateWithPriority(&f->front, hipStreamNonBlocking, prio_hi));
-    SF_CREATE_CHECK(hipStreamCreateWithPriority(&f->front_lo, hipStreamNonBlocking, prio_lo));   // (sf_input_stream: the front chain beside the persistent kernel)
+    // (front_lo, the front chain's stream beside the persistent kernel, is made by the first pass that latches that schedule: a stream nobody uses still takes its turn
+    // in the mapping of streams to hardware queues, and sf_fuse_run's seven to nine streams are short of those already)
     SF_CREATE_CHECK(hipEventCreateWithFlags(&f->ev_front_switch, hipEventDisableTiming));
   }
   for (int q = 0; q < 2; q++) {
@@ -2953,10 +2961,8 @@ SF_API int sf_fuser_tune(sf_fuser* f, const char* key, int value) {
     f->stream = ns;
     f->front = nf;
     f->last_front = nullptr;
-    if (value == 0) {   // (a CU-masked front stream is the only front stream: the mask, not a priority, keeps it out of the integrate kernel's way)
-      int lo2 = 0, hi2 = 0;
-      if (hipDeviceGetStreamPriorityRange(&lo2, &hi2) == hipSuccess) (void)hipStreamCreateWithPriority(&f->front_lo, hipStreamNonBlocking, lo2);
-    }
+    // (a CU-masked front stream is the only front stream: the mask, not a priority, keeps it out of the integrate kernel's way; back at 0 the low-priority
+    // one is made again on first need)
     f->front_cus = value;
   }
   else if (k == "alloc_group" && in(1, MAX_BATCH)) f->alloc_group = value;

@@ -105,8 +105,6 @@ enum Counter {
   C_LAST_BLOCKS = 5,
   C_GC_FREED = 7,
   C_IMPORTED = 8,
-  C_ALLOC_PROBED = 10,  // look-ups of the allocation kernels that went to the hash table (not answered by the presence cache)
-  C_ALLOC_DIRECT = 9,   // blocks an allocation workgroup could not queue in LDS and took to the global table one by one (the slow path)
   // 64-bit compaction counters (8-byte aligned, own cache line): low word = entries in the compact list,
   // high word = blocks the LAST frame of the batch updates
   C_COMPACT = 16,
@@ -114,6 +112,11 @@ enum Counter {
   C_EXPORT = 20,
   C_TOTAL_LO = 32,   // 64-bit sum of N_blk over all frames lives in counters[32..33] (own cache line)
   C_TILES_LO = 34,   // 64-bit sum over the passes of the tiles each pass touched (the pass's list length): counters[34..35], same line
+  // the allocation kernels' two statistics, one atomic per wave each -- in the line of the compaction's sums (another kernel's, later in the stream), NOT in the
+  // first line: an atomic there, returning or not, takes its turn with the heap pops every claiming wave waits for (the probe count in word 10 cost a 20-frame
+  // call into an empty volume 2 %: k_alloc_ray 121 -> 131 us per launch)
+  C_ALLOC_DIRECT = 40,  // blocks an allocation workgroup could not queue in LDS and took to the global table one by one (the slow path)
+  C_ALLOC_PROBED = 41,  // look-ups of the allocation kernels that went to the hash table (not answered by the presence cache)
   C_COUNT = 48
 };
 

@@ -851,7 +851,7 @@ def _probe_count(f):
 @pytest.mark.parametrize("kernel", ["ray", "cube32", "cube64"])
 def test_presence_cache_changes_nothing_but_the_probes(oracle, kernel):
     """The allocation kernels' presence cache (fuser_internal.h BrickCache: "this block is in the table and older than this batch") on and off, on the
-    three allocation kernels, one frame per launch and 32 per pass: the same block set, birth frames (hence voxels) as the oracle either way -- also across a
+    three allocation kernels (the two cube-window kernels use it; the ray-space kernel must not care), one frame per launch and 32 per pass: the same block set, birth frames (hence voxels) as the oracle either way -- also across a
     deintegration + garbage collection that takes blocks OUT of the table (the cache must forget them: the frames fused afterwards allocate them again) --
     and, one frame per launch, a fraction of the table probes."""
     from scannet_amd import fusion
@@ -898,8 +898,11 @@ def test_presence_cache_changes_nothing_but_the_probes(oracle, kernel):
                     dev.fuse(f, poses, n_first, len(idx))
                     assert f.stats()["alloc_failures"] == 0
                     _assert_same(ovol, f)
-        assert probes[(1, 1)] * 3 < probes[(1, 0)], probes   # one frame per launch: all but the new blocks and the previous frame's are answered by the cache
-        assert probes[(32, 1)] <= probes[(32, 0)], probes
+        if kernel == "ray":   # the ray-space kernel does not use the cache (its "already queued" bitmap leaves few look-ups to save) and does not count probes
+            assert set(probes.values()) == {0}, probes
+        else:
+            assert probes[(1, 1)] * 3 < probes[(1, 0)], probes   # one frame per launch: all but the new blocks and the previous frame's are answered by the cache
+            assert probes[(32, 1)] <= probes[(32, 0)], probes
     finally:
         dev.close()
 
