@@ -907,6 +907,45 @@ def test_presence_cache_changes_nothing_but_the_probes(oracle, kernel):
         dev.close()
 
 
+@pytest.mark.parametrize("front_prio", [-1, 0, 1])
+def test_front_streams_change_hands_between_single_frames_and_batches(oracle, front_prio):
+    """The front chain of a frame that runs beside the persistent one-frame kernel goes down the LOW-priority front stream (made on first need), that of a pass of
+    several frames down the high-priority one (fuser.hip sf_input_stream): a stream that alternates between single frames and batches -- beside the kernel forced with
+    pipe_overlap 1, the tile set here is far below the size that switches it on -- hands the allocation over from one front stream to the other and back, ordered by an
+    event.  Same volume as the oracle and as one stream for everything, bit for bit, with the front stream chosen automatically, always low and always high."""
+    from scannet_amd import fusion
+    W, H = 320, 240
+    boxes = synth.clutter_boxes()
+    n = 44
+    depth = np.zeros((n, H, W), np.uint16)
+    poses = np.zeros((n, 16), np.float32)
+    for k in range(n):
+        pose = synth.trajectory_pose(3 * k, 1200)
+        depth[k] = synth.render_room_depth(pose, W, H, noise_frame=k, noise=2, boxes=boxes)
+        poses[k] = pose.reshape(16)
+    op, gp = _mk(oracle, W, H, voxel=0.008, num_sdf_blocks=1 << 17)
+    ovol = oracle.Volume(op, threads=8)
+    for k in range(n):
+        ovol.integrate(depth[k], poses[k].reshape(4, 4))
+    # single frames, a batch of 20 (passes of 4 + 4 + 12), single frames, a batch of 9, single frames
+    cuts = [(0, 1), (1, 2), (2, 3), (3, 23), (23, 24), (24, 25), (25, 34), (34, 35), (35, 36)] + [(k, k + 1) for k in range(36, n)]
+    dev = _DeviceFrames(depth)
+    try:
+        with fusion.Fuser(gp, pipe_overlap=1, front_prio=front_prio) as f:
+            for a, b in cuts:
+                dev.fuse(f, poses, a, b)
+            assert f.stats()["alloc_failures"] == 0
+            _assert_same(ovol, f)
+            a_c, a_v = f.export_blocks()
+        with fusion.Fuser(gp, overlap=0) as g:
+            for a, b in cuts:
+                dev.fuse(g, poses, a, b)
+            b_c, b_v = g.export_blocks()
+        assert np.array_equal(a_c, b_c) and np.array_equal(a_v.view(np.uint8), b_v.view(np.uint8))
+    finally:
+        dev.close()
+
+
 def test_ray_space_allocation_at_full_size_on_the_furnished_stream(oracle):
     """640x480, 4 mm, the furnished bench stream with hashed noise and sensor holes: 48 frames through the default schedule, bit for bit."""
     from scannet_amd import fusion
