@@ -2391,8 +2391,11 @@ hipStream_t sf_input_stream(const sf_fuser* f, int n, bool color, int sign) {
   // The front stream has the device's highest priority: in a pass of several frames its short kernels must slip in between the workgroups of the integrate
   // kernel, or the next pass waits for them.  Beside the PERSISTENT kernel of one frame per launch (1 mm voxels: the tile set is far beyond the cache) that
   // priority is what the integrate kernel pays for: the allocation's 72 KiB workgroups, dispatched first, take the LDS its third workgroup per CU needs until
-  // they are through -- measured 0.54 of peak HBM shipped against 0.61-0.62 with the front chain at the LOWEST priority, three runs each, nothing else changed
-  // (tools/gpu/r06_zk.sh).  So such a frame's front chain goes down a second, low-priority stream (front_prio -1, the default; 1 / 0: always high / low).
+  // they are through -- 0.54 of peak HBM shipped and 322-335 frames/s, against 0.60-0.61 / 360 with the front chain at the MAIN stream's priority and 0.62 / 369
+  // at the device's lowest (tools/gpu/r06_zk.sh, r06_zv.sh: two or three runs each, nothing else changed).  So such a frame's front chain goes down a second
+  // front stream, `front_lo` (front_prio -1, the default; 1 / 0: always the high-priority / always the second one).  It has the MAIN stream's priority, not the
+  // lowest (tune front_lo_lowest): the first stream of a priority class makes the runtime open that class's hardware queues for the life of the process, and
+  // a later sf_fuse_run in the same process -- seven to nine busy streams -- then ran 12 % slower (depth-only end to end 34.2 k -> 30.0 k frames/s).
   const bool lo = f->front_lo != nullptr && (f->front_prio == 0 || (f->front_prio < 0 && pipe_batch(f, n, color, sign)));
   return lo ? f->front_lo : f->front;
 }
@@ -2556,9 +2559,16 @@ int run_batch(sf_fuser* f, const void* const* d_depth, const void* const* d_rgb,
   if (f->overlap && sa != s) (void)hipEventRecord(f->ev_fused[sl], s);
   if (f->overlap && sa == s) f->serial_tail = true;  // no cross-stream traffic at all while single-stream batches follow each other
   f->pipe_beside = f->pipe_overlap == 1 || (f->pipe_overlap < 0 && big_pass(f));
-  if ((f->pipe_beside || f->front_prio == 0) && f->front_lo == nullptr && f->front_cus == 0 && f->overlap) {   // the low-priority front stream, on first need (sf_input_stream)
+  if ((f->pipe_beside || f->front_prio == 0) && f->front_lo == nullptr && f->front_cus == 0 && f->overlap) {   // the second front stream, on first need (sf_input_stream)
     int prio_lo = 0, prio_hi = 0;
-    if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess || hipStreamCreateWithPriority(&f->front_lo, hipStreamNonBlocking, prio_lo) != hipSuccess) {
+    hipError_t e_ = hipSuccess;
+    if (f->front_lo_lowest) {
+      e_ = hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+      if (e_ == hipSuccess) e_ = hipStreamCreateWithPriority(&f->front_lo, hipStreamNonBlocking, prio_lo);
+    } else {
+      e_ = hipStreamCreateWithFlags(&f->front_lo, hipStreamNonBlocking);   // the main stream's priority
+    }
+    if (e_ != hipSuccess) {
       f->front_lo = nullptr;   // (the high-priority one serves)
       (void)hipGetLastError();
     }
@@ -2961,7 +2971,7 @@ SF_API int sf_fuser_tune(sf_fuser* f, const char* key, int value) {
     f->stream = ns;
     f->front = nf;
     f->last_front = nullptr;
-    // (a CU-masked front stream is the only front stream: the mask, not a priority, keeps it out of the integrate kernel's way; back at 0 the low-priority
+    // (a CU-masked front stream is the only front stream: the mask, not a priority, keeps it out of the integrate kernel's way; back at 0 the second
     // one is made again on first need)
     f->front_cus = value;
   }
@@ -2976,9 +2986,10 @@ SF_API int sf_fuser_tune(sf_fuser* f, const char* key, int value) {
   else if (k == "alloc_ablate")
     return sf::fail(SF_ERR_INVALID_ARG, "sf_fuser_tune: alloc_ablate switches parts of the allocation off (the volume is wrong under it): only in a library built with -DSF_MEASURE_ABLATE");
 #endif
-  // which of the two front streams a pass's pre-pass / allocation / compaction goes down (sf_input_stream): -1 the low-priority one beside the persistent kernel of
-  // one frame per launch, the high-priority one otherwise (default); 1 always the high-priority one (rounds 2-5); 0 always the low-priority one
+  // which of the two front streams a pass's pre-pass / allocation / compaction goes down (sf_input_stream): -1 the second one (front_lo) beside the persistent kernel of
+  // one frame per launch, the high-priority one otherwise (default); 1 always the high-priority one (rounds 2-5); 0 always the second one
   else if (k == "front_prio" && in(-1, 1)) f->front_prio = value;
+  else if (k == "front_lo_lowest" && in(0, 1)) f->front_lo_lowest = value != 0;   // before the stream's first need: 1 = the device's lowest priority, 0 = the main stream's
   else if (k == "alloc_ray" && in(0, 1)) f->alloc_ray = value != 0;   // 1: the ray-space window whatever the geometry (rays outside it take the slow path), 0: the cube window
   else if (k == "ramp" && in(0, MAX_BATCH)) f->ramp = value;
   else if (k == "ramp_geo" && in(0, 1)) f->ramp_geo = value != 0;

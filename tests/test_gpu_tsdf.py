@@ -907,12 +907,12 @@ def test_presence_cache_changes_nothing_but_the_probes(oracle, kernel):
         dev.close()
 
 
-@pytest.mark.parametrize("front_prio", [-1, 0, 1])
-def test_front_streams_change_hands_between_single_frames_and_batches(oracle, front_prio):
-    """The front chain of a frame that runs beside the persistent one-frame kernel goes down the LOW-priority front stream (made on first need), that of a pass of
+@pytest.mark.parametrize("front_prio,lowest", [(-1, 0), (0, 0), (1, 0), (-1, 1)])
+def test_front_streams_change_hands_between_single_frames_and_batches(oracle, front_prio, lowest):
+    """The front chain of a frame that runs beside the persistent one-frame kernel goes down a second front stream that does NOT have the front stream's high priority (made on first need), that of a pass of
     several frames down the high-priority one (fuser.hip sf_input_stream): a stream that alternates between single frames and batches -- beside the kernel forced with
     pipe_overlap 1, the tile set here is far below the size that switches it on -- hands the allocation over from one front stream to the other and back, ordered by an
-    event.  Same volume as the oracle and as one stream for everything, bit for bit, with the front stream chosen automatically, always low and always high."""
+    event.  Same volume as the oracle and as one stream for everything, bit for bit, with the front stream chosen automatically, always the second and always the first."""
     from scannet_amd import fusion
     W, H = 320, 240
     boxes = synth.clutter_boxes()
@@ -931,7 +931,7 @@ def test_front_streams_change_hands_between_single_frames_and_batches(oracle, fr
     cuts = [(0, 1), (1, 2), (2, 3), (3, 23), (23, 24), (24, 25), (25, 34), (34, 35), (35, 36)] + [(k, k + 1) for k in range(36, n)]
     dev = _DeviceFrames(depth)
     try:
-        with fusion.Fuser(gp, pipe_overlap=1, front_prio=front_prio) as f:
+        with fusion.Fuser(gp, front_lo_lowest=lowest, pipe_overlap=1, front_prio=front_prio) as f:
             for a, b in cuts:
                 dev.fuse(f, poses, a, b)
             assert f.stats()["alloc_failures"] == 0
