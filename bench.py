@@ -874,7 +874,34 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
                                                   "what": "sf_fuser_integrate per depth frame from pageable host memory (copy into a page-locked ring slot, H2D, "
                                                           "pre-pass, allocation, compaction, integrate queued; no stream drained per frame), PCIe included"}
                 out["roofline_single_frame"] = r1
+        if e2e_n:
+            # the metric is RGB-D: the leg named end_to_end is the WHOLE scan with ScanNet's real colour stream (1296x968 baseline JPEG over zlib depth), the first
+            # sf_fuse_run of this process (VERDICT round 5: the 5 578-frame leg was depth only and the RGB-D one 1 024 frames); the geometry-only file of the same
+            # frames (the same reference-written depth streams) follows as end_to_end.depth_only
+            zcache = {}
+            e_rgbd = None
+            if rgbd and not args.no_e2e_rgbd:
+                n_rgbd = min(e2e_n, args.e2e_rgbd_frames)
+                if shutil.disk_usage("/tmp").free < 2 * n_rgbd * 700000:   # ~590 KB per frame, and the depth-only files behind it
+                    n_rgbd = min(n_rgbd, 1024)
+                try:
+                    e_rgbd = end_to_end(frames, poses, n_rgbd, params, local_rank, torch, colour="jpeg1296", cache=zcache)
+                except Exception as ex:   # a leg beside the metric (disk full in /tmp, ...): never take the line down
+                    e_rgbd = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+            try:
+                e_depth = end_to_end(frames, poses, e2e_n, params, local_rank, torch, cache=zcache)
+            except Exception as ex:
+                e_depth = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+            zcache.clear()
+            if e_rgbd is not None:
+                out["end_to_end"] = dict(e_rgbd, depth_only=e_depth)
+                out["end_to_end_rgbd"] = {k: e_rgbd.get(k) for k in ("frames_per_s", "frames_per_s_best", "frames", "colour_fused", "decode_threads", "error") if k in e_rgbd}
+                out["end_to_end_rgbd"]["what"] = "the same leg as end_to_end (kept under the name earlier rounds reported it by)"
+            else:
+                out["end_to_end"] = e_depth
         if extras and ooc_n:
+            # (behind the end-to-end legs: this leg's fusers open the second front stream at the device's lowest priority, and the first stream of a priority class makes the
+            # runtime open that class's hardware queues for the life of the process -- sf_fuse_run's seven to nine busy streams then run ~12 % slower)
             # BASELINE configs[2] bounded: the same first frames at 1 mm voxels (2^22 buckets, 2^25 blocks = 137 GB of tiles reserved), one frame per
             # launch -- every launch's tile set is ~20 x the Infinity Cache, so this IS an HBM figure
             c1 = CONFIGS["1mm"]
@@ -907,31 +934,6 @@ def run_stream(args, cfg_name, rank, local_rank, world, dist, torch):
                                                             "duration / 8 TB/s in the shipped schedule; details under roofline_out_of_cache"}
             except _abi.ScanfuseError as e:   # a smaller GPU than the 288 GB part cannot reserve the tiles
                 out["roofline_out_of_cache"] = {"error": str(e)}
-        if e2e_n:
-            # the metric is RGB-D: the leg named end_to_end is the WHOLE scan with ScanNet's real colour stream (1296x968 baseline JPEG over zlib depth), the first
-            # sf_fuse_run of this process (VERDICT round 5: the 5 578-frame leg was depth only and the RGB-D one 1 024 frames); the geometry-only file of the same
-            # frames (the same reference-written depth streams) follows as end_to_end.depth_only
-            zcache = {}
-            e_rgbd = None
-            if rgbd and not args.no_e2e_rgbd:
-                n_rgbd = min(e2e_n, args.e2e_rgbd_frames)
-                if shutil.disk_usage("/tmp").free < 2 * n_rgbd * 700000:   # ~590 KB per frame, and the depth-only files behind it
-                    n_rgbd = min(n_rgbd, 1024)
-                try:
-                    e_rgbd = end_to_end(frames, poses, n_rgbd, params, local_rank, torch, colour="jpeg1296", cache=zcache)
-                except Exception as ex:   # a leg beside the metric (disk full in /tmp, ...): never take the line down
-                    e_rgbd = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
-            try:
-                e_depth = end_to_end(frames, poses, e2e_n, params, local_rank, torch, cache=zcache)
-            except Exception as ex:
-                e_depth = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
-            zcache.clear()
-            if e_rgbd is not None:
-                out["end_to_end"] = dict(e_rgbd, depth_only=e_depth)
-                out["end_to_end_rgbd"] = {k: e_rgbd.get(k) for k in ("frames_per_s", "frames_per_s_best", "frames", "colour_fused", "decode_threads", "error") if k in e_rgbd}
-                out["end_to_end_rgbd"]["what"] = "the same leg as end_to_end (kept under the name earlier rounds reported it by)"
-            else:
-                out["end_to_end"] = e_depth
         if cpu_n:   # rank 0 at N = 1 only
             host = frames[:cpu_n].cpu().numpy().view(np.uint16)
             rgb_dev = colour_tensor(max(cpu_n, 1)) if rgbd else None

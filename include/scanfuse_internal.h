@@ -38,12 +38,13 @@ extern "C" {
  *   "xrow"        0/1    passes of several frames run k_integrate in the x-row lane layout: a lane holds one x-row of the block (y = lane & 7, z = lane >> 3)
  *                        instead of two x-neighbours in four z-layers -- the same voxels, 18 fma fewer per lane and frame, and the gathers of one instruction
  *                        fall on two image rows instead of four or five (default 1)
- *   "front_prio"  -1/0/1 which front stream a pass's pre-pass / allocation / compaction goes down: -1 (default) a second one at the MAIN stream's priority beside the persistent
- *                        kernel of one frame per launch out of cache reach (at the highest priority the allocation's 72 KiB workgroups take the LDS the integrate kernel's third
- *                        workgroup per CU needs: 0.54 -> 0.61 of peak HBM shipped at 1 mm), the high-priority one for passes of several frames; 1 always high (rounds 2-5), 0
- *                        always the second one
- *   "front_lo_lowest" 0/1 that second stream at the device's LOWEST priority (0.62 instead of 0.61, but a process that later runs sf_fuse_run pays 12 % there: the first stream
- *                        of a priority class opens that class's hardware queues for good); before the stream's first use (default 0)
+ *   "front_prio"  -1/0/1 which front stream a pass's pre-pass / allocation / compaction goes down: -1 (default) a second one at the device's LOWEST priority beside the
+ *                        persistent kernel of one frame per launch out of cache reach (at the highest priority the allocation's 72 KiB workgroups take the LDS the integrate
+ *                        kernel's third workgroup per CU needs: 0.54 -> 0.62 of peak HBM shipped at 1 mm), the high-priority one for passes of several frames; 1 always high
+ *                        (rounds 2-5), 0 always the second one
+ *   "front_lo_lowest" 1/0 that second stream at the device's lowest priority (default) or at the main stream's (0.60-0.61 instead of 0.62).  For a process that ALSO runs
+ *                        sf_fuse_run later: the first stream of a priority class opens that class's hardware queues for the life of the process, and sf_fuse_run's seven to
+ *                        nine busy streams then run 12 % slower; set 0 there.  Before the stream's first use.
  *   "brick_cache" 0/1    the cube-window allocation kernels (voxels under 2.5 mm, or "alloc_ray" 0) ask the presence cache (one {tag, 64-bit mask} entry per 4x4x4-block brick: "this block is in the table and
  *                        older than this batch") before they probe the hash table (default 1; 0: every look-up probes the table, rounds 1-5).  The allocated
  *                        set and every birth frame are the same either way.

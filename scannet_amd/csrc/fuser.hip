@@ -2393,9 +2393,10 @@ hipStream_t sf_input_stream(const sf_fuser* f, int n, bool color, int sign) {
   // priority is what the integrate kernel pays for: the allocation's 72 KiB workgroups, dispatched first, take the LDS its third workgroup per CU needs until
   // they are through -- 0.54 of peak HBM shipped and 322-335 frames/s, against 0.60-0.61 / 360 with the front chain at the MAIN stream's priority and 0.62 / 369
   // at the device's lowest (tools/gpu/r06_zk.sh, r06_zv.sh: two or three runs each, nothing else changed).  So such a frame's front chain goes down a second
-  // front stream, `front_lo` (front_prio -1, the default; 1 / 0: always the high-priority / always the second one).  It has the MAIN stream's priority, not the
-  // lowest (tune front_lo_lowest): the first stream of a priority class makes the runtime open that class's hardware queues for the life of the process, and
-  // a later sf_fuse_run in the same process -- seven to nine busy streams -- then ran 12 % slower (depth-only end to end 34.2 k -> 30.0 k frames/s).
+  // front stream, `front_lo` (front_prio -1, the default; 1 / 0: always the high-priority / always the second one), at the device's lowest priority.  One thing to
+  // know about that: the first stream of a priority class makes the runtime open that class's hardware queues for the life of the PROCESS, and a later sf_fuse_run
+  // in the same process -- seven to nine busy streams -- then runs 12 % slower (depth-only end to end 34.2 k -> 30.0 k frames/s; bench.py therefore runs its 1 mm
+  // leg last).  A process that does both sets front_lo_lowest 0: the second stream at the main stream's priority, 0.60-0.61 here instead of 0.62.
   const bool lo = f->front_lo != nullptr && (f->front_prio == 0 || (f->front_prio < 0 && pipe_batch(f, n, color, sign)));
   return lo ? f->front_lo : f->front;
 }

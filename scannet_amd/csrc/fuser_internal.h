@@ -280,11 +280,11 @@ struct sf_fuser {
   int device = 0;
   hipStream_t stream = nullptr;  // integrate / deintegrate and everything synchronous
   hipStream_t front = nullptr;   // pre-pass, allocation, compaction of the NEXT frame (overlaps integrate)
-  hipStream_t front_lo = nullptr;   // the same at the MAIN stream's priority (not the highest): the front chain beside the persistent kernel of one frame per launch (sf_input_stream)
+  hipStream_t front_lo = nullptr;   // the same at the device's LOWEST priority: the front chain beside the persistent kernel of one frame per launch (sf_input_stream)
   hipStream_t last_front = nullptr; // which of the two the pass before used (a change of stream is ordered by ev_front_switch)
   hipEvent_t ev_front_switch = nullptr;
   int front_prio = -1;              // tune "front_prio"
-  bool front_lo_lowest = false;     // tune "front_lo_lowest": front_lo at the lowest priority instead of the main stream's
+  bool front_lo_lowest = true;      // tune "front_lo_lowest": front_lo at the device's lowest priority (default) or at the main stream's
   hipEvent_t ev_compact[2] = {nullptr, nullptr};   // front: frame slot ready for integrate
   hipEvent_t ev_fused[2] = {nullptr, nullptr};     // stream: frame slot consumed
   hipEvent_t ev_input = nullptr;                   // front: the caller's staging work queued so far (single-stream batches wait for it)
