@@ -111,6 +111,39 @@ def test_batched_pass_equals_frame_by_frame(oracle, tail_wide):
         L.sf_device_free(dptr)
 
 
+@pytest.mark.parametrize("batch", [2, 3, 4])
+def test_passes_of_a_few_frames_with_births_in_the_middle(oracle, batch):
+    """Passes of 2, 3 and 4 frames (tune batch): the compaction of such a pass is k_compactify_few's loop over the frames with the birth-frame mask -- eight directory entries
+    per thread, one list-counter atomic per 2 048 -- not the lane-per-(entry, frame) kernel of longer passes.  Pose jumps put blocks' births in the middle of a pass, skipped poses
+    leave gaps: the oracle's volume, bit for bit, and the last frame's block count."""
+    from scannet_amd import fusion
+    W, H = 320, 240
+    op, gp = _mk(oracle, W, H, voxel=0.008, num_sdf_blocks=1 << 17)
+    ovol = oracle.Volume(op, threads=8)
+    idx = [0, 1, 300, 301, 2, 600, 3, 4, 900, 901, 5, 302, 6, 7, 601, 8, 9, 10, 1100, 11, 303, 12, 13]
+    depth = np.zeros((len(idx), H, W), np.uint16)
+    poses = np.zeros((len(idx), 16), np.float32)
+    last = None
+    for k, i in enumerate(idx):
+        pose = synth.trajectory_pose(i, 1200)
+        depth[k] = synth.render_room_depth(pose, W, H, noise_frame=i)
+        if k in (4, 15):
+            pose = np.full((4, 4), -np.inf, np.float32)  # tracking lost
+        else:
+            last = ovol.integrate(depth[k], pose)
+        poses[k] = pose.reshape(16)
+    dev = _DeviceFrames(depth)
+    try:
+        with fusion.Fuser(gp, batch=batch) as f:
+            dev.fuse(f, poses, 0, len(idx))
+            st = f.stats()
+            assert st["frames_integrated"] == len(idx) - 2 and st["frames_skipped"] == 2 and st["alloc_failures"] == 0
+            assert st["last_frame_blocks"] == last
+            _assert_same(ovol, f)
+    finally:
+        dev.close()
+
+
 def test_colour_deintegrate_gc_ragged(oracle):
     """Ragged image size (not a multiple of 8 or 16), colour fusion, deintegration and garbage collection."""
     from scannet_amd import fusion
